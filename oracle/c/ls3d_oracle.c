@@ -1,0 +1,190 @@
+/*
+ * oracle/c/ls3d_oracle.c — CPU restatement of the integer / index / nearest-neighbour
+ * stages of the lidarseg3d segmentation forward path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (lidarseg3d_amd/) never
+ * links, imports or falls back to anything in oracle/.
+ *
+ * Each function names the reference file:line whose behaviour it restates
+ * (paths relative to the jialeli1/lidarseg3d tree).  Written from the behaviour,
+ * not from the text, of those files.
+ *
+ * Build: gcc -O2 -fPIC -shared -fopenmp -ffp-contract=off oracle/c/ls3d_oracle.c -o oracle/c/libls3d_oracle.so -lm
+ * (-ffp-contract=off so that every float expression below rounds exactly where it is written;
+ *  fused multiply-adds are spelled fmaf() explicitly.)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* grid size per axis: round((hi-lo)/vs) in f32.
+ * det3d/ops/point_cloud/point_cloud_ops.py:26-29, det3d/ops/voxel/src/voxelization_cpu.cpp:118-121 */
+static void grid_size_of(const float *vs, const float *range, int *grid) {
+  for (int a = 0; a < 3; ++a) {
+    float g = (range[3 + a] - range[a]) / vs[a];
+    grid[a] = (int)roundf(g);
+  }
+}
+
+/* per-point voxel coordinate (z,y,x) or -1,-1,-1 when outside.
+ * det3d/ops/voxel/src/voxelization_cpu.cpp:8-40 ; det3d/ops/point_cloud/point_cloud_ops.py:33-42
+ * f32 subtraction, f32 DIVISION, floor. */
+static int coord_of(const float *p, const float *vs, const float *range, const int *grid, int *zyx) {
+  for (int a = 0; a < 3; ++a) {
+    float c = floorf((p[a] - range[a]) / vs[a]);
+    if (c < 0.0f || c >= (float)grid[a]) return 0;
+    zyx[2 - a] = (int)c;
+  }
+  return 1;
+}
+
+/* dynamic voxelization: coors[N,3] (z,y,x) int32, -1 for points outside.
+ * det3d/ops/voxel/src/voxelization_cpu.cpp:8-40,144-169 */
+void orc_dynamic_voxelize(const float *points, int n, int c, const float *vs, const float *range,
+                          int32_t *coors) {
+  int grid[3];
+  grid_size_of(vs, range, grid);
+  for (int i = 0; i < n; ++i) {
+    int zyx[3];
+    if (coord_of(points + (size_t)i * c, vs, range, grid, zyx)) {
+      coors[3 * i + 0] = zyx[0]; coors[3 * i + 1] = zyx[1]; coors[3 * i + 2] = zyx[2];
+    } else {
+      coors[3 * i + 0] = coors[3 * i + 1] = coors[3 * i + 2] = -1;
+    }
+  }
+}
+
+/* hard voxelization.
+ *   overflow_mode 0: numba semantics — once max_voxels voxels exist, a point that would open a NEW
+ *                    voxel is skipped but later points still fill existing voxels
+ *                    (det3d/ops/point_cloud/point_cloud_ops.py:43-54, `continue` at :46-47).
+ *   overflow_mode 1: det3d/ops/voxel C++ semantics — the first such point ends the whole scan
+ *                    (det3d/ops/voxel/src/voxelization_cpu.cpp:66-92, `break` at :78).
+ * voxels[max_voxels,max_points,c] and num_points[max_voxels] must be zero-initialised by the caller,
+ * coors[max_voxels,3] receives (z,y,x).  Returns the number of voxels.
+ * Voxel ids are first-appearance order over the input point order; the first max_points points of a
+ * voxel are kept. */
+int orc_hard_voxelize(const float *points, int n, int c, const float *vs, const float *range,
+                      int max_points, int max_voxels, int overflow_mode, float *voxels,
+                      int32_t *coors, int32_t *num_points) {
+  int grid[3];
+  grid_size_of(vs, range, grid);
+  size_t cells = (size_t)grid[0] * grid[1] * grid[2];
+  int32_t *lut = (int32_t *)malloc(cells * sizeof(int32_t));
+  if (!lut) return -1;
+  memset(lut, 0xff, cells * sizeof(int32_t));
+  int nvox = 0;
+  for (int i = 0; i < n; ++i) {
+    int zyx[3];
+    const float *p = points + (size_t)i * c;
+    if (!coord_of(p, vs, range, grid, zyx)) continue;
+    size_t cell = ((size_t)zyx[0] * grid[1] + zyx[1]) * grid[0] + zyx[2];
+    int v = lut[cell];
+    if (v < 0) {
+      if (nvox >= max_voxels) {
+        if (overflow_mode == 1) break;
+        continue;
+      }
+      v = nvox++;
+      lut[cell] = v;
+      coors[3 * v + 0] = zyx[0]; coors[3 * v + 1] = zyx[1]; coors[3 * v + 2] = zyx[2];
+    }
+    int k = num_points[v];
+    if (k < max_points) {
+      memcpy(voxels + ((size_t)v * max_points + k) * c, p, sizeof(float) * c);
+      num_points[v] = k + 1;
+    }
+  }
+  free(lut);
+  return nvox;
+}
+
+/* dynamic scatter bookkeeping: groups points of equal coordinate (first-appearance voxel order),
+ * returns voxel_num, fills point2voxel[N] (-1 outside) and the position of each point inside its
+ * voxel.  det3d/ops/voxel/src/scatter_points_cpu.cpp:8-36.  coors is [N,3] (z,y,x) with -1 rows. */
+int orc_dynamic_scatter_index(const int32_t *coors, int n, const int *grid_zyx, int32_t *point2voxel,
+                              int32_t *point_pos, int32_t *voxel_coors, int32_t *num_points) {
+  size_t cells = (size_t)grid_zyx[0] * grid_zyx[1] * grid_zyx[2];
+  int32_t *lut = (int32_t *)malloc(cells * sizeof(int32_t));
+  if (!lut) return -1;
+  memset(lut, 0xff, cells * sizeof(int32_t));
+  int nvox = 0;
+  for (int i = 0; i < n; ++i) {
+    const int32_t *q = coors + 3 * i;
+    if (q[0] == -1) { point2voxel[i] = -1; point_pos[i] = -1; continue; }
+    size_t cell = ((size_t)q[0] * grid_zyx[1] + q[1]) * grid_zyx[2] + q[2];
+    int v = lut[cell];
+    if (v < 0) {
+      v = nvox++;
+      lut[cell] = v;
+      voxel_coors[3 * v + 0] = q[0]; voxel_coors[3 * v + 1] = q[1]; voxel_coors[3 * v + 2] = q[2];
+      num_points[v] = 0;
+    }
+    point2voxel[i] = v;
+    point_pos[i] = num_points[v]++;
+  }
+  free(lut);
+  return nvox;
+}
+
+/* exact 3 nearest neighbours, brute force.
+ * det3d/ops/pointnet2_batch/src/interpolate_gpu.cu:16-59.
+ * The squared distance is evaluated in f32 as the reference's CUDA build evaluates it: nvcc's default
+ * -fmad=true contracts (a*a + b*b) + c*c into fma(c,c, fma(b,b, a*a)); that is what is spelled here.
+ * Running best values are kept in double (reference :37), comparison is strict '<' so the lowest
+ * index wins ties; with m<3 the missing slots keep index 0 and dist2 = (float)1e40 = +inf. */
+void orc_three_nn(int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    float ux = unknown[3 * i], uy = unknown[3 * i + 1], uz = unknown[3 * i + 2];
+    double b1 = 1e40, b2 = 1e40, b3 = 1e40;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int k = 0; k < m; ++k) {
+      float dx = ux - known[3 * k], dy = uy - known[3 * k + 1], dz = uz - known[3 * k + 2];
+      float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+      else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+      else if (d < b3) { b3 = d; i3 = k; }
+    }
+    dist2[3 * i] = (float)b1; dist2[3 * i + 1] = (float)b2; dist2[3 * i + 2] = (float)b3;
+    idx[3 * i] = i1; idx[3 * i + 1] = i2; idx[3 * i + 2] = i3;
+  }
+}
+
+/* out[c,n] = sum_j w[n,j] * feat[c, idx[n,j]]   (channel-major features, as the reference kernel)
+ * det3d/ops/pointnet2_batch/src/interpolate_gpu.cu:84-104.  Evaluated as the CUDA build does:
+ * fma(w2,f2, fma(w1,f1, w0*f0)). */
+void orc_three_interpolate(int c, int m, int n, const float *feat, const int32_t *idx,
+                           const float *weight, float *out) {
+#pragma omp parallel for schedule(static)
+  for (int ch = 0; ch < c; ++ch) {
+    const float *f = feat + (size_t)ch * m;
+    for (int i = 0; i < n; ++i) {
+      const int32_t *q = idx + 3 * i;
+      const float *w = weight + 3 * i;
+      out[(size_t)ch * n + i] = fmaf(w[2], f[q[2]], fmaf(w[1], f[q[1]], w[0] * f[q[0]]));
+    }
+  }
+}
+
+/* gather-GEMM-scatter sparse convolution over an explicit pair list (spconv v1.x native algorithm,
+ * SURVEY.md §2.3): out[o] += W[k]^T in[i] for each pair (i,o) of offset k.
+ * pairs_in/pairs_out: concatenated per-offset lists, pair_off[k]..pair_off[k+1] delimits offset k.
+ * W layout (K, Cin, Cout) row-major (= spconv's (kD,kH,kW,Cin,Cout) flattened).  out must be zeroed. */
+void orc_spconv_pairs(const float *in, const float *w, int K, int cin, int cout, const int32_t *pairs_in,
+                      const int32_t *pairs_out, const int64_t *pair_off, float *out) {
+  for (int k = 0; k < K; ++k) {
+    const float *wk = w + (size_t)k * cin * cout;
+    for (int64_t p = pair_off[k]; p < pair_off[k + 1]; ++p) {
+      const float *x = in + (size_t)pairs_in[p] * cin;
+      float *y = out + (size_t)pairs_out[p] * cout;
+      for (int ci = 0; ci < cin; ++ci) {
+        float xv = x[ci];
+        const float *wr = wk + (size_t)ci * cout;
+        for (int co = 0; co < cout; ++co) y[co] += xv * wr[co];
+      }
+    }
+  }
+}
