@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py — frames/s of the SDSeg3D segmentation forward path on MI355X (BASELINE.json configs[1]).
+
+One "step" = one full forward of one synthetic 120 000-point nuScenes-style frame per GPU:
+    points (resident in HBM) -> GPU hard voxelization -> TransVFE -> UNetSCN3D (37 sparse convs + 8 rulebooks)
+    -> 3-NN devoxelization -> PointSegBatchlossHead -> per-point logits [N,17] -> argmax.
+Weights are random-init of the reference architecture (no checkpoints offline); data is synthetic.
+Multi-GPU: frames shard one-per-GPU, no data-path collective (scaling "weak"); the only collectives are the
+timing barrier and the max-over-ranks of the elapsed time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points 120000] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     — the dominant kernel (k_gather_gemm, the sparse-conv gather-GEMM): algorithmic pair-model bytes
+                 sum_l P_l*(Cin+Cout)*4 over the summed HIP-event durations of those launches;
+  cpu_baseline — the CPU oracle (oracle/ref.py, kind "port") timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
+
+
+def build_model(dev, seed=5):
+    import lidarseg3d_amd as L
+    from lidarseg3d_amd import models_cfg, synth
+    model = L.build_detector(models_cfg.sdseg3d(), train_cfg=None, test_cfg={}).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, seed).items()}
+    model.load_state_dict(sd)
+    return model.to(dev), sd
+
+
+class ConvTimer:
+    """HIP-event brackets around every sparse-conv gather-GEMM launch (installed as ops.gather_gemm wrapper)."""
+
+    def __init__(self, ops):
+        self.ops, self.orig = ops, ops.gather_gemm
+        self.events, self.algo_bytes, self.flops, self.enabled = [], 0.0, 0.0, False
+        self.pairs_cache = {}
+
+    def install(self):
+        def wrapped(x, w, tbl=None, **kw):
+            if not self.enabled or tbl is None:
+                return self.orig(x, w, tbl=tbl, **kw)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = self.orig(x, w, tbl=tbl, **kw)
+            b.record()
+            self.events.append((a, b))
+            key = (tbl.data_ptr(), tbl.shape[0])
+            if key not in self.pairs_cache:
+                self.pairs_cache[key] = None  # filled after the timed region (needs a sync)
+            self.meta.append((key, tbl, w.shape[1], kw.get("cout") or w.shape[2]))
+            return out
+        self.meta = []
+        self.ops.gather_gemm = wrapped
+        # modules imported `ops` as a module, so they see the replacement
+        return self
+
+    def summarize(self):
+        torch.cuda.synchronize()
+        total_ms = sum(a.elapsed_time(b) for a, b in self.events)
+        pairs = {}
+        algo = flops = 0.0
+        for key, tbl, cin, cout in self.meta:
+            if key not in pairs:
+                pairs[key] = int((tbl >= 0).sum().item())
+            p = pairs[key]
+            algo += p * (cin + cout) * 4.0
+            flops += 2.0 * p * cin * cout
+        n = max(len(self.events), 1)
+        return dict(launches=len(self.events), total_ms=total_ms, avg_us=1e3 * total_ms / n, algo_bytes=algo, flops=flops)
+
+
+def cpu_baseline(sd, n_points, seed):
+    """the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)"""
+    from lidarseg3d_amd import synth
+    from oracle import ref as orc
+    orc.build_c()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    frame = synth.lidar_frame(n_points, seed=seed, **synth.NUSC)
+    t0 = time.time()
+    out = orc.sdseg3d_forward(sd, [frame], synth.NUSC["voxel_size"], synth.NUSC["pc_range"])
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit="frames/s", cores=cores, kind="port",
+                sample="1 frame of %d points (full SDSeg3D forward incl. CPU voxelization) in %.1f s; oracle/ref.py "
+                       "(torch-CPU gather-mm-scatter spconv restatement, OpenMP C 3-NN)" % (n_points, dt)), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=120000)
+    ap.add_argument("--cpu-points", type=int, default=30000, help="points of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://")
+
+    from lidarseg3d_amd import ops, synth
+    model, sd = build_model(dev)
+    frame = synth.lidar_frame(args.points, seed=100 + rank, **synth.NUSC)
+    pts = torch.from_numpy(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)).to(dev)
+    timer = ConvTimer(ops).install()
+
+    def step():
+        ret = model(dict(points=pts, batch_size=1), return_loss=False)
+        return ret[0]["pred_point_sem_labels"]
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        timer.enabled = True
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            labels = step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    conv = timer.summarize()
+    V = int(model.point_head.forward_ret_dict["conv_logits"].shape[0])
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        achieved = conv["algo_bytes"] / (conv["total_ms"] * 1e-3) / 1e9 if conv["total_ms"] > 0 else 0.0
+        out = {
+            "metric": "frames/sec, SDSeg3D forward, 120k-pt nuScenes-style frame",
+            "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead), "
+                                   "%d pts/frame, voxel [0.1,0.1,0.2], range [-51.2,-51.2,-5,51.2,51.2,3], 17 classes, "
+                                   "1 frame per GPU per step, GPU voxelization included" % args.points,
+                       "active_voxels": V, "frames_per_gpu_per_step": 1, "parallelism": "frames sharded 1/GPU (dp%d)" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_gather_gemm (sparse-conv gather-GEMM, %d launches/frame)"
+                                  % (conv["launches"] // max(args.steps, 1)),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_us": conv["avg_us"],
+                         "algo_bytes_per_frame": conv["algo_bytes"] / max(args.steps, 1),
+                         "tflops": conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0,
+                         "sparse_conv_ms_per_frame": conv["total_ms"] / max(args.steps, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, _ = cpu_baseline({k: v.cpu() for k, v in sd.items()}, args.cpu_points, 100)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,250 @@
+/*
+ * include/ls3d.h — C ABI of libls3d.so: the MI355X (gfx950) kernels of the MSeg3D / SDSeg3D
+ * segmentation forward path of jialeli1/lidarseg3d.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host;
+ *   - the caller owns every buffer (incl. workspaces, sized by the *_workspace_bytes queries);
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*), never synchronises
+ *     and never allocates;
+ *   - return value: LS3D_OK (0) or a negative LS3D_ERR_* code; no exit(), no exceptions
+ *     (the reference's pointnet2 launcher calls exit(-1) on a CUDA error,
+ *     det3d/ops/pointnet2_batch/src/interpolate_gpu.cu:76-80 — deliberately not reproduced);
+ *   - row counts come as a host capacity `n` plus an optional device count `n_dev` (int32*): when
+ *     n_dev != NULL the kernels process min(*n_dev, n) rows, so producer -> consumer chains need no
+ *     host round trip.
+ *
+ * Each entry point cites the reference interface (file:line in the jialeli1/lidarseg3d tree) it replaces.
+ */
+#ifndef LS3D_H
+#define LS3D_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LS3D_OK 0
+#define LS3D_ERR_ARG (-1)
+#define LS3D_ERR_LAUNCH (-2)
+#define LS3D_ERR_UNSUPPORTED (-3)
+#define LS3D_ERR_WORKSPACE (-4)
+
+typedef void *ls3d_stream_t;
+
+/* library / build identification: returns e.g. "ls3d 0.1 gfx950" */
+const char *ls3d_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Voxelization
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Geometry of a voxel grid.  grid = round((hi-lo)/vs) per axis, computed by the caller in f32 exactly as
+ * det3d/ops/point_cloud/point_cloud_ops.py:26-29 / det3d/ops/voxel/src/voxelization_cpu.cpp:118-121. */
+typedef struct {
+  float vs[3];    /* voxel size x,y,z */
+  float lo[3];    /* range minimum x,y,z */
+  int32_t grid[3];/* cells x,y,z */
+} ls3d_grid_t;
+
+/* Layout of a point table: row i starts at points + i*stride (floats); xyz at columns xyz_col..+2;
+ * batch index (as float, collate_kitti's column 0, det3d/torchie/parallel/collate.py:141-150) at
+ * batch_col or -1 for a single frame; the n_feat columns copied into `voxels` start at feat_col. */
+typedef struct {
+  int32_t stride, xyz_col, batch_col, feat_col, n_feat;
+} ls3d_points_layout_t;
+
+/* dynamic voxelization: coors[n,3] = (z,y,x) int32, (-1,-1,-1) for points outside the range.
+ * Replaces voxel_layer.dynamic_voxelize (det3d/ops/voxel/src/voxelization.h:77-88,
+ * CUDA kernel det3d/ops/voxel/src/voxelization_cuda.cu:25-61).  f32 subtraction, f32 division, floor. */
+int ls3d_voxelize_dynamic(const float *points, int n, const ls3d_points_layout_t *lay_host,
+                          const ls3d_grid_t *grid_host, int32_t *coors, ls3d_stream_t stream);
+
+size_t ls3d_voxelize_hard_workspace_bytes(int n, int max_points, int max_voxels);
+
+/* hard voxelization, bit-exact with the reference's serial algorithms:
+ *   overflow_mode 0 = numba kernel, det3d/ops/point_cloud/point_cloud_ops.py:7-55 (what the MSeg3D/SDSeg3D
+ *                     configs run in the dataloader; `continue` once max_voxels is reached);
+ *   overflow_mode 1 = voxel_layer.hard_voxelize, det3d/ops/voxel/src/voxelization.h:46-61,
+ *                     voxelization_cpu.cpp:42-99 (`break`).
+ * Voxel ids are first-appearance order over the point order, the first max_points points are kept.
+ * Outputs: voxels[max_voxels,max_points,n_feat] (zero padded), coors[max_voxels,coors_cols] with
+ * coors_cols==3 -> (z,y,x), ==4 -> (batch,z,y,x); num_points[max_voxels]; *num_voxels_dev.
+ * With batch_col >= 0 the frames must be concatenated in batch order; max_voxels then bounds the TOTAL
+ * (callers needing a per-frame cap below the frame's point count voxelise frame by frame). */
+int ls3d_voxelize_hard(const float *points, int n, const ls3d_points_layout_t *lay_host,
+                       const ls3d_grid_t *grid_host, int max_points, int max_voxels, int overflow_mode,
+                       void *workspace, size_t workspace_bytes, float *voxels, int32_t *coors, int coors_cols,
+                       int32_t *num_points, int32_t *num_voxels_dev, ls3d_stream_t stream);
+
+size_t ls3d_dynamic_scatter_workspace_bytes(int n);
+
+/* DynamicScatter (det3d/ops/voxel/scatter_points.py:68-129 over dynamic_point_to_voxel_forward,
+ * det3d/ops/voxel/src/voxelization.h:90-100): group points of equal coordinate (coors[n,coors_cols],
+ * rows with -1 dropped), first-appearance voxel order, reduce ALL points of a voxel:
+ * mode 0 = mean, 1 = max.  Outputs feats[n,n_feat] (first *num_voxels_dev rows valid), voxel_coors[n,coors_cols],
+ * point2voxel[n] (may be NULL). */
+int ls3d_dynamic_scatter(const float *feats_in, int n, int n_feat, const int32_t *coors, int coors_cols,
+                         const int32_t shape_zyx_host[3], int mode, void *workspace, size_t workspace_bytes,
+                         float *feats_out, int32_t *voxel_coors, int32_t *point2voxel,
+                         int32_t *num_voxels_dev, ls3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Voxel feature extractors (readers)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* MeanVoxelFeatureExtractor.forward, det3d/models/readers/voxel_encoder.py:51-58. out[v,c] ld = out_ld */
+int ls3d_vfe_mean(const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int max_points,
+                  int n_feat, float *out, int out_ld, ls3d_stream_t stream);
+
+/* ImprovedMeanVoxelFeatureExtractor.forward, voxel_encoder.py:74-124:
+ * [mean_xyz, max_xyz, min_xyz, mean_other, density, std] -> out[v, 0..n_feat+8); columns up to out_ld are
+ * zero filled (so the 13-channel descriptor can feed a 16-wide GEMM). */
+int ls3d_vfe_improved_mean(const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev,
+                           int max_points, int n_feat, float *out, int out_ld, ls3d_stream_t stream);
+
+/* TransformerVoxelFeatureExtractor token assembly, voxel_encoder.py:210-252: row (v*max_points+t) of
+ * tokens = [point features (n_feat), descriptor (n_feat+8), zeros up to tok_ld]. */
+int ls3d_vfe_tokens(const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int max_points,
+                    int n_feat, float *tokens, int tok_ld, ls3d_stream_t stream);
+
+/* multi-head self attention core over groups of `seq` consecutive rows (nn.MultiheadAttention, eval, no masks;
+ * used with seq = 5 points of a voxel, voxel_encoder.py:155, and seq = 2*num_class memory tokens,
+ * det3d/models/point_heads/context_module.py:231).  qkv[rows, 3*embed] = (q | k | v); out[rows, embed]. */
+int ls3d_mha_core(const float *qkv, int groups, const int32_t *groups_dev, int seq, int embed, int heads,
+                  float *out, ls3d_stream_t stream);
+
+/* max over the `seq` rows of every group: in[groups*seq, c] -> out[groups, c] (voxel_encoder.py:265) */
+int ls3d_group_max(const float *in, int groups, const int32_t *groups_dev, int seq, int c, float *out,
+                   ls3d_stream_t stream);
+
+/* y = LayerNorm(x (+ res)) * gamma + beta over the last dim c (<= 256); ld = c for all */
+int ls3d_layernorm(const float *x, const float *res, const float *gamma, const float *beta, float eps, int rows,
+                   const int32_t *rows_dev, int c, float *y, ls3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse convolution: coordinate index + rulebooks + gather-GEMM
+ * (third-party spconv v1.x @ fad3000, call sites det3d/models/backbones/scn_unet.py:15-24,205;
+ *  semantics SURVEY.md §2.3)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* open-addressing hash (64-bit linearised (b,z,y,x) keys -> row).  cap must be a power of two >= 2*n.
+ * keys[cap] (uint64), vals[cap] (int32). */
+int ls3d_index_build(const int32_t *coords /*[n,4]*/, int n, const int32_t *n_dev, const int32_t shape_zyx_host[3],
+                     uint64_t *keys, int32_t *vals, int cap, ls3d_stream_t stream);
+
+/* SubMConv3d rulebook: nbr[n, kvol] with kvol = kz*ky*kx, nbr[v,k] = input row at coords[v] + k - ksize/2
+ * (kernel offset index row-major over (kz,ky,kx)) or -1. */
+int ls3d_rulebook_subm(const int32_t *coords, int n, const int32_t *n_dev, const int32_t shape_zyx_host[3],
+                       const int32_t ksize_host[3], const uint64_t *keys, const int32_t *vals, int cap,
+                       int32_t *nbr, ls3d_stream_t stream);
+
+size_t ls3d_rulebook_conv_workspace_bytes(int batch, const int32_t out_shape_zyx_host[3]);
+
+/* SparseConv3d rulebook (+ the transposed table SparseInverseConv3d needs).
+ *   out_shape = (in + 2*pad - k)/stride + 1;  output sites in ascending linear index (spconv's CUDA order);
+ *   nbr_out[out_cap, kvol]: nbr_out[o,k] = input row at o*stride - pad + k, or -1;
+ *   nbr_inv[n_in, kvol]:    nbr_inv[i,k] = output row fed by input i through offset k, or -1;
+ *   out_coords[out_cap,4]; *n_out_dev = number of output sites (rows beyond out_cap are dropped and
+ *   *overflow_dev is set to 1). */
+int ls3d_rulebook_conv(const int32_t *coords_in, int n_in, const int32_t *n_in_dev, int batch,
+                       const int32_t in_shape_zyx_host[3], const int32_t ksize_host[3],
+                       const int32_t stride_host[3], const int32_t pad_host[3], void *workspace,
+                       size_t workspace_bytes, int32_t *out_coords, int out_cap, int32_t *n_out_dev,
+                       int32_t *nbr_out, int32_t *nbr_inv, int32_t *overflow_dev, ls3d_stream_t stream);
+
+/* Fused epilogue of the gather-GEMM (all optional):
+ *   v = acc * scale[c] + shift[c]           (folded eval BatchNorm / bias)
+ *   v += res_pre[r*res_pre_ld + c]          (SparseBasicBlock identity, scn_unet.py:66)
+ *   v = relu ? max(v,0) : v
+ *   v += pair[r*pair_ld + 2c] + pair[r*pair_ld + 2c+1]   (channel_reduction + add, scn_unet.py:168-169) */
+typedef struct {
+  const float *scale, *shift;
+  const float *res_pre;
+  int32_t res_pre_ld;
+  const float *pair;
+  int32_t pair_ld;
+  int32_t relu;
+} ls3d_epilogue_t;
+
+/* out[r, 0..cout) = epilogue( sum_k W[k]^T * in[tbl[r,k]] ), tbl == NULL means the identity table with
+ * kvol == 1 (a dense Linear layer).  in[*, cin] row stride in_ld, W[kvol][cin][cout_pad] with
+ * cout_pad = roundup(cout,32), out row stride out_ld.  cin must be a multiple of 16, in_ld of 4.
+ * f32 MFMA (v_mfma_f32_32x32x2_f32): exact f32 products and accumulation.
+ * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
+ * (tbl = nbr_inv) and every nn.Linear on the path. */
+int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int cin, int cout,
+                     int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
+                     int out_ld, ls3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Devoxelization
+ * ---------------------------------------------------------------------------------------------- */
+
+/* voxel centres: out[v] = (b, (x+.5)*vx+x0, (y+.5)*vy+y0, (z+.5)*vz+z0), f32 mul then add (unfused),
+ * det3d/core/utils/common_utils.py:74-90 + scn_unet.py:243-247. */
+int ls3d_voxel_centers(const int32_t *coords, int n, const int32_t *n_dev, const float vs_host[3],
+                       const float lo_host[3], float *out, ls3d_stream_t stream);
+
+/* three_nn_wrapper(b,n,m,unknown,known,dist2,idx), det3d/ops/pointnet2_batch/src/pointnet2_api.cpp:21,
+ * interpolate_gpu.cu:16-59: exact brute-force 3 nearest, squared f32 distance evaluated as
+ * fma(dz,dz,fma(dy,dy,dx*dx)), strict '<' (lowest index wins ties), dist2 = +inf / idx = 0 for m < 3.
+ * unknown (b,n,3), known (b,m,3) contiguous. */
+int ls3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx,
+                  ls3d_stream_t stream);
+
+/* three_interpolate_wrapper(b,c,m,n,points,idx,weight,out), pointnet2_api.cpp:22, interpolate_gpu.cu:84-104:
+ * channel-major points (b,c,m) -> out (b,c,n). */
+int ls3d_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                           const float *weight, float *out, ls3d_stream_t stream);
+
+/* three_interpolate_grad_wrapper, pointnet2_api.cpp:23, interpolate_gpu.cu:127-149 (training only). */
+int ls3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int32_t *idx,
+                                const float *weight, float *grad_points, ls3d_stream_t stream);
+
+/* The whole of point_utils.three_interpolate_wrap (det3d/models/point_heads/point_utils.py:8-52) for a
+ * collated batch: per frame f, for the points rows [pt_off[f], pt_off[f+1]) find the 3 nearest voxel
+ * centres among rows [vx_off[f], vx_off[f+1]) of centers[*,4] (col 0 = batch), weights
+ * w_j = (1/(sqrt(d2_j)+1e-8))/sum, out[p, 0..c) = sum_j w_j * feat[vx_off[f]+idx_j].
+ * points[*, pt_stride] with xyz at columns 1..3.  idx_out[n,3] (frame-relative, may be NULL). */
+int ls3d_devoxelize(const float *points, int pt_stride, int n_points, const int32_t *pt_off /*[batch+1] dev*/,
+                    const float *centers, const int32_t *vx_off /*[batch+1] dev*/, int batch, int max_frame_points,
+                    const float *feat, int feat_ld, int c, float *out, int out_ld, int32_t *idx_out,
+                    ls3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LiDAR-camera fusion (MSeg3D point head)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* get_points_image_feature (det3d/models/point_heads/point_seg_mseg3d_head.py:200-236): 5-D grid_sample of
+ * image_features[batch,ncam,c,h,w] at points_cuv[n,4] = (valid, cam, h, w in [-1,1]), trilinear over
+ * (cam,h,w), zeros padding, align_corners=True.  Rows with valid != 1 get zeros.  out[n, c] ld out_ld. */
+int ls3d_grid_gather(const float *image_features, int batch, int ncam, int c, int h, int w,
+                     const float *points_cuv, const float *points, int pt_stride, int n, float *out, int out_ld,
+                     ls3d_stream_t stream);
+
+/* feature completion (point_seg_mseg3d_head.py:314-334) fused with the concat of :341:
+ * lc[p, 0..c_l) = lidar[p], lc[p, c_l..c_l+c_c) = valid[p] ? camera[p] : pseudo[p].
+ * pseudo == NULL means zeros: that is what the reference's forward produces, because it evaluates the mimic
+ * layer on the VALID points only and zero-pads the rest before the torch.where (:305,:320-334). */
+int ls3d_complete_concat(const float *lidar, int c_l, const float *camera, const float *pseudo, int c_c,
+                         const float *points_cuv, int n, float *lc, ls3d_stream_t stream);
+
+/* LiDARSemanticFeatureAggregationModule.forward (context_module.py:25-53): per frame softmax of
+ * logits[V,cls] over the voxels of the frame, emb[f, cls, c] = sum_v p[v,cls] * feats[v,c].
+ * workspace: 2*batch*cls floats. */
+int ls3d_sfam(const float *feats, int feat_ld, int c, const float *logits, int cls, const int32_t *vx_off, int batch,
+              int max_frame_voxels, float *workspace, float *emb /*[batch,cls,c]*/, ls3d_stream_t stream);
+
+/* SparsePointCorssAttention core (context_module.py:339-372): q[n,embed] (already projected), per-frame
+ * k,v[batch, heads, embed/heads, L] (Conv1d outputs reshaped as the reference does), softmax(q.k*scale) v
+ * -> out[n, embed].  frame of point p = (int)points[p*pt_stride]. */
+int ls3d_cross_attn(const float *q, const float *k, const float *v, int batch, int heads, int embed, int L,
+                    const float *points, int pt_stride, int n, float *out, ls3d_stream_t stream);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LS3D_H */

@@ -1,0 +1,84 @@
+"""ctypes binding of libls3d.so (the hipcc-built C ABI declared in include/ls3d.h).
+
+The product path has exactly one implementation: the HIP library.  If it is missing or fails to load,
+importing any op raises — there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libls3d.so")
+
+OK = 0
+_ERR = {-1: "LS3D_ERR_ARG", -2: "LS3D_ERR_LAUNCH", -3: "LS3D_ERR_UNSUPPORTED", -4: "LS3D_ERR_WORKSPACE"}
+
+EXPORTS = [
+    "ls3d_version", "ls3d_voxelize_dynamic", "ls3d_voxelize_hard_workspace_bytes", "ls3d_voxelize_hard",
+    "ls3d_dynamic_scatter_workspace_bytes", "ls3d_dynamic_scatter", "ls3d_vfe_mean", "ls3d_vfe_improved_mean",
+    "ls3d_vfe_tokens", "ls3d_mha_core", "ls3d_group_max", "ls3d_layernorm", "ls3d_index_build",
+    "ls3d_rulebook_subm", "ls3d_rulebook_conv_workspace_bytes", "ls3d_rulebook_conv", "ls3d_gather_gemm",
+    "ls3d_voxel_centers", "ls3d_three_nn", "ls3d_three_interpolate", "ls3d_three_interpolate_grad",
+    "ls3d_devoxelize", "ls3d_grid_gather", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn",
+]
+
+
+class Grid(ctypes.Structure):
+    _fields_ = [("vs", ctypes.c_float * 3), ("lo", ctypes.c_float * 3), ("grid", ctypes.c_int32 * 3)]
+
+
+class PointsLayout(ctypes.Structure):
+    _fields_ = [("stride", ctypes.c_int32), ("xyz_col", ctypes.c_int32), ("batch_col", ctypes.c_int32),
+                ("feat_col", ctypes.c_int32), ("n_feat", ctypes.c_int32)]
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("res_pre", ctypes.c_void_p),
+                ("res_pre_ld", ctypes.c_int32), ("pair", ctypes.c_void_p), ("pair_ld", ctypes.c_int32),
+                ("relu", ctypes.c_int32)]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def _configure(lib):
+    lib.ls3d_version.restype = ctypes.c_char_p
+    for name in ("ls3d_voxelize_hard_workspace_bytes", "ls3d_dynamic_scatter_workspace_bytes",
+                 "ls3d_rulebook_conv_workspace_bytes"):
+        getattr(lib, name).restype = ctypes.c_size_t
+    for name in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        if fn.restype is ctypes.c_int:
+            fn.restype = ctypes.c_int
+    return lib
+
+
+def load(path=None):
+    """Load (once) and return the HIP library.  Raises LibraryMissing when it has not been built
+    (`python -m lidarseg3d_amd.build`)."""
+    global _lib
+    if _lib is None or path is not None:
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise LibraryMissing(
+                "%s not found: build it with `python -m lidarseg3d_amd.build` (hipcc, gfx950). "
+                "lidarseg3d_amd has no CPU/PyTorch fallback." % p)
+        _lib = _configure(ctypes.CDLL(p))
+    return _lib
+
+
+def use_library_for_testing(path):
+    """TEST HOOK: make the Python host layer call another build of the same C ABI (tests/hipsim's host
+    emulation of the kernels) so that host logic and kernel indexing can be exercised without a GPU.
+    Never called by the package itself."""
+    global _lib
+    _lib = _configure(ctypes.CDLL(path)) if path else None
+    return _lib
+
+
+def check(rc, what):
+    if rc != OK:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, rc)))

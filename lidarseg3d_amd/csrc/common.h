@@ -1,0 +1,70 @@
+// common.h — shared device helpers for libls3d (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ls3d.h"
+
+#define LS3D_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define LS3D_INF_I32 0x7F7F7F7F  // memset(0x7F) sentinel: larger than any row index
+
+#define LS3D_RETURN_IF_LAUNCH_FAILED()            \
+  do {                                            \
+    if (hipGetLastError() != hipSuccess) return LS3D_ERR_LAUNCH; \
+  } while (0)
+
+// 1-D launch geometry for grid-stride kernels: enough blocks to cover `work` items, capped so that a
+// launch never exceeds ~8 blocks per CU (256 CUs); the kernels loop over the remainder.
+static inline dim3 ls3d_grid(long long work, int block = 256, int max_blocks = 2048) {
+  long long b = (work + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return dim3((unsigned)b);
+}
+
+__device__ __forceinline__ int ls3d_count(int n, const int32_t *n_dev) {
+  if (n_dev) {
+    int d = *n_dev;
+    return d < n ? d : n;
+  }
+  return n;
+}
+
+__device__ __forceinline__ uint64_t ls3d_mix(uint64_t k) {  // 64-bit finaliser (splitmix)
+  k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
+  k ^= k >> 27; k *= 0x94d049bb133111ebull;
+  k ^= k >> 31;
+  return k;
+}
+
+// find-or-insert; returns the slot.  keys[] initialised to LS3D_EMPTY_KEY (memset 0xFF).
+__device__ __forceinline__ int ls3d_hash_claim(uint64_t *keys, uint32_t mask, uint64_t key) {
+  uint32_t s = (uint32_t)ls3d_mix(key) & mask;
+  for (;;) {
+    unsigned long long prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)LS3D_EMPTY_KEY,
+                                        (unsigned long long)key);
+    if (prev == LS3D_EMPTY_KEY || prev == key) return (int)s;
+    s = (s + 1) & mask;
+  }
+}
+
+// lookup; returns the slot or -1
+__device__ __forceinline__ int ls3d_hash_find(const uint64_t *keys, uint32_t mask, uint64_t key) {
+  uint32_t s = (uint32_t)ls3d_mix(key) & mask;
+  for (;;) {
+    uint64_t k = keys[s];
+    if (k == key) return (int)s;
+    if (k == LS3D_EMPTY_KEY) return -1;
+    s = (s + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ uint64_t ls3d_key(int b, int z, int y, int x, int Z, int Y, int X) {
+  return (((uint64_t)b * (uint64_t)Z + (uint64_t)z) * (uint64_t)Y + (uint64_t)y) * (uint64_t)X + (uint64_t)x;
+}
+
+// exclusive scan of int32 (shared by voxelize / rulebook): three launches, any n.
+// tmp must hold roundup(n,1024)/1024 + 1 ints.  total_out (device) receives the grand total (may be NULL).
+int ls3d_exclusive_scan_i32(const int32_t *in, int32_t *out, int n, int32_t *tmp, int32_t *total_out,
+                            hipStream_t stream);
+static inline size_t ls3d_scan_tmp_ints(long long n) { return (size_t)((n + 1023) / 1024 + 1); }

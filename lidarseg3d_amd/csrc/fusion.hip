@@ -1,0 +1,212 @@
+// fusion.hip — LiDAR-camera fusion kernels of the MSeg3D point head (GF-Phase gather/completion, SF-Phase
+// aggregation and point<->class-embedding cross attention).
+//
+// Reference: det3d/models/point_heads/point_seg_mseg3d_head.py:200-236 (get_points_image_feature, a 5-D
+// F.grid_sample), :314-341 (feature completion + concat), det3d/models/point_heads/context_module.py:25-53
+// (LiDARSemanticFeatureAggregationModule) and :320-376 (SparsePointCorssAttention).  The reference loops over
+// frames in Python with boolean-mask gathers; here every kernel takes the collated batch in one launch.
+// All four are gather/stream kernels (HBM/L2-bound); the dense projections around them run through
+// ls3d_gather_gemm.
+#include "common.h"
+
+// trilinear sample of one channel plane stack.  PyTorch grid_sampler_3d semantics, align_corners=True:
+// unnormalise ((g+1)/2)*(size-1); corners floor/floor+1; out-of-bounds corners contribute 0; corner order
+// tnw,tne,tsw,tse,bnw,bne,bsw,bse.
+__global__ __launch_bounds__(256) void k_grid_gather(const float *img, int ncam, int C, int H, int W, const float *cuv, const float *points,
+                                                    int pt_stride, int n, float *out, int out_ld) {
+  const long long work = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(t / C), c = (int)(t % C);
+    const float *g = cuv + 4 * (size_t)p;
+    float r = 0.0f;
+    if (g[0] == 1.0f) {
+      const int b = (int)points[(size_t)p * pt_stride];
+      const float ix = ((g[3] + 1.0f) / 2.0f) * (float)(W - 1);
+      const float iy = ((g[2] + 1.0f) / 2.0f) * (float)(H - 1);
+      const float iz = ((g[1] + 1.0f) / 2.0f) * (float)(ncam - 1);
+      const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+      const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+      const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix;
+      const float wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+      const float wz1 = iz - fz, wz0 = (fz + 1.0f) - iz;
+      const float *base = img + ((size_t)b * ncam * C + c) * H * W;  // + cam*C*H*W
+      const size_t cam_stride = (size_t)C * H * W;
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+            const float wgt = ((dx ? wx1 : wx0) * (dy ? wy1 : wy0)) * (dz ? wz1 : wz0);
+            if (x >= 0 && x < W && y >= 0 && y < H && z >= 0 && z < ncam) r += base[z * cam_stride + (size_t)y * W + x] * wgt;
+          }
+    }
+    out[(size_t)p * out_ld + c] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_complete_concat(const float *lidar, int CL, const float *camera, const float *pseudo, int CC,
+                                                        const float *cuv, int n, float *lc) {
+  const int ld = CL + CC;
+  const long long work = (long long)n * ld;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(t / ld), c = (int)(t % ld);
+    float v;
+    if (c < CL) v = lidar[(size_t)p * CL + c];
+    else v = (cuv[4 * (size_t)p] == 1.0f) ? camera[(size_t)p * CC + (c - CL)] : (pseudo ? pseudo[(size_t)p * CC + (c - CL)] : 0.0f);
+    lc[t] = v;
+  }
+}
+
+__device__ __forceinline__ int f2o(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+// pass 1: per (frame, class) max of the logits over the frame's voxels
+__global__ __launch_bounds__(256) void k_sfam_max(const float *logits, int cls, const int32_t *vx_off, int32_t *ws_max) {
+  const int f = blockIdx.y;
+  const int v0 = vx_off[f], v1 = vx_off[f + 1];
+  const long long work = (long long)(v1 - v0) * cls;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % cls);
+    atomicMax(&ws_max[f * cls + c], f2o(logits[(size_t)v0 * cls + t]));
+  }
+}
+// pass 2: per (frame, class) sum of exp(l - max)
+__global__ __launch_bounds__(256) void k_sfam_sum(const float *logits, int cls, const int32_t *vx_off, const int32_t *ws_max, float *ws_sum) {
+  const int f = blockIdx.y;
+  const int v0 = vx_off[f], v1 = vx_off[f + 1];
+  const long long work = (long long)(v1 - v0) * cls;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % cls);
+    atomicAdd(&ws_sum[f * cls + c], expf(logits[(size_t)v0 * cls + t] - o2f(ws_max[f * cls + c])));
+  }
+}
+// pass 3: emb[f, cls, c] += sum over a chunk of 64 voxels of p[v,cls] * feat[v,c]
+__global__ __launch_bounds__(256) void k_sfam_acc(const float *feats, int feat_ld, int C, const float *logits, int cls, const int32_t *vx_off,
+                                                 const int32_t *ws_max, const float *ws_sum, float *emb) {
+  __shared__ float sp[64 * 32];   // probabilities [64 voxels][cls<=32]
+  __shared__ float sf[64 * 128];  // features [64 voxels][C<=128]
+  const int f = blockIdx.y;
+  const int v0 = vx_off[f], v1 = vx_off[f + 1];
+  for (int base = v0 + blockIdx.x * 64; base < v1; base += gridDim.x * 64) {
+    const int cnt = min(64, v1 - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * cls; e += 256) {
+      const int v = e / cls, c = e % cls;
+      sp[v * 32 + c] = expf(logits[(size_t)(base + v) * cls + c] - o2f(ws_max[f * cls + c])) / ws_sum[f * cls + c];
+    }
+    for (int e = threadIdx.x; e < cnt * C; e += 256) {
+      const int v = e / C, c = e % C;
+      sf[v * 128 + c] = feats[(size_t)(base + v) * feat_ld + c];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < cls * C; o += 256) {
+      const int k = o / C, c = o % C;
+      float acc = 0.0f;
+      for (int v = 0; v < cnt; ++v) acc = fmaf(sp[v * 32 + k], sf[v * 128 + c], acc);
+      atomicAdd(&emb[((size_t)f * cls + k) * C + c], acc);
+    }
+  }
+}
+
+// one thread per (point, head): softmax over the L class embeddings of the point's frame
+template <int HD>
+__global__ __launch_bounds__(256) void k_cross_attn(const float *q, const float *k, const float *v, int H, int L, const float *points,
+                                                   int pt_stride, int n, float *out) {
+  const int E = H * HD;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const long long work = (long long)n * H;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(t / H), h = (int)(t % H);
+    const int b = (int)points[(size_t)p * pt_stride];
+    const float *qp = q + (size_t)p * E + h * HD;
+    const float *kb = k + ((size_t)b * H + h) * HD * L;
+    const float *vb = v + ((size_t)b * H + h) * HD * L;
+    float qr[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { qr[d] = qp[d]; acc[d] = 0.0f; }
+    float m = -3.0e38f;
+    for (int l = 0; l < L; ++l) {
+      float s = 0.0f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) s = fmaf(qr[d], kb[d * L + l], s);
+      m = fmaxf(m, s * scale);
+    }
+    float den = 0.0f;
+    for (int l = 0; l < L; ++l) {
+      float s = 0.0f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) s = fmaf(qr[d], kb[d * L + l], s);
+      const float pr = expf(s * scale - m);
+      den += pr;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) acc[d] = fmaf(pr, vb[d * L + l], acc[d]);
+    }
+    const float inv = 1.0f / den;
+    float *op = out + (size_t)p * E + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
+  }
+}
+
+extern "C" int ls3d_grid_gather(const float *image_features, int batch, int ncam, int c, int h, int w, const float *points_cuv,
+                                const float *points, int pt_stride, int n, float *out, int out_ld, ls3d_stream_t stream) {
+  if (!image_features || !points_cuv || !points || !out || batch < 1 || ncam < 1 || c < 1 || h < 1 || w < 1 || n < 0 || out_ld < c)
+    return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  hipLaunchKernelGGL(k_grid_gather, ls3d_grid((long long)n * c), dim3(256), 0, (hipStream_t)stream, image_features, ncam, c, h, w, points_cuv,
+                     points, pt_stride, n, out, out_ld);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_complete_concat(const float *lidar, int c_l, const float *camera, const float *pseudo, int c_c, const float *points_cuv,
+                                    int n, float *lc, ls3d_stream_t stream) {
+  if (!lidar || !camera || !points_cuv || !lc || n < 0 || c_l < 1 || c_c < 1) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  hipLaunchKernelGGL(k_complete_concat, ls3d_grid((long long)n * (c_l + c_c)), dim3(256), 0, (hipStream_t)stream, lidar, c_l, camera, pseudo,
+                     c_c, points_cuv, n, lc);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_sfam(const float *feats, int feat_ld, int c, const float *logits, int cls, const int32_t *vx_off, int batch,
+                         int max_frame_voxels, float *workspace, float *emb, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!feats || !logits || !vx_off || !workspace || !emb || batch < 1 || c < 1 || c > 128 || cls < 1 || cls > 32 || feat_ld < c)
+    return LS3D_ERR_ARG;
+  int32_t *ws_max = (int32_t *)workspace;
+  float *ws_sum = workspace + (size_t)batch * cls;
+  hipMemsetAsync(ws_max, 0x80, (size_t)batch * cls * 4, stream);  // 0x80808080: below every ordered float
+  hipMemsetAsync(ws_sum, 0, (size_t)batch * cls * 4, stream);
+  hipMemsetAsync(emb, 0, (size_t)batch * cls * c * 4, stream);
+  if (max_frame_voxels <= 0) return LS3D_OK;
+  dim3 g1 = ls3d_grid((long long)max_frame_voxels * cls);
+  g1.y = batch;
+  hipLaunchKernelGGL(k_sfam_max, g1, dim3(256), 0, stream, logits, cls, vx_off, ws_max);
+  hipLaunchKernelGGL(k_sfam_sum, g1, dim3(256), 0, stream, logits, cls, vx_off, (const int32_t *)ws_max, ws_sum);
+  dim3 g3 = ls3d_grid(((long long)max_frame_voxels + 63) / 64 * 256, 256, 1024);
+  g3.y = batch;
+  hipLaunchKernelGGL(k_sfam_acc, g3, dim3(256), 0, stream, feats, feat_ld, c, logits, cls, vx_off, (const int32_t *)ws_max,
+                     (const float *)ws_sum, emb);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_cross_attn(const float *q, const float *k, const float *v, int batch, int heads, int embed, int L, const float *points,
+                               int pt_stride, int n, float *out, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!q || !k || !v || !points || !out || batch < 1 || heads < 1 || embed % heads || L < 1 || n < 0) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  const dim3 grid = ls3d_grid((long long)n * heads);
+  switch (embed / heads) {
+    case 8: hipLaunchKernelGGL((k_cross_attn<8>), grid, dim3(256), 0, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
+    case 16: hipLaunchKernelGGL((k_cross_attn<16>), grid, dim3(256), 0, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
+    case 24: hipLaunchKernelGGL((k_cross_attn<24>), grid, dim3(256), 0, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
+    case 32: hipLaunchKernelGGL((k_cross_attn<32>), grid, dim3(256), 0, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
+    default: return LS3D_ERR_UNSUPPORTED;
+  }
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

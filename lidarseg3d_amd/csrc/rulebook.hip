@@ -1,0 +1,208 @@
+// rulebook.hip — coordinate index and rulebooks for SubMConv3d / SparseConv3d / SparseInverseConv3d.
+//
+// spconv v1.x (third party, pinned @ fad3000 by docs/INSTALL.md:88-99; call sites
+// det3d/models/backbones/scn_unet.py:15-24,205) builds per-offset (in,out) PAIR lists and runs
+// gather -> GEMM -> scatter-add per offset.  Here the rulebook is OUTPUT-MAJOR instead: one row of
+// `kvol` int32 per output site naming the input row that feeds it through each kernel offset (-1 = none).
+// That is what an output-stationary gather-GEMM wants (no atomics, no zero-init, fused epilogue), and the
+// same table shape serves all three conv types:
+//     SubM      nbr[v][k]      = row of coords[v] + k - ksize/2
+//     strided   nbr_out[o][k]  = row of o*stride - pad + k
+//     inverse   nbr_inv[i][k]  = output row o with o*stride - pad + k == i     (transposed relation)
+// Strided-conv output sites come out in ascending linear index (spconv's CUDA ordering) without a sort:
+// candidate sites set bits in a dense bitmap of the (small) output grid, a popcount prefix sum ranks them.
+// Integer work only; bound by L2 atomics/hash-probe latency, tables stay in L2/MALL.
+#include "common.h"
+
+struct Shape3 { int z, y, x; };
+
+__global__ __launch_bounds__(256) void k_index_build(const int32_t *coords, int n, const int32_t *n_dev, Shape3 s, uint64_t *keys,
+                                                    int32_t *vals, uint32_t mask) {
+  const int N = ls3d_count(n, n_dev);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const int32_t *c = coords + 4 * (size_t)i;
+    const int slot = ls3d_hash_claim(keys, mask, ls3d_key(c[0], c[1], c[2], c[3], s.z, s.y, s.x));
+    vals[slot] = i;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_subm(const int32_t *coords, int n, const int32_t *n_dev, Shape3 s, Shape3 ks,
+                                             const uint64_t *keys, const int32_t *vals, uint32_t mask, int32_t *nbr) {
+  const int N = ls3d_count(n, n_dev);
+  const int kvol = ks.z * ks.y * ks.x;
+  const long long work = (long long)N * kvol;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(t / kvol), k = (int)(t % kvol);
+    const int kz = k / (ks.y * ks.x), ky = (k / ks.x) % ks.y, kx = k % ks.x;
+    const int32_t *c = coords + 4 * (size_t)v;
+    const int z = c[1] + kz - ks.z / 2, y = c[2] + ky - ks.y / 2, x = c[3] + kx - ks.x / 2;
+    int r = -1;
+    if (z >= 0 && z < s.z && y >= 0 && y < s.y && x >= 0 && x < s.x) {
+      const int slot = ls3d_hash_find(keys, mask, ls3d_key(c[0], z, y, x, s.z, s.y, s.x));
+      if (slot >= 0) r = vals[slot];
+    }
+    nbr[t] = r;
+  }
+}
+
+struct ConvGeom {
+  Shape3 in, out, ks, st, pd;
+};
+
+// output site fed by input (z,y,x) through kernel offset (kz,ky,kx):  o = (i + pad - k) / stride
+__device__ __forceinline__ bool conv_out_site(const ConvGeom &g, int z, int y, int x, int kz, int ky, int kx, int &oz, int &oy, int &ox) {
+  const int nz = z + g.pd.z - kz, ny = y + g.pd.y - ky, nx = x + g.pd.x - kx;
+  if (nz < 0 || ny < 0 || nx < 0) return false;
+  if (nz % g.st.z || ny % g.st.y || nx % g.st.x) return false;
+  oz = nz / g.st.z; oy = ny / g.st.y; ox = nx / g.st.x;
+  return oz < g.out.z && oy < g.out.y && ox < g.out.x;
+}
+
+__global__ __launch_bounds__(256) void k_conv_mark(const int32_t *coords, int n, const int32_t *n_dev, ConvGeom g, uint32_t *bitmap) {
+  const int N = ls3d_count(n, n_dev);
+  const int kvol = g.ks.z * g.ks.y * g.ks.x;
+  const long long work = (long long)N * kvol;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / kvol), k = (int)(t % kvol);
+    const int kz = k / (g.ks.y * g.ks.x), ky = (k / g.ks.x) % g.ks.y, kx = k % g.ks.x;
+    const int32_t *c = coords + 4 * (size_t)i;
+    int oz, oy, ox;
+    if (conv_out_site(g, c[1], c[2], c[3], kz, ky, kx, oz, oy, ox)) {
+      const uint64_t lin = ls3d_key(c[0], oz, oy, ox, g.out.z, g.out.y, g.out.x);
+      atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_popc(const uint32_t *bitmap, int nwords, int32_t *cnt) {
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) cnt[w] = __popc(bitmap[w]);
+}
+
+__global__ __launch_bounds__(256) void k_conv_emit(const uint32_t *bitmap, const int32_t *prefix, int nwords, Shape3 o, int out_cap,
+                                                  const int32_t *total, int32_t *out_coords, int32_t *n_out, int32_t *overflow) {
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
+    uint32_t bits = bitmap[w];
+    int rank = prefix[w];
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1;
+      if (rank < out_cap) {
+        uint64_t lin = ((uint64_t)w << 5) + (uint64_t)b;
+        int32_t *c = out_coords + 4 * (size_t)rank;
+        c[3] = (int)(lin % (uint64_t)o.x); lin /= (uint64_t)o.x;
+        c[2] = (int)(lin % (uint64_t)o.y); lin /= (uint64_t)o.y;
+        c[1] = (int)(lin % (uint64_t)o.z); lin /= (uint64_t)o.z;
+        c[0] = (int)lin;
+      }
+      ++rank;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int t = *total;
+    *n_out = t < out_cap ? t : out_cap;
+    if (t > out_cap && overflow) *overflow = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_conv_tables(const int32_t *coords, int n, const int32_t *n_dev, ConvGeom g, const uint32_t *bitmap,
+                                                    const int32_t *prefix, int out_cap, int32_t *nbr_out, int32_t *nbr_inv) {
+  const int N = ls3d_count(n, n_dev);
+  const int kvol = g.ks.z * g.ks.y * g.ks.x;
+  const long long work = (long long)N * kvol;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / kvol), k = (int)(t % kvol);
+    const int kz = k / (g.ks.y * g.ks.x), ky = (k / g.ks.x) % g.ks.y, kx = k % g.ks.x;
+    const int32_t *c = coords + 4 * (size_t)i;
+    int oz, oy, ox, o = -1;
+    if (conv_out_site(g, c[1], c[2], c[3], kz, ky, kx, oz, oy, ox)) {
+      const uint64_t lin = ls3d_key(c[0], oz, oy, ox, g.out.z, g.out.y, g.out.x);
+      const uint32_t word = bitmap[lin >> 5];
+      o = prefix[lin >> 5] + __popc(word & ((1u << (lin & 31)) - 1u));
+      if (o < out_cap) nbr_out[(size_t)o * kvol + k] = i;  // each (o,k) has exactly one source: no conflict
+      else o = -1;
+    }
+    if (nbr_inv) nbr_inv[t] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fill_m1(int32_t *p, long long n) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) p[t] = -1;
+}
+
+static inline size_t rb_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int ls3d_index_build(const int32_t *coords, int n, const int32_t *n_dev, const int32_t shape[3], uint64_t *keys,
+                                int32_t *vals, int cap, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!coords || !shape || !keys || !vals || n < 0 || cap < 2 || (cap & (cap - 1)) || (long long)cap < 2LL * n) return LS3D_ERR_ARG;
+  hipMemsetAsync(keys, 0xFF, (size_t)cap * 8, stream);
+  if (n == 0) return LS3D_OK;
+  hipLaunchKernelGGL(k_index_build, ls3d_grid(n), dim3(256), 0, stream, coords, n, n_dev, Shape3{shape[0], shape[1], shape[2]}, keys, vals,
+                     (uint32_t)(cap - 1));
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_rulebook_subm(const int32_t *coords, int n, const int32_t *n_dev, const int32_t shape[3], const int32_t ksize[3],
+                                  const uint64_t *keys, const int32_t *vals, int cap, int32_t *nbr, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!coords || !shape || !ksize || !keys || !vals || !nbr || n < 0 || (cap & (cap - 1))) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  const int kvol = ksize[0] * ksize[1] * ksize[2];
+  hipLaunchKernelGGL(k_subm, ls3d_grid((long long)n * kvol), dim3(256), 0, stream, coords, n, n_dev, Shape3{shape[0], shape[1], shape[2]},
+                     Shape3{ksize[0], ksize[1], ksize[2]}, keys, vals, (uint32_t)(cap - 1), nbr);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+static inline long long rb_words(int batch, const int32_t oshape[3]) {
+  return ((long long)batch * oshape[0] * oshape[1] * oshape[2] + 31) / 32;
+}
+
+extern "C" size_t ls3d_rulebook_conv_workspace_bytes(int batch, const int32_t oshape[3]) {
+  const long long nw = rb_words(batch, oshape);
+  return rb_align((size_t)nw * 4) * 3 + rb_align(ls3d_scan_tmp_ints(nw) * 4) + 256;
+}
+
+extern "C" int ls3d_rulebook_conv(const int32_t *coords_in, int n_in, const int32_t *n_in_dev, int batch, const int32_t in_shape[3],
+                                  const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3], void *workspace,
+                                  size_t workspace_bytes, int32_t *out_coords, int out_cap, int32_t *n_out_dev, int32_t *nbr_out,
+                                  int32_t *nbr_inv, int32_t *overflow_dev, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!coords_in || !in_shape || !ksize || !stride || !pad || !workspace || !out_coords || !n_out_dev || !nbr_out) return LS3D_ERR_ARG;
+  if (n_in < 0 || batch < 1 || out_cap < 1) return LS3D_ERR_ARG;
+  ConvGeom g;
+  g.in = Shape3{in_shape[0], in_shape[1], in_shape[2]};
+  g.ks = Shape3{ksize[0], ksize[1], ksize[2]};
+  g.st = Shape3{stride[0], stride[1], stride[2]};
+  g.pd = Shape3{pad[0], pad[1], pad[2]};
+  if (g.st.z < 1 || g.st.y < 1 || g.st.x < 1) return LS3D_ERR_ARG;
+  int32_t os[3];
+  for (int a = 0; a < 3; ++a) os[a] = (in_shape[a] + 2 * pad[a] - ksize[a]) / stride[a] + 1;
+  if (os[0] < 1 || os[1] < 1 || os[2] < 1) return LS3D_ERR_ARG;
+  g.out = Shape3{os[0], os[1], os[2]};
+  const long long nw = rb_words(batch, os);
+  if (nw > 0x7FFFFFFFLL) return LS3D_ERR_UNSUPPORTED;
+  if (workspace_bytes < ls3d_rulebook_conv_workspace_bytes(batch, os)) return LS3D_ERR_WORKSPACE;
+  char *base = (char *)workspace;
+  uint32_t *bitmap = (uint32_t *)base; base += rb_align((size_t)nw * 4);
+  int32_t *cnt = (int32_t *)base; base += rb_align((size_t)nw * 4);
+  int32_t *prefix = (int32_t *)base; base += rb_align((size_t)nw * 4);
+  int32_t *scan_tmp = (int32_t *)base; base += rb_align(ls3d_scan_tmp_ints(nw) * 4);
+  int32_t *total = (int32_t *)base;
+  const int kvol = ksize[0] * ksize[1] * ksize[2];
+  hipMemsetAsync(bitmap, 0, (size_t)nw * 4, stream);
+  hipLaunchKernelGGL(k_fill_m1, ls3d_grid((long long)out_cap * kvol), dim3(256), 0, stream, nbr_out, (long long)out_cap * kvol);
+  if (n_in > 0)
+    hipLaunchKernelGGL(k_conv_mark, ls3d_grid((long long)n_in * kvol), dim3(256), 0, stream, coords_in, n_in, n_in_dev, g, bitmap);
+  hipLaunchKernelGGL(k_popc, ls3d_grid(nw), dim3(256), 0, stream, (const uint32_t *)bitmap, (int)nw, cnt);
+  int rc = ls3d_exclusive_scan_i32(cnt, prefix, (int)nw, scan_tmp, total, stream);
+  if (rc != LS3D_OK) return rc;
+  hipLaunchKernelGGL(k_conv_emit, ls3d_grid(nw), dim3(256), 0, stream, (const uint32_t *)bitmap, (const int32_t *)prefix, (int)nw, g.out,
+                     out_cap, (const int32_t *)total, out_coords, n_out_dev, overflow_dev);
+  if (n_in > 0)
+    hipLaunchKernelGGL(k_conv_tables, ls3d_grid((long long)n_in * kvol), dim3(256), 0, stream, coords_in, n_in, n_in_dev, g,
+                       (const uint32_t *)bitmap, (const int32_t *)prefix, out_cap, nbr_out, nbr_inv);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

@@ -1,0 +1,115 @@
+"""SegNet (SDSeg3D) and SegMSeg3DNet (MSeg3D) detectors with the reference's registry names and constructor
+signatures (det3d/models/detectors/seg_net.py:11-107, seg_mseg3d_net.py:6-147, single_stage.py:10-33).
+
+forward(example, return_loss=False) consumes the collated `example` dict of the reference dataloader
+(det3d/torchie/parallel/collate.py:91-170) and returns point_head.predict(...)'s per-frame list.
+Two input modes:
+  * drop-in: example carries the dataloader's CPU-voxelised `voxels / coordinates / num_points` -> used as is;
+  * MI355X-native: example carries only `points` ([N,1+C], batch index in column 0) -> hard voxelization runs
+    on the GPU (csrc/voxelize.hip), bit-exact with the dataloader's numba kernel.
+The camera CNN (HRNet + FCN head) is outside the hot-path scope: SegMSeg3DNet takes `image_features`
+[B,ncam,C,h,w] and `camera_semantic_embeddings` [B,C,num_cls,1] from `example` unless an img_backbone /
+img_head registered by the user is configured."""
+import numpy as np
+import torch
+from torch import nn
+
+from . import builder, ops
+from .registry import DETECTORS
+
+
+def _voxel_inputs(example, voxel_cfg):
+    """-> voxels, coordinates[V,4], num_points, batch_size, input_shape(x,y,z)"""
+    if "voxels" in example:
+        shape = example["shape"][0] if "shape" in example else ops.make_grid(voxel_cfg["voxel_size"], voxel_cfg["range"])[1]
+        return (example["voxels"], example["coordinates"], example["num_points"], len(example["num_voxels"]),
+                np.asarray(shape))
+    if voxel_cfg is None:
+        raise KeyError("example has no 'voxels' and the detector was built without a voxel_generator cfg")
+    points = example["points"].contiguous()
+    batch_size = int(example["batch_size"]) if "batch_size" in example else int(points[:, 0].max().item()) + 1
+    mv = voxel_cfg.get("max_voxel_num", 300000)
+    mv = mv[1] if isinstance(mv, (list, tuple)) else mv
+    v, c, n, nv = ops.voxelize_hard(points, voxel_cfg["voxel_size"], voxel_cfg["range"], voxel_cfg.get("max_points_in_voxel", 5),
+                                    int(mv) * batch_size, batched=True)
+    V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it
+    _, grid = ops.make_grid(voxel_cfg["voxel_size"], voxel_cfg["range"])
+    example["num_voxels"] = ops.frame_offsets(c[:V, 0], batch_size).diff()
+    return v[:V], c[:V], n[:V], batch_size, np.asarray(grid)
+
+
+class SingleStageDetector(nn.Module):
+    def __init__(self, reader, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.reader = builder.build_reader(reader)
+        self.backbone = builder.build_backbone(backbone)
+        if neck is not None:
+            self.neck = builder.build_neck(neck)
+        if bbox_head is not None:
+            self.bbox_head = builder.build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    def init_weights(self, pretrained=None):
+        if pretrained is None:
+            return
+        from .checkpoint import load_checkpoint
+        load_checkpoint(self, pretrained, strict=False)
+
+
+@DETECTORS.register_module
+class SegNet(SingleStageDetector):
+    def __init__(self, reader, backbone, point_head, neck=None, bbox_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, voxel_generator=None, **kwargs):
+        super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained=None)
+        self.point_head = builder.build_point_head(point_head)
+        self.voxel_generator = voxel_generator
+        self.init_weights(pretrained=pretrained)
+
+    def forward_features(self, example):
+        voxels, coords, num, batch_size, shape = _voxel_inputs(example, self.voxel_generator)
+        data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
+                    points=example["points"][:, 0:4])
+        data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
+        return self.backbone(data)
+
+    def forward(self, example, return_loss=True, **kwargs):
+        if return_loss:
+            raise NotImplementedError("training step: next row of the scope table (SURVEY.md §8f rank 1)")
+        data = self.forward_features(example)
+        self.point_head(batch_dict=data, return_loss=False)
+        return self.point_head.predict(example=example, test_cfg=self.test_cfg)
+
+
+@DETECTORS.register_module
+class SegMSeg3DNet(SingleStageDetector):
+    def __init__(self, reader, backbone, point_head, img_backbone=None, img_head=None, neck=None, bbox_head=None,
+                 train_cfg=None, test_cfg=None, pretrained=None, voxel_generator=None, **kwargs):
+        super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained=None)
+        self.img_backbone = builder.build_img_backbone(img_backbone) if img_backbone is not None else None
+        self.img_head = builder.build_img_head(img_head) if img_head is not None else None
+        self.point_head = builder.build_point_head(point_head)
+        self.voxel_generator = voxel_generator
+        self.init_weights(pretrained=pretrained)
+
+    def forward(self, example, return_loss=True, **kwargs):
+        if return_loss:
+            raise NotImplementedError("training step: next row of the scope table (SURVEY.md §8f rank 1)")
+        voxels, coords, num, batch_size, shape = _voxel_inputs(example, self.voxel_generator)
+        if self.img_backbone is not None and "image_features" not in example:
+            images = example["images"]
+            ncam, hi, wi = images.shape[1], images.shape[3], images.shape[4]
+            img_data = self.img_head(batch_dict=dict(inputs=self.img_backbone(images.view(-1, 3, hi, wi)),
+                                                     batch_size=batch_size), return_loss=False)
+            feats = img_data["image_features"]
+            image_features = feats.view(batch_size, ncam, *feats.shape[1:])
+            cam_emb = img_data.get("camera_semantic_embeddings")
+        else:
+            image_features, cam_emb = example["image_features"], example["camera_semantic_embeddings"]
+        data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
+                    points=example["points"][:, 0:4])
+        data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
+        data = self.backbone(data)
+        data.update(points_cuv=example["points_cuv"], image_features=image_features,
+                    camera_semantic_embeddings=cam_emb, metadata=example.get("metadata"))
+        self.point_head(batch_dict=data, return_loss=False)
+        return self.point_head.predict(example=example, test_cfg=self.test_cfg)

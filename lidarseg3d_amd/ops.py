@@ -1,0 +1,359 @@
+"""Thin torch-tensor front end of the C ABI (include/ls3d.h).
+
+torch is used for device memory and streams only: every function below allocates its outputs with torch,
+passes raw device pointers + the current HIP stream to libls3d.so, and returns torch tensors.  There is no
+computation in Python and no fallback: tensors must live on the GPU (the only exception is the test hook
+``_lib.use_library_for_testing`` which swaps in tests/hipsim's host build of the same kernels and then
+requires CPU tensors).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Epilogue, Grid, PointsLayout, check
+
+_i32 = torch.int32
+_SIM = False
+
+
+def _L():
+    return _lib.load()
+
+
+def set_sim(flag):
+    """tests only — see _lib.use_library_for_testing"""
+    global _SIM
+    _SIM = bool(flag)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if _SIM:
+        if t.is_cuda:
+            raise RuntimeError("hipsim test hook active: CPU tensors only")
+    elif not t.is_cuda:
+        raise RuntimeError("lidarseg3d_amd ops need tensors on the MI355X (got a %s tensor); "
+                           "there is no CPU fallback" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("non-contiguous tensor passed to libls3d")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(0)
+
+
+def _i3(v):
+    return (ctypes.c_int32 * 3)(*[int(x) for x in v])
+
+
+def _f3(v):
+    return (ctypes.c_float * 3)(*[float(np.float32(x)) for x in v])
+
+
+def make_grid(voxel_size, pc_range):
+    """grid = round((hi-lo)/vs) in f32, as point_cloud_ops.py:26-29 / voxelization_cpu.cpp:118-121."""
+    vs = np.asarray(voxel_size, np.float32)
+    r = np.asarray(pc_range, np.float32)
+    g = np.round((r[3:] - r[:3]) / vs).astype(np.int64)
+    return Grid(_f3(vs), _f3(r[:3]), _i3(g)), [int(x) for x in g]
+
+
+def _ws(nbytes, like):
+    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=like.device)
+
+
+# ---------------------------------------------------------------------------------------------- voxelization
+def voxelize_dynamic(points, voxel_size, pc_range, xyz_col=0):
+    n = points.shape[0]
+    grid, _ = make_grid(voxel_size, pc_range)
+    lay = PointsLayout(points.shape[1], xyz_col, -1, xyz_col, points.shape[1] - xyz_col)
+    coors = torch.empty((n, 3), dtype=_i32, device=points.device)
+    check(_L().ls3d_voxelize_dynamic(_ptr(points), n, ctypes.byref(lay), ctypes.byref(grid), _ptr(coors),
+                                     _stream(points)), "ls3d_voxelize_dynamic")
+    return coors
+
+
+def voxelize_hard(points, voxel_size, pc_range, max_points, max_voxels, overflow="numba", batched=False):
+    """points [N,C] (one frame) or, batched=True, [N,1+C] with the batch index in column 0.
+    -> voxels[cap,max_points,C], coors[cap,3|4], num_points[cap], num_voxels (1-elt device tensor).
+    Rows beyond num_voxels are undefined; slice after reading the count (one host sync)."""
+    n = points.shape[0]
+    grid, _ = make_grid(voxel_size, pc_range)
+    off = 1 if batched else 0
+    c = points.shape[1] - off
+    lay = PointsLayout(points.shape[1], off, 0 if batched else -1, off, c)
+    cap = max(min(n, int(max_voxels)), 1)
+    dev = points.device
+    voxels = torch.empty((cap, max_points, c), dtype=torch.float32, device=dev)
+    cols = 4 if batched else 3
+    coors = torch.empty((cap, cols), dtype=_i32, device=dev)
+    num = torch.empty((cap,), dtype=_i32, device=dev)
+    nv = torch.zeros((1,), dtype=_i32, device=dev)
+    L = _L()
+    ws = _ws(L.ls3d_voxelize_hard_workspace_bytes(n, max_points, int(max_voxels)), points)
+    check(L.ls3d_voxelize_hard(_ptr(points), n, ctypes.byref(lay), ctypes.byref(grid), int(max_points), int(max_voxels),
+                               1 if overflow == "break" else 0, _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(voxels),
+                               _ptr(coors), cols, _ptr(num), _ptr(nv), _stream(points)), "ls3d_voxelize_hard")
+    return voxels, coors, num, nv
+
+
+def dynamic_scatter(feats, coors, shape_zyx, mode="mean"):
+    n, c = feats.shape
+    cols = coors.shape[1]
+    dev = feats.device
+    out = torch.empty((max(n, 1), c), dtype=torch.float32, device=dev)
+    vc = torch.empty((max(n, 1), cols), dtype=_i32, device=dev)
+    p2v = torch.empty((max(n, 1),), dtype=_i32, device=dev)
+    nv = torch.zeros((1,), dtype=_i32, device=dev)
+    L = _L()
+    ws = _ws(L.ls3d_dynamic_scatter_workspace_bytes(n), feats)
+    check(L.ls3d_dynamic_scatter(_ptr(feats), n, c, _ptr(coors), cols, _i3(shape_zyx), 0 if mode == "mean" else 1,
+                                 _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(out), _ptr(vc), _ptr(p2v), _ptr(nv),
+                                 _stream(feats)), "ls3d_dynamic_scatter")
+    return out, vc, p2v, nv
+
+
+# ---------------------------------------------------------------------------------------------- readers
+def _ndev(nd):
+    return _ptr(nd) if nd is not None else None
+
+
+def vfe_mean(voxels, num_points, n_dev=None):
+    n, p, c = voxels.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=voxels.device)
+    check(_L().ls3d_vfe_mean(_ptr(voxels), _ptr(num_points), n, _ndev(n_dev), p, c, _ptr(out), c, _stream(voxels)),
+          "ls3d_vfe_mean")
+    return out
+
+
+def vfe_improved_mean(voxels, num_points, out_ld=None, n_dev=None):
+    n, p, c = voxels.shape
+    ld = out_ld or (c + 8)
+    out = torch.empty((n, ld), dtype=torch.float32, device=voxels.device)
+    check(_L().ls3d_vfe_improved_mean(_ptr(voxels), _ptr(num_points), n, _ndev(n_dev), p, c, _ptr(out), ld,
+                                      _stream(voxels)), "ls3d_vfe_improved_mean")
+    return out
+
+
+def vfe_tokens(voxels, num_points, tok_ld, n_dev=None):
+    n, p, c = voxels.shape
+    out = torch.empty((n * p, tok_ld), dtype=torch.float32, device=voxels.device)
+    check(_L().ls3d_vfe_tokens(_ptr(voxels), _ptr(num_points), n, _ndev(n_dev), p, c, _ptr(out), tok_ld,
+                               _stream(voxels)), "ls3d_vfe_tokens")
+    return out
+
+
+def mha_core(qkv, groups, seq, embed, heads):
+    out = torch.empty((groups * seq, embed), dtype=torch.float32, device=qkv.device)
+    check(_L().ls3d_mha_core(_ptr(qkv), groups, None, seq, embed, heads, _ptr(out), _stream(qkv)), "ls3d_mha_core")
+    return out
+
+
+def group_max(x, groups, seq):
+    c = x.shape[1]
+    out = torch.empty((groups, c), dtype=torch.float32, device=x.device)
+    check(_L().ls3d_group_max(_ptr(x), groups, None, seq, c, _ptr(out), _stream(x)), "ls3d_group_max")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, res=None):
+    rows, c = x.shape
+    y = torch.empty_like(x)
+    check(_L().ls3d_layernorm(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), ctypes.c_float(eps), rows, None, c, _ptr(y),
+                              _stream(x)), "ls3d_layernorm")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------- sparse conv
+def hash_capacity(n):
+    c = 1024
+    while c < 2 * n:
+        c *= 2
+    return c
+
+
+def index_build(coords, shape_zyx):
+    n = coords.shape[0]
+    cap = hash_capacity(n)
+    keys = torch.empty((cap,), dtype=torch.int64, device=coords.device)
+    vals = torch.empty((cap,), dtype=_i32, device=coords.device)
+    check(_L().ls3d_index_build(_ptr(coords), n, None, _i3(shape_zyx), _ptr(keys), _ptr(vals), cap, _stream(coords)),
+          "ls3d_index_build")
+    return keys, vals
+
+
+def rulebook_subm(coords, shape_zyx, ksize, index=None):
+    n = coords.shape[0]
+    keys, vals = index if index is not None else index_build(coords, shape_zyx)
+    kvol = int(ksize[0] * ksize[1] * ksize[2])
+    nbr = torch.empty((n, kvol), dtype=_i32, device=coords.device)
+    check(_L().ls3d_rulebook_subm(_ptr(coords), n, None, _i3(shape_zyx), _i3(ksize), _ptr(keys), _ptr(vals),
+                                  keys.numel(), _ptr(nbr), _stream(coords)), "ls3d_rulebook_subm")
+    return nbr
+
+
+def conv_out_shape(shape_zyx, ksize, stride, pad):
+    return [(int(shape_zyx[a]) + 2 * int(pad[a]) - int(ksize[a])) // int(stride[a]) + 1 for a in range(3)]
+
+
+def rulebook_conv(coords, batch, shape_zyx, ksize, stride, pad, out_cap=None):
+    """-> out_coords[cap,4], n_out (1-elt device tensor), nbr_out[cap,kvol], nbr_inv[n_in,kvol], out_shape, overflow"""
+    n = coords.shape[0]
+    kvol = int(ksize[0] * ksize[1] * ksize[2])
+    oshape = conv_out_shape(shape_zyx, ksize, stride, pad)
+    per_in = 1
+    for a in range(3):  # outputs one input can feed along an axis
+        per_in *= -(-int(ksize[a]) // int(stride[a]))
+    cells = batch * oshape[0] * oshape[1] * oshape[2]
+    cap = int(out_cap) if out_cap else max(1, min(n * per_in, cells))
+    dev = coords.device
+    oc = torch.empty((cap, 4), dtype=_i32, device=dev)
+    nbr_out = torch.empty((cap, kvol), dtype=_i32, device=dev)
+    nbr_inv = torch.empty((max(n, 1), kvol), dtype=_i32, device=dev)
+    cnt = torch.zeros((2,), dtype=_i32, device=dev)  # [n_out, overflow]
+    L = _L()
+    ws = _ws(L.ls3d_rulebook_conv_workspace_bytes(batch, _i3(oshape)), coords)
+    check(L.ls3d_rulebook_conv(_ptr(coords), n, None, batch, _i3(shape_zyx), _i3(ksize), _i3(stride), _i3(pad), _ptr(ws),
+                               ctypes.c_size_t(ws.numel()), _ptr(oc), cap, _ptr(cnt), _ptr(nbr_out), _ptr(nbr_inv),
+                               ctypes.c_void_p(cnt.data_ptr() + 4), _stream(coords)), "ls3d_rulebook_conv")
+    return oc, cnt, nbr_out, nbr_inv, oshape
+
+
+def gather_gemm(x, w, tbl=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
+                out=None, out_ld=None, in_ld=None, cin=None):
+    """out[r, :cout] = epilogue(sum_k W[k]^T x[tbl[r,k]]).  w: packed [kvol, cin, roundup(cout,32)]."""
+    kvol, wcin, wld = w.shape
+    cin = cin or wcin
+    assert wcin == cin
+    in_ld = in_ld or x.shape[1]
+    cout = cout or wld
+    if tbl is not None:
+        n_rows = tbl.shape[0] if n_rows is None else n_rows
+        assert tbl.shape[1] == kvol
+    else:
+        n_rows = x.shape[0] if n_rows is None else n_rows
+    if out is None:
+        out_ld = out_ld or cout
+        out = torch.empty((n_rows, out_ld), dtype=torch.float32, device=x.device)
+        out_view = out
+    else:
+        out_view = out
+        out_ld = out_ld or out.shape[1]
+    epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
+                   pair.shape[1] if pair is not None else 0, 1 if relu else 0)
+    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), kvol, _ptr(w), cin, cout, n_rows, None, ctypes.byref(epi),
+                                _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
+    return out
+
+
+def _vp(t):
+    p = _ptr(t)
+    return p if p is not None else ctypes.c_void_p(0)
+
+
+def _vp_any(t):
+    """pointer of a possibly non-contiguous VIEW (column slice of a wider buffer): rows stay out_ld apart."""
+    if _SIM and t.is_cuda:
+        raise RuntimeError("hipsim test hook active: CPU tensors only")
+    if not _SIM and not t.is_cuda:
+        raise RuntimeError("lidarseg3d_amd ops need tensors on the MI355X; there is no CPU fallback")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------------------------------------- devoxelization
+def voxel_centers(coords, voxel_size, pc_range):
+    n = coords.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=coords.device)
+    check(_L().ls3d_voxel_centers(_ptr(coords), n, None, _f3(voxel_size), _f3(pc_range[:3]), _ptr(out), _stream(coords)),
+          "ls3d_voxel_centers")
+    return out
+
+
+def three_nn(unknown, known):
+    """unknown (B,N,3), known (B,M,3) -> dist2 (B,N,3) SQUARED, idx (B,N,3)"""
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknown.device)
+    idx = torch.empty((b, n, 3), dtype=_i32, device=unknown.device)
+    check(_L().ls3d_three_nn(b, n, m, _ptr(unknown), _ptr(known), _ptr(d2), _ptr(idx), _stream(unknown)), "ls3d_three_nn")
+    return d2, idx
+
+
+def three_interpolate(features, idx, weight):
+    b, c, m = features.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=features.device)
+    check(_L().ls3d_three_interpolate(b, c, m, n, _ptr(features), _ptr(idx), _ptr(weight), _ptr(out), _stream(features)),
+          "ls3d_three_interpolate")
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    b, c, n = grad_out.shape
+    g = torch.zeros((b, c, m), dtype=torch.float32, device=grad_out.device)
+    check(_L().ls3d_three_interpolate_grad(b, c, n, m, _ptr(grad_out), _ptr(idx), _ptr(weight), _ptr(g),
+                                           _stream(grad_out)), "ls3d_three_interpolate_grad")
+    return g
+
+
+def frame_offsets(batch_col, batch_size):
+    """[B+1] int32 device offsets of frame-sorted rows (torch bookkeeping, no host sync)."""
+    cnt = torch.bincount(batch_col.to(torch.int64), minlength=batch_size)[:batch_size]
+    off = torch.zeros((batch_size + 1,), dtype=_i32, device=batch_col.device)
+    off[1:] = torch.cumsum(cnt, 0).to(_i32)
+    return off
+
+
+def devoxelize(points, pt_off, centers, vx_off, batch, max_frame_points, feat, c=None, return_idx=False):
+    n = points.shape[0]
+    c = c or feat.shape[1]
+    out = torch.empty((n, c), dtype=torch.float32, device=points.device)
+    idx = torch.empty((n, 3), dtype=_i32, device=points.device) if return_idx else None
+    check(_L().ls3d_devoxelize(_ptr(points), points.shape[1], n, _ptr(pt_off), _ptr(centers), _ptr(vx_off), batch,
+                               int(max_frame_points), _ptr(feat), feat.shape[1], c, _ptr(out), c, _ptr(idx),
+                               _stream(points)), "ls3d_devoxelize")
+    return (out, idx) if return_idx else out
+
+
+# ---------------------------------------------------------------------------------------------- fusion
+def grid_gather(image_features, points_cuv, points):
+    b, ncam, c, h, w = image_features.shape
+    n = points_cuv.shape[0]
+    out = torch.empty((n, c), dtype=torch.float32, device=points.device)
+    check(_L().ls3d_grid_gather(_ptr(image_features), b, ncam, c, h, w, _ptr(points_cuv), _ptr(points), points.shape[1], n,
+                                _ptr(out), c, _stream(points)), "ls3d_grid_gather")
+    return out
+
+
+def complete_concat(lidar, camera, pseudo, points_cuv):
+    n, cl = lidar.shape
+    cc = camera.shape[1]
+    out = torch.empty((n, cl + cc), dtype=torch.float32, device=lidar.device)
+    check(_L().ls3d_complete_concat(_ptr(lidar), cl, _ptr(camera), _ptr(pseudo), cc, _ptr(points_cuv), n, _ptr(out),
+                                    _stream(lidar)), "ls3d_complete_concat")
+    return out
+
+
+def sfam(feats, logits, vx_off, batch, max_frame_voxels, c=None):
+    c = c or feats.shape[1]
+    cls = logits.shape[1]
+    ws = torch.empty((2 * batch * cls,), dtype=torch.float32, device=feats.device)
+    emb = torch.empty((batch, cls, c), dtype=torch.float32, device=feats.device)
+    check(_L().ls3d_sfam(_ptr(feats), feats.shape[1], c, _ptr(logits), cls, _ptr(vx_off), batch, int(max_frame_voxels),
+                         _ptr(ws), _ptr(emb), _stream(feats)), "ls3d_sfam")
+    return emb
+
+
+def cross_attn(q, k, v, batch, heads, points):
+    n, e = q.shape
+    L = k.numel() // (batch * e)
+    out = torch.empty((n, e), dtype=torch.float32, device=q.device)
+    check(_L().ls3d_cross_attn(_ptr(q), _ptr(k), _ptr(v), batch, heads, e, L, _ptr(points), points.shape[1], n, _ptr(out),
+                               _stream(q)), "ls3d_cross_attn")
+    return out

@@ -1,0 +1,92 @@
+"""Weight packing for the HIP kernels: reference-layout parameters (nn.Linear (out,in), spconv
+(kD,kH,kW,Cin,Cout), BatchNorm running stats) -> GEMM-ready device buffers.
+
+ls3d_gather_gemm wants W[kvol][cin_pad][roundup(cout,32)] (input-major, zero padded) and a per-column
+scale/shift epilogue; eval-mode BatchNorm and biases fold into that epilogue:
+    BN(x W + b) = x W * s + ((b - mean) * s + beta),   s = gamma / sqrt(var + eps)
+Packing happens once per weight version (see PackedModule), never per forward.
+"""
+import torch
+from torch import nn
+
+
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def fold_bn(bias, bn, cout, dev):
+    """-> (scale, shift) float32 [cout] or (None, bias)"""
+    if bn is None:
+        return None, (bias.detach().float().contiguous() if bias is not None else None)
+    s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    b = bias.detach().double() if bias is not None else torch.zeros(cout, dtype=torch.float64, device=dev)
+    t = (b - bn.running_mean.detach().double()) * s + bn.bias.detach().double()
+    return s.float().contiguous(), t.float().contiguous()
+
+
+def pack_linear(weight, bias=None, bn=None, cin_pad=None):
+    """nn.Linear / Conv1d(k=1) weight (out,in[,1]) -> (W[1,cin_pad,cout_pad], scale, shift, cout)"""
+    w = weight.detach().float()
+    if w.dim() == 3:
+        w = w.squeeze(-1)
+    cout, cin = w.shape
+    cin_pad = cin_pad or _pad16(cin)
+    W = torch.zeros((1, cin_pad, _pad32(cout)), dtype=torch.float32, device=w.device)
+    W[0, :cin, :cout] = w.t()
+    scale, shift = fold_bn(bias, bn, cout, w.device)
+    return W.contiguous(), scale, shift, cout
+
+
+def pack_spconv(weight, bn=None, cin_pad=None):
+    """spconv weight (kD,kH,kW,Cin,Cout) -> (W[kvol,cin_pad,cout_pad], scale, shift, cout)"""
+    w = weight.detach().float()
+    cin, cout = w.shape[-2], w.shape[-1]
+    kvol = w.numel() // (cin * cout)
+    cin_pad = cin_pad or _pad16(cin)
+    W = torch.zeros((kvol, cin_pad, _pad32(cout)), dtype=torch.float32, device=w.device)
+    W[:, :cin, :cout] = w.reshape(kvol, cin, cout)
+    scale, shift = fold_bn(None, bn, cout, w.device)
+    return W.contiguous(), scale, shift, cout
+
+
+class PackedModule(nn.Module):
+    """nn.Module whose kernel-ready buffers are rebuilt lazily after anything that can change the weights:
+    load_state_dict, .to()/.cuda() (via _apply), train()/eval()."""
+
+    def __init__(self):
+        super().__init__()
+        self._packed = None
+        self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate_packed())
+
+    def invalidate_packed(self):
+        for m in self.modules():
+            if isinstance(m, PackedModule):
+                m._packed = None
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._packed = None
+        return r
+
+    def train(self, mode=True):
+        self._packed = None
+        return super().train(mode)
+
+    def packed(self):
+        if self._packed is None:
+            with torch.no_grad():
+                self._packed = self._pack()
+        return self._packed
+
+    def _pack(self):
+        raise NotImplementedError
+
+    def _require_eval(self):
+        if self.training:
+            raise NotImplementedError(
+                "%s: the HIP path implements the inference forward (eval-mode BatchNorm); the training step is the "
+                "next row of the scope table (SURVEY.md §8f rank 1). Call .eval()." % type(self).__name__)

@@ -1,0 +1,336 @@
+"""Point heads registered under the reference's names / constructor signatures / attribute names:
+PointSegBatchlossHead (SDSeg3D; det3d/models/point_heads/point_seg_batchloss_head.py:14-271) and
+PointSegMSeg3DHead (MSeg3D GF-Phase + SF-Phase; point_seg_mseg3d_head.py:17-479) with its context modules
+(context_module.py).  forward(batch_dict, return_loss=False) -> batch_dict['out_logits'] [N, num_class].
+
+Everything numeric is a libls3d kernel: fused devoxelization (csrc/devox.hip), the MFMA gather-GEMM for every
+Linear/Conv1d(k=1) (+ folded eval BatchNorm / ReLU / residual), LayerNorm + attention cores (csrc/vfe.hip,
+csrc/fusion.hip).  The reference's per-frame Python loops with boolean-mask gathers are replaced by frame
+offsets handed to the kernels."""
+import copy
+from functools import partial
+
+import torch
+from torch import nn
+
+from . import ops
+from .packing import PackedModule, pack_linear
+from .registry import POINT_HEADS
+
+
+def _lin(x, pk, relu=False, res=None, n_rows=None):
+    W, scale, shift, cout = pk
+    if x.shape[1] != W.shape[1]:
+        x = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1]))
+    return ops.gather_gemm(x, W, cout=cout, scale=scale, shift=shift, relu=relu, res_pre=res, n_rows=n_rows)
+
+
+def _pack_mlp(seq):
+    """[Dropout]? (Linear(no bias), BN, ReLU)* Linear(bias) -> list of (packed, relu)"""
+    mods = [m for m in seq if not isinstance(m, (nn.Dropout, nn.ReLU))]
+    out, i = [], 0
+    while i < len(mods):
+        lin = mods[i]
+        bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+        out.append((pack_linear(lin.weight, lin.bias, bn), bn is not None))
+        i += 2 if bn is not None else 1
+    return out
+
+
+def _run_mlp(x, packed):
+    for pk, relu in packed:
+        x = _lin(x, pk, relu=relu)
+    return x
+
+
+def _make_convcls_head(fc_cfg, input_channels, output_channels, dp_ratio=0):
+    layers, c_in = [], input_channels
+    if dp_ratio > 0:
+        layers.append(nn.Dropout(dp_ratio))
+    for c in fc_cfg:
+        layers += [nn.Linear(c_in, c, bias=False), nn.BatchNorm1d(c), nn.ReLU()]
+        c_in = c
+    layers.append(nn.Linear(c_in, output_channels, bias=True))
+    return nn.Sequential(*layers)
+
+
+def _frame_layout(points, conv_point_coords, batch_size):
+    """device offsets of the frame-sorted point / voxel rows + host upper bounds for the launch grids"""
+    pt_off = ops.frame_offsets(points[:, 0], batch_size)
+    vx_off = ops.frame_offsets(conv_point_coords[:, 0], batch_size)
+    return pt_off, vx_off
+
+
+def _predict(head, example, test_cfg):
+    """point_seg_batchloss_head.py:171-271 / point_seg_mseg3d_head.py:379-479: per-frame argmax, or the mean of
+    the softmax over TTA variants.  Pure bookkeeping on top of out_logits."""
+    test_cfg = test_cfg or {}
+    batch_size = len(example["num_voxels"])
+    pts = example["points"][:, 0:4]
+    logits = head.forward_ret_dict["out_logits"]
+    meta = example.get("metadata") or [None] * batch_size
+    ret_list = []
+    if test_cfg.get("tta_flag", False):
+        k = test_cfg.get("num_tta_tranforms", 4)
+        if test_cfg.get("merge_type", "ArithmeticMean") != "ArithmeticMean":
+            raise NotImplementedError
+        probs = torch.softmax(logits, dim=-1)
+        masks = [pts[:, 0] == i for i in range(batch_size)]
+        left = 0
+        for j, i in enumerate(range(0, batch_size, k)):
+            merged = torch.stack([probs[masks[t]] for t in range(i, i + k)], 0).mean(0)
+            ret = dict(metadata=meta[i], pred_point_sem_labels=torch.argmax(merged, dim=1))
+            if "point_sem_labels" in example:
+                n = int(masks[i].sum())
+                ret["point_sem_labels"] = example["point_sem_labels"][left:left + n]
+                left += n
+            ret_list.append(ret)
+        return ret_list
+    labels = torch.argmax(logits, dim=1)
+    for i in range(batch_size):
+        m = pts[:, 0] == i
+        ret = dict(metadata=meta[i], pred_point_sem_labels=labels[m])
+        if "point_sem_labels" in example:
+            ret["point_sem_labels"] = example["point_sem_labels"][m]
+        ret_list.append(ret)
+    return ret_list
+
+
+@POINT_HEADS.register_module
+class PointSegBatchlossHead(PackedModule):
+    def __init__(self, class_agnostic, num_class, model_cfg, **kwargs):
+        super().__init__()
+        self.num_class = 1 if class_agnostic else num_class
+        cin = model_cfg["CONV_IN_DIM"]
+        self.conv_cls_layers = _make_convcls_head(model_cfg["CONV_CLS_FC"], cin, self.num_class)
+        cal = model_cfg["CONV_ALIGN_DIM"]
+        self.conv_align_layers = nn.Sequential(nn.Linear(cin, cal), nn.BatchNorm1d(cal, eps=1e-6), nn.ReLU())
+        self.out_cls_layers = _make_convcls_head(model_cfg["OUT_CLS_FC"], cal, self.num_class)
+        self.forward_ret_dict = {}
+        self.ignored_label = model_cfg["IGNORED_LABEL"]
+        self.tasks = ["out"]
+
+    def _pack(self):
+        return dict(conv_cls=_pack_mlp(self.conv_cls_layers), align=_pack_mlp(self.conv_align_layers),
+                    out_cls=_pack_mlp(self.out_cls_layers))
+
+    def forward(self, batch_dict, return_loss=True, **kwargs):
+        if return_loss or self.training:
+            raise NotImplementedError("PointSegBatchlossHead: inference forward only (SURVEY.md §8f rank 1)")
+        pk = self.packed()
+        batch_size = batch_dict["batch_size"]
+        feat = batch_dict["conv_point_features"]
+        self.forward_ret_dict["conv_logits"] = _run_mlp(feat, pk["conv_cls"])
+        points = batch_dict["points"].contiguous()
+        centers = batch_dict["conv_point_coords"]
+        pt_off, vx_off = _frame_layout(points, centers, batch_size)
+        pf = ops.devoxelize(points, pt_off, centers, vx_off, batch_size, points.shape[0], feat)
+        out = _run_mlp(_run_mlp(pf, pk["align"]), pk["out_cls"])
+        batch_dict["out_logits"] = out
+        self.forward_ret_dict["out_logits"] = out
+        return batch_dict
+
+    def get_loss(self, point_loss_dict=None):
+        raise NotImplementedError("losses belong to the training step (SURVEY.md §8f rank 1)")
+
+    @torch.no_grad()
+    def predict(self, example, test_cfg=None, **kwargs):
+        return _predict(self, example, test_cfg)
+
+
+# ------------------------------------------------------------------------------------------ SF-Phase containers
+class LiDARSemanticFeatureAggregationModule(nn.Module):
+    """context_module.py:18-53 -> [B, C, num_cls, 1]"""
+
+    def __init__(self, scale=1):
+        super().__init__()
+
+    def forward(self, feats, probs, batch_idx, batch_size):
+        vx_off = ops.frame_offsets(batch_idx, batch_size)
+        emb = ops.sfam(feats.contiguous(), probs.contiguous(), vx_off, batch_size, feats.shape[0])
+        return emb.permute(0, 2, 1).contiguous().unsqueeze(3)
+
+
+class SparsePointCorssAttention(nn.Module):
+    """parameter container, context_module.py:304-317"""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, kv_proj_kernel_size=1, bias=True, matmul_norm=True, **kw):
+        super().__init__()
+        assert kv_proj_kernel_size == 1 and matmul_norm
+        self.d_embed, self.n_head, self.d_head = embed_dim, num_heads, embed_dim // num_heads
+        self.q_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self.k_proj = nn.Conv1d(embed_dim, embed_dim, kv_proj_kernel_size, bias=bias)
+        self.v_proj = nn.Conv1d(embed_dim, embed_dim, kv_proj_kernel_size, bias=bias)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+
+
+class TransformerDecoderLayer(nn.Module):
+    """parameter container, context_module.py:175-206"""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, embeddings_proj_kernel_size=1,
+                 activation="relu", normalize_before=False):
+        super().__init__()
+        assert activation == "relu" and not normalize_before, "post-norm ReLU layers (the shipped configs)"
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.crossocr_attn = SparsePointCorssAttention(d_model, nhead, dropout, embeddings_proj_kernel_size)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm_tgt=None, norm_mem=None):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(decoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm_tgt = norm_tgt
+        self.norm_mem = norm_mem
+
+
+class SemanticFeatureFusionModule(PackedModule):
+    """SFFM (context_module.py:56-117): points attend to the 2*num_cls class embeddings (camera + LiDAR) of their
+    frame through num_decoder_layers post-norm decoder layers; the embeddings self-attend between layers."""
+
+    def __init__(self, d_input_point, d_input_embeddings1, d_input_embeddings2, embeddings_proj_kernel_size=1,
+                 d_model=512, nhead=8, num_decoder_layers=6, dim_feedforward=2048, dropout=0.0, activation="relu",
+                 normalize_before=False):
+        super().__init__()
+        self.input_proj_point = nn.Linear(d_input_point, d_model)
+        self.input_proj_embeddings1 = nn.Conv1d(d_input_embeddings1, d_model, embeddings_proj_kernel_size)
+        self.input_proj_embeddings2 = nn.Conv1d(d_input_embeddings2, d_model, embeddings_proj_kernel_size)
+        layer = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, embeddings_proj_kernel_size,
+                                        activation, normalize_before)
+        self.decoder = TransformerDecoder(layer, num_decoder_layers, nn.LayerNorm(d_model), None)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.d_model, self.nhead = d_model, nhead
+
+    def _pack(self):
+        ln = lambda m: (m.weight.detach().contiguous(), m.bias.detach().contiguous(), m.eps)
+        p = dict(point=pack_linear(self.input_proj_point.weight, self.input_proj_point.bias),
+                 emb1=pack_linear(self.input_proj_embeddings1.weight, self.input_proj_embeddings1.bias),
+                 emb2=pack_linear(self.input_proj_embeddings2.weight, self.input_proj_embeddings2.bias),
+                 norm_tgt=ln(self.decoder.norm_tgt), layers=[])
+        for l in self.decoder.layers:
+            ca = l.crossocr_attn
+            p["layers"].append(dict(
+                sa_qkv=pack_linear(l.self_attn.in_proj_weight, l.self_attn.in_proj_bias),
+                sa_out=pack_linear(l.self_attn.out_proj.weight, l.self_attn.out_proj.bias),
+                q=pack_linear(ca.q_proj.weight, ca.q_proj.bias), k=pack_linear(ca.k_proj.weight, ca.k_proj.bias),
+                v=pack_linear(ca.v_proj.weight, ca.v_proj.bias), o=pack_linear(ca.out_proj.weight, ca.out_proj.bias),
+                ff1=pack_linear(l.linear1.weight, l.linear1.bias), ff2=pack_linear(l.linear2.weight, l.linear2.bias),
+                n1=ln(l.norm1), n2=ln(l.norm2), n3=ln(l.norm3)))
+        return p
+
+    def forward(self, input_point_features, input_sem_embeddings1, input_sem_embeddings2, batch_idx, batch_size,
+                return_context=False, points=None):
+        """embeddings [B, C, num_cls, 1]; `points` (rows with the batch index in column 0) may be passed to avoid
+        rebuilding it from batch_idx."""
+        self._require_eval()
+        pk = self.packed()
+        E, H = self.d_model, self.nhead
+        if points is None:
+            points = batch_idx.float().unsqueeze(1).contiguous()
+        B = batch_size
+        # memory rows ordered (frame, token): tokens 0..cls-1 camera, cls..2cls-1 LiDAR  (context_module.py:105-108)
+        e1 = input_sem_embeddings1.squeeze(-1).permute(0, 2, 1).contiguous()  # [B,cls,C1]
+        e2 = input_sem_embeddings2.squeeze(-1).permute(0, 2, 1).contiguous()
+        cls = e1.shape[1]
+        L = 2 * cls
+        mem = torch.empty((B, L, E), dtype=torch.float32, device=e1.device)
+        mem[:, :cls] = _lin(e1.reshape(B * cls, -1), pk["emb1"]).view(B, cls, E)
+        mem[:, cls:] = _lin(e2.reshape(B * cls, -1), pk["emb2"]).view(B, cls, E)
+        mem = mem.view(B * L, E)
+        tgt = _lin(input_point_features, pk["point"])
+        for lp in pk["layers"]:
+            att = ops.mha_core(_lin(mem, lp["sa_qkv"]), B, L, E, H)
+            mem = ops.layernorm(_lin(att, lp["sa_out"]), *lp["n1"], res=mem)
+            q = _lin(tgt, lp["q"])
+            # k_proj / v_proj are Conv1d(k=1) over the tokens; the reference then VIEWS [B,E,L] as [B,H,hd,L]
+            k = _lin(mem, lp["k"]).view(B, L, E).permute(0, 2, 1).contiguous()
+            v = _lin(mem, lp["v"]).view(B, L, E).permute(0, 2, 1).contiguous()
+            att = ops.cross_attn(q, k, v, B, H, points)
+            tgt = ops.layernorm(_lin(att, lp["o"]), *lp["n2"], res=tgt)
+            ff = _lin(_lin(tgt, lp["ff1"], relu=True), lp["ff2"])
+            tgt = ops.layernorm(ff, *lp["n3"], res=tgt)
+        tgt = ops.layernorm(tgt, *pk["norm_tgt"])
+        if return_context:
+            return tgt, mem.view(B, L, E).permute(1, 0, 2).contiguous()
+        return tgt
+
+
+@POINT_HEADS.register_module
+class PointSegMSeg3DHead(PackedModule):
+    def __init__(self, class_agnostic, num_class, model_cfg, **kwargs):
+        super().__init__()
+        self.num_class = 1 if class_agnostic else num_class
+        norm_layer = partial(nn.BatchNorm1d, eps=1e-6)
+        vin = model_cfg["VOXEL_IN_DIM"]
+        self.dp_ratio = model_cfg["DP_RATIO"]
+        self.voxel_cls_layers = _make_convcls_head(model_cfg["VOXEL_CLS_FC"], vin, self.num_class, self.dp_ratio)
+        val = model_cfg["VOXEL_ALIGN_DIM"]
+        self.gffm_lidar = nn.Sequential(nn.Linear(vin, val), norm_layer(val), nn.ReLU())
+        iin, ial = model_cfg["IMAGE_IN_DIM"], model_cfg["IMAGE_ALIGN_DIM"]
+        self.gffm_camera = nn.Sequential(nn.Linear(iin, ial), norm_layer(ial), nn.ReLU())
+        fused = model_cfg["GEO_FUSED_DIM"]
+        self.gffm_lc = nn.Sequential(nn.Linear(val + ial, fused), nn.BatchNorm1d(fused), nn.ReLU())
+        self.lidar_camera_mimic_layer = _make_convcls_head(model_cfg["MIMIC_FC"], val, ial, 0)
+        sf = model_cfg["SFPhase_CFG"]
+        self.lidar_sfam = LiDARSemanticFeatureAggregationModule()
+        self.sffm = SemanticFeatureFusionModule(
+            d_input_point=fused, d_input_embeddings1=iin, d_input_embeddings2=vin,
+            embeddings_proj_kernel_size=sf["embeddings_proj_kernel_size"], d_model=sf["d_model"], nhead=sf["n_head"],
+            num_decoder_layers=sf["n_layer"], dim_feedforward=sf["n_ffn"], dropout=sf["drop_ratio"],
+            activation=sf["activation"], normalize_before=sf["pre_norm"])
+        self.out_cls_layers = nn.Linear(self.sffm.d_model, num_class)
+        self.forward_ret_dict = {}
+        self.ignored_label = model_cfg["IGNORED_LABEL"]
+        self.tasks = ["out"]
+
+    def _pack(self):
+        return dict(voxel_cls=_pack_mlp(self.voxel_cls_layers), lidar=_pack_mlp(self.gffm_lidar),
+                    camera=_pack_mlp(self.gffm_camera), lc=_pack_mlp(self.gffm_lc),
+                    mimic=_pack_mlp(self.lidar_camera_mimic_layer),
+                    out=pack_linear(self.out_cls_layers.weight, self.out_cls_layers.bias))
+
+    def get_points_image_feature(self, input_img_feature, points_cuv, batch_idx):
+        """point_seg_mseg3d_head.py:200-236 (rows with valid != 1 come back as zeros)"""
+        pts = batch_idx.float().unsqueeze(1).contiguous()
+        return ops.grid_gather(input_img_feature.contiguous(), points_cuv.contiguous(), pts)
+
+    def forward(self, batch_dict, return_loss=True, **kwargs):
+        if return_loss or self.training:
+            raise NotImplementedError("PointSegMSeg3DHead: inference forward only (SURVEY.md §8f rank 1)")
+        pk = self.packed()
+        B = batch_dict["batch_size"]
+        vf = batch_dict["conv_point_features"]
+        voxel_logits = _run_mlp(vf, pk["voxel_cls"])
+        self.forward_ret_dict["voxel_logits"] = voxel_logits
+        centers = batch_dict["conv_point_coords"]
+        points = batch_dict["points"].contiguous()
+        pt_off, vx_off = _frame_layout(points, centers, B)
+        # GF-Phase (:272-342).  The reference runs the camera / mimic branches on the valid subset and scatters
+        # back; here they run on all rows and complete_concat selects per row (eval BatchNorm is row-wise).
+        pl = _run_mlp(ops.devoxelize(points, pt_off, centers, vx_off, B, points.shape[0], vf), pk["lidar"])
+        cuv = batch_dict["points_cuv"].contiguous()
+        pc = _run_mlp(ops.grid_gather(batch_dict["image_features"].contiguous(), cuv, points), pk["camera"])
+        # The mimic (pseudo-camera) branch only feeds the training loss: the reference evaluates it on the valid
+        # points and zero-pads the others (:305,:320-334), so points without a camera hit get ZERO camera
+        # features at inference.  It is still evaluated here, as the reference's forward does.
+        self.forward_ret_dict["point_features_pcamera"] = _run_mlp(pl, pk["mimic"])
+        fused = _run_mlp(ops.complete_concat(pl, pc, None, cuv), pk["lc"])
+        # SF-Phase (:348-365)
+        lemb = ops.sfam(vf, voxel_logits, vx_off, B, vf.shape[0]).permute(0, 2, 1).contiguous().unsqueeze(3)
+        sem = self.sffm(fused, batch_dict["camera_semantic_embeddings"], lemb, points[:, 0], B, points=points)
+        out = _lin(sem, pk["out"])
+        batch_dict["out_logits"] = out
+        self.forward_ret_dict["out_logits"] = out
+        return batch_dict
+
+    def get_loss(self, point_loss_dict=None):
+        raise NotImplementedError("losses belong to the training step (SURVEY.md §8f rank 1)")
+
+    @torch.no_grad()
+    def predict(self, example, test_cfg=None, **kwargs):
+        return _predict(self, example, test_cfg)

@@ -1,0 +1,122 @@
+"""Voxel feature extractors registered under the reference's names and constructor signatures
+(det3d/models/readers/voxel_encoder.py:39-270).  call: reader(features[V,P,C], num_voxels[V], coors=None) -> [V,C']
+
+Forward runs on libls3d kernels only: the per-voxel descriptor / attention / pooling kernels of csrc/vfe.hip and
+the MFMA gather-GEMM (csrc/spconv.hip) for every projection."""
+import torch
+from torch import nn
+
+from . import ops
+from .packing import PackedModule, pack_linear
+from .registry import READERS
+
+
+@READERS.register_module
+class MeanVoxelFeatureExtractor(nn.Module):
+    """voxel_encoder.py:39-58"""
+
+    def __init__(self, num_input_features=4, name="MeanVoxelFeatureExtractor"):
+        super().__init__()
+        self.name = name
+        self.num_input_features = num_input_features
+
+    def forward(self, features, num_voxels, coors=None):
+        assert self.num_input_features == features.shape[-1]
+        return ops.vfe_mean(features.contiguous(), num_voxels.to(torch.int32).contiguous())
+
+
+@READERS.register_module
+class ImprovedMeanVoxelFeatureExtractor(nn.Module):
+    """voxel_encoder.py:62-124 — 13-/12-channel descriptor (mean, max, min, density, std)."""
+
+    def __init__(self, num_input_features=4, norm_cfg=None, name="ImprovedMeanVoxelFeatureExtractor"):
+        super().__init__()
+        self.name = name
+        self.num_input_features = num_input_features
+
+    def forward(self, features, num_voxels, coors=None, out_ld=None):
+        assert self.num_input_features == features.shape[-1]
+        return ops.vfe_improved_mean(features.contiguous(), num_voxels.to(torch.int32).contiguous(), out_ld=out_ld)
+
+
+class TransformerEncoderLayerPreNorm(nn.Module):
+    """parameter container with the reference's attribute names (voxel_encoder.py:128-147);
+    the arithmetic lives in TransformerVoxelFeatureExtractor.forward."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class _LayerStack(nn.Module):
+    """stands in for nn.TransformerEncoder: same `.layers.{i}` state_dict keys, norm=None."""
+
+    def __init__(self, make_layer, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([make_layer() for _ in range(num_layers)])
+
+
+@READERS.register_module
+class TransformerVoxelFeatureExtractor(PackedModule):
+    """TransVFE (voxel_encoder.py:166-270): per voxel, its <=5 points are tokens [point feats | descriptor];
+    Conv1d(k=1) embed -> num_layers x pre-norm transformer layers (residual taken from the NORMED tensor,
+    :154-161, no padding mask) -> max over the tokens -> Linear+ReLU compression."""
+
+    def __init__(self, num_input_features=4, num_compressed_features=16, num_embed=64, num_head=4, num_layers=2,
+                 norm_cfg=None, name="TransformerVoxelFeatureExtractor"):
+        super().__init__()
+        self.name = name
+        self.num_input_features = num_input_features
+        self.num_embed, self.num_head = num_embed, num_head
+        n_desc = num_input_features + 3 + 3 + 1 + 1
+        self.feature_conv = nn.Sequential(nn.Conv1d(num_input_features + n_desc, num_embed, 1, bias=True))
+        self.chunck = _LayerStack(lambda: TransformerEncoderLayerPreNorm(num_embed, num_head, num_embed * 2, dropout=0),
+                                  num_layers)
+        if num_compressed_features > 0:
+            self.compress_layer = nn.Sequential(nn.Linear(num_embed, num_compressed_features), nn.ReLU())
+            self.num_out_features = num_compressed_features
+        else:
+            self.compress_layer = None
+            self.num_out_features = num_embed
+
+    def _pack(self):
+        conv = self.feature_conv[0]
+        p = dict(embed=pack_linear(conv.weight, conv.bias), layers=[])
+        for l in self.chunck.layers:
+            p["layers"].append(dict(
+                qkv=pack_linear(l.self_attn.in_proj_weight, l.self_attn.in_proj_bias),
+                out=pack_linear(l.self_attn.out_proj.weight, l.self_attn.out_proj.bias),
+                ff1=pack_linear(l.linear1.weight, l.linear1.bias), ff2=pack_linear(l.linear2.weight, l.linear2.bias),
+                n1=(l.norm1.weight.detach().contiguous(), l.norm1.bias.detach().contiguous(), l.norm1.eps),
+                n2=(l.norm2.weight.detach().contiguous(), l.norm2.bias.detach().contiguous(), l.norm2.eps)))
+        if self.compress_layer is not None:
+            p["compress"] = pack_linear(self.compress_layer[0].weight, self.compress_layer[0].bias)
+        return p
+
+    @staticmethod
+    def _lin(x, pk, relu=False, res=None):
+        W, scale, shift, cout = pk
+        return ops.gather_gemm(x, W, cout=cout, scale=scale, shift=shift, relu=relu, res_pre=res)
+
+    def forward(self, features, num_voxels, coors=None):
+        assert self.num_input_features == features.shape[-1]
+        self._require_eval()
+        pk = self.packed()
+        V, P, C = features.shape
+        E, H = self.num_embed, self.num_head
+        tok = ops.vfe_tokens(features.contiguous(), num_voxels.to(torch.int32).contiguous(), pk["embed"][0].shape[1])
+        x = self._lin(tok, pk["embed"])
+        for lp in pk["layers"]:
+            x = ops.layernorm(x, lp["n1"][0], lp["n1"][1], lp["n1"][2])
+            att = ops.mha_core(self._lin(x, lp["qkv"]), V, P, E, H)
+            x = self._lin(att, lp["out"], res=x)
+            x = ops.layernorm(x, lp["n2"][0], lp["n2"][1], lp["n2"][2])
+            x = self._lin(self._lin(x, lp["ff1"], relu=True), lp["ff2"], res=x)
+        x = ops.group_max(x, V, P)
+        if self.compress_layer is not None:
+            x = self._lin(x, pk["compress"], relu=True)
+        return x

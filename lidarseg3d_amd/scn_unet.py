@@ -1,0 +1,147 @@
+"""UNetSCN3D — the sparse-conv UNet voxel encoder (det3d/models/backbones/scn_unet.py:72-249), same registry
+name, constructor signature, attribute names (=> state_dict keys) and batch_dict contract; forward runs on the
+libls3d gather-GEMM with BatchNorm(eval)/ReLU/residual/channel-reduction fused into each conv's epilogue."""
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from . import spconv
+from .registry import BACKBONES
+from .spconv import conv_bn_act
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type="subm",
+                   norm_fn=None):
+    """(conv, BN, ReLU) triple — scn_unet.py:11-30"""
+    if conv_type == "subm":
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == "spconv":
+        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                                   indice_key=indice_key)
+    elif conv_type == "inverseconv":
+        conv = spconv.SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False)
+    else:
+        raise NotImplementedError
+    return spconv.SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    """scn_unet.py:34-69: relu(bn2(conv2(relu(bn1(conv1(x))))) + x), two kernel launches."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, indice_key=None, norm_fn=None):
+        super().__init__()
+        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False,
+                                       indice_key=indice_key)
+        self.bn1 = norm_fn(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False,
+                                       indice_key=indice_key)
+        self.bn2 = norm_fn(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        assert x.features.dim() == 2, "x.features.dim()=%d" % x.features.dim()
+        identity = x.features if self.downsample is None else self.downsample(x)
+        out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        return conv_bn_act(self.conv2, self.bn2, out, relu=True, res_pre=identity)
+
+
+@BACKBONES.register_module
+class UNetSCN3D(nn.Module):
+    def __init__(self, num_input_features=128, name="UNetSCN3D", voxel_size=[], point_cloud_range=[], model_cfg={},
+                 **kwargs):
+        super().__init__()
+        self.model_cfg, self.voxel_size, self.point_cloud_range = model_cfg, voxel_size, point_cloud_range
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        r = model_cfg.get("SCALING_RATIO", 1)
+        c1, c2, c3, c4 = 16 * r, 32 * r, 64 * r, 64 * r
+        block = post_act_block
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(num_input_features, c1, 3, padding=1, bias=False, indice_key="subm1"), norm_fn(c1), nn.ReLU())
+        self.conv1 = spconv.SparseSequential(SparseBasicBlock(c1, c1, norm_fn=norm_fn, indice_key="subm1"),
+                                             SparseBasicBlock(c1, c1, norm_fn=norm_fn, indice_key="subm1"))
+        self.conv2 = spconv.SparseSequential(
+            block(c1, c2, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv2", conv_type="spconv"),
+            SparseBasicBlock(c2, c2, norm_fn=norm_fn, indice_key="subm2"),
+            SparseBasicBlock(c2, c2, norm_fn=norm_fn, indice_key="subm2"))
+        self.conv3 = spconv.SparseSequential(
+            block(c2, c3, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key="spconv3", conv_type="spconv"),
+            SparseBasicBlock(c3, c3, norm_fn=norm_fn, indice_key="subm3"),
+            SparseBasicBlock(c3, c3, norm_fn=norm_fn, indice_key="subm3"))
+        self.conv4 = spconv.SparseSequential(
+            block(c3, c4, 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key="spconv4", conv_type="spconv"),
+            SparseBasicBlock(c4, c4, norm_fn=norm_fn, indice_key="subm4"),
+            SparseBasicBlock(c4, c4, norm_fn=norm_fn, indice_key="subm4"))
+        if self.model_cfg.get("RETURN_ENCODED_TENSOR", True):
+            last_pad = self.model_cfg.get("last_pad", 0)
+            self.conv_out = spconv.SparseSequential(
+                spconv.SparseConv3d(c4, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                    indice_key="spconv_down2"), norm_fn(128), nn.ReLU())
+        else:
+            self.conv_out = None
+        # decoder (scn_unet.py:138-160)
+        self.conv_up_t4 = SparseBasicBlock(c4, c4, indice_key="subm4", norm_fn=norm_fn)
+        self.conv_up_m4 = block(2 * c4, c4, 3, norm_fn=norm_fn, padding=1, indice_key="subm4")
+        self.inv_conv4 = block(c4, c3, 3, norm_fn=norm_fn, indice_key="spconv4", conv_type="inverseconv")
+        self.conv_up_t3 = SparseBasicBlock(c3, c3, indice_key="subm3", norm_fn=norm_fn)
+        self.conv_up_m3 = block(2 * c3, c3, 3, norm_fn=norm_fn, padding=1, indice_key="subm3")
+        self.inv_conv3 = block(c3, c2, 3, norm_fn=norm_fn, indice_key="spconv3", conv_type="inverseconv")
+        self.conv_up_t2 = SparseBasicBlock(c2, c2, indice_key="subm2", norm_fn=norm_fn)
+        self.conv_up_m2 = block(2 * c2, c2, 3, norm_fn=norm_fn, indice_key="subm2")
+        self.inv_conv2 = block(c2, c1, 3, norm_fn=norm_fn, indice_key="spconv2", conv_type="inverseconv")
+        self.conv_up_t1 = SparseBasicBlock(c1, c1, indice_key="subm1", norm_fn=norm_fn)
+        self.conv_up_m1 = block(2 * c1, c1, 3, norm_fn=norm_fn, indice_key="subm1")
+        self.conv5 = spconv.SparseSequential(block(c1, c1, 3, norm_fn=norm_fn, padding=1, indice_key="subm1"))
+        self.num_point_features = c1
+
+    def UR_block_forward(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv):
+        """scn_unet.py:163-171.  The lateral block's second conv writes straight into the right half of the
+        concat buffer, conv_m's epilogue adds the channel-pair sums of that buffer (channel_reduction + add),
+        so cat / view-sum / add never run as separate passes."""
+        n, c = x_bottom.features.shape
+        cat = torch.empty((n, 2 * c), dtype=torch.float32, device=x_bottom.features.device)
+        cat[:, :c].copy_(x_bottom.features)
+        mid = conv_bn_act(conv_t.conv1, conv_t.bn1, x_lateral, relu=True)
+        rb = conv_t.conv2.rulebook(mid)
+        s, t = spconv.bn_scale_shift(conv_t.bn2)
+        conv_t.conv2.conv(mid, rb, scale=s, shift=t, relu=True, res_pre=x_lateral.features, out=cat[:, c:], out_ld=2 * c)
+        x = x_lateral._like(cat)
+        x = conv_bn_act(conv_m[0], conv_m[1], x, relu=True, pair=cat)
+        return conv_inv(x)
+
+    @staticmethod
+    def channel_reduction(x, out_channels):
+        """scn_unet.py:173-187 (kept for API parity; the forward fuses it into conv_m's epilogue)"""
+        n, cin = x.features.shape
+        assert cin % out_channels == 0 and cin >= out_channels
+        x.features = x.features.view(n, out_channels, -1).sum(dim=2)
+        return x
+
+    def forward(self, batch_dict):
+        if self.training:
+            raise NotImplementedError("UNetSCN3D: inference forward only (eval-mode BatchNorm); call .eval()")
+        voxel_features, voxel_coords = batch_dict["voxel_features"], batch_dict["voxel_coords"]
+        batch_size = batch_dict["batch_size"]
+        sparse_shape = np.array(batch_dict["input_shape"][::-1]) + [1, 0, 0]
+        x = spconv.SparseConvTensor(voxel_features, voxel_coords.int().contiguous(), sparse_shape, batch_size)
+        x = self.conv_input(x)
+        x_conv1 = self.conv1(x)
+        x_conv2 = self.conv2(x_conv1)
+        x_conv3 = self.conv3(x_conv2)
+        x_conv4 = self.conv4(x_conv3)
+        if self.conv_out is not None:
+            batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
+            batch_dict["encoded_spconv_tensor_stride"] = 8
+        x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4)
+        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3)
+        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2)
+        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5)
+        batch_dict["multi_scale_3d_features"] = dict(x_conv1=x_up2, x_conv2=x_up3, x_conv3=x_up4, x_conv4=x_conv4)
+        batch_dict["conv_point_features"] = x_up1.features
+        batch_dict["conv_point_coords"] = ops.voxel_centers(x_up1.indices, self.voxel_size, self.point_cloud_range)
+        return batch_dict

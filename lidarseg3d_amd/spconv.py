@@ -1,0 +1,209 @@
+"""A `spconv`-v1-shaped namespace (SparseConvTensor, SubMConv3d, SparseConv3d, SparseInverseConv3d,
+SparseSequential, SparseModule) backed by libls3d.
+
+The reference builds its backbone from third-party spconv v1.x @ fad3000 (det3d/models/backbones/scn_unet.py:3,
+15-24,34,205; docs/INSTALL.md:88-99).  Module constructor signatures, the (kD,kH,kW,Cin,Cout) weight layout
+and the `indice_key` rulebook sharing are kept so that model code written against spconv v1 and its
+checkpoints work unchanged; the arithmetic is the output-stationary gather-GEMM of csrc/spconv.hip over the
+output-major rulebooks of csrc/rulebook.hip (semantics: SURVEY.md §2.3)."""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .packing import PackedModule, pack_spconv
+
+
+def _triple(v):
+    return tuple(int(x) for x in v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+class SparseConvTensor(object):
+    """features [V,C] f32, indices [V,4] int32 (batch,z,y,x), spatial_shape (Z,Y,X), batch_size.
+    `indice_dict` is shared by reference by every tensor derived from this one (as in spconv)."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices if indices.dtype == torch.int32 else indices.int()
+        self.spatial_shape = [int(v) for v in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}
+        self.grid = grid
+
+    def _like(self, features, indices=None, spatial_shape=None):
+        t = SparseConvTensor(features, self.indices if indices is None else indices,
+                             self.spatial_shape if spatial_shape is None else spatial_shape, self.batch_size)
+        t.indice_dict = self.indice_dict
+        return t
+
+    def find_indice_pair(self, key):
+        return self.indice_dict.get(key) if key is not None else None
+
+    def dense(self, channels_first=True):
+        """scatter to a dense [B,C,Z,Y,X] (or [B,Z,Y,X,C]) tensor — torch indexing, for inspection only"""
+        b, (z, y, x) = self.batch_size, self.spatial_shape
+        out = torch.zeros((b, z, y, x, self.features.shape[1]), dtype=self.features.dtype, device=self.features.device)
+        i = self.indices.long()
+        out[i[:, 0], i[:, 1], i[:, 2], i[:, 3]] = self.features
+        return out.permute(0, 4, 1, 2, 3).contiguous() if channels_first else out
+
+
+class SparseModule(nn.Module):
+    """marker base class: SparseSequential hands these the SparseConvTensor, anything else the feature matrix"""
+
+
+class _Rulebook(object):
+    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index")
+
+
+class SparseConvolution(PackedModule, SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 fused_bn=False):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and _triple(dilation) == (1, 1, 1), "3-D, groups=1, dilation=1 only"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        self.subm, self.inverse, self.indice_key = subm, inverse, indice_key
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.weight.numel() // self.out_channels
+            nn.init.uniform_(self.bias, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+
+    def _pack(self):
+        return pack_spconv(self.weight)
+
+    # ---- rulebooks (shared through indice_key exactly like spconv's indice_dict)
+    def rulebook(self, x):
+        rb = x.find_indice_pair(self.indice_key)
+        if self.inverse:
+            assert rb is not None and rb.kind == "conv", "SparseInverseConv3d needs the rulebook of the SparseConv3d " \
+                "with indice_key=%r" % (self.indice_key,)
+            return rb
+        if rb is not None and self.subm:
+            return rb
+        rb = _Rulebook()
+        rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)
+        if self.subm:
+            rb.kind = "subm"
+            rb.tbl = ops.rulebook_subm(x.indices, x.spatial_shape, self.kernel_size)
+            rb.out_indices, rb.out_shape, rb.tbl_inv = x.indices, list(x.spatial_shape), None
+        else:
+            rb.kind = "conv"
+            oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape,
+                                                                   self.kernel_size, self.stride, self.padding)
+            n_out, overflow = (int(v) for v in cnt.tolist())  # host sync: tensor shapes need the count
+            assert not overflow
+            rb.out_indices, rb.out_shape = oc[:n_out], oshape
+            rb.tbl, rb.tbl_inv = nbr_out[:n_out], nbr_inv
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = rb
+        return rb
+
+    def conv(self, x, rb, scale=None, shift=None, relu=False, res_pre=None, pair=None, out=None, out_ld=None):
+        """the gather-GEMM with a fused epilogue; x: SparseConvTensor or a feature matrix on rb's input sites"""
+        feats = x.features if isinstance(x, SparseConvTensor) else x
+        W, _, _, cout = self.packed()
+        if self.bias is not None:
+            b = self.bias.detach()
+            shift = b if shift is None else shift + (b * (scale if scale is not None else 1.0))
+        tbl = rb.tbl_inv if self.inverse else rb.tbl
+        if feats.shape[1] != W.shape[1]:  # e.g. 13 input channels feeding a 16-wide K chunk
+            feats = torch.nn.functional.pad(feats, (0, W.shape[1] - feats.shape[1]))
+        return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, cout=cout, scale=scale, shift=shift, relu=relu,
+                               res_pre=res_pre, pair=pair, out=out, out_ld=out_ld)
+
+    def forward(self, x):
+        rb = self.rulebook(x)
+        f = self.conv(x, rb)
+        if self.inverse:
+            return x._like(f, rb.in_indices, rb.in_shape)
+        return x._like(f, rb.out_indices, rb.out_shape)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, **kw):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, subm=True,
+                         indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, **kw):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, **kw):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)
+
+
+class SparseSequential(SparseModule):
+    """spconv.SparseSequential: sparse modules get the tensor, plain modules get `.features` (only when the
+    tensor is non-empty).  The pattern (sparse conv, BatchNorm1d[, ReLU]) in eval mode is fused into the conv's
+    epilogue instead of running BN/ReLU as separate passes."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], dict):
+            for k, m in args[0].items():
+                self.add_module(k, m)
+        else:
+            for i, m in enumerate(args):
+                self.add_module(str(i), m)
+        for k, m in kwargs.items():
+            self.add_module(k, m)
+
+    def __getitem__(self, i):
+        return list(self._modules.values())[i]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, SparseConvolution) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) \
+                    and not mods[i + 1].training:
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                x = conv_bn_act(m, mods[i + 1], x, relu=relu)
+                i += 3 if relu else 2
+            elif isinstance(m, SparseModule):
+                x = m(x)
+                i += 1
+            else:
+                if x.indices.shape[0] != 0:
+                    x.features = m(x.features)
+                i += 1
+        return x
+
+
+def bn_scale_shift(bn):
+    s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    t = bn.bias.detach().double() - bn.running_mean.detach().double() * s
+    return s.float().contiguous(), t.float().contiguous()
+
+
+def conv_bn_act(conv, bn, x, relu=True, res_pre=None, pair=None):
+    """SparseSequential(conv, BN(eval), ReLU) as ONE kernel launch"""
+    cache = conv.__dict__.setdefault("_bn_cache", {})
+    key = (id(bn), bn.weight._version, bn.running_var._version, bn.weight.data_ptr())
+    if cache.get("key") != key:
+        cache["key"], cache["ss"] = key, bn_scale_shift(bn)
+    scale, shift = cache["ss"]
+    rb = conv.rulebook(x)
+    f = conv.conv(x, rb, scale=scale, shift=shift, relu=relu, res_pre=res_pre, pair=pair)
+    if conv.inverse:
+        return x._like(f, rb.in_indices, rb.in_shape)
+    return x._like(f, rb.out_indices, rb.out_shape)

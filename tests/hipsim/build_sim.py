@@ -1,0 +1,31 @@
+"""Host build of the kernel sources against tests/hipsim (TEST INFRASTRUCTURE ONLY — see hip_runtime.h there).
+Produces tests/hipsim/libls3d_sim.so with the same C ABI; only tests load it, explicitly."""
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "lidarseg3d_amd", "csrc")
+LIB = os.path.join(HERE, "libls3d_sim.so")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build(force=False):
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "*.cpp")) + \
+        glob.glob(os.path.join(HERE, "hip", "*.h")) + [os.path.join(ROOT, "include", "ls3d.h")]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return LIB
+    objs = []
+    for s in srcs + [os.path.join(HERE, "hipsim.cpp")]:
+        o = os.path.join(HERE, os.path.basename(s) + ".o")
+        subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-Wno-psabi",
+                               "-Wno-unused-value", "-I", HERE, "-c", s, "-o", o])
+        objs.append(o)
+    subprocess.check_call([CLANG, "-shared", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,211 @@
+// tests/hipsim/hipsim.cpp — fiber scheduler behind tests/hipsim/hip/hip_runtime.h (TEST INFRASTRUCTURE ONLY).
+#include <hip/hip_runtime.h>
+
+uint3_ threadIdx, blockIdx;
+dim3 blockDim, gridDim;
+
+// minimal x86-64 SysV context switch (callee-saved registers + stack pointer); ~50x cheaper than
+// swapcontext(), which makes a sigprocmask system call per switch.
+extern "C" void hipsim_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl hipsim_switch
+.type hipsim_switch,@function
+hipsim_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipsim_switch,.-hipsim_switch
+)");
+
+namespace hipsim {
+std::vector<Fiber> fibers;
+void *sched_sp = nullptr;
+int cur = 0;
+static uint64_t xstore[16][4][64];  // [wave][slot][lane]
+int bar_acc = 0;
+static const std::function<void()> *body_fn = nullptr;
+static const size_t STACK = 256 * 1024;
+
+uint64_t *wslot(int slot) { return xstore[wave()][slot]; }
+
+static void trampoline() {
+  (*body_fn)();
+  fibers[cur].wait = DONE;
+  hipsim_switch(&fibers[cur].sp, sched_sp);
+  abort();  // a finished fiber is never resumed
+}
+
+void yield_wait(int kind) {
+  fibers[cur].wait = kind;
+  hipsim_switch(&fibers[cur].sp, sched_sp);
+}
+
+void wave_barrier() { yield_wait(WAVE_BAR); }
+
+static void resume(int i) {
+  cur = i;
+  threadIdx = fibers[i].tid;
+  fibers[i].wait = RUN;
+  hipsim_switch(&sched_sp, fibers[i].sp);
+}
+
+static void run_block(int nthreads) {
+  if ((int)fibers.size() < nthreads) fibers.resize(nthreads);
+  for (int i = 0; i < nthreads; ++i) {
+    Fiber &f = fibers[i];
+    if (!f.stack) f.stack = (char *)malloc(STACK);
+    uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+    void **sp = (void **)top;
+    *--sp = nullptr;               // fake return address of trampoline
+    *--sp = (void *)trampoline;    // `ret` of the first switch jumps here
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
+    f.sp = (void *)sp;
+    f.tid.x = i % blockDim.x;
+    f.tid.y = (i / blockDim.x) % blockDim.y;
+    f.tid.z = i / (blockDim.x * blockDim.y);
+    f.wait = RUN;
+  }
+  // first pass: start every fiber
+  for (int i = 0; i < nthreads; ++i) resume(i);
+  int nwaves = (nthreads + 63) / 64;
+  for (;;) {
+    bool progress = false, all_done = true;
+    // wave barriers
+    for (int w = 0; w < nwaves; ++w) {
+      int lo = w * 64, hi = std::min(nthreads, lo + 64);
+      int waiting = 0, live = 0;
+      for (int i = lo; i < hi; ++i) {
+        if (fibers[i].wait != DONE) ++live;
+        if (fibers[i].wait == WAVE_BAR) ++waiting;
+      }
+      if (live && waiting == live) {
+        for (int i = lo; i < hi; ++i)
+          if (fibers[i].wait == WAVE_BAR) resume(i);
+        progress = true;
+      }
+    }
+    int live = 0, atbar = 0;
+    for (int i = 0; i < nthreads; ++i) {
+      if (fibers[i].wait != DONE) { ++live; all_done = false; }
+      if (fibers[i].wait == BLOCK_BAR) ++atbar;
+    }
+    if (all_done) break;
+    if (live && atbar == live) {
+      for (int i = 0; i < nthreads; ++i)
+        if (fibers[i].wait == BLOCK_BAR) resume(i);
+      progress = true;
+    }
+    if (!progress) {
+      fprintf(stderr, "hipsim: DEADLOCK in block (%u,%u,%u): divergent barrier/collective\n", blockIdx.x, blockIdx.y, blockIdx.z);
+      for (int i = 0; i < nthreads; ++i) fprintf(stderr, "%d", fibers[i].wait);
+      fprintf(stderr, "\n");
+      abort();
+    }
+  }
+}
+
+void run_grid(dim3 grid, dim3 block, const std::function<void()> &body) {
+  body_fn = &body;
+  gridDim = grid;
+  blockDim = block;
+  int nthreads = block.x * block.y * block.z;
+  if (nthreads > 1024) { fprintf(stderr, "hipsim: block too large\n"); abort(); }
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) {
+        blockIdx.x = x; blockIdx.y = y; blockIdx.z = z;
+        run_block(nthreads);
+      }
+  body_fn = nullptr;
+}
+}  // namespace hipsim
+
+int __syncthreads_or(int pred) {
+  static int acc;
+  if (pred) acc = 1;
+  __syncthreads();
+  int r = acc;
+  __syncthreads();
+  if (hipsim::cur == 0) acc = 0;
+  __syncthreads();
+  return r;
+}
+
+int __syncthreads_count(int pred) {
+  static int acc;
+  if (pred) acc += 1;
+  __syncthreads();
+  int r = acc;
+  __syncthreads();
+  if (hipsim::cur == 0) acc = 0;
+  __syncthreads();
+  return r;
+}
+
+unsigned long long __ballot(int pred) {
+  uint64_t *row = hipsim::wslot(1);
+  row[hipsim::lane()] = pred ? 1 : 0;
+  // lanes that already exited must read as 0: clear is done by the first arriving lane of each op,
+  // so instead gather only over lanes that wrote in this round using a round tag
+  static uint64_t tag[16][64];
+  static uint64_t round[16];
+  int w = hipsim::wave();
+  uint64_t my = round[w] + 1;
+  tag[w][hipsim::lane()] = my;
+  hipsim::wave_barrier();
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if (tag[w][l] == my && row[l]) m |= 1ull << l;
+  hipsim::wave_barrier();
+  round[w] = my;
+  return m;
+}
+
+int __all(int p) {
+  uint64_t *row = hipsim::wslot(2);
+  static uint64_t tag[16][64];
+  static uint64_t round[16];
+  int w = hipsim::wave();
+  uint64_t my = round[w] + 1;
+  tag[w][hipsim::lane()] = my;
+  row[hipsim::lane()] = p ? 1 : 0;
+  hipsim::wave_barrier();
+  int ok = 1;
+  for (int l = 0; l < 64; ++l)
+    if (tag[w][l] == my && !row[l]) ok = 0;
+  hipsim::wave_barrier();
+  round[w] = my;
+  return ok;
+}
+
+hipsim_f32x16 hipsim_mfma_32x32x2f32(float a, float b, hipsim_f32x16 c, int, int, int) {
+  static float A[16][32][2], B[16][2][32];
+  int w = hipsim::wave(), l = hipsim::lane();
+  A[w][l & 31][l >> 5] = a;
+  B[w][l >> 5][l & 31] = b;
+  hipsim::wave_barrier();
+  hipsim_f32x16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    acc = fmaf(A[w][row][0], B[w][0][col], acc);
+    acc = fmaf(A[w][row][1], B[w][1][col], acc);
+    d[r] = acc;
+  }
+  hipsim::wave_barrier();
+  return d;
+}

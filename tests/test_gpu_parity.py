@@ -1,0 +1,212 @@
+"""Parity of the HIP path (through the C ABI, on a real MI355X) against the CPU oracle and the golden vectors
+generated from the reference.  Integer / index outputs bit-exact; float outputs within the stated tolerance."""
+import numpy as np
+import pytest
+import torch
+
+import lidarseg3d_amd as L
+from lidarseg3d_amd import models_cfg, ops, point_heads, readers, scn_unet, synth
+from oracle import ref as orc
+from tests.util import golden, seeded_sd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def cu(a):
+    return torch.as_tensor(a).to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["nusc", "nusc_cap", "kitti"])
+def test_hard_voxelize_bit_exact(tag):
+    g = golden("voxelize_%s.npz" % tag)
+    mv = int(g["max_voxels"])
+    for mode, pre in (("numba", "numba"), ("break", "cpp_hard")):
+        v, c, n, nv = ops.voxelize_hard(cu(g["points"]), g["voxel_size"], g["pc_range"], 5, mv, overflow=mode)
+        V = int(nv)
+        assert V == g[pre + "_coors"].shape[0]
+        assert np.array_equal(c[:V].cpu().numpy(), g[pre + "_coors"])
+        assert np.array_equal(n[:V].cpu().numpy(), g[pre + "_num"])
+        assert np.array_equal(v[:V].cpu().numpy(), g[pre + "_voxels"])
+    d = ops.voxelize_dynamic(cu(g["points"]), g["voxel_size"], g["pc_range"])
+    assert np.array_equal(d.cpu().numpy(), g["cpp_dyn_coors"])
+
+
+def test_hard_voxelize_120k_vs_oracle_and_batched():
+    cfg = synth.NUSC
+    frames = [synth.lidar_frame(120000, seed=3, **cfg), synth.lidar_frame(34720, seed=4, **cfg)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    v, c, n, nv = ops.voxelize_hard(cu(pts), cfg["voxel_size"], cfg["pc_range"], 5, 600000, batched=True)
+    V = int(nv)
+    want = orc.collate_frames(frames, cfg["voxel_size"], cfg["pc_range"], 5, 300000)
+    assert V == want["coordinates"].shape[0]
+    assert torch.equal(c[:V].cpu(), want["coordinates"]) and torch.equal(n[:V].cpu(), want["num_points"])
+    assert torch.equal(v[:V].cpu(), want["voxels"])
+    # size-independent properties: every in-range point's voxel exists exactly once
+    key = (c[:V, 0].long() * 41 + c[:V, 1]) * 1024 * 1024 + c[:V, 2].long() * 1024 + c[:V, 3]
+    assert key.unique().numel() == V
+    assert int(n[:V].min()) >= 1 and int(n[:V].max()) <= 5
+
+
+@pytest.mark.parametrize("tag", ["nusc", "kitti"])
+def test_dynamic_scatter(tag):
+    g = golden("voxelize_%s.npz" % tag)
+    gs = orc.grid_size(g["voxel_size"], g["pc_range"])
+    shape = [int(gs[2]), int(gs[1]), int(gs[0])]
+    f, vc, p2v, nv = ops.dynamic_scatter(cu(g["points"]), cu(g["cpp_dyn_coors"]), shape, "mean")
+    V = int(nv)
+    assert np.array_equal(vc[:V].cpu().numpy(), g["cpp_scatter_coors"])
+    want = torch.from_numpy(g["cpp_scatter_voxels"]).sum(1) / torch.from_numpy(g["cpp_scatter_num"]).float()[:, None]
+    np.testing.assert_allclose(f[:V].cpu().numpy(), want.numpy(), rtol=2e-6, atol=1e-6)
+    f, _, _, _ = ops.dynamic_scatter(cu(g["points"]), cu(g["cpp_dyn_coors"]), shape, "max")
+    np.testing.assert_array_equal(f[:V].cpu().numpy(), g["cpp_scatter_voxels"].max(1))
+
+
+def test_vfe_readers():
+    g = golden("vfe_nusc.npz")
+    vx, num = cu(g["voxels"]), cu(g["num"])
+    np.testing.assert_allclose(readers.MeanVoxelFeatureExtractor(5)(vx, num).cpu().numpy(), g["mean"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(readers.ImprovedMeanVoxelFeatureExtractor(5)(vx, num).cpu().numpy(), g["improved"], rtol=0, atol=1e-5)
+    tv = readers.TransformerVoxelFeatureExtractor(5, 16, 64, 4, 3)
+    tv.load_state_dict(seeded_sd("reader.TransformerVoxelFeatureExtractor", g["trans_seed"]), strict=True)
+    out = tv.to(DEV).eval()(vx, num)
+    np.testing.assert_allclose(out.cpu().numpy(), g["trans"], rtol=0, atol=1e-4)
+
+
+def test_gather_gemm_layout_asymmetric():
+    """transpose-detecting check of the MFMA fragment layout: C = A B with asymmetric random A, B"""
+    rng = np.random.default_rng(0)
+    for m, k, n in ((200, 16, 17), (333, 48, 64), (1000, 128, 96), (129, 256, 192)):
+        a = rng.normal(size=(m, k)).astype(np.float32)
+        b = rng.normal(size=(k, n)).astype(np.float32)
+        W = torch.zeros((1, k, (n + 31) // 32 * 32))
+        W[0, :, :n] = torch.from_numpy(b)
+        out = ops.gather_gemm(cu(a), W.to(DEV), cout=n)
+        np.testing.assert_allclose(out.cpu().numpy(), a.astype(np.float64) @ b.astype(np.float64), rtol=0, atol=2e-4)
+
+
+def test_rulebooks_bit_exact_and_unet_vs_golden():
+    cfg = synth.NUSC
+    for tag in ("c13", "c16"):
+        g = golden("unet_nusc_%s.npz" % tag)
+        sd = seeded_sd("backbone.UNetSCN3D.%s" % tag, g["seed"])
+        net = scn_unet.UNetSCN3D(num_input_features=int(tag[1:]), voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
+                                 model_cfg=dict(SCALING_RATIO=2), ds_factor=8, us_factor=8)
+        net.load_state_dict(sd, strict=True)
+        net.to(DEV).eval()
+        bd = net(dict(voxel_features=cu(g["voxel_features"]), voxel_coords=cu(g["coords"]), batch_size=1,
+                      input_shape=np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))))
+        got = bd["conv_point_features"].cpu().numpy()
+        scale = np.abs(g["conv_point_features"]).max()
+        np.testing.assert_allclose(got, g["conv_point_features"], rtol=0, atol=1e-3 + 2e-5 * scale)
+        if tag == "c13":
+            ms = bd["multi_scale_3d_features"]
+            np.testing.assert_array_equal(bd["conv_point_coords"].cpu().numpy(), g["conv_point_coords"])
+            np.testing.assert_array_equal(ms["x_conv4"].indices.cpu().numpy(), g["x_conv4_indices"])
+            np.testing.assert_array_equal(ms["x_conv3"].indices.cpu().numpy(), g["x_up4_indices"])
+            np.testing.assert_array_equal(ms["x_conv2"].indices.cpu().numpy(), g["x_up3_indices"])
+            np.testing.assert_array_equal(bd["encoded_spconv_tensor"].indices.cpu().numpy(), g["enc_indices"])
+            rb = orc.UNetRulebooks(g["coords"], orc.spatial_shape(cfg["voxel_size"], cfg["pc_range"]))
+            x = next(iter(ms.values()))
+            d = x.indice_dict
+            for key, want in (("subm1", rb.subm1), ("subm2", rb.subm2), ("subm3", rb.subm3), ("subm4", rb.subm4),
+                              ("spconv2", rb.down2), ("spconv3", rb.down3), ("spconv4", rb.down4)):
+                np.testing.assert_array_equal(d[key].tbl.cpu().numpy(), want)
+
+
+def test_three_nn_exact_and_devoxelize():
+    g = golden("head_batchloss_nusc.npz")
+    pts, ctr, feat = g["points"], g["conv_point_coords"], g["conv_point_features"]
+    d2, idx = ops.three_nn(cu(pts[None, :, 1:4].copy()), cu(ctr[None, :, 1:4].copy()))
+    wd2, widx = orc.three_nn(pts[:, 1:4], ctr[:, 1:4])
+    assert np.array_equal(idx[0].cpu().numpy(), widx)
+    assert np.array_equal(d2[0].cpu().numpy(), wd2)
+    p = cu(pts[:, :4].copy())
+    c = cu(ctr)
+    out, didx = ops.devoxelize(p, ops.frame_offsets(p[:, 0], 1), c, ops.frame_offsets(c[:, 0], 1), 1, p.shape[0], cu(feat),
+                               return_idx=True)
+    assert np.array_equal(didx.cpu().numpy(), widx)
+    want = orc.three_interpolate_wrap(torch.from_numpy(pts[:, :4]), torch.from_numpy(ctr), torch.from_numpy(feat), 1)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5 * np.abs(feat).max())
+    # few known points: missing neighbours keep index 0 / +inf
+    d2, idx = ops.three_nn(cu(pts[None, :50, 1:4].copy()), cu(ctr[None, :2, 1:4].copy()))
+    wd2, widx = orc.three_nn(pts[:50, 1:4], ctr[:2, 1:4])
+    assert np.array_equal(idx[0].cpu().numpy(), widx) and np.array_equal(d2[0].cpu().numpy(), wd2)
+
+
+def test_batchloss_head_vs_golden():
+    g = golden("head_batchloss_nusc.npz")
+    head = point_heads.PointSegBatchlossHead(False, 17, dict(CONV_IN_DIM=32, CONV_CLS_FC=[64], CONV_ALIGN_DIM=64,
+                                                              OUT_CLS_FC=[64, 64], IGNORED_LABEL=0))
+    head.load_state_dict(seeded_sd("point_head.PointSegBatchlossHead", g["seed"]), strict=True)
+    head.to(DEV).eval()
+    bd = head(dict(batch_size=1, conv_point_features=cu(g["conv_point_features"]), conv_point_coords=cu(g["conv_point_coords"]),
+                   points=cu(g["points"][:, :4].copy())), return_loss=False)
+    scale = np.abs(g["out_logits"]).max()
+    np.testing.assert_allclose(bd["out_logits"].cpu().numpy(), g["out_logits"], rtol=0, atol=1e-3 + 2e-5 * scale)
+    np.testing.assert_allclose(head.forward_ret_dict["conv_logits"].cpu().numpy(), g["conv_logits"], rtol=0,
+                               atol=1e-3 + 2e-5 * np.abs(g["conv_logits"]).max())
+
+
+def test_mseg3d_head_vs_golden():
+    g = golden("head_mseg3d_nusc.npz")
+    mcfg = models_cfg.mseg3d()["point_head"]["model_cfg"]
+    head = point_heads.PointSegMSeg3DHead(False, 17, mcfg)
+    head.load_state_dict(seeded_sd("point_head.PointSegMSeg3DHead", g["seed"]), strict=True)
+    head.to(DEV).eval()
+    pts = g["points"]
+    h, w = (int(v) for v in g["cam_hw"])
+    img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=int(g["cam_seed"]), ncam=6, c_img=48, h=h, w=w, batch=2)
+    bd = head(dict(batch_size=2, conv_point_features=cu(g["conv_point_features"]), conv_point_coords=cu(g["conv_point_coords"]),
+                   points=cu(pts[:, :4].copy()), image_features=cu(img), points_cuv=cu(cuv),
+                   camera_semantic_embeddings=cu(emb)), return_loss=False)
+    np.testing.assert_allclose(head.forward_ret_dict["voxel_logits"].cpu().numpy(), g["voxel_logits"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(bd["out_logits"].cpu().numpy(), g["out_logits"], rtol=0, atol=1e-3)
+
+
+def _model(cfg, seed=5):
+    model = L.build_detector(cfg, train_cfg=None, test_cfg={}).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, seed).items()}
+    model.load_state_dict(sd)
+    return model.to(DEV), sd
+
+
+def test_sdseg3d_end_to_end_vs_oracle():
+    """points -> logits on the GPU vs the CPU oracle, two ragged frames (one tiny)"""
+    cfg = synth.NUSC
+    model, sd = _model(models_cfg.sdseg3d())
+    frames = [synth.lidar_frame(20000, seed=1, **cfg), synth.lidar_frame(700, seed=2, **cfg)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    ret = model(dict(points=cu(pts), batch_size=2), return_loss=False)
+    got = model.point_head.forward_ret_dict["out_logits"].cpu()
+    want = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])
+    scale = float(want["out_logits"].abs().max())
+    err = float((got - want["out_logits"]).abs().max())
+    assert err <= 1e-3 + 2e-5 * scale, (err, scale)
+    pred = torch.cat([r["pred_point_sem_labels"].cpu() for r in ret])
+    ref = want["out_logits"].argmax(1)
+    assert float((pred == ref).float().mean()) >= 0.999
+    assert orc.miou(pred.numpy(), ref.numpy(), 17) >= 0.999  # "mIoU parity" of GPU argmax vs oracle argmax
+
+
+def test_sdseg3d_120k_properties():
+    """full BASELINE size: determinism, finiteness, frame-permutation invariance of per-frame results"""
+    cfg = synth.NUSC
+    model, _ = _model(models_cfg.sdseg3d())
+    f0, f1 = synth.lidar_frame(120000, seed=7, **cfg), synth.lidar_frame(60000, seed=8, **cfg)
+
+    def run(frames):
+        pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+        model(dict(points=cu(pts), batch_size=len(frames)), return_loss=False)
+        return model.point_head.forward_ret_dict["out_logits"].cpu()
+
+    a = run([f0])
+    assert torch.isfinite(a).all() and a.shape == (120000, 17)
+    assert torch.equal(a, run([f0]))  # no atomics on the float path: bit-reproducible
+    ab = run([f0, f1])
+    ba = run([f1, f0])
+    scale = float(a.abs().max())
+    assert float((ab[:120000] - a).abs().max()) <= 1e-3 + 2e-5 * scale
+    assert float((ba[60000:] - a).abs().max()) <= 1e-3 + 2e-5 * scale
+    assert float((ba[:60000] - ab[120000:]).abs().max()) <= 1e-3 + 2e-5 * scale
