@@ -213,6 +213,19 @@ int ls3d_devoxelize(const float *points, int pt_stride, int n_points, const int3
                     const float *feat, int feat_ld, int c, float *out, int out_ld, int32_t *idx_out,
                     ls3d_stream_t stream);
 
+size_t ls3d_devoxelize_grid_workspace_bytes(int n_voxels, int batch, const int32_t grid_xyz_host[3]);
+
+/* Same result as ls3d_devoxelize (bit-identical neighbours and weights) when the known points are voxel
+ * centres on a regular lattice: the centres are binned into coarse cells (counting sort) and each point
+ * searches expanding shells of coarse cells with an exact stopping bound, instead of scanning every centre
+ * (the reference kernel is O(N*V), interpolate_gpu.cu:36-57).  coords[V,4] = integer (batch,z,y,x) of the
+ * centres, centers[V,4] as written by ls3d_voxel_centers, grid_xyz = fine cells per axis. */
+int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *coords, const float *centers,
+                         int n_voxels, const int32_t *n_voxels_dev, const int32_t *vx_off /*[batch+1] dev*/, int batch,
+                         const float vs_host[3], const float lo_host[3], const int32_t grid_xyz_host[3], const float *feat,
+                         int feat_ld, int c, float *out, int out_ld, int32_t *idx_out, void *workspace,
+                         size_t workspace_bytes, ls3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LiDAR-camera fusion (MSeg3D point head)
  * ---------------------------------------------------------------------------------------------- */

@@ -160,6 +160,199 @@ __global__ __launch_bounds__(256) void k_devoxelize(const float *points, int pt_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Exact 3-NN through a coarse uniform grid over the voxel centres.
+// Voxel centres live on the voxel lattice, so they are binned into coarse cells of CGX x CGY x CGZ fine
+// voxels (counting sort: count -> exclusive scan -> fill).  A point visits the coarse cells around its own
+// in Chebyshev shells r = 0,1,2,...; after shell r every unvisited centre is at least
+//     lb(r) = min_axis( gap_axis + r * cell_size_axis )
+// away (gap = distance from the point to the nearer face of its own coarse cell, 0 if it lies outside), so
+// the search stops as soon as the 3rd best squared distance is strictly below lb^2 (with a 1e-5 safety
+// margin for f32 rounding).  Candidates are compared with the same f32 expression as the brute-force kernel
+// and ordered lexicographically by (distance, index), which yields exactly the brute-force result
+// (strict '<' in ascending index order == smallest index among equal distances).  Points far outside the
+// range simply walk more shells: always exact, no fallback path.
+#define CGX 8
+#define CGY 8
+#define CGZ 4
+
+struct CGeom {
+  float vs[3], lo[3];
+  int grid[3];  // fine cells x,y,z
+  int dim[3];   // coarse cells x,y,z
+};
+
+__device__ __forceinline__ void top3_push_lex(Top3 &t, float d, int k) {
+  if (d < t.d2 || (d == t.d2 && k < t.i2)) {
+    if (d < t.d0 || (d == t.d0 && k < t.i0)) { t.d2 = t.d1; t.i2 = t.i1; t.d1 = t.d0; t.i1 = t.i0; t.d0 = d; t.i0 = k; }
+    else if (d < t.d1 || (d == t.d1 && k < t.i1)) { t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = k; }
+    else { t.d2 = d; t.i2 = k; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cg_count(const int32_t *coords, int n, const int32_t *n_dev, CGeom g, int32_t *cell_of, int32_t *cnt) {
+  const int N = ls3d_count(n, n_dev);
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
+    const int32_t *c = coords + 4 * (size_t)v;
+    const int cz = min(c[1] / CGZ, g.dim[2] - 1), cy = min(c[2] / CGY, g.dim[1] - 1), cx = min(c[3] / CGX, g.dim[0] - 1);
+    const int cell = ((c[0] * g.dim[2] + cz) * g.dim[1] + cy) * g.dim[0] + cx;
+    cell_of[v] = cell;
+    atomicAdd(&cnt[cell], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cg_fill(const float *centers, int n, const int32_t *n_dev, const int32_t *vx_off, const int32_t *cell_of,
+                                                const int32_t *start, int32_t *cursor, float4 *sorted) {
+  const int N = ls3d_count(n, n_dev);
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
+    const int cell = cell_of[v];
+    const int pos = start[cell] + atomicAdd(&cursor[cell], 1);
+    const float *c = centers + 4 * (size_t)v;
+    const int f = (int)c[0];
+    sorted[pos] = make_float4(c[1], c[2], c[3], __int_as_float(v - vx_off[f]));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_stride, int n, CGeom g, const int32_t *start, const float4 *sorted,
+                                                   const int32_t *vx_off, const float *feat, int feat_ld, int C, float *out, int out_ld,
+                                                   int32_t *idx_out) {
+  __shared__ int s_idx[256 * 3];
+  __shared__ float s_w[256 * 3];
+  __shared__ int s_base[256];
+  const int first = blockIdx.x * 256;
+  const int i = first + threadIdx.x;
+  const bool active = i < n;
+  Top3 t;
+  top3_init(t);
+  int frame = 0;
+  if (active) {
+    const float *u = points + (size_t)i * pt_stride;
+    frame = (int)u[0];
+    const float ux = u[1], uy = u[2], uz = u[3];
+    // own coarse cell (fine coordinate as in voxelization, clamped into the grid)
+    int fc[3];
+    float gap[3];
+    const float pu[3] = {ux, uy, uz};
+    const int cgs[3] = {CGX, CGY, CGZ};
+    int cc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float fcoord = floorf(__fdiv_rn(__fsub_rn(pu[a], g.lo[a]), g.vs[a]));
+      fcoord = fminf(fmaxf(fcoord, 0.0f), (float)(g.grid[a] - 1));
+      fc[a] = (int)fcoord;
+      cc[a] = min(fc[a] / cgs[a], g.dim[a] - 1);
+      const float cs = g.vs[a] * (float)cgs[a];
+      const float clo = g.lo[a] + cs * (float)cc[a];
+      // the last coarse cell of an axis may hold more fine cells than CG*: use its true upper face
+      const float chi = (cc[a] == g.dim[a] - 1) ? g.lo[a] + g.vs[a] * (float)g.grid[a] : clo + cs;
+      gap[a] = fmaxf(fminf(pu[a] - clo, chi - pu[a]), 0.0f);
+    }
+    const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
+    for (int r = 0; r <= rmax; ++r) {
+      const int z0 = max(cc[2] - r, 0), z1 = min(cc[2] + r, g.dim[2] - 1);
+      const int y0 = max(cc[1] - r, 0), y1 = min(cc[1] + r, g.dim[1] - 1);
+      const int x0 = max(cc[0] - r, 0), x1 = min(cc[0] + r, g.dim[0] - 1);
+      for (int z = z0; z <= z1; ++z) {
+        const bool zs = (z == cc[2] - r) || (z == cc[2] + r);
+        for (int y = y0; y <= y1; ++y) {
+          const bool ys = zs || (y == cc[1] - r) || (y == cc[1] + r);
+          const int step = (ys || r == 0) ? 1 : max(x1 - x0, 1);  // interior rows: only the two end cells can be on the shell
+          for (int x = x0; x <= x1; x += step) {
+            if (!ys && x != cc[0] - r && x != cc[0] + r) continue;
+            const int cell = ((frame * g.dim[2] + z) * g.dim[1] + y) * g.dim[0] + x;
+            const int s0 = start[cell], s1 = start[cell + 1];
+            for (int j = s0; j < s1; ++j) {
+              const float4 q = sorted[j];
+              const float dx = ux - q.x, dy = uy - q.y, dz = uz - q.z;
+              const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+              top3_push_lex(t, d, __float_as_int(q.w));
+            }
+          }
+        }
+      }
+      // lower bound on the distance to anything outside the visited box
+      const float lb = fminf(gap[0] + (float)r * g.vs[0] * CGX, fminf(gap[1] + (float)r * g.vs[1] * CGY, gap[2] + (float)r * g.vs[2] * CGZ));
+      if (t.d2 < lb * lb * 0.99999f) break;
+      if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1) break;  // whole grid seen
+    }
+  }
+  const float r0 = __fdiv_rn(1.0f, sqrtf(t.d0) + 1e-8f), r1 = __fdiv_rn(1.0f, sqrtf(t.d1) + 1e-8f), r2 = __fdiv_rn(1.0f, sqrtf(t.d2) + 1e-8f);
+  const float norm = (r0 + r1) + r2;
+  s_idx[threadIdx.x * 3 + 0] = t.i0; s_idx[threadIdx.x * 3 + 1] = t.i1; s_idx[threadIdx.x * 3 + 2] = t.i2;
+  s_w[threadIdx.x * 3 + 0] = __fdiv_rn(r0, norm); s_w[threadIdx.x * 3 + 1] = __fdiv_rn(r1, norm); s_w[threadIdx.x * 3 + 2] = __fdiv_rn(r2, norm);
+  s_base[threadIdx.x] = active ? vx_off[frame] : 0;
+  if (active && idx_out) {
+    int32_t *q = idx_out + (size_t)i * 3;
+    q[0] = t.i0; q[1] = t.i1; q[2] = t.i2;
+  }
+  __syncthreads();
+  const int cnt = min(256, n - first);
+  const int c4n = C >> 2;
+  for (int e = threadIdx.x; e < cnt * c4n; e += 256) {
+    const int p = e / c4n, c4 = e % c4n;
+    const int v0 = s_base[p];
+    const float w0 = s_w[p * 3], w1 = s_w[p * 3 + 1], w2 = s_w[p * 3 + 2];
+    const float4 a = *(const float4 *)(feat + (size_t)(v0 + s_idx[p * 3]) * feat_ld + c4 * 4);
+    const float4 b = *(const float4 *)(feat + (size_t)(v0 + s_idx[p * 3 + 1]) * feat_ld + c4 * 4);
+    const float4 c = *(const float4 *)(feat + (size_t)(v0 + s_idx[p * 3 + 2]) * feat_ld + c4 * 4);
+    float4 o;
+    o.x = fmaf(w2, c.x, fmaf(w1, b.x, w0 * a.x));
+    o.y = fmaf(w2, c.y, fmaf(w1, b.y, w0 * a.y));
+    o.z = fmaf(w2, c.z, fmaf(w1, b.z, w0 * a.z));
+    o.w = fmaf(w2, c.w, fmaf(w1, b.w, w0 * a.w));
+    *(float4 *)(out + (size_t)(first + p) * out_ld + c4 * 4) = o;
+  }
+}
+
+static inline size_t dv_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static void cg_dims(const int32_t grid_xyz[3], int dim[3]) {
+  const int cgs[3] = {CGX, CGY, CGZ};
+  for (int a = 0; a < 3; ++a) { dim[a] = grid_xyz[a] / cgs[a]; if (dim[a] < 1) dim[a] = 1; }
+}
+
+extern "C" size_t ls3d_devoxelize_grid_workspace_bytes(int n_voxels, int batch, const int32_t grid_xyz[3]) {
+  int dim[3];
+  cg_dims(grid_xyz, dim);
+  const long long ncell = (long long)batch * dim[0] * dim[1] * dim[2];
+  return dv_align((size_t)(n_voxels > 0 ? n_voxels : 1) * 4) + 3 * dv_align((size_t)(ncell + 1) * 4) + dv_align(ls3d_scan_tmp_ints(ncell + 1) * 4) +
+         dv_align((size_t)(n_voxels > 0 ? n_voxels : 1) * 16);
+}
+
+extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *coords, const float *centers,
+                                    int n_voxels, const int32_t *n_voxels_dev, const int32_t *vx_off, int batch, const float vs[3],
+                                    const float lo[3], const int32_t grid_xyz[3], const float *feat, int feat_ld, int c, float *out,
+                                    int out_ld, int32_t *idx_out, void *workspace, size_t workspace_bytes, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!points || !coords || !centers || !vx_off || !vs || !lo || !grid_xyz || !feat || !out || !workspace || batch < 1 || pt_stride < 4)
+    return LS3D_ERR_ARG;
+  if ((c % 4) || (feat_ld % 4) || (out_ld % 4) || feat_ld < c || out_ld < c || n_voxels < 1) return LS3D_ERR_ARG;
+  if (workspace_bytes < ls3d_devoxelize_grid_workspace_bytes(n_voxels, batch, grid_xyz)) return LS3D_ERR_WORKSPACE;
+  if (n_points == 0) return LS3D_OK;
+  CGeom g;
+  for (int a = 0; a < 3; ++a) { g.vs[a] = vs[a]; g.lo[a] = lo[a]; g.grid[a] = grid_xyz[a]; }
+  cg_dims(grid_xyz, g.dim);
+  const long long ncell = (long long)batch * g.dim[0] * g.dim[1] * g.dim[2];
+  if (ncell + 1 > 0x7FFFFFFFLL) return LS3D_ERR_UNSUPPORTED;
+  char *base = (char *)workspace;
+  int32_t *cell_of = (int32_t *)base; base += dv_align((size_t)n_voxels * 4);
+  int32_t *cnt = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  int32_t *start = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  int32_t *cursor = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  int32_t *scan_tmp = (int32_t *)base; base += dv_align(ls3d_scan_tmp_ints(ncell + 1) * 4);
+  float4 *sorted = (float4 *)base;
+  hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * 4, stream);
+  hipMemsetAsync(cursor, 0, (size_t)(ncell + 1) * 4, stream);
+  hipLaunchKernelGGL(k_cg_count, ls3d_grid(n_voxels), dim3(256), 0, stream, coords, n_voxels, n_voxels_dev, g, cell_of, cnt);
+  int rc = ls3d_exclusive_scan_i32(cnt, start, (int)(ncell + 1), scan_tmp, nullptr, stream);
+  if (rc != LS3D_OK) return rc;
+  hipLaunchKernelGGL(k_cg_fill, ls3d_grid(n_voxels), dim3(256), 0, stream, centers, n_voxels, n_voxels_dev, vx_off, (const int32_t *)cell_of,
+                     (const int32_t *)start, cursor, sorted);
+  hipLaunchKernelGGL(k_devox_grid, dim3((n_points + 255) / 256), dim3(256), 0, stream, points, pt_stride, n_points, g, (const int32_t *)start,
+                     (const float4 *)sorted, vx_off, feat, feat_ld, c, out, out_ld, idx_out);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
 extern "C" int ls3d_voxel_centers(const int32_t *coords, int n, const int32_t *n_dev, const float vs[3], const float lo[3], float *out,
                                   ls3d_stream_t stream) {
   if (!coords || !vs || !lo || !out || n < 0) return LS3D_ERR_ARG;

@@ -32,79 +32,198 @@ template <int KC, int NT>
 __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl, int kvol,
                                                     const float *__restrict__ w, int cin, int w_ld, int cout, int n_rows,
                                                     const int32_t *n_rows_dev, EpiDev e, float *__restrict__ out, int out_ld) {
-  constexpr int SPL = KC / 2;    // floats of a row chunk held per lane
-  constexpr int SLAB = NT * 32;  // output columns handled by this workgroup
-  __shared__ float Bs[KC * SLAB];
+  constexpr int SPL = KC / 2;                          // floats of a row chunk held per lane
+  constexpr int SLAB = NT * 32;                        // output columns handled by this workgroup
+  constexpr int BV = KC * SLAB / 4;                    // float4s in one weight chunk
+  constexpr int BPT = (BV + 255) / 256;                // float4s staged per thread
+  __shared__ float Bs[2][KC * SLAB];                   // double-buffered weight chunk
+  __shared__ unsigned long long s_kmask;               // kernel offsets with an active neighbour in this tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kk = lane >> 5;
   const int n0 = blockIdx.y * SLAB;
   const int N = ls3d_count(n_rows, n_rows_dev);
   const int ntiles = (N + 127) / 128;
+  const float *wbase = w + n0;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row = tile * 128 + wave * 32 + col;
+    // ---- which kernel offsets does this tile / this wave need at all?
+    if (tid == 0) s_kmask = 0ull;
+    __syncthreads();
+    unsigned long long wmask = 0ull;
+    if (tbl) {
+      for (int k = 0; k < kvol; ++k) {
+        const int idx = (row < N) ? tbl[(size_t)row * kvol + k] : -1;
+        if (__any(idx >= 0)) wmask |= 1ull << k;
+      }
+    } else {
+      wmask = __any(row < N) ? 1ull : 0ull;
+    }
+    if (lane == 0 && wmask) atomicOr(&s_kmask, wmask);
+    __syncthreads();
+    unsigned long long rem = s_kmask;
     f32x16 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-    for (int k = 0; k < kvol; ++k) {
-      int idx = -1;
-      if (row < N) idx = tbl ? tbl[(size_t)row * kvol + k] : row;
-      if (!__syncthreads_or(idx >= 0)) continue;  // nobody in the tile has this neighbour
-      const bool wave_any = __any(idx >= 0);
-      const float *wk = w + (size_t)k * cin * w_ld + n0;
-      for (int c0 = 0; c0 < cin; c0 += KC) {
-        float a[SPL];
-        if (idx >= 0) {
-          const float4 *p = (const float4 *)(in + (size_t)idx * in_ld + c0 + kk * SPL);
+    if (rem) {
+      // ---- software pipeline over the chunks (k, c0): while chunk i feeds the MFMAs, the gathered A rows and
+      //      the weight chunk of i+1 are already in flight (registers / the other LDS buffer).
+      int k_cur = __ffsll((long long)rem) - 1;
+      rem &= rem - 1;
+      int k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
+#define LS3D_LOAD_IDX(k) ((row < N) ? (tbl ? tbl[(size_t)row * kvol + (k)] : row) : -1)
+#define LS3D_LOAD_A(dst, idx, c0_)                                                              \
+  do {                                                                                          \
+    if ((idx) >= 0) {                                                                           \
+      const float4 *p_ = (const float4 *)(in + (size_t)(idx)*in_ld + (c0_) + kk * SPL);         \
+      _Pragma("unroll") for (int q = 0; q < SPL / 4; ++q) dst[q] = p_[q];                       \
+    } else {                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < SPL / 4; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f); \
+    }                                                                                           \
+  } while (0)
+// weight staging registers are named scalars (not an array): an array indexed inside the pipelined loop is not
+// promoted to registers by hipcc and ends up in scratch.
+#define LS3D_B_ONE(j, reg, OP)                                                                  \
+  if constexpr (BPT > (j)) {                                                                    \
+    const int i_ = tid + (j)*256;                                                               \
+    if (BV % 256 == 0 || i_ < BV) { OP(reg, i_); }                                              \
+  }
+#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)((i_) / (SLAB / 4)) * w_ld + ((i_) % (SLAB / 4)) * 4)
+#define LS3D_B_ST(reg, i_) *(float4 *)(dst_ + (i_)*4) = reg
+#define LS3D_LOAD_B(k, c0_)                                                                     \
+  do {                                                                                          \
+    const float *wk_ = wbase + ((size_t)(k)*cin + (c0_)) * w_ld;                                \
+    LS3D_B_ONE(0, breg0, LS3D_B_LD) LS3D_B_ONE(1, breg1, LS3D_B_LD)                             \
+    LS3D_B_ONE(2, breg2, LS3D_B_LD) LS3D_B_ONE(3, breg3, LS3D_B_LD)                             \
+  } while (0)
+#define LS3D_STORE_B(dst)                                                                       \
+  do {                                                                                          \
+    float *dst_ = (dst);                                                                        \
+    LS3D_B_ONE(0, breg0, LS3D_B_ST) LS3D_B_ONE(1, breg1, LS3D_B_ST)                             \
+    LS3D_B_ONE(2, breg2, LS3D_B_ST) LS3D_B_ONE(3, breg3, LS3D_B_ST)                             \
+  } while (0)
+      int idx_cur = LS3D_LOAD_IDX(k_cur);
+      int idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
+      float4 a_cur[SPL / 4], a_nxt[SPL / 4];
+      float4 breg0, breg1, breg2, breg3;
+      static_assert(BPT <= 4, "weight chunk too large for the staging registers");
+      int c0 = 0, buf = 0;
+      LS3D_LOAD_A(a_cur, idx_cur, 0);
+      LS3D_LOAD_B(k_cur, 0);
+      LS3D_STORE_B(Bs[0]);
+      __syncthreads();
+      for (;;) {
+        int nk = k_cur, nc0 = c0 + KC, nidx = idx_cur;
+        bool has_next = true;
+        if (nc0 >= cin) {
+          nc0 = 0; nk = k_nxt; nidx = idx_nxt;
+          has_next = nk >= 0;
+        }
+        if (has_next) {
+          LS3D_LOAD_A(a_nxt, nidx, nc0);
+          LS3D_LOAD_B(nk, nc0);
+        }
+        if ((wmask >> k_cur) & 1ull) {
+          const float *bs = Bs[buf] + kk * SPL * SLAB + col;
 #pragma unroll
           for (int q = 0; q < SPL / 4; ++q) {
-            const float4 v = p[q];
-            a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+#define LS3D_MFMA_STEP(u, aval)                                                            \
+  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                            \
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), bs[(4 * q + (u)) * SLAB + n * 32], acc[n], 0, 0, 0);
+            LS3D_MFMA_STEP(0, a_cur[q].x)
+            LS3D_MFMA_STEP(1, a_cur[q].y)
+            LS3D_MFMA_STEP(2, a_cur[q].z)
+            LS3D_MFMA_STEP(3, a_cur[q].w)
+#undef LS3D_MFMA_STEP
           }
-        } else {
-#pragma unroll
-          for (int q = 0; q < SPL; ++q) a[q] = 0.0f;
         }
-        __syncthreads();  // every wave is done reading the previous chunk of Bs
-        for (int i = tid; i < KC * (SLAB / 4); i += 256) {
-          const int r = i / (SLAB / 4), c4 = i % (SLAB / 4);
-          *(float4 *)(Bs + r * SLAB + c4 * 4) = *(const float4 *)(wk + (size_t)(c0 + r) * w_ld + c4 * 4);
-        }
+        if (!has_next) break;
+        LS3D_STORE_B(Bs[buf ^ 1]);
         __syncthreads();
-        if (wave_any) {
+        buf ^= 1;
 #pragma unroll
-          for (int s = 0; s < SPL; ++s) {
+        for (int q = 0; q < SPL / 4; ++q) a_cur[q] = a_nxt[q];
+        if (nk != k_cur) {
+          k_cur = nk; idx_cur = idx_nxt;
+          rem &= rem - 1;
+          k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
+          idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
+        }
+        c0 = nc0;
+      }
+    }
+#undef LS3D_LOAD_IDX
+#undef LS3D_LOAD_A
+#undef LS3D_LOAD_B
+#undef LS3D_B_ONE
+#undef LS3D_B_LD
+#undef LS3D_B_ST
+#undef LS3D_STORE_B
+    // ---- epilogue through LDS: the accumulators (fragment layout: register r of lane (col,kk) = output row
+    //      (r&3) + 8*(r>>2) + 4*kk, column col) are transposed into row-major tiles in the weight buffer, then
+    //      all 256 threads apply scale/shift, residual, ReLU, pair-sum and store whole rows with float4.
+    constexpr int RPP = 2 * KC;       // tile rows that fit in Bs per pass (64 or 32)
+    constexpr int WPP = RPP / 32;     // waves per pass
+    float *stage = &Bs[0][0];
+    const bool vec = ((cout & 3) == 0) && ((out_ld & 3) == 0) && (!e.res_pre || (e.res_pre_ld & 3) == 0) &&
+                     (!e.pair || (e.pair_ld & 3) == 0);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              const float b = Bs[(kk * SPL + s) * SLAB + n * 32 + col];
-              acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b, acc[n], 0, 0, 0);
+    for (int pass = 0; pass < 128 / RPP; ++pass) {
+      __syncthreads();  // previous readers of Bs (MFMA loop or previous pass) are done
+      if (wave / WPP == pass) {
+        float *dst = stage + ((wave % WPP) * 32 + 4 * kk) * SLAB + col;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB + n * 32] = acc[n][r];
+      }
+      __syncthreads();
+      const int prow0 = tile * 128 + pass * RPP;
+      if (vec) {
+        for (int i = tid; i < RPP * (SLAB / 4); i += 256) {
+          const int lr = i / (SLAB / 4), c4 = i % (SLAB / 4);
+          const int orow = prow0 + lr, oc = n0 + c4 * 4;
+          if (orow < N && oc < cout) {
+            float4 v = *(const float4 *)(stage + lr * SLAB + c4 * 4);
+            if (e.scale) {
+              const float4 sc = *(const float4 *)(e.scale + oc);
+              v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
             }
+            if (e.shift) {
+              const float4 sh = *(const float4 *)(e.shift + oc);
+              v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
+            }
+            if (e.res_pre) {
+              const float4 q = *(const float4 *)(e.res_pre + (size_t)orow * e.res_pre_ld + oc);
+              v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (e.pair) {
+              const float4 p0 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc);
+              const float4 p1 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc + 4);
+              v.x += p0.x + p0.y; v.y += p0.z + p0.w; v.z += p1.x + p1.y; v.w += p1.z + p1.w;
+            }
+            *(float4 *)(out + (size_t)orow * out_ld + oc) = v;
+          }
+        }
+      } else {
+        for (int i = tid; i < RPP * SLAB; i += 256) {
+          const int lr = i / SLAB, c = i % SLAB;
+          const int orow = prow0 + lr, oc = n0 + c;
+          if (orow < N && oc < cout) {
+            float v = stage[lr * SLAB + c];
+            if (e.scale) v *= e.scale[oc];
+            if (e.shift) v += e.shift[oc];
+            if (e.res_pre) v += e.res_pre[(size_t)orow * e.res_pre_ld + oc];
+            if (e.relu) v = fmaxf(v, 0.0f);
+            if (e.pair) v += e.pair[(size_t)orow * e.pair_ld + 2 * oc] + e.pair[(size_t)orow * e.pair_ld + 2 * oc + 1];
+            out[(size_t)orow * out_ld + oc] = v;
           }
         }
       }
     }
-    // epilogue: acc register r of lane (col, kk) is output row (r&3) + 8*(r>>2) + 4*kk, column col
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int oc = n0 + n * 32 + col;
-      if (oc >= cout) continue;
-      const float sc = e.scale ? e.scale[oc] : 1.0f;
-      const float sh = e.shift ? e.shift[oc] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int orow = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (orow >= N) continue;
-        float v = fmaf(acc[n][r], sc, sh);
-        if (e.res_pre) v += e.res_pre[(size_t)orow * e.res_pre_ld + oc];
-        if (e.relu) v = fmaxf(v, 0.0f);
-        if (e.pair) {
-          const float *pp = e.pair + (size_t)orow * e.pair_ld + 2 * oc;
-          v += pp[0] + pp[1];
-        }
-        out[(size_t)orow * out_ld + oc] = v;
-      }
-    }
+    __syncthreads();  // Bs is reused by the next tile
   }
 }
 
@@ -120,7 +239,7 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !w || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
-  if (!tbl && kvol != 1) return LS3D_ERR_ARG;
+  if ((!tbl && kvol != 1) || kvol > 64) return LS3D_ERR_ARG;
   if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return LS3D_ERR_ARG;
   if (n_rows == 0) return LS3D_OK;
   EpiDev e = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};

@@ -321,6 +321,22 @@ def devoxelize(points, pt_off, centers, vx_off, batch, max_frame_points, feat, c
     return (out, idx) if return_idx else out
 
 
+def devoxelize_grid(points, coords, centers, vx_off, batch, voxel_size, pc_range, feat, c=None, return_idx=False):
+    """grid-accelerated exact 3-NN devoxelization (known points = voxel centres on the voxel lattice)"""
+    n = points.shape[0]
+    c = c or feat.shape[1]
+    _, grid = make_grid(voxel_size, pc_range)
+    out = torch.empty((n, c), dtype=torch.float32, device=points.device)
+    idx = torch.empty((n, 3), dtype=_i32, device=points.device) if return_idx else None
+    L = _L()
+    V = coords.shape[0]
+    ws = _ws(L.ls3d_devoxelize_grid_workspace_bytes(V, batch, _i3(grid)), points)
+    check(L.ls3d_devoxelize_grid(_ptr(points), points.shape[1], n, _ptr(coords), _ptr(centers), V, None, _ptr(vx_off), batch,
+                                 _f3(voxel_size), _f3(pc_range[:3]), _i3(grid), _ptr(feat), feat.shape[1], c, _ptr(out), c,
+                                 _ptr(idx), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(points)), "ls3d_devoxelize_grid")
+    return (out, idx) if return_idx else out
+
+
 # ---------------------------------------------------------------------------------------------- fusion
 def grid_gather(image_features, points_cuv, points):
     b, ncam, c, h, w = image_features.shape

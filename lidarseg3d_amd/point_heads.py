@@ -61,6 +61,16 @@ def _frame_layout(points, conv_point_coords, batch_size):
     return pt_off, vx_off
 
 
+def _devoxelize(batch_dict, points, centers, feat, batch_size):
+    """three_interpolate_wrap (point_utils.py:8-52) for the whole batch: the grid-accelerated exact search when the
+    backbone handed over the voxels' lattice coordinates, the O(N*V) scan otherwise (identical results)."""
+    pt_off, vx_off = _frame_layout(points, centers, batch_size)
+    if "conv_point_indices" in batch_dict and "voxel_geometry" in batch_dict:
+        vs, rng = batch_dict["voxel_geometry"]
+        return ops.devoxelize_grid(points, batch_dict["conv_point_indices"], centers, vx_off, batch_size, vs, rng, feat), vx_off
+    return ops.devoxelize(points, pt_off, centers, vx_off, batch_size, points.shape[0], feat), vx_off
+
+
 def _predict(head, example, test_cfg):
     """point_seg_batchloss_head.py:171-271 / point_seg_mseg3d_head.py:379-479: per-frame argmax, or the mean of
     the softmax over TTA variants.  Pure bookkeeping on top of out_logits."""
@@ -123,8 +133,7 @@ class PointSegBatchlossHead(PackedModule):
         self.forward_ret_dict["conv_logits"] = _run_mlp(feat, pk["conv_cls"])
         points = batch_dict["points"].contiguous()
         centers = batch_dict["conv_point_coords"]
-        pt_off, vx_off = _frame_layout(points, centers, batch_size)
-        pf = ops.devoxelize(points, pt_off, centers, vx_off, batch_size, points.shape[0], feat)
+        pf, _ = _devoxelize(batch_dict, points, centers, feat, batch_size)
         out = _run_mlp(_run_mlp(pf, pk["align"]), pk["out_cls"])
         batch_dict["out_logits"] = out
         self.forward_ret_dict["out_logits"] = out
@@ -309,10 +318,10 @@ class PointSegMSeg3DHead(PackedModule):
         self.forward_ret_dict["voxel_logits"] = voxel_logits
         centers = batch_dict["conv_point_coords"]
         points = batch_dict["points"].contiguous()
-        pt_off, vx_off = _frame_layout(points, centers, B)
+        pl0, vx_off = _devoxelize(batch_dict, points, centers, vf, B)
         # GF-Phase (:272-342).  The reference runs the camera / mimic branches on the valid subset and scatters
         # back; here they run on all rows and complete_concat selects per row (eval BatchNorm is row-wise).
-        pl = _run_mlp(ops.devoxelize(points, pt_off, centers, vx_off, B, points.shape[0], vf), pk["lidar"])
+        pl = _run_mlp(pl0, pk["lidar"])
         cuv = batch_dict["points_cuv"].contiguous()
         pc = _run_mlp(ops.grid_gather(batch_dict["image_features"].contiguous(), cuv, points), pk["camera"])
         # The mimic (pseudo-camera) branch only feeds the training loss: the reference evaluates it on the valid

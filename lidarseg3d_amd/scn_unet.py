@@ -108,7 +108,7 @@ class UNetSCN3D(nn.Module):
         cat[:, :c].copy_(x_bottom.features)
         mid = conv_bn_act(conv_t.conv1, conv_t.bn1, x_lateral, relu=True)
         rb = conv_t.conv2.rulebook(mid)
-        s, t = spconv.bn_scale_shift(conv_t.bn2)
+        s, t = spconv.cached_bn_scale_shift(conv_t.conv2, conv_t.bn2)
         conv_t.conv2.conv(mid, rb, scale=s, shift=t, relu=True, res_pre=x_lateral.features, out=cat[:, c:], out_ld=2 * c)
         x = x_lateral._like(cat)
         x = conv_bn_act(conv_m[0], conv_m[1], x, relu=True, pair=cat)
@@ -144,4 +144,8 @@ class UNetSCN3D(nn.Module):
         batch_dict["multi_scale_3d_features"] = dict(x_conv1=x_up2, x_conv2=x_up3, x_conv3=x_up4, x_conv4=x_conv4)
         batch_dict["conv_point_features"] = x_up1.features
         batch_dict["conv_point_coords"] = ops.voxel_centers(x_up1.indices, self.voxel_size, self.point_cloud_range)
+        # extra keys (not in the reference): integer lattice coordinates + geometry of the output voxels, which let
+        # the point heads use the grid-accelerated exact 3-NN instead of the O(N*V) scan
+        batch_dict["conv_point_indices"] = x_up1.indices
+        batch_dict["voxel_geometry"] = (list(self.voxel_size), list(self.point_cloud_range))
         return batch_dict

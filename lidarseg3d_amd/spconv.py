@@ -195,13 +195,19 @@ def bn_scale_shift(bn):
     return s.float().contiguous(), t.float().contiguous()
 
 
-def conv_bn_act(conv, bn, x, relu=True, res_pre=None, pair=None):
-    """SparseSequential(conv, BN(eval), ReLU) as ONE kernel launch"""
+def cached_bn_scale_shift(conv, bn):
+    """folded eval-BN of the BatchNorm that follows `conv`, recomputed only when the BN tensors change"""
     cache = conv.__dict__.setdefault("_bn_cache", {})
-    key = (id(bn), bn.weight._version, bn.running_var._version, bn.weight.data_ptr())
+    key = (id(bn), bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr())
     if cache.get("key") != key:
         cache["key"], cache["ss"] = key, bn_scale_shift(bn)
-    scale, shift = cache["ss"]
+    return cache["ss"]
+
+
+def conv_bn_act(conv, bn, x, relu=True, res_pre=None, pair=None):
+    """SparseSequential(conv, BN(eval), ReLU) as ONE kernel launch"""
+    scale, shift = cached_bn_scale_shift(conv, bn)
     rb = conv.rulebook(x)
     f = conv.conv(x, rb, scale=scale, shift=shift, relu=relu, res_pre=res_pre, pair=pair)
     if conv.inverse:

@@ -1,0 +1,17 @@
+#!/bin/bash
+# One gpurun call: parity tests, smoke, bench, rocprofv3 kernel stats.  Everything lands in gpurun_out/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd "$R"; mkdir -p gpurun_out; OUT="$R/gpurun_out"
+export TMPDIR=/tmp
+rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
+lscpu | egrep 'Model name|^CPU\(s\)' >> $OUT/gpu.txt
+timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $OUT/summary.txt
+timeout 400 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt
+timeout 900 python bench.py --steps ${STEPS:-20} --warmup 5 > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/summary.txt
+if [ "${PROFILE:-1}" = "1" ]; then
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof.log 2>&1
+  echo "rocprof rc=$?" >> $OUT/summary.txt
+  cd "$R"
+fi
+tail -5 $OUT/pytest_gpu.log; cat $OUT/summary.txt; tail -3 $OUT/smoke.log; cat $OUT/bench.log

@@ -210,3 +210,23 @@ def test_sdseg3d_120k_properties():
     assert float((ab[:120000] - a).abs().max()) <= 1e-3 + 2e-5 * scale
     assert float((ba[60000:] - a).abs().max()) <= 1e-3 + 2e-5 * scale
     assert float((ba[:60000] - ab[120000:]).abs().max()) <= 1e-3 + 2e-5 * scale
+
+
+def test_devoxelize_grid_equals_brute_force_120k():
+    """the coarse-grid 3-NN must return exactly the brute-force neighbours, also for points far outside the range"""
+    cfg = synth.NUSC
+    frames = [synth.lidar_frame(120000, seed=11, **cfg), synth.lidar_frame(30000, seed=12, **cfg)]
+    frames[0][:50, :3] += np.float32([90.0, 0.0, 20.0])   # far outside the range
+    frames[1][:50, :3] -= np.float32([0.0, 120.0, 9.0])
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    p = cu(pts[:, :4].copy())
+    v, c, n, nv = ops.voxelize_hard(cu(pts), cfg["voxel_size"], cfg["pc_range"], 5, 600000, batched=True)
+    V = int(nv)
+    coords = c[:V].contiguous()
+    ctr = ops.voxel_centers(coords, cfg["voxel_size"], cfg["pc_range"])
+    feat = torch.randn((V, 32), device=DEV)
+    pt_off, vx_off = ops.frame_offsets(p[:, 0], 2), ops.frame_offsets(ctr[:, 0], 2)
+    a, ia = ops.devoxelize_grid(p, coords, ctr, vx_off, 2, cfg["voxel_size"], cfg["pc_range"], feat, return_idx=True)
+    b, ib = ops.devoxelize(p, pt_off, ctr, vx_off, 2, p.shape[0], feat, return_idx=True)
+    assert torch.equal(ia, ib)
+    assert torch.equal(a, b)
