@@ -62,7 +62,7 @@ class ConvTimer:
             key = (tbl.data_ptr(), tbl.shape[0])
             if key not in self.pairs_cache:
                 self.pairs_cache[key] = None  # filled after the timed region (needs a sync)
-            self.meta.append((key, tbl, w.shape[1], kw.get("cout") or w.shape[2]))
+            self.meta.append((key, tbl, w.shape[1], kw.get("cout") or w.cout))
             return out
         self.meta = []
         self.ops.gather_gemm = wrapped

@@ -168,9 +168,18 @@ typedef struct {
   int32_t relu;
 } ls3d_epilogue_t;
 
+/* Weight packing for ls3d_gather_gemm.  Input: plain row-major W[kvol][cin_src][cout] (= spconv's
+ * (kD,kH,kW,Cin,Cout) flattened, or a transposed nn.Linear weight with kvol = 1).  Output (w_packed, holding
+ * ls3d_gather_gemm_packed_floats(kvol,cin_pad,cout) floats): zero padded to cin_pad (multiple of 16) rows and
+ * roundup(cout,32) columns, laid out [kvol][slab][cin_pad][32][NT] so that a workgroup's weight chunk is one
+ * contiguous copy into LDS and a lane's MFMA B operands for one k-step are one LDS read. */
+size_t ls3d_gather_gemm_packed_floats(int kvol, int cin_pad, int cout);
+int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, float *w_packed,
+                          ls3d_stream_t stream);
+
 /* out[r, 0..cout) = epilogue( sum_k W[k]^T * in[tbl[r,k]] ), tbl == NULL means the identity table with
- * kvol == 1 (a dense Linear layer).  in[*, cin] row stride in_ld, W[kvol][cin][cout_pad] with
- * cout_pad = roundup(cout,32), out row stride out_ld.  cin must be a multiple of 16, in_ld of 4.
+ * kvol == 1 (a dense Linear layer).  in[*, cin] row stride in_ld, `w` = weights packed by
+ * ls3d_gather_gemm_pack with cin_pad == cin, out row stride out_ld.  cin must be a multiple of 16, in_ld of 4.
  * f32 MFMA (v_mfma_f32_32x32x2_f32): exact f32 products and accumulation.
  * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
  * (tbl = nbr_inv) and every nn.Linear on the path. */
@@ -220,7 +229,8 @@ size_t ls3d_devoxelize_grid_workspace_bytes(int n_voxels, int batch, const int32
  * searches expanding shells of coarse cells with an exact stopping bound, instead of scanning every centre
  * (the reference kernel is O(N*V), interpolate_gpu.cu:36-57).  coords[V,4] = integer (batch,z,y,x) of the
  * centres, centers[V,4] as written by ls3d_voxel_centers, grid_xyz = fine cells per axis. */
-int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *coords, const float *centers,
+int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *pt_off /*[batch+1] dev*/,
+                         int max_frame_points, const int32_t *coords, const float *centers,
                          int n_voxels, const int32_t *n_voxels_dev, const int32_t *vx_off /*[batch+1] dev*/, int batch,
                          const float vs_host[3], const float lo_host[3], const int32_t grid_xyz_host[3], const float *feat,
                          int feat_ld, int c, float *out, int out_ld, int32_t *idx_out, void *workspace,

@@ -172,14 +172,12 @@ __global__ __launch_bounds__(256) void k_devoxelize(const float *points, int pt_
 // and ordered lexicographically by (distance, index), which yields exactly the brute-force result
 // (strict '<' in ascending index order == smallest index among equal distances).  Points far outside the
 // range simply walk more shells: always exact, no fallback path.
-#define CGX 8
-#define CGY 8
-#define CGZ 4
-
 struct CGeom {
   float vs[3], lo[3];
   int grid[3];  // fine cells x,y,z
+  int cg[3];    // fine cells per coarse cell x,y,z
   int dim[3];   // coarse cells x,y,z
+  int wpf;      // occupancy-bitmap words per frame
 };
 
 __device__ __forceinline__ void top3_push_lex(Top3 &t, float d, int k) {
@@ -190,14 +188,17 @@ __device__ __forceinline__ void top3_push_lex(Top3 &t, float d, int k) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_cg_count(const int32_t *coords, int n, const int32_t *n_dev, CGeom g, int32_t *cell_of, int32_t *cnt) {
+__global__ __launch_bounds__(256) void k_cg_count(const int32_t *coords, int n, const int32_t *n_dev, CGeom g, int32_t *cell_of, int32_t *cnt,
+                                                 uint32_t *occ) {
   const int N = ls3d_count(n, n_dev);
+  const int ncf = g.dim[0] * g.dim[1] * g.dim[2];
   for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
     const int32_t *c = coords + 4 * (size_t)v;
-    const int cz = min(c[1] / CGZ, g.dim[2] - 1), cy = min(c[2] / CGY, g.dim[1] - 1), cx = min(c[3] / CGX, g.dim[0] - 1);
-    const int cell = ((c[0] * g.dim[2] + cz) * g.dim[1] + cy) * g.dim[0] + cx;
-    cell_of[v] = cell;
-    atomicAdd(&cnt[cell], 1);
+    const int cz = min(c[1] / g.cg[2], g.dim[2] - 1), cy = min(c[2] / g.cg[1], g.dim[1] - 1), cx = min(c[3] / g.cg[0], g.dim[0] - 1);
+    const int cf = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    cell_of[v] = c[0] * ncf + cf;
+    atomicAdd(&cnt[c[0] * ncf + cf], 1);
+    atomicOr(&occ[(size_t)c[0] * g.wpf + (cf >> 5)], 1u << (cf & 31));
   }
 }
 
@@ -213,38 +214,42 @@ __global__ __launch_bounds__(256) void k_cg_fill(const float *centers, int n, co
   }
 }
 
-__global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_stride, int n, CGeom g, const int32_t *start, const float4 *sorted,
-                                                   const int32_t *vx_off, const float *feat, int feat_ld, int C, float *out, int out_ld,
-                                                   int32_t *idx_out) {
+// grid = (ceil(max_frame_points/256), batch); dynamic LDS = the frame's coarse-cell occupancy bitmap, so that
+// walking through empty space costs LDS bit tests only.
+__global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_stride, const int32_t *pt_off, CGeom g, const int32_t *start,
+                                                   const float4 *sorted, const uint32_t *occ, const int32_t *vx_off, const float *feat,
+                                                   int feat_ld, int C, float *out, int out_ld, int32_t *idx_out) {
+  HIP_DYNAMIC_SHARED(uint32_t, s_occ)
   __shared__ int s_idx[256 * 3];
   __shared__ float s_w[256 * 3];
-  __shared__ int s_base[256];
-  const int first = blockIdx.x * 256;
+  const int frame = blockIdx.y;
+  const int p0 = pt_off[frame], p1 = pt_off[frame + 1];
+  const int first = p0 + blockIdx.x * 256;
+  if (first >= p1) return;  // block-uniform
+  for (int w = threadIdx.x; w < g.wpf; w += 256) s_occ[w] = occ[(size_t)frame * g.wpf + w];
+  __syncthreads();
   const int i = first + threadIdx.x;
-  const bool active = i < n;
+  const bool active = i < p1;
+  const int ncf = g.dim[0] * g.dim[1] * g.dim[2];
+  const int32_t *fstart = start + (size_t)frame * ncf;
   Top3 t;
   top3_init(t);
-  int frame = 0;
   if (active) {
     const float *u = points + (size_t)i * pt_stride;
-    frame = (int)u[0];
     const float ux = u[1], uy = u[2], uz = u[3];
-    // own coarse cell (fine coordinate as in voxelization, clamped into the grid)
-    int fc[3];
-    float gap[3];
     const float pu[3] = {ux, uy, uz};
-    const int cgs[3] = {CGX, CGY, CGZ};
+    float gap[3], cs[3];
     int cc[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
+      // own coarse cell: fine coordinate as in voxelization, clamped into the grid
       float fcoord = floorf(__fdiv_rn(__fsub_rn(pu[a], g.lo[a]), g.vs[a]));
       fcoord = fminf(fmaxf(fcoord, 0.0f), (float)(g.grid[a] - 1));
-      fc[a] = (int)fcoord;
-      cc[a] = min(fc[a] / cgs[a], g.dim[a] - 1);
-      const float cs = g.vs[a] * (float)cgs[a];
-      const float clo = g.lo[a] + cs * (float)cc[a];
-      // the last coarse cell of an axis may hold more fine cells than CG*: use its true upper face
-      const float chi = (cc[a] == g.dim[a] - 1) ? g.lo[a] + g.vs[a] * (float)g.grid[a] : clo + cs;
+      cc[a] = min((int)fcoord / g.cg[a], g.dim[a] - 1);
+      cs[a] = g.vs[a] * (float)g.cg[a];
+      const float clo = g.lo[a] + cs[a] * (float)cc[a];
+      // the last coarse cell of an axis may hold more fine cells: use its true upper face
+      const float chi = (cc[a] == g.dim[a] - 1) ? g.lo[a] + g.vs[a] * (float)g.grid[a] : clo + cs[a];
       gap[a] = fmaxf(fminf(pu[a] - clo, chi - pu[a]), 0.0f);
     }
     const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
@@ -255,23 +260,39 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
       for (int z = z0; z <= z1; ++z) {
         const bool zs = (z == cc[2] - r) || (z == cc[2] + r);
         for (int y = y0; y <= y1; ++y) {
-          const bool ys = zs || (y == cc[1] - r) || (y == cc[1] + r);
-          const int step = (ys || r == 0) ? 1 : max(x1 - x0, 1);  // interior rows: only the two end cells can be on the shell
-          for (int x = x0; x <= x1; x += step) {
-            if (!ys && x != cc[0] - r && x != cc[0] + r) continue;
-            const int cell = ((frame * g.dim[2] + z) * g.dim[1] + y) * g.dim[0] + x;
-            const int s0 = start[cell], s1 = start[cell + 1];
-            for (int j = s0; j < s1; ++j) {
-              const float4 q = sorted[j];
-              const float dx = ux - q.x, dy = uy - q.y, dz = uz - q.z;
-              const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-              top3_push_lex(t, d, __float_as_int(q.w));
+          const bool face = zs || (y == cc[1] - r) || (y == cc[1] + r);
+          const int rowbase = (z * g.dim[1] + y) * g.dim[0];
+          // cells of this row that lie on shell r: the whole clipped x-range on a face row, else only the two ends
+          const int b0 = rowbase + x0, b1 = rowbase + x1;
+          for (int wi = b0 >> 5; wi <= (b1 >> 5); ++wi) {
+            uint32_t m = s_occ[wi];
+            if (!m) continue;
+            const int wlo = wi << 5;
+            if (b0 > wlo) m &= ~0u << (b0 - wlo);
+            if (b1 < wlo + 31) m &= ~0u >> (wlo + 31 - b1);
+            if (!face) {
+              uint32_t keep = 0;
+              const int e0 = rowbase + cc[0] - r, e1 = rowbase + cc[0] + r;
+              if (cc[0] - r >= 0 && (e0 >> 5) == wi) keep |= 1u << (e0 & 31);
+              if (cc[0] + r < g.dim[0] && (e1 >> 5) == wi) keep |= 1u << (e1 & 31);
+              m &= keep;
+            }
+            while (m) {
+              const int cell = wlo + __ffs((int)m) - 1;
+              m &= m - 1;
+              const int s0 = fstart[cell], s1 = fstart[cell + 1];
+              for (int j = s0; j < s1; ++j) {
+                const float4 q = sorted[j];
+                const float dx = ux - q.x, dy = uy - q.y, dz = uz - q.z;
+                const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                top3_push_lex(t, d, __float_as_int(q.w));
+              }
             }
           }
         }
       }
       // lower bound on the distance to anything outside the visited box
-      const float lb = fminf(gap[0] + (float)r * g.vs[0] * CGX, fminf(gap[1] + (float)r * g.vs[1] * CGY, gap[2] + (float)r * g.vs[2] * CGZ));
+      const float lb = fminf(gap[0] + (float)r * cs[0], fminf(gap[1] + (float)r * cs[1], gap[2] + (float)r * cs[2]));
       if (t.d2 < lb * lb * 0.99999f) break;
       if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1) break;  // whole grid seen
     }
@@ -280,17 +301,20 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
   const float norm = (r0 + r1) + r2;
   s_idx[threadIdx.x * 3 + 0] = t.i0; s_idx[threadIdx.x * 3 + 1] = t.i1; s_idx[threadIdx.x * 3 + 2] = t.i2;
   s_w[threadIdx.x * 3 + 0] = __fdiv_rn(r0, norm); s_w[threadIdx.x * 3 + 1] = __fdiv_rn(r1, norm); s_w[threadIdx.x * 3 + 2] = __fdiv_rn(r2, norm);
-  s_base[threadIdx.x] = active ? vx_off[frame] : 0;
   if (active && idx_out) {
     int32_t *q = idx_out + (size_t)i * 3;
     q[0] = t.i0; q[1] = t.i1; q[2] = t.i2;
   }
   __syncthreads();
-  const int cnt = min(256, n - first);
+  const int cnt = min(256, p1 - first);
   const int c4n = C >> 2;
+  const int v0 = vx_off[frame], m = vx_off[frame + 1] - v0;
   for (int e = threadIdx.x; e < cnt * c4n; e += 256) {
     const int p = e / c4n, c4 = e % c4n;
-    const int v0 = s_base[p];
+    if (m <= 0) {
+      *(float4 *)(out + (size_t)(first + p) * out_ld + c4 * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      continue;
+    }
     const float w0 = s_w[p * 3], w1 = s_w[p * 3 + 1], w2 = s_w[p * 3 + 2];
     const float4 a = *(const float4 *)(feat + (size_t)(v0 + s_idx[p * 3]) * feat_ld + c4 * 4);
     const float4 b = *(const float4 *)(feat + (size_t)(v0 + s_idx[p * 3 + 1]) * feat_ld + c4 * 4);
@@ -305,32 +329,41 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
 }
 
 static inline size_t dv_align(size_t v) { return (v + 255) & ~(size_t)255; }
-static void cg_dims(const int32_t grid_xyz[3], int dim[3]) {
-  const int cgs[3] = {CGX, CGY, CGZ};
-  for (int a = 0; a < 3; ++a) { dim[a] = grid_xyz[a] / cgs[a]; if (dim[a] < 1) dim[a] = 1; }
+// coarse cells of 8x8x4 fine voxels, doubled until one frame's occupancy bitmap fits in 48 KB of LDS
+static void cg_setup(const int32_t grid_xyz[3], CGeom &g) {
+  int cg[3] = {8, 8, 4};
+  for (;;) {
+    long long cells = 1;
+    for (int a = 0; a < 3; ++a) { g.cg[a] = cg[a]; g.dim[a] = grid_xyz[a] / cg[a]; if (g.dim[a] < 1) g.dim[a] = 1; cells *= g.dim[a]; }
+    g.wpf = (int)((cells + 31) / 32);
+    if ((long long)g.wpf * 4 <= 48 * 1024) break;
+    for (int a = 0; a < 3; ++a) cg[a] *= 2;
+  }
 }
 
 extern "C" size_t ls3d_devoxelize_grid_workspace_bytes(int n_voxels, int batch, const int32_t grid_xyz[3]) {
-  int dim[3];
-  cg_dims(grid_xyz, dim);
-  const long long ncell = (long long)batch * dim[0] * dim[1] * dim[2];
+  CGeom g;
+  cg_setup(grid_xyz, g);
+  const long long ncell = (long long)batch * g.dim[0] * g.dim[1] * g.dim[2];
   return dv_align((size_t)(n_voxels > 0 ? n_voxels : 1) * 4) + 3 * dv_align((size_t)(ncell + 1) * 4) + dv_align(ls3d_scan_tmp_ints(ncell + 1) * 4) +
-         dv_align((size_t)(n_voxels > 0 ? n_voxels : 1) * 16);
+         dv_align((size_t)(n_voxels > 0 ? n_voxels : 1) * 16) + dv_align((size_t)batch * g.wpf * 4);
 }
 
-extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *coords, const float *centers,
-                                    int n_voxels, const int32_t *n_voxels_dev, const int32_t *vx_off, int batch, const float vs[3],
-                                    const float lo[3], const int32_t grid_xyz[3], const float *feat, int feat_ld, int c, float *out,
-                                    int out_ld, int32_t *idx_out, void *workspace, size_t workspace_bytes, ls3d_stream_t stream_) {
+extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *pt_off, int max_frame_points,
+                                    const int32_t *coords, const float *centers, int n_voxels, const int32_t *n_voxels_dev,
+                                    const int32_t *vx_off, int batch, const float vs[3], const float lo[3], const int32_t grid_xyz[3],
+                                    const float *feat, int feat_ld, int c, float *out, int out_ld, int32_t *idx_out, void *workspace,
+                                    size_t workspace_bytes, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!points || !coords || !centers || !vx_off || !vs || !lo || !grid_xyz || !feat || !out || !workspace || batch < 1 || pt_stride < 4)
+  if (!points || !pt_off || !coords || !centers || !vx_off || !vs || !lo || !grid_xyz || !feat || !out || !workspace || batch < 1 ||
+      pt_stride < 4)
     return LS3D_ERR_ARG;
   if ((c % 4) || (feat_ld % 4) || (out_ld % 4) || feat_ld < c || out_ld < c || n_voxels < 1) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_devoxelize_grid_workspace_bytes(n_voxels, batch, grid_xyz)) return LS3D_ERR_WORKSPACE;
-  if (n_points == 0) return LS3D_OK;
+  if (n_points == 0 || max_frame_points == 0) return LS3D_OK;
   CGeom g;
   for (int a = 0; a < 3; ++a) { g.vs[a] = vs[a]; g.lo[a] = lo[a]; g.grid[a] = grid_xyz[a]; }
-  cg_dims(grid_xyz, g.dim);
+  cg_setup(grid_xyz, g);
   const long long ncell = (long long)batch * g.dim[0] * g.dim[1] * g.dim[2];
   if (ncell + 1 > 0x7FFFFFFFLL) return LS3D_ERR_UNSUPPORTED;
   char *base = (char *)workspace;
@@ -339,16 +372,18 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   int32_t *start = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
   int32_t *cursor = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
   int32_t *scan_tmp = (int32_t *)base; base += dv_align(ls3d_scan_tmp_ints(ncell + 1) * 4);
-  float4 *sorted = (float4 *)base;
+  float4 *sorted = (float4 *)base; base += dv_align((size_t)n_voxels * 16);
+  uint32_t *occ = (uint32_t *)base;
   hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * 4, stream);
   hipMemsetAsync(cursor, 0, (size_t)(ncell + 1) * 4, stream);
-  hipLaunchKernelGGL(k_cg_count, ls3d_grid(n_voxels), dim3(256), 0, stream, coords, n_voxels, n_voxels_dev, g, cell_of, cnt);
+  hipMemsetAsync(occ, 0, (size_t)batch * g.wpf * 4, stream);
+  hipLaunchKernelGGL(k_cg_count, ls3d_grid(n_voxels), dim3(256), 0, stream, coords, n_voxels, n_voxels_dev, g, cell_of, cnt, occ);
   int rc = ls3d_exclusive_scan_i32(cnt, start, (int)(ncell + 1), scan_tmp, nullptr, stream);
   if (rc != LS3D_OK) return rc;
   hipLaunchKernelGGL(k_cg_fill, ls3d_grid(n_voxels), dim3(256), 0, stream, centers, n_voxels, n_voxels_dev, vx_off, (const int32_t *)cell_of,
                      (const int32_t *)start, cursor, sorted);
-  hipLaunchKernelGGL(k_devox_grid, dim3((n_points + 255) / 256), dim3(256), 0, stream, points, pt_stride, n_points, g, (const int32_t *)start,
-                     (const float4 *)sorted, vx_off, feat, feat_ld, c, out, out_ld, idx_out);
+  hipLaunchKernelGGL(k_devox_grid, dim3((max_frame_points + 255) / 256, batch), dim3(256), (size_t)g.wpf * 4, stream, points, pt_stride, pt_off, g,
+                     (const int32_t *)start, (const float4 *)sorted, (const uint32_t *)occ, vx_off, feat, feat_ld, c, out, out_ld, idx_out);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

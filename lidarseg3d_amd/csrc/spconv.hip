@@ -36,14 +36,16 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
   constexpr int SLAB = NT * 32;                        // output columns handled by this workgroup
   constexpr int BV = KC * SLAB / 4;                    // float4s in one weight chunk
   constexpr int BPT = (BV + 255) / 256;                // float4s staged per thread
-  __shared__ float Bs[2][KC * SLAB];                   // double-buffered weight chunk
+  struct alignas(NT == 3 ? 4 : 4 * NT) BVec { float v[NT]; };
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC * SLAB];  // double-buffered weight chunk
   __shared__ unsigned long long s_kmask;               // kernel offsets with an active neighbour in this tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kk = lane >> 5;
   const int n0 = blockIdx.y * SLAB;
   const int N = ls3d_count(n_rows, n_rows_dev);
   const int ntiles = (N + 127) / 128;
-  const float *wbase = w + n0;
+  const int nslab = w_ld / SLAB;
+  const float *wbase = w + (size_t)blockIdx.y * cin * SLAB;  // packed: [kvol][slab][cin][32][NT]
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int row = tile * 128 + wave * 32 + col;
     // ---- which kernel offsets does this tile / this wave need at all?
@@ -89,11 +91,11 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
     const int i_ = tid + (j)*256;                                                               \
     if (BV % 256 == 0 || i_ < BV) { OP(reg, i_); }                                              \
   }
-#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)((i_) / (SLAB / 4)) * w_ld + ((i_) % (SLAB / 4)) * 4)
+#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)(i_)*4)
 #define LS3D_B_ST(reg, i_) *(float4 *)(dst_ + (i_)*4) = reg
 #define LS3D_LOAD_B(k, c0_)                                                                     \
   do {                                                                                          \
-    const float *wk_ = wbase + ((size_t)(k)*cin + (c0_)) * w_ld;                                \
+    const float *wk_ = wbase + ((size_t)(k)*cin * nslab + (c0_)) * SLAB;                         \
     LS3D_B_ONE(0, breg0, LS3D_B_LD) LS3D_B_ONE(1, breg1, LS3D_B_LD)                             \
     LS3D_B_ONE(2, breg2, LS3D_B_LD) LS3D_B_ONE(3, breg3, LS3D_B_LD)                             \
   } while (0)
@@ -125,16 +127,21 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
           LS3D_LOAD_B(nk, nc0);
         }
         if ((wmask >> k_cur) & 1ull) {
-          const float *bs = Bs[buf] + kk * SPL * SLAB + col;
+          // packed weight layout: the NT values a lane needs for one k-step are adjacent -> one ds_read of NT dwords;
+          // the read for step s+1 is issued before the MFMAs of step s (register double buffer).
+          const float *bs = Bs[buf] + (kk * SPL * 32 + col) * NT;
+          BVec bb0, bb1;
+          bb0 = *(const BVec *)bs;
 #pragma unroll
           for (int q = 0; q < SPL / 4; ++q) {
-#define LS3D_MFMA_STEP(u, aval)                                                            \
-  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                            \
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), bs[(4 * q + (u)) * SLAB + n * 32], acc[n], 0, 0, 0);
-            LS3D_MFMA_STEP(0, a_cur[q].x)
-            LS3D_MFMA_STEP(1, a_cur[q].y)
-            LS3D_MFMA_STEP(2, a_cur[q].z)
-            LS3D_MFMA_STEP(3, a_cur[q].w)
+#define LS3D_MFMA_STEP(u, aval, cur, nxt)                                                        \
+  if (4 * q + (u) + 1 < SPL) nxt = *(const BVec *)(bs + (4 * q + (u) + 1) * 32 * NT);            \
+  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                  \
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32((aval), cur.v[n], acc[n], 0, 0, 0);
+            LS3D_MFMA_STEP(0, a_cur[q].x, bb0, bb1)
+            LS3D_MFMA_STEP(1, a_cur[q].y, bb1, bb0)
+            LS3D_MFMA_STEP(2, a_cur[q].z, bb0, bb1)
+            LS3D_MFMA_STEP(3, a_cur[q].w, bb1, bb0)
 #undef LS3D_MFMA_STEP
           }
         }
@@ -234,6 +241,44 @@ static void launch_gg(dim3 grid, hipStream_t stream, const float *in, int in_ld,
                      out, out_ld);
 }
 
+// column-block decomposition shared by the kernel dispatch and the weight packer
+static inline int gg_nt(int cout) {
+  const int nt_total = (cout + 31) / 32;
+  for (int c = 4; c >= 1; --c)
+    if (nt_total % c == 0) return c;
+  return 1;
+}
+
+// plain [kvol][cin_src][cout] -> packed [kvol][slab][cin_pad][32][NT] (zero padded), see ls3d.h
+__global__ __launch_bounds__(256) void k_gg_pack(const float *src, int kvol, int cin_src, int cin_pad, int cout, int nt, float *dst) {
+  const int slab = nt * 32, nslab = ((cout + 31) / 32) / nt;
+  const long long total = (long long)kvol * nslab * cin_pad * slab;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    long long r = t;
+    const int n = (int)(r % nt); r /= nt;
+    const int col = (int)(r % 32); r /= 32;
+    const int c = (int)(r % cin_pad); r /= cin_pad;
+    const int sl = (int)(r % nslab); r /= nslab;
+    const int k = (int)r;
+    const int oc = sl * slab + n * 32 + col;
+    dst[t] = (c < cin_src && oc < cout) ? src[((size_t)k * cin_src + c) * cout + oc] : 0.0f;
+  }
+}
+
+extern "C" size_t ls3d_gather_gemm_packed_floats(int kvol, int cin_pad, int cout) {
+  return (size_t)kvol * cin_pad * ((cout + 31) / 32 * 32);
+}
+
+extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, float *w_packed,
+                                     ls3d_stream_t stream) {
+  if (!w_plain || !w_packed || kvol < 1 || cin_src < 1 || cin_pad < cin_src || (cin_pad % 16) || cout < 1) return LS3D_ERR_ARG;
+  const long long total = (long long)ls3d_gather_gemm_packed_floats(kvol, cin_pad, cout);
+  hipLaunchKernelGGL(k_gg_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, gg_nt(cout),
+                     w_packed);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
 extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int cin, int cout, int n_rows,
                                 const int32_t *n_rows_dev, const ls3d_epilogue_t *epi, float *out, int out_ld, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -249,9 +294,7 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   }
   const int w_ld = (cout + 31) / 32 * 32;
   const int nt_total = w_ld / 32;
-  int nt = 1;
-  for (int c = 4; c >= 1; --c)
-    if (nt_total % c == 0) { nt = c; break; }
+  const int nt = gg_nt(cout);
   const int slabs = nt_total / nt;
   const int ntiles = (n_rows + 127) / 128;
   dim3 grid((unsigned)(ntiles < 2048 ? ntiles : 2048), (unsigned)slabs);

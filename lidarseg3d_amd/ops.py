@@ -225,14 +225,23 @@ def rulebook_conv(coords, batch, shape_zyx, ksize, stride, pad, out_cap=None):
     return oc, cnt, nbr_out, nbr_inv, oshape
 
 
+def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout):
+    """plain [kvol,cin,cout] -> kernel layout (flat tensor)"""
+    L = _L()
+    out = torch.empty((L.ls3d_gather_gemm_packed_floats(kvol, cin_pad, cout),), dtype=torch.float32, device=w_plain.device)
+    check(L.ls3d_gather_gemm_pack(_ptr(w_plain), kvol, cin, cin_pad, cout, _ptr(out), _stream(w_plain)), "ls3d_gather_gemm_pack")
+    return out
+
+
 def gather_gemm(x, w, tbl=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
                 out=None, out_ld=None, in_ld=None, cin=None):
-    """out[r, :cout] = epilogue(sum_k W[k]^T x[tbl[r,k]]).  w: packed [kvol, cin, roundup(cout,32)]."""
+    """out[r, :cout] = epilogue(sum_k W[k]^T x[tbl[r,k]]).  w: packing.PackedWeight."""
     kvol, wcin, wld = w.shape
     cin = cin or wcin
     assert wcin == cin
     in_ld = in_ld or x.shape[1]
-    cout = cout or wld
+    cout = cout or w.cout
+    assert cout == w.cout, "packed layout depends on cout"
     if tbl is not None:
         n_rows = tbl.shape[0] if n_rows is None else n_rows
         assert tbl.shape[1] == kvol
@@ -247,7 +256,7 @@ def gather_gemm(x, w, tbl=None, n_rows=None, cout=None, scale=None, shift=None, 
         out_ld = out_ld or out.shape[1]
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0)
-    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), kvol, _ptr(w), cin, cout, n_rows, None, ctypes.byref(epi),
+    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), kvol, _ptr(w.data), cin, cout, n_rows, None, ctypes.byref(epi),
                                 _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
     return out
 
@@ -321,7 +330,7 @@ def devoxelize(points, pt_off, centers, vx_off, batch, max_frame_points, feat, c
     return (out, idx) if return_idx else out
 
 
-def devoxelize_grid(points, coords, centers, vx_off, batch, voxel_size, pc_range, feat, c=None, return_idx=False):
+def devoxelize_grid(points, pt_off, coords, centers, vx_off, batch, voxel_size, pc_range, feat, c=None, return_idx=False):
     """grid-accelerated exact 3-NN devoxelization (known points = voxel centres on the voxel lattice)"""
     n = points.shape[0]
     c = c or feat.shape[1]
@@ -331,7 +340,7 @@ def devoxelize_grid(points, coords, centers, vx_off, batch, voxel_size, pc_range
     L = _L()
     V = coords.shape[0]
     ws = _ws(L.ls3d_devoxelize_grid_workspace_bytes(V, batch, _i3(grid)), points)
-    check(L.ls3d_devoxelize_grid(_ptr(points), points.shape[1], n, _ptr(coords), _ptr(centers), V, None, _ptr(vx_off), batch,
+    check(L.ls3d_devoxelize_grid(_ptr(points), points.shape[1], n, _ptr(pt_off), n, _ptr(coords), _ptr(centers), V, None, _ptr(vx_off), batch,
                                  _f3(voxel_size), _f3(pc_range[:3]), _i3(grid), _ptr(feat), feat.shape[1], c, _ptr(out), c,
                                  _ptr(idx), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(points)), "ls3d_devoxelize_grid")
     return (out, idx) if return_idx else out

@@ -28,17 +28,32 @@ def fold_bn(bias, bn, cout, dev):
     return s.float().contiguous(), t.float().contiguous()
 
 
+class PackedWeight(object):
+    """kernel-layout weights (ls3d_gather_gemm_pack) + the logical shape"""
+    __slots__ = ("data", "kvol", "cin", "cout")
+
+    def __init__(self, data, kvol, cin, cout):
+        self.data, self.kvol, self.cin, self.cout = data, kvol, cin, cout
+
+    @property
+    def shape(self):  # (kvol, cin_pad, cout_pad) — what callers size their inputs against
+        return (self.kvol, self.cin, _pad32(self.cout))
+
+
+def _pack(plain, kvol, cin, cin_pad, cout):
+    from . import ops
+    return PackedWeight(ops.gather_gemm_pack(plain.contiguous(), kvol, cin, cin_pad, cout), kvol, cin_pad, cout)
+
+
 def pack_linear(weight, bias=None, bn=None, cin_pad=None):
-    """nn.Linear / Conv1d(k=1) weight (out,in[,1]) -> (W[1,cin_pad,cout_pad], scale, shift, cout)"""
+    """nn.Linear / Conv1d(k=1) weight (out,in[,1]) -> (PackedWeight, scale, shift, cout)"""
     w = weight.detach().float()
     if w.dim() == 3:
         w = w.squeeze(-1)
     cout, cin = w.shape
     cin_pad = cin_pad or _pad16(cin)
-    W = torch.zeros((1, cin_pad, _pad32(cout)), dtype=torch.float32, device=w.device)
-    W[0, :cin, :cout] = w.t()
     scale, shift = fold_bn(bias, bn, cout, w.device)
-    return W.contiguous(), scale, shift, cout
+    return _pack(w.t(), 1, cin, cin_pad, cout), scale, shift, cout
 
 
 def pack_spconv(weight, bn=None, cin_pad=None):
@@ -47,10 +62,8 @@ def pack_spconv(weight, bn=None, cin_pad=None):
     cin, cout = w.shape[-2], w.shape[-1]
     kvol = w.numel() // (cin * cout)
     cin_pad = cin_pad or _pad16(cin)
-    W = torch.zeros((kvol, cin_pad, _pad32(cout)), dtype=torch.float32, device=w.device)
-    W[:, :cin, :cout] = w.reshape(kvol, cin, cout)
     scale, shift = fold_bn(None, bn, cout, w.device)
-    return W.contiguous(), scale, shift, cout
+    return _pack(w.reshape(kvol, cin, cout), kvol, cin, cin_pad, cout), scale, shift, cout
 
 
 class PackedModule(nn.Module):

@@ -67,7 +67,7 @@ def _devoxelize(batch_dict, points, centers, feat, batch_size):
     pt_off, vx_off = _frame_layout(points, centers, batch_size)
     if "conv_point_indices" in batch_dict and "voxel_geometry" in batch_dict:
         vs, rng = batch_dict["voxel_geometry"]
-        return ops.devoxelize_grid(points, batch_dict["conv_point_indices"], centers, vx_off, batch_size, vs, rng, feat), vx_off
+        return ops.devoxelize_grid(points, pt_off, batch_dict["conv_point_indices"], centers, vx_off, batch_size, vs, rng, feat), vx_off
     return ops.devoxelize(points, pt_off, centers, vx_off, batch_size, points.shape[0], feat), vx_off
 
 

@@ -89,8 +89,11 @@ int __syncthreads_count(int pred);
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 
+namespace hipsim { extern char dyn_smem[160 * 1024]; }
+#define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)hipsim::dyn_smem;
 template <typename... KArgs, typename... Args>
-inline void hipLaunchKernelGGL(void (*k)(KArgs...), dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
+inline void hipLaunchKernelGGL(void (*k)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t, Args... args) {
+  if (shmem > sizeof(hipsim::dyn_smem)) { fprintf(stderr, "hipsim: dynamic LDS too large\n"); abort(); }
   hipsim::run_grid(grid, block, [=]() { k(args...); });
 }
 

@@ -31,6 +31,7 @@ hipsim_switch:
 )");
 
 namespace hipsim {
+char dyn_smem[160 * 1024];
 std::vector<Fiber> fibers;
 void *sched_sp = nullptr;
 int cur = 0;

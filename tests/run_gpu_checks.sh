@@ -12,6 +12,13 @@ if [ "${PROFILE:-1}" = "1" ]; then
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof.log 2>&1
   echo "rocprof rc=$?" >> $OUT/summary.txt
+  if [ "${PMC:-0}" = "1" ]; then
+    # HBM traffic counters: separate passes (FETCH_SIZE takes 3 of the 4 TCC slots), kernel-trace only
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+      echo "pmc $c rc=$?" >> $OUT/summary.txt
+    done
+  fi
   cd "$R"
 fi
 tail -5 $OUT/pytest_gpu.log; cat $OUT/summary.txt; tail -3 $OUT/smoke.log; cat $OUT/bench.log

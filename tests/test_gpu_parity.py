@@ -226,7 +226,7 @@ def test_devoxelize_grid_equals_brute_force_120k():
     ctr = ops.voxel_centers(coords, cfg["voxel_size"], cfg["pc_range"])
     feat = torch.randn((V, 32), device=DEV)
     pt_off, vx_off = ops.frame_offsets(p[:, 0], 2), ops.frame_offsets(ctr[:, 0], 2)
-    a, ia = ops.devoxelize_grid(p, coords, ctr, vx_off, 2, cfg["voxel_size"], cfg["pc_range"], feat, return_idx=True)
+    a, ia = ops.devoxelize_grid(p, pt_off, coords, ctr, vx_off, 2, cfg["voxel_size"], cfg["pc_range"], feat, return_idx=True)
     b, ib = ops.devoxelize(p, pt_off, ctr, vx_off, 2, p.shape[0], feat, return_idx=True)
     assert torch.equal(ia, ib)
     assert torch.equal(a, b)
