@@ -172,9 +172,14 @@ typedef struct {
  * (kD,kH,kW,Cin,Cout) flattened, or a transposed nn.Linear weight with kvol = 1).  Output (w_packed, holding
  * ls3d_gather_gemm_packed_floats(kvol,cin_pad,cout) floats): zero padded to cin_pad (multiple of 16) rows and
  * roundup(cout,32) columns, laid out [kvol][slab][cin_pad][32][NT] so that a workgroup's weight chunk is one
- * contiguous copy into LDS and a lane's MFMA B operands for one k-step are one LDS read. */
+ * contiguous copy into LDS and a lane's MFMA B operands for one k-step are one LDS read.
+ * NT (1..4, must divide roundup(cout,32)/32) is the number of 32-column blocks one workgroup computes: large NT
+ * = fewer, fatter workgroups (best MFMA/byte ratio), small NT = more workgroups (needed to fill 256 CUs when
+ * the row count is small).  nt == 0 selects ls3d_gather_gemm_default_nt(cout).  The same nt must be passed
+ * to ls3d_gather_gemm. */
 size_t ls3d_gather_gemm_packed_floats(int kvol, int cin_pad, int cout);
-int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, float *w_packed,
+int ls3d_gather_gemm_default_nt(int cout);
+int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, int nt, float *w_packed,
                           ls3d_stream_t stream);
 
 /* out[r, 0..cout) = epilogue( sum_k W[k]^T * in[tbl[r,k]] ), tbl == NULL means the identity table with
@@ -183,7 +188,7 @@ int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_p
  * f32 MFMA (v_mfma_f32_32x32x2_f32): exact f32 products and accumulation.
  * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
  * (tbl = nbr_inv) and every nn.Linear on the path. */
-int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int cin, int cout,
+int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int nt, int cin, int cout,
                      int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
                      int out_ld, ls3d_stream_t stream);
 
@@ -222,7 +227,7 @@ int ls3d_devoxelize(const float *points, int pt_stride, int n_points, const int3
                     const float *feat, int feat_ld, int c, float *out, int out_ld, int32_t *idx_out,
                     ls3d_stream_t stream);
 
-size_t ls3d_devoxelize_grid_workspace_bytes(int n_voxels, int batch, const int32_t grid_xyz_host[3]);
+size_t ls3d_devoxelize_grid_workspace_bytes(int n_points, int n_voxels, int batch, const int32_t grid_xyz_host[3]);
 
 /* Same result as ls3d_devoxelize (bit-identical neighbours and weights) when the known points are voxel
  * centres on a regular lattice: the centres are binned into coarse cells (counting sort) and each point

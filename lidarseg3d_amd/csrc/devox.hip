@@ -214,22 +214,56 @@ __global__ __launch_bounds__(256) void k_cg_fill(const float *centers, int n, co
   }
 }
 
+// own coarse cell of a point (fine coordinate as in voxelization, clamped into the grid)
+__device__ __forceinline__ void cg_point_cell(const CGeom &g, const float *pu, int *cc) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float fcoord = floorf(__fdiv_rn(__fsub_rn(pu[a], g.lo[a]), g.vs[a]));
+    fcoord = fminf(fmaxf(fcoord, 0.0f), (float)(g.grid[a] - 1));
+    cc[a] = min((int)fcoord / g.cg[a], g.dim[a] - 1);
+  }
+}
+
+// The query points are processed in coarse-cell order (counting sort -> `perm`): the lanes of a wave then walk
+// the same cells, so the search neither diverges nor scatters its candidate reads, whatever order the LiDAR
+// points arrive in.
+__global__ __launch_bounds__(256) void k_pt_count(const float *points, int pt_stride, int n, CGeom g, int32_t *cell_of, int32_t *cnt) {
+  const int ncf = g.dim[0] * g.dim[1] * g.dim[2];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float *u = points + (size_t)i * pt_stride;
+    int cc[3];
+    cg_point_cell(g, u + 1, cc);
+    const int cell = (int)u[0] * ncf + (cc[2] * g.dim[1] + cc[1]) * g.dim[0] + cc[0];
+    cell_of[i] = cell;
+    atomicAdd(&cnt[cell], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pt_fill(int n, const int32_t *cell_of, const int32_t *start, int32_t *cursor, int32_t *perm) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int cell = cell_of[i];
+    perm[start[cell] + atomicAdd(&cursor[cell], 1)] = i;
+  }
+}
+
 // grid = (ceil(max_frame_points/256), batch); dynamic LDS = the frame's coarse-cell occupancy bitmap, so that
 // walking through empty space costs LDS bit tests only.
-__global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_stride, const int32_t *pt_off, CGeom g, const int32_t *start,
-                                                   const float4 *sorted, const uint32_t *occ, const int32_t *vx_off, const float *feat,
-                                                   int feat_ld, int C, float *out, int out_ld, int32_t *idx_out) {
+__global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_stride, const int32_t *pt_off, const int32_t *perm, CGeom g,
+                                                   const int32_t *start, const float4 *sorted, const uint32_t *occ, const int32_t *vx_off,
+                                                   const float *feat, int feat_ld, int C, float *out, int out_ld, int32_t *idx_out) {
   HIP_DYNAMIC_SHARED(uint32_t, s_occ)
   __shared__ int s_idx[256 * 3];
   __shared__ float s_w[256 * 3];
+  __shared__ int s_pt[256];
   const int frame = blockIdx.y;
   const int p0 = pt_off[frame], p1 = pt_off[frame + 1];
   const int first = p0 + blockIdx.x * 256;
   if (first >= p1) return;  // block-uniform
   for (int w = threadIdx.x; w < g.wpf; w += 256) s_occ[w] = occ[(size_t)frame * g.wpf + w];
   __syncthreads();
-  const int i = first + threadIdx.x;
-  const bool active = i < p1;
+  const bool active = first + (int)threadIdx.x < p1;
+  const int i = active ? perm[first + threadIdx.x] : 0;  // points are visited in coarse-cell order
+  s_pt[threadIdx.x] = i;
   const int ncf = g.dim[0] * g.dim[1] * g.dim[2];
   const int32_t *fstart = start + (size_t)frame * ncf;
   Top3 t;
@@ -240,12 +274,9 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
     const float pu[3] = {ux, uy, uz};
     float gap[3], cs[3];
     int cc[3];
+    cg_point_cell(g, pu, cc);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      // own coarse cell: fine coordinate as in voxelization, clamped into the grid
-      float fcoord = floorf(__fdiv_rn(__fsub_rn(pu[a], g.lo[a]), g.vs[a]));
-      fcoord = fminf(fmaxf(fcoord, 0.0f), (float)(g.grid[a] - 1));
-      cc[a] = min((int)fcoord / g.cg[a], g.dim[a] - 1);
       cs[a] = g.vs[a] * (float)g.cg[a];
       const float clo = g.lo[a] + cs[a] * (float)cc[a];
       // the last coarse cell of an axis may hold more fine cells: use its true upper face
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
   for (int e = threadIdx.x; e < cnt * c4n; e += 256) {
     const int p = e / c4n, c4 = e % c4n;
     if (m <= 0) {
-      *(float4 *)(out + (size_t)(first + p) * out_ld + c4 * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      *(float4 *)(out + (size_t)s_pt[p] * out_ld + c4 * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       continue;
     }
     const float w0 = s_w[p * 3], w1 = s_w[p * 3 + 1], w2 = s_w[p * 3 + 2];
@@ -324,7 +355,7 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
     o.y = fmaf(w2, c.y, fmaf(w1, b.y, w0 * a.y));
     o.z = fmaf(w2, c.z, fmaf(w1, b.z, w0 * a.z));
     o.w = fmaf(w2, c.w, fmaf(w1, b.w, w0 * a.w));
-    *(float4 *)(out + (size_t)(first + p) * out_ld + c4 * 4) = o;
+    *(float4 *)(out + (size_t)s_pt[p] * out_ld + c4 * 4) = o;
   }
 }
 
@@ -341,13 +372,17 @@ static void cg_setup(const int32_t grid_xyz[3], CGeom &g) {
   }
 }
 
-extern "C" size_t ls3d_devoxelize_grid_workspace_bytes(int n_voxels, int batch, const int32_t grid_xyz[3]) {
+static size_t dv_points_ws(int n_points, long long ncell);
+extern "C" size_t ls3d_devoxelize_grid_workspace_bytes(int n_points, int n_voxels, int batch, const int32_t grid_xyz[3]) {
   CGeom g;
   cg_setup(grid_xyz, g);
   const long long ncell = (long long)batch * g.dim[0] * g.dim[1] * g.dim[2];
-  return dv_align((size_t)(n_voxels > 0 ? n_voxels : 1) * 4) + 3 * dv_align((size_t)(ncell + 1) * 4) + dv_align(ls3d_scan_tmp_ints(ncell + 1) * 4) +
+  return dv_points_ws(n_points, ncell) + dv_align((size_t)(n_voxels > 0 ? n_voxels : 1) * 4) + 3 * dv_align((size_t)(ncell + 1) * 4) + dv_align(ls3d_scan_tmp_ints(ncell + 1) * 4) +
          dv_align((size_t)(n_voxels > 0 ? n_voxels : 1) * 16) + dv_align((size_t)batch * g.wpf * 4);
 }
+
+// extra workspace for the coarse-cell ordering of the query points
+static size_t dv_points_ws(int n_points, long long ncell) { return 2 * dv_align((size_t)(n_points > 0 ? n_points : 1) * 4) + 3 * dv_align((size_t)(ncell + 1) * 4); }
 
 extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *pt_off, int max_frame_points,
                                     const int32_t *coords, const float *centers, int n_voxels, const int32_t *n_voxels_dev,
@@ -359,7 +394,7 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
       pt_stride < 4)
     return LS3D_ERR_ARG;
   if ((c % 4) || (feat_ld % 4) || (out_ld % 4) || feat_ld < c || out_ld < c || n_voxels < 1) return LS3D_ERR_ARG;
-  if (workspace_bytes < ls3d_devoxelize_grid_workspace_bytes(n_voxels, batch, grid_xyz)) return LS3D_ERR_WORKSPACE;
+  if (workspace_bytes < ls3d_devoxelize_grid_workspace_bytes(n_points, n_voxels, batch, grid_xyz)) return LS3D_ERR_WORKSPACE;
   if (n_points == 0 || max_frame_points == 0) return LS3D_OK;
   CGeom g;
   for (int a = 0; a < 3; ++a) { g.vs[a] = vs[a]; g.lo[a] = lo[a]; g.grid[a] = grid_xyz[a]; }
@@ -373,7 +408,18 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   int32_t *cursor = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
   int32_t *scan_tmp = (int32_t *)base; base += dv_align(ls3d_scan_tmp_ints(ncell + 1) * 4);
   float4 *sorted = (float4 *)base; base += dv_align((size_t)n_voxels * 16);
-  uint32_t *occ = (uint32_t *)base;
+  uint32_t *occ = (uint32_t *)base; base += dv_align((size_t)batch * g.wpf * 4);
+  int32_t *pcell = (int32_t *)base; base += dv_align((size_t)n_points * 4);
+  int32_t *perm = (int32_t *)base; base += dv_align((size_t)n_points * 4);
+  int32_t *pcnt = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  int32_t *pstart = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  int32_t *pcursor = (int32_t *)base;
+  hipMemsetAsync(pcnt, 0, (size_t)(ncell + 1) * 4, stream);
+  hipMemsetAsync(pcursor, 0, (size_t)(ncell + 1) * 4, stream);
+  hipLaunchKernelGGL(k_pt_count, ls3d_grid(n_points), dim3(256), 0, stream, points, pt_stride, n_points, g, pcell, pcnt);
+  int rcp = ls3d_exclusive_scan_i32(pcnt, pstart, (int)(ncell + 1), scan_tmp, nullptr, stream);
+  if (rcp != LS3D_OK) return rcp;
+  hipLaunchKernelGGL(k_pt_fill, ls3d_grid(n_points), dim3(256), 0, stream, n_points, (const int32_t *)pcell, (const int32_t *)pstart, pcursor, perm);
   hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * 4, stream);
   hipMemsetAsync(cursor, 0, (size_t)(ncell + 1) * 4, stream);
   hipMemsetAsync(occ, 0, (size_t)batch * g.wpf * 4, stream);
@@ -382,8 +428,8 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   if (rc != LS3D_OK) return rc;
   hipLaunchKernelGGL(k_cg_fill, ls3d_grid(n_voxels), dim3(256), 0, stream, centers, n_voxels, n_voxels_dev, vx_off, (const int32_t *)cell_of,
                      (const int32_t *)start, cursor, sorted);
-  hipLaunchKernelGGL(k_devox_grid, dim3((max_frame_points + 255) / 256, batch), dim3(256), (size_t)g.wpf * 4, stream, points, pt_stride, pt_off, g,
-                     (const int32_t *)start, (const float4 *)sorted, (const uint32_t *)occ, vx_off, feat, feat_ld, c, out, out_ld, idx_out);
+  hipLaunchKernelGGL(k_devox_grid, dim3((max_frame_points + 255) / 256, batch), dim3(256), (size_t)g.wpf * 4, stream, points, pt_stride, pt_off,
+                     (const int32_t *)perm, g, (const int32_t *)start, (const float4 *)sorted, (const uint32_t *)occ, vx_off, feat, feat_ld, c, out, out_ld, idx_out);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

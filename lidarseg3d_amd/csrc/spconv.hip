@@ -269,18 +269,24 @@ extern "C" size_t ls3d_gather_gemm_packed_floats(int kvol, int cin_pad, int cout
   return (size_t)kvol * cin_pad * ((cout + 31) / 32 * 32);
 }
 
-extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, float *w_packed,
+extern "C" int ls3d_gather_gemm_default_nt(int cout) { return gg_nt(cout); }
+
+static inline bool gg_nt_ok(int cout, int nt) { return nt >= 1 && nt <= 4 && (((cout + 31) / 32) % nt) == 0; }
+
+extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, int nt, float *w_packed,
                                      ls3d_stream_t stream) {
   if (!w_plain || !w_packed || kvol < 1 || cin_src < 1 || cin_pad < cin_src || (cin_pad % 16) || cout < 1) return LS3D_ERR_ARG;
+  if (nt == 0) nt = gg_nt(cout);
+  if (!gg_nt_ok(cout, nt)) return LS3D_ERR_ARG;
   const long long total = (long long)ls3d_gather_gemm_packed_floats(kvol, cin_pad, cout);
-  hipLaunchKernelGGL(k_gg_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, gg_nt(cout),
-                     w_packed);
+  hipLaunchKernelGGL(k_gg_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt, w_packed);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
 
-extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int cin, int cout, int n_rows,
-                                const int32_t *n_rows_dev, const ls3d_epilogue_t *epi, float *out, int out_ld, ls3d_stream_t stream_) {
+extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int nt, int cin, int cout,
+                                int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi, float *out, int out_ld,
+                                ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !w || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
@@ -294,7 +300,8 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   }
   const int w_ld = (cout + 31) / 32 * 32;
   const int nt_total = w_ld / 32;
-  const int nt = gg_nt(cout);
+  if (nt == 0) nt = gg_nt(cout);
+  if (!gg_nt_ok(cout, nt)) return LS3D_ERR_ARG;
   const int slabs = nt_total / nt;
   const int ntiles = (n_rows + 127) / 128;
   dim3 grid((unsigned)(ntiles < 2048 ? ntiles : 2048), (unsigned)slabs);

@@ -225,12 +225,22 @@ def rulebook_conv(coords, batch, shape_zyx, ksize, stride, pad, out_cap=None):
     return oc, cnt, nbr_out, nbr_inv, oshape
 
 
-def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout):
-    """plain [kvol,cin,cout] -> kernel layout (flat tensor)"""
+def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0):
+    """plain [kvol,cin,cout] -> kernel layout (flat tensor) for column-block count nt (0 = default)"""
     L = _L()
     out = torch.empty((L.ls3d_gather_gemm_packed_floats(kvol, cin_pad, cout),), dtype=torch.float32, device=w_plain.device)
-    check(L.ls3d_gather_gemm_pack(_ptr(w_plain), kvol, cin, cin_pad, cout, _ptr(out), _stream(w_plain)), "ls3d_gather_gemm_pack")
+    check(L.ls3d_gather_gemm_pack(_ptr(w_plain), kvol, cin, cin_pad, cout, nt, _ptr(out), _stream(w_plain)), "ls3d_gather_gemm_pack")
     return out
+
+
+def choose_nt(cout, n_rows, target_blocks=1024):
+    """column blocks per workgroup: the widest slab that still yields ~4 workgroups per CU (256 CUs)"""
+    total = (cout + 31) // 32
+    tiles = max((n_rows + 127) // 128, 1)
+    for nt in (4, 3, 2, 1):
+        if total % nt == 0 and tiles * (total // nt) >= target_blocks:
+            return nt
+    return 1
 
 
 def gather_gemm(x, w, tbl=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
@@ -242,6 +252,9 @@ def gather_gemm(x, w, tbl=None, n_rows=None, cout=None, scale=None, shift=None, 
     in_ld = in_ld or x.shape[1]
     cout = cout or w.cout
     assert cout == w.cout, "packed layout depends on cout"
+    rows_hint = tbl.shape[0] if (tbl is not None and n_rows is None) else (n_rows if n_rows is not None else x.shape[0])
+    nt = choose_nt(cout, rows_hint)
+    wdata = w.for_nt(nt)
     if tbl is not None:
         n_rows = tbl.shape[0] if n_rows is None else n_rows
         assert tbl.shape[1] == kvol
@@ -256,7 +269,7 @@ def gather_gemm(x, w, tbl=None, n_rows=None, cout=None, scale=None, shift=None, 
         out_ld = out_ld or out.shape[1]
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0)
-    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), kvol, _ptr(w.data), cin, cout, n_rows, None, ctypes.byref(epi),
+    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), kvol, _ptr(wdata), nt, cin, cout, n_rows, None, ctypes.byref(epi),
                                 _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
     return out
 
@@ -339,7 +352,7 @@ def devoxelize_grid(points, pt_off, coords, centers, vx_off, batch, voxel_size, 
     idx = torch.empty((n, 3), dtype=_i32, device=points.device) if return_idx else None
     L = _L()
     V = coords.shape[0]
-    ws = _ws(L.ls3d_devoxelize_grid_workspace_bytes(V, batch, _i3(grid)), points)
+    ws = _ws(L.ls3d_devoxelize_grid_workspace_bytes(n, V, batch, _i3(grid)), points)
     check(L.ls3d_devoxelize_grid(_ptr(points), points.shape[1], n, _ptr(pt_off), n, _ptr(coords), _ptr(centers), V, None, _ptr(vx_off), batch,
                                  _f3(voxel_size), _f3(pc_range[:3]), _i3(grid), _ptr(feat), feat.shape[1], c, _ptr(out), c,
                                  _ptr(idx), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(points)), "ls3d_devoxelize_grid")

@@ -29,11 +29,20 @@ def fold_bn(bias, bn, cout, dev):
 
 
 class PackedWeight(object):
-    """kernel-layout weights (ls3d_gather_gemm_pack) + the logical shape"""
-    __slots__ = ("data", "kvol", "cin", "cout")
+    """kernel-layout weights (ls3d_gather_gemm_pack).  The layout depends on the column-block count `nt` the launch
+    uses (chosen from the row count, ops.choose_nt), so packed copies are made lazily per nt and cached."""
+    __slots__ = ("plain", "kvol", "cin_src", "cin", "cout", "_by_nt")
 
-    def __init__(self, data, kvol, cin, cout):
-        self.data, self.kvol, self.cin, self.cout = data, kvol, cin, cout
+    def __init__(self, plain, kvol, cin_src, cin_pad, cout):
+        self.plain, self.kvol, self.cin_src, self.cin, self.cout = plain, kvol, cin_src, cin_pad, cout
+        self._by_nt = {}
+
+    def for_nt(self, nt):
+        d = self._by_nt.get(nt)
+        if d is None:
+            from . import ops
+            d = self._by_nt[nt] = ops.gather_gemm_pack(self.plain, self.kvol, self.cin_src, self.cin, self.cout, nt)
+        return d
 
     @property
     def shape(self):  # (kvol, cin_pad, cout_pad) — what callers size their inputs against
@@ -41,8 +50,7 @@ class PackedWeight(object):
 
 
 def _pack(plain, kvol, cin, cin_pad, cout):
-    from . import ops
-    return PackedWeight(ops.gather_gemm_pack(plain.contiguous(), kvol, cin, cin_pad, cout), kvol, cin_pad, cout)
+    return PackedWeight(plain.contiguous(), kvol, cin, cin_pad, cout)
 
 
 def pack_linear(weight, bias=None, bn=None, cin_pad=None):

@@ -79,9 +79,8 @@ def test_gather_gemm_layout_asymmetric():
     for m, k, n in ((200, 16, 17), (333, 48, 64), (1000, 128, 96), (129, 256, 192)):
         a = rng.normal(size=(m, k)).astype(np.float32)
         b = rng.normal(size=(k, n)).astype(np.float32)
-        W = torch.zeros((1, k, (n + 31) // 32 * 32))
-        W[0, :, :n] = torch.from_numpy(b)
-        out = ops.gather_gemm(cu(a), W.to(DEV), cout=n)
+        from lidarseg3d_amd.packing import PackedWeight
+        out = ops.gather_gemm(cu(a), PackedWeight(cu(b).reshape(1, k, n).contiguous(), 1, k, k, n), cout=n)
         np.testing.assert_allclose(out.cpu().numpy(), a.astype(np.float64) @ b.astype(np.float64), rtol=0, atol=2e-4)
 
 
