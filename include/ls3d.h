@@ -154,6 +154,13 @@ int ls3d_rulebook_conv(const int32_t *coords_in, int n_in, const int32_t *n_in_d
                        size_t workspace_bytes, int32_t *out_coords, int out_cap, int32_t *n_out_dev,
                        int32_t *nbr_out, int32_t *nbr_inv, int32_t *overflow_dev, ls3d_stream_t stream);
 
+/* mask[r] = bitmask of the kernel offsets with an active neighbour in row r of a rulebook table (kvol <= 31).
+ * A permutation of the rows sorted by this key, passed as `row_order` to ls3d_gather_gemm, makes the rows that a
+ * wave processes together share their empty offsets, so whole MFMA groups / weight chunks are skipped (the same
+ * idea as spconv v2's mask-sorted implicit GEMM).  Results are written to the original rows: only the processing
+ * order changes. */
+int ls3d_rulebook_masks(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int32_t *mask, ls3d_stream_t stream);
+
 /* Fused epilogue of the gather-GEMM (all optional):
  *   v = acc * scale[c] + shift[c]           (folded eval BatchNorm / bias)
  *   v += res_pre[r*res_pre_ld + c]          (SparseBasicBlock identity, scn_unet.py:66)
@@ -186,9 +193,10 @@ int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_p
  * kvol == 1 (a dense Linear layer).  in[*, cin] row stride in_ld, `w` = weights packed by
  * ls3d_gather_gemm_pack with cin_pad == cin, out row stride out_ld.  cin must be a multiple of 16, in_ld of 4.
  * f32 MFMA (v_mfma_f32_32x32x2_f32): exact f32 products and accumulation.
+ * row_order (optional, int32[n_rows]): tile slot i processes output row row_order[i] (see ls3d_rulebook_masks).
  * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
  * (tbl = nbr_inv) and every nn.Linear on the path. */
-int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int nt, int cin, int cout,
+int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int cin, int cout,
                      int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
                      int out_ld, ls3d_stream_t stream);
 

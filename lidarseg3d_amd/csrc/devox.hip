@@ -312,11 +312,19 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
               const int cell = wlo + __ffs((int)m) - 1;
               m &= m - 1;
               const int s0 = fstart[cell], s1 = fstart[cell + 1];
-              for (int j = s0; j < s1; ++j) {
-                const float4 q = sorted[j];
-                const float dx = ux - q.x, dy = uy - q.y, dz = uz - q.z;
-                const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                top3_push_lex(t, d, __float_as_int(q.w));
+              // 4 candidates per trip, loads issued together: the scan is latency-, not ALU-bound
+              for (int j = s0; j < s1; j += 4) {
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = sorted[min(j + u, s1 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  if (j + u < s1) {
+                    const float dx = ux - q[u].x, dy = uy - q[u].y, dz = uz - q[u].z;
+                    const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    top3_push_lex(t, d, __float_as_int(q[u].w));
+                  }
+                }
               }
             }
           }

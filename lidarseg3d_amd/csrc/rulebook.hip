@@ -125,6 +125,17 @@ __global__ __launch_bounds__(256) void k_conv_tables(const int32_t *coords, int 
   }
 }
 
+// neighbour bitmask of every table row (bit k set <=> tbl[r][k] >= 0), kvol <= 32.  Rows sorted by this key give
+// the gather-GEMM tiles whose rows share their empty kernel offsets.
+__global__ __launch_bounds__(256) void k_tbl_mask(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int32_t *mask) {
+  const int N = ls3d_count(n, n_dev);
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) {
+    uint32_t m = 0;
+    for (int k = 0; k < kvol; ++k) m |= (tbl[(size_t)r * kvol + k] >= 0 ? 1u : 0u) << k;
+    mask[r] = (int32_t)m;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fill_m1(int32_t *p, long long n) {
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) p[t] = -1;
 }
@@ -151,6 +162,14 @@ extern "C" int ls3d_rulebook_subm(const int32_t *coords, int n, const int32_t *n
   const int kvol = ksize[0] * ksize[1] * ksize[2];
   hipLaunchKernelGGL(k_subm, ls3d_grid((long long)n * kvol), dim3(256), 0, stream, coords, n, n_dev, Shape3{shape[0], shape[1], shape[2]},
                      Shape3{ksize[0], ksize[1], ksize[2]}, keys, vals, (uint32_t)(cap - 1), nbr);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_rulebook_masks(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int32_t *mask, ls3d_stream_t stream) {
+  if (!tbl || !mask || n < 0 || kvol < 1 || kvol > 31) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  hipLaunchKernelGGL(k_tbl_mask, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, tbl, n, n_dev, kvol, mask);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

@@ -29,9 +29,10 @@ struct EpiDev {
 };
 
 template <int KC, int NT>
-__global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl, int kvol,
-                                                    const float *__restrict__ w, int cin, int w_ld, int cout, int n_rows,
-                                                    const int32_t *n_rows_dev, EpiDev e, float *__restrict__ out, int out_ld) {
+__global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
+                                                    const int32_t *__restrict__ order, int kvol, const float *__restrict__ w, int cin,
+                                                    int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
+                                                    float *__restrict__ out, int out_ld) {
   constexpr int SPL = KC / 2;                          // floats of a row chunk held per lane
   constexpr int SLAB = NT * 32;                        // output columns handled by this workgroup
   constexpr int BV = KC * SLAB / 4;                    // float4s in one weight chunk
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
   struct alignas(NT == 3 ? 4 : 4 * NT) BVec { float v[NT]; };
   __shared__ __attribute__((aligned(16))) float Bs[2][KC * SLAB];  // double-buffered weight chunk
   __shared__ unsigned long long s_kmask;               // kernel offsets with an active neighbour in this tile
+  __shared__ int s_rows[128];                          // output row handled by each tile slot (-1 = none)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kk = lane >> 5;
   const int n0 = blockIdx.y * SLAB;
@@ -47,18 +49,24 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
   const int nslab = w_ld / SLAB;
   const float *wbase = w + (size_t)blockIdx.y * cin * SLAB;  // packed: [kvol][slab][cin][32][NT]
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row = tile * 128 + wave * 32 + col;
-    // ---- which kernel offsets does this tile / this wave need at all?
+    // ---- tile slots -> output rows.  With `order` (rows sorted by their neighbour bitmask, rulebook.hip) the 32
+    //      rows of a wave share most of their empty kernel offsets, so the skips below remove most zero work.
     if (tid == 0) s_kmask = 0ull;
+    if (tid < 128) {
+      const int r = tile * 128 + tid;
+      s_rows[tid] = r < N ? (order ? order[r] : r) : -1;
+    }
     __syncthreads();
+    const int row = s_rows[wave * 32 + col];
+    // ---- which kernel offsets does this tile / this wave need at all?
     unsigned long long wmask = 0ull;
     if (tbl) {
       for (int k = 0; k < kvol; ++k) {
-        const int idx = (row < N) ? tbl[(size_t)row * kvol + k] : -1;
+        const int idx = (row >= 0) ? tbl[(size_t)row * kvol + k] : -1;
         if (__any(idx >= 0)) wmask |= 1ull << k;
       }
     } else {
-      wmask = __any(row < N) ? 1ull : 0ull;
+      wmask = __any(row >= 0) ? 1ull : 0ull;
     }
     if (lane == 0 && wmask) atomicOr(&s_kmask, wmask);
     __syncthreads();
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
       int k_cur = __ffsll((long long)rem) - 1;
       rem &= rem - 1;
       int k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
-#define LS3D_LOAD_IDX(k) ((row < N) ? (tbl ? tbl[(size_t)row * kvol + (k)] : row) : -1)
+#define LS3D_LOAD_IDX(k) ((row >= 0) ? (tbl ? tbl[(size_t)row * kvol + (k)] : row) : -1)
 #define LS3D_LOAD_A(dst, idx, c0_)                                                              \
   do {                                                                                          \
     if ((idx) >= 0) {                                                                           \
@@ -186,12 +194,11 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
           for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB + n * 32] = acc[n][r];
       }
       __syncthreads();
-      const int prow0 = tile * 128 + pass * RPP;
       if (vec) {
         for (int i = tid; i < RPP * (SLAB / 4); i += 256) {
           const int lr = i / (SLAB / 4), c4 = i % (SLAB / 4);
-          const int orow = prow0 + lr, oc = n0 + c4 * 4;
-          if (orow < N && oc < cout) {
+          const int orow = s_rows[pass * RPP + lr], oc = n0 + c4 * 4;
+          if (orow >= 0 && oc < cout) {
             float4 v = *(const float4 *)(stage + lr * SLAB + c4 * 4);
             if (e.scale) {
               const float4 sc = *(const float4 *)(e.scale + oc);
@@ -217,8 +224,8 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
       } else {
         for (int i = tid; i < RPP * SLAB; i += 256) {
           const int lr = i / SLAB, c = i % SLAB;
-          const int orow = prow0 + lr, oc = n0 + c;
-          if (orow < N && oc < cout) {
+          const int orow = s_rows[pass * RPP + lr], oc = n0 + c;
+          if (orow >= 0 && oc < cout) {
             float v = stage[lr * SLAB + c];
             if (e.scale) v *= e.scale[oc];
             if (e.shift) v += e.shift[oc];
@@ -235,10 +242,10 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
 }
 
 template <int KC, int NT>
-static void launch_gg(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int cin,
-                      int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
-  hipLaunchKernelGGL((k_gather_gemm<KC, NT>), grid, dim3(256), 0, stream, in, in_ld, tbl, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e,
-                     out, out_ld);
+static void launch_gg(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
+                      const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
+  hipLaunchKernelGGL((k_gather_gemm<KC, NT>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
+                     n_rows_dev, e, out, out_ld);
 }
 
 // column-block decomposition shared by the kernel dispatch and the weight packer
@@ -284,7 +291,7 @@ extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src
   return LS3D_OK;
 }
 
-extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, int kvol, const float *w, int nt, int cin, int cout,
+extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int cin, int cout,
                                 int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi, float *out, int out_ld,
                                 ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -306,7 +313,7 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   const int ntiles = (n_rows + 127) / 128;
   dim3 grid((unsigned)(ntiles < 2048 ? ntiles : 2048), (unsigned)slabs);
   const bool k32 = (cin % 32) == 0;
-#define LS3D_GG(KC, NT) launch_gg<KC, NT>(grid, stream, in, in_ld, tbl, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld)
+#define LS3D_GG(KC, NT) launch_gg<KC, NT>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld)
   if (k32) {
     switch (nt) { case 1: LS3D_GG(32, 1); break; case 2: LS3D_GG(32, 2); break; case 3: LS3D_GG(32, 3); break; default: LS3D_GG(32, 4); }
   } else {

@@ -225,6 +225,17 @@ def rulebook_conv(coords, batch, shape_zyx, ksize, stride, pad, out_cap=None):
     return oc, cnt, nbr_out, nbr_inv, oshape
 
 
+def rulebook_order(tbl):
+    """processing order of a rulebook table's rows: sorted by neighbour bitmask (kernel ls3d_rulebook_masks; the
+    sort itself is torch.argsort — plumbing, to be replaced by a radix sort kernel)."""
+    n, kvol = tbl.shape
+    if n == 0 or kvol > 31:
+        return None
+    mask = torch.empty((n,), dtype=_i32, device=tbl.device)
+    check(_L().ls3d_rulebook_masks(_ptr(tbl), n, None, kvol, _ptr(mask), _stream(tbl)), "ls3d_rulebook_masks")
+    return torch.argsort(mask).to(_i32)
+
+
 def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0):
     """plain [kvol,cin,cout] -> kernel layout (flat tensor) for column-block count nt (0 = default)"""
     L = _L()
@@ -243,7 +254,7 @@ def choose_nt(cout, n_rows, target_blocks=1024):
     return 1
 
 
-def gather_gemm(x, w, tbl=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
+def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
                 out=None, out_ld=None, in_ld=None, cin=None):
     """out[r, :cout] = epilogue(sum_k W[k]^T x[tbl[r,k]]).  w: packing.PackedWeight."""
     kvol, wcin, wld = w.shape
@@ -269,7 +280,7 @@ def gather_gemm(x, w, tbl=None, n_rows=None, cout=None, scale=None, shift=None, 
         out_ld = out_ld or out.shape[1]
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0)
-    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), kvol, _ptr(wdata), nt, cin, cout, n_rows, None, ctypes.byref(epi),
+    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, cin, cout, n_rows, None, ctypes.byref(epi),
                                 _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
     return out
 

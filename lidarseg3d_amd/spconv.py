@@ -55,7 +55,15 @@ class SparseModule(nn.Module):
 
 
 class _Rulebook(object):
-    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index")
+    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index", "_orders")
+
+    def order(self, inverse):
+        """mask-sorted processing order of the (inverse) table, built once per rulebook"""
+        if getattr(self, "_orders", None) is None:
+            self._orders = {}
+        if inverse not in self._orders:
+            self._orders[inverse] = ops.rulebook_order(self.tbl_inv if inverse else self.tbl)
+        return self._orders[inverse]
 
 
 class SparseConvolution(PackedModule, SparseModule):
@@ -90,6 +98,7 @@ class SparseConvolution(PackedModule, SparseModule):
         if rb is not None and self.subm:
             return rb
         rb = _Rulebook()
+        rb._orders = None
         rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)
         if self.subm:
             rb.kind = "subm"
@@ -117,7 +126,7 @@ class SparseConvolution(PackedModule, SparseModule):
         tbl = rb.tbl_inv if self.inverse else rb.tbl
         if feats.shape[1] != W.shape[1]:  # e.g. 13 input channels feeding a 16-wide K chunk
             feats = torch.nn.functional.pad(feats, (0, W.shape[1] - feats.shape[1]))
-        return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, cout=cout, scale=scale, shift=shift, relu=relu,
+        return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, order=rb.order(self.inverse), cout=cout, scale=scale, shift=shift, relu=relu,
                                res_pre=res_pre, pair=pair, out=out, out_ld=out_ld)
 
     def forward(self, x):
