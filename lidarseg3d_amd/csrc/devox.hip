@@ -311,6 +311,17 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
             while (m) {
               const int cell = wlo + __ffs((int)m) - 1;
               m &= m - 1;
+              {
+                // prune: a cell whose box is farther than the current 3rd best cannot contribute (strictly farther,
+                // with a rounding margin, so equal-distance candidates with a lower index are never lost)
+                const int cxi = cell - rowbase;
+                const float bx0 = g.lo[0] + cs[0] * (float)cxi, bx1 = (cxi == g.dim[0] - 1) ? g.lo[0] + g.vs[0] * (float)g.grid[0] : bx0 + cs[0];
+                const float by0 = g.lo[1] + cs[1] * (float)y, by1 = (y == g.dim[1] - 1) ? g.lo[1] + g.vs[1] * (float)g.grid[1] : by0 + cs[1];
+                const float bz0 = g.lo[2] + cs[2] * (float)z, bz1 = (z == g.dim[2] - 1) ? g.lo[2] + g.vs[2] * (float)g.grid[2] : bz0 + cs[2];
+                const float ex = fmaxf(fmaxf(bx0 - ux, ux - bx1), 0.0f), ey = fmaxf(fmaxf(by0 - uy, uy - by1), 0.0f),
+                            ez = fmaxf(fmaxf(bz0 - uz, uz - bz1), 0.0f);
+                if ((ex * ex + ey * ey + ez * ez) * 0.9999f > t.d2) continue;
+              }
               const int s0 = fstart[cell], s1 = fstart[cell + 1];
               // 4 candidates per trip, loads issued together: the scan is latency-, not ALU-bound
               for (int j = s0; j < s1; j += 4) {
