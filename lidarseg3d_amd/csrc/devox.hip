@@ -172,6 +172,8 @@ __global__ __launch_bounds__(256) void k_devoxelize(const float *points, int pt_
 // and ordered lexicographically by (distance, index), which yields exactly the brute-force result
 // (strict '<' in ascending index order == smallest index among equal distances).  Points far outside the
 // range simply walk more shells: always exact, no fallback path.
+#define CG_RMAX 3
+
 struct CGeom {
   float vs[3], lo[3];
   int grid[3];  // fine cells x,y,z
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(256) void k_pt_fill(int n, const int32_t *cell_of, 
 // walking through empty space costs LDS bit tests only.
 __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_stride, const int32_t *pt_off, const int32_t *perm, CGeom g,
                                                    const int32_t *start, const float4 *sorted, const uint32_t *occ, const int32_t *vx_off,
-                                                   const float *feat, int feat_ld, int C, float *out, int out_ld, int32_t *idx_out) {
+                                                   const float *feat, int feat_ld, int C, float *out, int out_ld, int32_t *idx_out,
+                                                   int32_t *hard_list, int32_t *hard_count) {
   HIP_DYNAMIC_SHARED(uint32_t, s_occ)
   __shared__ int s_idx[256 * 3];
   __shared__ float s_w[256 * 3];
@@ -283,8 +286,11 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
       const float chi = (cc[a] == g.dim[a] - 1) ? g.lo[a] + g.vs[a] * (float)g.grid[a] : clo + cs[a];
       gap[a] = fmaxf(fminf(pu[a] - clo, chi - pu[a]), 0.0f);
     }
-    const int rmax = max(g.dim[0], max(g.dim[1], g.dim[2]));
-    for (int r = 0; r <= rmax; ++r) {
+    // Shells up to CG_RMAX resolve all but the ~1 % of points whose neighbours are metres away (isolated returns,
+    // points outside the voxel range); those are handed to k_devox_hard, where a whole workgroup scans the frame
+    // for ONE point — a lane walking thousands of cells alone would stall its wave for milliseconds.
+    bool resolved = false;
+    for (int r = 0; r <= CG_RMAX; ++r) {
       const int z0 = max(cc[2] - r, 0), z1 = min(cc[2] + r, g.dim[2] - 1);
       const int y0 = max(cc[1] - r, 0), y1 = min(cc[1] + r, g.dim[1] - 1);
       const int x0 = max(cc[0] - r, 0), x1 = min(cc[0] + r, g.dim[0] - 1);
@@ -343,15 +349,19 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
       }
       // lower bound on the distance to anything outside the visited box
       const float lb = fminf(gap[0] + (float)r * cs[0], fminf(gap[1] + (float)r * cs[1], gap[2] + (float)r * cs[2]));
-      if (t.d2 < lb * lb * 0.99999f) break;
-      if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1) break;  // whole grid seen
+      if (t.d2 < lb * lb * 0.99999f) { resolved = true; break; }
+      if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1) { resolved = true; break; }
+    }
+    if (!resolved) {
+      hard_list[atomicAdd(hard_count, 1)] = i;
+      s_pt[threadIdx.x] = -1;  // no output from this kernel for the point
     }
   }
   const float r0 = __fdiv_rn(1.0f, sqrtf(t.d0) + 1e-8f), r1 = __fdiv_rn(1.0f, sqrtf(t.d1) + 1e-8f), r2 = __fdiv_rn(1.0f, sqrtf(t.d2) + 1e-8f);
   const float norm = (r0 + r1) + r2;
   s_idx[threadIdx.x * 3 + 0] = t.i0; s_idx[threadIdx.x * 3 + 1] = t.i1; s_idx[threadIdx.x * 3 + 2] = t.i2;
   s_w[threadIdx.x * 3 + 0] = __fdiv_rn(r0, norm); s_w[threadIdx.x * 3 + 1] = __fdiv_rn(r1, norm); s_w[threadIdx.x * 3 + 2] = __fdiv_rn(r2, norm);
-  if (active && idx_out) {
+  if (active && idx_out && s_pt[threadIdx.x] >= 0) {
     int32_t *q = idx_out + (size_t)i * 3;
     q[0] = t.i0; q[1] = t.i1; q[2] = t.i2;
   }
@@ -361,6 +371,7 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
   const int v0 = vx_off[frame], m = vx_off[frame + 1] - v0;
   for (int e = threadIdx.x; e < cnt * c4n; e += 256) {
     const int p = e / c4n, c4 = e % c4n;
+    if (s_pt[p] < 0) continue;
     if (m <= 0) {
       *(float4 *)(out + (size_t)s_pt[p] * out_ld + c4 * 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       continue;
@@ -375,6 +386,70 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
     o.z = fmaf(w2, c.z, fmaf(w1, b.z, w0 * a.z));
     o.w = fmaf(w2, c.w, fmaf(w1, b.w, w0 * a.w));
     *(float4 *)(out + (size_t)s_pt[p] * out_ld + c4 * 4) = o;
+  }
+}
+
+// one workgroup per deferred point: exact scan of every voxel centre of the point's frame, block-wide top-3 merge
+// in lexicographic (distance, index) order, then the interpolated row.
+__global__ __launch_bounds__(256) void k_devox_hard(const float *points, int pt_stride, const int32_t *hard_list, const int32_t *hard_count,
+                                                   const float *centers, const int32_t *vx_off, const float *feat, int feat_ld, int C,
+                                                   float *out, int out_ld, int32_t *idx_out) {
+  __shared__ float s_d[4 * 3];
+  __shared__ int s_i[4 * 3];
+  __shared__ float s_w3[3];
+  __shared__ int s_i3[3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int count = *hard_count;
+  for (int h = blockIdx.x; h < count; h += gridDim.x) {
+    const int i = hard_list[h];
+    const float *u = points + (size_t)i * pt_stride;
+    const int frame = (int)u[0];
+    const float ux = u[1], uy = u[2], uz = u[3];
+    const int v0 = vx_off[frame], m = vx_off[frame + 1] - v0;
+    Top3 t;
+    top3_init(t);
+    for (int k = threadIdx.x; k < m; k += 256) {
+      const float *c = centers + 4 * (size_t)(v0 + k);
+      const float dx = ux - c[1], dy = uy - c[2], dz = uz - c[3];
+      top3_push_lex(t, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), k);
+    }
+    // wave merge (butterfly): after each step every lane holds the top-3 of a growing group
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float e0 = __shfl_xor(t.d0, off), e1 = __shfl_xor(t.d1, off), e2 = __shfl_xor(t.d2, off);
+      const int j0 = __shfl_xor(t.i0, off), j1 = __shfl_xor(t.i1, off), j2 = __shfl_xor(t.i2, off);
+      // untouched slots are (+inf, 0): they never displace a real candidate, and real candidates of both halves are distinct
+      if (e0 < __int_as_float(0x7f800000)) top3_push_lex(t, e0, j0);
+      if (e1 < __int_as_float(0x7f800000)) top3_push_lex(t, e1, j1);
+      if (e2 < __int_as_float(0x7f800000)) top3_push_lex(t, e2, j2);
+    }
+    __syncthreads();  // previous iteration's readers of s_* are done
+    if (lane == 0) {
+      s_d[wave * 3 + 0] = t.d0; s_d[wave * 3 + 1] = t.d1; s_d[wave * 3 + 2] = t.d2;
+      s_i[wave * 3 + 0] = t.i0; s_i[wave * 3 + 1] = t.i1; s_i[wave * 3 + 2] = t.i2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      Top3 b;
+      top3_init(b);
+      for (int q = 0; q < 12; ++q)
+        if (s_d[q] < __int_as_float(0x7f800000)) top3_push_lex(b, s_d[q], s_i[q]);
+      const float r0 = __fdiv_rn(1.0f, sqrtf(b.d0) + 1e-8f), r1 = __fdiv_rn(1.0f, sqrtf(b.d1) + 1e-8f), r2 = __fdiv_rn(1.0f, sqrtf(b.d2) + 1e-8f);
+      const float norm = (r0 + r1) + r2;
+      s_w3[0] = __fdiv_rn(r0, norm); s_w3[1] = __fdiv_rn(r1, norm); s_w3[2] = __fdiv_rn(r2, norm);
+      s_i3[0] = b.i0; s_i3[1] = b.i1; s_i3[2] = b.i2;
+      if (idx_out) { idx_out[(size_t)i * 3] = b.i0; idx_out[(size_t)i * 3 + 1] = b.i1; idx_out[(size_t)i * 3 + 2] = b.i2; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float o = 0.0f;
+      if (m > 0) {
+        const float a = feat[(size_t)(v0 + s_i3[0]) * feat_ld + c], b2 = feat[(size_t)(v0 + s_i3[1]) * feat_ld + c],
+                    c2 = feat[(size_t)(v0 + s_i3[2]) * feat_ld + c];
+        o = fmaf(s_w3[2], c2, fmaf(s_w3[1], b2, s_w3[0] * a));
+      }
+      out[(size_t)i * out_ld + c] = o;
+    }
   }
 }
 
@@ -401,7 +476,7 @@ extern "C" size_t ls3d_devoxelize_grid_workspace_bytes(int n_points, int n_voxel
 }
 
 // extra workspace for the coarse-cell ordering of the query points
-static size_t dv_points_ws(int n_points, long long ncell) { return 2 * dv_align((size_t)(n_points > 0 ? n_points : 1) * 4) + 3 * dv_align((size_t)(ncell + 1) * 4); }
+static size_t dv_points_ws(int n_points, long long ncell) { return 3 * dv_align((size_t)(n_points > 0 ? n_points : 1) * 4) + 3 * dv_align((size_t)(ncell + 1) * 4) + 256; }
 
 extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *pt_off, int max_frame_points,
                                     const int32_t *coords, const float *centers, int n_voxels, const int32_t *n_voxels_dev,
@@ -432,7 +507,10 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   int32_t *perm = (int32_t *)base; base += dv_align((size_t)n_points * 4);
   int32_t *pcnt = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
   int32_t *pstart = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
-  int32_t *pcursor = (int32_t *)base;
+  int32_t *pcursor = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  int32_t *hard_list = (int32_t *)base; base += dv_align((size_t)n_points * 4);
+  int32_t *hard_count = (int32_t *)base;
+  hipMemsetAsync(hard_count, 0, 4, stream);
   hipMemsetAsync(pcnt, 0, (size_t)(ncell + 1) * 4, stream);
   hipMemsetAsync(pcursor, 0, (size_t)(ncell + 1) * 4, stream);
   hipLaunchKernelGGL(k_pt_count, ls3d_grid(n_points), dim3(256), 0, stream, points, pt_stride, n_points, g, pcell, pcnt);
@@ -448,7 +526,10 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   hipLaunchKernelGGL(k_cg_fill, ls3d_grid(n_voxels), dim3(256), 0, stream, centers, n_voxels, n_voxels_dev, vx_off, (const int32_t *)cell_of,
                      (const int32_t *)start, cursor, sorted);
   hipLaunchKernelGGL(k_devox_grid, dim3((max_frame_points + 255) / 256, batch), dim3(256), (size_t)g.wpf * 4, stream, points, pt_stride, pt_off,
-                     (const int32_t *)perm, g, (const int32_t *)start, (const float4 *)sorted, (const uint32_t *)occ, vx_off, feat, feat_ld, c, out, out_ld, idx_out);
+                     (const int32_t *)perm, g, (const int32_t *)start, (const float4 *)sorted, (const uint32_t *)occ, vx_off, feat, feat_ld, c, out, out_ld, idx_out,
+                     hard_list, hard_count);
+  hipLaunchKernelGGL(k_devox_hard, dim3(n_points < 2048 ? (n_points > 0 ? n_points : 1) : 2048), dim3(256), 0, stream, points, pt_stride,
+                     (const int32_t *)hard_list, (const int32_t *)hard_count, centers, vx_off, feat, feat_ld, c, out, out_ld, idx_out);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

@@ -1,0 +1,220 @@
+"""Kernel LOGIC tests without a GPU: the unmodified HIP sources are compiled for the host against tests/hipsim (a
+fiber-based emulation of blocks / waves / LDS / MFMA — test infrastructure, see tests/hipsim/hip/hip_runtime.h) and driven
+through the same C ABI and the same Python host layer as on the MI355X.  They catch indexing / protocol bugs before a
+GPU run; numerical parity proper is the job of tests/test_gpu_parity.py on the real device."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lidarseg3d_amd import _lib, ops, point_heads, readers, scn_unet, synth
+from lidarseg3d_amd.packing import PackedWeight
+from oracle import ref as orc
+from tests.util import golden, seeded_sd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def sim_library():
+    sys.path.insert(0, os.path.join(HERE, "hipsim"))
+    import build_sim
+    path = build_sim.build()
+    _lib.use_library_for_testing(path)
+    ops.set_sim(True)
+    yield
+    ops.set_sim(False)
+    _lib.use_library_for_testing(None)
+
+
+@pytest.mark.parametrize("tag", ["nusc", "nusc_cap", "kitti"])
+def test_voxelize_bit_exact_vs_reference(tag):
+    g = golden("voxelize_%s.npz" % tag)
+    pts, mv = torch.from_numpy(g["points"]), int(g["max_voxels"])
+    for mode, pre in (("numba", "numba"), ("break", "cpp_hard")):
+        v, c, n, nv = ops.voxelize_hard(pts, g["voxel_size"], g["pc_range"], 5, mv, overflow=mode)
+        V = int(nv)
+        assert V == g[pre + "_coors"].shape[0]
+        assert np.array_equal(c[:V].numpy(), g[pre + "_coors"]) and np.array_equal(n[:V].numpy(), g[pre + "_num"])
+        assert np.array_equal(v[:V].numpy(), g[pre + "_voxels"])
+    assert np.array_equal(ops.voxelize_dynamic(pts, g["voxel_size"], g["pc_range"]).numpy(), g["cpp_dyn_coors"])
+
+
+def test_voxelize_empty_and_all_outside():
+    cfg = synth.NUSC
+    pts = torch.full((10, 5), 1000.0)
+    v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 5, 100)
+    assert int(nv) == 0
+    assert (ops.voxelize_dynamic(pts, cfg["voxel_size"], cfg["pc_range"]) == -1).all()
+
+
+def test_batched_voxelize_equals_per_frame_collate():
+    cfg = synth.NUSC
+    frames = [synth.lidar_frame(1500, seed=1, **cfg), synth.lidar_frame(40, seed=2, **cfg), synth.lidar_frame(900, seed=3, **cfg)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    v, c, n, nv = ops.voxelize_hard(torch.from_numpy(pts), cfg["voxel_size"], cfg["pc_range"], 5, 900000, batched=True)
+    V = int(nv)
+    want = orc.collate_frames(frames, cfg["voxel_size"], cfg["pc_range"], 5, 300000)
+    assert torch.equal(c[:V], want["coordinates"]) and torch.equal(n[:V], want["num_points"]) and torch.equal(v[:V], want["voxels"])
+
+
+def test_dynamic_scatter_vs_reference_cpp():
+    g = golden("voxelize_nusc.npz")
+    gs = orc.grid_size(g["voxel_size"], g["pc_range"])
+    shape = [int(gs[2]), int(gs[1]), int(gs[0])]
+    f, vc, p2v, nv = ops.dynamic_scatter(torch.from_numpy(g["points"]), torch.from_numpy(g["cpp_dyn_coors"]), shape, "mean")
+    V = int(nv)
+    assert np.array_equal(vc[:V].numpy(), g["cpp_scatter_coors"])
+    want = torch.from_numpy(g["cpp_scatter_voxels"]).sum(1) / torch.from_numpy(g["cpp_scatter_num"]).float()[:, None]
+    np.testing.assert_allclose(f[:V].numpy(), want.numpy(), rtol=2e-6, atol=1e-6)
+    f, _, _, _ = ops.dynamic_scatter(torch.from_numpy(g["points"]), torch.from_numpy(g["cpp_dyn_coors"]), shape, "max")
+    np.testing.assert_array_equal(f[:V].numpy(), g["cpp_scatter_voxels"].max(1))
+
+
+def test_rulebooks_bit_exact_vs_oracle_all_levels():
+    g = golden("unet_nusc_c13.npz")
+    coords = torch.from_numpy(g["coords"])
+    shape = orc.spatial_shape(synth.NUSC["voxel_size"], synth.NUSC["pc_range"])
+    rb = orc.UNetRulebooks(g["coords"], shape)
+    assert np.array_equal(ops.rulebook_subm(coords, shape, (3, 3, 3)).numpy(), rb.subm1)
+    cur, cshape = coords, list(shape)
+    for want_c, want_tbl, ks, st, pd in ((rb.c2, rb.down2, (3, 3, 3), (2, 2, 2), (1, 1, 1)), (rb.c3, rb.down3, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                         (rb.c4, rb.down4, (3, 3, 3), (2, 2, 2), (0, 1, 1)), (rb.c5, rb.down5, (3, 1, 1), (2, 1, 1), (0, 0, 0))):
+        oc, cnt, nbo, nbi, osh = ops.rulebook_conv(cur, 1, cshape, ks, st, pd)
+        n = int(cnt[0])
+        assert int(cnt[1]) == 0 and n == want_c.shape[0]
+        assert np.array_equal(oc[:n].numpy(), want_c) and np.array_equal(nbo[:n].numpy(), want_tbl)
+        inv = np.full((cur.shape[0], want_tbl.shape[1]), -1, np.int32)
+        o, k = np.nonzero(want_tbl >= 0)
+        inv[want_tbl[o, k], k] = o
+        assert np.array_equal(nbi.numpy(), inv)  # the transposed table SparseInverseConv3d uses
+        cur, cshape = oc[:n].contiguous(), osh
+        if ks == (3, 3, 3):
+            want_subm = {tuple(rb.s2): rb.subm2, tuple(rb.s3): rb.subm3, tuple(rb.s4): rb.subm4}[tuple(osh)]
+            assert np.array_equal(ops.rulebook_subm(cur, osh, (3, 3, 3)).numpy(), want_subm)
+    # overflow is reported, not silently truncated
+    oc, cnt, _, _, _ = ops.rulebook_conv(coords, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), out_cap=100)
+    assert int(cnt[0]) == 100 and int(cnt[1]) == 1
+
+
+@pytest.mark.parametrize("m,k,n,nt", [(70, 16, 17, 1), (200, 48, 64, 2), (150, 32, 96, 3), (260, 64, 128, 4), (129, 32, 192, 3)])
+def test_gather_gemm_dense_all_column_block_variants(m, k, n, nt, monkeypatch):
+    """C = A B (asymmetric operands: catches transposed fragments), every NT variant, both K-chunk sizes"""
+    rng = np.random.default_rng(m)
+    a, b = rng.normal(size=(m, k)).astype(np.float32), rng.normal(size=(k, n)).astype(np.float32)
+    monkeypatch.setattr(ops, "choose_nt", lambda cout, rows, target_blocks=1024: nt)
+    out = ops.gather_gemm(torch.from_numpy(a), PackedWeight(torch.from_numpy(b).reshape(1, k, n).contiguous(), 1, k, k, n), cout=n)
+    np.testing.assert_allclose(out.numpy(), a.astype(np.float64) @ b.astype(np.float64), rtol=0, atol=1e-4)
+
+
+def test_gather_gemm_sparse_with_order_and_fused_epilogue(monkeypatch):
+    rng = np.random.default_rng(3)
+    vin, vout, kvol, cin, cout = 300, 170, 27, 32, 64
+    x = rng.normal(size=(vin, cin)).astype(np.float32)
+    w = rng.normal(size=(kvol, cin, cout)).astype(np.float32) * 0.1
+    tbl = rng.integers(-1, vin, size=(vout, kvol)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.7] = -1
+    tbl[5] = -1  # a row without any neighbour
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(vout, cout)).astype(np.float32)
+    pair = rng.normal(size=(vout, 2 * cout)).astype(np.float32)
+    acc = np.zeros((vout, cout), np.float64)
+    for kk in range(kvol):
+        o = np.nonzero(tbl[:, kk] >= 0)[0]
+        acc[o] += x[tbl[o, kk]].astype(np.float64) @ w[kk].astype(np.float64)
+    want = np.maximum(acc * scale + shift + res, 0) + pair[:, 0::2] + pair[:, 1::2]
+    T = torch.from_numpy
+    pw = PackedWeight(T(w), kvol, cin, cin, cout)
+    for nt in (1, 2):
+        monkeypatch.setattr(ops, "choose_nt", lambda c, r, target_blocks=1024, nt=nt: nt)
+        for order in (None, ops.rulebook_order(T(tbl))):
+            out = ops.gather_gemm(T(x), pw, tbl=T(tbl), order=order, cout=cout, scale=T(scale), shift=T(shift), res_pre=T(res),
+                                  relu=True, pair=T(pair))
+            np.testing.assert_allclose(out.numpy(), want, rtol=0, atol=2e-4)
+    # writing into a column slice of a wider buffer (the UNet decoder's concat)
+    wide = torch.zeros((vout, 2 * cout))
+    ops.gather_gemm(T(x), pw, tbl=T(tbl), cout=cout, out=wide[:, cout:], out_ld=2 * cout)
+    np.testing.assert_allclose(wide[:, cout:].numpy(), acc, rtol=0, atol=2e-4)
+    assert float(wide[:, :cout].abs().max()) == 0.0
+
+
+def test_vfe_readers_vs_reference():
+    g = golden("vfe_nusc.npz")
+    sel = slice(0, 96)
+    vx, num = torch.from_numpy(g["voxels"][sel]), torch.from_numpy(g["num"][sel])
+    np.testing.assert_allclose(readers.MeanVoxelFeatureExtractor(5)(vx, num).numpy(), g["mean"][sel], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(readers.ImprovedMeanVoxelFeatureExtractor(5)(vx, num).numpy(), g["improved"][sel], rtol=0, atol=1e-5)
+    tv = readers.TransformerVoxelFeatureExtractor(5, 16, 64, 4, 3)
+    tv.load_state_dict(seeded_sd("reader.TransformerVoxelFeatureExtractor", g["trans_seed"]), strict=True)
+    np.testing.assert_allclose(tv.eval()(vx, num).numpy(), g["trans"][sel], rtol=0, atol=1e-4)
+
+
+def test_unet_small_vs_oracle():
+    cfg = synth.NUSC
+    g = golden("unet_nusc_c13.npz")
+    n = 100
+    coords, feats = g["coords"][:n], torch.from_numpy(g["voxel_features"][:n])
+    net = scn_unet.UNetSCN3D(num_input_features=13, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
+                             model_cfg=dict(SCALING_RATIO=2), ds_factor=8, us_factor=8)
+    sd = seeded_sd("backbone.UNetSCN3D.c13", g["seed"])
+    net.load_state_dict(sd, strict=True)
+    bd = net.eval()(dict(voxel_features=feats, voxel_coords=torch.from_numpy(coords), batch_size=1,
+                         input_shape=np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))))
+    want, ctr, aux = orc.unet_scn3d(sd, feats, coords, orc.spatial_shape(cfg["voxel_size"], cfg["pc_range"]), cfg["voxel_size"],
+                                    cfg["pc_range"], return_all=True)
+    scale = float(want.abs().max())
+    assert float((bd["conv_point_features"] - want).abs().max()) <= 1e-5 * scale + 1e-4
+    assert torch.equal(bd["conv_point_coords"], ctr)
+    assert float((bd["encoded_spconv_tensor"].features - aux["enc"]).abs().max()) <= 1e-5 * float(aux["enc"].abs().max()) + 1e-4
+
+
+def test_three_nn_grid_equals_brute_force_and_oracle():
+    g = golden("head_mseg3d_nusc.npz")
+    pts = torch.from_numpy(g["points"][:, :4].copy())
+    coords, ctr, feat = torch.from_numpy(g["coords"]), torch.from_numpy(g["conv_point_coords"]), torch.from_numpy(g["conv_point_features"])
+    extra = torch.tensor([[0, 80.0, 3.0, 10.0], [0, -70.0, -60.0, -8.0], [1, 0.0, 0.0, 30.0], [1, 51.19, 51.19, 2.99], [1, -51.2, -51.2, -5.0]])
+    pts = torch.cat([pts[pts[:, 0] == 0][:1500], extra[:2], pts[pts[:, 0] == 1][:1000], extra[2:]]).contiguous()
+    cfg = synth.NUSC
+    pt_off, vx_off = ops.frame_offsets(pts[:, 0], 2), ops.frame_offsets(ctr[:, 0], 2)
+    a, ia = ops.devoxelize_grid(pts, pt_off, coords, ctr, vx_off, 2, cfg["voxel_size"], cfg["pc_range"], feat, return_idx=True)
+    b, ib = ops.devoxelize(pts, pt_off, ctr, vx_off, 2, pts.shape[0], feat, return_idx=True)
+    assert torch.equal(ia, ib) and torch.equal(a, b)
+    want, widx = orc.three_interpolate_wrap(pts, ctr, feat, 2, return_idx=True)
+    assert np.array_equal(ia.numpy(), np.concatenate(widx))
+    np.testing.assert_allclose(a.numpy(), want.numpy(), rtol=0, atol=1e-5)
+    # pointnet2-style API, incl. fewer than 3 known points
+    d2, idx = ops.three_nn(pts[None, :200, 1:4].contiguous(), ctr[None, :2, 1:4].contiguous())
+    wd2, wi = orc.three_nn(pts[:200, 1:4].numpy(), ctr[:2, 1:4].numpy())
+    assert np.array_equal(idx[0].numpy(), wi) and np.array_equal(d2[0].numpy(), wd2)
+
+
+def test_point_heads_small_vs_oracle():
+    from lidarseg3d_amd import models_cfg
+    g = golden("head_batchloss_nusc.npz")
+    head = point_heads.PointSegBatchlossHead(False, 17, models_cfg.sdseg3d()["point_head"]["model_cfg"])
+    sd = seeded_sd("point_head.PointSegBatchlossHead", g["seed"])
+    head.load_state_dict(sd, strict=True)
+    feat, ctr = torch.from_numpy(g["conv_point_features"][:500]), torch.from_numpy(g["conv_point_coords"][:500])
+    pts = torch.from_numpy(g["points"][:400, :4]).contiguous()
+    bd = head.eval()(dict(batch_size=1, conv_point_features=feat, conv_point_coords=ctr, points=pts), return_loss=False)
+    cl, out = orc.batchloss_head(sd, feat, ctr, pts, 1)
+    assert float((bd["out_logits"] - out).abs().max()) <= 1e-5 * float(out.abs().max()) + 1e-4
+
+    g = golden("head_mseg3d_nusc.npz")
+    head = point_heads.PointSegMSeg3DHead(False, 17, models_cfg.mseg3d()["point_head"]["model_cfg"])
+    sd = seeded_sd("point_head.PointSegMSeg3DHead", g["seed"])
+    head.load_state_dict(sd, strict=True)
+    pts_all, cp_all = torch.from_numpy(g["points"]), torch.from_numpy(g["conv_point_coords"])
+    h, w = (int(v) for v in g["cam_hw"])
+    img, emb, cuv = synth.camera_inputs(pts_all.shape[0], seed=int(g["cam_seed"]), ncam=6, c_img=48, h=h, w=w, batch=2)
+    pm = torch.cat([torch.nonzero(pts_all[:, 0] == b)[:150, 0] for b in range(2)])
+    vm = torch.cat([torch.nonzero(cp_all[:, 0] == b)[:200, 0] for b in range(2)])
+    pts, cuvs = pts_all[pm][:, :4].contiguous(), torch.from_numpy(cuv)[pm].contiguous()
+    vf, ctr = torch.from_numpy(g["conv_point_features"])[vm].contiguous(), cp_all[vm].contiguous()
+    bd = head.eval()(dict(batch_size=2, conv_point_features=vf, conv_point_coords=ctr, points=pts, image_features=torch.from_numpy(img),
+                          points_cuv=cuvs, camera_semantic_embeddings=torch.from_numpy(emb)), return_loss=False)
+    vl, out = orc.mseg3d_head(sd, vf, ctr, pts, cuvs, torch.from_numpy(img), torch.from_numpy(emb), 2)
+    assert float((head.forward_ret_dict["voxel_logits"] - vl).abs().max()) <= 1e-4
+    assert float((bd["out_logits"] - out).abs().max()) <= 1e-4
