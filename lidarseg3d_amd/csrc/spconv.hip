@@ -28,7 +28,9 @@ struct EpiDev {
   int res_pre_ld, pair_ld, relu;
 };
 
-template <int KC, int NT>
+// SPARSE = a rulebook table is present (sparse convolution); false = dense Linear (identity table).  A template
+// parameter so that the two show up as separate kernels in rocprof traces.
+template <int KC, int NT, bool SPARSE>
 __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
                                                     const int32_t *__restrict__ order, int kvol, const float *__restrict__ w, int cin,
                                                     int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
     const int row = s_rows[wave * 32 + col];
     // ---- which kernel offsets does this tile / this wave need at all?
     unsigned long long wmask = 0ull;
-    if (tbl) {
+    if (SPARSE) {
       for (int k = 0; k < kvol; ++k) {
         const int idx = (row >= 0) ? tbl[(size_t)row * kvol + k] : -1;
         if (__any(idx >= 0)) wmask |= 1ull << k;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
       int k_cur = __ffsll((long long)rem) - 1;
       rem &= rem - 1;
       int k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
-#define LS3D_LOAD_IDX(k) ((row >= 0) ? (tbl ? tbl[(size_t)row * kvol + (k)] : row) : -1)
+#define LS3D_LOAD_IDX(k) ((row >= 0) ? (SPARSE ? tbl[(size_t)row * kvol + (k)] : row) : -1)
 #define LS3D_LOAD_A(dst, idx, c0_)                                                              \
   do {                                                                                          \
     if ((idx) >= 0) {                                                                           \
@@ -244,8 +246,12 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
 template <int KC, int NT>
 static void launch_gg(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
                       const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
-  hipLaunchKernelGGL((k_gather_gemm<KC, NT>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
-                     n_rows_dev, e, out, out_ld);
+  if (tbl)
+    hipLaunchKernelGGL((k_gather_gemm<KC, NT, true>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
+                       n_rows_dev, e, out, out_ld);
+  else
+    hipLaunchKernelGGL((k_gather_gemm<KC, NT, false>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
+                       n_rows_dev, e, out, out_ld);
 }
 
 // column-block decomposition shared by the kernel dispatch and the weight packer

@@ -85,11 +85,25 @@ class SegMSeg3DNet(SingleStageDetector):
     def __init__(self, reader, backbone, point_head, img_backbone=None, img_head=None, neck=None, bbox_head=None,
                  train_cfg=None, test_cfg=None, pretrained=None, voxel_generator=None, **kwargs):
         super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained=None)
-        self.img_backbone = builder.build_img_backbone(img_backbone) if img_backbone is not None else None
-        self.img_head = builder.build_img_head(img_head) if img_head is not None else None
+        self.img_backbone = self._build_camera(builder.build_img_backbone, img_backbone)
+        self.img_head = self._build_camera(builder.build_img_head, img_head)
         self.point_head = builder.build_point_head(point_head)
         self.voxel_generator = voxel_generator
         self.init_weights(pretrained=pretrained)
+
+    @staticmethod
+    def _build_camera(build, cfg):
+        """the camera CNN (HRNet / FCN head) is not part of this package: an unregistered type degrades to "features
+        come in through `example`" with a warning instead of failing the whole config"""
+        if cfg is None:
+            return None
+        try:
+            return build(cfg)
+        except KeyError as e:
+            import warnings
+            warnings.warn("camera branch not built (%s); SegMSeg3DNet expects example['image_features'] and "
+                          "example['camera_semantic_embeddings']" % (e,))
+            return None
 
     def forward(self, example, return_loss=True, **kwargs):
         if return_loss:

@@ -157,3 +157,33 @@ def test_frame_sharding_two_process_gloo(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "OK 2" in out.stdout
+
+
+REF_CFGS = ["/root/reference/configs/semanticnusc/SDSeg3D/semnusc_transvfe_unetscn3d_batchloss_e48.py",
+            "/root/reference/configs/semanticnusc/MSeg3D/semnusc_avgvfe_unetscn3d_hrnetw18_lr1en2_e12.py",
+            "/root/reference/configs/semantickitti/SDSeg3D/semkitti_transVFE_unetscn3d_batchloss_e10.py",
+            "/root/reference/configs/semanticwaymo/MSeg3D/semwaymo_avgvfe_unetscn3d_hrnetw18_lr1en2_e12.py"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("path", REF_CFGS)
+def test_reference_config_files_build_unchanged(path):
+    """the reference's own config files load through the det3d.* aliases and build the hot-path model"""
+    import warnings
+    import lidarseg3d_amd.compat as compat
+    compat.install(force=True)
+    try:
+        from det3d.models import build_detector
+        from det3d.torchie import Config
+        cfg = Config.fromfile(path)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # camera CNN types are outside the package
+            model = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+        keys = list(model.state_dict())
+        assert any(k.startswith("backbone.conv_up_m4.0.weight") for k in keys)
+        assert any(k.startswith("point_head.out_cls_layers") for k in keys)
+        assert type(model).__name__ == cfg.model["type"]
+    finally:
+        for name in [m for m in sys.modules if m == "det3d" or m.startswith("det3d.") or m in ("spconv", "addict", "addict.addict")]:
+            if getattr(sys.modules[name], "__ls3d_alias__", False) or name.startswith("det3d"):
+                sys.modules.pop(name, None)
