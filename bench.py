@@ -32,10 +32,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
 
 
-def build_model(dev, seed=5):
+def build_model(dev, seed=5, kind="sdseg3d"):
     import lidarseg3d_amd as L
     from lidarseg3d_amd import models_cfg, synth
-    model = L.build_detector(models_cfg.sdseg3d(), train_cfg=None, test_cfg={}).eval()
+    cfg = models_cfg.mseg3d() if kind == "mseg3d" else models_cfg.sdseg3d()
+    model = L.build_detector(cfg, train_cfg=None, test_cfg={}).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, seed).items()}
     model.load_state_dict(sd)
@@ -129,6 +130,8 @@ def main():
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--cpu-points", type=int, default=None, help="points of the CPU-baseline frame (default: --points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=["sdseg3d", "mseg3d"], default="sdseg3d",
+                    help="sdseg3d = BASELINE configs[1] (the metric's config); mseg3d = configs[2] (LiDAR + 6-camera features)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -149,13 +152,18 @@ def main():
         dist.init_process_group("nccl", init_method="env://")
 
     from lidarseg3d_amd import ops, synth
-    model, sd = build_model(dev)
+    model, sd = build_model(dev, kind=args.model)
     frame = synth.lidar_frame(args.points, seed=100 + rank, **synth.NUSC)
     pts = torch.from_numpy(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)).to(dev)
+    extra = {}
+    if args.model == "mseg3d":  # HRNet-w18 feature maps of 6 cameras at 1/4 resolution + camera class embeddings (inputs of the path)
+        img, emb, cuv = synth.camera_inputs(args.points, seed=100 + rank, ncam=6, c_img=48, h=160, w=240, batch=1)
+        extra = dict(points_cuv=torch.from_numpy(cuv).to(dev), image_features=torch.from_numpy(img).to(dev),
+                     camera_semantic_embeddings=torch.from_numpy(emb).to(dev))
     timer = ConvTimer(ops).install()
 
     def step():
-        ret = model(dict(points=pts, batch_size=1), return_loss=False)
+        ret = model(dict(points=pts, batch_size=1, **extra), return_loss=False)
         return ret[0]["pred_point_sem_labels"]
 
     with torch.no_grad():
@@ -200,7 +208,12 @@ def main():
                          "tflops": conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0,
                          "sparse_conv_ms_per_frame": conv["total_ms"] / max(args.steps, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.model == "mseg3d":
+            out["metric"] = "frames/sec, MSeg3D forward (LiDAR + 6-cam features), 120k-pt nuScenes-style frame"
+            out["config"]["workload"] = out["config"]["workload"].replace(
+                "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead)",
+                "nuScenes MSeg3D (ImprovedMeanVFE->UNetSCN3D->PointSegMSeg3DHead GF+SF-Phase, image_features [1,6,48,160,240])")
+        if world == 1 and not args.no_cpu_baseline and args.model == "sdseg3d":
             out["cpu_baseline"] = cpu_baseline(args.cpu_points or args.points, 100)
         print(json.dumps(out))
     if dist is not None:

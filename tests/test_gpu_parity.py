@@ -229,3 +229,22 @@ def test_devoxelize_grid_equals_brute_force_120k():
     b, ib = ops.devoxelize(p, pt_off, ctr, vx_off, 2, p.shape[0], feat, return_idx=True)
     assert torch.equal(ia, ib)
     assert torch.equal(a, b)
+
+
+def test_mseg3d_end_to_end_vs_oracle():
+    """SegMSeg3DNet: points + camera features -> logits on the GPU vs the CPU oracle (two ragged frames)"""
+    cfg = synth.NUSC
+    model, sd = _model(models_cfg.mseg3d(), seed=9)
+    frames = [synth.lidar_frame(15000, seed=21, **cfg), synth.lidar_frame(4000, seed=22, **cfg)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=5, ncam=6, c_img=48, h=40, w=60, batch=2)
+    ret = model(dict(points=cu(pts), batch_size=2, points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb)),
+                return_loss=False)
+    got = model.point_head.forward_ret_dict["out_logits"].cpu()
+    want = orc.mseg3d_forward(sd, frames, torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), cfg["voxel_size"],
+                              cfg["pc_range"])
+    scale = float(want["out_logits"].abs().max())
+    err = float((got - want["out_logits"]).abs().max())
+    assert err <= 1e-3 + 2e-5 * scale, (err, scale)
+    pred = torch.cat([r["pred_point_sem_labels"].cpu() for r in ret])
+    assert float((pred == want["out_logits"].argmax(1)).float().mean()) >= 0.999
