@@ -187,7 +187,8 @@ def main():
         elapsed = float(t.item())
 
     conv = timer.summarize()
-    V = int(model.point_head.forward_ret_dict["conv_logits"].shape[0])
+    frd = model.point_head.forward_ret_dict
+    V = int((frd["conv_logits"] if "conv_logits" in frd else frd["voxel_logits"]).shape[0])
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         achieved = conv["algo_bytes"] / (conv["total_ms"] * 1e-3) / 1e9 if conv["total_ms"] > 0 else 0.0

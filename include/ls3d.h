@@ -193,10 +193,13 @@ int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_p
  * kvol == 1 (a dense Linear layer).  in[*, cin] row stride in_ld, `w` = weights packed by
  * ls3d_gather_gemm_pack with cin_pad == cin, out row stride out_ld.  cin must be a multiple of 16, in_ld of 4.
  * f32 MFMA (v_mfma_f32_32x32x2_f32): exact f32 products and accumulation.
+ * Workgroup geometry: 4 waves as a (4/wc) x wc grid, each wave 32 rows x 32*nt columns, so a workgroup covers
+ * 32*(4/wc) rows x 32*nt*wc columns (nt*wc <= 4, must divide roundup(cout,32)/32; wc == 0 means 1).  The weights must
+ * have been packed with the same nt.
  * row_order (optional, int32[n_rows]): tile slot i processes output row row_order[i] (see ls3d_rulebook_masks).
  * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
  * (tbl = nbr_inv) and every nn.Linear on the path. */
-int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int cin, int cout,
+int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int wc, int cin, int cout,
                      int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
                      int out_ld, ls3d_stream_t stream);
 

@@ -28,38 +28,50 @@ struct EpiDev {
   int res_pre_ld, pair_ld, relu;
 };
 
-// SPARSE = a rulebook table is present (sparse convolution); false = dense Linear (identity table).  A template
-// parameter so that the two show up as separate kernels in rocprof traces.
-template <int KC, int NT, bool SPARSE>
+// Template parameters
+//   KC     K-chunk (input channels per LDS weight chunk): 32, or 16 when cin % 32 != 0
+//   NT     32-column blocks per WAVE (accumulators per wave)
+//   WC     waves along the columns; the 4 waves form a (4/WC) x WC grid, so a workgroup covers
+//          TR = 32*(4/WC) rows x SLAB = 32*NT*WC columns.  WC > 1 trades tile height for width: more workgroups for
+//          small levels WITHOUT splitting the columns across workgroups (which would gather every input row once
+//          per column slab from L2/MALL) — the WC waves of a row group read the same A rows through the CU's L1.
+//   SPARSE a rulebook table is present (sparse convolution); false = dense Linear.  A template parameter so that the
+//          two show up as separate kernels in rocprof traces.
+template <int KC, int NT, int WC, bool SPARSE>
 __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
                                                     const int32_t *__restrict__ order, int kvol, const float *__restrict__ w, int cin,
                                                     int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
                                                     float *__restrict__ out, int out_ld) {
+  constexpr int WR = 4 / WC;                           // waves along the rows
+  constexpr int TR = 32 * WR;                          // rows per workgroup tile
   constexpr int SPL = KC / 2;                          // floats of a row chunk held per lane
-  constexpr int SLAB = NT * 32;                        // output columns handled by this workgroup
-  constexpr int BV = KC * SLAB / 4;                    // float4s in one weight chunk
+  constexpr int WSLAB = NT * 32;                       // columns per wave
+  constexpr int SLAB = WSLAB * WC;                     // columns per workgroup
+  constexpr int PV = KC * WSLAB / 4;                   // float4s in one wave-slab weight piece
+  constexpr int BV = PV * WC;                          // float4s in the workgroup's weight chunk
   constexpr int BPT = (BV + 255) / 256;                // float4s staged per thread
   struct alignas(NT == 3 ? 4 : 4 * NT) BVec { float v[NT]; };
-  __shared__ __attribute__((aligned(16))) float Bs[2][KC * SLAB];  // double-buffered weight chunk
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC * SLAB];  // double-buffered weight chunk, [piece][k][32][NT]
   __shared__ unsigned long long s_kmask;               // kernel offsets with an active neighbour in this tile
-  __shared__ int s_rows[128];                          // output row handled by each tile slot (-1 = none)
+  __shared__ int s_rows[TR];                           // output row handled by each tile slot (-1 = none)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
   const int col = lane & 31, kk = lane >> 5;
   const int n0 = blockIdx.y * SLAB;
   const int N = ls3d_count(n_rows, n_rows_dev);
-  const int ntiles = (N + 127) / 128;
-  const int nslab = w_ld / SLAB;
-  const float *wbase = w + (size_t)blockIdx.y * cin * SLAB;  // packed: [kvol][slab][cin][32][NT]
+  const int ntiles = (N + TR - 1) / TR;
+  const int nwslab = w_ld / WSLAB;                     // packed: [kvol][wslab][cin][32][NT]
+  const float *wbase = w + (size_t)blockIdx.y * WC * cin * WSLAB;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // ---- tile slots -> output rows.  With `order` (rows sorted by their neighbour bitmask, rulebook.hip) the 32
     //      rows of a wave share most of their empty kernel offsets, so the skips below remove most zero work.
     if (tid == 0) s_kmask = 0ull;
-    if (tid < 128) {
-      const int r = tile * 128 + tid;
+    if (tid < TR) {
+      const int r = tile * TR + tid;
       s_rows[tid] = r < N ? (order ? order[r] : r) : -1;
     }
     __syncthreads();
-    const int row = s_rows[wave * 32 + col];
+    const int row = s_rows[wr * 32 + col];
     // ---- which kernel offsets does this tile / this wave need at all?
     unsigned long long wmask = 0ull;
     if (SPARSE) {
@@ -95,17 +107,17 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
     }                                                                                           \
   } while (0)
 // weight staging registers are named scalars (not an array): an array indexed inside the pipelined loop is not
-// promoted to registers by hipcc and ends up in scratch.
+// promoted to registers by hipcc and ends up in scratch.  Float4 i_ of the chunk = piece (i_/PV), offset (i_%PV).
 #define LS3D_B_ONE(j, reg, OP)                                                                  \
   if constexpr (BPT > (j)) {                                                                    \
     const int i_ = tid + (j)*256;                                                               \
     if (BV % 256 == 0 || i_ < BV) { OP(reg, i_); }                                              \
   }
-#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)(i_)*4)
+#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)((i_) / PV) * cin * WSLAB + (size_t)((i_) % PV) * 4)
 #define LS3D_B_ST(reg, i_) *(float4 *)(dst_ + (i_)*4) = reg
 #define LS3D_LOAD_B(k, c0_)                                                                     \
   do {                                                                                          \
-    const float *wk_ = wbase + ((size_t)(k)*cin * nslab + (c0_)) * SLAB;                         \
+    const float *wk_ = wbase + ((size_t)(k)*cin * nwslab + (c0_)) * WSLAB;                      \
     LS3D_B_ONE(0, breg0, LS3D_B_LD) LS3D_B_ONE(1, breg1, LS3D_B_LD)                             \
     LS3D_B_ONE(2, breg2, LS3D_B_LD) LS3D_B_ONE(3, breg3, LS3D_B_LD)                             \
   } while (0)
@@ -139,7 +151,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
         if ((wmask >> k_cur) & 1ull) {
           // packed weight layout: the NT values a lane needs for one k-step are adjacent -> one ds_read of NT dwords;
           // the read for step s+1 is issued before the MFMAs of step s (register double buffer).
-          const float *bs = Bs[buf] + (kk * SPL * 32 + col) * NT;
+          const float *bs = Bs[buf] + wc * (KC * WSLAB) + (kk * SPL * 32 + col) * NT;
           BVec bb0, bb1;
           bb0 = *(const BVec *)bs;
 #pragma unroll
@@ -180,16 +192,15 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
     // ---- epilogue through LDS: the accumulators (fragment layout: register r of lane (col,kk) = output row
     //      (r&3) + 8*(r>>2) + 4*kk, column col) are transposed into row-major tiles in the weight buffer, then
     //      all 256 threads apply scale/shift, residual, ReLU, pair-sum and store whole rows with float4.
-    constexpr int RPP = 2 * KC;       // tile rows that fit in Bs per pass (64 or 32)
-    constexpr int WPP = RPP / 32;     // waves per pass
+    constexpr int RPP = (2 * KC < TR) ? 2 * KC : TR;  // tile rows that fit in Bs per pass
     float *stage = &Bs[0][0];
     const bool vec = ((cout & 3) == 0) && ((out_ld & 3) == 0) && (!e.res_pre || (e.res_pre_ld & 3) == 0) &&
                      (!e.pair || (e.pair_ld & 3) == 0);
 #pragma unroll
-    for (int pass = 0; pass < 128 / RPP; ++pass) {
+    for (int pass = 0; pass < TR / RPP; ++pass) {
       __syncthreads();  // previous readers of Bs (MFMA loop or previous pass) are done
-      if (wave / WPP == pass) {
-        float *dst = stage + ((wave % WPP) * 32 + 4 * kk) * SLAB + col;
+      if ((wr * 32) / RPP == pass) {
+        float *dst = stage + ((wr * 32) % RPP + 4 * kk) * SLAB + wc * WSLAB + col;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -239,19 +250,19 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
         }
       }
     }
-    __syncthreads();  // Bs is reused by the next tile
+    __syncthreads();  // Bs and s_rows are reused by the next tile
   }
 }
 
-template <int KC, int NT>
+template <int KC, int NT, int WC>
 static void launch_gg(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
                       const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
   if (tbl)
-    hipLaunchKernelGGL((k_gather_gemm<KC, NT, true>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
-                       n_rows_dev, e, out, out_ld);
+    hipLaunchKernelGGL((k_gather_gemm<KC, NT, WC, true>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout,
+                       n_rows, n_rows_dev, e, out, out_ld);
   else
-    hipLaunchKernelGGL((k_gather_gemm<KC, NT, false>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
-                       n_rows_dev, e, out, out_ld);
+    hipLaunchKernelGGL((k_gather_gemm<KC, NT, WC, false>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout,
+                       n_rows, n_rows_dev, e, out, out_ld);
 }
 
 // column-block decomposition shared by the kernel dispatch and the weight packer
@@ -297,9 +308,9 @@ extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src
   return LS3D_OK;
 }
 
-extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int cin, int cout,
-                                int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi, float *out, int out_ld,
-                                ls3d_stream_t stream_) {
+extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt,
+                                int wc, int cin, int cout, int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi, float *out,
+                                int out_ld, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !w || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
@@ -314,17 +325,27 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   const int w_ld = (cout + 31) / 32 * 32;
   const int nt_total = w_ld / 32;
   if (nt == 0) nt = gg_nt(cout);
-  if (!gg_nt_ok(cout, nt)) return LS3D_ERR_ARG;
-  const int slabs = nt_total / nt;
-  const int ntiles = (n_rows + 127) / 128;
-  dim3 grid((unsigned)(ntiles < 2048 ? ntiles : 2048), (unsigned)slabs);
+  if (wc == 0) wc = 1;
+  if (!gg_nt_ok(cout, nt) || (wc != 1 && wc != 2 && wc != 4) || (nt_total % (nt * wc)) || nt * wc > 4) return LS3D_ERR_ARG;
+  const int slabs = nt_total / (nt * wc);
+  const int tr = 32 * (4 / wc);
+  const int ntiles = (n_rows + tr - 1) / tr;
+  dim3 grid((unsigned)(ntiles < 4096 ? ntiles : 4096), (unsigned)slabs);
   const bool k32 = (cin % 32) == 0;
-#define LS3D_GG(KC, NT) launch_gg<KC, NT>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld)
-  if (k32) {
-    switch (nt) { case 1: LS3D_GG(32, 1); break; case 2: LS3D_GG(32, 2); break; case 3: LS3D_GG(32, 3); break; default: LS3D_GG(32, 4); }
-  } else {
-    switch (nt) { case 1: LS3D_GG(16, 1); break; case 2: LS3D_GG(16, 2); break; case 3: LS3D_GG(16, 3); break; default: LS3D_GG(16, 4); }
+#define LS3D_GG(KC, NT, WC) launch_gg<KC, NT, WC>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld)
+#define LS3D_GG_K(KC)                                              \
+  switch (nt * 10 + wc) {                                          \
+    case 11: LS3D_GG(KC, 1, 1); break;                             \
+    case 12: LS3D_GG(KC, 1, 2); break;                             \
+    case 14: LS3D_GG(KC, 1, 4); break;                             \
+    case 21: LS3D_GG(KC, 2, 1); break;                             \
+    case 22: LS3D_GG(KC, 2, 2); break;                             \
+    case 31: LS3D_GG(KC, 3, 1); break;                             \
+    case 41: LS3D_GG(KC, 4, 1); break;                             \
+    default: return LS3D_ERR_ARG;                                  \
   }
+  if (k32) { LS3D_GG_K(32) } else { LS3D_GG_K(16) }
+#undef LS3D_GG_K
 #undef LS3D_GG
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;

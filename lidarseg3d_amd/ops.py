@@ -244,14 +244,25 @@ def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0):
     return out
 
 
-def choose_nt(cout, n_rows, target_blocks=1024):
-    """column blocks per workgroup: the widest slab that still yields ~4 workgroups per CU (256 CUs)"""
+def choose_geometry(cout, n_rows, target_blocks=768):
+    """(nt, wc): 32-column blocks per wave and waves along the columns (workgroup = 32*(4/wc) rows x 32*nt*wc columns).
+    Among the geometries that give the 256 CUs at least ~3 workgroups each, take the one with the fewest column slabs
+    (every extra slab re-gathers the input rows) and then the tallest tile; if none does, take the one with the most
+    workgroups (fewest slabs on ties)."""
     total = (cout + 31) // 32
-    tiles = max((n_rows + 127) // 128, 1)
-    for nt in (4, 3, 2, 1):
-        if total % nt == 0 and tiles * (total // nt) >= target_blocks:
-            return nt
-    return 1
+    cands = []
+    for nt, wc in ((4, 1), (3, 1), (2, 2), (2, 1), (1, 4), (1, 2), (1, 1)):
+        if total % (nt * wc):
+            continue
+        slabs = total // (nt * wc)
+        blocks = -(-n_rows // (32 * (4 // wc))) * slabs
+        cands.append((blocks, slabs, wc, nt))
+    ok = [c for c in cands if c[0] >= target_blocks]
+    if ok:
+        blocks, slabs, wc, nt = min(ok, key=lambda c: (c[1], c[2]))
+    else:
+        blocks, slabs, wc, nt = max(cands, key=lambda c: (c[0], -c[1]))
+    return nt, wc
 
 
 def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
@@ -264,7 +275,7 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     cout = cout or w.cout
     assert cout == w.cout, "packed layout depends on cout"
     rows_hint = tbl.shape[0] if (tbl is not None and n_rows is None) else (n_rows if n_rows is not None else x.shape[0])
-    nt = choose_nt(cout, rows_hint)
+    nt, wc = choose_geometry(cout, rows_hint)
     wdata = w.for_nt(nt)
     if tbl is not None:
         n_rows = tbl.shape[0] if n_rows is None else n_rows
@@ -280,7 +291,7 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
         out_ld = out_ld or out.shape[1]
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0)
-    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, cin, cout, n_rows, None, ctypes.byref(epi),
+    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, wc, cin, cout, n_rows, None, ctypes.byref(epi),
                                 _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
     return out
 

@@ -99,12 +99,14 @@ def test_rulebooks_bit_exact_vs_oracle_all_levels():
     assert int(cnt[0]) == 100 and int(cnt[1]) == 1
 
 
-@pytest.mark.parametrize("m,k,n,nt", [(70, 16, 17, 1), (200, 48, 64, 2), (150, 32, 96, 3), (260, 64, 128, 4), (129, 32, 192, 3)])
-def test_gather_gemm_dense_all_column_block_variants(m, k, n, nt, monkeypatch):
-    """C = A B (asymmetric operands: catches transposed fragments), every NT variant, both K-chunk sizes"""
+@pytest.mark.parametrize("m,k,n,nt,wc", [(70, 16, 17, 1, 1), (200, 48, 64, 2, 1), (150, 32, 96, 3, 1), (260, 64, 128, 4, 1),
+                                         (129, 32, 192, 3, 1), (100, 32, 128, 2, 2), (77, 64, 128, 1, 4), (90, 16, 64, 1, 2),
+                                         (300, 32, 128, 1, 2)])
+def test_gather_gemm_dense_all_geometries(m, k, n, nt, wc, monkeypatch):
+    """C = A B (asymmetric operands: catches transposed fragments), every (NT, WC) variant, both K-chunk sizes"""
     rng = np.random.default_rng(m)
     a, b = rng.normal(size=(m, k)).astype(np.float32), rng.normal(size=(k, n)).astype(np.float32)
-    monkeypatch.setattr(ops, "choose_nt", lambda cout, rows, target_blocks=1024: nt)
+    monkeypatch.setattr(ops, "choose_geometry", lambda cout, rows, target_blocks=1024: (nt, wc))
     out = ops.gather_gemm(torch.from_numpy(a), PackedWeight(torch.from_numpy(b).reshape(1, k, n).contiguous(), 1, k, k, n), cout=n)
     np.testing.assert_allclose(out.numpy(), a.astype(np.float64) @ b.astype(np.float64), rtol=0, atol=1e-4)
 
@@ -127,8 +129,8 @@ def test_gather_gemm_sparse_with_order_and_fused_epilogue(monkeypatch):
     want = np.maximum(acc * scale + shift + res, 0) + pair[:, 0::2] + pair[:, 1::2]
     T = torch.from_numpy
     pw = PackedWeight(T(w), kvol, cin, cin, cout)
-    for nt in (1, 2):
-        monkeypatch.setattr(ops, "choose_nt", lambda c, r, target_blocks=1024, nt=nt: nt)
+    for nt, wc in ((1, 1), (2, 1), (1, 2)):
+        monkeypatch.setattr(ops, "choose_geometry", lambda c, r, target_blocks=1024, g=(nt, wc): g)
         for order in (None, ops.rulebook_order(T(tbl))):
             out = ops.gather_gemm(T(x), pw, tbl=T(tbl), order=order, cout=cout, scale=T(scale), shift=T(shift), res_pre=T(res),
                                   relu=True, pair=T(pair))
