@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--cpu-points", type=int, default=None, help="points of the CPU-baseline frame (default: --points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
+                    help="gather-GEMM arithmetic: f32 = exact f32 MFMA (default, the parity configuration); bf16x3 = split-bf16 "
+                         "(3 bf16 MFMAs per product, ~1e-5 relative error)")
     ap.add_argument("--model", choices=["sdseg3d", "mseg3d"], default="sdseg3d",
                     help="sdseg3d = BASELINE configs[1] (the metric's config); mseg3d = configs[2] (LiDAR + 6-camera features)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, default=None, help=argparse.SUPPRESS)
@@ -152,6 +155,7 @@ def main():
         dist.init_process_group("nccl", init_method="env://")
 
     from lidarseg3d_amd import ops, synth
+    ops.set_precision(args.precision)
     model, sd = build_model(dev, kind=args.model)
     frame = synth.lidar_frame(args.points, seed=100 + rank, **synth.NUSC)
     pts = torch.from_numpy(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)).to(dev)
@@ -196,7 +200,7 @@ def main():
             "metric": "frames/sec, SDSeg3D forward, 120k-pt nuScenes-style frame",
             "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.precision == "f32" else "f32 via split-bf16 (bf16x3 MFMA, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead), "
                                    "%d pts/frame, voxel [0.1,0.1,0.2], range [-51.2,-51.2,-5,51.2,51.2,3], 17 classes, "
                                    "1 frame per GPU per step, GPU voxelization included" % args.points,

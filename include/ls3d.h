@@ -31,6 +31,12 @@ extern "C" {
 #define LS3D_ERR_UNSUPPORTED (-3)
 #define LS3D_ERR_WORKSPACE (-4)
 
+/* arithmetic of ls3d_gather_gemm.  F32: exact f32 products and accumulation (v_mfma_f32_32x32x2_f32).
+ * BF16X3: f32 operands split into bf16 head + tail, a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
+ * v_mfma_f32_32x32x16_bf16 with f32 accumulation: ~1e-5 relative error per layer, 5.3x less matrix-pipe time. */
+#define LS3D_PRECISION_F32 0
+#define LS3D_PRECISION_BF16X3 1
+
 typedef void *ls3d_stream_t;
 
 /* library / build identification: returns e.g. "ls3d 0.1 gfx950" */
@@ -186,8 +192,8 @@ typedef struct {
  * to ls3d_gather_gemm. */
 size_t ls3d_gather_gemm_packed_floats(int kvol, int cin_pad, int cout);
 int ls3d_gather_gemm_default_nt(int cout);
-int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, int nt, float *w_packed,
-                          ls3d_stream_t stream);
+int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, int nt, int precision,
+                          float *w_packed, ls3d_stream_t stream);
 
 /* out[r, 0..cout) = epilogue( sum_k W[k]^T * in[tbl[r,k]] ), tbl == NULL means the identity table with
  * kvol == 1 (a dense Linear layer).  in[*, cin] row stride in_ld, `w` = weights packed by
@@ -199,7 +205,8 @@ int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_p
  * row_order (optional, int32[n_rows]): tile slot i processes output row row_order[i] (see ls3d_rulebook_masks).
  * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
  * (tbl = nbr_inv) and every nn.Linear on the path. */
-int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int wc, int cin, int cout,
+int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int wc,
+                     int precision /* must equal the packing's; BF16X3 needs cin % 32 == 0 and wc == 1 */, int cin, int cout,
                      int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
                      int out_ld, ls3d_stream_t stream);
 

@@ -254,6 +254,275 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") variant: every f32 operand is split into a bf16 head and a bf16 tail (a = a_hi + a_lo,
+// |a - a_hi - a_lo| <= 2^-16 |a|) and a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
+// v_mfma_f32_32x32x16_bf16 with f32 accumulation — 3 bf16 MFMAs (3 x 32 cycles per K=16) instead of 8 f32 MFMAs
+// (8 x 64 cycles), i.e. 5.3x less matrix-pipe time, at ~1e-5 relative error per layer (the dropped a_lo*b_lo term
+// and the tail's rounding).  Measured end to end on SDSeg3D: 1.4e-5 of the logit range (tests/…), i.e. well inside
+// the 1e-3 budget for logits of magnitude <= 50.  Weights are split once at pack time; gathered rows are split in
+// registers right after the load (truncated head, round-to-nearest tail: 4 VALU ops per element).
+// Same tiling / pipeline / epilogue as k_gather_gemm (KC = 32, WC = 1).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned ls3d_bf16_rne(float x) {  // bits of bf16(x), round to nearest even
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void ls3d_split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+  const unsigned ha = __float_as_uint(a) & 0xFFFF0000u, hb = __float_as_uint(b) & 0xFFFF0000u;
+  hi = (ha >> 16) | hb;
+  lo = ls3d_bf16_rne(a - __uint_as_float(ha)) | (ls3d_bf16_rne(b - __uint_as_float(hb)) << 16);
+}
+__device__ __forceinline__ void ls3d_split8(const float4 &f0, const float4 &f1, uint4 &hi, uint4 &lo) {
+  ls3d_split_pair(f0.x, f0.y, hi.x, lo.x);
+  ls3d_split_pair(f0.z, f0.w, hi.y, lo.y);
+  ls3d_split_pair(f1.x, f1.y, hi.z, lo.z);
+  ls3d_split_pair(f1.z, f1.w, hi.w, lo.w);
+}
+
+template <int NT, bool SPARSE>
+__global__ __launch_bounds__(256) void k_gather_gemm_bf16x3(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
+                                                           const int32_t *__restrict__ order, int kvol, const float *__restrict__ w,
+                                                           int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
+                                                           float *__restrict__ out, int out_ld) {
+  constexpr int KC = 32, TR = 128, SLAB = NT * 32;
+  constexpr int BV = KC * SLAB / 4;      // 16-byte units in one weight chunk (same bytes as the f32 chunk)
+  constexpr int BPT = BV / 256;          // NT
+  __shared__ __attribute__((aligned(16))) float Bs[2][KC * SLAB];  // chunk layout: [n][t][hi/lo][kk][col] x (8 bf16)
+  __shared__ unsigned long long s_kmask;
+  __shared__ int s_rows[TR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kk = lane >> 5;
+  const int n0 = blockIdx.y * SLAB;
+  const int N = ls3d_count(n_rows, n_rows_dev);
+  const int ntiles = (N + TR - 1) / TR;
+  const int nslab = w_ld / SLAB;
+  const float *wbase = w + (size_t)blockIdx.y * cin * SLAB;  // packed: [kvol][slab][cin/32][chunk]
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (tid == 0) s_kmask = 0ull;
+    if (tid < TR) {
+      const int r = tile * TR + tid;
+      s_rows[tid] = r < N ? (order ? order[r] : r) : -1;
+    }
+    __syncthreads();
+    const int row = s_rows[wave * 32 + col];
+    unsigned long long wmask = 0ull;
+    if (SPARSE) {
+      for (int k = 0; k < kvol; ++k) {
+        const int idx = (row >= 0) ? tbl[(size_t)row * kvol + k] : -1;
+        if (__any(idx >= 0)) wmask |= 1ull << k;
+      }
+    } else {
+      wmask = __any(row >= 0) ? 1ull : 0ull;
+    }
+    if (lane == 0 && wmask) atomicOr(&s_kmask, wmask);
+    __syncthreads();
+    unsigned long long rem = s_kmask;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    if (rem) {
+      int k_cur = __ffsll((long long)rem) - 1;
+      rem &= rem - 1;
+      int k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
+#define LS3D_LOAD_IDX(k) ((row >= 0) ? (SPARSE ? tbl[(size_t)row * kvol + (k)] : row) : -1)
+#define LS3D_LOAD_A(dst, idx, c0_)                                                              \
+  do {                                                                                          \
+    if ((idx) >= 0) {                                                                           \
+      const float4 *p_ = (const float4 *)(in + (size_t)(idx)*in_ld + (c0_) + kk * 16);          \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) dst[q] = p_[q];                             \
+    } else {                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);   \
+    }                                                                                           \
+  } while (0)
+#define LS3D_B_ONE(j, reg, OP) \
+  if constexpr (BPT > (j)) { const int i_ = tid + (j)*256; OP(reg, i_); }
+#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)(i_)*4)
+#define LS3D_B_ST(reg, i_) *(float4 *)(dst_ + (i_)*4) = reg
+#define LS3D_LOAD_B(k, c0_)                                                                     \
+  do {                                                                                          \
+    const float *wk_ = wbase + ((size_t)(k)*cin * nslab + (c0_)) * SLAB;                        \
+    LS3D_B_ONE(0, breg0, LS3D_B_LD) LS3D_B_ONE(1, breg1, LS3D_B_LD)                             \
+    LS3D_B_ONE(2, breg2, LS3D_B_LD) LS3D_B_ONE(3, breg3, LS3D_B_LD)                             \
+  } while (0)
+#define LS3D_STORE_B(dst)                                                                       \
+  do {                                                                                          \
+    float *dst_ = (dst);                                                                        \
+    LS3D_B_ONE(0, breg0, LS3D_B_ST) LS3D_B_ONE(1, breg1, LS3D_B_ST)                             \
+    LS3D_B_ONE(2, breg2, LS3D_B_ST) LS3D_B_ONE(3, breg3, LS3D_B_ST)                             \
+  } while (0)
+      int idx_cur = LS3D_LOAD_IDX(k_cur);
+      int idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
+      float4 a_cur[4], a_nxt[4];
+      float4 breg0, breg1, breg2, breg3;
+      int c0 = 0, buf = 0;
+      LS3D_LOAD_A(a_cur, idx_cur, 0);
+      LS3D_LOAD_B(k_cur, 0);
+      LS3D_STORE_B(Bs[0]);
+      __syncthreads();
+      for (;;) {
+        int nk = k_cur, nc0 = c0 + KC, nidx = idx_cur;
+        bool has_next = true;
+        if (nc0 >= cin) {
+          nc0 = 0; nk = k_nxt; nidx = idx_nxt;
+          has_next = nk >= 0;
+        }
+        if (has_next) {
+          LS3D_LOAD_A(a_nxt, nidx, nc0);
+          LS3D_LOAD_B(nk, nc0);
+        }
+        if ((wmask >> k_cur) & 1ull) {
+          uint4 ah0, al0, ah1, al1;  // heads / tails of this lane's 16 floats: k-step 0 uses floats 0-7, k-step 1 floats 8-15
+          ls3d_split8(a_cur[0], a_cur[1], ah0, al0);
+          ls3d_split8(a_cur[2], a_cur[3], ah1, al1);
+          const bf16x8 vah0 = __builtin_bit_cast(bf16x8, ah0), val0 = __builtin_bit_cast(bf16x8, al0);
+          const bf16x8 vah1 = __builtin_bit_cast(bf16x8, ah1), val1 = __builtin_bit_cast(bf16x8, al1);
+          const uint4 *bs = (const uint4 *)Bs[buf] + kk * 32 + col;  // unit index (((n*2+t)*2+h)*2+kk)*32+col
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const bf16x8 bh0 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 0) * 2 + 0) * 64]);
+            const bf16x8 bl0 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 0) * 2 + 1) * 64]);
+            const bf16x8 bh1 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 1) * 2 + 0) * 64]);
+            const bf16x8 bl1 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 1) * 2 + 1) * 64]);
+            // small terms first
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val0, bh0, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah0, bl0, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val1, bh1, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bl1, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah0, bh0, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bh1, acc[n], 0, 0, 0);
+          }
+        }
+        if (!has_next) break;
+        LS3D_STORE_B(Bs[buf ^ 1]);
+        __syncthreads();
+        buf ^= 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+        if (nk != k_cur) {
+          k_cur = nk; idx_cur = idx_nxt;
+          rem &= rem - 1;
+          k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
+          idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
+        }
+        c0 = nc0;
+      }
+    }
+#undef LS3D_LOAD_IDX
+#undef LS3D_LOAD_A
+#undef LS3D_LOAD_B
+#undef LS3D_B_ONE
+#undef LS3D_B_LD
+#undef LS3D_B_ST
+#undef LS3D_STORE_B
+    constexpr int RPP = 64;
+    float *stage = &Bs[0][0];
+    const bool vec = ((cout & 3) == 0) && ((out_ld & 3) == 0) && (!e.res_pre || (e.res_pre_ld & 3) == 0) &&
+                     (!e.pair || (e.pair_ld & 3) == 0);
+#pragma unroll
+    for (int pass = 0; pass < TR / RPP; ++pass) {
+      __syncthreads();
+      if ((wave * 32) / RPP == pass) {
+        float *dst = stage + ((wave * 32) % RPP + 4 * kk) * SLAB + col;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB + n * 32] = acc[n][r];
+      }
+      __syncthreads();
+      if (vec) {
+        for (int i = tid; i < RPP * (SLAB / 4); i += 256) {
+          const int lr = i / (SLAB / 4), c4 = i % (SLAB / 4);
+          const int orow = s_rows[pass * RPP + lr], oc = n0 + c4 * 4;
+          if (orow >= 0 && oc < cout) {
+            float4 v = *(const float4 *)(stage + lr * SLAB + c4 * 4);
+            if (e.scale) {
+              const float4 sc = *(const float4 *)(e.scale + oc);
+              v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+            }
+            if (e.shift) {
+              const float4 sh = *(const float4 *)(e.shift + oc);
+              v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
+            }
+            if (e.res_pre) {
+              const float4 q = *(const float4 *)(e.res_pre + (size_t)orow * e.res_pre_ld + oc);
+              v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (e.pair) {
+              const float4 p0 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc);
+              const float4 p1 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc + 4);
+              v.x += p0.x + p0.y; v.y += p0.z + p0.w; v.z += p1.x + p1.y; v.w += p1.z + p1.w;
+            }
+            *(float4 *)(out + (size_t)orow * out_ld + oc) = v;
+          }
+        }
+      } else {
+        for (int i = tid; i < RPP * SLAB; i += 256) {
+          const int lr = i / SLAB, c = i % SLAB;
+          const int orow = s_rows[pass * RPP + lr], oc = n0 + c;
+          if (orow >= 0 && oc < cout) {
+            float v = stage[lr * SLAB + c];
+            if (e.scale) v *= e.scale[oc];
+            if (e.shift) v += e.shift[oc];
+            if (e.res_pre) v += e.res_pre[(size_t)orow * e.res_pre_ld + oc];
+            if (e.relu) v = fmaxf(v, 0.0f);
+            if (e.pair) v += e.pair[(size_t)orow * e.pair_ld + 2 * oc] + e.pair[(size_t)orow * e.pair_ld + 2 * oc + 1];
+            out[(size_t)orow * out_ld + oc] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// plain [kvol][cin_src][cout] -> split-bf16 packed [kvol][slab][cin_pad/32][n][t][hi/lo][kk][col] x 8 bf16
+__global__ __launch_bounds__(256) void k_gg_pack_bf16x3(const float *src, int kvol, int cin_src, int cin_pad, int cout, int nt, uint4 *dst) {
+  const int slab = nt * 32, nslab = ((cout + 31) / 32) / nt, nchunk = cin_pad / 32;
+  const long long total = (long long)kvol * nslab * nchunk * nt * 256;  // 16-byte units
+  for (long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; t_ < total; t_ += (long long)gridDim.x * blockDim.x) {
+    long long r = t_;
+    const int col = (int)(r % 32); r /= 32;
+    const int kk = (int)(r % 2); r /= 2;
+    const int h = (int)(r % 2); r /= 2;
+    const int t = (int)(r % 2); r /= 2;
+    const int n = (int)(r % nt); r /= nt;
+    const int ch = (int)(r % nchunk); r /= nchunk;
+    const int sl = (int)(r % nslab); r /= nslab;
+    const int k = (int)r;
+    const int oc = sl * slab + n * 32 + col;
+    unsigned wds[4];
+    for (int pr = 0; pr < 4; ++pr) {
+      unsigned half[2];
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int c = ch * 32 + kk * 16 + t * 8 + pr * 2 + e2;
+        const float v = (c < cin_src && oc < cout) ? src[((size_t)k * cin_src + c) * cout + oc] : 0.0f;
+        const unsigned hb = ls3d_bf16_rne(v);
+        half[e2] = h == 0 ? hb : ls3d_bf16_rne(v - __uint_as_float(hb << 16));
+      }
+      wds[pr] = half[0] | (half[1] << 16);
+    }
+    uint4 o;
+    o.x = wds[0]; o.y = wds[1]; o.z = wds[2]; o.w = wds[3];
+    dst[t_] = o;
+  }
+}
+
+template <int NT>
+static void launch_gg3(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
+                       const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
+  if (tbl)
+    hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, true>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
+                       n_rows_dev, e, out, out_ld);
+  else
+    hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, false>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
+                       n_rows_dev, e, out, out_ld);
+}
+
 template <int KC, int NT, int WC>
 static void launch_gg(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
                       const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
@@ -297,20 +566,28 @@ extern "C" int ls3d_gather_gemm_default_nt(int cout) { return gg_nt(cout); }
 
 static inline bool gg_nt_ok(int cout, int nt) { return nt >= 1 && nt <= 4 && (((cout + 31) / 32) % nt) == 0; }
 
-extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, int nt, float *w_packed,
-                                     ls3d_stream_t stream) {
+extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, int nt, int precision,
+                                     float *w_packed, ls3d_stream_t stream) {
   if (!w_plain || !w_packed || kvol < 1 || cin_src < 1 || cin_pad < cin_src || (cin_pad % 16) || cout < 1) return LS3D_ERR_ARG;
   if (nt == 0) nt = gg_nt(cout);
   if (!gg_nt_ok(cout, nt)) return LS3D_ERR_ARG;
   const long long total = (long long)ls3d_gather_gemm_packed_floats(kvol, cin_pad, cout);
+  if (precision == LS3D_PRECISION_BF16X3) {
+    if (cin_pad % 32) return LS3D_ERR_ARG;
+    hipLaunchKernelGGL(k_gg_pack_bf16x3, ls3d_grid(total / 4), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt,
+                       (uint4 *)w_packed);
+    LS3D_RETURN_IF_LAUNCH_FAILED();
+    return LS3D_OK;
+  }
+  if (precision != LS3D_PRECISION_F32) return LS3D_ERR_ARG;
   hipLaunchKernelGGL(k_gg_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt, w_packed);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
 
 extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt,
-                                int wc, int cin, int cout, int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi, float *out,
-                                int out_ld, ls3d_stream_t stream_) {
+                                int wc, int precision, int cin, int cout, int n_rows, const int32_t *n_rows_dev,
+                                const ls3d_epilogue_t *epi, float *out, int out_ld, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !w || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
@@ -331,6 +608,18 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   const int tr = 32 * (4 / wc);
   const int ntiles = (n_rows + tr - 1) / tr;
   dim3 grid((unsigned)(ntiles < 4096 ? ntiles : 4096), (unsigned)slabs);
+  if (precision == LS3D_PRECISION_BF16X3) {
+    if ((cin % 32) || wc != 1) return LS3D_ERR_ARG;
+    switch (nt) {
+      case 1: launch_gg3<1>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld); break;
+      case 2: launch_gg3<2>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld); break;
+      case 3: launch_gg3<3>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld); break;
+      default: launch_gg3<4>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld);
+    }
+    LS3D_RETURN_IF_LAUNCH_FAILED();
+    return LS3D_OK;
+  }
+  if (precision != LS3D_PRECISION_F32) return LS3D_ERR_ARG;
   const bool k32 = (cin % 32) == 0;
 #define LS3D_GG(KC, NT, WC) launch_gg<KC, NT, WC>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld)
 #define LS3D_GG_K(KC)                                              \

@@ -236,22 +236,40 @@ def rulebook_order(tbl):
     return torch.argsort(mask).to(_i32)
 
 
-def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0):
+F32, BF16X3 = 0, 1
+_PRECISION = F32
+
+
+def set_precision(name):
+    """arithmetic of every gather-GEMM whose cin is a multiple of 32: "f32" (default; exact f32 MFMA) or "bf16x3"
+    (split-bf16: 3 bf16 MFMAs per product, ~1e-5 relative error per layer, ~5x less matrix time)"""
+    global _PRECISION
+    _PRECISION = {"f32": F32, "bf16x3": BF16X3}[name]
+
+
+def get_precision():
+    return "bf16x3" if _PRECISION == BF16X3 else "f32"
+
+
+def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0, precision=F32):
     """plain [kvol,cin,cout] -> kernel layout (flat tensor) for column-block count nt (0 = default)"""
     L = _L()
     out = torch.empty((L.ls3d_gather_gemm_packed_floats(kvol, cin_pad, cout),), dtype=torch.float32, device=w_plain.device)
-    check(L.ls3d_gather_gemm_pack(_ptr(w_plain), kvol, cin, cin_pad, cout, nt, _ptr(out), _stream(w_plain)), "ls3d_gather_gemm_pack")
+    check(L.ls3d_gather_gemm_pack(_ptr(w_plain), kvol, cin, cin_pad, cout, nt, precision, _ptr(out), _stream(w_plain)),
+          "ls3d_gather_gemm_pack")
     return out
 
 
-def choose_geometry(cout, n_rows, target_blocks=768):
+def choose_geometry(cout, n_rows, target_blocks=1024):
     """(nt, wc): 32-column blocks per wave and waves along the columns (workgroup = 32*(4/wc) rows x 32*nt*wc columns).
     Among the geometries that give the 256 CUs at least ~3 workgroups each, take the one with the fewest column slabs
     (every extra slab re-gathers the input rows) and then the tallest tile; if none does, take the one with the most
     workgroups (fewest slabs on ties)."""
     total = (cout + 31) // 32
     cands = []
-    for nt, wc in ((4, 1), (3, 1), (2, 2), (2, 1), (1, 4), (1, 2), (1, 1)):
+    # measured on MI355X (profiles/): sharing gathered rows between waves (wc > 1) is slower than re-gathering them
+    # per column slab (L3: 779 vs 749 us, L4: 414 vs 299 us) — the wide geometries stay available but are not chosen
+    for nt, wc in ((4, 1), (3, 1), (2, 1), (1, 1)):
         if total % (nt * wc):
             continue
         slabs = total // (nt * wc)
@@ -276,7 +294,10 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     assert cout == w.cout, "packed layout depends on cout"
     rows_hint = tbl.shape[0] if (tbl is not None and n_rows is None) else (n_rows if n_rows is not None else x.shape[0])
     nt, wc = choose_geometry(cout, rows_hint)
-    wdata = w.for_nt(nt)
+    prec = BF16X3 if (_PRECISION == BF16X3 and cin % 32 == 0) else F32
+    if prec == BF16X3:
+        wc = 1
+    wdata = w.for_nt(nt, prec)
     if tbl is not None:
         n_rows = tbl.shape[0] if n_rows is None else n_rows
         assert tbl.shape[1] == kvol
@@ -291,7 +312,7 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
         out_ld = out_ld or out.shape[1]
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0)
-    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, wc, cin, cout, n_rows, None, ctypes.byref(epi),
+    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, wc, prec, cin, cout, n_rows, None, ctypes.byref(epi),
                                 _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
     return out
 

@@ -37,11 +37,12 @@ class PackedWeight(object):
         self.plain, self.kvol, self.cin_src, self.cin, self.cout = plain, kvol, cin_src, cin_pad, cout
         self._by_nt = {}
 
-    def for_nt(self, nt):
-        d = self._by_nt.get(nt)
+    def for_nt(self, nt, precision=0):
+        d = self._by_nt.get((nt, precision))
         if d is None:
             from . import ops
-            d = self._by_nt[nt] = ops.gather_gemm_pack(self.plain, self.kvol, self.cin_src, self.cin, self.cout, nt)
+            d = self._by_nt[(nt, precision)] = ops.gather_gemm_pack(self.plain, self.kvol, self.cin_src, self.cin, self.cout, nt,
+                                                                     precision)
         return d
 
     @property

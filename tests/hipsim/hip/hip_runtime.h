@@ -173,5 +173,8 @@ typedef float hipsim_f32x16 __attribute__((ext_vector_type(16)));
 typedef float hipsim_f32x4 __attribute__((ext_vector_type(4)));
 hipsim_f32x16 hipsim_mfma_32x32x2f32(float a, float b, hipsim_f32x16 c, int, int, int);
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipsim_mfma_32x32x2f32
+typedef __bf16 hipsim_bf16x8 __attribute__((ext_vector_type(8)));
+hipsim_f32x16 hipsim_mfma_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim_f32x16 c, int, int, int);
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipsim_mfma_32x32x16_bf16
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

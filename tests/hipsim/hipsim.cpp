@@ -210,3 +210,32 @@ hipsim_f32x16 hipsim_mfma_32x32x2f32(float a, float b, hipsim_f32x16 c, int, int
   hipsim::wave_barrier();
   return d;
 }
+
+// 32x32x16 bf16: lane l holds A[i=l&31][k=8*(l>>5)+j] and B[k=8*(l>>5)+j][col=l&31], j = 0..7; C/D as the f32 form.
+// (Any consistent k assignment gives the same product; kernels must not depend on it beyond A/B pairing.)
+hipsim_f32x16 hipsim_mfma_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim_f32x16 c, int, int, int) {
+  static float A[16][32][16], B[16][16][32];
+  int w = hipsim::wave(), l = hipsim::lane();
+  uint16_t ra[8], rb[8];
+  memcpy(ra, &a, 16);
+  memcpy(rb, &b, 16);
+  for (int j = 0; j < 8; ++j) {
+    uint32_t ua = (uint32_t)ra[j] << 16, ub = (uint32_t)rb[j] << 16;
+    float fa, fb;
+    memcpy(&fa, &ua, 4);
+    memcpy(&fb, &ub, 4);
+    A[w][l & 31][8 * (l >> 5) + j] = fa;
+    B[w][8 * (l >> 5) + j][l & 31] = fb;
+  }
+  hipsim::wave_barrier();
+  hipsim_f32x16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) acc = fmaf(A[w][row][k], B[w][k][col], acc);
+    d[r] = acc;
+  }
+  hipsim::wave_barrier();
+  return d;
+}

@@ -8,6 +8,7 @@ lscpu | egrep 'Model name|^CPU\(s\)' >> $OUT/gpu.txt
 timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $OUT/summary.txt
 timeout 400 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt
 timeout 900 python bench.py --steps ${STEPS:-20} --warmup 5 > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/summary.txt
+timeout 600 python bench.py --precision bf16x3 --no-cpu-baseline --steps ${STEPS:-20} --warmup 5 > $OUT/bench_bf16x3.log 2> $OUT/bench_bf16x3.err; echo "bench bf16x3 rc=$?" >> $OUT/summary.txt
 timeout 600 python bench.py --model mseg3d --steps ${STEPS:-20} --warmup 5 > $OUT/bench_mseg3d.log 2> $OUT/bench_mseg3d.err; echo "bench mseg3d rc=$?" >> $OUT/summary.txt
 if [ "${PROFILE:-1}" = "1" ]; then
   cd /tmp
@@ -22,4 +23,4 @@ if [ "${PROFILE:-1}" = "1" ]; then
   fi
   cd "$R"
 fi
-tail -5 $OUT/pytest_gpu.log; cat $OUT/summary.txt; tail -3 $OUT/smoke.log; cat $OUT/bench.log; cat $OUT/bench_mseg3d.log; tail -3 $OUT/bench_mseg3d.err
+tail -5 $OUT/pytest_gpu.log; cat $OUT/summary.txt; tail -3 $OUT/smoke.log; cat $OUT/bench.log; cat $OUT/bench_bf16x3.log; tail -3 $OUT/bench_bf16x3.err; cat $OUT/bench_mseg3d.log; tail -3 $OUT/bench_mseg3d.err

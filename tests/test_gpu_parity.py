@@ -248,3 +248,28 @@ def test_mseg3d_end_to_end_vs_oracle():
     assert err <= 1e-3 + 2e-5 * scale, (err, scale)
     pred = torch.cat([r["pred_point_sem_labels"].cpu() for r in ret])
     assert float((pred == want["out_logits"].argmax(1)).float().mean()) >= 0.999
+
+
+def test_bf16x3_gemm_and_end_to_end():
+    """split-bf16 fast mode: GEMM within 3e-5 relative, SDSeg3D logits within 1e-3 + 5e-5*range of the f32 oracle"""
+    from lidarseg3d_amd.packing import PackedWeight
+    rng = np.random.default_rng(1)
+    a, b = rng.normal(size=(5000, 128)).astype(np.float32), rng.normal(size=(128, 128)).astype(np.float32)
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    ops.set_precision("bf16x3")
+    try:
+        out = ops.gather_gemm(cu(a), PackedWeight(cu(b).reshape(1, 128, 128).contiguous(), 1, 128, 128, 128), cout=128)
+        assert np.abs(out.cpu().numpy() - want).max() <= 3e-5 * np.abs(want).max()
+        cfg = synth.NUSC
+        model, sd = _model(models_cfg.sdseg3d())
+        frames = [synth.lidar_frame(20000, seed=1, **cfg)]
+        pts = np.concatenate([np.zeros((20000, 1), np.float32), frames[0]], 1)
+        model(dict(points=cu(pts), batch_size=1), return_loss=False)
+        got = model.point_head.forward_ret_dict["out_logits"].cpu()
+    finally:
+        ops.set_precision("f32")
+    wantl = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])["out_logits"]
+    scale = float(wantl.abs().max())
+    err = float((got - wantl).abs().max())
+    assert err <= 1e-3 + 5e-5 * scale, (err, scale)
+    assert float((got.argmax(1) == wantl.argmax(1)).float().mean()) >= 0.999

@@ -220,3 +220,41 @@ def test_point_heads_small_vs_oracle():
     vl, out = orc.mseg3d_head(sd, vf, ctr, pts, cuvs, torch.from_numpy(img), torch.from_numpy(emb), 2)
     assert float((head.forward_ret_dict["voxel_logits"] - vl).abs().max()) <= 1e-4
     assert float((bd["out_logits"] - out).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("m,k,n,nt", [(150, 32, 64, 2), (140, 64, 128, 4), (70, 96, 96, 3), (200, 32, 17, 1)])
+def test_gather_gemm_bf16x3_close_to_f32(m, k, n, nt, monkeypatch):
+    """split-bf16 path: within ~2e-5 of the f64 product (and much closer than plain bf16 would be)"""
+    rng = np.random.default_rng(m)
+    a, b = rng.normal(size=(m, k)).astype(np.float32), rng.normal(size=(k, n)).astype(np.float32)
+    monkeypatch.setattr(ops, "choose_geometry", lambda cout, rows, target_blocks=1024: (nt, 1))
+    pw = PackedWeight(torch.from_numpy(b).reshape(1, k, n).contiguous(), 1, k, k, n)
+    ops.set_precision("bf16x3")
+    try:
+        out = ops.gather_gemm(torch.from_numpy(a), pw, cout=n)
+    finally:
+        ops.set_precision("f32")
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    err = np.abs(out.numpy() - want).max()
+    assert err <= 3e-5 * np.abs(a).max() * np.abs(b).max() * np.sqrt(k), err
+    bf = lambda x: torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    plain = np.abs(bf(a).astype(np.float64) @ bf(b).astype(np.float64) - want).max()
+    assert err < plain / 20
+
+
+def test_sparse_conv_bf16x3_vs_f32(monkeypatch):
+    rng = np.random.default_rng(4)
+    vin, vout, kvol, cin, cout = 200, 150, 27, 64, 64
+    x = rng.normal(size=(vin, cin)).astype(np.float32)
+    w = rng.normal(size=(kvol, cin, cout)).astype(np.float32) * 0.1
+    tbl = rng.integers(-1, vin, size=(vout, kvol)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.6] = -1
+    T = torch.from_numpy
+    pw = PackedWeight(T(w), kvol, cin, cin, cout)
+    ref = ops.gather_gemm(T(x), pw, tbl=T(tbl), cout=cout, relu=True)
+    ops.set_precision("bf16x3")
+    try:
+        got = ops.gather_gemm(T(x), pw, tbl=T(tbl), order=ops.rulebook_order(T(tbl)), cout=cout, relu=True)
+    finally:
+        ops.set_precision("f32")
+    assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
