@@ -23,6 +23,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+static int g_xcd_map = 0;  // XCD-contiguous tile mapping (see k_gather_gemm): measured SLOWER on MI355X (-4..-6 % fps in every mode,
+                           // profiles/round1_experiments.md), so off by default; LS3D_XCD_MAP=1 enables it for A/B measurements
+extern "C" void ls3d_set_xcd_map(int on) { g_xcd_map = on ? 1 : 0; }
+
 struct EpiDev {
   const float *scale, *shift, *res_pre, *pair;
   int res_pre_ld, pair_ld, relu;
@@ -41,7 +45,7 @@ template <int KC, int NT, int WC, bool SPARSE>
 __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
                                                     const int32_t *__restrict__ order, int kvol, const float *__restrict__ w, int cin,
                                                     int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
-                                                    float *__restrict__ out, int out_ld) {
+                                                    float *__restrict__ out, int out_ld, int xcd_map) {
   constexpr int WR = 4 / WC;                           // waves along the rows
   constexpr int TR = 32 * WR;                          // rows per workgroup tile
   constexpr int SPL = KC / 2;                          // floats of a row chunk held per lane
@@ -62,7 +66,13 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
   const int ntiles = (N + TR - 1) / TR;
   const int nwslab = w_ld / WSLAB;                     // packed: [kvol][wslab][cin][32][NT]
   const float *wbase = w + (size_t)blockIdx.y * WC * cin * WSLAB;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch; speed only, never correctness), so
+  // workgroup b takes tile (b % 8) * ceil(ntiles/8) + b / 8: each XCD's private L2 then serves one contiguous range
+  // of (spatially sorted) rows and their neighbours instead of 1/8 of everything.
+  const int tiles_per_xcd = (ntiles + 7) / 8;
+  for (int slot = blockIdx.x; slot < tiles_per_xcd * 8; slot += gridDim.x) {
+    const int tile = xcd_map ? (slot & 7) * tiles_per_xcd + (slot >> 3) : slot;
+    if (tile >= ntiles) continue;
     // ---- tile slots -> output rows.  With `order` (rows sorted by their neighbour bitmask, rulebook.hip) the 32
     //      rows of a wave share most of their empty kernel offsets, so the skips below remove most zero work.
     if (tid == 0) s_kmask = 0ull;
@@ -285,7 +295,7 @@ template <int NT, bool SPARSE>
 __global__ __launch_bounds__(256) void k_gather_gemm_bf16x3(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
                                                            const int32_t *__restrict__ order, int kvol, const float *__restrict__ w,
                                                            int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
-                                                           float *__restrict__ out, int out_ld) {
+                                                           float *__restrict__ out, int out_ld, int xcd_map) {
   constexpr int KC = 32, TR = 128, SLAB = NT * 32;
   constexpr int BV = KC * SLAB / 4;      // 16-byte units in one weight chunk (same bytes as the f32 chunk)
   constexpr int BPT = BV / 256;          // NT
@@ -299,7 +309,13 @@ __global__ __launch_bounds__(256) void k_gather_gemm_bf16x3(const float *__restr
   const int ntiles = (N + TR - 1) / TR;
   const int nslab = w_ld / SLAB;
   const float *wbase = w + (size_t)blockIdx.y * cin * SLAB;  // packed: [kvol][slab][cin/32][chunk]
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch; speed only, never correctness), so
+  // workgroup b takes tile (b % 8) * ceil(ntiles/8) + b / 8: each XCD's private L2 then serves one contiguous range
+  // of (spatially sorted) rows and their neighbours instead of 1/8 of everything.
+  const int tiles_per_xcd = (ntiles + 7) / 8;
+  for (int slot = blockIdx.x; slot < tiles_per_xcd * 8; slot += gridDim.x) {
+    const int tile = xcd_map ? (slot & 7) * tiles_per_xcd + (slot >> 3) : slot;
+    if (tile >= ntiles) continue;
     if (tid == 0) s_kmask = 0ull;
     if (tid < TR) {
       const int r = tile * TR + tid;
@@ -517,10 +533,10 @@ static void launch_gg3(dim3 grid, hipStream_t stream, const float *in, int in_ld
                        const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
   if (tbl)
     hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, true>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
-                       n_rows_dev, e, out, out_ld);
+                       n_rows_dev, e, out, out_ld, g_xcd_map);
   else
     hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, false>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
-                       n_rows_dev, e, out, out_ld);
+                       n_rows_dev, e, out, out_ld, g_xcd_map);
 }
 
 template <int KC, int NT, int WC>
@@ -528,10 +544,10 @@ static void launch_gg(dim3 grid, hipStream_t stream, const float *in, int in_ld,
                       const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
   if (tbl)
     hipLaunchKernelGGL((k_gather_gemm<KC, NT, WC, true>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout,
-                       n_rows, n_rows_dev, e, out, out_ld);
+                       n_rows, n_rows_dev, e, out, out_ld, g_xcd_map);
   else
     hipLaunchKernelGGL((k_gather_gemm<KC, NT, WC, false>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout,
-                       n_rows, n_rows_dev, e, out, out_ld);
+                       n_rows, n_rows_dev, e, out, out_ld, g_xcd_map);
 }
 
 // column-block decomposition shared by the kernel dispatch and the weight packer

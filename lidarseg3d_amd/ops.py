@@ -18,8 +18,21 @@ _i32 = torch.int32
 _SIM = False
 
 
+_XCD_SET = False
+
+
 def _L():
-    return _lib.load()
+    global _XCD_SET
+    L = _lib.load()
+    if not _XCD_SET:
+        _XCD_SET = True
+        L.ls3d_set_xcd_map(int(_os_environ_get("LS3D_XCD_MAP", "0")))
+    return L
+
+
+def _os_environ_get(k, d):
+    import os
+    return os.environ.get(k, d)
 
 
 def set_sim(flag):
@@ -225,11 +238,22 @@ def rulebook_conv(coords, batch, shape_zyx, ksize, stride, pad, out_cap=None):
     return oc, cnt, nbr_out, nbr_inv, oshape
 
 
+_ROW_ORDER = "mask"
+
+
+def set_row_order(kind):
+    """"mask": gather-GEMM tiles take rows sorted by neighbour bitmask (skips zero MFMA work); "none": natural row order
+    (keeps the spatial locality of sorted coordinates)"""
+    global _ROW_ORDER
+    assert kind in ("mask", "none")
+    _ROW_ORDER = kind
+
+
 def rulebook_order(tbl):
     """processing order of a rulebook table's rows: sorted by neighbour bitmask (kernel ls3d_rulebook_masks; the
     sort itself is torch.argsort — plumbing, to be replaced by a radix sort kernel)."""
     n, kvol = tbl.shape
-    if n == 0 or kvol > 31:
+    if n == 0 or kvol > 31 or _ROW_ORDER == "none":
         return None
     mask = torch.empty((n,), dtype=_i32, device=tbl.device)
     check(_L().ls3d_rulebook_masks(_ptr(tbl), n, None, kvol, _ptr(mask), _stream(tbl)), "ls3d_rulebook_masks")
@@ -260,11 +284,20 @@ def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0, precision=F32):
     return out
 
 
-def choose_geometry(cout, n_rows, target_blocks=1024):
+import os as _os
+_TARGET_BLOCKS = int(_os.environ.get("LS3D_TARGET_BLOCKS", "0"))
+
+
+def choose_geometry(cout, n_rows, target_blocks=None):
     """(nt, wc): 32-column blocks per wave and waves along the columns (workgroup = 32*(4/wc) rows x 32*nt*wc columns).
     Among the geometries that give the 256 CUs at least ~3 workgroups each, take the one with the fewest column slabs
     (every extra slab re-gathers the input rows) and then the tallest tile; if none does, take the one with the most
     workgroups (fewest slabs on ties)."""
+    if target_blocks is None:
+        # measured on MI355X (120k-pt frame): the f32 path is matrix-pipe bound and wants many small workgroups
+        # (60.5 fps at >=1500 vs 53 at 256); the split-bf16 path is bound by re-gathering the input rows once per
+        # column slab and wants few, wide workgroups (84.6 fps at 128-384 vs 67.5 at 1500)
+        target_blocks = _TARGET_BLOCKS or (192 if _PRECISION == BF16X3 else 2000)
     total = (cout + 31) // 32
     cands = []
     # measured on MI355X (profiles/): sharing gathered rows between waves (wc > 1) is slower than re-gathering them

@@ -106,7 +106,7 @@ def test_gather_gemm_dense_all_geometries(m, k, n, nt, wc, monkeypatch):
     """C = A B (asymmetric operands: catches transposed fragments), every (NT, WC) variant, both K-chunk sizes"""
     rng = np.random.default_rng(m)
     a, b = rng.normal(size=(m, k)).astype(np.float32), rng.normal(size=(k, n)).astype(np.float32)
-    monkeypatch.setattr(ops, "choose_geometry", lambda cout, rows, target_blocks=1024: (nt, wc))
+    monkeypatch.setattr(ops, "choose_geometry", lambda cout, rows, target_blocks=None: (nt, wc))
     out = ops.gather_gemm(torch.from_numpy(a), PackedWeight(torch.from_numpy(b).reshape(1, k, n).contiguous(), 1, k, k, n), cout=n)
     np.testing.assert_allclose(out.numpy(), a.astype(np.float64) @ b.astype(np.float64), rtol=0, atol=1e-4)
 
@@ -130,7 +130,7 @@ def test_gather_gemm_sparse_with_order_and_fused_epilogue(monkeypatch):
     T = torch.from_numpy
     pw = PackedWeight(T(w), kvol, cin, cin, cout)
     for nt, wc in ((1, 1), (2, 1), (1, 2)):
-        monkeypatch.setattr(ops, "choose_geometry", lambda c, r, target_blocks=1024, g=(nt, wc): g)
+        monkeypatch.setattr(ops, "choose_geometry", lambda c, r, target_blocks=None, g=(nt, wc): g)
         for order in (None, ops.rulebook_order(T(tbl))):
             out = ops.gather_gemm(T(x), pw, tbl=T(tbl), order=order, cout=cout, scale=T(scale), shift=T(shift), res_pre=T(res),
                                   relu=True, pair=T(pair))
@@ -227,7 +227,7 @@ def test_gather_gemm_bf16x3_close_to_f32(m, k, n, nt, monkeypatch):
     """split-bf16 path: within ~2e-5 of the f64 product (and much closer than plain bf16 would be)"""
     rng = np.random.default_rng(m)
     a, b = rng.normal(size=(m, k)).astype(np.float32), rng.normal(size=(k, n)).astype(np.float32)
-    monkeypatch.setattr(ops, "choose_geometry", lambda cout, rows, target_blocks=1024: (nt, 1))
+    monkeypatch.setattr(ops, "choose_geometry", lambda cout, rows, target_blocks=None: (nt, 1))
     pw = PackedWeight(torch.from_numpy(b).reshape(1, k, n).contiguous(), 1, k, k, n)
     ops.set_precision("bf16x3")
     try:
