@@ -244,6 +244,13 @@ def main():
                          "tflops": conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0,
                          "sparse_conv_ms_per_frame": conv["total_ms"] / max(args.steps, 1)},
         }
+        pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")
+        if args.model == "sdseg3d" and args.precision == "f32" and args.points == 120000 and os.path.exists(pmc):
+            # HBM-side bytes per sparse-conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+            # same command (profiles/round1_pmc.md; counters cannot be collected from inside the timed run)
+            out["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/round1_pmc.json (2*FETCH_SIZE+WRITE_SIZE, KiB, corrected per MI355X_MICROARCH.md)"
+        out["roofline"]["algo_bytes_per_launch"] = conv["algo_bytes"] / max(conv["launches"], 1)
         if fast is not None:
             out["fast_mode"] = fast
         if args.model == "mseg3d":
