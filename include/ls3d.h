@@ -174,7 +174,9 @@ void ls3d_set_xcd_map(int on);
  *   v = acc * scale[c] + shift[c]           (folded eval BatchNorm / bias)
  *   v += res_pre[r*res_pre_ld + c]          (SparseBasicBlock identity, scn_unet.py:66)
  *   v = relu ? max(v,0) : v
- *   v += pair[r*pair_ld + 2c] + pair[r*pair_ld + 2c+1]   (channel_reduction + add, scn_unet.py:168-169) */
+ *   v += pair[r*pair_ld + 2c] + pair[r*pair_ld + 2c+1]   (channel_reduction + add, scn_unet.py:168-169)
+ *   v = LayerNorm_row(v) * ln_gamma[c] + ln_beta[c]      (post-/pre-norm transformer layers; needs nt*wc*32 >= cout,
+ *                                                          i.e. the whole row in one workgroup; exclusive with `pair`) */
 typedef struct {
   const float *scale, *shift;
   const float *res_pre;
@@ -182,6 +184,8 @@ typedef struct {
   const float *pair;
   int32_t pair_ld;
   int32_t relu;
+  const float *ln_gamma, *ln_beta;
+  float ln_eps;
 } ls3d_epilogue_t;
 
 /* Weight packing for ls3d_gather_gemm.  Input: plain row-major W[kvol][cin_src][cout] (= spconv's
@@ -216,6 +220,11 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
 /* ------------------------------------------------------------------------------------------------
  * Devoxelization
  * ---------------------------------------------------------------------------------------------- */
+
+/* Row offsets of the frames of a frame-sorted table (points [n,stride] f32 or coordinates [n,stride] int32 with the
+ * batch index in column `col`): off[b] = first row with batch index >= b, b = 0..batch (off[batch] = n).  Replaces the
+ * reference's per-frame boolean masks (`coords[:, 0] == i`, point_utils.py:20-21, context_module.py:39,350). */
+int ls3d_frame_offsets(const void *table, int is_float, int stride, int col, int n, int batch, int32_t *off, ls3d_stream_t stream);
 
 /* voxel centres: out[v] = (b, (x+.5)*vx+x0, (y+.5)*vy+y0, (z+.5)*vz+z0), f32 mul then add (unfused),
  * det3d/core/utils/common_utils.py:74-90 + scn_unet.py:243-247. */

@@ -534,6 +534,26 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   return LS3D_OK;
 }
 
+// off[b] = first row whose batch index (column `col` of a frame-sorted table) is >= b, b = 0..batch  (binary search)
+__global__ void k_frame_offsets(const void *table, int is_float, int stride, int col, int n, int batch, int32_t *off) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > batch) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int v = is_float ? (int)((const float *)table)[(size_t)mid * stride + col] : ((const int32_t *)table)[(size_t)mid * stride + col];
+    if (v < b) lo = mid + 1; else hi = mid;
+  }
+  off[b] = lo;
+}
+
+extern "C" int ls3d_frame_offsets(const void *table, int is_float, int stride, int col, int n, int batch, int32_t *off, ls3d_stream_t stream) {
+  if (!table || !off || n < 0 || batch < 1 || stride < 1 || col < 0 || col >= stride) return LS3D_ERR_ARG;
+  hipLaunchKernelGGL(k_frame_offsets, dim3((batch + 1 + 63) / 64), dim3(64), 0, (hipStream_t)stream, table, is_float, stride, col, n, batch, off);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
 extern "C" int ls3d_voxel_centers(const int32_t *coords, int n, const int32_t *n_dev, const float vs[3], const float lo[3], float *out,
                                   ls3d_stream_t stream) {
   if (!coords || !vs || !lo || !out || n < 0) return LS3D_ERR_ARG;

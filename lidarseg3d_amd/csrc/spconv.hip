@@ -28,9 +28,107 @@ static int g_xcd_map = 0;  // XCD-contiguous tile mapping (see k_gather_gemm): m
 extern "C" void ls3d_set_xcd_map(int on) { g_xcd_map = on ? 1 : 0; }
 
 struct EpiDev {
-  const float *scale, *shift, *res_pre, *pair;
+  const float *scale, *shift, *res_pre, *pair, *ln_gamma, *ln_beta;
   int res_pre_ld, pair_ld, relu;
+  float ln_eps;
 };
+
+// ---- epilogue through LDS (shared by the f32 and split-bf16 kernels): the accumulators (fragment layout: register r of
+//      lane (col,kk) = output row (r&3) + 8*(r>>2) + 4*kk, column col) are transposed into row-major tiles in the weight
+//      buffer, then all 256 threads apply scale/shift, residual, ReLU, pair-sum, optionally a row LayerNorm (whole row in
+//      this workgroup's slab), and store whole rows with float4.
+template <int NT, int WC, int TR, int RPP>
+__device__ __forceinline__ void gg_epilogue(f32x16 (&acc)[NT], float *stage, const int *s_rows, float *s_stat, int wr, int wc, int kk,
+                                            int col, int n0, int cout, const EpiDev &e, float *__restrict__ out, int out_ld) {
+  constexpr int WSLAB = NT * 32, SLAB = WSLAB * WC;
+  const int tid = threadIdx.x;
+  const bool vec = ((cout & 3) == 0) && ((out_ld & 3) == 0) && (!e.res_pre || (e.res_pre_ld & 3) == 0) && (!e.pair || (e.pair_ld & 3) == 0);
+#pragma unroll
+  for (int pass = 0; pass < TR / RPP; ++pass) {
+    __syncthreads();  // previous readers of the buffer (MFMA loop or previous pass) are done
+    if ((wr * 32) / RPP == pass) {
+      float *dst = stage + ((wr * 32) % RPP + 4 * kk) * SLAB + wc * WSLAB + col;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB + n * 32] = acc[n][r];
+    }
+    __syncthreads();
+    if (e.ln_gamma) {
+      // LayerNorm needs the finished row: apply the element-wise part in place, then per-row statistics, then normalise
+      for (int i = tid; i < RPP * SLAB; i += 256) {
+        const int lr = i / SLAB, c = i % SLAB;
+        const int orow = s_rows[pass * RPP + lr], oc = n0 + c;
+        if (orow >= 0 && oc < cout) {
+          float v = stage[i];
+          if (e.scale) v *= e.scale[oc];
+          if (e.shift) v += e.shift[oc];
+          if (e.res_pre) v += e.res_pre[(size_t)orow * e.res_pre_ld + oc];
+          if (e.relu) v = fmaxf(v, 0.0f);
+          stage[i] = v;
+        }
+      }
+      __syncthreads();
+      for (int lr = tid; lr < RPP; lr += 256) {
+        float s = 0.0f;
+        for (int c = 0; c < cout; ++c) s += stage[lr * SLAB + c];
+        const float mean = s / (float)cout;
+        float q = 0.0f;
+        for (int c = 0; c < cout; ++c) { const float d = stage[lr * SLAB + c] - mean; q += d * d; }
+        s_stat[2 * lr] = mean;
+        s_stat[2 * lr + 1] = 1.0f / sqrtf(q / (float)cout + e.ln_eps);
+      }
+      __syncthreads();
+      for (int i = tid; i < RPP * SLAB; i += 256) {
+        const int lr = i / SLAB, c = i % SLAB;
+        const int orow = s_rows[pass * RPP + lr], oc = n0 + c;
+        if (orow >= 0 && oc < cout) out[(size_t)orow * out_ld + oc] = (stage[i] - s_stat[2 * lr]) * s_stat[2 * lr + 1] * e.ln_gamma[oc] + e.ln_beta[oc];
+      }
+    } else if (vec) {
+      for (int i = tid; i < RPP * (SLAB / 4); i += 256) {
+        const int lr = i / (SLAB / 4), c4 = i % (SLAB / 4);
+        const int orow = s_rows[pass * RPP + lr], oc = n0 + c4 * 4;
+        if (orow >= 0 && oc < cout) {
+          float4 v = *(const float4 *)(stage + lr * SLAB + c4 * 4);
+          if (e.scale) {
+            const float4 sc = *(const float4 *)(e.scale + oc);
+            v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+          }
+          if (e.shift) {
+            const float4 sh = *(const float4 *)(e.shift + oc);
+            v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
+          }
+          if (e.res_pre) {
+            const float4 q = *(const float4 *)(e.res_pre + (size_t)orow * e.res_pre_ld + oc);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+          }
+          if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (e.pair) {
+            const float4 p0 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc);
+            const float4 p1 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc + 4);
+            v.x += p0.x + p0.y; v.y += p0.z + p0.w; v.z += p1.x + p1.y; v.w += p1.z + p1.w;
+          }
+          *(float4 *)(out + (size_t)orow * out_ld + oc) = v;
+        }
+      }
+    } else {
+      for (int i = tid; i < RPP * SLAB; i += 256) {
+        const int lr = i / SLAB, c = i % SLAB;
+        const int orow = s_rows[pass * RPP + lr], oc = n0 + c;
+        if (orow >= 0 && oc < cout) {
+          float v = stage[lr * SLAB + c];
+          if (e.scale) v *= e.scale[oc];
+          if (e.shift) v += e.shift[oc];
+          if (e.res_pre) v += e.res_pre[(size_t)orow * e.res_pre_ld + oc];
+          if (e.relu) v = fmaxf(v, 0.0f);
+          if (e.pair) v += e.pair[(size_t)orow * e.pair_ld + 2 * oc] + e.pair[(size_t)orow * e.pair_ld + 2 * oc + 1];
+          out[(size_t)orow * out_ld + oc] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();  // buffer and s_rows are reused by the next tile
+}
 
 // Template parameters
 //   KC     K-chunk (input channels per LDS weight chunk): 32, or 16 when cin % 32 != 0
@@ -58,6 +156,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
   __shared__ __attribute__((aligned(16))) float Bs[2][KC * SLAB];  // double-buffered weight chunk, [piece][k][32][NT]
   __shared__ unsigned long long s_kmask;               // kernel offsets with an active neighbour in this tile
   __shared__ int s_rows[TR];                           // output row handled by each tile slot (-1 = none)
+  __shared__ float s_stat[2 * 64];                     // per-row mean / rstd of the LayerNorm epilogue
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int col = lane & 31, kk = lane >> 5;
@@ -199,68 +298,8 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float *__restrict__ i
 #undef LS3D_B_LD
 #undef LS3D_B_ST
 #undef LS3D_STORE_B
-    // ---- epilogue through LDS: the accumulators (fragment layout: register r of lane (col,kk) = output row
-    //      (r&3) + 8*(r>>2) + 4*kk, column col) are transposed into row-major tiles in the weight buffer, then
-    //      all 256 threads apply scale/shift, residual, ReLU, pair-sum and store whole rows with float4.
-    constexpr int RPP = (2 * KC < TR) ? 2 * KC : TR;  // tile rows that fit in Bs per pass
-    float *stage = &Bs[0][0];
-    const bool vec = ((cout & 3) == 0) && ((out_ld & 3) == 0) && (!e.res_pre || (e.res_pre_ld & 3) == 0) &&
-                     (!e.pair || (e.pair_ld & 3) == 0);
-#pragma unroll
-    for (int pass = 0; pass < TR / RPP; ++pass) {
-      __syncthreads();  // previous readers of Bs (MFMA loop or previous pass) are done
-      if ((wr * 32) / RPP == pass) {
-        float *dst = stage + ((wr * 32) % RPP + 4 * kk) * SLAB + wc * WSLAB + col;
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB + n * 32] = acc[n][r];
-      }
-      __syncthreads();
-      if (vec) {
-        for (int i = tid; i < RPP * (SLAB / 4); i += 256) {
-          const int lr = i / (SLAB / 4), c4 = i % (SLAB / 4);
-          const int orow = s_rows[pass * RPP + lr], oc = n0 + c4 * 4;
-          if (orow >= 0 && oc < cout) {
-            float4 v = *(const float4 *)(stage + lr * SLAB + c4 * 4);
-            if (e.scale) {
-              const float4 sc = *(const float4 *)(e.scale + oc);
-              v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-            }
-            if (e.shift) {
-              const float4 sh = *(const float4 *)(e.shift + oc);
-              v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
-            }
-            if (e.res_pre) {
-              const float4 q = *(const float4 *)(e.res_pre + (size_t)orow * e.res_pre_ld + oc);
-              v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
-            if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (e.pair) {
-              const float4 p0 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc);
-              const float4 p1 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc + 4);
-              v.x += p0.x + p0.y; v.y += p0.z + p0.w; v.z += p1.x + p1.y; v.w += p1.z + p1.w;
-            }
-            *(float4 *)(out + (size_t)orow * out_ld + oc) = v;
-          }
-        }
-      } else {
-        for (int i = tid; i < RPP * SLAB; i += 256) {
-          const int lr = i / SLAB, c = i % SLAB;
-          const int orow = s_rows[pass * RPP + lr], oc = n0 + c;
-          if (orow >= 0 && oc < cout) {
-            float v = stage[lr * SLAB + c];
-            if (e.scale) v *= e.scale[oc];
-            if (e.shift) v += e.shift[oc];
-            if (e.res_pre) v += e.res_pre[(size_t)orow * e.res_pre_ld + oc];
-            if (e.relu) v = fmaxf(v, 0.0f);
-            if (e.pair) v += e.pair[(size_t)orow * e.pair_ld + 2 * oc] + e.pair[(size_t)orow * e.pair_ld + 2 * oc + 1];
-            out[(size_t)orow * out_ld + oc] = v;
-          }
-        }
-      }
-    }
-    __syncthreads();  // Bs and s_rows are reused by the next tile
+    constexpr int RPP = (2 * KC < TR) ? 2 * KC : TR;  // tile rows that fit in the weight buffer per pass
+    gg_epilogue<NT, WC, TR, RPP>(acc, &Bs[0][0], s_rows, s_stat, wr, wc, kk, col, n0, cout, e, out, out_ld);
   }
 }
 
@@ -302,6 +341,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm_bf16x3(const float *__restr
   __shared__ __attribute__((aligned(16))) float Bs[2][KC * SLAB];  // chunk layout: [n][t][hi/lo][kk][col] x (8 bf16)
   __shared__ unsigned long long s_kmask;
   __shared__ int s_rows[TR];
+  __shared__ float s_stat[2 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kk = lane >> 5;
   const int n0 = blockIdx.y * SLAB;
@@ -434,65 +474,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm_bf16x3(const float *__restr
 #undef LS3D_B_LD
 #undef LS3D_B_ST
 #undef LS3D_STORE_B
-    constexpr int RPP = 64;
-    float *stage = &Bs[0][0];
-    const bool vec = ((cout & 3) == 0) && ((out_ld & 3) == 0) && (!e.res_pre || (e.res_pre_ld & 3) == 0) &&
-                     (!e.pair || (e.pair_ld & 3) == 0);
-#pragma unroll
-    for (int pass = 0; pass < TR / RPP; ++pass) {
-      __syncthreads();
-      if ((wave * 32) / RPP == pass) {
-        float *dst = stage + ((wave * 32) % RPP + 4 * kk) * SLAB + col;
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB + n * 32] = acc[n][r];
-      }
-      __syncthreads();
-      if (vec) {
-        for (int i = tid; i < RPP * (SLAB / 4); i += 256) {
-          const int lr = i / (SLAB / 4), c4 = i % (SLAB / 4);
-          const int orow = s_rows[pass * RPP + lr], oc = n0 + c4 * 4;
-          if (orow >= 0 && oc < cout) {
-            float4 v = *(const float4 *)(stage + lr * SLAB + c4 * 4);
-            if (e.scale) {
-              const float4 sc = *(const float4 *)(e.scale + oc);
-              v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-            }
-            if (e.shift) {
-              const float4 sh = *(const float4 *)(e.shift + oc);
-              v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
-            }
-            if (e.res_pre) {
-              const float4 q = *(const float4 *)(e.res_pre + (size_t)orow * e.res_pre_ld + oc);
-              v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
-            if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (e.pair) {
-              const float4 p0 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc);
-              const float4 p1 = *(const float4 *)(e.pair + (size_t)orow * e.pair_ld + 2 * oc + 4);
-              v.x += p0.x + p0.y; v.y += p0.z + p0.w; v.z += p1.x + p1.y; v.w += p1.z + p1.w;
-            }
-            *(float4 *)(out + (size_t)orow * out_ld + oc) = v;
-          }
-        }
-      } else {
-        for (int i = tid; i < RPP * SLAB; i += 256) {
-          const int lr = i / SLAB, c = i % SLAB;
-          const int orow = s_rows[pass * RPP + lr], oc = n0 + c;
-          if (orow >= 0 && oc < cout) {
-            float v = stage[lr * SLAB + c];
-            if (e.scale) v *= e.scale[oc];
-            if (e.shift) v += e.shift[oc];
-            if (e.res_pre) v += e.res_pre[(size_t)orow * e.res_pre_ld + oc];
-            if (e.relu) v = fmaxf(v, 0.0f);
-            if (e.pair) v += e.pair[(size_t)orow * e.pair_ld + 2 * oc] + e.pair[(size_t)orow * e.pair_ld + 2 * oc + 1];
-            out[(size_t)orow * out_ld + oc] = v;
-          }
-        }
-      }
-    }
-    __syncthreads();
+    gg_epilogue<NT, 1, TR, 64>(acc, &Bs[0][0], s_rows, s_stat, wave, 0, kk, col, n0, cout, e, out, out_ld);
   }
 }
 
@@ -610,10 +592,12 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   if ((!tbl && kvol != 1) || kvol > 64) return LS3D_ERR_ARG;
   if (((uintptr_t)in & 15) || ((uintptr_t)w & 15)) return LS3D_ERR_ARG;
   if (n_rows == 0) return LS3D_OK;
-  EpiDev e = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  EpiDev e = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.0f};
   if (epi) {
     e.scale = epi->scale; e.shift = epi->shift; e.res_pre = epi->res_pre; e.pair = epi->pair;
     e.res_pre_ld = epi->res_pre_ld; e.pair_ld = epi->pair_ld; e.relu = epi->relu;
+    e.ln_gamma = epi->ln_gamma; e.ln_beta = epi->ln_beta; e.ln_eps = epi->ln_eps;
+    if ((e.ln_gamma != nullptr) != (e.ln_beta != nullptr) || (e.ln_gamma && e.pair)) return LS3D_ERR_ARG;
   }
   const int w_ld = (cout + 31) / 32 * 32;
   const int nt_total = w_ld / 32;
@@ -621,6 +605,7 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   if (wc == 0) wc = 1;
   if (!gg_nt_ok(cout, nt) || (wc != 1 && wc != 2 && wc != 4) || (nt_total % (nt * wc)) || nt * wc > 4) return LS3D_ERR_ARG;
   const int slabs = nt_total / (nt * wc);
+  if (e.ln_gamma && slabs != 1) return LS3D_ERR_ARG;  // the LayerNorm epilogue needs the whole row in one workgroup
   const int tr = 32 * (4 / wc);
   const int ntiles = (n_rows + tr - 1) / tr;
   dim3 grid((unsigned)(ntiles < 4096 ? ntiles : 4096), (unsigned)slabs);

@@ -34,7 +34,7 @@ def _voxel_inputs(example, voxel_cfg):
                                     int(mv) * batch_size, batched=True)
     V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it
     _, grid = ops.make_grid(voxel_cfg["voxel_size"], voxel_cfg["range"])
-    example["num_voxels"] = ops.frame_offsets(c[:V, 0], batch_size).diff()
+    example["num_voxels"] = ops.frame_offsets(c[:V], batch_size).diff()
     return v[:V], c[:V], n[:V], batch_size, np.asarray(grid)
 
 

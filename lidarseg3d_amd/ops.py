@@ -317,7 +317,7 @@ def choose_geometry(cout, n_rows, target_blocks=None):
 
 
 def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
-                out=None, out_ld=None, in_ld=None, cin=None):
+                out=None, out_ld=None, in_ld=None, cin=None, ln=None):
     """out[r, :cout] = epilogue(sum_k W[k]^T x[tbl[r,k]]).  w: packing.PackedWeight."""
     kvol, wcin, wld = w.shape
     cin = cin or wcin
@@ -327,6 +327,9 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     assert cout == w.cout, "packed layout depends on cout"
     rows_hint = tbl.shape[0] if (tbl is not None and n_rows is None) else (n_rows if n_rows is not None else x.shape[0])
     nt, wc = choose_geometry(cout, rows_hint)
+    if ln is not None:  # LayerNorm epilogue: the whole row must sit in one workgroup slab
+        assert cout <= 128, "LayerNorm epilogue supports up to 128 columns"
+        nt, wc = (cout + 31) // 32, 1
     prec = BF16X3 if (_PRECISION == BF16X3 and cin % 32 == 0) else F32
     if prec == BF16X3:
         wc = 1
@@ -344,7 +347,8 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
         out_view = out
         out_ld = out_ld or out.shape[1]
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
-                   pair.shape[1] if pair is not None else 0, 1 if relu else 0)
+                   pair.shape[1] if pair is not None else 0, 1 if relu else 0, _vp(ln[0]) if ln is not None else ctypes.c_void_p(0),
+                   _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
     check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, wc, prec, cin, cout, n_rows, None, ctypes.byref(epi),
                                 _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
     return out
@@ -400,11 +404,19 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return g
 
 
-def frame_offsets(batch_col, batch_size):
-    """[B+1] int32 device offsets of frame-sorted rows (torch bookkeeping, no host sync)."""
-    cnt = torch.bincount(batch_col.to(torch.int64), minlength=batch_size)[:batch_size]
-    off = torch.zeros((batch_size + 1,), dtype=_i32, device=batch_col.device)
-    off[1:] = torch.cumsum(cnt, 0).to(_i32)
+def frame_offsets(table, batch_size, col=0):
+    """[B+1] int32 device offsets of the frames of a frame-sorted table (f32 points or int32 coordinates, batch index in
+    column `col`); a 1-D tensor is taken as the batch column itself.  One tiny kernel, no host sync."""
+    if table.dim() == 1:
+        table = table.unsqueeze(1)
+    if not table.is_contiguous():
+        table = table.contiguous()
+    is_float = 1 if table.dtype == torch.float32 else 0
+    if not is_float and table.dtype != _i32:
+        table = table.to(_i32)
+    off = torch.empty((batch_size + 1,), dtype=_i32, device=table.device)
+    check(_L().ls3d_frame_offsets(_ptr(table), is_float, table.shape[1], col, table.shape[0], batch_size, _ptr(off), _stream(table)),
+          "ls3d_frame_offsets")
     return off
 
 

@@ -18,11 +18,11 @@ from .packing import PackedModule, pack_linear
 from .registry import POINT_HEADS
 
 
-def _lin(x, pk, relu=False, res=None, n_rows=None):
+def _lin(x, pk, relu=False, res=None, n_rows=None, ln=None):
     W, scale, shift, cout = pk
     if x.shape[1] != W.shape[1]:
         x = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1]))
-    return ops.gather_gemm(x, W, cout=cout, scale=scale, shift=shift, relu=relu, res_pre=res, n_rows=n_rows)
+    return ops.gather_gemm(x, W, cout=cout, scale=scale, shift=shift, relu=relu, res_pre=res, n_rows=n_rows, ln=ln)
 
 
 def _pack_mlp(seq):
@@ -56,9 +56,7 @@ def _make_convcls_head(fc_cfg, input_channels, output_channels, dp_ratio=0):
 
 def _frame_layout(points, conv_point_coords, batch_size):
     """device offsets of the frame-sorted point / voxel rows + host upper bounds for the launch grids"""
-    pt_off = ops.frame_offsets(points[:, 0], batch_size)
-    vx_off = ops.frame_offsets(conv_point_coords[:, 0], batch_size)
-    return pt_off, vx_off
+    return ops.frame_offsets(points, batch_size), ops.frame_offsets(conv_point_coords, batch_size)
 
 
 def _devoxelize(batch_dict, points, centers, feat, batch_size):
@@ -97,6 +95,11 @@ def _predict(head, example, test_cfg):
             ret_list.append(ret)
         return ret_list
     labels = torch.argmax(logits, dim=1)
+    if batch_size == 1:  # one frame: no masking (boolean-mask indexing would force a host sync)
+        ret = dict(metadata=meta[0], pred_point_sem_labels=labels)
+        if "point_sem_labels" in example:
+            ret["point_sem_labels"] = example["point_sem_labels"]
+        return [ret]
     for i in range(batch_size):
         m = pts[:, 0] == i
         ret = dict(metadata=meta[i], pred_point_sem_labels=labels[m])
@@ -155,7 +158,7 @@ class LiDARSemanticFeatureAggregationModule(nn.Module):
         super().__init__()
 
     def forward(self, feats, probs, batch_idx, batch_size):
-        vx_off = ops.frame_offsets(batch_idx, batch_size)
+        vx_off = ops.frame_offsets(batch_idx.contiguous(), batch_size)
         emb = ops.sfam(feats.contiguous(), probs.contiguous(), vx_off, batch_size, feats.shape[0])
         return emb.permute(0, 2, 1).contiguous().unsqueeze(3)
 
@@ -254,15 +257,14 @@ class SemanticFeatureFusionModule(PackedModule):
         tgt = _lin(input_point_features, pk["point"])
         for lp in pk["layers"]:
             att = ops.mha_core(_lin(mem, lp["sa_qkv"]), B, L, E, H)
-            mem = ops.layernorm(_lin(att, lp["sa_out"]), *lp["n1"], res=mem)
+            mem = _lin(att, lp["sa_out"], res=mem, ln=lp["n1"])  # LayerNorm fused into the GEMM epilogue
             q = _lin(tgt, lp["q"])
             # k_proj / v_proj are Conv1d(k=1) over the tokens; the reference then VIEWS [B,E,L] as [B,H,hd,L]
             k = _lin(mem, lp["k"]).view(B, L, E).permute(0, 2, 1).contiguous()
             v = _lin(mem, lp["v"]).view(B, L, E).permute(0, 2, 1).contiguous()
             att = ops.cross_attn(q, k, v, B, H, points)
-            tgt = ops.layernorm(_lin(att, lp["o"]), *lp["n2"], res=tgt)
-            ff = _lin(_lin(tgt, lp["ff1"], relu=True), lp["ff2"])
-            tgt = ops.layernorm(ff, *lp["n3"], res=tgt)
+            tgt = _lin(att, lp["o"], res=tgt, ln=lp["n2"])
+            tgt = _lin(_lin(tgt, lp["ff1"], relu=True), lp["ff2"], res=tgt, ln=lp["n3"])
         tgt = ops.layernorm(tgt, *pk["norm_tgt"])
         if return_context:
             return tgt, mem.view(B, L, E).permute(1, 0, 2).contiguous()

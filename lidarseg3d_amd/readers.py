@@ -98,9 +98,9 @@ class TransformerVoxelFeatureExtractor(PackedModule):
         return p
 
     @staticmethod
-    def _lin(x, pk, relu=False, res=None):
+    def _lin(x, pk, relu=False, res=None, ln=None):
         W, scale, shift, cout = pk
-        return ops.gather_gemm(x, W, cout=cout, scale=scale, shift=shift, relu=relu, res_pre=res)
+        return ops.gather_gemm(x, W, cout=cout, scale=scale, shift=shift, relu=relu, res_pre=res, ln=ln)
 
     def forward(self, features, num_voxels, coors=None):
         assert self.num_input_features == features.shape[-1]
@@ -109,13 +109,15 @@ class TransformerVoxelFeatureExtractor(PackedModule):
         V, P, C = features.shape
         E, H = self.num_embed, self.num_head
         tok = ops.vfe_tokens(features.contiguous(), num_voxels.to(torch.int32).contiguous(), pk["embed"][0].shape[1])
-        x = self._lin(tok, pk["embed"])
-        for lp in pk["layers"]:
-            x = ops.layernorm(x, lp["n1"][0], lp["n1"][1], lp["n1"][2])
+        # every LayerNorm runs in the epilogue of the GEMM that produces its input (norm1 of layer l+1 in layer l's
+        # ff2 GEMM, norm1 of layer 0 in the embedding GEMM): no separate pass over the [V*5, 64] token matrix
+        layers = pk["layers"]
+        x = self._lin(tok, pk["embed"], ln=layers[0]["n1"] if layers else None)
+        for li, lp in enumerate(layers):
             att = ops.mha_core(self._lin(x, lp["qkv"]), V, P, E, H)
-            x = self._lin(att, lp["out"], res=x)
-            x = ops.layernorm(x, lp["n2"][0], lp["n2"][1], lp["n2"][2])
-            x = self._lin(self._lin(x, lp["ff1"], relu=True), lp["ff2"], res=x)
+            x = self._lin(att, lp["out"], res=x, ln=lp["n2"])
+            nxt = layers[li + 1]["n1"] if li + 1 < len(layers) else None
+            x = self._lin(self._lin(x, lp["ff1"], relu=True), lp["ff2"], res=x, ln=nxt)
         x = ops.group_max(x, V, P)
         if self.compress_layer is not None:
             x = self._lin(x, pk["compress"], relu=True)

@@ -99,20 +99,32 @@ class UNetSCN3D(nn.Module):
         self.conv5 = spconv.SparseSequential(block(c1, c1, 3, norm_fn=norm_fn, padding=1, indice_key="subm1"))
         self.num_point_features = c1
 
-    def UR_block_forward(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv):
-        """scn_unet.py:163-171.  The lateral block's second conv writes straight into the right half of the
-        concat buffer, conv_m's epilogue adds the channel-pair sums of that buffer (channel_reduction + add),
-        so cat / view-sum / add never run as separate passes."""
-        n, c = x_bottom.features.shape
-        cat = torch.empty((n, 2 * c), dtype=torch.float32, device=x_bottom.features.device)
-        cat[:, :c].copy_(x_bottom.features)
+    def UR_block_forward(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv, cat=None, next_cat=None):
+        """scn_unet.py:163-171 with the data movement fused away:
+          * `cat` [V, 2C] is the concat buffer; its left half already holds x_bottom when the previous UR block's
+            inverse conv wrote there (`next_cat`), otherwise it is copied in;
+          * the lateral block's second conv writes straight into the right half;
+          * conv_m's epilogue adds the channel-pair sums of `cat` (channel_reduction + add);
+          * the inverse conv writes into the left half of the NEXT level's concat buffer.
+        cat / view-sum / add / copies never run as separate passes."""
+        n, c = x_lateral.features.shape
+        if cat is None:
+            cat = torch.empty((n, 2 * c), dtype=torch.float32, device=x_lateral.features.device)
+            cat[:, :c].copy_(x_bottom.features)
         mid = conv_bn_act(conv_t.conv1, conv_t.bn1, x_lateral, relu=True)
         rb = conv_t.conv2.rulebook(mid)
         s, t = spconv.cached_bn_scale_shift(conv_t.conv2, conv_t.bn2)
         conv_t.conv2.conv(mid, rb, scale=s, shift=t, relu=True, res_pre=x_lateral.features, out=cat[:, c:], out_ld=2 * c)
         x = x_lateral._like(cat)
         x = conv_bn_act(conv_m[0], conv_m[1], x, relu=True, pair=cat)
-        return conv_inv(x)
+        if next_cat is None:
+            return conv_inv(x)
+        inv, bn = conv_inv[0], conv_inv[1]
+        rbi = inv.rulebook(x)
+        s, t = spconv.cached_bn_scale_shift(inv, bn)
+        cout = inv.out_channels
+        inv.conv(x, rbi, scale=s, shift=t, relu=True, out=next_cat[:, :cout], out_ld=next_cat.shape[1])
+        return x._like(next_cat[:, :cout], rbi.in_indices, rbi.in_shape)
 
     @staticmethod
     def channel_reduction(x, out_channels):
@@ -137,10 +149,13 @@ class UNetSCN3D(nn.Module):
         if self.conv_out is not None:
             batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
             batch_dict["encoded_spconv_tensor_stride"] = 8
-        x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4)
-        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3)
-        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2)
-        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5)
+        dev = voxel_features.device
+        cats = [torch.empty((t.features.shape[0], 2 * t.features.shape[1]), dtype=torch.float32, device=dev)
+                for t in (x_conv3, x_conv2, x_conv1)]
+        x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4, next_cat=cats[0])
+        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1])
+        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2])
+        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2])
         batch_dict["multi_scale_3d_features"] = dict(x_conv1=x_up2, x_conv2=x_up3, x_conv3=x_up4, x_conv4=x_conv4)
         batch_dict["conv_point_features"] = x_up1.features
         batch_dict["conv_point_coords"] = ops.voxel_centers(x_up1.indices, self.voxel_size, self.point_cloud_range)
