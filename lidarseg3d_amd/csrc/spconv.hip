@@ -54,8 +54,49 @@ __device__ __forceinline__ void gg_epilogue(f32x16 (&acc)[NT], float *stage, con
         for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB + n * 32] = acc[n][r];
     }
     __syncthreads();
-    if (e.ln_gamma) {
-      // LayerNorm needs the finished row: apply the element-wise part in place, then per-row statistics, then normalise
+    if (e.ln_gamma && vec) {
+      // LayerNorm epilogue, vectorised: a row's SLAB/4 float4s sit in LW consecutive lanes (LW = next power of two), so
+      // mean and variance are two shuffle reductions; nothing goes back through LDS.
+      constexpr int LW = (SLAB / 4 <= 8) ? 8 : (SLAB / 4 <= 16) ? 16 : 32;
+      for (int i = tid; i < RPP * LW; i += 256) {
+        const int lr = i / LW, c4 = i % LW;
+        const int orow = s_rows[pass * RPP + lr], oc = n0 + c4 * 4;
+        const bool on = (c4 < SLAB / 4) && (oc < cout);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on && orow >= 0) {
+          v = *(const float4 *)(stage + lr * SLAB + c4 * 4);
+          if (e.scale) {
+            const float4 sc = *(const float4 *)(e.scale + oc);
+            v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+          }
+          if (e.shift) {
+            const float4 sh = *(const float4 *)(e.shift + oc);
+            v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
+          }
+          if (e.res_pre) {
+            const float4 q = *(const float4 *)(e.res_pre + (size_t)orow * e.res_pre_ld + oc);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+          }
+          if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        float sum = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int d = LW / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        const float mean = sum / (float)cout;
+        const float dx = on ? v.x - mean : 0.f, dy = on ? v.y - mean : 0.f, dz = on ? v.z - mean : 0.f, dw = on ? v.w - mean : 0.f;
+        float q2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+        for (int d = LW / 2; d >= 1; d >>= 1) q2 += __shfl_xor(q2, d);
+        const float rstd = 1.0f / sqrtf(q2 / (float)cout + e.ln_eps);
+        if (on && orow >= 0) {
+          const float4 g = *(const float4 *)(e.ln_gamma + oc), bt = *(const float4 *)(e.ln_beta + oc);
+          float4 o;
+          o.x = dx * rstd * g.x + bt.x; o.y = dy * rstd * g.y + bt.y; o.z = dz * rstd * g.z + bt.z; o.w = dw * rstd * g.w + bt.w;
+          *(float4 *)(out + (size_t)orow * out_ld + oc) = o;
+        }
+      }
+    } else if (e.ln_gamma) {
+      // scalar fallback (unaligned leading dimensions): element-wise part in place, per-row statistics, normalise
       for (int i = tid; i < RPP * SLAB; i += 256) {
         const int lr = i / SLAB, c = i % SLAB;
         const int orow = s_rows[pass * RPP + lr], oc = n0 + c;
