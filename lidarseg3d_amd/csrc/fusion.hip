@@ -62,24 +62,55 @@ __global__ __launch_bounds__(256) void k_complete_concat(const float *lidar, int
 __device__ __forceinline__ int f2o(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-// pass 1: per (frame, class) max of the logits over the frame's voxels
+// block-level reduction helpers (256 threads): combine per-thread values per class, one atomic per (block, class)
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// pass 1: per (frame, class) max of the logits over the frame's voxels.  Thread = voxel, loop over classes;
+// wave shuffle + LDS combine, ONE atomic per (workgroup, class) instead of one per element.
 __global__ __launch_bounds__(256) void k_sfam_max(const float *logits, int cls, const int32_t *vx_off, int32_t *ws_max) {
+  __shared__ float s_part[4 * 32];
   const int f = blockIdx.y;
   const int v0 = vx_off[f], v1 = vx_off[f + 1];
-  const long long work = (long long)(v1 - v0) * cls;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(t % cls);
-    atomicMax(&ws_max[f * cls + c], f2o(logits[(size_t)v0 * cls + t]));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = v0 + blockIdx.x * 256; base < v1; base += gridDim.x * 256) {
+    const int v = base + threadIdx.x;
+    for (int c = 0; c < cls; ++c) {
+      const float m = wave_max(v < v1 ? logits[(size_t)v * cls + c] : -3.0e38f);
+      if (lane == 0) s_part[wave * 32 + c] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < cls) {
+      const float m = fmaxf(fmaxf(s_part[threadIdx.x], s_part[32 + threadIdx.x]), fmaxf(s_part[64 + threadIdx.x], s_part[96 + threadIdx.x]));
+      atomicMax(&ws_max[f * cls + threadIdx.x], f2o(m));
+    }
+    __syncthreads();
   }
 }
 // pass 2: per (frame, class) sum of exp(l - max)
 __global__ __launch_bounds__(256) void k_sfam_sum(const float *logits, int cls, const int32_t *vx_off, const int32_t *ws_max, float *ws_sum) {
+  __shared__ float s_part[4 * 32];
   const int f = blockIdx.y;
   const int v0 = vx_off[f], v1 = vx_off[f + 1];
-  const long long work = (long long)(v1 - v0) * cls;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(t % cls);
-    atomicAdd(&ws_sum[f * cls + c], expf(logits[(size_t)v0 * cls + t] - o2f(ws_max[f * cls + c])));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = v0 + blockIdx.x * 256; base < v1; base += gridDim.x * 256) {
+    const int v = base + threadIdx.x;
+    for (int c = 0; c < cls; ++c) {
+      const float t = wave_sum(v < v1 ? expf(logits[(size_t)v * cls + c] - o2f(ws_max[f * cls + c])) : 0.0f);
+      if (lane == 0) s_part[wave * 32 + c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < cls)
+      atomicAdd(&ws_sum[f * cls + threadIdx.x], (s_part[threadIdx.x] + s_part[32 + threadIdx.x]) + (s_part[64 + threadIdx.x] + s_part[96 + threadIdx.x]));
+    __syncthreads();
   }
 }
 // pass 3: emb[f, cls, c] += sum over a chunk of 64 voxels of p[v,cls] * feat[v,c]
@@ -110,43 +141,58 @@ __global__ __launch_bounds__(256) void k_sfam_acc(const float *feats, int feat_l
   }
 }
 
-// one thread per (point, head): softmax over the L class embeddings of the point's frame
+// one thread per (point, head): softmax over the L class embeddings of the point's frame.  The frame's K and V
+// ([H*HD, L] each, a few KB) are staged in LDS when the whole workgroup belongs to one frame (the common case: frames
+// are contiguous), so the inner loops are LDS broadcasts instead of dependent global loads.
 template <int HD>
 __global__ __launch_bounds__(256) void k_cross_attn(const float *q, const float *k, const float *v, int H, int L, const float *points,
                                                    int pt_stride, int n, float *out) {
+  HIP_DYNAMIC_SHARED(float, s_kv)  // [2][H*HD*L]
   const int E = H * HD;
+  const int per = 256 / H;  // points per workgroup
   const float scale = 1.0f / sqrtf((float)HD);
-  const long long work = (long long)n * H;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
-    const int p = (int)(t / H), h = (int)(t % H);
-    const int b = (int)points[(size_t)p * pt_stride];
-    const float *qp = q + (size_t)p * E + h * HD;
-    const float *kb = k + ((size_t)b * H + h) * HD * L;
-    const float *vb = v + ((size_t)b * H + h) * HD * L;
-    float qr[HD], acc[HD];
-#pragma unroll
-    for (int d = 0; d < HD; ++d) { qr[d] = qp[d]; acc[d] = 0.0f; }
-    float m = -3.0e38f;
-    for (int l = 0; l < L; ++l) {
-      float s = 0.0f;
-#pragma unroll
-      for (int d = 0; d < HD; ++d) s = fmaf(qr[d], kb[d * L + l], s);
-      m = fmaxf(m, s * scale);
+  for (long long pbase = (long long)blockIdx.x * per; pbase < n; pbase += (long long)gridDim.x * per) {
+    const int plast = (int)min((long long)n - 1, pbase + per - 1);
+    const int b0 = (int)points[(size_t)pbase * pt_stride], b1 = (int)points[(size_t)plast * pt_stride];
+    const bool staged = (b0 == b1);
+    __syncthreads();
+    if (staged) {
+      const float *kb0 = k + (size_t)b0 * E * L, *vb0 = v + (size_t)b0 * E * L;
+      for (int i = threadIdx.x; i < E * L; i += 256) { s_kv[i] = kb0[i]; s_kv[E * L + i] = vb0[i]; }
     }
-    float den = 0.0f;
-    for (int l = 0; l < L; ++l) {
-      float s = 0.0f;
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int p = (int)pbase + t / H, h = t % H;
+    if (t < per * H && p < n) {
+      const int b = (int)points[(size_t)p * pt_stride];
+      const float *qp = q + (size_t)p * E + h * HD;
+      const float *kb = staged ? s_kv + h * HD * L : k + ((size_t)b * H + h) * HD * L;
+      const float *vb = staged ? s_kv + E * L + h * HD * L : v + ((size_t)b * H + h) * HD * L;
+      float qr[HD], acc[HD];
 #pragma unroll
-      for (int d = 0; d < HD; ++d) s = fmaf(qr[d], kb[d * L + l], s);
-      const float pr = expf(s * scale - m);
-      den += pr;
+      for (int d = 0; d < HD; ++d) { qr[d] = qp[d]; acc[d] = 0.0f; }
+      float m = -3.0e38f;
+      for (int l = 0; l < L; ++l) {
+        float sc = 0.0f;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) acc[d] = fmaf(pr, vb[d * L + l], acc[d]);
+        for (int d = 0; d < HD; ++d) sc = fmaf(qr[d], kb[d * L + l], sc);
+        m = fmaxf(m, sc * scale);
+      }
+      float den = 0.0f;
+      for (int l = 0; l < L; ++l) {
+        float sc = 0.0f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) sc = fmaf(qr[d], kb[d * L + l], sc);
+        const float pr = expf(sc * scale - m);
+        den += pr;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = fmaf(pr, vb[d * L + l], acc[d]);
+      }
+      const float inv = 1.0f / den;
+      float *op = out + (size_t)p * E + h * HD;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
     }
-    const float inv = 1.0f / den;
-    float *op = out + (size_t)p * E + h * HD;
-#pragma unroll
-    for (int d = 0; d < HD; ++d) op[d] = acc[d] * inv;
   }
 }
 
@@ -182,7 +228,7 @@ extern "C" int ls3d_sfam(const float *feats, int feat_ld, int c, const float *lo
   hipMemsetAsync(ws_sum, 0, (size_t)batch * cls * 4, stream);
   hipMemsetAsync(emb, 0, (size_t)batch * cls * c * 4, stream);
   if (max_frame_voxels <= 0) return LS3D_OK;
-  dim3 g1 = ls3d_grid((long long)max_frame_voxels * cls);
+  dim3 g1 = ls3d_grid((long long)max_frame_voxels, 256, 1024);
   g1.y = batch;
   hipLaunchKernelGGL(k_sfam_max, g1, dim3(256), 0, stream, logits, cls, vx_off, ws_max);
   hipLaunchKernelGGL(k_sfam_sum, g1, dim3(256), 0, stream, logits, cls, vx_off, (const int32_t *)ws_max, ws_sum);
@@ -199,12 +245,16 @@ extern "C" int ls3d_cross_attn(const float *q, const float *k, const float *v, i
   hipStream_t stream = (hipStream_t)stream_;
   if (!q || !k || !v || !points || !out || batch < 1 || heads < 1 || embed % heads || L < 1 || n < 0) return LS3D_ERR_ARG;
   if (n == 0) return LS3D_OK;
-  const dim3 grid = ls3d_grid((long long)n * heads);
+  if (heads > 256) return LS3D_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)2 * embed * L * sizeof(float);
+  if (lds > 60 * 1024) return LS3D_ERR_UNSUPPORTED;
+  const int per = 256 / heads;
+  const dim3 grid = ls3d_grid(((long long)n + per - 1) / per * 256, 256, 4096);
   switch (embed / heads) {
-    case 8: hipLaunchKernelGGL((k_cross_attn<8>), grid, dim3(256), 0, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
-    case 16: hipLaunchKernelGGL((k_cross_attn<16>), grid, dim3(256), 0, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
-    case 24: hipLaunchKernelGGL((k_cross_attn<24>), grid, dim3(256), 0, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
-    case 32: hipLaunchKernelGGL((k_cross_attn<32>), grid, dim3(256), 0, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
+    case 8: hipLaunchKernelGGL((k_cross_attn<8>), grid, dim3(256), lds, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
+    case 16: hipLaunchKernelGGL((k_cross_attn<16>), grid, dim3(256), lds, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
+    case 24: hipLaunchKernelGGL((k_cross_attn<24>), grid, dim3(256), lds, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
+    case 32: hipLaunchKernelGGL((k_cross_attn<32>), grid, dim3(256), lds, stream, q, k, v, heads, L, points, pt_stride, n, out); break;
     default: return LS3D_ERR_UNSUPPORTED;
   }
   LS3D_RETURN_IF_LAUNCH_FAILED();
