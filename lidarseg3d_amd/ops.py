@@ -330,7 +330,9 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     if ln is not None:  # LayerNorm epilogue: the whole row must sit in one workgroup slab
         assert cout <= 128, "LayerNorm epilogue supports up to 128 columns"
         nt, wc = (cout + 31) // 32, 1
-    prec = BF16X3 if (_PRECISION == BF16X3 and cin % 32 == 0) else F32
+    # split-bf16 only where it pays and where its error budget is spent wisely: the sparse convolutions (matrix-pipe
+    # bound).  Dense Linear layers (TransVFE, heads, SF-Phase) are memory-bound and stay in exact f32.
+    prec = BF16X3 if (_PRECISION == BF16X3 and cin % 32 == 0 and tbl is not None) else F32
     if prec == BF16X3:
         wc = 1
     wdata = w.for_nt(nt, prec)

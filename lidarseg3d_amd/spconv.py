@@ -126,7 +126,9 @@ class SparseConvolution(PackedModule, SparseModule):
         tbl = rb.tbl_inv if self.inverse else rb.tbl
         if feats.shape[1] != W.shape[1]:  # e.g. 13 input channels feeding a 16-wide K chunk
             feats = torch.nn.functional.pad(feats, (0, W.shape[1] - feats.shape[1]))
-        return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, order=rb.order(self.inverse), cout=cout, scale=scale, shift=shift, relu=relu,
+        # mask-sorted processing order only for the layers whose matrix work can repay the sort (>= 64x64 channels)
+        order = rb.order(self.inverse) if self.in_channels * self.out_channels >= 4096 else None
+        return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, order=order, cout=cout, scale=scale, shift=shift, relu=relu,
                                res_pre=res_pre, pair=pair, out=out, out_ld=out_ld)
 
     def forward(self, x):

@@ -258,7 +258,8 @@ def test_bf16x3_gemm_and_end_to_end():
     want = a.astype(np.float64) @ b.astype(np.float64)
     ops.set_precision("bf16x3")
     try:
-        out = ops.gather_gemm(cu(a), PackedWeight(cu(b).reshape(1, 128, 128).contiguous(), 1, 128, 128, 128), cout=128)
+        ident = torch.arange(5000, dtype=torch.int32, device=DEV).unsqueeze(1).contiguous()  # identity rulebook, kvol = 1
+        out = ops.gather_gemm(cu(a), PackedWeight(cu(b).reshape(1, 128, 128).contiguous(), 1, 128, 128, 128), tbl=ident, cout=128)
         assert np.abs(out.cpu().numpy() - want).max() <= 3e-5 * np.abs(want).max()
         cfg = synth.NUSC
         model, sd = _model(models_cfg.sdseg3d())

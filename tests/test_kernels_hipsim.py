@@ -231,7 +231,8 @@ def test_gather_gemm_bf16x3_close_to_f32(m, k, n, nt, monkeypatch):
     pw = PackedWeight(torch.from_numpy(b).reshape(1, k, n).contiguous(), 1, k, k, n)
     ops.set_precision("bf16x3")
     try:
-        out = ops.gather_gemm(torch.from_numpy(a), pw, cout=n)
+        ident = torch.arange(m, dtype=torch.int32).unsqueeze(1).contiguous()  # identity rulebook (split-bf16 = sparse convs only)
+        out = ops.gather_gemm(torch.from_numpy(a), pw, tbl=ident, cout=n)
     finally:
         ops.set_precision("f32")
     want = a.astype(np.float64) @ b.astype(np.float64)
