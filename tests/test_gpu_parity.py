@@ -274,3 +274,54 @@ def test_bf16x3_gemm_and_end_to_end():
     err = float((got - wantl).abs().max())
     assert err <= 1e-3 + 5e-5 * scale, (err, scale)
     assert float((got.argmax(1) == wantl.argmax(1)).float().mean()) >= 0.999
+
+
+def test_semantickitti_config_end_to_end():
+    """BASELINE configs[0] geometry (SemanticKITTI SDSeg3D: 4 point features, 20 classes, range +-75.2 m, voxel
+    [0.1,0.1,0.15] -> grid 1504x1504x40) against the CPU oracle"""
+    cfg = synth.KITTI
+    model, sd = _model(models_cfg.sdseg3d(num_class=20, cp=4, pc_range=cfg["pc_range"], voxel_size=cfg["voxel_size"]), seed=3)
+    frames = [synth.lidar_frame(30000, seed=31, **cfg)]
+    pts = np.concatenate([np.zeros((30000, 1), np.float32), frames[0]], 1)
+    model(dict(points=cu(pts), batch_size=1), return_loss=False)
+    got = model.point_head.forward_ret_dict["out_logits"].cpu()
+    want = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])
+    assert got.shape == (30000, 20)
+    scale = float(want["out_logits"].abs().max())
+    assert float((got - want["out_logits"]).abs().max()) <= 1e-3 + 2e-5 * scale
+    assert float((got.argmax(1) == want["out_logits"].argmax(1)).float().mean()) >= 0.999
+
+
+def test_waymo_config_mseg3d_end_to_end():
+    """BASELINE configs[3] geometry (Waymo MSeg3D: 5 cameras, 23 classes, range [-75.2,-75.2,-2,75.2,75.2,4], 2 frames)"""
+    cfg = synth.WAYMO
+    model, sd = _model(models_cfg.mseg3d(num_class=23, cp=5, pc_range=cfg["pc_range"], voxel_size=cfg["voxel_size"]), seed=4)
+    frames = [synth.lidar_frame(18000, seed=41, **cfg), synth.lidar_frame(9000, seed=42, **cfg)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=6, ncam=5, c_img=48, h=40, w=60, num_class=23, batch=2)
+    model(dict(points=cu(pts), batch_size=2, points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb)),
+          return_loss=False)
+    got = model.point_head.forward_ret_dict["out_logits"].cpu()
+    want = orc.mseg3d_forward(sd, frames, torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), cfg["voxel_size"],
+                              cfg["pc_range"])
+    assert got.shape == (27000, 23)
+    scale = float(want["out_logits"].abs().max())
+    assert float((got - want["out_logits"]).abs().max()) <= 1e-3 + 2e-5 * scale
+    assert float((got.argmax(1) == want["out_logits"].argmax(1)).float().mean()) >= 0.999
+
+
+def test_drop_in_mode_with_dataloader_voxels():
+    """`example` carrying the dataloader's CPU-voxelised tensors (reference input contract) gives the same logits as the
+    points-only mode that voxelises on the GPU"""
+    cfg = synth.NUSC
+    model, sd = _model(models_cfg.sdseg3d())
+    frames = [synth.lidar_frame(9000, seed=51, **cfg), synth.lidar_frame(5000, seed=52, **cfg)]
+    ex = orc.collate_frames(frames, cfg["voxel_size"], cfg["pc_range"], 5, 300000)
+    example = dict(voxels=ex["voxels"].to(DEV), coordinates=ex["coordinates"].to(DEV), num_points=ex["num_points"].to(DEV),
+                   num_voxels=ex["num_voxels"].to(DEV), shape=ex["shape"], points=ex["points"].to(DEV), metadata=[{"token": "a"}, {"token": "b"}])
+    ret = model(example, return_loss=False)
+    a = model.point_head.forward_ret_dict["out_logits"].clone()
+    assert [r["metadata"]["token"] for r in ret] == ["a", "b"]
+    assert [int(r["pred_point_sem_labels"].shape[0]) for r in ret] == [9000, 5000]
+    model(dict(points=ex["points"].to(DEV), batch_size=2), return_loss=False)
+    assert torch.equal(a, model.point_head.forward_ret_dict["out_logits"])
