@@ -134,6 +134,8 @@ def main():
                     help="gather-GEMM arithmetic: f32 = exact f32 MFMA (default, the parity configuration); bf16x3 = split-bf16 "
                          "(3 bf16 MFMAs per product, ~1e-5 relative error)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 measurement")
+    ap.add_argument("--frames-per-step", type=int, default=1,
+                    help="frames collated into one forward per GPU per step (1 = the reference's --speed_test batch size)")
     ap.add_argument("--row-order", choices=["mask", "none"], default="mask")
     ap.add_argument("--model", choices=["sdseg3d", "mseg3d"], default="sdseg3d",
                     help="sdseg3d = BASELINE configs[1] (the metric's config); mseg3d = configs[2] (LiDAR + 6-camera features)")
@@ -160,17 +162,19 @@ def main():
     ops.set_precision(args.precision)
     ops.set_row_order(args.row_order)
     model, sd = build_model(dev, kind=args.model)
-    frame = synth.lidar_frame(args.points, seed=100 + rank, **synth.NUSC)
-    pts = torch.from_numpy(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)).to(dev)
+    B = max(1, args.frames_per_step)
+    frames = [synth.lidar_frame(args.points, seed=100 + rank * B + b, **synth.NUSC) for b in range(B)]
+    pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1)
+                                           for b, f in enumerate(frames)])).to(dev)
     extra = {}
     if args.model == "mseg3d":  # HRNet-w18 feature maps of 6 cameras at 1/4 resolution + camera class embeddings (inputs of the path)
-        img, emb, cuv = synth.camera_inputs(args.points, seed=100 + rank, ncam=6, c_img=48, h=160, w=240, batch=1)
+        img, emb, cuv = synth.camera_inputs(args.points * B, seed=100 + rank, ncam=6, c_img=48, h=160, w=240, batch=B)
         extra = dict(points_cuv=torch.from_numpy(cuv).to(dev), image_features=torch.from_numpy(img).to(dev),
                      camera_semantic_embeddings=torch.from_numpy(emb).to(dev))
     timer = ConvTimer(ops).install()
 
     def step():
-        ret = model(dict(points=pts, batch_size=1, **extra), return_loss=False)
+        ret = model(dict(points=pts, batch_size=B, **extra), return_loss=False)
         return ret[0]["pred_point_sem_labels"]
 
     with torch.no_grad():
@@ -195,7 +199,7 @@ def main():
 
     conv = timer.summarize()
     fast = None
-    if args.precision == "f32" and not args.no_fast_mode:
+    if args.precision == "f32" and not args.no_fast_mode and world == 1:
         # the same step in the split-bf16 arithmetic (fp32-level accuracy): reported beside, never as, `value`
         ref_logits = model.point_head.forward_ret_dict["out_logits"].clone()
         ops.set_precision("bf16x3")
@@ -216,7 +220,7 @@ def main():
             timer2.enabled = False
         c2 = timer2.summarize()
         got = model.point_head.forward_ret_dict["out_logits"]
-        fast = dict(precision="bf16x3 (split-bf16 MFMA, f32 accumulate)", value=args.steps / el2, ms_per_step=1e3 * el2 / args.steps,
+        fast = dict(precision="bf16x3 (split-bf16 MFMA, f32 accumulate)", value=B * args.steps / el2, ms_per_step=1e3 * el2 / args.steps,
                     sparse_conv_ms_per_frame=c2["total_ms"] / max(args.steps, 1),
                     roofline_frac=(c2["algo_bytes"] / (c2["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if c2["total_ms"] > 0 else 0.0,
                     max_rel_logit_diff_vs_f32=float((got - ref_logits).abs().max() / ref_logits.abs().max()),
@@ -229,13 +233,13 @@ def main():
         achieved = conv["algo_bytes"] / (conv["total_ms"] * 1e-3) / 1e9 if conv["total_ms"] > 0 else 0.0
         out = {
             "metric": "frames/sec, SDSeg3D forward, 120k-pt nuScenes-style frame",
-            "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": world * B * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f32 via split-bf16 (bf16x3 MFMA, f32 accumulate)", "data": "synthetic",
             "config": {"workload": "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead), "
                                    "%d pts/frame, voxel [0.1,0.1,0.2], range [-51.2,-51.2,-5,51.2,51.2,3], 17 classes, "
                                    "1 frame per GPU per step, GPU voxelization included" % args.points,
-                       "active_voxels": V, "frames_per_gpu_per_step": 1, "parallelism": "frames sharded 1/GPU (dp%d)" % world},
+                       "active_voxels": V, "frames_per_gpu_per_step": B, "parallelism": "frames sharded 1/GPU (dp%d)" % world},
             "roofline": {"bound": "hbm", "kernel": "k_gather_gemm (sparse-conv gather-GEMM, %d launches/frame)"
                                   % (conv["launches"] // max(args.steps, 1)),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

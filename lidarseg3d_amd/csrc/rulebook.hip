@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256) void k_conv_mark(const int32_t *coords, int n,
     int oz, oy, ox;
     if (conv_out_site(g, c[1], c[2], c[3], kz, ky, kx, oz, oy, ox)) {
       const uint64_t lin = ls3d_key(c[0], oz, oy, ox, g.out.z, g.out.y, g.out.x);
-      atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+      // up to 27 (input, offset) pairs hit the same output bit: test first so that only the first few pay an atomic
+      // (a stale read merely costs one redundant atomicOr)
+      const uint32_t bit = 1u << (lin & 31);
+      if (!(bitmap[lin >> 5] & bit)) atomicOr(&bitmap[lin >> 5], bit);
     }
   }
 }

@@ -257,7 +257,9 @@ def rulebook_order(tbl):
         return None
     mask = torch.empty((n,), dtype=_i32, device=tbl.device)
     check(_L().ls3d_rulebook_masks(_ptr(tbl), n, None, kvol, _ptr(mask), _stream(tbl)), "ls3d_rulebook_masks")
-    return torch.argsort(mask).to(_i32)
+    # descending: tiles with the most active offsets (the longest-running workgroups) are dispatched first, the short
+    # ones fill the tail of the launch
+    return torch.argsort(mask, descending=_os_environ_get("LS3D_ORDER_ASC", "0") != "1").to(_i32)
 
 
 F32, BF16X3 = 0, 1

@@ -1,4 +1,8 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out; OUT=$R/gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -k "mseg3d" 2>&1 | tail -3
-cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mseg3d -o bench -- python $R/bench.py --model mseg3d --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_mseg3d.log 2>&1
-grep '"metric"' $OUT/prof_mseg3d.log | cut -c1-2500
+rm -f $OUT/exp_*.log
+for a in 1 0 1 0; do
+  LS3D_ORDER_ASC=$a python bench.py --no-cpu-baseline --steps 15 --warmup 4 > $OUT/exp_asc${a}_$RANDOM.log 2>&1
+done
+cd $R; for f in $OUT/exp_*.log; do echo -n "$f "; python -c "
+import json,sys
+l=[x for x in open('$f') if x.startswith('{')][-1]; d=json.loads(l); print(round(d['value'],2), round(d['ms_per_step'],2), round(d['roofline']['frac'],3), 'fast', round(d['fast_mode']['value'],2), round(d['fast_mode']['roofline_frac'],3))"; done
