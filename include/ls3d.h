@@ -167,8 +167,10 @@ int ls3d_rulebook_conv(const int32_t *coords_in, int n_in, const int32_t *n_in_d
  * order changes. */
 int ls3d_rulebook_masks(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int32_t *mask, ls3d_stream_t stream);
 
-/* tuning knob (default off: measured slower): XCD-contiguous tile -> workgroup mapping of ls3d_gather_gemm; results are identical */
-void ls3d_set_xcd_map(int on);
+/* tuning knob: workgroup -> (tile, column slab) mapping of ls3d_gather_gemm; results are identical for every value.
+ * 0 (default): the slabs of a tile run on one XCD, tiles interleaved over the 8 XCDs; bit 0: each XCD takes a
+ * contiguous range of tiles; bit 1: slab-major dispatch (every slab re-gathers its rows from HBM). */
+void ls3d_set_xcd_map(int flags);
 
 /* Fused epilogue of the gather-GEMM (all optional):
  *   v = acc * scale[c] + shift[c]           (folded eval BatchNorm / bias)

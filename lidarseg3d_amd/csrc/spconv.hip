@@ -23,9 +23,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static int g_xcd_map = 0;  // XCD-contiguous tile mapping (see k_gather_gemm): measured SLOWER on MI355X (-4..-6 % fps in every mode,
-                           // profiles/round1_experiments.md), so off by default; LS3D_XCD_MAP=1 enables it for A/B measurements
-extern "C" void ls3d_set_xcd_map(int on) { g_xcd_map = on ? 1 : 0; }
+static int g_xcd_map = 0;  // workgroup -> (tile, slab) mapping flags (see k_gather_gemm); 0 = slabs of a tile share an XCD, tiles
+                           // interleaved over the XCDs.  LS3D_XCD_MAP=<flags> selects the alternatives for A/B measurements
+extern "C" void ls3d_set_xcd_map(int on) { g_xcd_map = on & 3; }
 
 struct EpiDev {
   const float *scale, *shift, *res_pre, *pair, *ln_gamma, *ln_beta;
@@ -201,18 +201,28 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm(const float *__restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int col = lane & 31, kk = lane >> 5;
-  const int n0 = blockIdx.y * SLAB;
   const int N = ls3d_count(n_rows, n_rows_dev);
   const int ntiles = (N + TR - 1) / TR;
   const int nwslab = w_ld / WSLAB;                     // packed: [kvol][wslab][cin][32][NT]
-  const float *wbase = w + (size_t)blockIdx.y * WC * cin * WSLAB;
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch; speed only, never correctness), so
-  // workgroup b takes tile (b % 8) * ceil(ntiles/8) + b / 8: each XCD's private L2 then serves one contiguous range
-  // of (spatially sorted) rows and their neighbours instead of 1/8 of everything.
+  const int nslab = w_ld / SLAB;                       // column slabs: one workgroup per (tile, slab)
+  // Workgroup -> (tile, slab), 1-D grid.  Workgroup b runs on XCD b % 8 (observed dispatch; speed only, never
+  // correctness): the nslab column slabs of one tile get consecutive b/8, i.e. they run on the SAME XCD at about the
+  // same time, so the rows the first slab gathers are L2 hits for the others.  xcd_map bit 0: each XCD takes a
+  // contiguous range of tiles instead of every 8th; bit 1: slab-major order (all tiles of slab 0 first - the
+  // pre-remap behaviour, kept for A/B measurements).
   const int tiles_per_xcd = (ntiles + 7) / 8;
-  for (int slot = blockIdx.x; slot < tiles_per_xcd * 8; slot += gridDim.x) {
-    const int tile = xcd_map ? (slot & 7) * tiles_per_xcd + (slot >> 3) : slot;
+  for (int b = blockIdx.x; b < tiles_per_xcd * 8 * nslab; b += gridDim.x) {
+    int tile, slab;
+    if (xcd_map & 2) {
+      tile = b % (tiles_per_xcd * 8); slab = b / (tiles_per_xcd * 8);
+    } else {
+      const int xcd = b & 7, j = b >> 3;
+      slab = j % nslab;
+      tile = (xcd_map & 1) ? xcd * tiles_per_xcd + j / nslab : (j / nslab) * 8 + xcd;
+    }
     if (tile >= ntiles) continue;
+    const int n0 = slab * SLAB;
+    const float *wbase = w + (size_t)slab * WC * cin * WSLAB;
     // ---- tile slots -> output rows.  With `order` (rows sorted by their neighbour bitmask, rulebook.hip) the 32
     //      rows of a wave share most of their empty kernel offsets, so the skips below remove most zero work.
     if (tid == 0) s_kmask = 0ull;
@@ -385,18 +395,27 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
   __shared__ float s_stat[2 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kk = lane >> 5;
-  const int n0 = blockIdx.y * SLAB;
   const int N = ls3d_count(n_rows, n_rows_dev);
   const int ntiles = (N + TR - 1) / TR;
-  const int nslab = w_ld / SLAB;
-  const float *wbase = w + (size_t)blockIdx.y * cin * SLAB;  // packed: [kvol][slab][cin/32][chunk]
-  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch; speed only, never correctness), so
-  // workgroup b takes tile (b % 8) * ceil(ntiles/8) + b / 8: each XCD's private L2 then serves one contiguous range
-  // of (spatially sorted) rows and their neighbours instead of 1/8 of everything.
+  const int nslab = w_ld / SLAB;                       // packed: [kvol][slab][cin/32][chunk]
+  // Workgroup -> (tile, slab), 1-D grid.  Workgroup b runs on XCD b % 8 (observed dispatch; speed only, never
+  // correctness): the nslab column slabs of one tile get consecutive b/8, i.e. they run on the SAME XCD at about the
+  // same time, so the rows the first slab gathers are L2 hits for the others.  xcd_map bit 0: each XCD takes a
+  // contiguous range of tiles instead of every 8th; bit 1: slab-major order (all tiles of slab 0 first - the
+  // pre-remap behaviour, kept for A/B measurements).
   const int tiles_per_xcd = (ntiles + 7) / 8;
-  for (int slot = blockIdx.x; slot < tiles_per_xcd * 8; slot += gridDim.x) {
-    const int tile = xcd_map ? (slot & 7) * tiles_per_xcd + (slot >> 3) : slot;
+  for (int b = blockIdx.x; b < tiles_per_xcd * 8 * nslab; b += gridDim.x) {
+    int tile, slab;
+    if (xcd_map & 2) {
+      tile = b % (tiles_per_xcd * 8); slab = b / (tiles_per_xcd * 8);
+    } else {
+      const int xcd = b & 7, j = b >> 3;
+      slab = j % nslab;
+      tile = (xcd_map & 1) ? xcd * tiles_per_xcd + j / nslab : (j / nslab) * 8 + xcd;
+    }
     if (tile >= ntiles) continue;
+    const int n0 = slab * SLAB;
+    const float *wbase = w + (size_t)slab * cin * SLAB;
     if (tid == 0) s_kmask = 0ull;
     if (tid < TR) {
       const int r = tile * TR + tid;
@@ -649,7 +668,8 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   if (e.ln_gamma && slabs != 1) return LS3D_ERR_ARG;  // the LayerNorm epilogue needs the whole row in one workgroup
   const int tr = 32 * (4 / wc);
   const int ntiles = (n_rows + tr - 1) / tr;
-  dim3 grid((unsigned)(ntiles < 4096 ? ntiles : 4096), (unsigned)slabs);
+  const long long nwg = (long long)((ntiles + 7) / 8) * 8 * slabs;  // one workgroup per (tile, slab), see the kernels
+  dim3 grid((unsigned)(nwg < (1 << 20) ? nwg : (1 << 20)));
   if (precision == LS3D_PRECISION_BF16X3) {
     if ((cin % 32) || wc != 1) return LS3D_ERR_ARG;
     switch (nt) {

@@ -62,7 +62,8 @@ class _Rulebook(object):
         if getattr(self, "_orders", None) is None:
             self._orders = {}
         if inverse not in self._orders:
-            self._orders[inverse] = ops.rulebook_order(self.tbl_inv if inverse else self.tbl)
+            self._orders[inverse] = ops.rulebook_order(self.tbl_inv if inverse else self.tbl,
+                                                       self.in_indices if inverse else self.out_indices)
         return self._orders[inverse]
 
 

@@ -111,6 +111,30 @@ def test_gather_gemm_dense_all_geometries(m, k, n, nt, wc, monkeypatch):
     np.testing.assert_allclose(out.numpy(), a.astype(np.float64) @ b.astype(np.float64), rtol=0, atol=1e-4)
 
 
+def test_gather_gemm_workgroup_mapping_flags_do_not_change_results(monkeypatch):
+    """ls3d_set_xcd_map only permutes which workgroup takes which (tile, slab): bitwise identical output (1300 rows = 11 tiles
+    over 8 XCD lanes, 4 column slabs; f32 and split-bf16 kernels)"""
+    rng = np.random.default_rng(11)
+    m, k, n = 1300, 32, 128
+    a, b = rng.normal(size=(m, k)).astype(np.float32), rng.normal(size=(k, n)).astype(np.float32)
+    tbl = torch.arange(m, dtype=torch.int32).reshape(m, 1)
+    monkeypatch.setattr(ops, "choose_geometry", lambda cout, rows, target_blocks=None: (1, 1))
+    pw = PackedWeight(torch.from_numpy(b).reshape(1, k, n).contiguous(), 1, k, k, n)
+    try:
+        for prec in ("f32", "bf16x3"):
+            ops.set_precision(prec)
+            outs = []
+            for flags in (0, 1, 2, 3):
+                _lib.load().ls3d_set_xcd_map(flags)
+                outs.append(ops.gather_gemm(torch.from_numpy(a), pw, tbl=tbl, cout=n).numpy().copy())
+            for o in outs[1:]:
+                assert np.array_equal(o, outs[0])
+            np.testing.assert_allclose(outs[0], a.astype(np.float64) @ b.astype(np.float64), rtol=0, atol=2e-3)
+    finally:
+        ops.set_precision("f32")
+        _lib.load().ls3d_set_xcd_map(0)
+
+
 def test_gather_gemm_sparse_with_order_and_fused_epilogue(monkeypatch):
     rng = np.random.default_rng(3)
     vin, vout, kvol, cin, cout = 300, 170, 27, 32, 64
