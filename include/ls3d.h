@@ -172,6 +172,11 @@ int ls3d_rulebook_masks(const int32_t *tbl, int n, const int32_t *n_dev, int kvo
  * contiguous range of tiles; bit 1: slab-major dispatch (every slab re-gathers its rows from HBM). */
 void ls3d_set_xcd_map(int flags);
 
+/* tuning knob (default 0: measured 10-20 % slower on the 120k-point frame, profiles/round1_experiments.md): sparse launches of ls3d_gather_gemm with cin % 32 == 0 and (nt, wc) in {(1,1), (1,2), (2,2)} use
+ * the LDS-DMA pipelined kernel (a ring of staged steps; wc = column groups of an 8-wave workgroup sharing the gathered
+ * rows); 0 sends every launch to the register-prefetch kernels.  Results differ only by f32 summation order: none. */
+void ls3d_set_gather_pipeline(int on);
+
 /* Fused epilogue of the gather-GEMM (all optional):
  *   v = acc * scale[c] + shift[c]           (folded eval BatchNorm / bias)
  *   v += res_pre[r*res_pre_ld + c]          (SparseBasicBlock identity, scn_unet.py:66)

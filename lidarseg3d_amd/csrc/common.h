@@ -30,6 +30,35 @@ __device__ __forceinline__ int ls3d_count(int n, const int32_t *n_dev) {
   return n;
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4): every lane copies 16 bytes from its own global address straight into LDS at
+//      lds_wave_base + lane * 16 (the destination is wave-uniform base + lane offset; no VGPRs, asynchronous, counted in
+//      vmcnt).  hipcc does not count inline-asm memory operations, so the callers wait with LS3D_WAIT_VMCNT themselves and
+//      synchronise waves with the raw s_barrier (a __syncthreads() would drain the whole DMA queue).  M0 (the DMA's LDS
+//      base) is written and restored inside one asm statement.  Under tests/hipsim these degrade to memcpy / no-op.
+#ifdef HIPSIM
+__device__ __forceinline__ void ls3d_glds16(const void *gsrc, void *lds_wave_base) {
+  memcpy((char *)lds_wave_base + hipsim::lane() * 16, gsrc, 16);
+}
+#define LS3D_WAIT_VMCNT(n) ((void)0)
+#define LS3D_SCHED_FENCE() ((void)0)
+#define LS3D_RAW_BARRIER() __syncthreads()
+#else
+__device__ __forceinline__ void ls3d_glds16(const void *gsrc, void *lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+#define LS3D_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define LS3D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  /* nothing is scheduled across: e.g. keeps a batch of ds_reads together */
+#define LS3D_RAW_BARRIER()                          \
+  do {                                              \
+    asm volatile("" ::: "memory");                  \
+    __builtin_amdgcn_s_barrier();                   \
+    asm volatile("" ::: "memory");                  \
+  } while (0)
+#endif
+
 __device__ __forceinline__ uint64_t ls3d_mix(uint64_t k) {  // 64-bit finaliser (splitmix)
   k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
   k ^= k >> 27; k *= 0x94d049bb133111ebull;

@@ -27,6 +27,7 @@ def _L():
     if not _XCD_SET:
         _XCD_SET = True
         L.ls3d_set_xcd_map(int(_os_environ_get("LS3D_XCD_MAP", "0")))
+        L.ls3d_set_gather_pipeline(1 if _PIPELINE else 0)
     return L
 
 
@@ -325,6 +326,31 @@ def choose_geometry(cout, n_rows, target_blocks=None):
     return nt, wc
 
 
+_PIPELINE = _os.environ.get("LS3D_PIPELINE", "0") != "0"  # measured slower than the register-prefetch kernels (profiles/round1_experiments.md)
+_PIPE_WIDE_ROWS = int(_os.environ.get("LS3D_PIPE_WIDE_ROWS", "0"))
+
+
+def set_pipeline(on):
+    """sparse convolutions with cin % 32 == 0 on the LDS-DMA pipelined kernel, or (default) on the register-prefetch kernels"""
+    global _PIPELINE
+    _PIPELINE = bool(on)
+    _L().ls3d_set_gather_pipeline(1 if on else 0)
+
+
+def pipeline_geometry(cout, n_rows, prec):
+    """(nt, wc) for the pipelined kernel, or None if the column count has no pipelined geometry: <= 32 columns (1,1);
+    <= 64 (1,2); 128 -> (2,2) (one 8-wave workgroup per 128-row tile covers the whole row, the gathered rows are staged
+    once) when the launch still has >= LS3D_PIPE_WIDE_ROWS rows, else two (1,2) slabs"""
+    total = (cout + 31) // 32
+    if total == 1:
+        return 1, 1
+    if total == 2:
+        return 1, 2
+    if total == 4:
+        return (2, 2) if n_rows >= _PIPE_WIDE_ROWS else (1, 2)
+    return None
+
+
 def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
                 out=None, out_ld=None, in_ld=None, cin=None, ln=None):
     """out[r, :cout] = epilogue(sum_k W[k]^T x[tbl[r,k]]).  w: packing.PackedWeight."""
@@ -335,15 +361,19 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     cout = cout or w.cout
     assert cout == w.cout, "packed layout depends on cout"
     rows_hint = tbl.shape[0] if (tbl is not None and n_rows is None) else (n_rows if n_rows is not None else x.shape[0])
-    nt, wc = choose_geometry(cout, rows_hint)
-    if ln is not None:  # LayerNorm epilogue: the whole row must sit in one workgroup slab
-        assert cout <= 128, "LayerNorm epilogue supports up to 128 columns"
-        nt, wc = (cout + 31) // 32, 1
     # split-bf16 only where it pays and where its error budget is spent wisely: the sparse convolutions (matrix-pipe
     # bound).  Dense Linear layers (TransVFE, heads, SF-Phase) are memory-bound and stay in exact f32.
     prec = BF16X3 if (_PRECISION == BF16X3 and cin % 32 == 0 and tbl is not None) else F32
-    if prec == BF16X3:
-        wc = 1
+    pipe = pipeline_geometry(cout, rows_hint, prec) if (_PIPELINE and tbl is not None and cin % 32 == 0 and kvol <= 32 and ln is None) else None
+    if pipe is not None:
+        nt, wc = pipe
+    else:
+        nt, wc = choose_geometry(cout, rows_hint)
+        if ln is not None:  # LayerNorm epilogue: the whole row must sit in one workgroup slab
+            assert cout <= 128, "LayerNorm epilogue supports up to 128 columns"
+            nt, wc = (cout + 31) // 32, 1
+        if prec == BF16X3:
+            wc = 1
     wdata = w.for_nt(nt, prec)
     if tbl is not None:
         n_rows = tbl.shape[0] if n_rows is None else n_rows

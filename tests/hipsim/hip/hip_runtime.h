@@ -49,6 +49,12 @@ inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return *p ? 0 : 1; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return 0; }
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return 0; }
 
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };

@@ -325,3 +325,49 @@ def test_drop_in_mode_with_dataloader_voxels():
     assert [int(r["pred_point_sem_labels"].shape[0]) for r in ret] == [9000, 5000]
     model(dict(points=ex["points"].to(DEV), batch_size=2), return_loss=False)
     assert torch.equal(a, model.point_head.forward_ret_dict["out_logits"])
+
+
+@pytest.mark.parametrize("cin,cout,wide", [(32, 32, True), (64, 64, True), (128, 128, True), (128, 128, False), (64, 16, True)])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_gather_gemm_pipelined_kernel_gpu(cin, cout, wide, prec, monkeypatch):
+    """the LDS-DMA pipelined kernel on the device (asynchronous DMA ring: the hipsim run of the same test cannot see a missing
+    wait) vs a float64 reference and vs the register-prefetch kernel; 100 launches must be bitwise reproducible"""
+    from lidarseg3d_amd.packing import PackedWeight
+    rng = np.random.default_rng(cin * 1000 + cout)
+    vin, vout, kvol = 30000, 20011, 27
+    x = rng.normal(size=(vin, cin)).astype(np.float32)
+    w = (rng.normal(size=(kvol, cin, cout)) * 0.1).astype(np.float32)
+    tbl = rng.integers(0, vin, size=(vout, kvol)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.5] = -1
+    tbl[7] = -1
+    tbl[1280:2560, 1:] = -1
+    tbl[12000:, 20:] = -1
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(vout, cout)).astype(np.float32)
+    acc = np.zeros((vout, cout), np.float64)
+    for kk in range(kvol):
+        o = np.nonzero(tbl[:, kk] >= 0)[0]
+        acc[o] += x[tbl[o, kk]].astype(np.float64) @ w[kk].astype(np.float64)
+    want = np.maximum(acc * scale + shift + res, 0)
+    pw = PackedWeight(cu(w), kvol, cin, cin, cout)
+    monkeypatch.setattr(ops, "_PIPE_WIDE_ROWS", 0 if wide else 10 ** 9)
+    tol = 3e-4 if prec == "f32" else 3e-3
+    X, TB, SC, SH, RS = cu(x), cu(tbl), cu(scale), cu(shift), cu(res)
+    try:
+        ops.set_precision(prec)
+        outs = {}
+        for pipe in (True, False):
+            ops.set_pipeline(pipe)
+            for order in (None, ops.rulebook_order(TB)):
+                out = ops.gather_gemm(X, pw, tbl=TB, order=order, cout=cout, scale=SC, shift=SH, res_pre=RS, relu=True)
+                np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=tol)
+                outs[(pipe, order is None)] = out
+        ops.set_pipeline(True)
+        order = ops.rulebook_order(TB)
+        first = ops.gather_gemm(X, pw, tbl=TB, order=order, cout=cout, scale=SC, shift=SH, res_pre=RS, relu=True)
+        for _ in range(100):
+            again = ops.gather_gemm(X, pw, tbl=TB, order=order, cout=cout, scale=SC, shift=SH, res_pre=RS, relu=True)
+            assert torch.equal(first, again)
+    finally:
+        ops.set_precision("f32")
+        ops.set_pipeline(False)  # the default

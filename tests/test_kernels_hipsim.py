@@ -135,6 +135,49 @@ def test_gather_gemm_workgroup_mapping_flags_do_not_change_results(monkeypatch):
         _lib.load().ls3d_set_xcd_map(0)
 
 
+@pytest.mark.parametrize("cin,cout,wide", [(32, 32, True), (64, 64, True), (32, 128, True), (96, 128, False), (128, 16, True)])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_gather_gemm_pipelined_kernel(cin, cout, wide, prec, monkeypatch):
+    """the LDS-DMA pipelined kernel (ring of staged steps, 4- and 8-wave workgroups, swizzled gather) against a float64
+    reference and against the register-prefetch kernel: every geometry, multi-chunk K, rows without neighbours, a tile with
+    a single active offset, ragged last tile, mask-sorted order, fused epilogue"""
+    rng = np.random.default_rng(cin * 1000 + cout)
+    vin, vout, kvol = 500, 333, 27
+    x = rng.normal(size=(vin, cin)).astype(np.float32)
+    w = (rng.normal(size=(kvol, cin, cout)) * 0.1).astype(np.float32)
+    tbl = rng.integers(0, vin, size=(vout, kvol)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.6] = -1
+    tbl[7] = -1
+    tbl[128:256, 1:] = -1   # a whole tile with one active offset (natural order)
+    tbl[256:, 20:] = -1     # offsets no row of the last tiles uses
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(vout, cout)).astype(np.float32)
+    acc = np.zeros((vout, cout), np.float64)
+    for kk in range(kvol):
+        o = np.nonzero(tbl[:, kk] >= 0)[0]
+        acc[o] += x[tbl[o, kk]].astype(np.float64) @ w[kk].astype(np.float64)
+    want = np.maximum(acc * scale + shift + res, 0)
+    T = torch.from_numpy
+    pw = PackedWeight(T(w), kvol, cin, cin, cout)
+    monkeypatch.setattr(ops, "_PIPE_WIDE_ROWS", 0 if wide else 10 ** 9)
+    tol = 2e-4 if prec == "f32" else 2e-3
+    try:
+        ops.set_precision(prec)
+        outs = {}
+        for pipe in (True, False):
+            ops.set_pipeline(pipe)
+            for order in (None, ops.rulebook_order(T(tbl))):
+                out = ops.gather_gemm(T(x), pw, tbl=T(tbl), order=order, cout=cout, scale=T(scale), shift=T(shift), res_pre=T(res),
+                                      relu=True).numpy()
+                np.testing.assert_allclose(out, want, rtol=0, atol=tol)
+                outs[(pipe, order is None)] = out
+        # same arithmetic, different summation order only
+        np.testing.assert_allclose(outs[(True, True)], outs[(False, True)], rtol=0, atol=tol)
+    finally:
+        ops.set_precision("f32")
+        ops.set_pipeline(False)  # the default
+
+
 def test_gather_gemm_sparse_with_order_and_fused_epilogue(monkeypatch):
     rng = np.random.default_rng(3)
     vin, vout, kvol, cin, cout = 300, 170, 27, 32, 64
