@@ -167,6 +167,14 @@ int ls3d_rulebook_conv(const int32_t *coords_in, int n_in, const int32_t *n_in_d
  * order changes. */
 int ls3d_rulebook_masks(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int32_t *mask, ls3d_stream_t stream);
 
+/* The same ordering for SEVERAL tables with one sort: keys[r] = (segment << 27) | mask(r) (descending != 0: mask
+ * complemented, densest rows first), kvol <= 27, segment <= 15.  The caller concatenates the keys of its tables, sorts
+ * them once (ascending, keeping the source positions) and converts the positions with ls3d_segment_local_index:
+ * out[i] = perm[i] - seg_offsets[s] for i in [seg_offsets[s], seg_offsets[s+1]) (seg_offsets: nseg + 1 host ints). */
+int ls3d_rulebook_sort_keys(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int segment, int descending, int32_t *keys,
+                            ls3d_stream_t stream);
+int ls3d_segment_local_index(const int64_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream);
+
 /* tuning knob: workgroup -> (tile, column slab) mapping of ls3d_gather_gemm; results are identical for every value.
  * 0 (default): the slabs of a tile run on one XCD, tiles interleaved over the 8 XCDs; bit 0: each XCD takes a
  * contiguous range of tiles; bit 1: slab-major dispatch (every slab re-gathers its rows from HBM). */

@@ -58,7 +58,9 @@ __device__ __forceinline__ bool conv_out_site(const ConvGeom &g, int z, int y, i
   return oz < g.out.z && oy < g.out.y && ox < g.out.x;
 }
 
-__global__ __launch_bounds__(256) void k_conv_mark(const int32_t *coords, int n, const int32_t *n_dev, ConvGeom g, uint32_t *bitmap) {
+// Marks the output sites in a BYTE map with plain stores (every hit writes the same 1: no atomics, no read-modify-write;
+// up to 27 (input, offset) pairs hit one site and the atomicOr version spent 60-130 us per level on them) ...
+__global__ __launch_bounds__(256) void k_conv_mark(const int32_t *coords, int n, const int32_t *n_dev, ConvGeom g, uint8_t *bytemap) {
   const int N = ls3d_count(n, n_dev);
   const int kvol = g.ks.z * g.ks.y * g.ks.x;
   const long long work = (long long)N * kvol;
@@ -67,18 +69,25 @@ __global__ __launch_bounds__(256) void k_conv_mark(const int32_t *coords, int n,
     const int kz = k / (g.ks.y * g.ks.x), ky = (k / g.ks.x) % g.ks.y, kx = k % g.ks.x;
     const int32_t *c = coords + 4 * (size_t)i;
     int oz, oy, ox;
-    if (conv_out_site(g, c[1], c[2], c[3], kz, ky, kx, oz, oy, ox)) {
-      const uint64_t lin = ls3d_key(c[0], oz, oy, ox, g.out.z, g.out.y, g.out.x);
-      // up to 27 (input, offset) pairs hit the same output bit: test first so that only the first few pay an atomic
-      // (a stale read merely costs one redundant atomicOr)
-      const uint32_t bit = 1u << (lin & 31);
-      if (!(bitmap[lin >> 5] & bit)) atomicOr(&bitmap[lin >> 5], bit);
-    }
+    if (conv_out_site(g, c[1], c[2], c[3], kz, ky, kx, oz, oy, ox)) bytemap[ls3d_key(c[0], oz, oy, ox, g.out.z, g.out.y, g.out.x)] = 1;
   }
 }
 
-__global__ __launch_bounds__(256) void k_popc(const uint32_t *bitmap, int nwords, int32_t *cnt) {
-  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) cnt[w] = __popc(bitmap[w]);
+// ... which this pass packs into the occupancy bitmap (bit = site's linear index) and its per-word population counts.
+// bytemap is padded to a multiple of 32 bytes and zero-filled.
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t *bytemap, int nwords, uint32_t *bitmap, int32_t *cnt) {
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
+    const uint4 lo = *(const uint4 *)(bytemap + (size_t)w * 32), hi = *(const uint4 *)(bytemap + (size_t)w * 32 + 16);
+    const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // bytes are 0 / 1: gather the low bit of each of the 4 bytes of a dword
+      const uint32_t x = v[q];
+      bits |= ((x & 1u) | ((x >> 7) & 2u) | ((x >> 14) & 4u) | ((x >> 21) & 8u)) << (4 * q);
+    }
+    bitmap[w] = bits;
+    cnt[w] = __popc(bits);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_conv_emit(const uint32_t *bitmap, const int32_t *prefix, int nwords, Shape3 o, int out_cap,
@@ -139,6 +148,28 @@ __global__ __launch_bounds__(256) void k_tbl_mask(const int32_t *tbl, int n, con
   }
 }
 
+// sort key of every table row for ONE batched sort of several tables: (segment << 27) | (mask ^ flip), kvol <= 27.
+// flip = 0x7FFFFFF orders a segment's rows by DESCENDING mask (densest rows first).
+__global__ __launch_bounds__(256) void k_tbl_sortkey(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, uint32_t seg_bits, uint32_t flip,
+                                                     int32_t *keys) {
+  const int N = ls3d_count(n, n_dev);
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) {
+    uint32_t m = 0;
+    for (int k = 0; k < kvol; ++k) m |= (tbl[(size_t)r * kvol + k] >= 0 ? 1u : 0u) << k;
+    keys[r] = (int32_t)(seg_bits | (m ^ flip));
+  }
+}
+
+// positions in the concatenation of several segments -> positions inside the own segment (int64 -> int32)
+struct SegOffsets { int32_t off[17]; int32_t nseg; };
+__global__ __launch_bounds__(256) void k_segment_local(const int64_t *perm, int n, SegOffsets so, int32_t *out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int s = 0;
+    while (s + 1 < so.nseg && i >= so.off[s + 1]) ++s;
+    out[i] = (int32_t)(perm[i] - (int64_t)so.off[s]);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fill_m1(int32_t *p, long long n) {
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) p[t] = -1;
 }
@@ -177,13 +208,34 @@ extern "C" int ls3d_rulebook_masks(const int32_t *tbl, int n, const int32_t *n_d
   return LS3D_OK;
 }
 
+extern "C" int ls3d_rulebook_sort_keys(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int segment, int descending, int32_t *keys,
+                                       ls3d_stream_t stream) {
+  if (!tbl || !keys || n < 0 || kvol < 1 || kvol > 27 || segment < 0 || segment > 15) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  hipLaunchKernelGGL(k_tbl_sortkey, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, tbl, n, n_dev, kvol, (uint32_t)segment << 27,
+                     descending ? 0x7FFFFFFu : 0u, keys);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_segment_local_index(const int64_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream) {
+  if (!perm || !out || !seg_offsets_host || n < 0 || nseg < 1 || nseg > 16) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  SegOffsets so;
+  for (int s = 0; s <= nseg; ++s) so.off[s] = seg_offsets_host[s];
+  so.nseg = nseg;
+  hipLaunchKernelGGL(k_segment_local, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, perm, n, so, out);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
 static inline long long rb_words(int batch, const int32_t oshape[3]) {
   return ((long long)batch * oshape[0] * oshape[1] * oshape[2] + 31) / 32;
 }
 
 extern "C" size_t ls3d_rulebook_conv_workspace_bytes(int batch, const int32_t oshape[3]) {
   const long long nw = rb_words(batch, oshape);
-  return rb_align((size_t)nw * 4) * 3 + rb_align(ls3d_scan_tmp_ints(nw) * 4) + 256;
+  return rb_align((size_t)nw * 4) * 3 + rb_align(ls3d_scan_tmp_ints(nw) * 4) + 256 + rb_align((size_t)nw * 32);
 }
 
 extern "C" int ls3d_rulebook_conv(const int32_t *coords_in, int n_in, const int32_t *n_in_dev, int batch, const int32_t in_shape[3],
@@ -211,13 +263,14 @@ extern "C" int ls3d_rulebook_conv(const int32_t *coords_in, int n_in, const int3
   int32_t *cnt = (int32_t *)base; base += rb_align((size_t)nw * 4);
   int32_t *prefix = (int32_t *)base; base += rb_align((size_t)nw * 4);
   int32_t *scan_tmp = (int32_t *)base; base += rb_align(ls3d_scan_tmp_ints(nw) * 4);
-  int32_t *total = (int32_t *)base;
+  int32_t *total = (int32_t *)base; base += 256;
+  uint8_t *bytemap = (uint8_t *)base;
   const int kvol = ksize[0] * ksize[1] * ksize[2];
-  hipMemsetAsync(bitmap, 0, (size_t)nw * 4, stream);
+  hipMemsetAsync(bytemap, 0, (size_t)nw * 32, stream);
   hipLaunchKernelGGL(k_fill_m1, ls3d_grid((long long)out_cap * kvol), dim3(256), 0, stream, nbr_out, (long long)out_cap * kvol);
   if (n_in > 0)
-    hipLaunchKernelGGL(k_conv_mark, ls3d_grid((long long)n_in * kvol), dim3(256), 0, stream, coords_in, n_in, n_in_dev, g, bitmap);
-  hipLaunchKernelGGL(k_popc, ls3d_grid(nw), dim3(256), 0, stream, (const uint32_t *)bitmap, (int)nw, cnt);
+    hipLaunchKernelGGL(k_conv_mark, ls3d_grid((long long)n_in * kvol), dim3(256), 0, stream, coords_in, n_in, n_in_dev, g, bytemap);
+  hipLaunchKernelGGL(k_pack_bits, ls3d_grid(nw), dim3(256), 0, stream, (const uint8_t *)bytemap, (int)nw, bitmap, cnt);
   int rc = ls3d_exclusive_scan_i32(cnt, prefix, (int)nw, scan_tmp, total, stream);
   if (rc != LS3D_OK) return rc;
   hipLaunchKernelGGL(k_conv_emit, ls3d_grid(nw), dim3(256), 0, stream, (const uint32_t *)bitmap, (const int32_t *)prefix, (int)nw, g.out,

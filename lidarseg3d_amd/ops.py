@@ -216,8 +216,10 @@ def conv_out_shape(shape_zyx, ksize, stride, pad):
     return [(int(shape_zyx[a]) + 2 * int(pad[a]) - int(ksize[a])) // int(stride[a]) + 1 for a in range(3)]
 
 
-def rulebook_conv(coords, batch, shape_zyx, ksize, stride, pad, out_cap=None):
-    """-> out_coords[cap,4], n_out (1-elt device tensor), nbr_out[cap,kvol], nbr_inv[n_in,kvol], out_shape, overflow"""
+def rulebook_conv(coords, batch, shape_zyx, ksize, stride, pad, out_cap=None, n_dev=None):
+    """-> out_coords[cap,4], cnt = [n_out, overflow] (device), nbr_out[cap,kvol], nbr_inv[n_in,kvol], out_shape.
+    n_dev: optional device int32 holding the number of valid rows of `coords` (<= coords.shape[0], which then is a
+    capacity): lets several rulebooks be chained without a host round trip for each size."""
     n = coords.shape[0]
     kvol = int(ksize[0] * ksize[1] * ksize[2])
     oshape = conv_out_shape(shape_zyx, ksize, stride, pad)
@@ -233,7 +235,7 @@ def rulebook_conv(coords, batch, shape_zyx, ksize, stride, pad, out_cap=None):
     cnt = torch.zeros((2,), dtype=_i32, device=dev)  # [n_out, overflow]
     L = _L()
     ws = _ws(L.ls3d_rulebook_conv_workspace_bytes(batch, _i3(oshape)), coords)
-    check(L.ls3d_rulebook_conv(_ptr(coords), n, None, batch, _i3(shape_zyx), _i3(ksize), _i3(stride), _i3(pad), _ptr(ws),
+    check(L.ls3d_rulebook_conv(_ptr(coords), n, _ptr(n_dev), batch, _i3(shape_zyx), _i3(ksize), _i3(stride), _i3(pad), _ptr(ws),
                                ctypes.c_size_t(ws.numel()), _ptr(oc), cap, _ptr(cnt), _ptr(nbr_out), _ptr(nbr_inv),
                                ctypes.c_void_p(cnt.data_ptr() + 4), _stream(coords)), "ls3d_rulebook_conv")
     return oc, cnt, nbr_out, nbr_inv, oshape
@@ -324,6 +326,34 @@ def choose_geometry(cout, n_rows, target_blocks=None):
     else:
         blocks, slabs, wc, nt = max(cands, key=lambda c: (c[0], -c[1]))
     return nt, wc
+
+
+def rulebook_orders(tbls):
+    """rulebook_order for several tables at once: one batched sort (keys carry the table number in their top bits) instead
+    of one sort per table - the sorts are launch-bound (~10 small kernels each).  -> list of int32 orders (None where a
+    table has no rows / too many offsets / row order is disabled)."""
+    descending = _os_environ_get("LS3D_ORDER_ASC", "0") != "1"
+    out = [None] * len(tbls)
+    sel = [i for i, t in enumerate(tbls) if t.shape[0] > 0 and t.shape[1] <= 27 and _ROW_ORDER != "none"]
+    for lo in range(0, len(sel), 16):
+        grp = sel[lo:lo + 16]
+        offs = [0]
+        for i in grp:
+            offs.append(offs[-1] + tbls[i].shape[0])
+        dev = tbls[grp[0]].device
+        keys = torch.empty((offs[-1],), dtype=_i32, device=dev)
+        L = _L()
+        for s, i in enumerate(grp):
+            t = tbls[i]
+            check(L.ls3d_rulebook_sort_keys(_ptr(t), t.shape[0], None, t.shape[1], s, 1 if descending else 0,
+                                            ctypes.c_void_p(keys.data_ptr() + 4 * offs[s]), _stream(t)), "ls3d_rulebook_sort_keys")
+        perm = torch.argsort(keys)  # plumbing (rocPRIM radix sort inside torch); int64 positions
+        local = torch.empty((offs[-1],), dtype=_i32, device=dev)
+        check(L.ls3d_segment_local_index(_ptr(perm), offs[-1], (ctypes.c_int32 * len(offs))(*offs), len(grp), _ptr(local), _stream(perm)),
+              "ls3d_segment_local_index")
+        for s, i in enumerate(grp):
+            out[i] = local[offs[s]:offs[s + 1]]
+    return out
 
 
 _PIPELINE = _os.environ.get("LS3D_PIPELINE", "0") != "0"  # measured slower than the register-prefetch kernels (profiles/round1_experiments.md)

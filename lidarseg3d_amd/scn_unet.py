@@ -141,6 +141,16 @@ class UNetSCN3D(nn.Module):
         batch_size = batch_dict["batch_size"]
         sparse_shape = np.array(batch_dict["input_shape"][::-1]) + [1, 0, 0]
         x = spconv.SparseConvTensor(voxel_features, voxel_coords.int().contiguous(), sparse_shape, batch_size)
+        # the four strided rulebooks of the encoder in one go (one host sync instead of four)
+        strided = [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
+        spconv.prebuild_conv_rulebooks(x, strided)
+        # ... then every SubM rulebook and, with one batched sort, every mask-sorted row order: after this point the conv
+        # stack is only gather-GEMM launches
+        for key, src in (("subm1", None), ("subm2", "spconv2"), ("subm3", "spconv3"), ("subm4", "spconv4")):
+            rb = x.find_indice_pair(src)
+            x.indice_dict[key] = spconv.subm_rulebook(x.indices if rb is None else rb.out_indices,
+                                                      x.spatial_shape if rb is None else rb.out_shape, 3)
+        spconv.prebuild_orders(x, self.modules())
         x = self.conv_input(x)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)

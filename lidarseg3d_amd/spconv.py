@@ -96,16 +96,14 @@ class SparseConvolution(PackedModule, SparseModule):
             assert rb is not None and rb.kind == "conv", "SparseInverseConv3d needs the rulebook of the SparseConv3d " \
                 "with indice_key=%r" % (self.indice_key,)
             return rb
-        if rb is not None and self.subm:
-            return rb
-        rb = _Rulebook()
-        rb._orders = None
-        rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)
+        if rb is not None and (self.subm or rb.kind == "conv"):
+            return rb  # spconv semantics: layers with one indice_key share the pairs (also prebuild_conv_rulebooks below)
         if self.subm:
-            rb.kind = "subm"
-            rb.tbl = ops.rulebook_subm(x.indices, x.spatial_shape, self.kernel_size)
-            rb.out_indices, rb.out_shape, rb.tbl_inv = x.indices, list(x.spatial_shape), None
+            rb = subm_rulebook(x.indices, x.spatial_shape, self.kernel_size)
         else:
+            rb = _Rulebook()
+            rb._orders = None
+            rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)
             rb.kind = "conv"
             oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape,
                                                                    self.kernel_size, self.stride, self.padding)
@@ -138,6 +136,62 @@ class SparseConvolution(PackedModule, SparseModule):
         if self.inverse:
             return x._like(f, rb.in_indices, rb.in_shape)
         return x._like(f, rb.out_indices, rb.out_shape)
+
+
+def subm_rulebook(indices, spatial_shape, kernel_size):
+    rb = _Rulebook()
+    rb._orders = None
+    rb.kind = "subm"
+    rb.in_indices, rb.in_shape = indices, list(spatial_shape)
+    rb.tbl = ops.rulebook_subm(indices, spatial_shape, _triple(kernel_size))
+    rb.out_indices, rb.out_shape, rb.tbl_inv = indices, list(spatial_shape), None
+    return rb
+
+
+def prebuild_orders(x, layers):
+    """mask-sorted processing orders of every rulebook table the given layers will ask for (same criterion as
+    SparseConvolution.conv), from ONE batched sort instead of one sort per table"""
+    want = []
+    for m in layers:
+        if not isinstance(m, SparseConvolution) or m.in_channels * m.out_channels < 4096:
+            continue
+        rb = x.find_indice_pair(m.indice_key)
+        if rb is None:
+            continue
+        if rb._orders is None:
+            rb._orders = {}
+        inv = bool(m.inverse)
+        if inv in rb._orders or any(r is rb and i == inv for r, i in want):
+            continue
+        want.append((rb, inv))
+    if want:
+        for (rb, inv), o in zip(want, ops.rulebook_orders([rb.tbl_inv if inv else rb.tbl for rb, inv in want])):
+            rb._orders[inv] = o
+
+
+def prebuild_conv_rulebooks(x, convs):
+    """Rulebooks of a chain of strided SparseConv3d layers (each one's output sites are the next one's input sites, as in a
+    UNet encoder) built back to back on device-side site counts, with ONE host synchronisation for all their sizes instead
+    of one per layer.  Intermediate tables are allocated for the worst case (min(8 x inputs, grid cells)) and sliced once
+    the counts are known.  The rulebooks are registered under the layers' indice_keys."""
+    pend, coords, n_dev, shape = [], x.indices, None, list(x.spatial_shape)
+    for c in convs:
+        assert not c.subm and not c.inverse and c.indice_key is not None
+        oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(coords, x.batch_size, shape, c.kernel_size, c.stride, c.padding,
+                                                               n_dev=n_dev)
+        pend.append((c, coords, shape, oc, cnt, nbr_out, nbr_inv, oshape))
+        coords, n_dev, shape = oc, cnt, oshape
+    counts = torch.stack([p[4] for p in pend]).tolist()  # host sync: tensor shapes need the counts
+    n_in = x.indices.shape[0]
+    for (c, icoords, ishape, oc, cnt, nbr_out, nbr_inv, oshape), (n_out, overflow) in zip(pend, counts):
+        assert not overflow
+        rb = _Rulebook()
+        rb._orders = None
+        rb.kind, rb.in_indices, rb.in_shape = "conv", icoords[:n_in], list(ishape)
+        rb.out_indices, rb.out_shape = oc[:n_out], oshape
+        rb.tbl, rb.tbl_inv = nbr_out[:n_out], nbr_inv[:n_in]
+        x.indice_dict[c.indice_key] = rb
+        n_in = n_out
 
 
 class SubMConv3d(SparseConvolution):

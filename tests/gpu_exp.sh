@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 OUT="$R/gpurun_out"; mkdir -p $OUT; export TMPDIR=/tmp
 run() {  # label, env...
   local label=$1; shift
-  env "$@" timeout 300 python bench.py --steps 12 --warmup 4 --no-cpu-baseline 2>$OUT/exp_err.log | python -c "
+  env "$@" timeout 300 python bench.py --steps 15 --warmup 4 --no-cpu-baseline 2>$OUT/exp_err.log | python -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()
@@ -13,9 +13,7 @@ for l in sys.stdin:
 " >> $OUT/exp.txt
 }
 : > $OUT/exp.txt
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "gather or unet or end_to_end" -p no:cacheprovider 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -p no:cacheprovider 2>&1 | tail -3
 run default
 run default
-run tb1024 LS3D_TARGET_BLOCKS=1024
-run tb4000 LS3D_TARGET_BLOCKS=4000
 cat $OUT/exp.txt

@@ -178,6 +178,27 @@ def test_gather_gemm_pipelined_kernel(cin, cout, wide, prec, monkeypatch):
         ops.set_pipeline(False)  # the default
 
 
+def test_rulebook_orders_batched_sort():
+    """one sort for several tables: every order is a permutation of its table's rows with non-increasing neighbour masks"""
+    rng = np.random.default_rng(5)
+    tbls = []
+    for n, kvol in ((300, 27), (1, 27), (0, 27), (170, 3), (64, 27)):
+        t = rng.integers(0, 50, size=(n, kvol)).astype(np.int32)
+        t[rng.uniform(size=t.shape) < 0.5] = -1
+        tbls.append(torch.from_numpy(t))
+    orders = ops.rulebook_orders(tbls)
+    assert orders[2] is None
+    for t, o in zip(tbls, orders):
+        if o is None:
+            continue
+        o = o.numpy()
+        assert sorted(o.tolist()) == list(range(t.shape[0]))
+        m = ((t.numpy() >= 0) * (1 << np.arange(t.shape[1]))).sum(1)
+        assert np.all(np.diff(m[o]) <= 0)
+        single = ops.rulebook_order(t).numpy()
+        assert np.array_equal(m[single], m[o])
+
+
 def test_gather_gemm_sparse_with_order_and_fused_epilogue(monkeypatch):
     rng = np.random.default_rng(3)
     vin, vout, kvol, cin, cout = 300, 170, 27, 32, 64
