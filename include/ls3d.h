@@ -125,6 +125,24 @@ int ls3d_mha_core(const float *qkv, int groups, const int32_t *groups_dev, int s
 int ls3d_group_max(const float *in, int groups, const int32_t *groups_dev, int seq, int c, float *out,
                    ls3d_stream_t stream);
 
+/* TransformerVoxelFeatureExtractor.forward (voxel_encoder.py:202-270) as ONE kernel: tokens -> embedding -> num_layers x
+ * TransformerEncoderLayerPreNorm (:149-163) -> max over the point slots -> Linear + ReLU compression; out[n, num_compressed]
+ * (or [n, embed] without compression).  Matrix weights in the layout of ls3d_gather_gemm_pack(nt = 2, F32) of the (in, out)
+ * matrices (embedding K padded to token_ld), w_compress: the PLAIN nn.Linear weight [num_compressed][embed].
+ * Supported: embed 64, heads 4, ffn 128, token_ld 32 (2C + 8 <= 32), P <= 32, num_layers <= 4; anything else returns
+ * LS3D_ERR_UNSUPPORTED and the caller composes the layer from ls3d_vfe_tokens / ls3d_gather_gemm / ls3d_mha_core / ls3d_group_max. */
+typedef struct {
+  const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2, *n1_gamma, *n1_beta, *n2_gamma, *n2_beta;
+  float n1_eps, n2_eps;
+} ls3d_transvfe_layer_t;
+typedef struct {
+  const float *w_embed, *b_embed, *w_compress, *b_compress;
+  const ls3d_transvfe_layer_t *layers; /* host array [num_layers] */
+  int num_layers, num_compressed, embed, heads, ffn, token_ld;
+} ls3d_transvfe_t;
+int ls3d_transvfe(const float *voxels /*[n,P,C]*/, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
+                  const ls3d_transvfe_t *model, float *out, int out_ld, ls3d_stream_t stream);
+
 /* y = LayerNorm(x (+ res)) * gamma + beta over the last dim c (<= 256); ld = c for all */
 int ls3d_layernorm(const float *x, const float *res, const float *gamma, const float *beta, float eps, int rows,
                    const int32_t *rows_dev, int c, float *y, ls3d_stream_t stream);

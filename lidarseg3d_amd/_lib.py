@@ -10,12 +10,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libls3d.so")
 
 OK = 0
+ERR_UNSUPPORTED = -3
 _ERR = {-1: "LS3D_ERR_ARG", -2: "LS3D_ERR_LAUNCH", -3: "LS3D_ERR_UNSUPPORTED", -4: "LS3D_ERR_WORKSPACE"}
 
 EXPORTS = [
     "ls3d_version", "ls3d_voxelize_dynamic", "ls3d_voxelize_hard_workspace_bytes", "ls3d_voxelize_hard",
     "ls3d_dynamic_scatter_workspace_bytes", "ls3d_dynamic_scatter", "ls3d_vfe_mean", "ls3d_vfe_improved_mean",
-    "ls3d_vfe_tokens", "ls3d_mha_core", "ls3d_group_max", "ls3d_layernorm", "ls3d_index_build",
+    "ls3d_vfe_tokens", "ls3d_transvfe", "ls3d_mha_core", "ls3d_group_max", "ls3d_layernorm", "ls3d_index_build",
     "ls3d_rulebook_subm", "ls3d_rulebook_conv_workspace_bytes", "ls3d_rulebook_conv", "ls3d_rulebook_masks", "ls3d_rulebook_sort_keys", "ls3d_segment_local_index", "ls3d_gather_gemm", "ls3d_gather_gemm_pack", "ls3d_gather_gemm_packed_floats", "ls3d_gather_gemm_default_nt", "ls3d_set_xcd_map", "ls3d_set_gather_pipeline",
     "ls3d_voxel_centers", "ls3d_frame_offsets", "ls3d_three_nn", "ls3d_three_interpolate", "ls3d_three_interpolate_grad",
     "ls3d_devoxelize", "ls3d_devoxelize_grid", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_grid_gather", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn",
@@ -35,6 +36,17 @@ class Epilogue(ctypes.Structure):
     _fields_ = [("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("res_pre", ctypes.c_void_p),
                 ("res_pre_ld", ctypes.c_int32), ("pair", ctypes.c_void_p), ("pair_ld", ctypes.c_int32),
                 ("relu", ctypes.c_int32), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float)]
+
+
+class TransVFELayer(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2", "n1_gamma", "n1_beta", "n2_gamma",
+                                                "n2_beta")] + [("n1_eps", ctypes.c_float), ("n2_eps", ctypes.c_float)]
+
+
+class TransVFE(ctypes.Structure):
+    _fields_ = [("w_embed", ctypes.c_void_p), ("b_embed", ctypes.c_void_p), ("w_compress", ctypes.c_void_p), ("b_compress", ctypes.c_void_p),
+                ("layers", ctypes.POINTER(TransVFELayer)), ("num_layers", ctypes.c_int32), ("num_compressed", ctypes.c_int32),
+                ("embed", ctypes.c_int32), ("heads", ctypes.c_int32), ("ffn", ctypes.c_int32), ("token_ld", ctypes.c_int32)]
 
 
 class LibraryMissing(RuntimeError):

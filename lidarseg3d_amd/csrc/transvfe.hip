@@ -1,0 +1,320 @@
+// transvfe.hip — TransformerVoxelFeatureExtractor as ONE kernel.
+//
+// Reference: det3d/models/readers/voxel_encoder.py:202-270 (TransformerVoxelFeatureExtractor.forward) with
+// TransformerEncoderLayerPreNorm (:149-163, the residual is taken from the NORMED tensor) iterated by hand.  Per voxel:
+// its P point slots are tokens [point feats | descriptor]; Conv1d(k=1) embedding -> num_layers x {LayerNorm, 4-head
+// self-attention over the P tokens (no padding mask), out-proj + residual, LayerNorm, FF(ReLU) + residual} -> max over
+// the tokens -> Linear + ReLU compression.
+//
+// The layer-by-layer version (ls3d_vfe_tokens -> ls3d_gather_gemm x (1 + 4 per layer) -> ls3d_mha_core -> ls3d_group_max
+// -> ls3d_gather_gemm) streams the [V*P, 64..192] token matrices through HBM a dozen times (1.35 ms of a 13.6 ms frame on
+// MI355X).  Here a wave owns G = 32 / P voxels = one 32-row MFMA tile of tokens and keeps it in LDS from the raw points
+// to the 16-float voxel feature; only the weights (staged per workgroup in LDS, shared by the 4 waves) and the points are
+// read, and V x 16 floats are written.
+//   * GEMMs: v_mfma_f32_32x32x2_f32 (exact f32), A fragments from the wave's LDS tile (row stride K + 4 floats:
+//     conflict-free ds_read_b128, the MFMA K index is permuted so that a lane reads 16 contiguous floats), B chunks of
+//     32 x 64 weights in the packed layout of ls3d_gather_gemm_pack(nt = 2), double buffered in LDS;
+//   * attention: one lane per (voxel, head, query token), the result overwrites the query's own slice of the QKV tile;
+//   * LayerNorm: two lanes per row, statistics by one shuffle.
+// LDS: 4 waves x (32 x 68 + 32 x 196) floats + 2 x 8 KB weight chunks = 151 KB -> one workgroup per CU; the kernel is
+// bound by the f32 matrix pipe (1568 MFMAs per 32-token tile for 3 layers; measured 1.08 ms for 65.9k voxels = 45 % of
+// the matrix-pipe bound, vs 1.75 ms for the layer-by-layer version).
+#include "common.h"
+#include "vfe_descriptor.h"
+
+typedef float tv_f32x16 __attribute__((ext_vector_type(16)));
+
+#define TV_MAX_LAYERS 4
+struct TvLayer {
+  const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2, *n1g, *n1b, *n2g, *n2b;
+  float n1eps, n2eps;
+};
+struct TvParams {
+  const float *we, *be;          // embedding, packed nt=2, K = KT
+  const float *wc, *bc;          // compression: PLAIN nn.Linear weight [ncomp][E] and bias, or null
+  TvLayer layer[TV_MAX_LAYERS];
+  int num_layers, ncomp;
+};
+
+#ifdef HIPSIM
+#define TV_WAVE_SYNC() hipsim::wave_barrier()
+#else
+#define TV_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+constexpr int TV_E = 64, TV_FF = 128, TV_HD = 16, TV_H = 4, TV_KT = 32;
+constexpr int TV_XS = TV_E + 4;          // row stride of the activation tile X
+constexpr int TV_TS = 3 * TV_E + 4;      // row stride of the scratch tile T (QKV / FF hidden / tokens)
+constexpr int TV_WAVE_FLOATS = 32 * TV_XS + 32 * TV_TS;
+constexpr int TV_BCHUNK = 32 * 64;       // floats in one staged weight chunk
+
+// out(32 x N) = A(32 x K, LDS, stride lda) x W (packed nt=2: [slab][K][32][2]), handed to `epi(slab, acc0, acc1)` per
+// 64-column slab.  All 4 waves of the workgroup call this together (the weight chunks are staged by the workgroup).
+template <typename Epi>
+__device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, const float *__restrict__ Wp, float *Bs, Epi epi) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int col = lane & 31, kk = lane >> 5;
+  const int nslab = N / 64, nkc = K / 32, nchunks = nslab * nkc;
+  // chunk c = (slab, kc): 32 x 32 x 2 floats at Wp + (slab * K + kc * 32) * 64
+  float4 r0, r1;
+  {
+    const float4 *src = (const float4 *)Wp;
+    r0 = src[tid]; r1 = src[tid + 256];
+  }
+  __syncthreads();  // previous users of Bs are done
+  ((float4 *)Bs)[tid] = r0; ((float4 *)Bs)[tid + 256] = r1;
+  __syncthreads();
+  tv_f32x16 acc0, acc1;
+  int buf = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int slab = c / nkc, kc = c - slab * nkc;
+    if (kc == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    }
+    if (c + 1 < nchunks) {
+      const int s2 = (c + 1) / nkc, k2 = (c + 1) - s2 * nkc;
+      const float4 *src = (const float4 *)(Wp + ((size_t)s2 * K + k2 * 32) * 64);
+      r0 = src[tid]; r1 = src[tid + 256];
+    }
+    {
+      const float4 *ap = (const float4 *)(A + col * lda + kc * 32 + kk * 16);
+      const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+      const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+      const float2 *bs = (const float2 *)(Bs + buf * TV_BCHUNK) + kk * 16 * 32 + col;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float2 b = bs[u * 32];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b.y, acc1, 0, 0, 0);
+      }
+    }
+    if (kc == nkc - 1) epi(slab, acc0, acc1);
+    if (c + 1 < nchunks) {
+      float4 *dst = (float4 *)(Bs + (buf ^ 1) * TV_BCHUNK);
+      dst[tid] = r0; dst[tid + 256] = r1;
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+}
+
+// accumulator fragment (register r of lane (col, kk)) -> tile row / column:  row = (r & 3) + 8 * (r >> 2) + 4 * kk
+#define TV_FOR_ACC(r, row) _Pragma("unroll") for (int r = 0, row = 4 * kk; r < 16; ++r, row = (r & 3) + 8 * (r >> 2) + 4 * kk)
+
+// in-place LayerNorm of the 32 x 64 tile X (two lanes per row)
+__device__ __forceinline__ void tv_layernorm(float *X, const float *g, const float *b, float eps) {
+  const int lane = threadIdx.x & 63, row = lane & 31, half = lane >> 5;
+  float4 *p = (float4 *)(X + row * TV_XS + half * 32);
+  float4 v[8];
+  float s = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { v[q] = p[q]; s += (v[q].x + v[q].y) + (v[q].z + v[q].w); }
+  s += __shfl_xor(s, 32);
+  const float mean = s / (float)TV_E;
+  float q2 = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    v[q].x -= mean; v[q].y -= mean; v[q].z -= mean; v[q].w -= mean;
+    q2 += (v[q].x * v[q].x + v[q].y * v[q].y) + (v[q].z * v[q].z + v[q].w * v[q].w);
+  }
+  q2 += __shfl_xor(q2, 32);
+  const float rstd = 1.0f / sqrtf(q2 / (float)TV_E + eps);
+  const float4 *gp = (const float4 *)(g + half * 32), *bp = (const float4 *)(b + half * 32);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float4 gg = gp[q], bb = bp[q];
+    float4 o;
+    o.x = v[q].x * rstd * gg.x + bb.x; o.y = v[q].y * rstd * gg.y + bb.y;
+    o.z = v[q].z * rstd * gg.z + bb.z; o.w = v[q].w * rstd * gg.w + bb.w;
+    p[q] = o;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ voxels, const int32_t *__restrict__ num, int n,
+                                                     const int32_t *n_dev, int P, int C, TvParams prm, float *__restrict__ out, int out_ld) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kk = lane >> 5;
+  float *X = smem + wave * TV_WAVE_FLOATS;     // [32][TV_XS]
+  float *T = X + 32 * TV_XS;                   // [32][TV_TS]
+  float *Bs = smem + 4 * TV_WAVE_FLOATS;       // [2][TV_BCHUNK]
+  const int N = ls3d_count(n, n_dev);
+  const int G = 32 / P;                        // voxels per wave tile
+  const int per_block = 4 * G;
+  for (int v0 = blockIdx.x * per_block; v0 < N; v0 += gridDim.x * per_block) {
+    const int vw = v0 + wave * G;              // first voxel of this wave
+    // ---- tokens -> T[:, 0:KT]: row g * P + p = [point p of voxel g | descriptor of voxel g | 0...]
+    {
+      const int row = lane & 31;
+      const int g = row / P, p = row - g * P, v = vw + g;
+      float *t = T + row * TV_TS;
+      if (lane < 32) {
+        if (g < G && v < N) {
+          const float *vox = voxels + (size_t)v * P * C;
+          float desc[LS3D_MAX_FEAT + 8];
+          vfe_descriptor(vox, P, C, num[v], desc);
+          for (int c = 0; c < C; ++c) t[c] = vox[p * C + c];
+          for (int c = 0; c < C + 8; ++c) t[C + c] = desc[c];
+          for (int c = 2 * C + 8; c < TV_KT; ++c) t[c] = 0.0f;
+        } else {
+          for (int c = 0; c < TV_KT; ++c) t[c] = 0.0f;
+        }
+      }
+    }
+    TV_WAVE_SYNC();
+    // ---- embedding (+ norm1 of layer 0)
+    tv_gemm(T, TV_TS, TV_KT, TV_E, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      const float b0 = prm.be[col], b1 = prm.be[32 + col];
+      TV_FOR_ACC(r, row) {
+        X[row * TV_XS + col] = a0[r] + b0;
+        X[row * TV_XS + 32 + col] = a1[r] + b1;
+      }
+    });
+    TV_WAVE_SYNC();
+    if (prm.num_layers > 0) tv_layernorm(X, prm.layer[0].n1g, prm.layer[0].n1b, prm.layer[0].n1eps);
+    TV_WAVE_SYNC();
+    for (int l = 0; l < prm.num_layers; ++l) {
+      const TvLayer &L = prm.layer[l];
+      // ---- QKV -> T[:, 0:192]
+      tv_gemm(X, TV_XS, TV_E, 3 * TV_E, L.wqkv, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+        const float b0 = L.bqkv[slab * 64 + col], b1 = L.bqkv[slab * 64 + 32 + col];
+        TV_FOR_ACC(r, row) {
+          T[row * TV_TS + slab * 64 + col] = a0[r] + b0;
+          T[row * TV_TS + slab * 64 + 32 + col] = a1[r] + b1;
+        }
+      });
+      TV_WAVE_SYNC();
+      // ---- attention inside each voxel: one lane per (voxel g, head h, query token t); output over the query's slice
+      {
+        const float scale = 1.0f / sqrtf((float)TV_HD);
+        const int items = G * TV_H * P;
+        for (int ps = 0; ps * 64 < items; ++ps) {
+          const int it = lane + 64 * ps;
+          const bool on = it < items;
+          const int g = on ? it / (TV_H * P) : 0, rem = on ? it - g * TV_H * P : 0;
+          const int h = rem / P, t = rem - h * P;
+          float *qp = T + (g * P + t) * TV_TS + h * TV_HD;
+          float q[TV_HD], o[TV_HD];
+#pragma unroll
+          for (int d = 0; d < TV_HD; ++d) { q[d] = qp[d] * scale; o[d] = 0.0f; }
+          float m = -3.0e38f;
+          for (int j = 0; j < P; ++j) {
+            const float *kp = T + (g * P + j) * TV_TS + TV_E + h * TV_HD;
+            float s = 0.0f;
+#pragma unroll
+            for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
+            m = fmaxf(m, s);
+          }
+          float den = 0.0f;
+          for (int j = 0; j < P; ++j) {
+            const float *kp = T + (g * P + j) * TV_TS + TV_E + h * TV_HD;
+            const float *vp = kp + TV_E;
+            float s = 0.0f;
+#pragma unroll
+            for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
+            const float pr = expf(s - m);
+            den += pr;
+#pragma unroll
+            for (int d = 0; d < TV_HD; ++d) o[d] = fmaf(pr, vp[d], o[d]);
+          }
+          const float inv = 1.0f / den;
+          if (on) {
+#pragma unroll
+            for (int d = 0; d < TV_HD; ++d) qp[d] = o[d] * inv;
+          }
+        }
+      }
+      TV_WAVE_SYNC();
+      // ---- out-proj + residual (from the normed X) -> X, then norm2
+      tv_gemm(T, TV_TS, TV_E, TV_E, L.wo, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+        const float b0 = L.bo[col], b1 = L.bo[32 + col];
+        TV_FOR_ACC(r, row) {
+          X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
+          X[row * TV_XS + 32 + col] = a1[r] + b1 + X[row * TV_XS + 32 + col];
+        }
+      });
+      TV_WAVE_SYNC();
+      tv_layernorm(X, L.n2g, L.n2b, L.n2eps);
+      TV_WAVE_SYNC();
+      // ---- FF1 + ReLU -> T[:, 0:128]
+      tv_gemm(X, TV_XS, TV_E, TV_FF, L.w1, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+        const float b0 = L.b1[slab * 64 + col], b1 = L.b1[slab * 64 + 32 + col];
+        TV_FOR_ACC(r, row) {
+          T[row * TV_TS + slab * 64 + col] = fmaxf(a0[r] + b0, 0.0f);
+          T[row * TV_TS + slab * 64 + 32 + col] = fmaxf(a1[r] + b1, 0.0f);
+        }
+      });
+      TV_WAVE_SYNC();
+      // ---- FF2 + residual -> X, then norm1 of the next layer
+      tv_gemm(T, TV_TS, TV_FF, TV_E, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+        const float b0 = L.b2[col], b1 = L.b2[32 + col];
+        TV_FOR_ACC(r, row) {
+          X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
+          X[row * TV_XS + 32 + col] = a1[r] + b1 + X[row * TV_XS + 32 + col];
+        }
+      });
+      TV_WAVE_SYNC();
+      if (l + 1 < prm.num_layers) {
+        tv_layernorm(X, prm.layer[l + 1].n1g, prm.layer[l + 1].n1b, prm.layer[l + 1].n1eps);
+        TV_WAVE_SYNC();
+      }
+    }
+    // ---- max over the P token slots (padding slots take part, as in the reference) -> T[g][0:64]
+    for (int g = 0; g < G; ++g) {
+      float m = X[(g * P) * TV_XS + lane];
+      for (int p = 1; p < P; ++p) m = fmaxf(m, X[(g * P + p) * TV_XS + lane]);
+      T[g * TV_TS + lane] = m;
+    }
+    TV_WAVE_SYNC();
+    if (prm.wc) {  // Linear + ReLU compression: one lane per (voxel, output)
+      for (int it = lane; it < G * prm.ncomp; it += 64) {
+        const int g = it / prm.ncomp, o = it - g * prm.ncomp;
+        const float *w = prm.wc + (size_t)o * TV_E, *x = T + g * TV_TS;
+        float s = 0.0f;
+        for (int c = 0; c < TV_E; ++c) s = fmaf(x[c], w[c], s);
+        s = fmaxf(s + prm.bc[o], 0.0f);
+        if (vw + g < N) out[(size_t)(vw + g) * out_ld + o] = s;
+      }
+    } else {
+      for (int g = 0; g < G; ++g)
+        if (vw + g < N) out[(size_t)(vw + g) * out_ld + lane] = T[g * TV_TS + lane];
+    }
+    TV_WAVE_SYNC();
+  }
+}
+
+extern "C" int ls3d_transvfe(const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
+                             const ls3d_transvfe_t *m, float *out, int out_ld, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!voxels || !num_points || !m || !out || n < 0 || P < 1 || C < 3) return LS3D_ERR_ARG;
+  if (!m->w_embed || !m->b_embed || (m->num_layers > 0 && !m->layers)) return LS3D_ERR_ARG;
+  // the fused kernel is specialised for the reference's configuration (num_embed 64, 4 heads, FF 128, <= 32-wide tokens)
+  if (m->embed != TV_E || m->heads != TV_H || m->ffn != TV_FF || m->token_ld != TV_KT || 2 * C + 8 > TV_KT || C > LS3D_MAX_FEAT || P > 32 ||
+      m->num_layers < 0 || m->num_layers > TV_MAX_LAYERS || (m->w_compress && (m->num_compressed < 1 || m->num_compressed > 64)))
+    return LS3D_ERR_UNSUPPORTED;
+  if (out_ld < (m->w_compress ? m->num_compressed : TV_E)) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  TvParams prm;
+  prm.we = m->w_embed; prm.be = m->b_embed; prm.wc = m->w_compress; prm.bc = m->b_compress;
+  prm.num_layers = m->num_layers; prm.ncomp = m->num_compressed;
+  for (int l = 0; l < m->num_layers; ++l) {
+    const ls3d_transvfe_layer_t &s = m->layers[l];
+    if (!s.wqkv || !s.bqkv || !s.wo || !s.bo || !s.w1 || !s.b1 || !s.w2 || !s.b2 || !s.n1_gamma || !s.n1_beta || !s.n2_gamma || !s.n2_beta)
+      return LS3D_ERR_ARG;
+    prm.layer[l] = TvLayer{s.wqkv, s.bqkv, s.wo, s.bo, s.w1, s.b1, s.w2, s.b2, s.n1_gamma, s.n1_beta, s.n2_gamma, s.n2_beta, s.n1_eps, s.n2_eps};
+  }
+  if (m->w_compress && !m->b_compress) return LS3D_ERR_ARG;
+  const int lds = (4 * TV_WAVE_FLOATS + 2 * TV_BCHUNK) * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)k_transvfe, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int per_block = 4 * (32 / P);
+  long long blocks = ((long long)n + per_block - 1) / per_block;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_transvfe, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

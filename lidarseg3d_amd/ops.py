@@ -163,6 +163,39 @@ def vfe_tokens(voxels, num_points, tok_ld, n_dev=None):
     return out
 
 
+class TransVFEModel(object):
+    """kernel-side description of a TransformerVoxelFeatureExtractor (keeps the packed tensors alive)"""
+
+    def __init__(self, embed, layers, compress, num_embed, num_head, ffn, token_ld):
+        """embed: (w_packed_nt2, bias); layers: dicts with wqkv,bqkv,wo,bo,w1,b1,w2,b2 (packed nt=2 / biases), n1/n2 =
+        (gamma, beta, eps); compress: (plain weight [out, in], bias) or None"""
+        self._keep = [embed, layers, compress]
+        arr = (_lib.TransVFELayer * max(len(layers), 1))()
+        for i, l in enumerate(layers):
+            for k in ("wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2"):
+                setattr(arr[i], k, l[k].data_ptr())
+            arr[i].n1_gamma, arr[i].n1_beta, arr[i].n1_eps = l["n1"][0].data_ptr(), l["n1"][1].data_ptr(), float(l["n1"][2])
+            arr[i].n2_gamma, arr[i].n2_beta, arr[i].n2_eps = l["n2"][0].data_ptr(), l["n2"][1].data_ptr(), float(l["n2"][2])
+        self._arr = arr
+        self.num_out = compress[0].shape[0] if compress is not None else num_embed
+        self.c = _lib.TransVFE(embed[0].data_ptr(), embed[1].data_ptr(), compress[0].data_ptr() if compress is not None else None,
+                               compress[1].data_ptr() if compress is not None else None, arr, len(layers),
+                               compress[0].shape[0] if compress is not None else 0, num_embed, num_head, ffn, token_ld)
+
+
+def transvfe(voxels, num_points, model):
+    """the whole TransformerVoxelFeatureExtractor in one kernel; returns None if the configuration is not the one the fused
+    kernel is specialised for (the caller then composes the layer from the individual ops)"""
+    n, p, c = voxels.shape
+    _ptr(voxels)  # device / contiguity checks
+    out = torch.empty((n, model.num_out), dtype=torch.float32, device=voxels.device)
+    rc = _L().ls3d_transvfe(_ptr(voxels), _ptr(num_points), n, None, p, c, ctypes.byref(model.c), _ptr(out), model.num_out, _stream(voxels))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "ls3d_transvfe")
+    return out
+
+
 def mha_core(qkv, groups, seq, embed, heads):
     out = torch.empty((groups * seq, embed), dtype=torch.float32, device=qkv.device)
     check(_L().ls3d_mha_core(_ptr(qkv), groups, None, seq, embed, heads, _ptr(out), _stream(qkv)), "ls3d_mha_core")

@@ -10,6 +10,9 @@ from . import ops
 from .packing import PackedModule, pack_linear
 from .registry import READERS
 
+import os as _os
+_FUSED = _os.environ.get("LS3D_TRANSVFE_FUSED", "1") != "0"  # 0: compose the TransVFE from the individual ops (A/B, tests)
+
 
 @READERS.register_module
 class MeanVoxelFeatureExtractor(nn.Module):
@@ -95,7 +98,29 @@ class TransformerVoxelFeatureExtractor(PackedModule):
                 n2=(l.norm2.weight.detach().contiguous(), l.norm2.bias.detach().contiguous(), l.norm2.eps)))
         if self.compress_layer is not None:
             p["compress"] = pack_linear(self.compress_layer[0].weight, self.compress_layer[0].bias)
+        p["fused"] = self._fused_model(p)
         return p
+
+    def _fused_model(self, p):
+        """description for the one-kernel path (ops.transvfe): 64-column-slab f32 packing of every matrix + plain biases"""
+        def mat(pk):
+            return pk[0].for_nt(2, ops.F32)
+
+        def vec(pk):  # pack_linear folds the bias into `shift` (no BatchNorm here: scale is None)
+            assert pk[1] is None and pk[2] is not None
+            return pk[2].contiguous()
+        conv = self.feature_conv[0]
+        if conv.bias is None or any(l.self_attn.in_proj_bias is None or l.linear1.bias is None for l in self.chunck.layers):
+            return None
+        layers = [dict(wqkv=mat(l["qkv"]), bqkv=vec(l["qkv"]), wo=mat(l["out"]), bo=vec(l["out"]), w1=mat(l["ff1"]), b1=vec(l["ff1"]),
+                       w2=mat(l["ff2"]), b2=vec(l["ff2"]), n1=l["n1"], n2=l["n2"]) for l in p["layers"]]
+        comp = None
+        if self.compress_layer is not None:
+            lin = self.compress_layer[0]
+            comp = (lin.weight.detach().float().contiguous(), lin.bias.detach().float().contiguous())
+        ffn = self.chunck.layers[0].linear1.out_features if len(self.chunck.layers) else 2 * self.num_embed
+        return ops.TransVFEModel((mat(p["embed"]), vec(p["embed"])), layers, comp, self.num_embed, self.num_head, ffn,
+                                 p["embed"][0].shape[1])
 
     @staticmethod
     def _lin(x, pk, relu=False, res=None, ln=None):
@@ -108,6 +133,11 @@ class TransformerVoxelFeatureExtractor(PackedModule):
         pk = self.packed()
         V, P, C = features.shape
         E, H = self.num_embed, self.num_head
+        if pk["fused"] is not None and _FUSED:
+            y = ops.transvfe(features.contiguous(), num_voxels.to(torch.int32).contiguous(), pk["fused"])
+            if y is not None:
+                return y
+        # configurations the fused kernel is not specialised for: the same computation layer by layer
         tok = ops.vfe_tokens(features.contiguous(), num_voxels.to(torch.int32).contiguous(), pk["embed"][0].shape[1])
         # every LayerNorm runs in the epilogue of the GEMM that produces its input (norm1 of layer l+1 in layer l's
         # ff2 GEMM, norm1 of layer 0 in the embedding GEMM): no separate pass over the [V*5, 64] token matrix

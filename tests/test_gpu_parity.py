@@ -69,8 +69,29 @@ def test_vfe_readers():
     np.testing.assert_allclose(readers.ImprovedMeanVoxelFeatureExtractor(5)(vx, num).cpu().numpy(), g["improved"], rtol=0, atol=1e-5)
     tv = readers.TransformerVoxelFeatureExtractor(5, 16, 64, 4, 3)
     tv.load_state_dict(seeded_sd("reader.TransformerVoxelFeatureExtractor", g["trans_seed"]), strict=True)
-    out = tv.to(DEV).eval()(vx, num)
+    out = tv.to(DEV).eval()(vx, num)  # the one-kernel path (ls3d_transvfe)
+    assert ops.transvfe(vx.contiguous(), num.to(torch.int32), tv.packed()["fused"]) is not None
     np.testing.assert_allclose(out.cpu().numpy(), g["trans"], rtol=0, atol=1e-4)
+    try:  # the layer-by-layer composition of the same module
+        readers._FUSED = False
+        np.testing.assert_allclose(tv(vx, num).cpu().numpy(), g["trans"], rtol=0, atol=1e-4)
+    finally:
+        readers._FUSED = True
+    # a full frame's worth of voxels (ragged last workgroup), fused vs composed, and run-to-run reproducibility
+    rng = np.random.default_rng(0)
+    nv = 65537
+    big = rng.normal(size=(nv, 5, 5)).astype(np.float32)
+    cnt = rng.integers(1, 6, size=nv).astype(np.int32)
+    big[np.arange(5)[None, :] >= cnt[:, None]] = 0.0
+    B, CN = cu(big), cu(cnt)
+    a = tv(B, CN)
+    assert torch.equal(a, tv(B, CN))
+    readers._FUSED = False
+    try:
+        b = tv(B, CN)
+    finally:
+        readers._FUSED = True
+    assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
 
 
 def test_gather_gemm_layout_asymmetric():

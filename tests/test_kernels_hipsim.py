@@ -238,7 +238,26 @@ def test_vfe_readers_vs_reference():
     np.testing.assert_allclose(readers.ImprovedMeanVoxelFeatureExtractor(5)(vx, num).numpy(), g["improved"][sel], rtol=0, atol=1e-5)
     tv = readers.TransformerVoxelFeatureExtractor(5, 16, 64, 4, 3)
     tv.load_state_dict(seeded_sd("reader.TransformerVoxelFeatureExtractor", g["trans_seed"]), strict=True)
-    np.testing.assert_allclose(tv.eval()(vx, num).numpy(), g["trans"][sel], rtol=0, atol=1e-4)
+    fused = tv.eval()(vx, num).numpy()  # the one-kernel path (ls3d_transvfe)
+    assert ops.transvfe(vx.contiguous(), num.to(torch.int32), tv.packed()["fused"]) is not None  # ... is really taken
+    np.testing.assert_allclose(fused, g["trans"][sel], rtol=0, atol=1e-4)
+    try:  # and the layer-by-layer composition of the same module (configurations the fused kernel does not cover)
+        readers._FUSED = False
+        np.testing.assert_allclose(tv(vx, num).numpy(), g["trans"][sel], rtol=0, atol=1e-4)
+    finally:
+        readers._FUSED = True
+    # ragged tail: 7 voxels = one full wave tile (6 voxels x 5 slots) + 1, workgroup partially filled
+    np.testing.assert_allclose(tv(vx[:7], num[:7]).numpy(), g["trans"][:7], rtol=0, atol=1e-4)
+    # no compression layer -> 64 features; 1 layer
+    tv2 = readers.TransformerVoxelFeatureExtractor(5, 0, 64, 4, 1).eval()
+    a = tv2(vx[:50], num[:50])
+    readers._FUSED = False
+    try:
+        b = tv2(vx[:50], num[:50])
+    finally:
+        readers._FUSED = True
+    assert a.shape == (50, 64)
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=1e-4)
 
 
 def test_unet_small_vs_oracle():
