@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
 
 
@@ -246,7 +247,13 @@ def main():
                          "traffic": None, "avg_launch_us": conv["avg_us"],
                          "algo_bytes_per_frame": conv["algo_bytes"] / max(args.steps, 1),
                          "tflops": conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0,
-                         "sparse_conv_ms_per_frame": conv["total_ms"] / max(args.steps, 1)},
+                         "sparse_conv_ms_per_frame": conv["total_ms"] / max(args.steps, 1),
+                         # the same launches against the matrix pipe: useful (pair) flops only, exact-f32 MFMA peak
+                         # (v_mfma_f32_32x32x2_f32: 256 CUs x 4 SIMDs x 4096 flop / 64 cycles x 2.4 GHz)
+                         "mfma": None if args.precision != "f32" else {"achieved_tflops": conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0,
+                                  "peak_tflops": F32_MFMA_PEAK_TFLOPS,
+                                  "frac": (conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if conv["total_ms"] > 0 else 0.0,
+                                  "counter_evidence": "profiles/round1_pmc_sq.md (SQ_VALU_MFMA_BUSY_CYCLES: 51 % of SIMD cycles)"}},
         }
         pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")
         if args.model == "sdseg3d" and args.precision == "f32" and args.points == 120000 and os.path.exists(pmc):

@@ -16,6 +16,8 @@ if [ "${PROFILE:-1}" = "1" ]; then
   echo "rocprof rc=$?" >> $OUT/summary.txt
   if [ "${PMC:-0}" = "1" ]; then
     # HBM traffic counters: separate passes (FETCH_SIZE takes 3 of the 4 TCC slots), kernel-trace only
+    timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_SQ -o bench -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1
+    echo "pmc SQ rc=$?" >> $OUT/summary.txt
     for c in FETCH_SIZE WRITE_SIZE; do
       timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
       echo "pmc $c rc=$?" >> $OUT/summary.txt
