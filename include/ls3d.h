@@ -250,6 +250,17 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
                      int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
                      int out_ld, ls3d_stream_t stream);
 
+/* Backward of the sparse convolutions (spconv v1.x indice_conv_backward).
+ *   grad_in : ls3d_gather_gemm on grad_out with the TRANSPOSED table (SubM: the same table; SparseConv3d: nbr_inv;
+ *             SparseInverseConv3d: nbr_out) and weights W'[k] = W[k]^T (SubM: W'[k] = W[kvol-1-k]^T) - no extra entry point;
+ *   grad_w  : grad_w[k][ci][co] = sum over rows o with tbl[o][k] >= 0 of in[tbl[o][k]][ci] * grad_out[o][co], tbl = the table
+ *             the FORWARD launch used, plain [kvol][cin][cout] layout (the layout of the module's weight), cout <= 128.
+ * Deterministic (fixed summation order). */
+size_t ls3d_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout, int n_rows);
+int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int grad_out_ld, const int32_t *tbl, const int32_t *row_order,
+                      int kvol, int cin, int cout, int n_rows, const int32_t *n_rows_dev, void *workspace, size_t workspace_bytes,
+                      float *grad_w, ls3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Devoxelization
  * ---------------------------------------------------------------------------------------------- */

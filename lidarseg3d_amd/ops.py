@@ -458,6 +458,18 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     return out
 
 
+def spconv_wgrad(x, grad_out, tbl, order, cin, cout):
+    """grad_w[kvol, cin, cout] of a sparse convolution: x = the forward input features (rows indexed by tbl), grad_out on the
+    forward output rows, tbl/order = the table and row order of the forward launch"""
+    n, kvol = tbl.shape
+    gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
+    L = _L()
+    ws = _ws(L.ls3d_spconv_wgrad_workspace_bytes(kvol, cin, cout, n), x)
+    check(L.ls3d_spconv_wgrad(_ptr(x), x.shape[1], _ptr(grad_out), grad_out.shape[1], _ptr(tbl), _ptr(order), kvol, cin, cout, n, None,
+                              _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(gw), _stream(x)), "ls3d_spconv_wgrad")
+    return gw
+
+
 def _vp(t):
     p = _ptr(t)
     return p if p is not None else ctypes.c_void_p(0)

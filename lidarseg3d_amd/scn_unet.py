@@ -47,6 +47,12 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         assert x.features.dim() == 2, "x.features.dim()=%d" % x.features.dim()
         identity = x.features if self.downsample is None else self.downsample(x)
+        if self.training:  # scn_unet.py:51-69 as written: batch-statistics BatchNorm, differentiable convolutions
+            out = self.conv1(x)
+            out.features = torch.relu(self.bn1(out.features))
+            out = self.conv2(out)
+            out.features = torch.relu(self.bn2(out.features) + identity)
+            return out
         out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         return conv_bn_act(self.conv2, self.bn2, out, relu=True, res_pre=identity)
 
@@ -126,6 +132,15 @@ class UNetSCN3D(nn.Module):
         inv.conv(x, rbi, scale=s, shift=t, relu=True, out=next_cat[:, :cout], out_ld=next_cat.shape[1])
         return x._like(next_cat[:, :cout], rbi.in_indices, rbi.in_shape)
 
+    def UR_block_forward_train(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv):
+        """scn_unet.py:163-171 as written (training: every step is a differentiable op)"""
+        x_trans = conv_t(x_lateral)
+        x = x_trans._like(torch.cat([x_bottom.features, x_trans.features], dim=1))
+        x_m = conv_m(x)
+        n, c = x_m.features.shape
+        x_m.features = x_m.features + x.features.view(n, c, -1).sum(dim=2)  # channel_reduction + add
+        return conv_inv(x_m)
+
     @staticmethod
     def channel_reduction(x, out_channels):
         """scn_unet.py:173-187 (kept for API parity; the forward fuses it into conv_m's epilogue)"""
@@ -135,8 +150,6 @@ class UNetSCN3D(nn.Module):
         return x
 
     def forward(self, batch_dict):
-        if self.training:
-            raise NotImplementedError("UNetSCN3D: inference forward only (eval-mode BatchNorm); call .eval()")
         voxel_features, voxel_coords = batch_dict["voxel_features"], batch_dict["voxel_coords"]
         batch_size = batch_dict["batch_size"]
         sparse_shape = np.array(batch_dict["input_shape"][::-1]) + [1, 0, 0]
@@ -159,6 +172,12 @@ class UNetSCN3D(nn.Module):
         if self.conv_out is not None:
             batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
             batch_dict["encoded_spconv_tensor_stride"] = 8
+        if self.training:
+            x_up4 = self.UR_block_forward_train(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4)
+            x_up3 = self.UR_block_forward_train(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3)
+            x_up2 = self.UR_block_forward_train(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2)
+            x_up1 = self.UR_block_forward_train(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5)
+            return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
         dev = voxel_features.device
         cats = [torch.empty((t.features.shape[0], 2 * t.features.shape[1]), dtype=torch.float32, device=dev)
                 for t in (x_conv3, x_conv2, x_conv1)]
@@ -166,6 +185,9 @@ class UNetSCN3D(nn.Module):
         x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1])
         x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2])
         x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2])
+        return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
+
+    def _outputs(self, batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4):
         batch_dict["multi_scale_3d_features"] = dict(x_conv1=x_up2, x_conv2=x_up3, x_conv3=x_up4, x_conv4=x_conv4)
         batch_dict["conv_point_features"] = x_up1.features
         batch_dict["conv_point_coords"] = ops.voxel_centers(x_up1.indices, self.voxel_size, self.point_cloud_range)

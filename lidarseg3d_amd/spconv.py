@@ -67,6 +67,57 @@ class _Rulebook(object):
         return self._orders[inverse]
 
 
+class _SparseConvFn(torch.autograd.Function):
+    """Differentiable sparse convolution (the training path; inference uses the packed, epilogue-fused launches).
+    forward: out = gather_gemm(feats, W, tbl) (+ bias); backward: grad_feats = the same gather-GEMM on the transposed table
+    with W^T (SubM: mirrored offsets), grad_W = ops.spconv_wgrad (include/ls3d.h: "Backward of the sparse convolutions")."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, rb, inverse, subm):
+        cin, cout = weight.shape[-2], weight.shape[-1]
+        W = pack_spconv(weight)[0]
+        tbl = rb.tbl_inv if inverse else rb.tbl
+        order = rb.order(inverse) if cin * cout >= 4096 else None
+        x = feats.detach().contiguous()
+        if x.shape[1] != W.shape[1]:
+            x = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1]))
+        out = ops.gather_gemm(x, W, tbl=tbl, order=order, cout=cout, shift=None if bias is None else bias.detach())
+        ctx.save_for_backward(feats, weight)
+        ctx.rb, ctx.inverse, ctx.subm, ctx.has_bias = rb, inverse, subm, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .packing import PackedWeight, _pad16
+        feats, weight = ctx.saved_tensors
+        rb, inverse, subm = ctx.rb, ctx.inverse, ctx.subm
+        cin, cout = weight.shape[-2], weight.shape[-1]
+        kvol = weight.numel() // (cin * cout)
+        gout = gout.contiguous()
+        gin = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wd = weight.detach().reshape(kvol, cin, cout).transpose(1, 2)  # [kvol, cout, cin]: grad_out -> grad_in
+            if subm:
+                wd = wd.flip(0)  # input i sees output o through the mirrored offset
+            Wd = PackedWeight(wd.contiguous(), kvol, cout, _pad16(cout), cin)
+            if subm:
+                tbl_t, order_t = rb.tbl, (rb.order(False) if cin * cout >= 4096 else None)
+            else:
+                tbl_t = rb.tbl if inverse else rb.tbl_inv
+                order_t = rb.order(not inverse) if cin * cout >= 4096 else None
+            g = gout
+            if g.shape[1] != Wd.shape[1]:
+                g = torch.nn.functional.pad(g, (0, Wd.shape[1] - g.shape[1]))
+            gin = ops.gather_gemm(g, Wd, tbl=tbl_t, order=order_t, cout=cin)
+        if ctx.needs_input_grad[1]:
+            tbl = rb.tbl_inv if inverse else rb.tbl
+            order = rb.order(inverse) if cin * cout >= 4096 else None
+            gw = ops.spconv_wgrad(feats.detach().contiguous(), gout, tbl, order, cin, cout).reshape(weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gout.sum(0)
+        return gin, gw, gb, None, None, None
+
+
 class SparseConvolution(PackedModule, SparseModule):
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
@@ -132,7 +183,10 @@ class SparseConvolution(PackedModule, SparseModule):
 
     def forward(self, x):
         rb = self.rulebook(x)
-        f = self.conv(x, rb)
+        if torch.is_grad_enabled() and (x.features.requires_grad or (self.training and self.weight.requires_grad)):
+            f = _SparseConvFn.apply(x.features, self.weight, self.bias, rb, bool(self.inverse), bool(self.subm))
+        else:
+            f = self.conv(x, rb)
         if self.inverse:
             return x._like(f, rb.in_indices, rb.in_shape)
         return x._like(f, rb.out_indices, rb.out_shape)

@@ -366,3 +366,96 @@ def test_sparse_conv_bf16x3_vs_f32(monkeypatch):
     finally:
         ops.set_precision("f32")
     assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
+
+
+def _spconv_ref(feats, w, tbl):
+    """differentiable torch restatement of out[o] = sum_k W[k]^T in[tbl[o][k]]"""
+    kvol = tbl.shape[1]
+    w = w.reshape(kvol, w.shape[-2], w.shape[-1])
+    out = torch.zeros((tbl.shape[0], w.shape[-1]), dtype=feats.dtype)
+    for k in range(kvol):
+        o = torch.nonzero(tbl[:, k] >= 0)[:, 0]
+        if o.numel():
+            out = out.index_add(0, o, feats[tbl[o, k].long()] @ w[k])
+    return out
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (32, 128), (64, 128)])
+def test_sparse_conv_backward_vs_autograd(cin, cout):
+    """SubMConv3d -> SparseConv3d(stride 2) -> SparseInverseConv3d in training mode: grad of the input features and of the
+    three weights (dgrad = gather-GEMM on the transposed tables, wgrad = ls3d_spconv_wgrad) vs torch autograd on a plain
+    restatement of the same sums"""
+    from lidarseg3d_amd import spconv
+    rng = np.random.default_rng(cin + cout)
+    shape = [9, 24, 24]
+    cells = rng.choice(shape[0] * shape[1] * shape[2], size=420, replace=False)
+    coords = np.stack([np.zeros_like(cells), cells // (24 * 24), (cells // 24) % 24, cells % 24], 1).astype(np.int32)
+    coords = coords[np.lexsort((coords[:, 3], coords[:, 2], coords[:, 1]))]
+    feats = torch.from_numpy(rng.normal(size=(len(coords), cin)).astype(np.float32)).requires_grad_(True)
+    torch.manual_seed(0)
+    c1 = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="s1").train()
+    c2 = spconv.SparseConv3d(cout, cout, 3, stride=2, padding=1, bias=True, indice_key="d1").train()
+    c3 = spconv.SparseInverseConv3d(cout, cin, 3, indice_key="d1", bias=False).train()
+    x = spconv.SparseConvTensor(feats, torch.from_numpy(coords), shape, 1)
+    y1 = c1(x); y2 = c2(y1); y3 = c3(y2)
+    r = torch.from_numpy(rng.normal(size=tuple(y3.features.shape)).astype(np.float32))
+    (y3.features * r).sum().backward()
+    got = [feats.grad.clone(), c1.weight.grad.clone(), c2.weight.grad.clone(), c2.bias.grad.clone(), c3.weight.grad.clone()]
+    # reference: same tables, torch autograd
+    rb1, rb2 = x.find_indice_pair("s1"), x.find_indice_pair("d1")
+    f2 = feats.detach().clone().requires_grad_(True)
+    w1, w2, b2, w3 = (t.detach().clone().requires_grad_(True) for t in (c1.weight, c2.weight, c2.bias, c3.weight))
+    z1 = _spconv_ref(f2, w1, rb1.tbl)
+    z2 = _spconv_ref(z1, w2, rb2.tbl) + b2
+    z3 = _spconv_ref(z2, w3, rb2.tbl_inv)
+    np.testing.assert_allclose(y3.features.detach().numpy(), z3.detach().numpy(), rtol=0, atol=2e-4)
+    (z3 * r).sum().backward()
+    for g, w in zip(got, (f2.grad, w1.grad, w2.grad, b2.grad, w3.grad)):
+        np.testing.assert_allclose(g.numpy(), w.numpy(), rtol=0, atol=2e-4 * max(1.0, float(w.abs().max())))
+
+
+def test_unet_training_forward_backward_vs_autograd(monkeypatch):
+    """UNetSCN3D in train() mode (batch-statistics BatchNorm, the reference's unfused composition): loss gradient w.r.t. the
+    input features and the 36 convolution weights on the path to the output, HIP dgrad/wgrad vs the same graph with every sparse convolution replaced
+    by the plain torch restatement"""
+    from lidarseg3d_amd import spconv
+    cfg = synth.NUSC
+    g = golden("unet_nusc_c13.npz")
+    n = 160
+    coords = torch.from_numpy(g["coords"][:n])
+    feats0 = torch.from_numpy(g["voxel_features"][:n])
+    net = scn_unet.UNetSCN3D(num_input_features=13, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
+                             model_cfg=dict(SCALING_RATIO=1), ds_factor=8, us_factor=8)
+    torch.manual_seed(1)
+    net.train()
+    shape = np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        for m in net.modules():  # same running-stat updates in both runs do not matter; same batch statistics do
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+        f = feats0.clone().requires_grad_(True)
+        bd = net(dict(voxel_features=f, voxel_coords=coords, batch_size=1, input_shape=shape))
+        out = bd["conv_point_features"]
+        w = torch.linspace(-1, 1, out.numel()).reshape(out.shape)
+        (out * w).sum().backward()
+        grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        return out.detach().clone(), f.grad.clone(), grads
+
+    out_a, gin_a, gw_a = run()
+
+    class RefFn(object):
+        @staticmethod
+        def apply(feats, weight, bias, rb, inverse, subm):
+            y = _spconv_ref(feats, weight, (rb.tbl_inv if inverse else rb.tbl))
+            return y if bias is None else y + bias
+    monkeypatch.setattr(spconv, "_SparseConvFn", RefFn)
+    out_b, gin_b, gw_b = run()
+    np.testing.assert_allclose(out_a.numpy(), out_b.numpy(), rtol=0, atol=1e-4 * max(1.0, float(out_b.abs().max())))
+    np.testing.assert_allclose(gin_a.numpy(), gin_b.numpy(), rtol=0, atol=2e-4 * max(1.0, float(gin_b.abs().max())))
+    convs = [k for k in gw_b if k.endswith("weight") and gw_b[k].dim() == 5]
+    assert len(convs) == 36 and set(gw_a) == set(gw_b)  # conv_out feeds nothing the loss sees
+    for k in gw_b:
+        np.testing.assert_allclose(gw_a[k].numpy(), gw_b[k].numpy(), rtol=0, atol=3e-4 * max(1.0, float(gw_b[k].abs().max())), err_msg=k)
