@@ -33,9 +33,13 @@ extern "C" {
 
 /* arithmetic of ls3d_gather_gemm.  F32: exact f32 products and accumulation (v_mfma_f32_32x32x2_f32).
  * BF16X3: f32 operands split into bf16 head + tail, a*b = a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
- * v_mfma_f32_32x32x16_bf16 with f32 accumulation: ~1e-5 relative error per layer, 5.3x less matrix-pipe time. */
+ * v_mfma_f32_32x32x16_bf16 with f32 accumulation: ~1e-5 relative error per layer, 5.3x less matrix-pipe time.
+ * BF16X6: operands split EXACTLY into three bf16 planes (8+8+8 mantissa bits), the six partial products of weight
+ * >= 2^-16 are accumulated in f32; the dropped ones are <= 2^-24 relative, the size of an f32 rounding error, so results
+ * agree with F32 to f32 rounding (measured against float64: tests/probes/bwd_dbg.py), at 2.7x less matrix-pipe time. */
 #define LS3D_PRECISION_F32 0
 #define LS3D_PRECISION_BF16X3 1
+#define LS3D_PRECISION_BF16X6 2
 
 typedef void *ls3d_stream_t;
 
@@ -246,7 +250,7 @@ int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_p
  * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
  * (tbl = nbr_inv) and every nn.Linear on the path. */
 int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int wc,
-                     int precision /* must equal the packing's; BF16X3 needs cin % 32 == 0 and wc == 1 */, int cin, int cout,
+                     int precision /* must equal the packing's; BF16X3 / BF16X6 need cin % 32 == 0 and wc == 1 */, int cin, int cout,
                      int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
                      int out_ld, ls3d_stream_t stream);
 

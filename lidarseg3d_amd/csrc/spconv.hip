@@ -381,15 +381,36 @@ __device__ __forceinline__ void ls3d_split8(const float4 &f0, const float4 &f1, 
   ls3d_split_pair(f1.z, f1.w, hi.w, lo.w);
 }
 
-template <int NT, bool SPARSE>
+// exact 3-way split of an f32 into bf16 planes: a = h + m + l with h, m truncated and l rounded (8 + 8 + 8 mantissa bits)
+__device__ __forceinline__ void ls3d_split_pair3(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  const unsigned ha = __float_as_uint(a) & 0xFFFF0000u, hb = __float_as_uint(b) & 0xFFFF0000u;
+  const float ra = a - __uint_as_float(ha), rb = b - __uint_as_float(hb);
+  const unsigned ma = __float_as_uint(ra) & 0xFFFF0000u, mb = __float_as_uint(rb) & 0xFFFF0000u;
+  h = (ha >> 16) | hb;
+  m = (ma >> 16) | mb;
+  l = ls3d_bf16_rne(ra - __uint_as_float(ma)) | (ls3d_bf16_rne(rb - __uint_as_float(mb)) << 16);
+}
+__device__ __forceinline__ void ls3d_split8x3(const float4 &f0, const float4 &f1, uint4 &h, uint4 &m, uint4 &l) {
+  ls3d_split_pair3(f0.x, f0.y, h.x, m.x, l.x);
+  ls3d_split_pair3(f0.z, f0.w, h.y, m.y, l.y);
+  ls3d_split_pair3(f1.x, f1.y, h.z, m.z, l.z);
+  ls3d_split_pair3(f1.z, f1.w, h.w, m.w, l.w);
+}
+
+// PL = number of bf16 planes per operand: 2 -> a*b ~ a0*b0 + a0*b1 + a1*b0 ("bf16x3", ~2^-16 relative per product),
+//      3 -> a = a0 + a1 + a2 (24 mantissa bits: an exact split of an f32), a*b ~ the 6 products of weight <= 2^-16
+//           ("bf16x6": dropped terms 2^-24 relative, i.e. the size of an f32 rounding error) = f32-grade results at
+//           6 x 32 MFMA cycles per K=16 instead of 8 x 64.
+template <int NT, bool SPARSE, int PL>
 __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
                                                            const int32_t *__restrict__ order, int kvol, const float *__restrict__ w,
                                                            int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
                                                            float *__restrict__ out, int out_ld, int xcd_map) {
   constexpr int KC = 32, TR = 128, SLAB = NT * 32;
-  constexpr int BV = KC * SLAB / 4;      // 16-byte units in one weight chunk (same bytes as the f32 chunk)
-  constexpr int BPT = BV / 256;          // NT
-  __shared__ __attribute__((aligned(16))) float Bs[2][KC * SLAB];  // chunk layout: [n][t][hi/lo][kk][col] x (8 bf16)
+  constexpr int BV = NT * 2 * PL * 64;   // 16-byte units in one weight chunk: [n][t][plane][kk][col] x (8 bf16)
+  constexpr int BPT = (BV + 255) / 256;  // units staged per thread
+  constexpr int CHF = BV * 4;            // floats per chunk
+  __shared__ __attribute__((aligned(16))) float Bs[2][CHF];
   __shared__ unsigned long long s_kmask;
   __shared__ int s_rows[TR];
   __shared__ float s_stat[2 * 64];
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
     }
     if (tile >= ntiles) continue;
     const int n0 = slab * SLAB;
-    const float *wbase = w + (size_t)slab * cin * SLAB;
+    const float *wbase = w + (size_t)slab * (cin / KC) * CHF;  // packed: [kvol][slab][cin/32][chunk]
     if (tid == 0) s_kmask = 0ull;
     if (tid < TR) {
       const int r = tile * TR + tid;
@@ -454,26 +475,32 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
       _Pragma("unroll") for (int q = 0; q < 4; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);   \
     }                                                                                           \
   } while (0)
-#define LS3D_B_ONE(j, reg, OP) \
-  if constexpr (BPT > (j)) { const int i_ = tid + (j)*256; OP(reg, i_); }
+#define LS3D_B_ONE(j, reg, OP)                                                                  \
+  if constexpr (BPT > (j)) {                                                                    \
+    const int i_ = tid + (j)*256;                                                               \
+    if (BV % 256 == 0 || i_ < BV) { OP(reg, i_); }                                              \
+  }
 #define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)(i_)*4)
 #define LS3D_B_ST(reg, i_) *(float4 *)(dst_ + (i_)*4) = reg
 #define LS3D_LOAD_B(k, c0_)                                                                     \
   do {                                                                                          \
-    const float *wk_ = wbase + ((size_t)(k)*cin * nslab + (c0_)) * SLAB;                        \
+    const float *wk_ = wbase + ((size_t)(k) * nslab * (cin / KC) + (c0_) / KC) * CHF;           \
     LS3D_B_ONE(0, breg0, LS3D_B_LD) LS3D_B_ONE(1, breg1, LS3D_B_LD)                             \
     LS3D_B_ONE(2, breg2, LS3D_B_LD) LS3D_B_ONE(3, breg3, LS3D_B_LD)                             \
+    LS3D_B_ONE(4, breg4, LS3D_B_LD) LS3D_B_ONE(5, breg5, LS3D_B_LD)                             \
   } while (0)
 #define LS3D_STORE_B(dst)                                                                       \
   do {                                                                                          \
     float *dst_ = (dst);                                                                        \
     LS3D_B_ONE(0, breg0, LS3D_B_ST) LS3D_B_ONE(1, breg1, LS3D_B_ST)                             \
     LS3D_B_ONE(2, breg2, LS3D_B_ST) LS3D_B_ONE(3, breg3, LS3D_B_ST)                             \
+    LS3D_B_ONE(4, breg4, LS3D_B_ST) LS3D_B_ONE(5, breg5, LS3D_B_ST)                             \
   } while (0)
       int idx_cur = LS3D_LOAD_IDX(k_cur);
       int idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
       float4 a_cur[4], a_nxt[4];
-      float4 breg0, breg1, breg2, breg3;
+      float4 breg0, breg1, breg2, breg3, breg4, breg5;
+      static_assert(BPT <= 6, "weight chunk too large for the staging registers");
       int c0 = 0, buf = 0;
       LS3D_LOAD_A(a_cur, idx_cur, 0);
       LS3D_LOAD_B(k_cur, 0);
@@ -491,25 +518,50 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
           LS3D_LOAD_B(nk, nc0);
         }
         if ((wmask >> k_cur) & 1ull) {
-          uint4 ah0, al0, ah1, al1;  // heads / tails of this lane's 16 floats: k-step 0 uses floats 0-7, k-step 1 floats 8-15
-          ls3d_split8(a_cur[0], a_cur[1], ah0, al0);
-          ls3d_split8(a_cur[2], a_cur[3], ah1, al1);
-          const bf16x8 vah0 = __builtin_bit_cast(bf16x8, ah0), val0 = __builtin_bit_cast(bf16x8, al0);
-          const bf16x8 vah1 = __builtin_bit_cast(bf16x8, ah1), val1 = __builtin_bit_cast(bf16x8, al1);
-          const uint4 *bs = (const uint4 *)Bs[buf] + kk * 32 + col;  // unit index (((n*2+t)*2+h)*2+kk)*32+col
+          // planes of this lane's 16 floats: k-step 0 uses floats 0-7, k-step 1 floats 8-15
+          const uint4 *bs = (const uint4 *)Bs[buf] + kk * 32 + col;  // unit index (((n*2+t)*PL+plane)*2+kk)*32+col
+          if constexpr (PL == 2) {
+            uint4 ah0, al0, ah1, al1;
+            ls3d_split8(a_cur[0], a_cur[1], ah0, al0);
+            ls3d_split8(a_cur[2], a_cur[3], ah1, al1);
+            const bf16x8 vah0 = __builtin_bit_cast(bf16x8, ah0), val0 = __builtin_bit_cast(bf16x8, al0);
+            const bf16x8 vah1 = __builtin_bit_cast(bf16x8, ah1), val1 = __builtin_bit_cast(bf16x8, al1);
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            const bf16x8 bh0 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 0) * 2 + 0) * 64]);
-            const bf16x8 bl0 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 0) * 2 + 1) * 64]);
-            const bf16x8 bh1 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 1) * 2 + 0) * 64]);
-            const bf16x8 bl1 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 1) * 2 + 1) * 64]);
-            // small terms first
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val0, bh0, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah0, bl0, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val1, bh1, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bl1, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah0, bh0, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bh1, acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) {
+              const bf16x8 bh0 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 0) * 2 + 0) * 64]);
+              const bf16x8 bl0 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 0) * 2 + 1) * 64]);
+              const bf16x8 bh1 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 1) * 2 + 0) * 64]);
+              const bf16x8 bl1 = __builtin_bit_cast(bf16x8, bs[((n * 2 + 1) * 2 + 1) * 64]);
+              // small terms first
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val0, bh0, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah0, bl0, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val1, bh1, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bl1, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah0, bh0, acc[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bh1, acc[n], 0, 0, 0);
+            }
+          } else {
+            uint4 a0[3], a1[3];  // [plane]: head / middle / tail
+            ls3d_split8x3(a_cur[0], a_cur[1], a0[0], a0[1], a0[2]);
+            ls3d_split8x3(a_cur[2], a_cur[3], a1[0], a1[1], a1[2]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, t ? a1[0] : a0[0]), am = __builtin_bit_cast(bf16x8, t ? a1[1] : a0[1]);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, t ? a1[2] : a0[2]);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bs[((n * 2 + t) * 3 + 0) * 64]);
+                const bf16x8 bm = __builtin_bit_cast(bf16x8, bs[((n * 2 + t) * 3 + 1) * 64]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, bs[((n * 2 + t) * 3 + 2) * 64]);
+                // the six products of weight >= 2^-16, smallest first
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+              }
+            }
           }
         }
         if (!has_next) break;
@@ -539,14 +591,14 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
 }
 
 // plain [kvol][cin_src][cout] -> split-bf16 packed [kvol][slab][cin_pad/32][n][t][hi/lo][kk][col] x 8 bf16
-__global__ __launch_bounds__(256) void k_gg_pack_bf16x3(const float *src, int kvol, int cin_src, int cin_pad, int cout, int nt, uint4 *dst) {
+__global__ __launch_bounds__(256) void k_gg_pack_bf16x3(const float *src, int kvol, int cin_src, int cin_pad, int cout, int nt, int pl, uint4 *dst) {
   const int slab = nt * 32, nslab = ((cout + 31) / 32) / nt, nchunk = cin_pad / 32;
-  const long long total = (long long)kvol * nslab * nchunk * nt * 256;  // 16-byte units
+  const long long total = (long long)kvol * nslab * nchunk * nt * 2 * pl * 64;  // 16-byte units
   for (long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; t_ < total; t_ += (long long)gridDim.x * blockDim.x) {
     long long r = t_;
     const int col = (int)(r % 32); r /= 32;
     const int kk = (int)(r % 2); r /= 2;
-    const int h = (int)(r % 2); r /= 2;
+    const int h = (int)(r % pl); r /= pl;
     const int t = (int)(r % 2); r /= 2;
     const int n = (int)(r % nt); r /= nt;
     const int ch = (int)(r % nchunk); r /= nchunk;
@@ -554,13 +606,22 @@ __global__ __launch_bounds__(256) void k_gg_pack_bf16x3(const float *src, int kv
     const int k = (int)r;
     const int oc = sl * slab + n * 32 + col;
     unsigned wds[4];
+#pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
       unsigned half[2];
+#pragma unroll
       for (int e2 = 0; e2 < 2; ++e2) {
         const int c = ch * 32 + kk * 16 + t * 8 + pr * 2 + e2;
         const float v = (c < cin_src && oc < cout) ? src[((size_t)k * cin_src + c) * cout + oc] : 0.0f;
-        const unsigned hb = ls3d_bf16_rne(v);
-        half[e2] = h == 0 ? hb : ls3d_bf16_rne(v - __uint_as_float(hb << 16));
+        if (pl == 2) {  // head rounded to nearest, tail = the rest
+          const unsigned hb = ls3d_bf16_rne(v);
+          half[e2] = h == 0 ? hb : ls3d_bf16_rne(v - __uint_as_float(hb << 16));
+        } else {        // exact 3-way split (the same one the kernel applies to the gathered rows)
+          const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
+          const float r1 = v - __uint_as_float(hb);
+          const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+          half[e2] = h == 0 ? (hb >> 16) : h == 1 ? (mb >> 16) : ls3d_bf16_rne(r1 - __uint_as_float(mb));
+        }
       }
       wds[pr] = half[0] | (half[1] << 16);
     }
@@ -840,14 +901,14 @@ static int launch_pipe(long long work_items, hipStream_t stream, const float *in
   return LS3D_OK;
 }
 
-template <int NT>
+template <int NT, int PL>
 static void launch_gg3(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
                        const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
   if (tbl)
-    hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, true>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
+    hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, true, PL>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
                        n_rows_dev, e, out, out_ld, g_xcd_map);
   else
-    hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, false>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
+    hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, false, PL>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
                        n_rows_dev, e, out, out_ld, g_xcd_map);
 }
 
@@ -887,7 +948,8 @@ __global__ __launch_bounds__(256) void k_gg_pack(const float *src, int kvol, int
 }
 
 extern "C" size_t ls3d_gather_gemm_packed_floats(int kvol, int cin_pad, int cout) {
-  return (size_t)kvol * cin_pad * ((cout + 31) / 32 * 32);
+  // sized for the largest layout (LS3D_PRECISION_BF16X6: three bf16 planes = 6 bytes per weight)
+  return (size_t)kvol * cin_pad * ((cout + 31) / 32 * 32) * 3 / 2;
 }
 
 extern "C" int ls3d_gather_gemm_default_nt(int cout) { return gg_nt(cout); }
@@ -899,10 +961,11 @@ extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src
   if (!w_plain || !w_packed || kvol < 1 || cin_src < 1 || cin_pad < cin_src || (cin_pad % 16) || cout < 1) return LS3D_ERR_ARG;
   if (nt == 0) nt = gg_nt(cout);
   if (!gg_nt_ok(cout, nt)) return LS3D_ERR_ARG;
-  const long long total = (long long)ls3d_gather_gemm_packed_floats(kvol, cin_pad, cout);
-  if (precision == LS3D_PRECISION_BF16X3) {
+  const long long total = (long long)kvol * cin_pad * ((cout + 31) / 32 * 32);  // weights incl. padding
+  if (precision == LS3D_PRECISION_BF16X3 || precision == LS3D_PRECISION_BF16X6) {
     if (cin_pad % 32) return LS3D_ERR_ARG;
-    hipLaunchKernelGGL(k_gg_pack_bf16x3, ls3d_grid(total / 4), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt,
+    const int pl = precision == LS3D_PRECISION_BF16X3 ? 2 : 3;
+    hipLaunchKernelGGL(k_gg_pack_bf16x3, ls3d_grid(total * pl / 8), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt, pl,
                        (uint4 *)w_packed);
     LS3D_RETURN_IF_LAUNCH_FAILED();
     return LS3D_OK;
@@ -958,14 +1021,25 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   const int ntiles = (n_rows + tr - 1) / tr;
   const long long nwg = (long long)((ntiles + 7) / 8) * 8 * slabs;  // one workgroup per (tile, slab), see the kernels
   dim3 grid((unsigned)(nwg < (1 << 20) ? nwg : (1 << 20)));
-  if (precision == LS3D_PRECISION_BF16X3) {
+  if (precision == LS3D_PRECISION_BF16X3 || precision == LS3D_PRECISION_BF16X6) {
     if ((cin % 32) || wc != 1) return LS3D_ERR_ARG;
-    switch (nt) {
-      case 1: launch_gg3<1>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld); break;
-      case 2: launch_gg3<2>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld); break;
-      case 3: launch_gg3<3>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld); break;
-      default: launch_gg3<4>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld);
+#define LS3D_GG3(NT_, PL_) launch_gg3<NT_, PL_>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld)
+    if (precision == LS3D_PRECISION_BF16X3) {
+      switch (nt) {
+        case 1: LS3D_GG3(1, 2); break;
+        case 2: LS3D_GG3(2, 2); break;
+        case 3: LS3D_GG3(3, 2); break;
+        default: LS3D_GG3(4, 2);
+      }
+    } else {
+      switch (nt) {
+        case 1: LS3D_GG3(1, 3); break;
+        case 2: LS3D_GG3(2, 3); break;
+        case 3: LS3D_GG3(3, 3); break;
+        default: LS3D_GG3(4, 3);
+      }
     }
+#undef LS3D_GG3
     LS3D_RETURN_IF_LAUNCH_FAILED();
     return LS3D_OK;
   }

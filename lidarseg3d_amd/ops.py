@@ -305,19 +305,20 @@ def rulebook_order(tbl, coords=None):
     return torch.argsort(mask, descending=_os_environ_get("LS3D_ORDER_ASC", "0") != "1").to(_i32)
 
 
-F32, BF16X3 = 0, 1
+F32, BF16X3, BF16X6 = 0, 1, 2
 _PRECISION = F32
 
 
 def set_precision(name):
-    """arithmetic of every gather-GEMM whose cin is a multiple of 32: "f32" (default; exact f32 MFMA) or "bf16x3"
-    (split-bf16: 3 bf16 MFMAs per product, ~1e-5 relative error per layer, ~5x less matrix time)"""
+    """arithmetic of the sparse convolutions whose cin is a multiple of 32: "f32" (default; exact f32 MFMA), "bf16x6" (exact
+    3-way bf16 split, 6 partial products: f32-grade results, 2.7x less matrix time) or "bf16x3" (2-way split, 3 products:
+    ~1e-5 relative error per layer, 5.3x less matrix time)"""
     global _PRECISION
-    _PRECISION = {"f32": F32, "bf16x3": BF16X3}[name]
+    _PRECISION = {"f32": F32, "bf16x3": BF16X3, "bf16x6": BF16X6}[name]
 
 
 def get_precision():
-    return "bf16x3" if _PRECISION == BF16X3 else "f32"
+    return {F32: "f32", BF16X3: "bf16x3", BF16X6: "bf16x6"}[_PRECISION]
 
 
 def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0, precision=F32):
@@ -342,7 +343,7 @@ def choose_geometry(cout, n_rows, target_blocks=None):
         # measured on MI355X (120k-pt frame): the f32 path is matrix-pipe bound and wants many small workgroups
         # (60.5 fps at >=1500 vs 53 at 256); the split-bf16 path is bound by re-gathering the input rows once per
         # column slab and wants few, wide workgroups (84.6 fps at 128-384 vs 67.5 at 1500)
-        target_blocks = _TARGET_BLOCKS or (192 if _PRECISION == BF16X3 else 2000)
+        target_blocks = _TARGET_BLOCKS or (192 if _PRECISION == BF16X3 else 512 if _PRECISION == BF16X6 else 2000)
     total = (cout + 31) // 32
     cands = []
     # measured on MI355X (profiles/): sharing gathered rows between waves (wc > 1) is slower than re-gathering them
@@ -426,7 +427,7 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     rows_hint = tbl.shape[0] if (tbl is not None and n_rows is None) else (n_rows if n_rows is not None else x.shape[0])
     # split-bf16 only where it pays and where its error budget is spent wisely: the sparse convolutions (matrix-pipe
     # bound).  Dense Linear layers (TransVFE, heads, SF-Phase) are memory-bound and stay in exact f32.
-    prec = BF16X3 if (_PRECISION == BF16X3 and cin % 32 == 0 and tbl is not None) else F32
+    prec = _PRECISION if (_PRECISION != F32 and cin % 32 == 0 and tbl is not None) else F32
     pipe = pipeline_geometry(cout, rows_hint, prec) if (_PIPELINE and tbl is not None and cin % 32 == 0 and kvol <= 32 and ln is None) else None
     if pipe is not None:
         nt, wc = pipe
@@ -435,7 +436,7 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
         if ln is not None:  # LayerNorm epilogue: the whole row must sit in one workgroup slab
             assert cout <= 128, "LayerNorm epilogue supports up to 128 columns"
             nt, wc = (cout + 31) // 32, 1
-        if prec == BF16X3:
+        if prec != F32:
             wc = 1
     wdata = w.for_nt(nt, prec)
     if tbl is not None:

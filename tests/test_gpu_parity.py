@@ -491,3 +491,36 @@ def test_unet_training_step_gpu():
     assert rel_l2(va, vc) <= 3e-2
     for k in gw_c:
         assert rel_l2(gw_a[k], gw_c[k]) <= 0.1, k
+
+
+def test_bf16x6_is_f32_grade_gemm_and_end_to_end():
+    """3-plane split-bf16 (6 partial products per f32 product): GEMM error vs float64 at the level of the exact-f32 MFMA path's
+    own rounding; SDSeg3D logits within the SAME tolerance as the f32 path (1e-3 + 2e-5 * range of the oracle)"""
+    from lidarseg3d_amd.packing import PackedWeight
+    rng = np.random.default_rng(2)
+    a = (rng.normal(size=(6000, 128)) * np.exp(rng.normal(size=(6000, 128)) * 2)).astype(np.float32)
+    b = (rng.normal(size=(128, 128)) * np.exp(rng.normal(size=(128, 128)) * 2)).astype(np.float32)
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    mag = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    ident = torch.arange(6000, dtype=torch.int32, device=DEV).unsqueeze(1).contiguous()
+    pw = PackedWeight(cu(b).reshape(1, 128, 128).contiguous(), 1, 128, 128, 128)
+    errs = {}
+    try:
+        for prec in ("f32", "bf16x6"):
+            ops.set_precision(prec)
+            out = ops.gather_gemm(cu(a), pw, tbl=ident, cout=128)
+            errs[prec] = float((np.abs(out.cpu().numpy() - want) / mag).max())
+        assert errs["bf16x6"] <= 4 * errs["f32"] + 2.0 ** -22, errs
+        cfg = synth.NUSC
+        model, sd = _model(models_cfg.sdseg3d())
+        frames = [synth.lidar_frame(20000, seed=1, **cfg)]
+        pts = np.concatenate([np.zeros((20000, 1), np.float32), frames[0]], 1)
+        model(dict(points=cu(pts), batch_size=1), return_loss=False)
+        got = model.point_head.forward_ret_dict["out_logits"].cpu()
+    finally:
+        ops.set_precision("f32")
+    wantl = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])["out_logits"]
+    scale = float(wantl.abs().max())
+    err = float((got - wantl).abs().max())
+    assert err <= 1e-3 + 2e-5 * scale, (err, scale)
+    assert float((got.argmax(1) == wantl.argmax(1)).float().mean()) >= 0.9995

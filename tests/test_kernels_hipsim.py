@@ -350,6 +350,30 @@ def test_gather_gemm_bf16x3_close_to_f32(m, k, n, nt, monkeypatch):
     assert err < plain / 20
 
 
+@pytest.mark.parametrize("m,k,n,nt", [(150, 32, 64, 2), (140, 64, 128, 4), (70, 96, 96, 3), (200, 32, 17, 1)])
+def test_gather_gemm_bf16x6_is_f32_grade(m, k, n, nt, monkeypatch):
+    """3-plane split-bf16 (6 partial products): error vs the float64 product at the level of the exact-f32 MFMA path's own
+    rounding (operands with a wide dynamic range), and the sparse path with skipped offsets"""
+    rng = np.random.default_rng(m)
+    a = (rng.normal(size=(m, k)) * np.exp(rng.normal(size=(m, k)) * 2)).astype(np.float32)
+    b = (rng.normal(size=(k, n)) * np.exp(rng.normal(size=(k, n)) * 2)).astype(np.float32)
+    monkeypatch.setattr(ops, "choose_geometry", lambda cout, rows, target_blocks=None: (nt, 1))
+    pw = PackedWeight(torch.from_numpy(b).reshape(1, k, n).contiguous(), 1, k, k, n)
+    ident = torch.arange(m, dtype=torch.int32).unsqueeze(1).contiguous()
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    mag = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)  # the scale rounding errors live on
+    errs = {}
+    try:
+        for prec in ("f32", "bf16x6"):
+            ops.set_precision(prec)
+            out = ops.gather_gemm(torch.from_numpy(a), pw, tbl=ident, cout=n)
+            errs[prec] = float((np.abs(out.numpy() - want) / mag).max())
+    finally:
+        ops.set_precision("f32")
+    assert errs["bf16x6"] <= 4 * 2.0 ** -24 * np.sqrt(k) + 3 * 2.0 ** -24, errs  # f32-grade: a few ulp of the |a||b| scale
+    assert errs["bf16x6"] <= 8 * errs["f32"] + 2.0 ** -22, errs
+
+
 def test_sparse_conv_bf16x3_vs_f32(monkeypatch):
     rng = np.random.default_rng(4)
     vin, vout, kvol, cin, cout = 200, 150, 27, 64, 64
