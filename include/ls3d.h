@@ -326,9 +326,13 @@ int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const
 /* get_points_image_feature (det3d/models/point_heads/point_seg_mseg3d_head.py:200-236): 5-D grid_sample of
  * image_features[batch,ncam,c,h,w] at points_cuv[n,4] = (valid, cam, h, w in [-1,1]), trilinear over
  * (cam,h,w), zeros padding, align_corners=True.  Rows with valid != 1 get zeros.  out[n, c] ld out_ld. */
-int ls3d_grid_gather(const float *image_features, int batch, int ncam, int c, int h, int w,
+/* channels_last != 0: image_features is [batch,ncam,h,w,c] (ls3d_nchw_to_nhwc of the reference layout): a point's c channels
+ * are contiguous per corner; same arithmetic and results. */
+int ls3d_grid_gather(const float *image_features, int batch, int ncam, int c, int h, int w, int channels_last,
                      const float *points_cuv, const float *points, int pt_stride, int n, float *out, int out_ld,
                      ls3d_stream_t stream);
+/* [planes][c][hw] -> [planes][hw][c] */
+int ls3d_nchw_to_nhwc(const float *in, int planes, int c, int hw, float *out, ls3d_stream_t stream);
 
 /* feature completion (point_seg_mseg3d_head.py:314-334) fused with the concat of :341:
  * lc[p, 0..c_l) = lidar[p], lc[p, c_l..c_l+c_c) = valid[p] ? camera[p] : pseudo[p].

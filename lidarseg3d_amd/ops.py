@@ -569,8 +569,12 @@ def grid_gather(image_features, points_cuv, points):
     b, ncam, c, h, w = image_features.shape
     n = points_cuv.shape[0]
     out = torch.empty((n, c), dtype=torch.float32, device=points.device)
-    check(_L().ls3d_grid_gather(_ptr(image_features), b, ncam, c, h, w, _ptr(points_cuv), _ptr(points), points.shape[1], n,
-                                _ptr(out), c, _stream(points)), "ls3d_grid_gather")
+    L = _L()
+    # one transpose of the camera feature maps to channels-last (44 MB for 6 x 48 x 160 x 240), then coalesced corner reads
+    nhwc = torch.empty_like(image_features)
+    check(L.ls3d_nchw_to_nhwc(_ptr(image_features), b * ncam, c, h * w, _ptr(nhwc), _stream(points)), "ls3d_nchw_to_nhwc")
+    check(L.ls3d_grid_gather(_ptr(nhwc), b, ncam, c, h, w, 1, _ptr(points_cuv), _ptr(points), points.shape[1], n,
+                             _ptr(out), c, _stream(points)), "ls3d_grid_gather")
     return out
 
 
