@@ -354,6 +354,24 @@ int ls3d_cross_attn(const float *q, const float *k, const float *v, int batch, i
                     const float *points, int pt_stride, int n, float *out, ls3d_stream_t stream);
 
 
+/* ------------------------------------------------------------------------------------------------
+ * Camera-branch input step on the GPU
+ * ---------------------------------------------------------------------------------------------- */
+
+/* points_cp (det3d/datasets/pipelines/loading.py:384-413): per camera c (in order, later cameras win):
+ *   X = cams_from_global[c] * (ref_to_global * [x y z 1]);  (u, v) = (K[c] X)_{0,1} / (K[c] X)_2    (float64)
+ *   visible iff X_z > 0 and 1 < u < im_w - 1 and 1 < v < im_h - 1
+ * points_cp[n,3] = (cam_id + 1, u, v) as float32, (-100,-100,-100) when no camera sees the point.
+ * Matrices are HOST arrays, row-major: ref_to_global[16], cams_from_global[ncam*16], intrinsics[ncam*9]; ncam <= 8. */
+int ls3d_points_cp(const float *points, int pt_stride, int xyz_col, int n, const double *ref_to_global,
+                   const double *cams_from_global, const double *intrinsics, int ncam, int im_h, int im_w,
+                   float *points_cp, ls3d_stream_t stream);
+
+/* points_cuv (det3d/datasets/pipelines/segpreprocess.py:649-671): points_cuv[n,4] = (valid = cam_id > 0,
+ * (cam_id-1)/(ncam-1)*2-1 (0 if ncam == 1), v/(res_h-1)*2-1, u/(res_w-1)*2-1), float32 in that operation order;
+ * points_cp is expected in the coordinates of the res_h x res_w feature-map input. */
+int ls3d_points_cuv(const float *points_cp, int n, int ncam, int res_h, int res_w, float *points_cuv, ls3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

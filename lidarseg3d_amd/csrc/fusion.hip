@@ -325,3 +325,88 @@ extern "C" int ls3d_cross_attn(const float *q, const float *k, const float *v, i
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// GPU-side input step of the camera branch
+// ------------------------------------------------------------------------------------------------------------
+#define LS3D_MAX_CAMS 8
+struct CamSet {
+  double ref_to_global[16];
+  double cam_from_global[LS3D_MAX_CAMS][16];
+  double intrinsic[LS3D_MAX_CAMS][9];
+  int ncam, im_h, im_w;
+};
+
+// points_cp (det3d/datasets/pipelines/loading.py:384-413): lidar -> global -> camera -> pixel in float64 like the numpy code,
+// stored as float32 [cam_id (1-based), u, v]; a point seen by several cameras keeps the LAST one; unseen: (-100,-100,-100).
+__global__ __launch_bounds__(256) void k_points_cp(const float *points, int pt_stride, int xyz_col, int n, CamSet cs, float *cp) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const float *pt = points + (size_t)p * pt_stride + xyz_col;
+    const double x = (double)pt[0], y = (double)pt[1], z = (double)pt[2];
+    double g[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double *m = cs.ref_to_global + 4 * r;
+      g[r] = ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+    }
+    float cam = -100.0f, u = -100.0f, v = -100.0f;
+    for (int c = 0; c < cs.ncam; ++c) {
+      double q[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double *m = cs.cam_from_global[c] + 4 * r;
+        q[r] = ((m[0] * g[0] + m[1] * g[1]) + m[2] * g[2]) + m[3] * g[3];
+      }
+      const double *K = cs.intrinsic[c];
+      double w[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) w[r] = (K[3 * r] * q[0] + K[3 * r + 1] * q[1]) + K[3 * r + 2] * q[2];  // view_points: viewpad * [q;1]
+      const double pu = w[0] / w[2], pv = w[1] / w[2];
+      if (q[2] > 0.0 && pu > 1.0 && pu < (double)(cs.im_w - 1) && pv > 1.0 && pv < (double)(cs.im_h - 1)) {
+        u = (float)pu; v = (float)pv; cam = (float)c + 1.0f;
+      }
+    }
+    float *o = cp + 3 * (size_t)p;
+    o[0] = cam; o[1] = u; o[2] = v;
+  }
+}
+
+// points_cuv (det3d/datasets/pipelines/segpreprocess.py:649-671): [valid, cam, v, u] normalised to [-1, 1] for grid_sample,
+// float32 arithmetic in the reference's operation order
+__global__ __launch_bounds__(256) void k_points_cuv(const float *cp, int n, int ncam, int res_h, int res_w, float *cuv) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const float c = cp[3 * (size_t)p], u = cp[3 * (size_t)p + 1], v = cp[3 * (size_t)p + 2];
+    float *o = cuv + 4 * (size_t)p;
+    o[0] = c > 0.0f ? 1.0f : 0.0f;
+    o[1] = ncam > 1 ? (c - 1.0f) / (float)(ncam - 1) * 2.0f - 1.0f : 0.0f;
+    o[2] = v / (float)(res_h - 1) * 2.0f - 1.0f;
+    o[3] = u / (float)(res_w - 1) * 2.0f - 1.0f;
+  }
+}
+
+extern "C" int ls3d_points_cp(const float *points, int pt_stride, int xyz_col, int n, const double *ref_to_global, const double *cams_from_global,
+                              const double *intrinsics, int ncam, int im_h, int im_w, float *points_cp, ls3d_stream_t stream) {
+  if (!points || !ref_to_global || !cams_from_global || !intrinsics || !points_cp || n < 0 || pt_stride < xyz_col + 3 || xyz_col < 0 ||
+      im_h < 3 || im_w < 3)
+    return LS3D_ERR_ARG;
+  if (ncam < 1 || ncam > LS3D_MAX_CAMS) return LS3D_ERR_UNSUPPORTED;
+  if (n == 0) return LS3D_OK;
+  CamSet cs;
+  for (int i = 0; i < 16; ++i) cs.ref_to_global[i] = ref_to_global[i];
+  for (int c = 0; c < ncam; ++c) {
+    for (int i = 0; i < 16; ++i) cs.cam_from_global[c][i] = cams_from_global[16 * c + i];
+    for (int i = 0; i < 9; ++i) cs.intrinsic[c][i] = intrinsics[9 * c + i];
+  }
+  cs.ncam = ncam; cs.im_h = im_h; cs.im_w = im_w;
+  hipLaunchKernelGGL(k_points_cp, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, points, pt_stride, xyz_col, n, cs, points_cp);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_points_cuv(const float *points_cp, int n, int ncam, int res_h, int res_w, float *points_cuv, ls3d_stream_t stream) {
+  if (!points_cp || !points_cuv || n < 0 || ncam < 1 || res_h < 2 || res_w < 2) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  hipLaunchKernelGGL(k_points_cuv, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, points_cp, n, ncam, res_h, res_w, points_cuv);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

@@ -597,10 +597,52 @@ def sfam(feats, logits, vx_off, batch, max_frame_voxels, c=None):
     return emb
 
 
+def camera_sfam(feats, probs, batch_size):
+    """CameraSemanticFeatureAggregationModule (fcn_mseg3d_head.py:23-51): feats [B*ncam, C, h, w], probs [B*ncam, cls, h, w]
+    -> semantic embeddings [B, C, cls, 1].  The maps go channels-last once; then it is the LiDAR SFAM kernels with
+    "voxels" = the ncam*h*w pixels of a frame."""
+    bn, c, h, w = feats.shape
+    cls = probs.shape[1]
+    rows = (bn // batch_size) * h * w
+    L = _L()
+    f = torch.empty((bn * h * w, c), dtype=torch.float32, device=feats.device)
+    p = torch.empty((bn * h * w, cls), dtype=torch.float32, device=feats.device)
+    check(L.ls3d_nchw_to_nhwc(_ptr(feats), bn, c, h * w, _ptr(f), _stream(feats)), "ls3d_nchw_to_nhwc")
+    check(L.ls3d_nchw_to_nhwc(_ptr(probs), bn, cls, h * w, _ptr(p), _stream(feats)), "ls3d_nchw_to_nhwc")
+    off = torch.arange(0, (batch_size + 1) * rows, rows, dtype=_i32, device=feats.device)
+    emb = sfam(f, p, off, batch_size, rows)  # [B, cls, C]
+    return emb.permute(0, 2, 1).contiguous().unsqueeze(3)
+
+
 def cross_attn(q, k, v, batch, heads, points):
     n, e = q.shape
     L = k.numel() // (batch * e)
     out = torch.empty((n, e), dtype=torch.float32, device=q.device)
     check(_L().ls3d_cross_attn(_ptr(q), _ptr(k), _ptr(v), batch, heads, e, L, _ptr(points), points.shape[1], n, _ptr(out),
                                _stream(q)), "ls3d_cross_attn")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- camera-branch input step
+def points_cp(points, ref_to_global, cams_from_global, intrinsics, im_shape=(900, 1600), xyz_col=0):
+    """loading.py:384-413 on the GPU: points [N, >=3] (xyz at xyz_col), ref_to_global [4,4], cams_from_global [ncam,4,4],
+    intrinsics [ncam,3,3] (numpy float64, host) -> points_cp [N,3] = (cam_id + 1, u, v) or -100s"""
+    n = points.shape[0]
+    r2g = np.ascontiguousarray(ref_to_global, np.float64)
+    c2g = np.ascontiguousarray(cams_from_global, np.float64)
+    K = np.ascontiguousarray(intrinsics, np.float64)
+    ncam = c2g.shape[0]
+    out = torch.empty((n, 3), dtype=torch.float32, device=points.device)
+    dp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    check(_L().ls3d_points_cp(_ptr(points), points.shape[1], xyz_col, n, dp(r2g), dp(c2g), dp(K), ncam, int(im_shape[0]), int(im_shape[1]),
+                              _ptr(out), _stream(points)), "ls3d_points_cp")
+    return out
+
+
+def points_cuv(points_cp_, ncam, res_shape):
+    """segpreprocess.py:649-671: points_cp [N,3] in feature-map-input pixel coordinates -> points_cuv [N,4]"""
+    n = points_cp_.shape[0]
+    out = torch.empty((n, 4), dtype=torch.float32, device=points_cp_.device)
+    check(_L().ls3d_points_cuv(_ptr(points_cp_), n, int(ncam), int(res_shape[0]), int(res_shape[1]), _ptr(out), _stream(points_cp_)),
+          "ls3d_points_cuv")
     return out

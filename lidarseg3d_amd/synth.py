@@ -80,3 +80,37 @@ def camera_inputs(n, seed=0, ncam=6, c_img=48, h=160, w=240, num_class=17, p_val
     cuv = np.stack([valid, cam_n, hw[:, 0], hw[:, 1]], axis=1).astype(np.float32)
     cuv[valid == 0, 1:] = 0.0
     return img, emb, cuv
+
+
+def camera_rig(ncam=6, seed=0, im_shape=(900, 1600)):
+    """nuScenes-like ring of pinhole cameras around the ego vehicle: (ref_to_global [4,4], cams_from_global [ncam,4,4],
+    intrinsics [ncam,3,3]) float64"""
+    rng = np.random.default_rng(seed)
+
+    def rot(axis, a):
+        c, s_ = np.cos(a), np.sin(a)
+        m = np.eye(3)
+        i, j = [(1, 2), (0, 2), (0, 1)][axis]
+        m[i, i], m[i, j], m[j, i], m[j, j] = c, -s_, s_, c
+        return m
+    yaw0 = rng.uniform(-np.pi, np.pi)
+    ref_to_global = np.eye(4)
+    ref_to_global[:3, :3] = rot(2, yaw0)
+    ref_to_global[:3, 3] = rng.uniform(-500, 500, 3) * np.array([1, 1, 0.01])
+    global_from_ref = ref_to_global
+    cams, Ks = [], []
+    for c in range(ncam):
+        yaw = 2 * np.pi * c / ncam + rng.normal() * 0.02
+        # camera frame: z forward, x right, y down; the camera looks along (cos yaw, sin yaw, 0) in the ego frame
+        fwd = np.array([np.cos(yaw), np.sin(yaw), 0.0])
+        right = np.array([np.sin(yaw), -np.cos(yaw), 0.0])
+        down = np.array([0.0, 0.0, -1.0])
+        R_ego_from_cam = np.stack([right, down, fwd], axis=1)
+        t = np.array([1.5 * np.cos(yaw), 1.5 * np.sin(yaw), 1.6])
+        ego_from_cam = np.eye(4)
+        ego_from_cam[:3, :3], ego_from_cam[:3, 3] = R_ego_from_cam, t
+        cam_from_global = np.linalg.inv(global_from_ref.dot(ego_from_cam))
+        cams.append(cam_from_global)
+        f = 1266.0 + rng.normal() * 5
+        Ks.append(np.array([[f, 0.0, im_shape[1] / 2 + rng.normal() * 5], [0.0, f, im_shape[0] / 2 + rng.normal() * 5], [0.0, 0.0, 1.0]]))
+    return ref_to_global, np.stack(cams), np.stack(Ks)

@@ -327,6 +327,38 @@ def main():
          points=pts2.numpy(), cam_seed=3, cam_hw=np.int64([40, 60]), seed=37,  # camera inputs: synth.camera_inputs(seed)
          out_logits=bd["out_logits"].numpy(), voxel_logits=head.forward_ret_dict["voxel_logits"].numpy())
 
+    # ---- camera SFAM (img_heads/fcn_mseg3d_head.py:17-51): the class is plain torch; its file's other imports are stubbed
+    for name in ("mmcv", "mmcv.cnn", "det3d.models.builder", "det3d.models.img_heads", "det3d.models.img_heads.decode_head",
+                 "det3d.ops.mmseg_ops", "det3d.models.img_heads.sc_conv"):
+        if name not in sys.modules:
+            _pkg(name)
+    sys.modules["mmcv.cnn"].ConvModule = object
+    sys.modules["det3d.models.builder"].IMG_HEADS = types.SimpleNamespace(register_module=lambda c: c)
+    sys.modules["det3d.models.img_heads.decode_head"].BaseDecodeHead = torch.nn.Module
+    sys.modules["det3d.ops.mmseg_ops"].resize = None
+    sys.modules["det3d.models.img_heads.sc_conv"].SCBottleneck = object
+    fh = _load("det3d.models.img_heads.fcn_mseg3d_head", "det3d/models/img_heads/fcn_mseg3d_head.py")
+    rng = np.random.default_rng(41)
+    cf = torch.from_numpy(rng.normal(size=(2 * 6, 48, 10, 15)).astype(np.float32))
+    cp = torch.from_numpy((rng.normal(size=(2 * 6, 17, 10, 15)) * 3).astype(np.float32))
+    with torch.no_grad():
+        cemb = fh.CameraSemanticFeatureAggregationModule()(cf, cp, 2)
+    save("camera_sfam.npz", feats=cf.numpy(), probs=cp.numpy(), batch_size=2, emb=cemb.numpy())
+
+    # ---- view_points (datasets/pipelines/loading.py:67-103), the projection helper under points_cp
+    for name in ("turtle", "pycocotools", "pycocotools.mask", "cv2", "det3d.core.box_np_ops", "det3d.datasets", "det3d.datasets.pipelines",
+                 "det3d.datasets.registry"):
+        if name not in sys.modules:
+            _pkg(name)
+    sys.modules["turtle"].shape = None
+    sys.modules["det3d.core"].box_np_ops = sys.modules["det3d.core.box_np_ops"]
+    sys.modules["det3d.datasets.registry"].PIPELINES = types.SimpleNamespace(register_module=lambda c: c)
+    ld = _load("det3d.datasets.pipelines.loading", "det3d/datasets/pipelines/loading.py")
+    rng = np.random.default_rng(43)
+    pc = rng.normal(size=(3, 500)) * np.array([[20.0], [20.0], [30.0]])
+    K = np.array([[1266.4, 0.0, 816.3], [0.0, 1266.4, 491.5], [0.0, 0.0, 1.0]])
+    save("view_points.npz", points=pc, view=K, out=ld.view_points(pc, K, normalize=True))
+
     with open(os.path.join(HERE, "manifests.json"), "w") as f:
         json.dump({k: {n: list(s) for n, s in v.items()} for k, v in manifests.items()}, f, indent=0, sort_keys=True)
     print("wrote manifests.json")

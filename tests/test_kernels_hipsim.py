@@ -483,3 +483,30 @@ def test_unet_training_forward_backward_vs_autograd(monkeypatch):
     assert len(convs) == 36 and set(gw_a) == set(gw_b)  # conv_out feeds nothing the loss sees
     for k in gw_b:
         np.testing.assert_allclose(gw_a[k].numpy(), gw_b[k].numpy(), rtol=0, atol=3e-4 * max(1.0, float(gw_b[k].abs().max())), err_msg=k)
+
+
+def test_camera_sfam_vs_reference():
+    from lidarseg3d_amd import img_heads
+    g = golden("camera_sfam.npz")
+    got = img_heads.CameraSemanticFeatureAggregationModule()(torch.from_numpy(g["feats"]), torch.from_numpy(g["probs"]), int(g["batch_size"]))
+    assert tuple(got.shape) == tuple(g["emb"].shape)
+    np.testing.assert_allclose(got.numpy(), g["emb"], rtol=0, atol=2e-5)
+
+
+def test_points_cp_and_cuv_vs_oracle():
+    """GPU-side camera projection of the points (loading.py:384-413) and grid_sample normalisation (segpreprocess.py:649-671)"""
+    cfg = synth.NUSC
+    pts = synth.lidar_frame(6000, seed=9, **cfg)
+    r2g, c2g, K = synth.camera_rig(6, seed=2)
+    want = orc.points_cp(pts, r2g, c2g, K)
+    got = ops.points_cp(torch.from_numpy(pts), r2g, c2g, K).numpy()
+    same_cam = got[:, 0] == want[:, 0]
+    assert same_cam.mean() >= 0.9995  # a pixel within 1e-9 of the 1-pixel margin may flip (different dot-product order)
+    assert (want[:, 0] > 0).mean() > 0.3  # the rig sees a good part of the sweep
+    np.testing.assert_allclose(got[same_cam], want[same_cam], rtol=0, atol=2e-4)
+    cuv_want = orc.points_cuv(want, 6, (640, 960))
+    want = np.ascontiguousarray(want)  # the oracle returns a fancy-indexed view
+    cuv_got = ops.points_cuv(torch.from_numpy(want), 6, (640, 960)).numpy()
+    np.testing.assert_array_equal(cuv_got, cuv_want)
+    one = ops.points_cuv(torch.from_numpy(want), 1, (640, 960)).numpy()
+    np.testing.assert_array_equal(one, orc.points_cuv(want, 1, (640, 960)))

@@ -82,3 +82,15 @@ def test_mseg3d_head_matches_reference():
                               pts, torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), 2)
     np.testing.assert_allclose(vl.numpy(), g["voxel_logits"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(out.numpy(), g["out_logits"], rtol=0, atol=2e-4)
+
+
+def test_camera_sfam_vs_reference():
+    """oracle restatement of CameraSemanticFeatureAggregationModule vs the reference class's output"""
+    g = golden("camera_sfam.npz")
+    got = orc.camera_sfam(torch.from_numpy(g["feats"]), torch.from_numpy(g["probs"]), int(g["batch_size"]))
+    np.testing.assert_allclose(got.numpy(), g["emb"], rtol=0, atol=1e-6)
+
+
+def test_view_points_vs_reference():
+    g = golden("view_points.npz")
+    np.testing.assert_array_equal(orc.view_points(g["points"], g["view"], normalize=True), g["out"])
