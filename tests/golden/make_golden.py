@@ -116,7 +116,7 @@ def make_spconv_shim():
             ks = orc._triple(kernel_size)
             self.ks, self.stride, self.padding, self.key = ks, stride, padding, indice_key
             self.weight = nn.Parameter(torch.zeros(*ks, in_channels, out_channels))
-            assert not bias
+            self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
         def forward(self, x):
             c = x.indices.numpy()
@@ -124,14 +124,17 @@ def make_spconv_shim():
                 if self.key not in x.indice_dict:
                     x.indice_dict[self.key] = ("subm", orc.subm_rulebook(c, x.spatial_shape, self.ks))
                 nbr = x.indice_dict[self.key][1]
-                return x.like(orc.spconv_fwd(x.features, self.weight, nbr))
+                return x.like(self._b(orc.spconv_fwd(x.features, self.weight, nbr)))
             if self.kind == "conv":
                 oc, oshape, nbr = orc.conv_rulebook(c, x.spatial_shape, self.ks, self.stride, self.padding)
                 x.indice_dict[self.key] = ("conv", nbr, x.indices, x.spatial_shape)
-                return x.like(orc.spconv_fwd(x.features, self.weight, nbr), torch.from_numpy(oc), oshape)
+                return x.like(self._b(orc.spconv_fwd(x.features, self.weight, nbr)), torch.from_numpy(oc), oshape)
             _, nbr, in_idx, in_shape = x.indice_dict[self.key]
             f = orc.spconv_fwd(x.features, self.weight, nbr, inverse=True, n_out=in_idx.shape[0])
-            return x.like(f, in_idx, in_shape)
+            return x.like(self._b(f), in_idx, in_shape)
+
+        def _b(self, f):
+            return f if self.bias is None else f + self.bias
 
     class SubMConv3d(_Conv):
         kind = "subm"
