@@ -56,6 +56,16 @@ class SingleStageDetector(nn.Module):
         load_checkpoint(self, pretrained, strict=False)
 
 
+def _coords_ready(coords):
+    """event on the current stream marking "voxel coordinates are final": the backbone builds its rulebooks on a side stream
+    from this point on, concurrently with the reader (extra batch_dict key, not in the reference)"""
+    if not coords.is_cuda:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(coords.device))
+    return ev
+
+
 @DETECTORS.register_module
 class SegNet(SingleStageDetector):
     def __init__(self, reader, backbone, point_head, neck=None, bbox_head=None, train_cfg=None, test_cfg=None,
@@ -69,6 +79,7 @@ class SegNet(SingleStageDetector):
         voxels, coords, num, batch_size, shape = _voxel_inputs(example, self.voxel_generator)
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
                     points=example["points"][:, 0:4])
+        data["voxel_coords_ready"] = _coords_ready(coords)
         data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
         return self.backbone(data)
 
@@ -121,6 +132,7 @@ class SegMSeg3DNet(SingleStageDetector):
             image_features, cam_emb = example["image_features"], example["camera_semantic_embeddings"]
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
                     points=example["points"][:, 0:4])
+        data["voxel_coords_ready"] = _coords_ready(coords)
         data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
         data = self.backbone(data)
         data.update(points_cuv=example["points_cuv"], image_features=image_features,

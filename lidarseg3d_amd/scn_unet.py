@@ -57,6 +57,53 @@ class SparseBasicBlock(spconv.SparseModule):
         return conv_bn_act(self.conv2, self.bn2, out, relu=True, res_pre=identity)
 
 
+_SIDE_STREAMS = {}
+
+
+class _GeometryStream(object):
+    """`with _GeometryStream(t):` runs the body on a per-device side stream that starts after the current stream's work so far;
+    on exit the current stream waits for it.  hand_over() tells the caching allocator that tensors created inside are used
+    on the main stream from now on.  A no-op for CPU tensors (tests/hipsim) and with LS3D_OVERLAP=0."""
+
+    def __init__(self, like, ready=None):
+        import os
+        self.ready = ready
+        self.on = like.is_cuda and os.environ.get("LS3D_OVERLAP", "1") != "0"
+        self.dev = like.device
+
+    def __enter__(self):
+        if self.on:
+            self.main = torch.cuda.current_stream(self.dev)
+            self.side = _SIDE_STREAMS.get(self.dev)
+            if self.side is None:
+                self.side = _SIDE_STREAMS[self.dev] = torch.cuda.Stream(self.dev)
+            if self.ready is not None:
+                self.side.wait_event(self.ready)  # only the coordinates, not the reader that was launched after them
+            else:
+                self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def hand_over(self, rulebooks):
+        if not self.on:
+            return
+        for rb in rulebooks:
+            for name in ("tbl", "tbl_inv", "in_indices", "out_indices"):
+                t = getattr(rb, name, None)
+                if t is not None:
+                    t.record_stream(self.main)
+            for o in (getattr(rb, "_orders", None) or {}).values():
+                if o is not None:
+                    o.record_stream(self.main)
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+            self.main.wait_stream(self.side)
+        return False
+
+
 @BACKBONES.register_module
 class UNetSCN3D(nn.Module):
     def __init__(self, num_input_features=128, name="UNetSCN3D", voxel_size=[], point_cloud_range=[], model_cfg={},
@@ -154,16 +201,21 @@ class UNetSCN3D(nn.Module):
         batch_size = batch_dict["batch_size"]
         sparse_shape = np.array(batch_dict["input_shape"][::-1]) + [1, 0, 0]
         x = spconv.SparseConvTensor(voxel_features, voxel_coords.int().contiguous(), sparse_shape, batch_size)
-        # the four strided rulebooks of the encoder in one go (one host sync instead of four)
-        strided = [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
-        spconv.prebuild_conv_rulebooks(x, strided)
-        # ... then every SubM rulebook and, with one batched sort, every mask-sorted row order: after this point the conv
-        # stack is only gather-GEMM launches
-        for key, src in (("subm1", None), ("subm2", "spconv2"), ("subm3", "spconv3"), ("subm4", "spconv4")):
-            rb = x.find_indice_pair(src)
-            x.indice_dict[key] = spconv.subm_rulebook(x.indices if rb is None else rb.out_indices,
-                                                      x.spatial_shape if rb is None else rb.out_shape, 3)
-        spconv.prebuild_orders(x, self.modules())
+        # All geometry of the frame up front.  It depends on the voxel COORDINATES only, so it runs on a side stream while the
+        # main stream is still busy with the reader that produces voxel_features (k_transvfe: one LDS-bound workgroup per CU,
+        # the small latency-bound rulebook kernels fit beside it); the conv stack then waits for the side stream.
+        with _GeometryStream(x.indices, batch_dict.get("voxel_coords_ready")) as gs:
+            # the four strided rulebooks of the encoder in one go (one host sync instead of four)
+            strided = [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
+            spconv.prebuild_conv_rulebooks(x, strided)
+            # ... then every SubM rulebook and, with one batched sort, every mask-sorted row order: after this point the conv
+            # stack is only gather-GEMM launches
+            for key, src in (("subm1", None), ("subm2", "spconv2"), ("subm3", "spconv3"), ("subm4", "spconv4")):
+                rb = x.find_indice_pair(src)
+                x.indice_dict[key] = spconv.subm_rulebook(x.indices if rb is None else rb.out_indices,
+                                                          x.spatial_shape if rb is None else rb.out_shape, 3)
+            spconv.prebuild_orders(x, self.modules())
+            gs.hand_over(x.indice_dict.values())
         x = self.conv_input(x)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)
