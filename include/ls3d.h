@@ -316,8 +316,13 @@ int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const
                          int max_frame_points, const int32_t *coords, const float *centers,
                          int n_voxels, const int32_t *n_voxels_dev, const int32_t *vx_off /*[batch+1] dev*/, int batch,
                          const float vs_host[3], const float lo_host[3], const int32_t grid_xyz_host[3], const float *feat,
-                         int feat_ld, int c, float *out, int out_ld, int32_t *idx_out, void *workspace,
-                         size_t workspace_bytes, ls3d_stream_t stream);
+                         int feat_ld, int c, float *out, int out_ld, int32_t *idx_out, float *weight_out /*[n,3] or NULL*/,
+                         void *workspace, size_t workspace_bytes, ls3d_stream_t stream);
+/* feat == NULL: search only (idx_out and weight_out required) - the neighbour search depends on geometry alone, so it can run
+ * on another stream while the features are still being computed; ls3d_interpolate_rows then finishes the job:
+ * out[p] = sum_j weight[p][j] * feat[vx_off[frame(p)] + idx[p][j]] (same arithmetic as the fused call). */
+int ls3d_interpolate_rows(const float *feat, int feat_ld, int c, const int32_t *idx, const float *weight, const float *points,
+                          int pt_stride, const int32_t *vx_off, int n_points, float *out, int out_ld, ls3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LiDAR-camera fusion (MSeg3D point head)

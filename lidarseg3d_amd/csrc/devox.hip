@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_pt_fill(int n, const int32_t *cell_of, 
 // walking through empty space costs LDS bit tests only.
 __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_stride, const int32_t *pt_off, const int32_t *perm, CGeom g,
                                                    const int32_t *start, const float4 *sorted, const uint32_t *occ, const int32_t *vx_off,
-                                                   const float *feat, int feat_ld, int C, float *out, int out_ld, int32_t *idx_out,
+                                                   const float *feat, int feat_ld, int C, float *out, int out_ld, int32_t *idx_out, float *w_out,
                                                    int32_t *hard_list, int32_t *hard_count) {
   HIP_DYNAMIC_SHARED(uint32_t, s_occ)
   __shared__ int s_idx[256 * 3];
@@ -365,9 +365,13 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
     int32_t *q = idx_out + (size_t)i * 3;
     q[0] = t.i0; q[1] = t.i1; q[2] = t.i2;
   }
+  if (active && w_out && s_pt[threadIdx.x] >= 0) {
+    float *q = w_out + (size_t)i * 3;
+    q[0] = s_w[threadIdx.x * 3]; q[1] = s_w[threadIdx.x * 3 + 1]; q[2] = s_w[threadIdx.x * 3 + 2];
+  }
   __syncthreads();
   const int cnt = min(256, p1 - first);
-  const int c4n = C >> 2;
+  const int c4n = feat ? (C >> 2) : 0;  // search only (feat == NULL): indices + weights, interpolation by ls3d_interpolate_rows
   const int v0 = vx_off[frame], m = vx_off[frame + 1] - v0;
   for (int e = threadIdx.x; e < cnt * c4n; e += 256) {
     const int p = e / c4n, c4 = e % c4n;
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
 // in lexicographic (distance, index) order, then the interpolated row.
 __global__ __launch_bounds__(256) void k_devox_hard(const float *points, int pt_stride, const int32_t *hard_list, const int32_t *hard_count,
                                                    const float *centers, const int32_t *vx_off, const float *feat, int feat_ld, int C,
-                                                   float *out, int out_ld, int32_t *idx_out) {
+                                                   float *out, int out_ld, int32_t *idx_out, float *w_out) {
   __shared__ float s_d[4 * 3];
   __shared__ int s_i[4 * 3];
   __shared__ float s_w3[3];
@@ -439,9 +443,10 @@ __global__ __launch_bounds__(256) void k_devox_hard(const float *points, int pt_
       s_w3[0] = __fdiv_rn(r0, norm); s_w3[1] = __fdiv_rn(r1, norm); s_w3[2] = __fdiv_rn(r2, norm);
       s_i3[0] = b.i0; s_i3[1] = b.i1; s_i3[2] = b.i2;
       if (idx_out) { idx_out[(size_t)i * 3] = b.i0; idx_out[(size_t)i * 3 + 1] = b.i1; idx_out[(size_t)i * 3 + 2] = b.i2; }
+      if (w_out) { w_out[(size_t)i * 3] = s_w3[0]; w_out[(size_t)i * 3 + 1] = s_w3[1]; w_out[(size_t)i * 3 + 2] = s_w3[2]; }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < (feat ? C : 0); c += 256) {
       float o = 0.0f;
       if (m > 0) {
         const float a = feat[(size_t)(v0 + s_i3[0]) * feat_ld + c], b2 = feat[(size_t)(v0 + s_i3[1]) * feat_ld + c],
@@ -481,13 +486,13 @@ static size_t dv_points_ws(int n_points, long long ncell) { return 3 * dv_align(
 extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const int32_t *pt_off, int max_frame_points,
                                     const int32_t *coords, const float *centers, int n_voxels, const int32_t *n_voxels_dev,
                                     const int32_t *vx_off, int batch, const float vs[3], const float lo[3], const int32_t grid_xyz[3],
-                                    const float *feat, int feat_ld, int c, float *out, int out_ld, int32_t *idx_out, void *workspace,
-                                    size_t workspace_bytes, ls3d_stream_t stream_) {
+                                    const float *feat, int feat_ld, int c, float *out, int out_ld, int32_t *idx_out, float *w_out,
+                                    void *workspace, size_t workspace_bytes, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!points || !pt_off || !coords || !centers || !vx_off || !vs || !lo || !grid_xyz || !feat || !out || !workspace || batch < 1 ||
-      pt_stride < 4)
+  if (!points || !pt_off || !coords || !centers || !vx_off || !vs || !lo || !grid_xyz || !workspace || batch < 1 || pt_stride < 4)
     return LS3D_ERR_ARG;
-  if ((c % 4) || (feat_ld % 4) || (out_ld % 4) || feat_ld < c || out_ld < c || n_voxels < 1) return LS3D_ERR_ARG;
+  if (feat ? (!out || (c % 4) || (feat_ld % 4) || (out_ld % 4) || feat_ld < c || out_ld < c) : (!idx_out || !w_out)) return LS3D_ERR_ARG;
+  if (n_voxels < 1) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_devoxelize_grid_workspace_bytes(n_points, n_voxels, batch, grid_xyz)) return LS3D_ERR_WORKSPACE;
   if (n_points == 0 || max_frame_points == 0) return LS3D_OK;
   CGeom g;
@@ -526,10 +531,46 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   hipLaunchKernelGGL(k_cg_fill, ls3d_grid(n_voxels), dim3(256), 0, stream, centers, n_voxels, n_voxels_dev, vx_off, (const int32_t *)cell_of,
                      (const int32_t *)start, cursor, sorted);
   hipLaunchKernelGGL(k_devox_grid, dim3((max_frame_points + 255) / 256, batch), dim3(256), (size_t)g.wpf * 4, stream, points, pt_stride, pt_off,
-                     (const int32_t *)perm, g, (const int32_t *)start, (const float4 *)sorted, (const uint32_t *)occ, vx_off, feat, feat_ld, c, out, out_ld, idx_out,
+                     (const int32_t *)perm, g, (const int32_t *)start, (const float4 *)sorted, (const uint32_t *)occ, vx_off, feat, feat_ld, c, out, out_ld, idx_out, w_out,
                      hard_list, hard_count);
   hipLaunchKernelGGL(k_devox_hard, dim3(n_points < 2048 ? (n_points > 0 ? n_points : 1) : 2048), dim3(256), 0, stream, points, pt_stride,
-                     (const int32_t *)hard_list, (const int32_t *)hard_count, centers, vx_off, feat, feat_ld, c, out, out_ld, idx_out);
+                     (const int32_t *)hard_list, (const int32_t *)hard_count, centers, vx_off, feat, feat_ld, c, out, out_ld, idx_out, w_out);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+// out[p] = sum_j w[p][j] * feat[vx_off[frame(p)] + idx[p][j]]: the interpolation half of ls3d_devoxelize_grid when the search ran
+// earlier (feat == NULL there); same arithmetic as the fused kernels
+__global__ __launch_bounds__(256) void k_interp_rows(const float *feat, int feat_ld, int C, const int32_t *idx, const float *w, const float *points,
+                                                    int pt_stride, const int32_t *vx_off, int n, float *out, int out_ld) {
+  const int c4n = C >> 2;
+  const long long work = (long long)n * c4n;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(t / c4n), c4 = (int)(t % c4n);
+    const int f = (int)points[(size_t)p * pt_stride];
+    const int v0 = vx_off[f], m = vx_off[f + 1] - v0;
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (m > 0) {
+      const float w0 = w[(size_t)p * 3], w1 = w[(size_t)p * 3 + 1], w2 = w[(size_t)p * 3 + 2];
+      const float4 a = *(const float4 *)(feat + (size_t)(v0 + idx[(size_t)p * 3]) * feat_ld + c4 * 4);
+      const float4 b = *(const float4 *)(feat + (size_t)(v0 + idx[(size_t)p * 3 + 1]) * feat_ld + c4 * 4);
+      const float4 c = *(const float4 *)(feat + (size_t)(v0 + idx[(size_t)p * 3 + 2]) * feat_ld + c4 * 4);
+      o.x = fmaf(w2, c.x, fmaf(w1, b.x, w0 * a.x));
+      o.y = fmaf(w2, c.y, fmaf(w1, b.y, w0 * a.y));
+      o.z = fmaf(w2, c.z, fmaf(w1, b.z, w0 * a.z));
+      o.w = fmaf(w2, c.w, fmaf(w1, b.w, w0 * a.w));
+    }
+    *(float4 *)(out + (size_t)p * out_ld + c4 * 4) = o;
+  }
+}
+
+extern "C" int ls3d_interpolate_rows(const float *feat, int feat_ld, int c, const int32_t *idx, const float *weight, const float *points,
+                                     int pt_stride, const int32_t *vx_off, int n_points, float *out, int out_ld, ls3d_stream_t stream) {
+  if (!feat || !idx || !weight || !points || !vx_off || !out || n_points < 0 || pt_stride < 1) return LS3D_ERR_ARG;
+  if ((c % 4) || (feat_ld % 4) || (out_ld % 4) || feat_ld < c || out_ld < c) return LS3D_ERR_ARG;
+  if (n_points == 0) return LS3D_OK;
+  hipLaunchKernelGGL(k_interp_rows, ls3d_grid((long long)n_points * (c / 4)), dim3(256), 0, (hipStream_t)stream, feat, feat_ld, c, idx, weight, points,
+                     pt_stride, vx_off, n_points, out, out_ld);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

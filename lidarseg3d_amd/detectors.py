@@ -78,7 +78,7 @@ class SegNet(SingleStageDetector):
     def forward_features(self, example):
         voxels, coords, num, batch_size, shape = _voxel_inputs(example, self.voxel_generator)
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
-                    points=example["points"][:, 0:4])
+                    points=example["points"][:, 0:4].contiguous())
         data["voxel_coords_ready"] = _coords_ready(coords)
         data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
         return self.backbone(data)
@@ -131,7 +131,7 @@ class SegMSeg3DNet(SingleStageDetector):
         else:
             image_features, cam_emb = example["image_features"], example["camera_semantic_embeddings"]
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
-                    points=example["points"][:, 0:4])
+                    points=example["points"][:, 0:4].contiguous())
         data["voxel_coords_ready"] = _coords_ready(coords)
         data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
         data = self.backbone(data)

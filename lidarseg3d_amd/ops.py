@@ -549,19 +549,41 @@ def devoxelize(points, pt_off, centers, vx_off, batch, max_frame_points, feat, c
 
 
 def devoxelize_grid(points, pt_off, coords, centers, vx_off, batch, voxel_size, pc_range, feat, c=None, return_idx=False):
-    """grid-accelerated exact 3-NN devoxelization (known points = voxel centres on the voxel lattice)"""
+    """grid-accelerated exact 3-NN devoxelization (known points = voxel centres on the voxel lattice).
+    feat=None: the neighbour search only -> (idx [n,3] int32 frame-local, weight [n,3]); finish with interpolate_rows."""
     n = points.shape[0]
-    c = c or feat.shape[1]
+    search_only = feat is None
     _, grid = make_grid(voxel_size, pc_range)
-    out = torch.empty((n, c), dtype=torch.float32, device=points.device)
-    idx = torch.empty((n, 3), dtype=_i32, device=points.device) if return_idx else None
+    dev = points.device
+    if search_only:
+        out, c, feat_ld = None, 0, 0
+        idx = torch.empty((n, 3), dtype=_i32, device=dev)
+        w = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    else:
+        c = c or feat.shape[1]
+        feat_ld = feat.shape[1]
+        out = torch.empty((n, c), dtype=torch.float32, device=dev)
+        idx = torch.empty((n, 3), dtype=_i32, device=dev) if return_idx else None
+        w = None
     L = _L()
     V = coords.shape[0]
     ws = _ws(L.ls3d_devoxelize_grid_workspace_bytes(n, V, batch, _i3(grid)), points)
     check(L.ls3d_devoxelize_grid(_ptr(points), points.shape[1], n, _ptr(pt_off), n, _ptr(coords), _ptr(centers), V, None, _ptr(vx_off), batch,
-                                 _f3(voxel_size), _f3(pc_range[:3]), _i3(grid), _ptr(feat), feat.shape[1], c, _ptr(out), c,
-                                 _ptr(idx), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(points)), "ls3d_devoxelize_grid")
+                                 _f3(voxel_size), _f3(pc_range[:3]), _i3(grid), _ptr(feat), feat_ld, c, _ptr(out), c,
+                                 _ptr(idx), _ptr(w), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(points)), "ls3d_devoxelize_grid")
+    if search_only:
+        return idx, w
     return (out, idx) if return_idx else out
+
+
+def interpolate_rows(feat, idx, weight, points, vx_off, c=None):
+    """second half of a split devoxelize_grid: out[p] = sum_j weight[p,j] * feat[vx_off[frame(p)] + idx[p,j]]"""
+    n = points.shape[0]
+    c = c or feat.shape[1]
+    out = torch.empty((n, c), dtype=torch.float32, device=feat.device)
+    check(_L().ls3d_interpolate_rows(_ptr(feat), feat.shape[1], c, _ptr(idx), _ptr(weight), _ptr(points), points.shape[1], _ptr(vx_off), n,
+                                     _ptr(out), c, _stream(feat)), "ls3d_interpolate_rows")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- fusion

@@ -62,6 +62,10 @@ def _frame_layout(points, conv_point_coords, batch_size):
 def _devoxelize(batch_dict, points, centers, feat, batch_size):
     """three_interpolate_wrap (point_utils.py:8-52) for the whole batch: the grid-accelerated exact search when the
     backbone handed over the voxels' lattice coordinates, the O(N*V) scan otherwise (identical results)."""
+    ds = batch_dict.get("devox_search")
+    if ds is not None and ds["centers"] is centers and ds["points"] is points:
+        # the backbone already ran the neighbour search (geometry only) beside its conv stack: interpolate
+        return ops.interpolate_rows(feat, ds["idx"], ds["weight"], points, ds["vx_off"]), ds["vx_off"]
     pt_off, vx_off = _frame_layout(points, centers, batch_size)
     if "conv_point_indices" in batch_dict and "voxel_geometry" in batch_dict:
         vs, rng = batch_dict["voxel_geometry"]

@@ -97,10 +97,32 @@ class _GeometryStream(object):
                 if o is not None:
                     o.record_stream(self.main)
 
+    def release(self):
+        """everything enqueued on the side stream so far must be done before the main stream continues; what follows inside
+        the block keeps running beside the main stream (pick it up with finish_event())"""
+        if self.on:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+            self.released = True
+
+    def finish_event(self):
+        if not self.on:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return ev
+
+    def keep(self, *tensors):
+        if self.on:
+            for t in tensors:
+                t.record_stream(self.main)
+
     def __exit__(self, *exc):
         if self.on:
             self.ctx.__exit__(*exc)
-            self.main.wait_stream(self.side)
+            if not getattr(self, "released", False):
+                self.main.wait_stream(self.side)
         return False
 
 
@@ -216,6 +238,10 @@ class UNetSCN3D(nn.Module):
                                                           x.spatial_shape if rb is None else rb.out_shape, 3)
             spconv.prebuild_orders(x, self.modules())
             gs.hand_over(x.indice_dict.values())
+            gs.release()
+            # ... and the neighbour search of the devoxelization (points -> 3 nearest voxel centres + weights): geometry as
+            # well, so it keeps running beside the conv stack; the point head only interpolates (point_heads._devoxelize)
+            self._start_devox_search(batch_dict, x, gs)
         x = self.conv_input(x)
         x_conv1 = self.conv1(x)
         x_conv2 = self.conv2(x_conv1)
@@ -239,10 +265,29 @@ class UNetSCN3D(nn.Module):
         x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2])
         return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
 
+    def _start_devox_search(self, batch_dict, x, gs):
+        pts = batch_dict.get("points")
+        if pts is None or pts.dim() != 2 or pts.shape[1] < 4 or pts.device != x.indices.device or not pts.is_contiguous():
+            return
+        bs = int(batch_dict["batch_size"])
+        centers = ops.voxel_centers(x.indices, self.voxel_size, self.point_cloud_range)
+        pt_off, vx_off = ops.frame_offsets(pts, bs), ops.frame_offsets(centers, bs)
+        idx, w = ops.devoxelize_grid(pts, pt_off, x.indices, centers, vx_off, bs, list(self.voxel_size), list(self.point_cloud_range), None)
+        gs.keep(centers, pt_off, vx_off, idx, w)
+        batch_dict["devox_search"] = dict(points=pts, indices=x.indices, centers=centers, pt_off=pt_off, vx_off=vx_off, idx=idx, weight=w,
+                                          event=gs.finish_event())
+
     def _outputs(self, batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4):
         batch_dict["multi_scale_3d_features"] = dict(x_conv1=x_up2, x_conv2=x_up3, x_conv3=x_up4, x_conv4=x_conv4)
         batch_dict["conv_point_features"] = x_up1.features
-        batch_dict["conv_point_coords"] = ops.voxel_centers(x_up1.indices, self.voxel_size, self.point_cloud_range)
+        ds = batch_dict.get("devox_search")
+        if ds is not None and ds["indices"] is x_up1.indices:  # the output sites are the input sites: centres already computed
+            if ds["event"] is not None:
+                torch.cuda.current_stream(x_up1.indices.device).wait_event(ds["event"])
+            batch_dict["conv_point_coords"] = ds["centers"]
+        else:
+            batch_dict.pop("devox_search", None)
+            batch_dict["conv_point_coords"] = ops.voxel_centers(x_up1.indices, self.voxel_size, self.point_cloud_range)
         # extra keys (not in the reference): integer lattice coordinates + geometry of the output voxels, which let
         # the point heads use the grid-accelerated exact 3-NN instead of the O(N*V) scan
         batch_dict["conv_point_indices"] = x_up1.indices

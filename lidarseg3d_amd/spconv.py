@@ -241,7 +241,7 @@ def prebuild_conv_rulebooks(x, convs):
         assert not overflow
         rb = _Rulebook()
         rb._orders = None
-        rb.kind, rb.in_indices, rb.in_shape = "conv", icoords[:n_in], list(ishape)
+        rb.kind, rb.in_indices, rb.in_shape = "conv", (icoords if n_in == icoords.shape[0] else icoords[:n_in]), list(ishape)
         rb.out_indices, rb.out_shape = oc[:n_out], oshape
         rb.tbl, rb.tbl_inv = nbr_out[:n_out], nbr_inv[:n_in]
         x.indice_dict[c.indice_key] = rb

@@ -510,3 +510,18 @@ def test_points_cp_and_cuv_vs_oracle():
     np.testing.assert_array_equal(cuv_got, cuv_want)
     one = ops.points_cuv(torch.from_numpy(want), 1, (640, 960)).numpy()
     np.testing.assert_array_equal(one, orc.points_cuv(want, 1, (640, 960)))
+
+
+def test_devoxelize_split_search_then_interpolate_equals_fused():
+    g = golden("head_mseg3d_nusc.npz")
+    pts = torch.from_numpy(g["points"][:, :4].copy())
+    coords, ctr, feat = torch.from_numpy(g["coords"]), torch.from_numpy(g["conv_point_coords"]), torch.from_numpy(g["conv_point_features"])
+    extra = torch.tensor([[0, 80.0, 3.0, 10.0], [1, 0.0, 0.0, 30.0]])
+    pts = torch.cat([pts[pts[:, 0] == 0][:900], extra[:1], pts[pts[:, 0] == 1][:700], extra[1:]]).contiguous()
+    cfg = synth.NUSC
+    pt_off, vx_off = ops.frame_offsets(pts[:, 0], 2), ops.frame_offsets(ctr[:, 0], 2)
+    fused, fi = ops.devoxelize_grid(pts, pt_off, coords, ctr, vx_off, 2, cfg["voxel_size"], cfg["pc_range"], feat, return_idx=True)
+    idx, w = ops.devoxelize_grid(pts, pt_off, coords, ctr, vx_off, 2, cfg["voxel_size"], cfg["pc_range"], None)
+    assert torch.equal(idx, fi)
+    assert torch.equal(ops.interpolate_rows(feat, idx, w, pts, vx_off), fused)
+    np.testing.assert_allclose(w.sum(1).numpy(), 1.0, atol=1e-6)
