@@ -286,20 +286,14 @@ def set_row_order(kind):
 
 
 def rulebook_order(tbl, coords=None):
-    """processing order of a rulebook table's rows: sorted by neighbour bitmask (kernel ls3d_rulebook_masks; the
-    sort itself is torch.argsort — plumbing, to be replaced by a radix sort kernel).
-    LS3D_REGION=r (experiment, needs the rows' coords): rows are first grouped into r x r (y, x) columns and
-    mask-sorted inside a column, trading some skipped matrix work for L2 locality of the gathers."""
+    """processing order of a rulebook table's rows: sorted by neighbour bitmask, densest rows first (kernel
+    ls3d_rulebook_masks; the sort itself is torch.argsort - plumbing; rulebook_orders below does several tables with one sort).
+    `coords` is unused (a region-blocked order was measured slower, profiles/round1_experiments.md)."""
     n, kvol = tbl.shape
     if n == 0 or kvol > 31 or _ROW_ORDER == "none":
         return None
     mask = torch.empty((n,), dtype=_i32, device=tbl.device)
     check(_L().ls3d_rulebook_masks(_ptr(tbl), n, None, kvol, _ptr(mask), _stream(tbl)), "ls3d_rulebook_masks")
-    region = int(_os_environ_get("LS3D_REGION", "0"))
-    if region > 0 and coords is not None:
-        c = coords[:n].to(torch.int64)
-        key = (((c[:, 0] << 12) + c[:, 2] // region << 12) + c[:, 3] // region << 28) + ((1 << 27) - mask.to(torch.int64))
-        return torch.argsort(key).to(_i32)
     # descending: tiles with the most active offsets (the longest-running workgroups) are dispatched first, the short
     # ones fill the tail of the launch
     return torch.argsort(mask, descending=_os_environ_get("LS3D_ORDER_ASC", "0") != "1").to(_i32)
