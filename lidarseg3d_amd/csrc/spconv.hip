@@ -181,7 +181,7 @@ __device__ __forceinline__ void gg_epilogue(f32x16 (&acc)[NT], float *stage, con
 //   SPARSE a rulebook table is present (sparse convolution); false = dense Linear.  A template parameter so that the
 //          two show up as separate kernels in rocprof traces.
 template <int KC, int NT, int WC, bool SPARSE>
-__global__ __launch_bounds__(256, (NT == 1 && WC == 1) ? 5 : 2) void k_gather_gemm(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
+__global__ __launch_bounds__(256, (NT == 1 && WC == 1) ? 5 : (NT == 2 && WC == 1) ? 4 : 2) void k_gather_gemm(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
                                                     const int32_t *__restrict__ order, int kvol, const float *__restrict__ w, int cin,
                                                     int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
                                                     float *__restrict__ out, int out_ld, int xcd_map) {
