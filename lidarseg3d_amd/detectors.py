@@ -84,9 +84,14 @@ class SegNet(SingleStageDetector):
         return self.backbone(data)
 
     def forward(self, example, return_loss=True, **kwargs):
-        if return_loss:
-            raise NotImplementedError("training step: next row of the scope table (SURVEY.md §8f rank 1)")
         data = self.forward_features(example)
+        if return_loss:  # seg_net.py:86-103: labels in, per-task loss list + detached parts for the logger out
+            data["voxel_sem_labels"], data["point_sem_labels"] = example["voxel_sem_labels"], example["point_sem_labels"]
+            self.point_head(batch_dict=data, return_loss=True)
+            loss, parts = self.point_head.get_loss()
+            ret = dict(loss=[loss])
+            ret.update({k: [v] for k, v in parts.items()})
+            return ret
         self.point_head(batch_dict=data, return_loss=False)
         return self.point_head.predict(example=example, test_cfg=self.test_cfg)
 

@@ -73,6 +73,17 @@ def _devoxelize(batch_dict, points, centers, feat, batch_size):
     return ops.devoxelize(points, pt_off, centers, vx_off, batch_size, points.shape[0], feat), vx_off
 
 
+def _devox_search(batch_dict, points, centers, batch_size):
+    """(idx [N,3] frame-local, weight [N,3], vx_off) of the 3-NN devoxelization: the backbone's early search when there is one"""
+    ds = batch_dict.get("devox_search")
+    if ds is not None and ds["centers"] is centers and ds["points"] is points:
+        return ds["idx"], ds["weight"], ds["vx_off"]
+    pt_off, vx_off = _frame_layout(points, centers, batch_size)
+    vs, rng = batch_dict["voxel_geometry"]
+    idx, w = ops.devoxelize_grid(points, pt_off, batch_dict["conv_point_indices"], centers, vx_off, batch_size, vs, rng, None)
+    return idx, w, vx_off
+
+
 def _predict(head, example, test_cfg):
     """point_seg_batchloss_head.py:171-271 / point_seg_mseg3d_head.py:379-479: per-frame argmax, or the mean of
     the softmax over TTA variants.  Pure bookkeeping on top of out_logits."""
@@ -131,9 +142,25 @@ class PointSegBatchlossHead(PackedModule):
         return dict(conv_cls=_pack_mlp(self.conv_cls_layers), align=_pack_mlp(self.conv_align_layers),
                     out_cls=_pack_mlp(self.out_cls_layers))
 
+    def _forward_train(self, batch_dict, return_loss):
+        """point_seg_batchloss_head.py:124-168 with autograd: the MLPs are the torch modules themselves (batch-statistics
+        BatchNorm), the devoxelization = HIP neighbour search (no gradient) + a differentiable weighted gather"""
+        feat = batch_dict["conv_point_features"]
+        conv_logits = self.conv_cls_layers(feat)
+        points = batch_dict["points"].contiguous()
+        idx, w, vx_off = _devox_search(batch_dict, points, batch_dict["conv_point_coords"], batch_dict["batch_size"])
+        v0 = vx_off[points[:, 0].long()].unsqueeze(1)
+        pf = (feat[(idx + v0).long()] * w.unsqueeze(-1)).sum(1)
+        out = self.out_cls_layers(self.conv_align_layers(pf))
+        batch_dict["out_logits"] = out
+        self.forward_ret_dict.update(conv_logits=conv_logits, out_logits=out)
+        if return_loss:
+            self.forward_ret_dict.update(voxel_sem_labels=batch_dict["voxel_sem_labels"], point_sem_labels=batch_dict["point_sem_labels"])
+        return batch_dict
+
     def forward(self, batch_dict, return_loss=True, **kwargs):
         if return_loss or self.training:
-            raise NotImplementedError("PointSegBatchlossHead: inference forward only (SURVEY.md §8f rank 1)")
+            return self._forward_train(batch_dict, return_loss)
         pk = self.packed()
         batch_size = batch_dict["batch_size"]
         feat = batch_dict["conv_point_features"]
@@ -147,7 +174,15 @@ class PointSegBatchlossHead(PackedModule):
         return batch_dict
 
     def get_loss(self, point_loss_dict=None):
-        raise NotImplementedError("losses belong to the training step (SURVEY.md §8f rank 1)")
+        """point_seg_batchloss_head.py:77-121: (CE + Lovasz-Softmax) on the voxel logits + the same on the point logits"""
+        from .losses import seg_loss
+        d = {} if point_loss_dict is None else point_loss_dict
+        r = self.forward_ret_dict
+        conv_ce, conv_lv = seg_loss(r["conv_logits"], r["voxel_sem_labels"], self.ignored_label)
+        out_ce, out_lv = seg_loss(r["out_logits"], r["point_sem_labels"], self.ignored_label)
+        d.update(conv_ce_loss=conv_ce.detach(), conv_lovasz_loss=conv_lv.detach(), out_ce_loss=out_ce.detach(),
+                 out_lovasz_loss=out_lv.detach())
+        return (conv_ce + conv_lv) + (out_ce + out_lv), d
 
     @torch.no_grad()
     def predict(self, example, test_cfg=None, **kwargs):

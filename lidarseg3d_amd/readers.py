@@ -127,8 +127,26 @@ class TransformerVoxelFeatureExtractor(PackedModule):
         W, scale, shift, cout = pk
         return ops.gather_gemm(x, W, cout=cout, scale=scale, shift=shift, relu=relu, res_pre=res, ln=ln)
 
+    def _forward_train(self, features, num_voxels):
+        """training mode: the same computation on torch modules / autograd (dense, small GEMMs on the
+        library path); the tokens (no gradient: they are inputs) still come from ls3d_vfe_tokens"""
+        V, P, C = features.shape
+        kt = 2 * C + 8
+        tok = ops.vfe_tokens(features.contiguous(), num_voxels.to(torch.int32).contiguous(), (kt + 15) // 16 * 16)[:, :kt]
+        conv = self.feature_conv[0]
+        x = torch.nn.functional.linear(tok, conv.weight.squeeze(-1), conv.bias).view(V, P, self.num_embed).permute(1, 0, 2)
+        for l in self.chunck.layers:  # voxel_encoder.py:149-163: the residuals start from the NORMED tensor
+            x = l.norm1(x)
+            x = x + l.self_attn(x, x, x, need_weights=False)[0]
+            x = l.norm2(x)
+            x = x + l.linear2(torch.relu(l.linear1(x)))
+        x = x.max(dim=0)[0]
+        return self.compress_layer(x) if self.compress_layer is not None else x
+
     def forward(self, features, num_voxels, coors=None):
         assert self.num_input_features == features.shape[-1]
+        if self.training:
+            return self._forward_train(features, num_voxels)
         self._require_eval()
         pk = self.packed()
         V, P, C = features.shape

@@ -362,6 +362,18 @@ def main():
     K = np.array([[1266.4, 0.0, 816.3], [0.0, 1266.4, 491.5], [0.0, 0.0, 1.0]])
     save("view_points.npz", points=pc, view=K, out=ld.view_points(pc, K, normalize=True))
 
+    # ---- Lovasz-Softmax + CE as the batch-loss head applies them (loss_utils.py:217-291, point_seg_batchloss_head.py:77-121)
+    lu = sys.modules["det3d.core.utils.loss_utils"]
+    rng = np.random.default_rng(47)
+    lg = torch.from_numpy((rng.normal(size=(700, 17)) * 2).astype(np.float32)).requires_grad_(True)
+    lb = torch.from_numpy(rng.integers(0, 17, size=700).astype(np.int64))
+    lb[rng.uniform(size=700) < 0.2] = 0  # ignored label
+    lb[lb == 5] = 6                      # a class that is absent
+    lv = lu.lovasz_softmax(torch.softmax(lg, dim=-1), lb, ignore=0)
+    ce = torch.nn.CrossEntropyLoss(ignore_index=0)(lg, lb)
+    (lv + ce).backward()
+    save("seg_loss.npz", logits=lg.detach().numpy(), labels=lb.numpy(), ignore=0, lovasz=float(lv), ce=float(ce), grad=lg.grad.numpy())
+
     with open(os.path.join(HERE, "manifests.json"), "w") as f:
         json.dump({k: {n: list(s) for n, s in v.items()} for k, v in manifests.items()}, f, indent=0, sort_keys=True)
     print("wrote manifests.json")

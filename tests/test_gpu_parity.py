@@ -553,3 +553,59 @@ def test_points_cp_and_cuv_gpu():
     assert same_cam.mean() >= 0.9999
     np.testing.assert_allclose(got[same_cam], want[same_cam], rtol=0, atol=2e-4)
     np.testing.assert_array_equal(ops.points_cuv(cu(want), 6, (640, 960)).cpu().numpy(), orc.points_cuv(want, 6, (640, 960)))
+
+
+def _train_example(points_per_frame):
+    cfg = synth.NUSC
+    frames = [synth.lidar_frame(n, seed=11 + i, **cfg) for i, n in enumerate(points_per_frame)]
+    pts = cu(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)]))
+    v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 5, 60000 * len(frames), batched=True)
+    V = int(nv)
+    gen = torch.Generator().manual_seed(3)
+    return dict(points=pts, voxels=v[:V], coordinates=c[:V], num_points=n[:V], num_voxels=[0] * len(frames),
+                shape=[np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))],
+                voxel_sem_labels=torch.randint(0, 17, (V,), generator=gen).to(DEV),
+                point_sem_labels=torch.randint(0, 17, (pts.shape[0],), generator=gen).to(DEV))
+
+
+def test_sdseg3d_training_step_gpu():
+    """SegNet(return_loss=True).train(): TransVFE (torch autograd) -> UNetSCN3D (HIP forward / dgrad / wgrad) -> batch-loss head
+    (HIP 3-NN search + differentiable gather) -> CE + Lovasz.  Loss and the whole gradient against the same graph with the
+    sparse convolutions replaced by the torch restatement; one SGD step lowers the loss."""
+    from lidarseg3d_amd import spconv
+    torch.manual_seed(0)
+    model = L.build_detector(models_cfg.sdseg3d(), train_cfg=None, test_cfg={}).to(DEV).train()
+    ex = _train_example([6000, 2500])
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        out = model(dict(ex), return_loss=True)
+        loss = out["loss"][0]
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, out
+
+    la, ga, out = run()
+    assert np.isfinite(la) and set(out) == {"loss", "conv_ce_loss", "conv_lovasz_loss", "out_ce_loss", "out_lovasz_loss"}
+    assert all(k.startswith("backbone.conv_out") for k, p in model.named_parameters() if p.grad is None)
+    orig = spconv._SparseConvFn
+
+    class RefFn(object):
+        @staticmethod
+        def apply(feats, weight, bias, rb, inverse, subm):
+            y = _spconv_ref(feats, weight, (rb.tbl_inv if inverse else rb.tbl))
+            return y if bias is None else y + bias
+    try:
+        spconv._SparseConvFn = RefFn
+        lb, gb, _ = run()
+    finally:
+        spconv._SparseConvFn = orig
+    assert abs(la - lb) <= 1e-3 * abs(lb)
+    assert set(ga) == set(gb)
+    va, vb = torch.cat([ga[k].flatten() for k in sorted(gb)]), torch.cat([gb[k].flatten() for k in sorted(gb)])
+    assert float(torch.dot(va, vb) / (va.norm() * vb.norm())) >= 0.999  # see test_unet_training_step_gpu for the tolerance model
+    opt = torch.optim.SGD(model.parameters(), lr=0.02)
+    l0, _, _ = run()
+    opt.step()
+    l1, _, _ = run()
+    assert l1 < l0

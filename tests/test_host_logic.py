@@ -6,6 +6,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -89,7 +90,8 @@ def test_build_detector_injects_cfgs_and_checkpoint_roundtrip(tmp_path):
 
 
 def test_training_forward_is_refused_not_silently_wrong():
-    model = L.build_detector(models_cfg.sdseg3d())
+    """the MSeg3D training step does not exist yet (SDSeg3D's does: test_sdseg3d_training_step_*): refused, not approximated"""
+    model = L.build_detector(models_cfg.mseg3d())
     with pytest.raises(NotImplementedError):
         model(dict(points=torch.zeros(4, 6)), return_loss=True)
 
@@ -187,3 +189,21 @@ def test_reference_config_files_build_unchanged(path):
         for name in [m for m in sys.modules if m == "det3d" or m.startswith("det3d.") or m in ("spconv", "addict", "addict.addict")]:
             if getattr(sys.modules[name], "__ls3d_alias__", False) or name.startswith("det3d"):
                 sys.modules.pop(name, None)
+
+
+def test_seg_loss_vs_reference():
+    """cross entropy (ignored label) + Lovasz-Softmax: value and gradient against the reference's loss_utils on 700 points"""
+    from lidarseg3d_amd import losses
+    from tests.util import golden
+    g = golden("seg_loss.npz")
+    lg = torch.from_numpy(g["logits"]).requires_grad_(True)
+    ce, lv = losses.seg_loss(lg, torch.from_numpy(g["labels"]), int(g["ignore"]))
+    assert abs(float(ce) - float(g["ce"])) <= 1e-6 and abs(float(lv) - float(g["lovasz"])) <= 1e-6
+    (ce + lv).backward()
+    np.testing.assert_allclose(lg.grad.numpy(), g["grad"], rtol=0, atol=1e-7)
+    # only ignored labels: zero loss, zero gradient
+    z = torch.zeros(5, dtype=torch.long)
+    lg2 = torch.randn(5, 17, requires_grad=True)
+    l0 = losses.lovasz_softmax(torch.softmax(lg2, -1), z, ignore=0)
+    l0.backward()
+    assert float(l0) == 0.0 and float(lg2.grad.abs().max()) == 0.0

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""One SDSeg3D training step (forward + loss + backward + SGD update) on a synthetic 120k-point frame: the reader and the head's
+MLPs on torch autograd, voxelization / sparse convolutions (forward, dgrad, wgrad) / 3-NN search on the HIP kernels.  Prints one
+JSON line; not the headline benchmark (bench.py is).  SURVEY.md 8f rank 1, single GPU (the gradient all-reduce is torch DDP)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=120000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    import lidarseg3d_amd as L
+    from lidarseg3d_amd import models_cfg, ops, synth
+    from oracle import ref as orc
+    cfg = synth.NUSC
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    model = L.build_detector(models_cfg.sdseg3d(), train_cfg=None, test_cfg={}).to(dev).train()
+    frame = synth.lidar_frame(args.points, seed=0, **cfg)
+    pts = torch.from_numpy(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)).to(dev)
+    v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 5, 300000, batched=True)
+    V = int(nv)
+    ex = dict(points=pts, voxels=v[:V], coordinates=c[:V], num_points=n[:V], num_voxels=[V],
+              shape=[np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))],
+              voxel_sem_labels=torch.randint(0, 17, (V,), device=dev), point_sem_labels=torch.randint(0, 17, (pts.shape[0],), device=dev))
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    tf = tb = to = 0.0
+    losses = []
+    for it in range(args.warmup + args.steps):
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        loss = model(dict(ex), return_loss=True)["loss"][0]
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        opt.step()
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        losses.append(float(loss.detach()))
+        if it >= args.warmup:
+            tf += t1 - t0; tb += t2 - t1; to += t3 - t2
+    k = args.steps
+    print(json.dumps({"what": "SDSeg3D training step (f32), 1 frame, 1 GPU", "points": args.points, "active_voxels": V,
+                      "forward_ms": 1e3 * tf / k, "backward_ms": 1e3 * tb / k, "optimizer_ms": 1e3 * to / k,
+                      "step_ms": 1e3 * (tf + tb + to) / k, "loss_first": losses[0], "loss_last": losses[-1], "steps": k}))
+
+
+if __name__ == "__main__":
+    main()
