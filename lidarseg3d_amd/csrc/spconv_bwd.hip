@@ -19,11 +19,25 @@ typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WG_UNROLL = 4;  // row pairs in flight per wave
 
+// tbl_t[k][p] = tbl[order[p]][k] (p = position in the processing order) and o_t[p] = order[p]: one pass over the table so that
+// the wgrad workgroups of offset k read their neighbour indices as contiguous ints instead of 4-byte gathers from 108-byte rows
+__global__ __launch_bounds__(256) void k_tbl_transpose(const int32_t *tbl, const int32_t *order, int n, const int32_t *n_dev, int kvol,
+                                                      int32_t *tbl_t, int32_t *o_t) {
+  const int N = ls3d_count(n, n_dev);
+  const long long work = (long long)N * kvol;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(t / kvol), k = (int)(t % kvol);
+    const int o = order ? order[p] : p;
+    tbl_t[(size_t)k * n + p] = tbl[(size_t)o * kvol + k];
+    if (k == 0) o_t[p] = o;
+  }
+}
+
 template <int COB>
 __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ in, int in_ld, const float *__restrict__ gout, int go_ld,
-                                                      const int32_t *__restrict__ tbl, const int32_t *__restrict__ order, int kvol, int cin,
+                                                      const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_t, int kvol, int cin,
                                                       int cout, int n_rows, const int32_t *n_rows_dev, int nchunks, float *__restrict__ partial) {
-  __shared__ float red[3][32 * 32 * COB];  // partial tiles of waves 1..3
+  __shared__ float red[32 * 32 * COB];     // one wave's partial tile at a time
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, half = lane >> 5;
   const int N = ls3d_count(n_rows, n_rows_dev);
@@ -34,57 +48,86 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ 
   const int npairs = (N + 1) / 2;
   const int per_chunk = (npairs + nchunks - 1) / nchunks;
   const int p0 = chunk * per_chunk, p1 = min(npairs, p0 + per_chunk);
+  const int32_t *tk = tbl_t + (size_t)k * n_rows;
   wg_f32x16 acc[COB];
 #pragma unroll
   for (int n = 0; n < COB; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-  for (int p = p0 + wave * WG_UNROLL; p < p1; p += 4 * WG_UNROLL) {
-    int o[WG_UNROLL], idx[WG_UNROLL];
+  // two-stage software pipeline over groups of WG_UNROLL row pairs: the operands of group g + 1 are loaded before the MFMAs
+  // of group g are issued, the (contiguous) indices of group g + 2 before that
+  int o_n[WG_UNROLL], idx_n[WG_UNROLL];
+  float a_c[WG_UNROLL], b_c[WG_UNROLL][COB];
+  unsigned any_c = 0u;
+#define WG_LOAD_IDX(p_)                                                                       \
+  _Pragma("unroll") for (int u = 0; u < WG_UNROLL; ++u) {                                     \
+    const int r_ = 2 * ((p_) + u) + half;                                                     \
+    const bool ok_ = (p_) + u < p1 && r_ < N;                                                 \
+    o_n[u] = ok_ ? o_t[r_] : -1;                                                              \
+    idx_n[u] = ok_ ? tk[r_] : -1;                                                             \
+  }
+#define WG_LOAD_OPS()                                                                         \
+  any_c = 0u;                                                                                 \
+  _Pragma("unroll") for (int u = 0; u < WG_UNROLL; ++u) {                                     \
+    const bool on_ = idx_n[u] >= 0;                                                           \
+    if (__any(on_)) any_c |= 1u << u;                                                         \
+    a_c[u] = (on_ && ci < cin) ? in[(size_t)idx_n[u] * in_ld + ci] : 0.0f;                    \
+    _Pragma("unroll") for (int n = 0; n < COB; ++n)                                           \
+        b_c[u][n] = (on_ && n * 32 + i < cout) ? gout[(size_t)o_n[u] * go_ld + n * 32 + i] : 0.0f; \
+  }
+  int p = p0 + wave * WG_UNROLL;
+  WG_LOAD_IDX(p)
+  WG_LOAD_OPS()
+  if (p + 4 * WG_UNROLL < p1) { WG_LOAD_IDX(p + 4 * WG_UNROLL) }
+  for (; p < p1; p += 4 * WG_UNROLL) {
+    float a[WG_UNROLL], bb[WG_UNROLL][COB];
+    const unsigned any = any_c;
 #pragma unroll
     for (int u = 0; u < WG_UNROLL; ++u) {
-      const int r = 2 * (p + u) + half;
-      o[u] = (p + u < p1 && r < N) ? (order ? order[r] : r) : -1;
-      idx[u] = o[u] >= 0 ? tbl[(size_t)o[u] * kvol + k] : -1;
+      a[u] = a_c[u];
+#pragma unroll
+      for (int n = 0; n < COB; ++n) bb[u][n] = b_c[u][n];
     }
-    float a[WG_UNROLL], b[WG_UNROLL][COB];
-    bool any[WG_UNROLL];
-#pragma unroll
-    for (int u = 0; u < WG_UNROLL; ++u) {
-      any[u] = __any(idx[u] >= 0);
-      const bool on = idx[u] >= 0;
-      a[u] = (on && ci < cin) ? in[(size_t)idx[u] * in_ld + ci] : 0.0f;
-#pragma unroll
-      for (int n = 0; n < COB; ++n) b[u][n] = (on && n * 32 + i < cout) ? gout[(size_t)o[u] * go_ld + n * 32 + i] : 0.0f;
+    if (p + 4 * WG_UNROLL < p1) {
+      WG_LOAD_OPS()                                                       // operands of the next group (indices already here)
+      if (p + 8 * WG_UNROLL < p1) { WG_LOAD_IDX(p + 8 * WG_UNROLL) }      // indices of the group after it
     }
 #pragma unroll
     for (int u = 0; u < WG_UNROLL; ++u) {
-      if (any[u]) {
+      if ((any >> u) & 1u) {
 #pragma unroll
-        for (int n = 0; n < COB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][n], acc[n], 0, 0, 0);
+        for (int n = 0; n < COB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb[u][n], acc[n], 0, 0, 0);
       }
     }
   }
-  // ---- waves 1..3 hand their tiles to wave 0 (fixed order), which writes the chunk's partial [32][cout] block
-  if (wave > 0) {
+#undef WG_LOAD_IDX
+#undef WG_LOAD_OPS
+  // ---- waves 1..3 hand their tiles to wave 0 one after the other (fixed order, 16 KB of LDS instead of 48: the LDS footprint,
+  //      not the registers, was limiting the resident workgroups), which then writes the chunk's partial [32][cout] block
+  for (int w2 = 1; w2 < 4; ++w2) {
+    if (wave == w2) {
 #pragma unroll
-    for (int n = 0; n < COB; ++n)
+      for (int n = 0; n < COB; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave - 1][(n * 16 + r) * 64 + lane] = acc[n][r];
+        for (int r = 0; r < 16; ++r) red[(n * 16 + r) * 64 + lane] = acc[n][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int n = 0; n < COB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] += red[(n * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (wave == 0) {
     float *dst = partial + (((size_t)chunk * kvol + k) * cin) * cout;
 #pragma unroll
     for (int n = 0; n < COB; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = acc[n][r];
-        v += red[0][(n * 16 + r) * 64 + lane];
-        v += red[1][(n * 16 + r) * 64 + lane];
-        v += red[2][(n * 16 + r) * 64 + lane];
         const int row = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, col = n * 32 + i;  // fragment layout of the 32x32 MFMA
-        if (row < cin && col < cout) dst[(size_t)row * cout + col] = v;
+        if (row < cin && col < cout) dst[(size_t)row * cout + col] = acc[n][r];
       }
   }
 }
@@ -108,8 +151,9 @@ static inline int wg_chunks(int n_rows, int kvol, int cin) {
   return (int)want;
 }
 
+static inline size_t wg_align(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t ls3d_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout, int n_rows) {
-  return (size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cout * sizeof(float) + 256;
+  return wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cout * sizeof(float)) + wg_align((size_t)(kvol + 1) * (n_rows > 0 ? n_rows : 1) * 4) + 256;
 }
 
 extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int go_ld, const int32_t *tbl, const int32_t *row_order,
@@ -128,17 +172,17 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
   const int nchunks = wg_chunks(n_rows, kvol, cin);
   const int ci_blocks = (cin + 31) / 32;
   float *partial = (float *)workspace;
+  int32_t *tbl_t = (int32_t *)((char *)workspace + wg_align((size_t)nchunks * kvol * cin * cout * sizeof(float)));
+  int32_t *o_t = tbl_t + (size_t)kvol * n_rows;
+  hipLaunchKernelGGL(k_tbl_transpose, ls3d_grid((long long)n_rows * kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, tbl_t, o_t);
   const dim3 grid((unsigned)(nchunks * ci_blocks), (unsigned)kvol);
   const int cob = (cout + 31) / 32;
-  if (cob == 1)
-    hipLaunchKernelGGL((k_spconv_wgrad<1>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, tbl, row_order, kvol, cin, cout, n_rows,
-                       n_rows_dev, nchunks, partial);
-  else if (cob == 2)
-    hipLaunchKernelGGL((k_spconv_wgrad<2>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, tbl, row_order, kvol, cin, cout, n_rows,
-                       n_rows_dev, nchunks, partial);
-  else
-    hipLaunchKernelGGL((k_spconv_wgrad<4>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, tbl, row_order, kvol, cin, cout, n_rows,
-                       n_rows_dev, nchunks, partial);
+#define LS3D_WG(COB_) hipLaunchKernelGGL((k_spconv_wgrad<COB_>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, (const int32_t *)tbl_t, \
+                                          (const int32_t *)o_t, kvol, cin, cout, n_rows, n_rows_dev, nchunks, partial)
+  if (cob == 1) LS3D_WG(1);
+  else if (cob == 2) LS3D_WG(2);
+  else LS3D_WG(4);
+#undef LS3D_WG
   hipLaunchKernelGGL(k_wgrad_reduce, ls3d_grid(elems), dim3(256), 0, stream, (const float *)partial, nchunks, elems, grad_w);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
