@@ -20,15 +20,27 @@ def main():
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ddp", action="store_true", help="wrap the model in DistributedDataParallel (RCCL gradient all-reduce); "
+                    "launch with python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... (N = 1 works too)")
     args = ap.parse_args()
     import lidarseg3d_amd as L
     from lidarseg3d_amd import models_cfg, ops, synth
     from oracle import ref as orc
     cfg = synth.NUSC
-    dev = "cuda:0"
+    rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
     torch.manual_seed(0)
     model = L.build_detector(models_cfg.sdseg3d(), train_cfg=None, test_cfg={}).to(dev).train()
-    frame = synth.lidar_frame(args.points, seed=0, **cfg)
+    net = model
+    if args.ddp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # conv_out (spconv_down2) feeds nothing the segmentation loss sees -> find_unused_parameters
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True)
+    frame = synth.lidar_frame(args.points, seed=rank, **cfg)
     pts = torch.from_numpy(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)).to(dev)
     v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 5, 300000, batched=True)
     V = int(nv)
@@ -41,7 +53,7 @@ def main():
     for it in range(args.warmup + args.steps):
         opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        loss = model(dict(ex), return_loss=True)["loss"][0]
+        loss = net(dict(ex), return_loss=True)["loss"][0]
         torch.cuda.synchronize(); t1 = time.perf_counter()
         loss.backward()
         torch.cuda.synchronize(); t2 = time.perf_counter()
@@ -51,9 +63,17 @@ def main():
         if it >= args.warmup:
             tf += t1 - t0; tb += t2 - t1; to += t3 - t2
     k = args.steps
-    print(json.dumps({"what": "SDSeg3D training step (f32), 1 frame, 1 GPU", "points": args.points, "active_voxels": V,
-                      "forward_ms": 1e3 * tf / k, "backward_ms": 1e3 * tb / k, "optimizer_ms": 1e3 * to / k,
-                      "step_ms": 1e3 * (tf + tb + to) / k, "loss_first": losses[0], "loss_last": losses[-1], "steps": k}))
+    if args.ddp:
+        t = torch.tensor([tf, tb, to], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tf, tb, to = (float(v) for v in t.tolist())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"what": "SDSeg3D training step (f32), 1 frame per GPU, %d GPU(s)%s" % (world, ", DDP" if args.ddp else ""),
+                          "points": args.points, "active_voxels": V,
+                          "forward_ms": 1e3 * tf / k, "backward_ms": 1e3 * tb / k, "optimizer_ms": 1e3 * to / k,
+                          "step_ms": 1e3 * (tf + tb + to) / k, "frames_per_s": world * k / (tf + tb + to),
+                          "loss_first": losses[0], "loss_last": losses[-1], "steps": k}))
 
 
 if __name__ == "__main__":
