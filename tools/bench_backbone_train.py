@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
     from lidarseg3d_amd import ops, scn_unet, synth
-    from oracle import ref as orc
     cfg = synth.NUSC
     dev = "cuda:0"
     frame = synth.lidar_frame(args.points, seed=0, **cfg)
@@ -32,7 +31,7 @@ def main():
     feats0 = torch.randn((V, 16), device=dev)
     net = scn_unet.UNetSCN3D(num_input_features=16, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
                              model_cfg=dict(SCALING_RATIO=2), ds_factor=8, us_factor=8).to(dev).train()
-    shape = np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))
+    shape = np.asarray(ops.make_grid(cfg["voxel_size"], cfg["pc_range"])[1])
     tf = tb = 0.0
     for it in range(args.warmup + args.steps):
         for p in net.parameters():

@@ -25,7 +25,6 @@ def main():
     args = ap.parse_args()
     import lidarseg3d_amd as L
     from lidarseg3d_amd import models_cfg, ops, synth
-    from oracle import ref as orc
     cfg = synth.NUSC
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     torch.cuda.set_device(local_rank)
@@ -45,7 +44,7 @@ def main():
     v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 5, 300000, batched=True)
     V = int(nv)
     ex = dict(points=pts, voxels=v[:V], coordinates=c[:V], num_points=n[:V], num_voxels=[V],
-              shape=[np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))],
+              shape=[np.asarray(ops.make_grid(cfg["voxel_size"], cfg["pc_range"])[1])],
               voxel_sem_labels=torch.randint(0, 17, (V,), device=dev), point_sem_labels=torch.randint(0, 17, (pts.shape[0],), device=dev))
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
     tf = tb = to = 0.0
