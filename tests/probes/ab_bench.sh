@@ -15,5 +15,7 @@ for l in sys.stdin:
         for k, t in (('f32_grade_mode', 'x6'), ('fast_mode', 'x3')):
             if k in j:
                 s += ' | %s %.2f fps conv %.2f' % (t, j[k]['value'], j[k]['sparse_conv_ms_per_frame'])
+        if 'throughput_mode' in j:
+            t = j['throughput_mode']; s += ' | 2-stream f32 %.2f x6 %.2f x3 %.2f' % (t['f32_frames_per_s'], t['bf16x6_frames_per_s'], t['bf16x3_frames_per_s'])
         print(s)
 "
