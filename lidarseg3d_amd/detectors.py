@@ -122,19 +122,20 @@ class SegMSeg3DNet(SingleStageDetector):
             return None
 
     def forward(self, example, return_loss=True, **kwargs):
-        if return_loss:
-            raise NotImplementedError("training step: next row of the scope table (SURVEY.md §8f rank 1)")
         voxels, coords, num, batch_size, shape = _voxel_inputs(example, self.voxel_generator)
         if self.img_backbone is not None and "image_features" not in example:
             images = example["images"]
             ncam, hi, wi = images.shape[1], images.shape[3], images.shape[4]
-            img_data = self.img_head(batch_dict=dict(inputs=self.img_backbone(images.view(-1, 3, hi, wi)),
-                                                     batch_size=batch_size), return_loss=False)
+            img_data = dict(inputs=self.img_backbone(images.view(-1, 3, hi, wi)), batch_size=batch_size)
+            if return_loss:
+                img_data["images_sem_labels"] = example["images_sem_labels"].view(-1, hi, wi).unsqueeze(1)
+            img_data = self.img_head(batch_dict=img_data, return_loss=return_loss)
+            camera_loss = self.img_head.get_loss if return_loss else None
             feats = img_data["image_features"]
             image_features = feats.view(batch_size, ncam, *feats.shape[1:])
             cam_emb = img_data.get("camera_semantic_embeddings")
         else:
-            image_features, cam_emb = example["image_features"], example["camera_semantic_embeddings"]
+            image_features, cam_emb, camera_loss = example["image_features"], example["camera_semantic_embeddings"], None
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
                     points=example["points"][:, 0:4].contiguous())
         data["voxel_coords_ready"] = _coords_ready(coords)
@@ -142,5 +143,15 @@ class SegMSeg3DNet(SingleStageDetector):
         data = self.backbone(data)
         data.update(points_cuv=example["points_cuv"], image_features=image_features,
                     camera_semantic_embeddings=cam_emb, metadata=example.get("metadata"))
+        if return_loss:  # seg_mseg3d_net.py:120-140; the image head's loss joins in when a user-registered camera branch runs
+            data["voxel_sem_labels"], data["point_sem_labels"] = example["voxel_sem_labels"], example["point_sem_labels"]
+            self.point_head(batch_dict=data, return_loss=True)
+            loss, parts = self.point_head.get_loss()
+            if camera_loss is not None:
+                img_loss, parts = camera_loss(parts)
+                loss = loss + img_loss
+            ret = dict(loss=[loss])
+            ret.update({k: [v] for k, v in parts.items()})
+            return ret
         self.point_head(batch_dict=data, return_loss=False)
         return self.point_head.predict(example=example, test_cfg=self.test_cfg)

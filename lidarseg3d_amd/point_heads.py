@@ -227,6 +227,7 @@ class TransformerDecoderLayer(nn.Module):
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout_p = dropout
 
 
 class TransformerDecoder(nn.Module):
@@ -278,6 +279,9 @@ class SemanticFeatureFusionModule(PackedModule):
                 return_context=False, points=None):
         """embeddings [B, C, num_cls, 1]; `points` (rows with the batch index in column 0) may be passed to avoid
         rebuilding it from batch_idx."""
+        if torch.is_grad_enabled() and (self.training or input_point_features.requires_grad):
+            return self._forward_train(input_point_features, input_sem_embeddings1, input_sem_embeddings2, batch_idx,
+                                       batch_size, return_context)
         self._require_eval()
         pk = self.packed()
         E, H = self.d_model, self.nhead
@@ -308,6 +312,59 @@ class SemanticFeatureFusionModule(PackedModule):
         if return_context:
             return tgt, mem.view(B, L, E).permute(1, 0, 2).contiguous()
         return tgt
+
+
+def _sffm_forward_train(self, x, emb1, emb2, batch_idx, batch_size, return_context=False):
+    """the same decoder under autograd (context_module.py:91-117, :222-257, :319-376): torch modules for the projections /
+    norms / embedding self-attention; the point->class-token attention is a per-frame einsum on the frame-sorted rows"""
+    F = torch.nn.functional
+    H, hd, B = self.nhead, self.d_model // self.nhead, batch_size
+    off = ops.frame_offsets(batch_idx.contiguous(), B).tolist()
+    tgt = self.input_proj_point(x)
+    mem = torch.cat([self.input_proj_embeddings1(emb1.squeeze(-1)), self.input_proj_embeddings2(emb2.squeeze(-1))], dim=2)
+    mem = mem.permute(2, 0, 1).contiguous()  # [L, B, E]
+    L = mem.shape[0]
+    for l in self.decoder.layers:
+        drop = lambda t: F.dropout(t, l.dropout_p, self.training)
+        mem = l.norm1(mem + drop(l.self_attn(mem, mem, value=mem)[0]))
+        ca = l.crossocr_attn
+        q = ca.q_proj(tgt).view(-1, H, hd)
+        kv_in = mem.permute(1, 2, 0)  # [B, E, L]; the [B,E,L] result is then VIEWED as [B,H,hd,L] like the reference
+        k, v = ca.k_proj(kv_in).reshape(B, H, hd, L), ca.v_proj(kv_in).reshape(B, H, hd, L)
+        rows = []
+        for b in range(B):
+            qb = q[off[b]:off[b + 1]]
+            att = torch.softmax(torch.einsum("nhd,hdl->nhl", qb, k[b]) * hd ** -0.5, dim=-1)
+            rows.append(torch.einsum("nhl,hdl->nhd", att, v[b]))
+        tgt = l.norm2(tgt + drop(ca.out_proj(torch.cat(rows, 0).reshape(-1, H * hd))))
+        tgt = l.norm3(tgt + drop(l.linear2(drop(F.relu(l.linear1(tgt))))))
+    tgt = self.decoder.norm_tgt(tgt)
+    return (tgt, mem) if return_context else tgt
+
+
+SemanticFeatureFusionModule._forward_train = _sffm_forward_train
+
+
+def _sample_image_rows(image_features, cuv, batch_idx):
+    """get_points_image_feature (point_seg_mseg3d_head.py:200-236) under autograd: the 5-D bilinear grid_sample
+    (align_corners=True, zeros padding) written as 8 weighted row gathers from the channels-last maps, all frames at once"""
+    B, ncam, C, h, w = image_features.shape
+    rows = image_features.permute(0, 1, 3, 4, 2).reshape(-1, C)
+    pos = [(cuv[:, 1] + 1) * 0.5 * (ncam - 1), (cuv[:, 2] + 1) * 0.5 * (h - 1), (cuv[:, 3] + 1) * 0.5 * (w - 1)]
+    lim = [ncam, h, w]
+    lo = [p.floor() for p in pos]
+    out = image_features.new_zeros((cuv.shape[0], C))
+    for corner in range(8):
+        wgt, inside, cell = 1.0, True, []
+        for a in range(3):
+            hi = (corner >> a) & 1
+            c = lo[a] + hi
+            wgt = wgt * ((pos[a] - lo[a]) if hi else (lo[a] + 1 - pos[a]))
+            inside = (c >= 0) & (c <= lim[a] - 1) & inside
+            cell.append(c.clamp(0, lim[a] - 1).long())
+        flat = ((batch_idx.long() * ncam + cell[0]) * h + cell[1]) * w + cell[2]
+        out = out + rows[flat] * (wgt * inside).unsqueeze(1)
+    return out
 
 
 @POINT_HEADS.register_module
@@ -349,9 +406,44 @@ class PointSegMSeg3DHead(PackedModule):
         pts = batch_idx.float().unsqueeze(1).contiguous()
         return ops.grid_gather(input_img_feature.contiguous(), points_cuv.contiguous(), pts)
 
+    def _forward_train(self, batch_dict, return_loss):
+        """point_seg_mseg3d_head.py:240-376 under autograd.  The MLPs are the torch modules (batch-statistics BatchNorm;
+        the camera / mimic branches see only the rows with a camera hit, as in the reference, which matters for those
+        statistics); devoxelization = HIP neighbour search (no gradient) + a differentiable weighted gather."""
+        B = batch_dict["batch_size"]
+        vf = batch_dict["conv_point_features"]
+        voxel_logits = self.voxel_cls_layers(vf)
+        points = batch_dict["points"].contiguous()
+        centers = batch_dict["conv_point_coords"]
+        idx, w, vx_off = _devox_search(batch_dict, points, centers, B)
+        v0 = vx_off[points[:, 0].long()].unsqueeze(1)
+        pl = self.gffm_lidar((vf[(idx + v0).long()] * w.unsqueeze(-1)).sum(1))
+        cuv = batch_dict["points_cuv"]
+        valid = cuv[:, 0] == 1
+        pc = self.gffm_camera(_sample_image_rows(batch_dict["image_features"], cuv[valid], points[:, 0][valid]))
+        ppc = self.lidar_camera_mimic_layer(pl[valid])
+        # completed camera features (:320-334): rows without a camera hit stay zero, the pseudo-camera branch only
+        # exists on the rows WITH a hit and feeds nothing but the mimic loss
+        cc = pc.new_zeros((points.shape[0], pc.shape[1])).index_put((valid.nonzero().squeeze(1),), pc)
+        fused = self.gffm_lc(torch.cat([pl, cc], dim=1))
+        lemb = []
+        vo = vx_off.tolist()
+        for b in range(B):  # SFAM (context_module.py:25-53): softmax over the voxels of a frame, per class
+            sl = slice(vo[b], vo[b + 1])
+            lemb.append(torch.softmax(voxel_logits[sl], dim=0).t() @ vf[sl])
+        lemb = torch.stack(lemb, 0).permute(0, 2, 1).unsqueeze(3)
+        sem = self.sffm._forward_train(fused, batch_dict["camera_semantic_embeddings"], lemb, points[:, 0], B)
+        out = self.out_cls_layers(sem)
+        batch_dict["out_logits"] = out
+        self.forward_ret_dict.update(voxel_logits=voxel_logits, out_logits=out)
+        if return_loss:
+            self.forward_ret_dict.update(voxel_sem_labels=batch_dict["voxel_sem_labels"], point_sem_labels=batch_dict["point_sem_labels"],
+                                         batch_size=B, point_features_pcamera=ppc, point_features_camera=pc.detach())
+        return batch_dict
+
     def forward(self, batch_dict, return_loss=True, **kwargs):
         if return_loss or self.training:
-            raise NotImplementedError("PointSegMSeg3DHead: inference forward only (SURVEY.md §8f rank 1)")
+            return self._forward_train(batch_dict, return_loss)
         pk = self.packed()
         B = batch_dict["batch_size"]
         vf = batch_dict["conv_point_features"]
@@ -379,7 +471,18 @@ class PointSegMSeg3DHead(PackedModule):
         return batch_dict
 
     def get_loss(self, point_loss_dict=None):
-        raise NotImplementedError("losses belong to the training step (SURVEY.md §8f rank 1)")
+        """point_seg_mseg3d_head.py:137-196: (CE + Lovasz-Softmax) on the voxel logits, the same on the point logits, and
+        the MSE between the pseudo-camera features and the (detached) camera features on the points with a camera hit"""
+        from .losses import seg_loss
+        d = {} if point_loss_dict is None else point_loss_dict
+        r = self.forward_ret_dict
+        v_ce, v_lv = seg_loss(r["voxel_logits"], r["voxel_sem_labels"], self.ignored_label)
+        o_ce, o_lv = seg_loss(r["out_logits"], r["point_sem_labels"], self.ignored_label)
+        assert not r["point_features_camera"].requires_grad
+        mimic = torch.nn.functional.mse_loss(r["point_features_pcamera"], r["point_features_camera"])
+        d.update(voxel_ce_loss=v_ce.detach(), voxel_lovasz_loss=v_lv.detach(), out_ce_loss=o_ce.detach(),
+                 out_lovasz_loss=o_lv.detach(), out_mimic_loss=mimic.detach())
+        return (v_ce + v_lv) + (o_ce + o_lv) + mimic, d
 
     @torch.no_grad()
     def predict(self, example, test_cfg=None, **kwargs):

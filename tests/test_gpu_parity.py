@@ -609,3 +609,49 @@ def test_sdseg3d_training_step_gpu():
     opt.step()
     l1, _, _ = run()
     assert l1 < l0
+
+
+def test_mseg3d_training_step_gpu():
+    """SegMSeg3DNet(return_loss=True).train(): reader -> UNetSCN3D (HIP forward / dgrad / wgrad) -> GF-/SF-Phase head under
+    autograd (HIP 3-NN search) -> voxel / point / mimic losses.  Loss and gradient against the same graph with the sparse
+    convolutions replaced by the torch restatement; one SGD step lowers the loss."""
+    from lidarseg3d_amd import spconv
+    torch.manual_seed(0)
+    model = L.build_detector(models_cfg.mseg3d(), train_cfg=None, test_cfg={}).to(DEV).train()
+    ex = _train_example([5000, 2000])
+    img, emb, cuv = synth.camera_inputs(ex["points"].shape[0], seed=2, ncam=6, c_img=48, h=40, w=60, batch=2)
+    ex.update(image_features=cu(img), camera_semantic_embeddings=cu(emb), points_cuv=cu(cuv))
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        out = model(dict(ex), return_loss=True)
+        loss = out["loss"][0]
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, out
+
+    la, ga, out = run()
+    assert np.isfinite(la)
+    assert set(out) == {"loss", "voxel_ce_loss", "voxel_lovasz_loss", "out_ce_loss", "out_lovasz_loss", "out_mimic_loss"}
+    assert all(k.startswith("backbone.conv_out") for k, p in model.named_parameters() if p.grad is None)
+    orig = spconv._SparseConvFn
+
+    class RefFn(object):
+        @staticmethod
+        def apply(feats, weight, bias, rb, inverse, subm):
+            y = _spconv_ref(feats, weight, (rb.tbl_inv if inverse else rb.tbl))
+            return y if bias is None else y + bias
+    try:
+        spconv._SparseConvFn = RefFn
+        lb, gb, _ = run()
+    finally:
+        spconv._SparseConvFn = orig
+    assert abs(la - lb) <= 1e-3 * abs(lb)
+    assert set(ga) == set(gb)
+    va, vb = torch.cat([ga[k].flatten() for k in sorted(gb)]), torch.cat([gb[k].flatten() for k in sorted(gb)])
+    assert float(torch.dot(va, vb) / (va.norm() * vb.norm())) >= 0.999
+    opt = torch.optim.SGD(model.parameters(), lr=0.02)
+    l0, _, _ = run()
+    opt.step()
+    l1, _, _ = run()
+    assert l1 < l0

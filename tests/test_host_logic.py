@@ -89,11 +89,29 @@ def test_build_detector_injects_cfgs_and_checkpoint_roundtrip(tmp_path):
         checkpoint.load_state_dict(other, bad, strict=True)
 
 
-def test_training_forward_is_refused_not_silently_wrong():
-    """the MSeg3D training step does not exist yet (SDSeg3D's does: test_sdseg3d_training_step_*): refused, not approximated"""
-    model = L.build_detector(models_cfg.mseg3d())
-    with pytest.raises(NotImplementedError):
-        model(dict(points=torch.zeros(4, 6)), return_loss=True)
+def test_image_row_sampling_matches_grid_sample_and_its_gradient():
+    """the training path's camera sampling (8 weighted row gathers, all frames at once) == the reference's per-frame 5-D
+    F.grid_sample (point_seg_mseg3d_head.py:200-236), values and d/d(image_features), incl. samples off the map edge"""
+    from lidarseg3d_amd.point_heads import _sample_image_rows
+    gen = torch.Generator().manual_seed(4)
+    B, ncam, C, h, w, n = 2, 3, 5, 7, 9, 64
+    img = torch.randn(B, ncam, C, h, w, generator=gen, dtype=torch.float64, requires_grad=True)
+    cam = torch.randint(0, ncam, (n,), generator=gen).double() / (ncam - 1) * 2 - 1
+    cuv = torch.stack([torch.ones(n, dtype=torch.float64), cam, torch.rand(n, generator=gen).double() * 2.4 - 1.2,
+                       torch.rand(n, generator=gen).double() * 2.4 - 1.2], 1)
+    bidx = torch.sort(torch.randint(0, B, (n,), generator=gen)).values.double()
+    got = _sample_image_rows(img, cuv, bidx)
+    g_got, = torch.autograd.grad(got.square().sum(), img)
+    rows = []
+    for b in range(B):
+        m = bidx == b
+        grid = cuv[m][:, [3, 2, 1]].reshape(1, 1, 1, -1, 3)
+        s_ = torch.nn.functional.grid_sample(img[b].transpose(0, 1).unsqueeze(0), grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        rows.append(s_.reshape(C, -1).t())
+    want = torch.cat(rows, 0)
+    g_want, = torch.autograd.grad(want.square().sum(), img)
+    assert float((got - want).abs().max()) < 1e-12 and float((g_got - g_want).abs().max()) < 1e-12
+    assert float(want.abs().max()) > 0.1
 
 
 def test_c_abi_library_exports_every_declared_symbol():

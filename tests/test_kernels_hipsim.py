@@ -565,3 +565,67 @@ def test_sdseg3d_training_step_runs(monkeypatch):
             assert p.grad is None, k  # feeds nothing the loss sees
         else:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+
+
+def test_mseg3d_head_training_path_vs_reference_golden():
+    """PointSegMSeg3DHead's autograd path (torch modules + HIP neighbour search) in eval mode reproduces the REFERENCE head's
+    logits of the golden fixture (eval BatchNorm is row-wise, so the valid-subset branches agree with the inference path);
+    then the loss (point_seg_mseg3d_head.py:137-196) back-propagates into every parameter and into the camera maps."""
+    from lidarseg3d_amd import models_cfg
+    g = golden("head_mseg3d_nusc.npz")
+    head = point_heads.PointSegMSeg3DHead(False, 17, models_cfg.mseg3d()["point_head"]["model_cfg"])
+    head.load_state_dict(seeded_sd("point_head.PointSegMSeg3DHead", g["seed"]), strict=True)
+    pts = torch.from_numpy(g["points"][:, :4].copy())
+    h, w = (int(v) for v in g["cam_hw"])
+    img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=int(g["cam_seed"]), ncam=6, c_img=48, h=h, w=w, batch=2)
+    cfg = synth.NUSC
+    gen = torch.Generator().manual_seed(1)
+    vf = torch.from_numpy(g["conv_point_features"]).requires_grad_(True)
+    imgt = torch.from_numpy(img).requires_grad_(True)
+    bd = dict(batch_size=2, conv_point_features=vf, conv_point_coords=torch.from_numpy(g["conv_point_coords"]),
+              conv_point_indices=torch.from_numpy(g["coords"]), voxel_geometry=(cfg["voxel_size"], cfg["pc_range"]),
+              points=pts, image_features=imgt, points_cuv=torch.from_numpy(cuv), camera_semantic_embeddings=torch.from_numpy(emb),
+              voxel_sem_labels=torch.randint(0, 17, (vf.shape[0],), generator=gen),
+              point_sem_labels=torch.randint(0, 17, (pts.shape[0],), generator=gen))
+    head.eval()(bd, return_loss=True)
+    r = head.forward_ret_dict
+    np.testing.assert_allclose(r["voxel_logits"].detach().numpy(), g["voxel_logits"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(r["out_logits"].detach().numpy(), g["out_logits"], rtol=0, atol=1e-4)
+    n_valid = int((cuv[:, 0] == 1).sum())
+    assert 0 < n_valid < pts.shape[0] and r["point_features_pcamera"].shape == r["point_features_camera"].shape == (n_valid, 64)
+    loss, parts = head.get_loss()
+    assert set(parts) == {"voxel_ce_loss", "voxel_lovasz_loss", "out_ce_loss", "out_lovasz_loss", "out_mimic_loss"}
+    want = sum(float(v) for v in parts.values())
+    assert abs(float(loss) - want) < 1e-5 * want
+    loss.backward()
+    for k, p in head.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0, k
+    assert float(vf.grad.abs().max()) > 0 and float(imgt.grad.abs().max()) > 0
+    # train mode (batch statistics, the camera branches normalised over the valid rows only) still runs
+    head.train()(bd, return_loss=True)
+    assert bool(torch.isfinite(head.get_loss()[0]))
+
+
+def test_mseg3d_training_step_runs():
+    """SegMSeg3DNet(return_loss=True) in train mode on a tiny two-frame batch: the wiring of the whole step (reader ->
+    UNetSCN3D HIP forward / dgrad / wgrad -> GF-/SF-Phase head under autograd -> losses)"""
+    import lidarseg3d_amd as L
+    from lidarseg3d_amd import models_cfg
+    torch.manual_seed(0)
+    cfgm = models_cfg.mseg3d()
+    cfgm["backbone"]["model_cfg"] = dict(cfgm["backbone"].get("model_cfg", {}), SCALING_RATIO=1)
+    cfgm["point_head"]["model_cfg"] = dict(cfgm["point_head"]["model_cfg"], VOXEL_IN_DIM=16)
+    model = L.build_detector(cfgm, train_cfg=None, test_cfg={}).train()
+    ex = _train_example([80, 40])
+    img, emb, cuv = synth.camera_inputs(ex["points"].shape[0], seed=2, ncam=6, c_img=48, h=8, w=12, batch=2)
+    ex.update(image_features=torch.from_numpy(img), camera_semantic_embeddings=torch.from_numpy(emb), points_cuv=torch.from_numpy(cuv))
+    out = model(dict(ex), return_loss=True)
+    loss = out["loss"][0]
+    loss.backward()
+    assert np.isfinite(float(loss.detach()))
+    assert set(out) == {"loss", "voxel_ce_loss", "voxel_lovasz_loss", "out_ce_loss", "out_lovasz_loss", "out_mimic_loss"}
+    for k, p in model.named_parameters():
+        if k.startswith("backbone.conv_out"):
+            assert p.grad is None, k
+        else:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One SDSeg3D training step (forward + loss + backward + SGD update) on a synthetic 120k-point frame: the reader and the head's
+"""One SDSeg3D (or, --model mseg3d, MSeg3D LiDAR side + fusion head) training step (forward + loss + backward + SGD update) on a synthetic 120k-point frame: the reader and the head's
 MLPs on torch autograd, voxelization / sparse convolutions (forward, dgrad, wgrad) / 3-NN search on the HIP kernels.  Prints one
 JSON line; not the headline benchmark (bench.py is).  SURVEY.md 8f rank 1, single GPU (the gradient all-reduce is torch DDP)."""
 import argparse
@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", choices=["sdseg3d", "mseg3d"], default="sdseg3d")
     ap.add_argument("--ddp", action="store_true", help="wrap the model in DistributedDataParallel (RCCL gradient all-reduce); "
                     "launch with python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... (N = 1 works too)")
     args = ap.parse_args()
@@ -30,7 +31,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     torch.manual_seed(0)
-    model = L.build_detector(models_cfg.sdseg3d(), train_cfg=None, test_cfg={}).to(dev).train()
+    model = L.build_detector(getattr(models_cfg, args.model)(), train_cfg=None, test_cfg={}).to(dev).train()
     net = model
     if args.ddp:
         import torch.distributed as dist
@@ -46,6 +47,10 @@ def main():
     ex = dict(points=pts, voxels=v[:V], coordinates=c[:V], num_points=n[:V], num_voxels=[V],
               shape=[np.asarray(ops.make_grid(cfg["voxel_size"], cfg["pc_range"])[1])],
               voxel_sem_labels=torch.randint(0, 17, (V,), device=dev), point_sem_labels=torch.randint(0, 17, (pts.shape[0],), device=dev))
+    if args.model == "mseg3d":  # camera CNN outputs at the shipped nuScenes config's shapes (6 cameras, 48 channels, 160x240 maps)
+        img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=rank, ncam=6, c_img=48, h=160, w=240, batch=1)
+        ex.update(image_features=torch.from_numpy(img).to(dev), camera_semantic_embeddings=torch.from_numpy(emb).to(dev),
+                  points_cuv=torch.from_numpy(cuv).to(dev))
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
     tf = tb = to = 0.0
     losses = []
@@ -68,7 +73,7 @@ def main():
         tf, tb, to = (float(v) for v in t.tolist())
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"what": "SDSeg3D training step (f32), 1 frame per GPU, %d GPU(s)%s" % (world, ", DDP" if args.ddp else ""),
+        print(json.dumps({"what": args.model + " training step (f32), 1 frame per GPU, %d GPU(s)%s" % (world, ", DDP" if args.ddp else ""),
                           "points": args.points, "active_voxels": V,
                           "forward_ms": 1e3 * tf / k, "backward_ms": 1e3 * tb / k, "optimizer_ms": 1e3 * to / k,
                           "step_ms": 1e3 * (tf + tb + to) / k, "frames_per_s": world * k / (tf + tb + to),
