@@ -623,6 +623,7 @@ def test_mseg3d_training_step_gpu():
     ex.update(image_features=cu(img), camera_semantic_embeddings=cu(emb), points_cuv=cu(cuv))
 
     def run():
+        torch.manual_seed(7)  # the voxel classifier's Dropout(0.25) draws the same mask in every run
         for p in model.parameters():
             p.grad = None
         out = model(dict(ex), return_loss=True)
