@@ -100,6 +100,18 @@ int ls3d_dynamic_scatter(const float *feats_in, int n, int n_feat, const int32_t
                          float *feats_out, int32_t *voxel_coors, int32_t *point2voxel,
                          int32_t *num_voxels_dev, ls3d_stream_t stream);
 
+size_t ls3d_dynamic_scatter_backward_workspace_bytes(int n, int n_feat);
+
+/* Backward of ls3d_dynamic_scatter: grad_points[n,n_feat] from grad_voxels[V,n_feat] and the forward's point2voxel[n].
+ * Replaces voxel_layer.dynamic_point_to_voxel_backward (det3d/ops/voxel/src/voxelization.h:95-110,
+ * scatter_points_cuda.cu:247-282) TOGETHER WITH torch's backward of the mean / max over the padded [V,M,C] tensor
+ * (scatter_points.py:34-50,89-98): mode 0: grad/count to every point of the voxel; mode 1: grad to the first point
+ * (lowest index) whose value equals the reduced value, nothing if only the zero padding attains it (needs the forward's
+ * feats_in[n,n_feat] and feats_out[V,n_feat]; both may be NULL for mode 0).  Points outside (point2voxel < 0) get zeros. */
+int ls3d_dynamic_scatter_backward(const float *grad_voxels, const int32_t *point2voxel, int n, int n_feat, int mode,
+                                  const float *feats_in, const float *feats_out, void *workspace, size_t workspace_bytes,
+                                  float *grad_points, ls3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Voxel feature extractors (readers)
  * ---------------------------------------------------------------------------------------------- */

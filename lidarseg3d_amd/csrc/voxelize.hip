@@ -432,3 +432,65 @@ extern "C" int ls3d_dynamic_scatter(const float *feats_in, int n, int n_feat, co
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ dynamic scatter, backward
+// The reference composes  voxels[V,M,C] = scatter(points)  ->  torch mean / max over M  (scatter_points.py:85-98); its backward is
+// torch's reduce backward followed by map_voxel_to_point_kernel (scatter_points_cuda.cu:247-282).  Fused here: mean sends
+// grad/count to every point of the voxel, max sends grad to the FIRST point (lowest index = lowest slot) that attains the reduced
+// value; if only the zero padding attains it (all points negative, voxel not the fullest) nothing flows.
+__global__ __launch_bounds__(256) void k_dsb_prepare(const float *feats, int n, int C, const int32_t *point2voxel, const float *feats_out,
+                                                    int mode, int32_t *aux) {
+  const long long work = (long long)n * (mode == 0 ? 1 : C);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    if (mode == 0) {
+      const int v = point2voxel[t];
+      if (v >= 0) atomicAdd(&aux[v], 1);
+    } else {
+      const int i = (int)(t / C), c = (int)(t % C);
+      const int v = point2voxel[i];
+      if (v >= 0 && feats[t] == feats_out[(size_t)v * C + c]) atomicMin(&aux[(size_t)v * C + c], i);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dsb_apply(const float *grad_voxels, int n, int C, const int32_t *point2voxel, int mode,
+                                                  const int32_t *aux, float *grad_points) {
+  const long long work = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / C), c = (int)(t % C);
+    const int v = point2voxel[i];
+    float g = 0.0f;
+    if (v >= 0) {
+      const float gv = grad_voxels[(size_t)v * C + c];
+      if (mode == 0) g = __fdiv_rn(gv, (float)aux[v]);
+      else if (aux[(size_t)v * C + c] == i) g = gv;
+    }
+    grad_points[t] = g;
+  }
+}
+
+extern "C" size_t ls3d_dynamic_scatter_backward_workspace_bytes(int n, int n_feat) {
+  return align256((size_t)(n > 0 ? n : 1) * (size_t)(n_feat > 0 ? n_feat : 1) * 4);
+}
+
+extern "C" int ls3d_dynamic_scatter_backward(const float *grad_voxels, const int32_t *point2voxel, int n, int n_feat, int mode,
+                                             const float *feats_in, const float *feats_out, void *workspace, size_t workspace_bytes,
+                                             float *grad_points, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!grad_voxels || !point2voxel || !workspace || !grad_points) return LS3D_ERR_ARG;
+  if (n < 0 || n_feat < 1 || (mode != 0 && mode != 1)) return LS3D_ERR_ARG;
+  if (mode == 1 && (!feats_in || !feats_out)) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  if (workspace_bytes < ls3d_dynamic_scatter_backward_workspace_bytes(n, n_feat)) return LS3D_ERR_WORKSPACE;
+  int32_t *aux = (int32_t *)workspace;
+  const dim3 blk(256);
+  // at most n voxels: counts[n] (mean) or the winning point per (voxel, channel) [n*C] (max), "none" = INT_MAX
+  if (mode == 0) hipMemsetAsync(aux, 0, (size_t)n * 4, stream);
+  else hipMemsetAsync(aux, 0x7F, (size_t)n * n_feat * 4, stream);
+  hipLaunchKernelGGL(k_dsb_prepare, ls3d_grid((long long)n * (mode == 0 ? 1 : n_feat)), blk, 0, stream, feats_in, n, n_feat, point2voxel,
+                     feats_out, mode, aux);
+  hipLaunchKernelGGL(k_dsb_apply, ls3d_grid((long long)n * n_feat), blk, 0, stream, grad_voxels, n, n_feat, point2voxel, mode,
+                     (const int32_t *)aux, grad_points);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

@@ -133,6 +133,18 @@ def dynamic_scatter(feats, coors, shape_zyx, mode="mean"):
     return out, vc, p2v, nv
 
 
+def dynamic_scatter_backward(grad_voxels, p2v, feats_in, feats_out, mode="mean"):
+    """grad of dynamic_scatter's `out` rows w.r.t. the points (include/ls3d.h: ls3d_dynamic_scatter_backward)"""
+    n, c = feats_in.shape
+    gp = torch.empty((n, c), dtype=torch.float32, device=feats_in.device)
+    L = _L()
+    ws = _ws(L.ls3d_dynamic_scatter_backward_workspace_bytes(n, c), feats_in)
+    check(L.ls3d_dynamic_scatter_backward(_ptr(grad_voxels), _ptr(p2v), n, c, 0 if mode == "mean" else 1, _ptr(feats_in), _ptr(feats_out),
+                                          _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(gp), _stream(feats_in)),
+          "ls3d_dynamic_scatter_backward")
+    return gp
+
+
 # ---------------------------------------------------------------------------------------------- readers
 def _ndev(nd):
     return _ptr(nd) if nd is not None else None

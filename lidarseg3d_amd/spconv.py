@@ -138,7 +138,23 @@ class SparseConvolution(PackedModule, SparseModule):
             nn.init.uniform_(self.bias, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
 
     def _pack(self):
-        return pack_spconv(self.weight)
+        return {self._kvol(): pack_spconv(self.weight)}
+
+    def _kvol(self):
+        return self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+
+    def _weight_for(self, rb):
+        """spconv v1 semantics when layers of DIFFERENT kernel shapes share an indice_key (Cylinder3D's blocks do: a (1,3,3), a
+        (3,1,3) and a 3x3x3 SubMConv3d under one key): the pairs stored by the first layer are used as they are, with the first
+        `stored kernel volume` filters of this layer's weight viewed as [-1, Cin, Cout] (spconv v1.2.1 ops.indice_conv: the kernel
+        volume is the pair table's, the filters are `weight.view(-1, Cin, Cout)`).  None = this layer's own weight fits."""
+        k = (rb.tbl_inv if self.inverse else rb.tbl).shape[1]
+        if k == self._kvol():
+            return None
+        if k > self._kvol():
+            raise ValueError("indice_key %r holds a rulebook of %d kernel offsets; this layer has only %d filters"
+                             % (self.indice_key, k, self._kvol()))
+        return self.weight.reshape(self._kvol(), self.in_channels, self.out_channels)[:k].reshape(k, 1, 1, self.in_channels, self.out_channels)
 
     # ---- rulebooks (shared through indice_key exactly like spconv's indice_dict)
     def rulebook(self, x):
@@ -169,7 +185,11 @@ class SparseConvolution(PackedModule, SparseModule):
     def conv(self, x, rb, scale=None, shift=None, relu=False, res_pre=None, pair=None, out=None, out_ld=None):
         """the gather-GEMM with a fused epilogue; x: SparseConvTensor or a feature matrix on rb's input sites"""
         feats = x.features if isinstance(x, SparseConvTensor) else x
-        W, _, _, cout = self.packed()
+        pk, k = self.packed(), (rb.tbl_inv if self.inverse else rb.tbl).shape[1]
+        if k not in pk:
+            with torch.no_grad():
+                pk[k] = pack_spconv(self._weight_for(rb))
+        W, _, _, cout = pk[k]
         if self.bias is not None:
             b = self.bias.detach()
             shift = b if shift is None else shift + (b * (scale if scale is not None else 1.0))
@@ -184,7 +204,8 @@ class SparseConvolution(PackedModule, SparseModule):
     def forward(self, x):
         rb = self.rulebook(x)
         if torch.is_grad_enabled() and (x.features.requires_grad or (self.training and self.weight.requires_grad)):
-            f = _SparseConvFn.apply(x.features, self.weight, self.bias, rb, bool(self.inverse), bool(self.subm))
+            w = self._weight_for(rb)
+            f = _SparseConvFn.apply(x.features, self.weight if w is None else w, self.bias, rb, bool(self.inverse), bool(self.subm))
         else:
             f = self.conv(x, rb)
         if self.inverse:

@@ -30,6 +30,26 @@ class Voxelization(nn.Module):
             type(self).__name__, self.voxel_size, self.point_cloud_range, self.max_num_points, self.max_voxels)
 
 
+class _DynamicScatterFn(torch.autograd.Function):
+    """the fused DynamicScatter with its backward (the reference: _dynamic_scatter + torch mean/max, scatter_points.py:9-50,85-98)"""
+
+    @staticmethod
+    def forward(ctx, points, coors, shape_zyx, mode):
+        pts = points.detach().contiguous()
+        f, vc, p2v, nv = ops.dynamic_scatter(pts, coors, shape_zyx, mode)
+        k = int(nv.item())  # host sync: the number of voxels is a tensor shape
+        f, vc = f[:k], vc[:k]
+        ctx.save_for_backward(pts, f, p2v)
+        ctx.mode = mode
+        ctx.mark_non_differentiable(vc)
+        return f, vc
+
+    @staticmethod
+    def backward(ctx, grad_f, grad_vc=None):
+        pts, f, p2v = ctx.saved_tensors
+        return ops.dynamic_scatter_backward(grad_f.contiguous(), p2v, pts, f, ctx.mode), None, None, None
+
+
 class DynamicScatter(nn.Module):
     def __init__(self, voxel_size, point_cloud_range, average_points: bool):
         super().__init__()
@@ -39,10 +59,7 @@ class DynamicScatter(nn.Module):
 
     def forward(self, points, coors):
         """points [N,C], coors [N,3] (z,y,x) or [N,4] (batch,z,y,x) -> (features [V,C], coors [V,3|4])"""
-        f, vc, _, nv = ops.dynamic_scatter(points.contiguous(), coors.int().contiguous(), self.shape_zyx,
-                                           "mean" if self.average_points else "max")
-        k = int(nv.item())
-        return f[:k], vc[:k]
+        return _DynamicScatterFn.apply(points, coors.int().contiguous(), self.shape_zyx, "mean" if self.average_points else "max")
 
     def __repr__(self):
         return "%s(voxel_size=%s, point_cloud_range=%s, average_points=%s)" % (

@@ -62,6 +62,28 @@ def test_dynamic_scatter(tag):
     np.testing.assert_array_equal(f[:V].cpu().numpy(), g["cpp_scatter_voxels"].max(1))
 
 
+@pytest.mark.parametrize("average", [True, False])
+def test_dynamic_scatter_backward(average):
+    """DynamicScatter under autograd on the GPU vs the reference's padded-tensor composition differentiated by torch on the CPU"""
+    from lidarseg3d_amd import voxel_ops
+    g = golden("voxelize_kitti.npz")
+    pts = g["points"].copy()
+    pts[:, 3] = -np.abs(pts[:, 3]) - 0.5
+    a = torch.from_numpy(pts).requires_grad_(True)
+    vox, num = orc.dynamic_scatter_padded(a, g["cpp_dyn_coors"], g["voxel_size"], g["pc_range"])
+    want = vox.sum(1) / num[:, None] if average else vox.max(1)[0]
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(5))
+    ga, = torch.autograd.grad(want, a, gout)
+    b = cu(pts).requires_grad_(True)
+    f, vc = voxel_ops.DynamicScatter(list(g["voxel_size"]), list(g["pc_range"]), average)(b, cu(g["cpp_dyn_coors"]))
+    assert np.array_equal(vc.cpu().numpy(), g["cpp_scatter_coors"])
+    gb, = torch.autograd.grad(f, b, gout.to(DEV))
+    if average:
+        np.testing.assert_allclose(gb.cpu().numpy(), ga.numpy(), rtol=1e-6, atol=1e-7)
+    else:
+        np.testing.assert_array_equal(gb.cpu().numpy(), ga.numpy())
+
+
 def test_vfe_readers():
     g = golden("vfe_nusc.npz")
     vx, num = cu(g["voxels"]), cu(g["num"])

@@ -73,6 +73,38 @@ def test_dynamic_scatter_vs_reference_cpp():
     np.testing.assert_array_equal(f[:V].numpy(), g["cpp_scatter_voxels"].max(1))
 
 
+@pytest.mark.parametrize("average", [True, False])
+def test_dynamic_scatter_backward_vs_reference_composition(average):
+    """voxel_ops.DynamicScatter under autograd == the reference's composition (padded [V,M,C] tensor, pinned here against the
+    compiled reference's forward output, then torch mean / max) differentiated by torch; incl. points outside the range,
+    negative-only channels (the zero padding wins the max: no gradient) and exact ties (first point wins)"""
+    from lidarseg3d_amd import voxel_ops
+    g = golden("voxelize_nusc.npz")
+    pts = g["points"].copy()
+    pts[:, 3] = -np.abs(pts[:, 3]) - 0.5     # a channel that is negative everywhere: padded voxels reduce to 0 under max
+    pts[:, 4] = np.round(pts[:, 4])          # many exact ties inside a voxel
+    coors = g["cpp_dyn_coors"]
+    a = torch.from_numpy(pts).requires_grad_(True)
+    vox, num = orc.dynamic_scatter_padded(a, coors, g["voxel_size"], g["pc_range"])
+    np.testing.assert_array_equal(vox.detach().numpy()[:, :, :3], g["cpp_scatter_voxels"][:, :, :3])  # the reference's own padded tensor
+    want = vox.sum(1) / num[:, None] if average else vox.max(1)[0]
+    gen = torch.Generator().manual_seed(5)
+    gout = torch.randn(want.shape, generator=gen)
+    ga, = torch.autograd.grad(want, a, gout)
+    b = torch.from_numpy(pts).requires_grad_(True)
+    mod = voxel_ops.DynamicScatter(list(g["voxel_size"]), list(g["pc_range"]), average)
+    f, vc = mod(b, torch.from_numpy(coors))
+    assert np.array_equal(vc.numpy(), g["cpp_scatter_coors"]) and not vc.requires_grad
+    np.testing.assert_allclose(f.detach().numpy(), want.detach().numpy(), rtol=2e-6, atol=1e-6)
+    gb, = torch.autograd.grad(f, b, gout)
+    if average:
+        np.testing.assert_allclose(gb.numpy(), ga.numpy(), rtol=1e-6, atol=1e-7)
+    else:
+        np.testing.assert_array_equal(gb.numpy(), ga.numpy())
+        assert float(gb[:, 3].abs().sum()) < float(gout[:, 3].abs().sum())  # some voxels' gradient went to the padding
+    assert (gb[torch.from_numpy((coors < 0).any(1))] == 0).all()
+
+
 def test_rulebooks_bit_exact_vs_oracle_all_levels():
     g = golden("unet_nusc_c13.npz")
     coords = torch.from_numpy(g["coords"])

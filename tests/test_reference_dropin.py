@@ -1,7 +1,8 @@
 """Drop-in check in the build container: the REFERENCE's own backbone files (det3d/models/backbones/scn_unet.py, scn.py),
 imported unmodified from /root/reference, run on `lidarseg3d_amd.spconv` (kernels on tests/hipsim) and on the oracle's spconv
 restatement, and must agree.  This is what "import lidarseg3d_amd.spconv as spconv" in INTEGRATION.md promises; it also covers
-SpMiddleResNetFHD (other sparse backbones on the same kernels, no new kernel classes).
+SpMiddleResNetFHD and the Cylinder3D backbones with their asymmetric (1,3,3)/(3,1,3)/(3,1,1)/... kernels and shared indice_keys
+(other sparse backbones on the same kernels, no new kernel classes).
 Skipped where /root/reference does not exist (the GPU box)."""
 import importlib.util
 import os
@@ -128,3 +129,63 @@ def test_reference_spmiddleresnetfhd_file_runs_on_our_spconv(harness):
     for k in ma:
         assert torch.equal(ma[k].indices.int(), mb[k].indices.int()), k
         assert float((ma[k].features - mb[k].features).abs().max()) <= 1e-5 * float(ma[k].features.abs().max()) + 1e-4, k
+
+
+def _cyl_inputs(n, cin, seed=0):
+    """voxels of a small two-frame cloud in a cylinder-style grid (z,y,x) = (rho, phi, height)-like extents"""
+    gen = np.random.default_rng(seed)
+    shape = np.array([16, 48, 40])  # input_shape is (x,y,z)-ordered in batch_dict; the backbones flip it
+    box = np.array([8, 12, 10])  # occupied sub-box: ~27 % full, so every kernel offset of every shape has pairs
+    lin = gen.choice(box.prod(), size=n, replace=False)
+    x, y, z = lin % box[0] + 3, (lin // box[0]) % box[1] + 17, lin // (box[0] * box[1]) + 11
+    b = (np.arange(n) >= n * 2 // 3).astype(np.int64)
+    coords = torch.from_numpy(np.stack([b, z, y, x], 1).astype(np.int32))
+    feats = torch.from_numpy(gen.normal(size=(n, cin)).astype(np.float32))
+    return coords, feats, shape
+
+
+def test_reference_unetcylinder3d_file_runs_on_our_spconv(harness):
+    """UNetCylinder3D (scn_unet_cylinder3d.py:257-335): asymmetric SubM kernels, several kernel shapes under ONE indice_key
+    (the stored pairs of the first layer are reused, spconv v1 semantics), stride-(2,2,1) pooling convs and their inverses,
+    features assigned in place between layers"""
+    import lidarseg3d_amd.spconv as ours
+    shim, load = harness
+    coords, feats, shape = _cyl_inputs(260, 16)
+    outs, sd = {}, None
+    for tag, sp in (("oracle", shim), ("ours", ours)):
+        m = load("scn_unet_cylinder3d", sp, tag)
+        torch.manual_seed(0)
+        net = m.UNetCylinder3D(num_input_features=16, voxel_size=[0.2, 0.2, 0.2], point_cloud_range=[0, 0, 0, 3.2, 9.6, 8.0],
+                               model_cfg=dict(init_size=8)).eval()
+        if sd is None:
+            sd = _randomise_bn({k: v.clone() for k, v in net.state_dict().items()}, 3)
+        net.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            outs[tag] = net(dict(voxel_features=feats.clone(), voxel_coords=coords, batch_size=2, input_shape=shape))
+    a, b = outs["oracle"], outs["ours"]
+    assert torch.equal(a["conv_point_coords"], b["conv_point_coords"])
+    fa, fb = a["conv_point_features"], b["conv_point_features"]
+    assert tuple(fa.shape) == (260, 32) and float(fa.abs().max()) > 1e-3
+    assert float((fa - fb).abs().max()) <= 1e-5 * float(fa.abs().max()) + 1e-4
+
+
+def test_reference_cylinder3d_asymm_file_runs_on_our_spconv(harness):
+    """Cylinder3D_Asymm_3d_spconv (cylinder3d_backbone.py:254-338): the same asymmetric blocks + a biased 3x3x3 SubM logits
+    layer + SparseConvTensor.dense()"""
+    import lidarseg3d_amd.spconv as ours
+    shim, load = harness
+    coords, feats, shape = _cyl_inputs(240, 16, seed=1)
+    outs, sd = {}, None
+    for tag, sp in (("oracle", shim), ("ours", ours)):
+        m = load("cylinder3d_backbone", sp, tag)
+        torch.manual_seed(0)
+        net = m.Cylinder3D_Asymm_3d_spconv(output_shape=[int(v) for v in shape], num_input_features=16, nclasses=7, init_size=8).eval()
+        if sd is None:
+            sd = _randomise_bn({k: v.clone() for k, v in net.state_dict().items()}, 4)
+            sd["logits.bias"] = torch.linspace(-1, 1, 7)
+        net.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            outs[tag] = net(dict(voxel_features=feats.clone(), voxel_coords=coords, batch_size=2))["voxel_features"]
+    a, b = outs["oracle"], outs["ours"]
+    assert tuple(a.shape) == tuple(b.shape) == (2, 7, 16, 48, 40) and float(a.abs().max()) > 1e-3
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-4
