@@ -112,6 +112,16 @@ int ls3d_dynamic_scatter_backward(const float *grad_voxels, const int32_t *point
                                   const float *feats_in, const float *feats_out, void *workspace, size_t workspace_bytes,
                                   float *grad_points, ls3d_stream_t stream);
 
+size_t ls3d_segment_reduce_workspace_bytes(int n_seg);
+
+/* Segment mean / max over dim 0: out[n_seg,n_feat] from src[n,n_feat] and one int64 segment id per row (mode 0 = mean,
+ * 1 = max with arg_out[n_seg,n_feat] = lowest row index attaining it, may be NULL).  Segments without rows give 0 (arg = n).
+ * Replaces torch_scatter.scatter_mean / scatter_max as the dynamic readers call them with torch.unique's inverse
+ * (det3d/models/readers/voxel_encoder.py:366-372,451-456,594-600,682-686; torch_scatter itself is a third-party
+ * dependency absent from the reference tree).  Ids outside [0, n_seg) are skipped. */
+int ls3d_segment_reduce(const float *src, const int64_t *index, int n, int n_feat, int n_seg, int mode, void *workspace,
+                        size_t workspace_bytes, float *out, int64_t *arg_out, ls3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Voxel feature extractors (readers)
  * ---------------------------------------------------------------------------------------------- */

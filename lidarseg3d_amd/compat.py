@@ -6,6 +6,7 @@
     import spconv                                     # -> lidarseg3d_amd.spconv (v1-shaped namespace)
     from det3d.ops.pointnet2_batch import pointnet2_utils
     from det3d.ops.voxel import Voxelization, DynamicScatter
+    import torch_scatter                              # -> lidarseg3d_amd.scatter, only when torch_scatter is not installed
 
 Only the hot-path surface is provided; asking for anything else raises ImportError as usual.  Refuses to install over
 a real `det3d` / `spconv` already imported."""
@@ -50,6 +51,11 @@ def install(force=False):
     mod("det3d.models.img_heads.fcn_mseg3d_head", CameraSemanticFeatureAggregationModule=img_heads.CameraSemanticFeatureAggregationModule)
     sys.modules["spconv"] = spconv
     spconv.__ls3d_alias__ = True
+    try:  # the dynamic readers' scatter_mean / scatter_max
+        import torch_scatter  # noqa: F401
+    except ImportError:
+        from . import scatter
+        sys.modules["torch_scatter"] = scatter
     try:  # the reference's config files do `from addict.addict import Dict` only to have it in scope
         import addict  # noqa: F401
     except ImportError:

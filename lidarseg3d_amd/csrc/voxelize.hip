@@ -494,3 +494,76 @@ extern "C" int ls3d_dynamic_scatter_backward(const float *grad_voxels, const int
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ segment reductions
+// What the dynamic readers (det3d/models/readers/voxel_encoder.py:366-372,451-456,594-600,682-686) ask of torch_scatter
+// (third-party, absent from the reference tree: scatter_mean / scatter_max over dim 0 with an int64 segment id per row, e.g.
+// torch.unique's inverse).  out[n_seg,C]; segments without rows give 0 (and arg = n), as torch_scatter does.
+// mean: f32 atomicAdd (run-to-run summation order, like torch_scatter's CUDA path) / count; max: order-preserving integer atomicMax,
+// arg = the LOWEST row index attaining it (torch_scatter leaves ties to a race).
+__global__ __launch_bounds__(256) void k_seg_accum(const float *src, const int64_t *index, int n, int C, int n_seg, int mode, float *out,
+                                                  int32_t *counts, int32_t *bad) {
+  const long long work = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / C), c = (int)(t % C);
+    const int64_t sg = index[i];
+    if (sg < 0 || sg >= n_seg) { *bad = 1; continue; }
+    if (mode == 0) atomicAdd(&out[(size_t)sg * C + c], src[t]);
+    else atomicMax((int *)&out[(size_t)sg * C + c], f2ord(src[t]));
+    if (c == 0) atomicAdd(&counts[sg], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_seg_finish(float *out, int n_seg, int C, int mode, const int32_t *counts) {
+  const long long work = (long long)n_seg * C;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int cnt = counts[t / C];
+    if (mode == 0) out[t] = cnt > 0 ? __fdiv_rn(out[t], (float)cnt) : 0.0f;
+    else out[t] = cnt > 0 ? ord2f(((int *)out)[t]) : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_seg_arg(const float *src, const int64_t *index, int n, int C, int n_seg, const float *out,
+                                                unsigned long long *arg) {
+  const long long work = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / C), c = (int)(t % C);
+    const int64_t sg = index[i];
+    if (sg < 0 || sg >= n_seg) continue;
+    if (src[t] == out[(size_t)sg * C + c]) atomicMin(&arg[(size_t)sg * C + c], (unsigned long long)i);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fill_u64(unsigned long long *p, long long n, unsigned long long v) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) p[t] = v;
+}
+
+extern "C" size_t ls3d_segment_reduce_workspace_bytes(int n_seg) { return align256((size_t)(n_seg > 0 ? n_seg : 1) * 4) + 256; }
+
+extern "C" int ls3d_segment_reduce(const float *src, const int64_t *index, int n, int n_feat, int n_seg, int mode, void *workspace,
+                                   size_t workspace_bytes, float *out, int64_t *arg_out, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!out || !workspace || n < 0 || n_feat < 1 || n_seg < 0 || (mode != 0 && mode != 1)) return LS3D_ERR_ARG;
+  if (n > 0 && (!src || !index)) return LS3D_ERR_ARG;
+  if (n_seg == 0) return LS3D_OK;
+  if (workspace_bytes < ls3d_segment_reduce_workspace_bytes(n_seg)) return LS3D_ERR_WORKSPACE;
+  int32_t *counts = (int32_t *)workspace;
+  int32_t *bad = (int32_t *)((char *)workspace + align256((size_t)n_seg * 4));
+  const dim3 blk(256);
+  const long long cells = (long long)n_seg * n_feat;
+  hipMemsetAsync(counts, 0, (size_t)n_seg * 4, stream);
+  hipMemsetAsync(bad, 0, 4, stream);
+  if (mode == 0) hipMemsetAsync(out, 0, (size_t)cells * 4, stream);
+  else hipLaunchKernelGGL(k_fill_i32, ls3d_grid(cells), blk, 0, stream, (int32_t *)out, cells, (int32_t)0x80000000);
+  if (n > 0)
+    hipLaunchKernelGGL(k_seg_accum, ls3d_grid((long long)n * n_feat), blk, 0, stream, src, index, n, n_feat, n_seg, mode, out, counts, bad);
+  hipLaunchKernelGGL(k_seg_finish, ls3d_grid(cells), blk, 0, stream, out, n_seg, n_feat, mode, (const int32_t *)counts);
+  if (mode == 1 && arg_out) {
+    hipLaunchKernelGGL(k_fill_u64, ls3d_grid(cells), blk, 0, stream, (unsigned long long *)arg_out, cells, (unsigned long long)n);
+    if (n > 0)
+      hipLaunchKernelGGL(k_seg_arg, ls3d_grid((long long)n * n_feat), blk, 0, stream, src, index, n, n_feat, n_seg, (const float *)out,
+                         (unsigned long long *)arg_out);
+  }
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

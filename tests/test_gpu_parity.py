@@ -84,6 +84,27 @@ def test_dynamic_scatter_backward(average):
         np.testing.assert_array_equal(gb.cpu().numpy(), ga.numpy())
 
 
+def test_segment_reduce_gpu():
+    """scatter_mean / scatter_max (torch_scatter signatures) at reader size: 120k rows x 64 channels into ~40k segments"""
+    from lidarseg3d_amd import scatter
+    gen = torch.Generator().manual_seed(3)
+    n, c, n_seg = 120000, 64, 40000
+    src = torch.randn(n, c, generator=gen)
+    index = torch.randint(0, n_seg - 100, (n,), generator=gen)
+    mean = torch.zeros((n_seg, c), dtype=torch.float64).index_add_(0, index, src.double())
+    cnt = torch.zeros((n_seg,), dtype=torch.float64).index_add_(0, index, torch.ones(n, dtype=torch.float64))
+    got = scatter.scatter_mean(src.to(DEV), index.to(DEV), dim=0, dim_size=n_seg).cpu()
+    np.testing.assert_allclose(got.numpy(), (mean / cnt.clamp(min=1)[:, None]).float().numpy(), rtol=1e-5, atol=1e-6)
+    mx = torch.full((n_seg, c), float("-inf")).scatter_reduce(0, index[:, None].expand(n, c), src, "amax", include_self=True)
+    got, arg = scatter.scatter_max(src.to(DEV), index.to(DEV), dim=0, dim_size=n_seg)
+    got, arg = got.cpu(), arg.cpu()
+    assert torch.equal(got, torch.where(torch.isinf(mx), torch.zeros(()), mx))
+    live = cnt > 0
+    assert bool((arg[~live] == n).all())
+    assert torch.equal(src[arg[live], torch.arange(c)[None, :].expand(int(live.sum()), c)], got[live])  # arg points at the max
+    assert torch.equal(index[arg[live]], torch.nonzero(live)[:, 0][:, None].expand(-1, c))            # ... inside its own segment
+
+
 def test_vfe_readers():
     g = golden("vfe_nusc.npz")
     vx, num = cu(g["voxels"]), cu(g["num"])

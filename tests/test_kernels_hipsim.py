@@ -105,6 +105,45 @@ def test_dynamic_scatter_backward_vs_reference_composition(average):
     assert (gb[torch.from_numpy((coors < 0).any(1))] == 0).all()
 
 
+def _segment_reference(src, index, n_seg, mode):
+    """torch restatement of torch_scatter's dim-0 reductions (empty segments -> 0, arg -> n)"""
+    n, c = src.shape
+    if mode == "mean":
+        out = torch.zeros((n_seg, c), dtype=torch.float64).index_add_(0, index, src.double())
+        cnt = torch.zeros((n_seg,), dtype=torch.float64).index_add_(0, index, torch.ones(n, dtype=torch.float64))
+        return (out / cnt.clamp(min=1)[:, None]).float(), None
+    out = torch.full((n_seg, c), float("-inf")).scatter_reduce(0, index[:, None].expand(n, c), src, "amax", include_self=True)
+    hit = src == out[index]
+    rows = torch.arange(n)[:, None].expand(n, c)
+    arg = torch.full((n_seg, c), n, dtype=torch.int64).scatter_reduce(0, index[:, None].expand(n, c), torch.where(hit, rows, n), "amin")
+    return torch.where(torch.isinf(out), torch.zeros(()), out), arg
+
+
+def test_segment_reduce_and_torch_scatter_signatures():
+    from lidarseg3d_amd import scatter
+    gen = torch.Generator().manual_seed(3)
+    n, c, n_seg = 3000, 7, 220
+    src = torch.randn(n, c, generator=gen)
+    src[:, 2] = torch.round(src[:, 2])  # ties
+    index = torch.randint(0, n_seg - 15, (n,), generator=gen)  # the last 15 segments stay empty
+    index[index == 5] = 6                                       # and one in the middle
+    want_mean, _ = _segment_reference(src, index, n_seg, "mean")
+    want_max, want_arg = _segment_reference(src, index, n_seg, "max")
+    got = scatter.scatter_mean(src, index, dim=0, dim_size=n_seg)
+    np.testing.assert_allclose(got.numpy(), want_mean.numpy(), rtol=1e-5, atol=1e-6)
+    got, arg = scatter.scatter_max(src, index, dim=0, dim_size=n_seg)
+    assert torch.equal(got, want_max) and torch.equal(arg, want_arg)
+    assert float(got[5].abs().max()) == 0 and bool((arg[5] == n).all()) and bool((arg[-1] == n).all())
+    # dim_size inferred; 1-D int64 values (the majority-vote label path, voxel_encoder.py:419-421)
+    cnt = torch.randint(1, 50, (n,), generator=gen)
+    v, a = scatter.scatter_max(cnt, index)
+    assert v.dtype == torch.int64 and v.shape == (int(index.max()) + 1,)
+    w, wa = _segment_reference(cnt.float()[:, None], index, int(index.max()) + 1, "max")
+    assert torch.equal(v, w[:, 0].long()) and torch.equal(a, wa[:, 0])
+    with pytest.raises(NotImplementedError):
+        scatter.scatter_mean(src, index, dim=1)
+
+
 def test_rulebooks_bit_exact_vs_oracle_all_levels():
     g = golden("unet_nusc_c13.npz")
     coords = torch.from_numpy(g["coords"])

@@ -189,3 +189,43 @@ def test_reference_cylinder3d_asymm_file_runs_on_our_spconv(harness):
     a, b = outs["oracle"], outs["ours"]
     assert tuple(a.shape) == tuple(b.shape) == (2, 7, 16, 48, 40) and float(a.abs().max()) > 1e-3
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("average", [True, False])
+def test_reference_cylinder3d_dynamic_reader_runs_on_our_scatter(harness, average):
+    """Cylinder3DDynamicVoxelFeatureExtractor (voxel_encoder.py:504-720), the reference's file unmodified, with `torch_scatter`
+    = lidarseg3d_amd.scatter (kernels on the simulator) vs `torch_scatter` = the oracle's torch restatement: cylindrical
+    voxelization, per-voxel mean for the point descriptor, the point MLP, mean / max pooling per voxel, majority-vote labels"""
+    import types
+    from lidarseg3d_amd import scatter as ours, synth
+    from oracle import ref as orc
+    oracle_ts = types.ModuleType("torch_scatter")
+    oracle_ts.scatter_mean, oracle_ts.scatter_max = orc.scatter_mean, orc.scatter_max
+    cfg = synth.NUSC
+    frames = [synth.lidar_frame(900, seed=3, **cfg), synth.lidar_frame(500, seed=4, **cfg)]
+    pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)]))
+    labels = torch.randint(0, 17, (pts.shape[0],), generator=torch.Generator().manual_seed(1))
+    outs, sd = {}, None
+    for tag, ts in (("oracle", oracle_ts), ("ours", ours)):
+        sys.modules["torch_scatter"] = ts
+        sys.modules["det3d.models.registry"].READERS._module_dict.clear()
+        name = "det3d.models.readers.voxel_encoder__" + tag
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "det3d/models/readers/voxel_encoder.py"))
+        m = importlib.util.module_from_spec(spec)
+        m.__package__ = "det3d.models.readers"
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        torch.manual_seed(0)
+        net = m.Cylinder3DDynamicVoxelFeatureExtractor(grid_size=[48, 36, 8], point_cloud_range=[0, -3.1415926, -5, 50, 3.1415926, 3],
+                                                       average_points=average, num_input_features=5, num_output_features=32,
+                                                       fea_compre=16, voxel_label_enc="major").eval()
+        if sd is None:
+            sd = _randomise_bn({k: v.clone() for k, v in net.state_dict().items()}, 5)
+        net.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            outs[tag] = net(dict(points=pts.clone(), batch_size=2, point_sem_labels=labels.clone()))
+    a, b = outs["oracle"], outs["ours"]
+    assert torch.equal(a["voxel_coords"], b["voxel_coords"]) and torch.equal(a["point_vcoors"], b["point_vcoors"])
+    assert a["voxel_features"].shape[1] == 16 and a["voxel_features"].shape[0] == a["voxel_coords"].shape[0] > 100
+    assert float((a["voxel_features"] - b["voxel_features"]).abs().max()) <= 1e-5 * float(a["voxel_features"].abs().max()) + 1e-5
+    assert torch.equal(a["voxel_sem_labels"], b["voxel_sem_labels"])
