@@ -15,7 +15,7 @@ _ERR = {-1: "LS3D_ERR_ARG", -2: "LS3D_ERR_LAUNCH", -3: "LS3D_ERR_UNSUPPORTED", -
 
 EXPORTS = [
     "ls3d_version", "ls3d_voxelize_dynamic", "ls3d_voxelize_hard_workspace_bytes", "ls3d_voxelize_hard",
-    "ls3d_dynamic_scatter_workspace_bytes", "ls3d_dynamic_scatter", "ls3d_dynamic_scatter_backward_workspace_bytes", "ls3d_segment_reduce_workspace_bytes",
+    "ls3d_dynamic_scatter_workspace_bytes", "ls3d_dynamic_scatter", "ls3d_dynamic_scatter_backward_workspace_bytes",
     "ls3d_dynamic_scatter_backward", "ls3d_segment_reduce_workspace_bytes", "ls3d_segment_reduce", "ls3d_vfe_mean", "ls3d_vfe_improved_mean",
     "ls3d_vfe_tokens", "ls3d_transvfe", "ls3d_mha_core", "ls3d_group_max", "ls3d_layernorm", "ls3d_index_build",
     "ls3d_rulebook_subm", "ls3d_rulebook_conv_workspace_bytes", "ls3d_rulebook_conv", "ls3d_rulebook_masks", "ls3d_rulebook_sort_keys", "ls3d_segment_local_index", "ls3d_gather_gemm", "ls3d_gather_gemm_pack", "ls3d_gather_gemm_packed_floats", "ls3d_gather_gemm_default_nt", "ls3d_spconv_wgrad_workspace_bytes", "ls3d_spconv_wgrad", "ls3d_set_xcd_map", "ls3d_set_gather_pipeline",
