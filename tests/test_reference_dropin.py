@@ -191,8 +191,9 @@ def test_reference_cylinder3d_asymm_file_runs_on_our_spconv(harness):
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-4
 
 
+@pytest.mark.parametrize("cls", ["Cylinder3DDynamicVoxelFeatureExtractor", "PolarNetDynamicVoxelFeatureExtractor"])
 @pytest.mark.parametrize("average", [True, False])
-def test_reference_cylinder3d_dynamic_reader_runs_on_our_scatter(harness, average):
+def test_reference_dynamic_readers_run_on_our_scatter(harness, average, cls):
     """Cylinder3DDynamicVoxelFeatureExtractor (voxel_encoder.py:504-720), the reference's file unmodified, with `torch_scatter`
     = lidarseg3d_amd.scatter (kernels on the simulator) vs `torch_scatter` = the oracle's torch restatement: cylindrical
     voxelization, per-voxel mean for the point descriptor, the point MLP, mean / max pooling per voxel, majority-vote labels"""
@@ -216,7 +217,7 @@ def test_reference_cylinder3d_dynamic_reader_runs_on_our_scatter(harness, averag
         sys.modules[name] = m
         spec.loader.exec_module(m)
         torch.manual_seed(0)
-        net = m.Cylinder3DDynamicVoxelFeatureExtractor(grid_size=[48, 36, 8], point_cloud_range=[0, -3.1415926, -5, 50, 3.1415926, 3],
+        net = getattr(m, cls)(grid_size=[48, 36, 8], point_cloud_range=[0, -3.1415926, -5, 50, 3.1415926, 3],
                                                        average_points=average, num_input_features=5, num_output_features=32,
                                                        fea_compre=16, voxel_label_enc="major").eval()
         if sd is None:
@@ -225,7 +226,11 @@ def test_reference_cylinder3d_dynamic_reader_runs_on_our_scatter(harness, averag
         with torch.no_grad():
             outs[tag] = net(dict(points=pts.clone(), batch_size=2, point_sem_labels=labels.clone()))
     a, b = outs["oracle"], outs["ours"]
-    assert torch.equal(a["voxel_coords"], b["voxel_coords"]) and torch.equal(a["point_vcoors"], b["point_vcoors"])
-    assert a["voxel_features"].shape[1] == 16 and a["voxel_features"].shape[0] == a["voxel_coords"].shape[0] > 100
+    assert torch.equal(a["point_vcoors"], b["point_vcoors"])
+    if cls.startswith("PolarNet"):  # dense BEV map [B, C, rho, phi] out of the per-pillar features
+        assert tuple(a["voxel_features"].shape) == (2, 16, 48, 36) and float(a["voxel_features"].abs().max()) > 1e-3
+    else:
+        assert torch.equal(a["voxel_coords"], b["voxel_coords"])
+        assert a["voxel_features"].shape[1] == 16 and a["voxel_features"].shape[0] == a["voxel_coords"].shape[0] > 100
     assert float((a["voxel_features"] - b["voxel_features"]).abs().max()) <= 1e-5 * float(a["voxel_features"].abs().max()) + 1e-5
     assert torch.equal(a["voxel_sem_labels"], b["voxel_sem_labels"])
