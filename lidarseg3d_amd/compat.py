@@ -42,6 +42,8 @@ def install(force=False):
     mod("det3d.models.builder", **builders)
     det3d.torchie = mod("det3d.torchie", Config=config.Config, is_str=lambda x: isinstance(x, str))
     mod("det3d.torchie.trainer", load_checkpoint=checkpoint.load_checkpoint)
+    from . import collate
+    mod("det3d.torchie.parallel", collate_kitti=collate.collate_kitti)
     det3d.ops = mod("det3d.ops")
     mod("det3d.ops.pointnet2_batch", pointnet2_utils=pointnet2_utils)
     sys.modules["det3d.ops.pointnet2_batch.pointnet2_utils"] = pointnet2_utils

@@ -234,3 +234,47 @@ def test_reference_dynamic_readers_run_on_our_scatter(harness, average, cls):
         assert a["voxel_features"].shape[1] == 16 and a["voxel_features"].shape[0] == a["voxel_coords"].shape[0] > 100
     assert float((a["voxel_features"] - b["voxel_features"]).abs().max()) <= 1e-5 * float(a["voxel_features"].abs().max()) + 1e-5
     assert torch.equal(a["voxel_sem_labels"], b["voxel_sem_labels"])
+
+
+def test_collate_kitti_equals_reference_on_segmentation_keys(harness):
+    """lidarseg3d_amd.collate.collate_kitti vs the reference's function (torchie/parallel/collate.py:91-170), imported
+    unmodified, on per-frame examples shaped like the segmentation pipeline's output (incl. a TTA list-of-variants frame)"""
+    import types
+    from lidarseg3d_amd import collate as ours
+    dc = types.ModuleType("det3d.torchie.parallel.data_container")
+    dc.DataContainer = type("DataContainer", (), {})
+    for name in ("det3d.torchie.parallel",):
+        pk = types.ModuleType(name)
+        pk.__path__ = []
+        sys.modules[name] = pk
+    sys.modules["det3d.torchie.parallel.data_container"] = dc
+    spec = importlib.util.spec_from_file_location("det3d.torchie.parallel.collate", os.path.join(REF, "det3d/torchie/parallel/collate.py"))
+    ref = importlib.util.module_from_spec(spec)
+    ref.__package__ = "det3d.torchie.parallel"
+    sys.modules["det3d.torchie.parallel.collate"] = ref
+    spec.loader.exec_module(ref)
+    rng = np.random.default_rng(0)
+
+    def frame(n, v, tag):
+        return dict(metadata=dict(token=tag), points=rng.normal(size=(n, 5)).astype(np.float32),
+                    voxels=rng.normal(size=(v, 5, 5)).astype(np.float32), num_points=rng.integers(1, 6, size=v).astype(np.int32),
+                    coordinates=rng.integers(0, 40, size=(v, 3)).astype(np.int32), num_voxels=np.array([v], dtype=np.int64),
+                    shape=np.array([1024, 1024, 40]), voxel_sem_labels=rng.integers(0, 17, size=v).astype(np.uint8),
+                    point_sem_labels=rng.integers(0, 17, size=n).astype(np.uint8), points_cuv=rng.normal(size=(n, 4)).astype(np.float32),
+                    points_cp=rng.normal(size=(n, 3)).astype(np.float32), images=rng.normal(size=(6, 3, 8, 12)).astype(np.float32),
+                    images_sem_labels=rng.integers(0, 17, size=(6, 8, 12)).astype(np.uint8))
+    batch = [frame(50, 30, "a"), [frame(20, 11, "b0"), frame(20, 12, "b1")], frame(1, 1, "c")]
+    want, got = ref.collate_kitti(batch), ours.collate_kitti(batch)
+    assert set(want) == set(got)
+    for k in want:
+        if isinstance(want[k], torch.Tensor):
+            assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), k
+        elif isinstance(want[k], np.ndarray):
+            assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), k
+        else:
+            assert got[k] == want[k], k
+    assert got["points"].shape == (91, 6) and got["points"][:, 0].unique().tolist() == [0.0, 1.0, 2.0, 3.0]
+    dev = ours.collate_points([torch.from_numpy(f["points"]) for f in (batch[0], batch[1][0], batch[1][1], batch[2])])
+    assert torch.equal(dev, got["points"])
+    with pytest.raises(NotImplementedError):
+        ours.collate_kitti([dict(metadata={}, gt_boxes=[np.zeros((1, 7))])])
