@@ -169,6 +169,10 @@ typedef struct {
 int ls3d_transvfe(const float *voxels /*[n,P,C]*/, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
                   const ls3d_transvfe_t *model, float *out, int out_ld, ls3d_stream_t stream);
 
+/* Experimental variant of the fused reader: B fragments straight from the L2-resident weights instead of LDS staging, no workgroup
+ * barriers (0 = off, the default).  Same results; a process-wide switch like ls3d_set_gather_pipeline. */
+void ls3d_set_transvfe_direct(int on);
+
 /* y = LayerNorm(x (+ res)) * gamma + beta over the last dim c (<= 256); ld = c for all */
 int ls3d_layernorm(const float *x, const float *res, const float *gamma, const float *beta, float eps, int rows,
                    const int32_t *rows_dev, int c, float *y, ls3d_stream_t stream);

@@ -50,11 +50,46 @@ constexpr int TV_BCHUNK = 32 * 64;       // floats in one staged weight chunk
 
 // out(32 x N) = A(32 x K, LDS, stride lda) x W (packed nt=2: [slab][K][32][2]), handed to `epi(slab, acc0, acc1)` per
 // 64-column slab.  All 4 waves of the workgroup call this together (the weight chunks are staged by the workgroup).
-template <typename Epi>
+// DIRECT: no LDS staging and no workgroup barrier - every wave reads its B fragments (float2 per lane, 512 contiguous bytes per
+// MFMA pair) straight from the L2-resident packed weights, one chunk ahead in registers; the 4 waves of a workgroup then never wait
+// for each other.  Experimental (ls3d_set_transvfe_direct), same arithmetic in the same order.
+template <bool DIRECT, typename Epi>
 __device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, const float *__restrict__ Wp, float *Bs, Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int col = lane & 31, kk = lane >> 5;
   const int nslab = N / 64, nkc = K / 32, nchunks = nslab * nkc;
+  if (DIRECT) {
+    const float2 *wl = (const float2 *)Wp + kk * 16 * 32 + col;  // chunk c starts c * 1024 float2 further: chunks are contiguous
+    float2 bc[16], bn[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bc[u] = wl[u * 32];
+    tv_f32x16 acc0, acc1;
+    for (int c = 0; c < nchunks; ++c) {
+      const int slab = c / nkc, kc = c - slab * nkc;
+      if (kc == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+      }
+      if (c + 1 < nchunks) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bn[u] = wl[(size_t)(c + 1) * 1024 + u * 32];
+      }
+      const float4 *ap = (const float4 *)(A + col * lda + kc * 32 + kk * 16);
+      const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+      const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[u].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[u].y, acc1, 0, 0, 0);
+      }
+      if (kc == nkc - 1) epi(slab, acc0, acc1);
+      if (c + 1 < nchunks) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bc[u] = bn[u];
+      }
+    }
+    return;
+  }
   // chunk c = (slab, kc): 32 x 32 x 2 floats at Wp + (slab * K + kc * 32) * 64
   float4 r0, r1;
   {
@@ -131,6 +166,7 @@ __device__ __forceinline__ void tv_layernorm(float *X, const float *g, const flo
   }
 }
 
+template <bool DIRECT>
 __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ voxels, const int32_t *__restrict__ num, int n,
                                                      const int32_t *n_dev, int P, int C, TvParams prm, float *__restrict__ out, int out_ld) {
   HIP_DYNAMIC_SHARED(float, smem)
@@ -164,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
     }
     TV_WAVE_SYNC();
     // ---- embedding (+ norm1 of layer 0)
-    tv_gemm(T, TV_TS, TV_KT, TV_E, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+    tv_gemm<DIRECT>(T, TV_TS, TV_KT, TV_E, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
       const float b0 = prm.be[col], b1 = prm.be[32 + col];
       TV_FOR_ACC(r, row) {
         X[row * TV_XS + col] = a0[r] + b0;
@@ -177,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
     for (int l = 0; l < prm.num_layers; ++l) {
       const TvLayer &L = prm.layer[l];
       // ---- QKV -> T[:, 0:192]
-      tv_gemm(X, TV_XS, TV_E, 3 * TV_E, L.wqkv, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<DIRECT>(X, TV_XS, TV_E, 3 * TV_E, L.wqkv, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.bqkv[slab * 64 + col], b1 = L.bqkv[slab * 64 + 32 + col];
         TV_FOR_ACC(r, row) {
           T[row * TV_TS + slab * 64 + col] = a0[r] + b0;
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       }
       TV_WAVE_SYNC();
       // ---- out-proj + residual (from the normed X) -> X, then norm2
-      tv_gemm(T, TV_TS, TV_E, TV_E, L.wo, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<DIRECT>(T, TV_TS, TV_E, TV_E, L.wo, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.bo[col], b1 = L.bo[32 + col];
         TV_FOR_ACC(r, row) {
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
@@ -238,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       tv_layernorm(X, L.n2g, L.n2b, L.n2eps);
       TV_WAVE_SYNC();
       // ---- FF1 + ReLU -> T[:, 0:128]
-      tv_gemm(X, TV_XS, TV_E, TV_FF, L.w1, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<DIRECT>(X, TV_XS, TV_E, TV_FF, L.w1, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.b1[slab * 64 + col], b1 = L.b1[slab * 64 + 32 + col];
         TV_FOR_ACC(r, row) {
           T[row * TV_TS + slab * 64 + col] = fmaxf(a0[r] + b0, 0.0f);
@@ -247,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       });
       TV_WAVE_SYNC();
       // ---- FF2 + residual -> X, then norm1 of the next layer
-      tv_gemm(T, TV_TS, TV_FF, TV_E, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<DIRECT>(T, TV_TS, TV_FF, TV_E, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.b2[col], b1 = L.b2[32 + col];
         TV_FOR_ACC(r, row) {
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
@@ -284,6 +320,9 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
   }
 }
 
+static int g_tv_direct = 0;
+extern "C" void ls3d_set_transvfe_direct(int on) { g_tv_direct = on ? 1 : 0; }
+
 extern "C" int ls3d_transvfe(const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
                              const ls3d_transvfe_t *m, float *out, int out_ld, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -308,13 +347,18 @@ extern "C" int ls3d_transvfe(const float *voxels, const int32_t *num_points, int
   const int lds = (4 * TV_WAVE_FLOATS + 2 * TV_BCHUNK) * (int)sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_transvfe, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_transvfe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_transvfe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
   const int per_block = 4 * (32 / P);
   long long blocks = ((long long)n + per_block - 1) / per_block;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(k_transvfe, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  if (g_tv_direct)
+    hipLaunchKernelGGL(k_transvfe<true>, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  else
+    hipLaunchKernelGGL(k_transvfe<false>, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

@@ -28,6 +28,7 @@ def _L():
         _XCD_SET = True
         L.ls3d_set_xcd_map(int(_os_environ_get("LS3D_XCD_MAP", "0")))
         L.ls3d_set_gather_pipeline(1 if _PIPELINE else 0)
+        L.ls3d_set_transvfe_direct(1 if _os_environ_get("LS3D_TRANSVFE_DIRECT", "0") != "0" else 0)
     return L
 
 
@@ -418,6 +419,12 @@ def set_pipeline(on):
     global _PIPELINE
     _PIPELINE = bool(on)
     _L().ls3d_set_gather_pipeline(1 if on else 0)
+
+
+def set_transvfe_direct(on):
+    """fused TransVFE reader with its weights read straight from L2 (no LDS staging, no workgroup barriers): experimental, not yet
+    measured on the device (env LS3D_TRANSVFE_DIRECT=1 sets it at start-up)"""
+    _L().ls3d_set_transvfe_direct(1 if on else 0)
 
 
 def pipeline_geometry(cout, n_rows, prec):

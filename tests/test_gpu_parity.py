@@ -115,6 +115,11 @@ def test_vfe_readers():
     out = tv.to(DEV).eval()(vx, num)  # the one-kernel path (ls3d_transvfe)
     assert ops.transvfe(vx.contiguous(), num.to(torch.int32), tv.packed()["fused"]) is not None
     np.testing.assert_allclose(out.cpu().numpy(), g["trans"], rtol=0, atol=1e-4)
+    try:  # experimental variant (weights straight from L2, no workgroup barriers): same arithmetic, same order
+        ops.set_transvfe_direct(True)
+        assert torch.equal(tv(vx, num), out)
+    finally:
+        ops.set_transvfe_direct(False)
     try:  # the layer-by-layer composition of the same module
         readers._FUSED = False
         np.testing.assert_allclose(tv(vx, num).cpu().numpy(), g["trans"], rtol=0, atol=1e-4)

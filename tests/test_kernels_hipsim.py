@@ -312,6 +312,11 @@ def test_vfe_readers_vs_reference():
     fused = tv.eval()(vx, num).numpy()  # the one-kernel path (ls3d_transvfe)
     assert ops.transvfe(vx.contiguous(), num.to(torch.int32), tv.packed()["fused"]) is not None  # ... is really taken
     np.testing.assert_allclose(fused, g["trans"][sel], rtol=0, atol=1e-4)
+    try:  # experimental variant: weights straight from memory, no workgroup barriers - the same arithmetic in the same order
+        ops.set_transvfe_direct(True)
+        assert np.array_equal(tv(vx, num).numpy(), fused) and np.array_equal(tv(vx[:7], num[:7]).numpy(), fused[:7])
+    finally:
+        ops.set_transvfe_direct(False)
     try:  # and the layer-by-layer composition of the same module (configurations the fused kernel does not cover)
         readers._FUSED = False
         np.testing.assert_allclose(tv(vx, num).numpy(), g["trans"][sel], rtol=0, atol=1e-4)
