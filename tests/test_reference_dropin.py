@@ -278,3 +278,33 @@ def test_collate_kitti_equals_reference_on_segmentation_keys(harness):
     assert torch.equal(dev, got["points"])
     with pytest.raises(NotImplementedError):
         ours.collate_kitti([dict(metadata={}, gt_boxes=[np.zeros((1, 7))])])
+
+
+@pytest.mark.parametrize("tta", [False, True])
+def test_predict_equals_reference(harness, tta):
+    """point_head.predict (per-frame argmax; TTA: mean of the variants' softmax) vs the reference head's own method
+    (point_seg_batchloss_head.py:171-271, the same code in point_seg_mseg3d_head.py:379-479) on the same logits"""
+    import make_golden as mg
+    from lidarseg3d_amd import point_heads
+    mg._load("det3d.models.point_heads.point_utils", "det3d/models/point_heads/point_utils.py")
+    sys.modules["det3d.models.registry"].POINT_HEADS._module_dict.clear()
+    bh = mg._load("det3d.models.point_heads.point_seg_batchloss_head__predict", "det3d/models/point_heads/point_seg_batchloss_head.py")
+    mcfg = dict(CONV_IN_DIM=32, CONV_CLS_FC=[64], CONV_ALIGN_DIM=64, OUT_CLS_FC=[64, 64], IGNORED_LABEL=0)
+    ref, ours = bh.PointSegBatchlossHead(class_agnostic=False, num_class=17, model_cfg=mcfg), point_heads.PointSegBatchlossHead(False, 17, mcfg)
+    gen = torch.Generator().manual_seed(2)
+    k, groups = 4, 2
+    sizes = [37, 37, 37, 37, 52, 52, 52, 52] if tta else [40, 1, 63]   # TTA variants of one frame have the same point count
+    B = len(sizes)
+    pts = torch.cat([torch.cat([torch.full((n, 1), float(b)), torch.randn(n, 4, generator=gen)], 1) for b, n in enumerate(sizes)])
+    logits = torch.randn(pts.shape[0], 17, generator=gen)
+    labels = torch.randint(0, 17, (pts.shape[0],), generator=gen)
+    example = dict(points=pts, num_voxels=torch.zeros(B), metadata=[dict(token="f%d" % b) for b in range(B)], point_sem_labels=labels)
+    cfg = dict(tta_flag=True, merge_type="ArithmeticMean", num_tta_tranforms=k) if tta else dict()
+    ref.forward_ret_dict["out_logits"] = logits
+    ours.forward_ret_dict["out_logits"] = logits
+    want, got = ref.predict(example=example, test_cfg=cfg), ours.predict(example=example, test_cfg=cfg)
+    assert len(want) == len(got) == (groups if tta else B)
+    for w, g in zip(want, got):
+        assert w["metadata"] == g["metadata"]
+        assert torch.equal(w["pred_point_sem_labels"], g["pred_point_sem_labels"])
+        assert torch.equal(w["point_sem_labels"], g["point_sem_labels"])
