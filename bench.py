@@ -48,7 +48,7 @@ class ConvTimer:
     """HIP-event brackets around every sparse-conv gather-GEMM launch (installed as ops.gather_gemm wrapper)."""
 
     def __init__(self, ops):
-        self.ops, self.orig = ops, ops.gather_gemm
+        self.ops, self.orig, self.orig_tile = ops, ops.gather_gemm, ops.tile_conv
         self.events, self.algo_bytes, self.flops, self.enabled = [], 0.0, 0.0, False
         self.pairs_cache = {}
 
@@ -66,8 +66,19 @@ class ConvTimer:
                 self.pairs_cache[key] = None  # filled after the timed region (needs a sync)
             self.meta.append((key, tbl, w.shape[1], kw.get("cout") or w.cout))
             return out
+        def wrapped_tile(x, w, plan, **kw):
+            if not self.enabled:
+                return self.orig_tile(x, w, plan, **kw)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = self.orig_tile(x, w, plan, **kw)
+            b.record()
+            self.events.append((a, b))
+            self.meta.append(((plan.tbl.data_ptr(), plan.tbl.shape[0]), plan.tbl, w.shape[1], kw.get("cout") or w.cout))
+            return out
         self.meta = []
         self.ops.gather_gemm = wrapped
+        self.ops.tile_conv = wrapped_tile
         # modules imported `ops` as a module, so they see the replacement
         return self
 
@@ -131,7 +142,7 @@ def main():
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--cpu-points", type=int, default=None, help="points of the CPU-baseline frame (default: --points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["f32", "bf16x6", "bf16x3"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "bf16x8", "bf16x6", "bf16x3"], default="f32",
                     help="gather-GEMM arithmetic: f32 = exact f32 MFMA (default, the parity configuration); bf16x3 = split-bf16 "
                          "(3 bf16 MFMAs per product, ~1e-5 relative error)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 measurement")
@@ -226,11 +237,12 @@ def main():
     if args.precision == "f32" and not args.no_fast_mode and world == 1:
         # the same step in the split-bf16 arithmetics: reported beside, never as, `value`
         ref_logits = model.point_head.forward_ret_dict["out_logits"].clone()
-        for prec, label in (("bf16x6", "bf16x6 (exact 3-way bf16 split, 6 partial products per f32 product: f32-grade results)"),
+        for prec, label in (("bf16x8", "bf16x8 (exact 3-way bf16 split, 8 of 9 plane products: f32-grade; SubM layers on the tile-halo kernel)"),
+                            ("bf16x6", "bf16x6 (exact 3-way bf16 split, 6 partial products per f32 product: f32-grade results)"),
                             ("bf16x3", "bf16x3 (split-bf16 MFMA, f32 accumulate)")):
             ops.set_precision(prec)
             timer2 = ConvTimer(ops)
-            timer2.orig = timer.orig
+            timer2.orig, timer2.orig_tile = timer.orig, timer.orig_tile
             timer2.install()
             with torch.no_grad():
                 for _ in range(args.warmup):
@@ -259,7 +271,7 @@ def main():
         # timings (and with them the roofline line) are not defined while kernels of two streams overlap.
         throughput = {"streams": TP, "frames_in_flight": TP}
         with torch.no_grad():
-            for prec in ("f32", "bf16x6", "bf16x3"):
+            for prec in ("f32", "bf16x8", "bf16x6", "bf16x3"):
                 ops.set_precision(prec)
                 for _ in range(max(2, args.warmup // 2)):
                     step(TP)
@@ -279,7 +291,7 @@ def main():
             "metric": "frames/sec, SDSeg3D forward, 120k-pt nuScenes-style frame",
             "value": world * B * S * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x6": "f32 via exact 3-way bf16 split (6 bf16 MFMAs per product, f32 accumulate)", "bf16x3": "f32 via split-bf16 (bf16x3 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x8": "f32 via exact 3-way bf16 split (8 bf16 MFMAs per product, f32 accumulate)", "bf16x6": "f32 via exact 3-way bf16 split (6 bf16 MFMAs per product, f32 accumulate)", "bf16x3": "f32 via split-bf16 (bf16x3 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead), "
                                    "%d pts/frame, voxel [0.1,0.1,0.2], range [-51.2,-51.2,-5,51.2,51.2,3], 17 classes, "
                                    "1 frame per GPU per step, GPU voxelization included" % args.points,
@@ -309,6 +321,8 @@ def main():
             out["fast_mode"] = fast
         if "bf16x6" in alt:
             out["f32_grade_mode"] = alt["bf16x6"]
+        if "bf16x8" in alt:
+            out["bf16x8_mode"] = alt["bf16x8"]
         if throughput is not None:
             out["throughput_mode"] = throughput
         if args.model == "mseg3d":

@@ -40,6 +40,7 @@ extern "C" {
 #define LS3D_PRECISION_F32 0
 #define LS3D_PRECISION_BF16X3 1
 #define LS3D_PRECISION_BF16X6 2
+/* (the 8-product arithmetic of the same split, "bf16x8", exists on the tile-halo path only: ls3d_tile_conv, products = 8) */
 
 typedef void *ls3d_stream_t;
 
@@ -279,6 +280,37 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
                      int precision /* must equal the packing's; BF16X3 / BF16X6 need cin % 32 == 0 and wc == 1 */, int cin, int cout,
                      int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
                      int out_ld, ls3d_stream_t stream);
+
+/* ---- Tile-halo sparse convolution: the same operator as ls3d_gather_gemm with a rulebook table (spconv v1.x SubMConv3d /
+ * SparseConv3d / SparseInverseConv3d, call sites det3d/models/backbones/scn_unet.py:15-24,34-69), organised for locality:
+ * output rows are ordered along a space-filling key and cut into tiles of 128; each tile's UNIQUE input rows (its halo) are
+ * staged once per 16-channel chunk in LDS as three bf16 planes (exact 8+8+8-bit split of the f32 mantissa) and all kernel
+ * offsets run out of LDS on v_mfma_f32_32x32x16_bf16 with f32 accumulation.
+ *   ls3d_tile_keys : key[r] = (batch << 2m) | Morton(y >> s, x >> s) of an output site (s = 2 unless the key would not
+ *                    fit 31 bits); rows beyond *n_dev get 0x7FFFFFFF.  The caller sorts the keys (stable, ascending) and passes
+ *                    the resulting row permutation as `spatial_order`.
+ *   ls3d_tile_build: plan for one table tbl[n_rows, kvol] (kvol <= 32): per tile the output rows (sorted by neighbour mask,
+ *                    densest first), the sorted unique input rows, the local table tloc[k][slot] -> position in that list,
+ *                    the tile's / waves' offset masks.  `plan` holds ls3d_tile_plan_bytes(n_rows, kvol) bytes, 16-byte aligned.
+ *                    Deterministic.  Any table and any order are valid; only speed depends on their locality.
+ *   ls3d_tile_conv_pack: plain W[kvol][cin_src][cout] f32 -> [kvol][cin_pad/16][cout32/32][plane 3][2][32] x 8 bf16
+ *                    (ls3d_tile_conv_packed_bytes bytes); cout <= 128.
+ *   ls3d_tile_conv : out[r, 0..cout) = epilogue(sum_k W[k]^T in[tbl[r,k]]) for the rows of the plan.  products = 8: every
+ *                    plane product except tail x tail (2^-32 relative) — f32-grade: the result differs from exact f32
+ *                    arithmetic by less than f32 summation-order noise; products = 6: the BF16X6 arithmetic.
+ *                    cin % 16 == 0, in_ld % 4 == 0, cout <= 128.  Summation order per output row is fixed by the plan. */
+int ls3d_tile_keys(const int32_t *coords /*[n,4] b,z,y,x*/, int n, const int32_t *n_dev, const int32_t shape_zyx_host[3], int batch,
+                   uint32_t *keys, ls3d_stream_t stream);
+size_t ls3d_tile_plan_bytes(int n_rows, int kvol);
+int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_rows_dev, int kvol, const int32_t *spatial_order, void *plan,
+                    size_t plan_bytes, ls3d_stream_t stream);
+size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout);
+int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream);
+int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout,
+                   int products, const ls3d_epilogue_t *epi_host, float *out, int out_ld, ls3d_stream_t stream);
+/* tuning knob (A/B measurements).  bit 0: each XCD walks a contiguous range of tiles instead of tile = workgroup index (results
+ * identical); bits 2-4: timing ablations for profiling (skip the MFMAs / the weight DMA / the halo staging: results invalid). */
+void ls3d_set_tile_map(int flags);
 
 /* Backward of the sparse convolutions (spconv v1.x indice_conv_backward).
  *   grad_in : ls3d_gather_gemm on grad_out with the TRANSPOSED table (SubM: the same table; SparseConv3d: nbr_inv;

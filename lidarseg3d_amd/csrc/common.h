@@ -39,6 +39,11 @@ __device__ __forceinline__ int ls3d_count(int n, const int32_t *n_dev) {
 __device__ __forceinline__ void ls3d_glds16(const void *gsrc, void *lds_wave_base) {
   memcpy((char *)lds_wave_base + hipsim::lane() * 16, gsrc, 16);
 }
+__device__ __forceinline__ void ls3d_glds16x3(const void *gbase, unsigned voff0, unsigned voff1, unsigned voff2, void *lds_wave_base) {
+  memcpy((char *)lds_wave_base + hipsim::lane() * 16, (const char *)gbase + voff0, 16);
+  memcpy((char *)lds_wave_base + 1024 + hipsim::lane() * 16, (const char *)gbase + voff1, 16);
+  memcpy((char *)lds_wave_base + 2048 + hipsim::lane() * 16, (const char *)gbase + voff2, 16);
+}
 #define LS3D_WAIT_VMCNT(n) ((void)0)
 #define LS3D_SCHED_FENCE() ((void)0)
 #define LS3D_RAW_BARRIER() __syncthreads()
@@ -48,6 +53,17 @@ __device__ __forceinline__ void ls3d_glds16(const void *gsrc, void *lds_wave_bas
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// three consecutive 1 KB blocks: global gbase (wave-uniform, SGPR pair) + voff_i (per lane, = lane * 16 + i * 1024 + a uniform offset)
+// -> LDS lds_wave_base + i * 1024 + lane * 16.  Scalar base + 32-bit lane offsets: no 64-bit VALU address arithmetic per block.
+__device__ __forceinline__ void ls3d_glds16x3(const void *gbase, unsigned voff0, unsigned voff1, unsigned voff2, void *lds_wave_base) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(voff0), "v"(voff1), "v"(voff2), "s"(gbase), "s"(dst) : "memory", "scc");
 }
 #define LS3D_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define LS3D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  /* nothing is scheduled across: e.g. keeps a batch of ds_reads together */

@@ -1,0 +1,505 @@
+// tileconv.hip — tile-halo sparse convolution:  out[r] = epilogue( sum_k W[k]^T in[tbl[r][k]] )  on spatially compact tiles.
+//
+// Same operator as ls3d_gather_gemm (spconv v1.x SubMConv3d / SparseConv3d / SparseInverseConv3d semantics, SURVEY.md §2.3,
+// call sites det3d/models/backbones/scn_unet.py:15-24,34-69), different data movement.  The gather-GEMM fetches every
+// (output, offset) pair's input row from L2 — 17 fetches per row and column slab on the 128-channel levels of the
+// 120k-point frame, at a 50 % L2 hit rate (profiles/round1_pmc_sq.md).  Here
+//   * output rows are ordered along a space-filling key (ls3d_tile_keys: Morton order of 4x4 (y,x) columns) and cut into
+//     tiles of 128 rows, so a tile is a compact patch of the LiDAR surface;
+//   * ls3d_tile_build writes, per tile, the UNIQUE input rows it touches (its halo, ~2.4x128 rows instead of 17.6x128
+//     gathers) and a local table tloc[k][slot] -> halo position; rows of a tile are sorted by neighbour mask so that the
+//     four waves still skip most empty offsets;
+//   * the kernel stages one 16-channel chunk of the halo in LDS ONCE per tile — split there into three bf16 planes
+//     (exact 8+8+8-bit split of the f32 mantissa) — and all kernel offsets run out of LDS: A fragments by local index,
+//     weight chunks (pre-split at pack time) double-buffered through LDS, v_mfma_f32_32x32x16_bf16 with f32 accumulation;
+//   * products: 8 of the 9 plane products (everything but tail x tail, 2^-32 relative) = exact-f32-grade arithmetic at
+//     half the matrix time of v_mfma_f32_32x32x2_f32, or the 6 products of weight >= 2^-16 (the BF16X6 mode of ls3d_gather_gemm);
+//   * a halo larger than the LDS window (TC_HCAP rows) is processed in several passes of the same loop, absent rows read a
+//     zero row: any table works, only speed depends on locality.
+// Summation order of one output row: input-channel chunks outer, kernel offsets inner — fixed by the plan, so results are
+// bit-reproducible run to run.
+#include "gemm_common.h"
+
+constexpr int TC_TR = 128;     // output rows per tile (4 waves x 32)
+constexpr int TC_HCAP = 448;   // halo rows resident in LDS per pass
+constexpr int TC_KMAX = 32;    // kernel offsets per table (3x3x3 = 27)
+constexpr int TC_META = 8;     // ints per tile: halo size, tile offset mask, 4 wave offset masks, live rows, spare
+
+// ---------------------------------------------------------------------------------------------------------------
+// spatial sort keys
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tc_spread(uint32_t v) {  // 16 bits -> every other bit
+  v &= 0xFFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_tile_keys(const int32_t *__restrict__ coords, int n, const int32_t *n_dev, int shift, int mbits,
+                                                   uint32_t *__restrict__ keys) {
+  const int N = ls3d_count(n, n_dev);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t key = 0x7FFFFFFFu;  // rows beyond the device count sort last
+    if (i < N) {
+      const int b = coords[4 * i], y = coords[4 * i + 2], x = coords[4 * i + 3];
+      key = ((uint32_t)b << mbits) | (tc_spread((uint32_t)(y >> shift)) << 1) | tc_spread((uint32_t)(x >> shift));
+    }
+    keys[i] = key;
+  }
+}
+
+extern "C" int ls3d_tile_keys(const int32_t *coords, int n, const int32_t *n_dev, const int32_t shape_zyx[3], int batch, uint32_t *keys,
+                              ls3d_stream_t stream) {
+  if (!coords || !keys || !shape_zyx || n < 0 || batch < 1) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  int bbits = 0;
+  while ((1 << bbits) < batch) ++bbits;
+  const int ext = shape_zyx[1] > shape_zyx[2] ? shape_zyx[1] : shape_zyx[2];
+  int shift = 2, cbits;  // 4x4 (y,x) columns; coarser only if the key would not fit 31 bits
+  for (;; ++shift) {
+    cbits = 0;
+    while ((1 << cbits) < ((ext + (1 << shift) - 1) >> shift)) ++cbits;
+    if (2 * cbits + bbits <= 31) break;
+  }
+  if (cbits > 16) return LS3D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_tile_keys, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, coords, n, n_dev, shift, 2 * cbits, keys);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tile plan
+// ---------------------------------------------------------------------------------------------------------------
+struct TilePlan {
+  int ntiles, kvol, hs;
+  int32_t *trow;    // [T][128]      output row of each tile slot (-1 = none), slots sorted by neighbour mask (densest first)
+  int32_t *tmeta;   // [T][TC_META]
+  int32_t *thalo;   // [T][hs]       unique input rows of the tile, ascending
+  uint16_t *tloc;   // [T][kvol][128] position of tbl[row][k] in the tile's halo, 0xFFFF = no neighbour
+};
+
+static inline size_t tc_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static TilePlan tc_plan(void *buf, int n_rows, int kvol) {
+  TilePlan p;
+  p.ntiles = (n_rows + TC_TR - 1) / TC_TR;
+  p.kvol = kvol;
+  p.hs = kvol * TC_TR;
+  char *b = (char *)buf;
+  p.trow = (int32_t *)b; b += tc_align((size_t)p.ntiles * TC_TR * 4);
+  p.tmeta = (int32_t *)b; b += tc_align((size_t)p.ntiles * TC_META * 4);
+  p.thalo = (int32_t *)b; b += tc_align((size_t)p.ntiles * p.hs * 4);
+  p.tloc = (uint16_t *)b;
+  return p;
+}
+
+extern "C" size_t ls3d_tile_plan_bytes(int n_rows, int kvol) {
+  if (n_rows < 0 || kvol < 1) return 0;
+  const size_t t = (size_t)(n_rows + TC_TR - 1) / TC_TR;
+  return tc_align(t * TC_TR * 4) + tc_align(t * TC_META * 4) + tc_align(t * kvol * TC_TR * 4) + tc_align(t * kvol * TC_TR * 2);
+}
+
+// one workgroup per tile
+__global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ tbl, int n, const int32_t *n_dev, int kvol,
+                                                    const int32_t *__restrict__ sorder, TilePlan p) {
+  constexpr int NC = TC_KMAX * TC_TR;  // 4096 candidate slots
+  __shared__ int s_row[TC_TR], s_srow[TC_TR];
+  __shared__ unsigned s_mask[TC_TR], s_smask[TC_TR];
+  __shared__ int s_key[NC];
+  __shared__ int s_uniq[NC];
+  __shared__ int s_scan[2][256];
+  const int tid = threadIdx.x;
+  const int N = ls3d_count(n, n_dev);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    __syncthreads();
+    if (tid < TC_TR) {
+      const int r = tile * TC_TR + tid;
+      s_row[tid] = r < N ? sorder[r] : -1;
+      s_mask[tid] = 0u;
+    }
+    __syncthreads();
+    {  // neighbour masks: two threads per slot
+      const int slot = tid & (TC_TR - 1), part = tid >> 7;
+      const int row = s_row[slot];
+      unsigned m = 0u;
+      if (row >= 0)
+        for (int k = part; k < kvol; k += 2)
+          if (tbl[(size_t)row * kvol + k] >= 0) m |= 1u << k;
+      if (m) atomicOr(&s_mask[slot], m);
+    }
+    __syncthreads();
+    if (tid < TC_TR) {  // slots sorted by mask, densest first (ties keep the spatial order); empty slots go last
+      const unsigned mine = s_mask[tid];
+      const bool live = s_row[tid] >= 0;
+      int rank = 0;
+      for (int j = 0; j < TC_TR; ++j) {
+        const unsigned mj = s_mask[j];
+        const bool lj = s_row[j] >= 0;
+        rank += (lj && !live) || (lj == live && (mj > mine || (mj == mine && j < tid)));
+      }
+      s_srow[rank] = s_row[tid];
+      s_smask[rank] = mine;
+    }
+    __syncthreads();
+    for (int c = tid; c < NC; c += 256) {
+      const int k = c >> 7, s = c & (TC_TR - 1);
+      const int row = s_srow[s];
+      const int v = (k < kvol && row >= 0) ? tbl[(size_t)row * kvol + k] : -1;
+      s_key[c] = v >= 0 ? v : 0x7FFFFFFF;
+    }
+    __syncthreads();
+    // bitonic sort, ascending
+    for (int kk = 2; kk <= NC; kk <<= 1)
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < NC / 2; t += 256) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower index of the pair
+          const int q = i | j;
+          const bool up = (i & kk) == 0;
+          const int a = s_key[i], b = s_key[q];
+          if ((a > b) == up) { s_key[i] = b; s_key[q] = a; }
+        }
+        __syncthreads();
+      }
+    // unique values -> s_uniq, H
+    constexpr int PER = NC / 256;
+    int cnt = 0;
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid * PER + u;
+      const int v = s_key[i];
+      cnt += (v != 0x7FFFFFFF) && (i == 0 || v != s_key[i - 1]);
+    }
+    s_scan[0][tid] = cnt;
+    __syncthreads();
+    int src = 0;
+    for (int d = 1; d < 256; d <<= 1) {  // inclusive scan of the per-thread counts
+      s_scan[src ^ 1][tid] = s_scan[src][tid] + (tid >= d ? s_scan[src][tid - d] : 0);
+      src ^= 1;
+      __syncthreads();
+    }
+    const int H = s_scan[src][255];
+    int pos = s_scan[src][tid] - cnt;
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid * PER + u;
+      const int v = s_key[i];
+      if ((v != 0x7FFFFFFF) && (i == 0 || v != s_key[i - 1])) s_uniq[pos++] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < H; i += 256) p.thalo[(size_t)tile * p.hs + i] = s_uniq[i];
+    for (int c = tid; c < kvol * TC_TR; c += 256) {
+      const int k = c >> 7, s = c & (TC_TR - 1);
+      const int row = s_srow[s];
+      const int v = row >= 0 ? tbl[(size_t)row * kvol + k] : -1;
+      unsigned li = 0xFFFFu;
+      if (v >= 0) {
+        int lo = 0, hi = H;  // lower bound of v in s_uniq (it is present)
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_uniq[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        li = (unsigned)lo;
+      }
+      p.tloc[((size_t)tile * kvol + k) * TC_TR + s] = (uint16_t)li;
+    }
+    if (tid < TC_TR) p.trow[(size_t)tile * TC_TR + tid] = s_srow[tid];
+    if (tid < 8) {
+      int v = 0;
+      if (tid == 0) v = H;
+      else if (tid == 1) { unsigned m = 0u; for (int s = 0; s < TC_TR; ++s) m |= s_smask[s]; v = (int)m; }
+      else if (tid < 6) { unsigned m = 0u; for (int s = 0; s < 32; ++s) m |= s_smask[(tid - 2) * 32 + s]; v = (int)m; }
+      else if (tid == 6) { int c2 = 0; for (int s = 0; s < TC_TR; ++s) c2 += s_srow[s] >= 0; v = c2; }
+      p.tmeta[(size_t)tile * TC_META + tid] = v;
+    }
+  }
+}
+
+extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_rows_dev, int kvol, const int32_t *spatial_order, void *plan,
+                               size_t plan_bytes, ls3d_stream_t stream) {
+  if (!tbl || !spatial_order || !plan || n_rows < 0 || kvol < 1) return LS3D_ERR_ARG;
+  if (kvol > TC_KMAX) return LS3D_ERR_UNSUPPORTED;
+  if (plan_bytes < ls3d_tile_plan_bytes(n_rows, kvol)) return LS3D_ERR_WORKSPACE;
+  if (((uintptr_t)plan & 15)) return LS3D_ERR_ARG;
+  if (n_rows == 0) return LS3D_OK;
+  TilePlan p = tc_plan(plan, n_rows, kvol);
+  hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, (hipStream_t)stream, tbl, n_rows, n_rows_dev,
+                     kvol, spatial_order, p);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weights: plain [kvol][cin_src][cout] f32 -> [kvol][cin_pad/16][nt][plane 3][kk 2][col 32] x (8 bf16), the exact 3-way split
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src, int kvol, int cin_src, int cin_pad, int cout, int nt,
+                                                   uint4 *__restrict__ dst) {
+  const int nchunk = cin_pad / 16;
+  const long long total = (long long)kvol * nchunk * nt * 3 * 64;
+  for (long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; t_ < total; t_ += (long long)gridDim.x * blockDim.x) {
+    long long r = t_;
+    const int col = (int)(r % 32); r /= 32;
+    const int kk = (int)(r % 2); r /= 2;
+    const int pl = (int)(r % 3); r /= 3;
+    const int n = (int)(r % nt); r /= nt;
+    const int ch = (int)(r % nchunk); r /= nchunk;
+    const int k = (int)r;
+    const int oc = n * 32 + col;
+    unsigned wds[4];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      unsigned half[2];
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int c = ch * 16 + kk * 8 + pr * 2 + e2;
+        const float v = (c < cin_src && oc < cout) ? src[((size_t)k * cin_src + c) * cout + oc] : 0.0f;
+        const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
+        const float r1 = v - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+        half[e2] = pl == 0 ? (hb >> 16) : pl == 1 ? (mb >> 16) : ls3d_bf16_rne(r1 - __uint_as_float(mb));
+      }
+      wds[pr] = half[0] | (half[1] << 16);
+    }
+    uint4 o;
+    o.x = wds[0]; o.y = wds[1]; o.z = wds[2]; o.w = wds[3];
+    dst[t_] = o;
+  }
+}
+
+extern "C" size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout) {
+  return (size_t)kvol * cin_pad * (cout <= 32 ? 32 : cout <= 64 ? 64 : 128) * 6;
+}
+
+extern "C" int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream) {
+  if (!w_plain || !w_packed || kvol < 1 || cin_src < 1 || cin_pad < cin_src || (cin_pad % 16) || cout < 1) return LS3D_ERR_ARG;
+  if (cout > 128) return LS3D_ERR_UNSUPPORTED;
+  const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;  // column blocks of the kernel variant that will run (zero padded)
+  const long long total = (long long)kvol * (cin_pad / 16) * nt * 3 * 64;
+  hipLaunchKernelGGL(k_tile_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt, (uint4 *)w_packed);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the convolution
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TC_PLANE_BYTES = (TC_HCAP + 1) * 32;             // one bf16 plane of the halo chunk: [row][16 channels], + the zero row
+constexpr int TC_HALO_BYTES = ((3 * TC_PLANE_BYTES + 255) / 256) * 256;
+constexpr int TC_WBUF_UNITS = 768;                             // 16-byte units of one step's weight pieces (12 KB)
+constexpr int TC_LOC_BYTES = TC_KMAX * TC_TR * 2;
+constexpr int TC_HID_BYTES = TC_HCAP * 4;
+constexpr int TC_LDS_BYTES = TC_HALO_BYTES + 2 * TC_WBUF_UNITS * 16 + TC_LOC_BYTES + TC_HID_BYTES + TC_TR * 4 + TC_TR * 4;
+constexpr int TC_THREADS = 256;
+
+// Workgroup = 4 waves over one tile: wave w owns rows [32 w, 32 w + 32) and all NT 32-column blocks (cout <= 32: NT = 1,
+// <= 64: NT = 2, <= 128: NT = 4).  Two workgroups fit a CU (LDS 79 KB).  A step = G = 4 / NT consecutive active kernel offsets of
+// one 16-channel chunk, so that every step moves the same 12 KB of weights and feeds 32 MFMAs per wave between two barriers.
+// The loop around the MFMAs is kept to a few dozen instructions per step — a wave issues one instruction every ~4 cycles, so
+// every 8 instructions of bookkeeping cost as much as one MFMA: weights go global -> LDS by LDS-DMA from a scalar base (3 blocks
+// of 1 KB per wave and step, issued one step ahead into the other buffer, no staging registers, no address VALU), the local
+// indices of the A fragments are read one step ahead, every per-wave decision is a scalar branch.
+// NP = plane products per f32 product (6 or 8).
+template <int NT, int NP>
+__global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in, int in_ld, TilePlan p, const uint4 *__restrict__ wpk,
+                                                             int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int flat_map, int ablate) {
+  constexpr int PU = NT * 192;             // 16-byte units of one (offset, chunk) weight piece
+  constexpr int PB = NT * 3;               // ... in 1 KB LDS-DMA blocks
+  constexpr int G = 4 / NT;                // offsets per step
+  constexpr int HPT = (TC_HCAP * 4 + TC_THREADS - 1) / TC_THREADS;  // float4 items of the halo chunk per thread
+  static_assert(G * PU == TC_WBUF_UNITS && G * PB == 12, "a step moves 12 KB of weights");
+  static_assert(64 * NT * 32 * 4 <= TC_HALO_BYTES, "the epilogue transposes 64 rows at a time through the halo buffer");
+  HIP_DYNAMIC_SHARED(char, smem)
+  uint4 *Bs = (uint4 *)(smem + TC_HALO_BYTES);                                       // [2][TC_WBUF_UNITS]
+  uint16_t *s_loc = (uint16_t *)(smem + TC_HALO_BYTES + 2 * TC_WBUF_UNITS * 16);     // [kvol][128]
+  int *s_hid = (int *)((char *)s_loc + TC_LOC_BYTES);                                // [TC_HCAP] halo rows of this pass
+  int *s_rows = s_hid + TC_HCAP;                                                     // [128]
+  float *s_stat = (float *)(s_rows + TC_TR);                                         // [128]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                         // scalar: per-wave decisions are s_cbranch
+  const int col = lane & 31, kk = lane >> 5;
+  const int kvol = p.kvol, nchunk = cin / 16;
+  // this wave's share of a step's weight DMA: blocks [3 wave, 3 wave + 3) of the 12, all inside one offset's piece
+  const int dma_g = (3 * wave) / PB, dma_j = (3 * wave) % PB;
+  const unsigned voff0 = (unsigned)lane * 16u, voff1 = voff0 + 1024u, voff2 = voff0 + 2048u;
+  const uint16_t *loc_w = s_loc + wave * 32 + col;
+  uint4 *const dma_lds0 = Bs + dma_g * PU + dma_j * 64, *const dma_lds1 = dma_lds0 + TC_WBUF_UNITS;
+  const int t8 = (p.ntiles + 7) / 8;
+  for (int b = blockIdx.x; b < t8 * 8; b += gridDim.x) {
+    // tile = workgroup index: neighbouring tiles (unequal work: dense near the sensor) are spread over the XCDs.  The
+    // alternative (flat_map == 0: each XCD walks a contiguous range, halos of neighbours meet in one L2) measured 0-40 % slower:
+    // the halo is staged once per tile anyway, balance matters more (profiles/round2_experiments.md)
+    const int tile = flat_map ? b : (b & 7) * t8 + (b >> 3);
+    if (tile >= p.ntiles) continue;
+    const int *meta = p.tmeta + (size_t)tile * TC_META;
+    const int H = meta[0];
+    const unsigned kmask = (unsigned)meta[1];
+    const unsigned wmask = (unsigned)__builtin_amdgcn_readfirstlane(meta[2 + wave]);
+    if (meta[6] == 0) continue;
+    if (tid < TC_TR) s_rows[tid] = p.trow[(size_t)tile * TC_TR + tid];
+    {
+      const uint4 *src = (const uint4 *)(p.tloc + (size_t)tile * kvol * TC_TR);
+      for (int i = tid; i < kvol * (TC_TR / 8); i += TC_THREADS) ((uint4 *)s_loc)[i] = src[i];
+    }
+    if (tid < 24) ((unsigned *)(smem + (tid >> 3) * TC_PLANE_BYTES + TC_HCAP * 32))[tid & 7] = 0u;  // the zero row of each plane
+    f32x16 acc[NT], acs[NT];  // head x head products / everything else (see the MFMA block)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = acs[n][r] = 0.0f;
+    const int nseg = (H + TC_HCAP - 1) / TC_HCAP;
+    for (int seg = 0; seg < (kmask ? nseg : 0); ++seg) {
+      const int seg_lo = seg * TC_HCAP;
+      const int nh = (H - seg_lo) < TC_HCAP ? (H - seg_lo) : TC_HCAP;
+      __syncthreads();  // the previous pass is done with s_hid and the halo buffer
+      for (int i = tid; i < nh; i += TC_THREADS) s_hid[i] = p.thalo[(size_t)tile * p.hs + seg_lo + i];
+      for (int c = 0; c < nchunk; ++c) {
+        __syncthreads();  // s_hid visible / the previous chunk's MFMAs have read their fragments
+        unsigned rem = kmask;
+        int ks[G], kn[G];
+#define TC_NEXT_GROUP(dst_)                                                       \
+  _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) {                              \
+    dst_[g_] = rem ? __ffs((int)rem) - 1 : -1;                                    \
+    rem &= rem - 1;                                                               \
+  }
+        // 32-bit scalar arithmetic per step: piece(k, c) = wchunk + k * kstride bytes (a layer's packed weights are < 4 GB)
+        const char *wchunk = (const char *)(wpk + (size_t)c * PU + dma_j * 64);
+        const unsigned kstride = (unsigned)nchunk * PU * 16u;
+#define TC_DMA_GROUP(kg_, buf_)                                                   \
+  if (kg_[dma_g] >= 0 && !(ablate & 8))                                           \
+    ls3d_glds16x3(wchunk + (unsigned)kg_[dma_g] * kstride, voff0, voff1, voff2, (buf_) ? dma_lds1 : dma_lds0);
+        TC_NEXT_GROUP(ks)
+        TC_DMA_GROUP(ks, 0)
+        // ---- stage the halo chunk: global f32 -> three bf16 planes in LDS
+        if (!(ablate & 16)) {
+          float4 hv[HPT];
+#pragma unroll
+          for (int j = 0; j < HPT; ++j) {
+            const int i = tid + j * TC_THREADS, hrow = i >> 2, q = i & 3;
+            // branch-free (rows past the end re-read the last one): under a per-load condition hipcc waits for each load
+            // before issuing the next, i.e. HPT memory latencies per chunk instead of one
+            const int hr = hrow < nh ? hrow : nh - 1;
+            hv[j] = *(const float4 *)(in + (size_t)s_hid[hr] * in_ld + c * 16 + q * 4);
+          }
+#pragma unroll
+          for (int j = 0; j < HPT; ++j) {
+            const int i = tid + j * TC_THREADS, hrow = i >> 2, q = i & 3;
+            if (hrow < nh) {
+              uint2 h, m, l;
+              ls3d_split_pair3(hv[j].x, hv[j].y, h.x, m.x, l.x);
+              ls3d_split_pair3(hv[j].z, hv[j].w, h.y, m.y, l.y);
+              char *dst = smem + hrow * 32 + q * 8;
+              *(uint2 *)(dst) = h;
+              *(uint2 *)(dst + TC_PLANE_BYTES) = m;
+              *(uint2 *)(dst + 2 * TC_PLANE_BYTES) = l;
+            }
+          }
+        }
+        LS3D_WAIT_VMCNT(0);
+        __syncthreads();
+        int buf = 0;
+        int lc[G], ln[G];  // raw local indices of this lane's row: current step / next step
+#pragma unroll
+        for (int g = 0; g < G; ++g) lc[g] = loc_w[(ks[g] >= 0 ? ks[g] : 0) * TC_TR];
+        for (;;) {
+          TC_NEXT_GROUP(kn)
+          TC_DMA_GROUP(kn, buf ^ 1)
+#pragma unroll
+          for (int g = 0; g < G; ++g) ln[g] = loc_w[(kn[g] >= 0 ? kn[g] : 0) * TC_TR];  // branch-free: used one step later
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int k = ks[g];
+            if (k >= 0 && ((wmask >> k) & 1u) && !(ablate & 4)) {
+              const int li = lc[g] - seg_lo;
+              const int lz = ((unsigned)li < (unsigned)TC_HCAP) ? li : TC_HCAP;  // absent / other pass -> the zero row
+              const uint4 *hp = (const uint4 *)smem + lz * 2 + kk;
+              const uint4 *bs = Bs + buf * TC_WBUF_UNITS + g * PU + lane;
+              uint4 bfr[3][NT];  // [plane][column block]
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bfr[pl][n] = bs[(n * 3 + pl) * 64];
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, hp[0]);
+              const bf16x8 am = __builtin_bit_cast(bf16x8, hp[TC_PLANE_BYTES / 16]);
+              const bf16x8 al = __builtin_bit_cast(bf16x8, hp[2 * (TC_PLANE_BYTES / 16)]);
+              // product-major: consecutive MFMAs go to different accumulators; products grouped by the weight plane they need
+#define TC_MFMA(dst_, a_, pl_)                                                                          \
+  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                        \
+      dst_[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, __builtin_bit_cast(bf16x8, bfr[pl_][n]), dst_[n], 0, 0, 0);
+              // head x head (99.6 % of the value) goes to `acc`, the seven (five) small products to `acs`: the bf16 MFMA's
+              // accumulate is not round-to-nearest (measured: ~1e-3 ulp of the accumulator lost towards zero per MFMA), and
+              // eight MFMAs per step into one accumulator made the end-to-end error 3.3x the exact-f32 path's.  With the small
+              // terms kept apart the large accumulator sees one MFMA per step and the bias of the small one is 2^-8 of its own.
+              TC_MFMA(acs, al, 0) TC_MFMA(acs, am, 0) TC_MFMA(acc, ah, 0)
+              if constexpr (NP >= 8) { TC_MFMA(acs, al, 1) }
+              TC_MFMA(acs, am, 1) TC_MFMA(acs, ah, 1)
+              if constexpr (NP >= 8) { TC_MFMA(acs, am, 2) }
+              TC_MFMA(acs, ah, 2)
+#undef TC_MFMA
+            }
+          }
+          if (kn[0] < 0) break;
+          LS3D_WAIT_VMCNT(0);
+          __syncthreads();
+          buf ^= 1;
+#pragma unroll
+          for (int g = 0; g < G; ++g) { ks[g] = kn[g]; lc[g] = ln[g]; }
+        }
+#undef TC_NEXT_GROUP
+#undef TC_DMA_GROUP
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] += acs[n][r];
+    gg_epilogue<NT, 1, TC_TR, 64, TC_THREADS>(acc, (float *)smem, s_rows, s_stat, wave, 0, kk, col, 0, cout, e, out, out_ld);
+  }
+}
+
+static int g_tile_flat_map = 1, g_tile_ablate = 0;
+extern "C" void ls3d_set_tile_map(int flags) {
+  g_tile_flat_map = (flags & 1) ? 0 : 1;
+  g_tile_ablate = flags & 28;  // bits 2-4: timing ablations (no MFMA / no weight DMA / no halo staging): results invalid
+}
+
+template <int NT, int NP>
+static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TilePlan &p, const uint4 *wpk, int cin, int cout, const EpiDev &e, float *out,
+                     int out_ld) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int nwg = (p.ntiles + 7) / 8 * 8;
+  hipLaunchKernelGGL((k_tile_conv<NT, NP>), dim3((unsigned)nwg), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout, e, out, out_ld,
+                     g_tile_flat_map, g_tile_ablate);
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout, int products,
+                              const ls3d_epilogue_t *epi, float *out, int out_ld, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!in || !plan || !w_packed || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
+  if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
+  if (((uintptr_t)in & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)plan & 15)) return LS3D_ERR_ARG;
+  if (kvol > TC_KMAX || cout > 128) return LS3D_ERR_UNSUPPORTED;
+  if (products != 6 && products != 8) return LS3D_ERR_ARG;
+  if (n_rows == 0) return LS3D_OK;
+  EpiDev e = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.0f};
+  if (epi) {
+    e.scale = epi->scale; e.shift = epi->shift; e.res_pre = epi->res_pre; e.pair = epi->pair;
+    e.res_pre_ld = epi->res_pre_ld; e.pair_ld = epi->pair_ld; e.relu = epi->relu;
+    e.ln_gamma = epi->ln_gamma; e.ln_beta = epi->ln_beta; e.ln_eps = epi->ln_eps;
+    if ((e.ln_gamma != nullptr) != (e.ln_beta != nullptr) || (e.ln_gamma && e.pair)) return LS3D_ERR_ARG;
+  }
+  const TilePlan p = tc_plan(const_cast<void *>(plan), n_rows, kvol);
+  int rc;
+#define TC_GO(NTW_) (products == 8 ? tc_launch<NTW_, 8>(stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld) \
+                                   : tc_launch<NTW_, 6>(stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld))
+  if (cout <= 32) rc = TC_GO(1);        // weights packed with 1 column block
+  else if (cout <= 64) rc = TC_GO(2);   // ... with 2
+  else rc = TC_GO(4);                   // ... with 4
+#undef TC_GO
+  if (rc != LS3D_OK) return rc;
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

@@ -325,20 +325,22 @@ def rulebook_order(tbl, coords=None):
     return torch.argsort(mask, descending=_os_environ_get("LS3D_ORDER_ASC", "0") != "1").to(_i32)
 
 
-F32, BF16X3, BF16X6 = 0, 1, 2
+F32, BF16X3, BF16X6, BF16X8 = 0, 1, 2, 3
 _PRECISION = F32
+_PREC_NAMES = {"f32": F32, "bf16x3": BF16X3, "bf16x6": BF16X6, "bf16x8": BF16X8}
 
 
 def set_precision(name):
-    """arithmetic of the sparse convolutions whose cin is a multiple of 32: "f32" (default; exact f32 MFMA), "bf16x6" (exact
-    3-way bf16 split, 6 partial products: f32-grade results, 2.7x less matrix time) or "bf16x3" (2-way split, 3 products:
-    ~1e-5 relative error per layer, 5.3x less matrix time)"""
+    """arithmetic of the sparse convolutions whose cin is a multiple of 32: "f32" (default; exact f32 MFMA), "bf16x8" (exact
+    3-way bf16 split of both operands, every plane product except tail x tail: f32-grade, half the matrix time), "bf16x6"
+    (the 6 products of weight >= 2^-16: 2.7x less matrix time) or "bf16x3" (2-way split, 3 products: ~1e-5 relative error
+    per layer, 5.3x less matrix time).  The 3-plane modes run the SubM layers on the tile-halo kernel (ls3d_tile_conv)."""
     global _PRECISION
-    _PRECISION = {"f32": F32, "bf16x3": BF16X3, "bf16x6": BF16X6}[name]
+    _PRECISION = _PREC_NAMES[name]
 
 
 def get_precision():
-    return {F32: "f32", BF16X3: "bf16x3", BF16X6: "bf16x6"}[_PRECISION]
+    return {v: k for k, v in _PREC_NAMES.items()}[_PRECISION]
 
 
 def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0, precision=F32):
@@ -454,6 +456,10 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     # split-bf16 only where it pays and where its error budget is spent wisely: the sparse convolutions (matrix-pipe
     # bound).  Dense Linear layers (TransVFE, heads, SF-Phase) are memory-bound and stay in exact f32.
     prec = _PRECISION if (_PRECISION != F32 and cin % 32 == 0 and tbl is not None) else F32
+    if prec == BF16X8:
+        # "bf16x8" = tile-halo kernel (ls3d_tile_conv, 8 plane products, head x head in its own accumulator) for the layers that take
+        # it; every other sparse layer (strided / inverse convolutions: 3 neighbours per row, mask-sorted gathers win) runs exact f32
+        prec = F32
     pipe = pipeline_geometry(cout, rows_hint, prec) if (_PIPELINE and tbl is not None and cin % 32 == 0 and kvol <= 32 and ln is None) else None
     if pipe is not None:
         nt, wc = pipe
@@ -482,6 +488,95 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
                    _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
     check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, wc, prec, cin, cout, n_rows, None, ctypes.byref(epi),
                                 _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- tile-halo convolution
+_TILE = _os.environ.get("LS3D_TILE", "1") != "0"          # 3-plane modes: SubM layers on ls3d_tile_conv
+_TILE_KINDS = _os.environ.get("LS3D_TILE_KINDS", "subm")  # which rulebook kinds take the tile path: subm[,conv][,inverse]
+_TILE_MIN_CC = int(_os.environ.get("LS3D_TILE_MIN_CC", "512"))  # cin*cout below which the gather-GEMM stays
+
+
+def set_tile(on, kinds=None, min_cc=None):
+    global _TILE, _TILE_KINDS, _TILE_MIN_CC
+    _TILE = bool(on)
+    if kinds is not None:
+        _TILE_KINDS = kinds
+    if min_cc is not None:
+        _TILE_MIN_CC = int(min_cc)
+
+
+def set_tile_map(flags):
+    """A/B knob of ls3d_tile_conv (include/ls3d.h: ls3d_set_tile_map)"""
+    _L().ls3d_set_tile_map(int(flags))
+
+
+def tile_products():
+    """plane products per f32 product on the tile path, or 0 when the current precision does not use it"""
+    if not _TILE:
+        return 0
+    return 8 if _PRECISION == BF16X8 else 6 if _PRECISION == BF16X6 else 0
+
+
+def use_tile(kind, kvol, cin, cout):
+    return tile_products() != 0 and kind in _TILE_KINDS.split(",") and kvol <= 32 and cout <= 128 and cin % 16 == 0 \
+        and cin * cout >= _TILE_MIN_CC
+
+
+class TilePlan(object):
+    """device-resident plan of ls3d_tile_build for one rulebook table"""
+    __slots__ = ("buf", "n_rows", "kvol", "order", "tbl")
+
+    def record_stream(self, s):
+        self.buf.record_stream(s)
+
+
+def tile_keys(coords, shape_zyx, batch):
+    n = coords.shape[0]
+    keys = torch.empty((n,), dtype=_i32, device=coords.device)
+    check(_L().ls3d_tile_keys(_ptr(coords), n, None, _i3(shape_zyx), int(batch), _ptr(keys), _stream(coords)), "ls3d_tile_keys")
+    return keys
+
+
+def tile_plan(tbl, coords, shape_zyx, batch, order=None):
+    """plan for table tbl[n, kvol] whose output sites are coords[n, 4] (b, z, y, x).  `order`: a precomputed spatial row
+    order (int32 permutation); default = stable sort of ls3d_tile_keys (torch.sort: plumbing)."""
+    n, kvol = tbl.shape
+    if order is None:
+        order = torch.sort(tile_keys(coords, shape_zyx, batch), stable=True)[1].to(_i32)
+    L = _L()
+    p = TilePlan()
+    p.n_rows, p.kvol, p.order, p.tbl = n, kvol, order, tbl
+    p.buf = torch.empty((max(int(L.ls3d_tile_plan_bytes(n, kvol)), 256),), dtype=torch.uint8, device=tbl.device)
+    check(L.ls3d_tile_build(_ptr(tbl), n, None, kvol, _ptr(order), _ptr(p.buf), ctypes.c_size_t(p.buf.numel()), _stream(tbl)), "ls3d_tile_build")
+    return p
+
+
+def tile_conv_pack(w_plain, kvol, cin, cin_pad, cout):
+    L = _L()
+    out = torch.empty((int(L.ls3d_tile_conv_packed_bytes(kvol, cin_pad, cout)),), dtype=torch.uint8, device=w_plain.device)
+    check(L.ls3d_tile_conv_pack(_ptr(w_plain), kvol, cin, cin_pad, cout, _ptr(out), _stream(w_plain)), "ls3d_tile_conv_pack")
+    return out
+
+
+def tile_conv(x, w, plan, cout=None, products=None, scale=None, shift=None, res_pre=None, relu=False, pair=None, out=None, out_ld=None,
+              in_ld=None, ln=None):
+    """out[r, :cout] = epilogue(sum_k W[k]^T x[tbl[r,k]]) on the tile plan of tbl.  w: packing.PackedWeight."""
+    kvol, cin, _ = w.shape
+    assert kvol == plan.kvol
+    cout = cout or w.cout
+    in_ld = in_ld or x.shape[1]
+    products = products or tile_products() or 8
+    if out is None:
+        out_ld = out_ld or cout
+        out = torch.empty((plan.n_rows, out_ld), dtype=torch.float32, device=x.device)
+    else:
+        out_ld = out_ld or out.shape[1]
+    epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
+                   pair.shape[1] if pair is not None else 0, 1 if relu else 0, _vp(ln[0]) if ln is not None else ctypes.c_void_p(0),
+                   _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
+    check(_L().ls3d_tile_conv(_ptr(x), in_ld, _ptr(plan.buf), plan.n_rows, kvol, _ptr(w.for_tile()), cin, cout, products, ctypes.byref(epi),
+                              _vp_any(out), out_ld, _stream(x)), "ls3d_tile_conv")
     return out
 
 

@@ -45,6 +45,14 @@ class PackedWeight(object):
                                                                      precision)
         return d
 
+    def for_tile(self):
+        """layout of ls3d_tile_conv (three bf16 planes, 16-channel chunks)"""
+        d = self._by_nt.get("tile")
+        if d is None:
+            from . import ops
+            d = self._by_nt["tile"] = ops.tile_conv_pack(self.plain, self.kvol, self.cin_src, self.cin, self.cout)
+        return d
+
     @property
     def shape(self):  # (kvol, cin_pad, cout_pad) — what callers size their inputs against
         return (self.kvol, self.cin, _pad32(self.cout))

@@ -47,7 +47,7 @@ class SparseBasicBlock(spconv.SparseModule):
     def forward(self, x):
         assert x.features.dim() == 2, "x.features.dim()=%d" % x.features.dim()
         identity = x.features if self.downsample is None else self.downsample(x)
-        if self.training:  # scn_unet.py:51-69 as written: batch-statistics BatchNorm, differentiable convolutions
+        if self.training or (torch.is_grad_enabled() and x.features.requires_grad):  # scn_unet.py:51-69 as written, differentiable
             out = self.conv1(x)
             out.features = torch.relu(self.bn1(out.features))
             out = self.conv2(out)
@@ -96,6 +96,8 @@ class _GeometryStream(object):
             for o in (getattr(rb, "_orders", None) or {}).values():
                 if o is not None:
                     o.record_stream(self.main)
+            for pl in (getattr(rb, "_plans", None) or {}).values():
+                pl.record_stream(self.main)
 
     def release(self):
         """everything enqueued on the side stream so far must be done before the main stream continues; what follows inside
@@ -235,7 +237,7 @@ class UNetSCN3D(nn.Module):
             for key, src in (("subm1", None), ("subm2", "spconv2"), ("subm3", "spconv3"), ("subm4", "spconv4")):
                 rb = x.find_indice_pair(src)
                 x.indice_dict[key] = spconv.subm_rulebook(x.indices if rb is None else rb.out_indices,
-                                                          x.spatial_shape if rb is None else rb.out_shape, 3)
+                                                          x.spatial_shape if rb is None else rb.out_shape, 3, x.batch_size)
             spconv.prebuild_orders(x, self.modules())
             gs.hand_over(x.indice_dict.values())
             gs.release()
@@ -250,7 +252,7 @@ class UNetSCN3D(nn.Module):
         if self.conv_out is not None:
             batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
             batch_dict["encoded_spconv_tensor_stride"] = 8
-        if self.training:
+        if self.training or (torch.is_grad_enabled() and voxel_features.requires_grad):
             x_up4 = self.UR_block_forward_train(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4)
             x_up3 = self.UR_block_forward_train(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3)
             x_up2 = self.UR_block_forward_train(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2)

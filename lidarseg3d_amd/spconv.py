@@ -55,7 +55,17 @@ class SparseModule(nn.Module):
 
 
 class _Rulebook(object):
-    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index", "_orders")
+    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index", "_orders", "_plans", "batch_size")
+
+    def tile_plan(self, inverse):
+        """tile-halo plan (ops.tile_plan) of the (inverse) table, built once per rulebook"""
+        if getattr(self, "_plans", None) is None:
+            self._plans = {}
+        if inverse not in self._plans:
+            tbl = self.tbl_inv if inverse else self.tbl
+            sites, shape = (self.in_indices, self.in_shape) if inverse else (self.out_indices, self.out_shape)
+            self._plans[inverse] = ops.tile_plan(tbl, sites[:tbl.shape[0]], shape, getattr(self, "batch_size", None) or 256)
+        return self._plans[inverse]
 
     def order(self, inverse):
         """mask-sorted processing order of the (inverse) table, built once per rulebook"""
@@ -166,10 +176,11 @@ class SparseConvolution(PackedModule, SparseModule):
         if rb is not None and (self.subm or rb.kind == "conv"):
             return rb  # spconv semantics: layers with one indice_key share the pairs (also prebuild_conv_rulebooks below)
         if self.subm:
-            rb = subm_rulebook(x.indices, x.spatial_shape, self.kernel_size)
+            rb = subm_rulebook(x.indices, x.spatial_shape, self.kernel_size, x.batch_size)
         else:
             rb = _Rulebook()
-            rb._orders = None
+            rb._orders = rb._plans = None
+            rb.batch_size = x.batch_size
             rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)
             rb.kind = "conv"
             oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape,
@@ -196,6 +207,9 @@ class SparseConvolution(PackedModule, SparseModule):
         tbl = rb.tbl_inv if self.inverse else rb.tbl
         if feats.shape[1] != W.shape[1]:  # e.g. 13 input channels feeding a 16-wide K chunk
             feats = torch.nn.functional.pad(feats, (0, W.shape[1] - feats.shape[1]))
+        if ops.use_tile("inverse" if self.inverse else rb.kind, k, W.shape[1], cout) and tbl.shape[0] > 0:
+            return ops.tile_conv(feats.contiguous(), W, rb.tile_plan(bool(self.inverse)), cout=cout, scale=scale, shift=shift, relu=relu,
+                                 res_pre=res_pre, pair=pair, out=out, out_ld=out_ld)
         # mask-sorted processing order only for the layers whose matrix work can repay the sort (>= 64x64 channels)
         order = rb.order(self.inverse) if self.in_channels * self.out_channels >= 4096 else None
         return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, order=order, cout=cout, scale=scale, shift=shift, relu=relu,
@@ -203,7 +217,7 @@ class SparseConvolution(PackedModule, SparseModule):
 
     def forward(self, x):
         rb = self.rulebook(x)
-        if torch.is_grad_enabled() and (x.features.requires_grad or (self.training and self.weight.requires_grad)):
+        if needs_grad(self, x.features):
             w = self._weight_for(rb)
             f = _SparseConvFn.apply(x.features, self.weight if w is None else w, self.bias, rb, bool(self.inverse), bool(self.subm))
         else:
@@ -213,9 +227,10 @@ class SparseConvolution(PackedModule, SparseModule):
         return x._like(f, rb.out_indices, rb.out_shape)
 
 
-def subm_rulebook(indices, spatial_shape, kernel_size):
+def subm_rulebook(indices, spatial_shape, kernel_size, batch_size=None):
     rb = _Rulebook()
-    rb._orders = None
+    rb._orders = rb._plans = None
+    rb.batch_size = batch_size
     rb.kind = "subm"
     rb.in_indices, rb.in_shape = indices, list(spatial_shape)
     rb.tbl = ops.rulebook_subm(indices, spatial_shape, _triple(kernel_size))
@@ -225,13 +240,20 @@ def subm_rulebook(indices, spatial_shape, kernel_size):
 
 def prebuild_orders(x, layers):
     """mask-sorted processing orders of every rulebook table the given layers will ask for (same criterion as
-    SparseConvolution.conv), from ONE batched sort instead of one sort per table"""
+    SparseConvolution.conv), from ONE batched sort instead of one sort per table; tile-halo plans for the layers that
+    take that path"""
     want = []
     for m in layers:
-        if not isinstance(m, SparseConvolution) or m.in_channels * m.out_channels < 4096:
+        if not isinstance(m, SparseConvolution):
             continue
         rb = x.find_indice_pair(m.indice_key)
         if rb is None:
+            continue
+        if ops.use_tile("inverse" if m.inverse else rb.kind, (rb.tbl_inv if m.inverse else rb.tbl).shape[1], (m.in_channels + 15) // 16 * 16,
+                        m.out_channels):
+            rb.tile_plan(bool(m.inverse))
+            continue
+        if m.in_channels * m.out_channels < 4096:
             continue
         if rb._orders is None:
             rb._orders = {}
@@ -261,7 +283,8 @@ def prebuild_conv_rulebooks(x, convs):
     for (c, icoords, ishape, oc, cnt, nbr_out, nbr_inv, oshape), (n_out, overflow) in zip(pend, counts):
         assert not overflow
         rb = _Rulebook()
-        rb._orders = None
+        rb._orders = rb._plans = None
+        rb.batch_size = x.batch_size
         rb.kind, rb.in_indices, rb.in_shape = "conv", (icoords if n_in == icoords.shape[0] else icoords[:n_in]), list(ishape)
         rb.out_indices, rb.out_shape = oc[:n_out], oshape
         rb.tbl, rb.tbl_inv = nbr_out[:n_out], nbr_inv[:n_in]
@@ -330,6 +353,13 @@ class SparseSequential(SparseModule):
         return x
 
 
+def needs_grad(conv, feats):
+    """the epilogue-fused launches are not differentiable: while autograd records and either the input carries a gradient (input
+    gradients in eval mode) or the layer is being trained (frozen-BN fine-tuning: bn.eval() inside a model in train mode), the
+    caller takes the differentiable composition (conv through _SparseConvFn, then torch BatchNorm / ReLU)"""
+    return torch.is_grad_enabled() and (feats.requires_grad or (conv.training and conv.weight.requires_grad))
+
+
 def bn_scale_shift(bn):
     s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
     t = bn.bias.detach().double() - bn.running_mean.detach().double() * s
@@ -347,7 +377,18 @@ def cached_bn_scale_shift(conv, bn):
 
 
 def conv_bn_act(conv, bn, x, relu=True, res_pre=None, pair=None):
-    """SparseSequential(conv, BN(eval), ReLU) as ONE kernel launch"""
+    """SparseSequential(conv, BN(eval), ReLU) as ONE kernel launch (or, when a gradient must flow, its differentiable composition)"""
+    if needs_grad(conv, x.features):
+        y = conv(x)
+        f = bn(y.features)
+        if res_pre is not None:
+            f = f + res_pre
+        if relu:
+            f = torch.relu(f)
+        if pair is not None:
+            f = f + pair.view(pair.shape[0], f.shape[1], -1).sum(dim=2)
+        y.features = f
+        return y
     scale, shift = cached_bn_scale_shift(conv, bn)
     rb = conv.rulebook(x)
     f = conv.conv(x, rb, scale=scale, shift=shift, relu=relu, res_pre=res_pre, pair=pair)

@@ -729,3 +729,178 @@ def test_mseg3d_training_step_gpu():
     opt.step()
     l1, _, _ = run()
     assert l1 < l0
+
+
+# ------------------------------------------------------------------------------------------------ tile-halo convolution, round 2
+def _subm_frame(n_points, seed, level_strides=0):
+    """coords / shape of the (level 0) active voxels of a synthetic frame"""
+    cfg = synth.NUSC
+    pts = synth.lidar_frame(n_points, seed=seed, **cfg)
+    v, c, n, nv = ops.voxelize_hard(cu(pts), cfg["voxel_size"], cfg["pc_range"], 5, 300000)
+    V = int(nv)
+    coords = torch.cat([torch.zeros((V, 1), dtype=torch.int32, device=DEV), c[:V]], 1).contiguous()
+    return coords, orc.spatial_shape(cfg["voxel_size"], cfg["pc_range"])
+
+
+@pytest.mark.parametrize("cin,cout,products", [(128, 128, 8), (64, 64, 8), (32, 32, 8), (256, 128, 6), (48, 96, 8)])
+def test_tile_conv_full_size_vs_gather_gemm_and_float64(cin, cout, products):
+    """SubM table of a 120k-point frame's stride-2 sites (the level the 64-channel layers run on): tile-halo convolution vs the
+    exact-f32 gather-GEMM (f32 summation-order noise) and both vs a float64 evaluation on the device; fused epilogue; bit-reproducible"""
+    from lidarseg3d_amd.packing import PackedWeight
+    coords, shape = _subm_frame(120000, 5)
+    oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(coords, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    n2 = int(cnt[0])
+    c2 = oc[:n2].contiguous()
+    tbl = ops.rulebook_subm(c2, oshape, (3, 3, 3))
+    g = torch.Generator(device="cpu").manual_seed(cin * 131 + cout)
+    x = (torch.randn((n2, cin), generator=g) * torch.exp(torch.randn((n2, cin), generator=g))).to(DEV)
+    w = (torch.randn((27, cin, cout), generator=g) * 0.05).to(DEV)
+    scale, shift = torch.rand(cout, generator=g).to(DEV) + 0.5, torch.randn(cout, generator=g).to(DEV)
+    res = torch.randn((n2, cout), generator=g).to(DEV)
+    pw = PackedWeight(w, 27, cin, cin, cout)
+    plan = ops.tile_plan(tbl, c2, oshape, 1)
+    got = ops.tile_conv(x, pw, plan, cout=cout, products=products)
+    ref32 = ops.gather_gemm(x, pw, tbl=tbl, order=ops.rulebook_order(tbl), cout=cout)
+    want = torch.zeros((n2, cout), dtype=torch.float64, device=DEV)
+    mag = torch.zeros((n2, cout), dtype=torch.float64, device=DEV)
+    for k in range(27):
+        o = torch.nonzero(tbl[:, k] >= 0)[:, 0]
+        i = tbl[o, k].long()
+        want.index_add_(0, o, x[i].double() @ w[k].double())
+        mag.index_add_(0, o, x[i].double().abs() @ w[k].double().abs())
+    mag += 1e-30
+    e_tile = float(((got.double() - want).abs() / mag).max())
+    e_f32 = float(((ref32.double() - want).abs() / mag).max())
+    r_tile = float(((got.double() - want) / mag).pow(2).mean().sqrt())
+    r_f32 = float(((ref32.double() - want) / mag).pow(2).mean().sqrt())
+    print("tile_conv %d->%d x%d: max %.3g rms %.3g | exact-f32 gather-GEMM: max %.3g rms %.3g" % (cin, cout, products, e_tile, r_tile, e_f32, r_f32))
+    assert e_tile <= 2.0 ** -20 and r_tile <= 2.0 ** -22
+    assert r_tile <= 1.1 * r_f32, (r_tile, r_f32)  # f32-grade: not worse than the exact-f32 MFMA chain against float64
+    fused = ops.tile_conv(x, pw, plan, cout=cout, products=products, scale=scale, shift=shift, res_pre=res, relu=True)
+    wantf = torch.relu(want * scale.double() + shift.double() + res.double())
+    assert float((fused.double() - wantf).abs().max()) <= 2e-5 * float(wantf.abs().max()) + 1e-5
+    assert torch.equal(ops.tile_conv(x, pw, plan, cout=cout, products=products), got)
+    # the plan partitions the rows: every row written exactly once (NaN canary)
+    canary = torch.full((n2, cout), float("nan"), device=DEV)
+    ops.tile_conv(x, pw, plan, cout=cout, products=products, out=canary)
+    assert torch.isfinite(canary).all()
+
+
+def _f64_sdseg3d(sd, frame, cfg):
+    """float64 evaluation of the SDSeg3D forward on the oracle's own f32 inputs and geometry (voxels, rulebooks, 3-NN indices and
+    squared distances): the yardstick for 'f32-grade' arithmetic"""
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    vs, pr = cfg["voxel_size"], cfg["pc_range"]
+    ex = orc.collate_frames([frame], vs, pr, 5, 300000)
+    vf = orc.trans_vfe(sd64, ex["voxels"].double(), ex["num_points"], prefix="reader.", nhead=4)
+    feat, centers = orc.unet_scn3d(sd64, vf, ex["coordinates"].numpy(), orc.spatial_shape(vs, pr), vs, pr, prefix="backbone.")
+    d2, idx = orc.three_nn(ex["points"][:, 1:4].contiguous().numpy(), centers[:, 1:4].contiguous().numpy())
+    recip = 1.0 / (torch.sqrt(torch.from_numpy(d2)).double() + 1e-8)
+    wgt = recip / recip.sum(dim=1, keepdim=True)
+    pf = (feat[torch.from_numpy(idx).long()] * wgt[:, :, None]).sum(1)
+    p = "point_head."
+    pf = orc._lin_bn_relu(sd64, p + "conv_align_layers.", pf, 1e-6)
+    return orc._mlp_cls(sd64, p + "out_cls_layers.", pf), feat
+
+
+def _scale_logits(sd, key_w, key_b, factor):
+    sd = dict(sd)
+    sd[key_w] = sd[key_w] * factor
+    sd[key_b] = sd[key_b] * factor
+    return sd
+
+
+def test_sdseg3d_every_arithmetic_vs_float64_and_absolute_tolerance():
+    """End-to-end logits of a 30k-point frame, weights scaled so that |logit|max ~ 10 (the scale at which the contract '<= 1e-3
+    fp32' means something): every mode within 1e-3 ABSOLUTE of the CPU oracle (f32) and of the float64 evaluation; the bf16x8
+    mode is f32-grade: its error against float64 is not larger than the exact-f32 MFMA path's own."""
+    import json
+    import os
+    cfg = synth.NUSC
+    model, sd = _model(models_cfg.sdseg3d())
+    frame = synth.lidar_frame(30000, seed=12, **cfg)
+    want32 = orc.sdseg3d_forward(sd, [frame], cfg["voxel_size"], cfg["pc_range"])["out_logits"]
+    last_w = max(k for k in sd if k.startswith("point_head.out_cls_layers.") and k.endswith(".weight") and sd[k].dim() == 2)
+    factor = 10.0 / float(want32.abs().max())
+    sd10 = _scale_logits(sd, last_w, last_w[:-6] + "bias", factor)
+    model.load_state_dict(sd10)
+    want32 = orc.sdseg3d_forward(sd10, [frame], cfg["voxel_size"], cfg["pc_range"])["out_logits"]
+    want64, feat64 = _f64_sdseg3d(sd10, frame, cfg)
+    assert 9.0 <= float(want32.abs().max()) <= 11.0
+    pts = cu(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1))
+    rec = {}
+    try:
+        for prec in ("f32", "bf16x8", "bf16x6", "bf16x3"):
+            ops.set_precision(prec)
+            with torch.no_grad():
+                model(dict(points=pts, batch_size=1), return_loss=False)
+            got = model.point_head.forward_ret_dict["out_logits"].cpu()
+            e32 = float((got - want32).abs().max())
+            d64 = (got.double() - want64).abs()
+            rec[prec] = dict(max_abs_vs_oracle_f32=e32, max_abs_vs_f64=float(d64.max()), rms_vs_f64=float(d64.pow(2).mean().sqrt()),
+                             argmax_vs_f64=float((got.argmax(1) == want64.argmax(1)).float().mean()))
+    finally:
+        ops.set_precision("f32")
+    rec["oracle_f32_vs_f64"] = dict(max_abs=float((want32.double() - want64).abs().max()),
+                                    rms=float((want32.double() - want64).pow(2).mean().sqrt()))
+    print(json.dumps(rec))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rec, open("gpurun_out/accuracy_e2e.json", "w"), indent=1)
+    for prec in ("f32", "bf16x8", "bf16x6"):
+        assert rec[prec]["max_abs_vs_oracle_f32"] <= 1e-3 and rec[prec]["max_abs_vs_f64"] <= 1e-3, (prec, rec[prec])
+        assert rec[prec]["argmax_vs_f64"] >= 0.9995
+    assert rec["bf16x3"]["max_abs_vs_f64"] <= 5e-3
+    # bf16x8 (tile-halo kernel with head x head in its own accumulator + exact f32 for the strided / inverse layers) is f32-grade:
+    # its error against float64 is not above the exact-f32 path's (measured: 0.73x on the rms).  bf16x6 drops two products of
+    # weight 2^-24 and accumulates everything in one accumulator: ~3x the f32 path's error, still 300x inside the contract.
+    assert rec["bf16x8"]["rms_vs_f64"] <= 1.0 * rec["f32"]["rms_vs_f64"], rec
+    assert rec["bf16x8"]["max_abs_vs_f64"] <= 1.1 * rec["f32"]["max_abs_vs_f64"], rec
+    assert rec["bf16x6"]["rms_vs_f64"] <= 6.0 * rec["f32"]["rms_vs_f64"], rec
+
+
+def test_mseg3d_absolute_tolerance_at_logit_scale_10():
+    """MSeg3D (GF-/SF-Phase head) end to end, |logit|max ~ 10: max-abs <= 1e-3 against the CPU oracle in every f32-grade mode"""
+    cfg = synth.NUSC
+    model, sd = _model(models_cfg.mseg3d())
+    n = 19000
+    frame = synth.lidar_frame(n, seed=14, **cfg)
+    img, emb, cuv = synth.camera_inputs(n, seed=5, ncam=6, c_img=48, h=40, w=60)
+    ref = orc.mseg3d_forward(sd, [frame], torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), cfg["voxel_size"], cfg["pc_range"])
+    last_w = max(k for k in sd if k.startswith("point_head.out_cls_layers.") and k.endswith(".weight") and sd[k].dim() == 2)
+    sd10 = _scale_logits(sd, last_w, last_w[:-6] + "bias", 10.0 / float(ref["out_logits"].abs().max()))
+    model.load_state_dict(sd10)
+    ref = orc.mseg3d_forward(sd10, [frame], torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), cfg["voxel_size"], cfg["pc_range"])
+    assert 9.0 <= float(ref["out_logits"].abs().max()) <= 11.0
+    pts = cu(np.concatenate([np.zeros((n, 1), np.float32), frame], 1))
+    try:
+        for prec in ("f32", "bf16x8", "bf16x6"):
+            ops.set_precision(prec)
+            with torch.no_grad():
+                model(dict(points=pts, batch_size=1, points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb)), return_loss=False)
+            got = model.point_head.forward_ret_dict["out_logits"].cpu()
+            err = float((got - ref["out_logits"]).abs().max())
+            assert err <= 1e-3, (prec, err)
+    finally:
+        ops.set_precision("f32")
+
+
+def test_unet_tile_path_equals_gather_path_120k():
+    """the whole conv stack of a 120k-point frame: precision bf16x8 with the SubM layers on the tile-halo kernel vs the same
+    arithmetic on the gather-GEMM kernels only (LS3D tile switch off): same products, different summation order"""
+    model, sd = _model(models_cfg.sdseg3d())
+    frame = synth.lidar_frame(120000, seed=6, **synth.NUSC)
+    pts = cu(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1))
+    outs = {}
+    try:
+        ops.set_precision("bf16x8")
+        for tile in (True, False):
+            ops.set_tile(tile)
+            with torch.no_grad():
+                model(dict(points=pts, batch_size=1), return_loss=False)
+            outs[tile] = model.point_head.forward_ret_dict["out_logits"].clone()
+    finally:
+        ops.set_precision("f32")
+        ops.set_tile(True)
+    scale = float(outs[False].abs().max())
+    assert float((outs[True] - outs[False]).abs().max()) <= 3e-6 * scale
+    assert float((outs[True].argmax(1) == outs[False].argmax(1)).float().mean()) >= 0.9999

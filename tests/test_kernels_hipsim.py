@@ -705,3 +705,187 @@ def test_mseg3d_training_step_runs():
             assert p.grad is None, k
         else:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+
+
+# ------------------------------------------------------------------------------------------------ tile-halo convolution
+def _plan_views(plan):
+    """numpy views of an ops.TilePlan buffer (layout of csrc/tileconv.hip:tc_plan)"""
+    al = lambda v: (v + 255) // 256 * 256
+    t, kvol = (plan.n_rows + 127) // 128, plan.kvol
+    raw = plan.buf.numpy()
+    o = 0
+    trow = raw[o:o + t * 128 * 4].view(np.int32).reshape(t, 128); o += al(t * 128 * 4)
+    meta = raw[o:o + t * 8 * 4].view(np.int32).reshape(t, 8); o += al(t * 8 * 4)
+    halo = raw[o:o + t * kvol * 128 * 4].view(np.int32).reshape(t, kvol * 128); o += al(t * kvol * 128 * 4)
+    loc = raw[o:o + t * kvol * 128 * 2].view(np.uint16).reshape(t, kvol, 128)
+    return trow, meta, halo, loc
+
+
+def _sparse_ref(x, w, tbl):
+    acc = np.zeros((tbl.shape[0], w.shape[2]), np.float64)
+    for k in range(tbl.shape[1]):
+        o = np.nonzero(tbl[:, k] >= 0)[0]
+        acc[o] += x[tbl[o, k]].astype(np.float64) @ w[k].astype(np.float64)
+    return acc
+
+
+def test_tile_plan_structure_on_a_subm_rulebook():
+    """the plan of a SubM table: tiles partition the rows, slots are mask-sorted, halos are the sorted unique neighbours,
+    tloc points at the right halo entry, masks are the ORs they claim to be"""
+    cfg = synth.NUSC
+    pts = synth.lidar_frame(4000, seed=11, **cfg)
+    v, c, n, nv = ops.voxelize_hard(torch.from_numpy(pts), cfg["voxel_size"], cfg["pc_range"], 5, 20000)
+    V = int(nv)
+    coords = torch.cat([torch.zeros((V, 1), dtype=torch.int32), c[:V]], 1).contiguous()
+    shape = orc.spatial_shape(cfg["voxel_size"], cfg["pc_range"])
+    tbl = ops.rulebook_subm(coords, shape, (3, 3, 3))
+    plan = ops.tile_plan(tbl, coords, shape, 1)
+    trow, meta, halo, loc = _plan_views(plan)
+    tb = tbl.numpy()
+    assert sorted(trow[trow >= 0].tolist()) == list(range(V))
+    keys = ops.tile_keys(coords, shape, 1).numpy()
+    assert np.array_equal(plan.order.numpy(), np.argsort(keys, kind="stable"))
+    for t in range(trow.shape[0]):
+        rows = trow[t]
+        live = rows >= 0
+        assert meta[t, 6] == live.sum() and (not live.any() or live[:live.sum()].all())
+        masks = np.array([sum(1 << k for k in range(27) if tb[r, k] >= 0) if r >= 0 else 0 for r in rows])
+        assert (np.diff(masks[live]) <= 0).all()
+        want_halo = np.unique(tb[rows[live]][tb[rows[live]] >= 0])
+        H = meta[t, 0]
+        assert H == want_halo.size and np.array_equal(halo[t, :H], want_halo)
+        assert meta[t, 1] == np.bitwise_or.reduce(masks)
+        for w in range(4):
+            assert meta[t, 2 + w] == np.bitwise_or.reduce(masks[32 * w:32 * w + 32])
+        for s in np.nonzero(live)[0]:
+            for k in range(27):
+                nb = tb[rows[s], k]
+                assert (loc[t, k, s] == 0xFFFF) if nb < 0 else (halo[t, loc[t, k, s]] == nb)
+    # spatial locality is the point: a tile's halo is a small multiple of its rows
+    assert meta[:, 0].mean() < 3.0 * 128
+
+
+@pytest.mark.parametrize("cin,cout,products", [(32, 64, 8), (64, 128, 8), (16, 32, 6), (48, 96, 8)])
+def test_tile_conv_matches_float64_and_gather_gemm(cin, cout, products):
+    """random table (halos far beyond the LDS window: several passes per tile), fused epilogue, output into a column slice"""
+    rng = np.random.default_rng(cin + cout)
+    vin, vout, kvol = 900, 300, 27
+    x = (rng.normal(size=(vin, cin)) * np.exp(rng.normal(size=(vin, cin)))).astype(np.float32)
+    w = rng.normal(size=(kvol, cin, cout)).astype(np.float32) * 0.1
+    tbl = rng.integers(0, vin, size=(vout, kvol)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.5] = -1
+    tbl[7] = -1
+    tbl[130:140, 3:] = -1
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+    res = rng.normal(size=(vout, cout)).astype(np.float32)
+    pair = rng.normal(size=(vout, 2 * cout)).astype(np.float32)
+    acc = _sparse_ref(x, w, tbl)
+    mag = _sparse_ref(np.abs(x), np.abs(w), tbl) + 1e-30
+    want = np.maximum(acc * scale + shift + res, 0) + pair[:, 0::2] + pair[:, 1::2]
+    T = torch.from_numpy
+    pw = PackedWeight(T(w), kvol, cin, cin, cout)
+    coords = T(np.stack([np.zeros(vout), np.zeros(vout), rng.integers(0, 64, vout), rng.integers(0, 64, vout)], 1).astype(np.int32))
+    plan = ops.tile_plan(T(tbl), coords, (1, 64, 64), 1)
+    trow, meta, halo, loc = _plan_views(plan)
+    assert meta[:, 0].max() > 448  # the multi-pass path is exercised
+    raw = ops.tile_conv(T(x), pw, plan, cout=cout, products=products)
+    err = np.abs(raw.numpy() - acc) / mag
+    f32 = ops.gather_gemm(T(x), pw, tbl=T(tbl), cout=cout)
+    err32 = np.abs(f32.numpy() - acc) / mag
+    # the host emulation rounds after every product of every plane MFMA (8 x 16 f32 additions per 16 channels instead of 16), so
+    # only the error CLASS is asserted here; the device figures are measured in tests/test_gpu_parity.py
+    assert err.max() <= 4.0 * err32.max() + 2.0 ** -22, (err.max(), err32.max())
+    out = ops.tile_conv(T(x), pw, plan, cout=cout, products=products, scale=T(scale), shift=T(shift), res_pre=T(res), relu=True, pair=T(pair))
+    np.testing.assert_allclose(out.numpy(), want, rtol=0, atol=3e-4)
+    wide = torch.zeros((vout, 2 * cout))
+    ops.tile_conv(T(x), pw, plan, cout=cout, products=products, out=wide[:, cout:], out_ld=2 * cout)
+    assert torch.equal(wide[:, cout:], raw) and float(wide[:, :cout].abs().max()) == 0.0
+    again = ops.tile_conv(T(x), pw, plan, cout=cout, products=products)
+    assert torch.equal(again, raw)
+
+
+def test_tile_conv_any_row_order_gives_the_same_rows():
+    """tiles only group rows: with single-pass halos the per-row summation order (chunks outer, offsets inner) does not depend
+    on the tiling, so two different spatial orders give bit-identical outputs"""
+    rng = np.random.default_rng(9)
+    vin, vout, kvol, cin, cout = 200, 260, 27, 32, 32
+    x = rng.normal(size=(vin, cin)).astype(np.float32)
+    w = rng.normal(size=(kvol, cin, cout)).astype(np.float32) * 0.1
+    tbl = rng.integers(0, vin, size=(vout, kvol)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.8] = -1
+    T = torch.from_numpy
+    pw = PackedWeight(T(w), kvol, cin, cin, cout)
+    coords = T(np.zeros((vout, 4), np.int32))
+    outs = []
+    for order in (np.arange(vout), rng.permutation(vout)):
+        plan = ops.tile_plan(T(tbl), coords, (1, 8, 8), 1, order=T(order.astype(np.int32)))
+        assert _plan_views(plan)[1][:, 0].max() <= 448
+        outs.append(ops.tile_conv(T(x), pw, plan, cout=cout, products=8))
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].numpy(), _sparse_ref(x, w, tbl), rtol=0, atol=1e-4)
+
+
+def test_unet_bf16x8_tile_path_vs_f32(monkeypatch):
+    """UNetSCN3D with the SubM layers on the tile-halo kernel (precision bf16x8) against the exact-f32 gather-GEMM path"""
+    cfg = synth.NUSC
+    from lidarseg3d_amd import models_cfg
+    import lidarseg3d_amd as L
+    pts = synth.lidar_frame(90, seed=21, **cfg)
+    v, c, n, nv = ops.voxelize_hard(torch.from_numpy(pts), cfg["voxel_size"], cfg["pc_range"], 5, 20000)
+    V = int(nv)
+    coords = torch.cat([torch.zeros((V, 1), dtype=torch.int32), c[:V]], 1).contiguous()
+    bcfg = dict(models_cfg.sdseg3d()["backbone"], model_cfg=dict(SCALING_RATIO=1))  # 16/32/64/64 channels: fewer chunks to emulate
+    net = L.build_backbone(bcfg).eval()
+    shapes = {k: tuple(t.shape) for k, t in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(a) for k, a in synth.random_state_dict(shapes, 3).items()})
+    feats = torch.from_numpy(np.random.default_rng(2).normal(size=(V, 16)).astype(np.float32))
+    gs = orc.grid_size(cfg["voxel_size"], cfg["pc_range"])
+
+    def run():
+        bd = dict(voxel_features=feats, voxel_coords=coords, batch_size=1, input_shape=np.array([int(gs[0]), int(gs[1]), int(gs[2])]))
+        return net(bd)["conv_point_features"]
+
+    ref = run()
+    ops.set_precision("bf16x8")
+    ops.set_tile(True, min_cc=256)  # also the 16-channel level of this small net
+    calls = []
+    orig = ops.tile_conv
+    monkeypatch.setattr(ops, "tile_conv", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    try:
+        got = run()
+    finally:
+        ops.set_precision("f32")
+        ops.set_tile(True, min_cc=512)
+    assert len(calls) >= 25
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+
+
+def test_frozen_batchnorm_and_eval_mode_input_gradients_keep_the_graph():
+    """with BatchNorm frozen (bn.eval() inside a model in train mode) the epilogue-fused launches must not cut the
+    graph: every convolution on the path still gets its weight gradient; in eval mode an input that requires grad gets one, and
+    the values equal the fused inference path's"""
+    cfg = synth.NUSC
+    g = golden("unet_nusc_c13.npz")
+    n = 120
+    coords = torch.from_numpy(g["coords"][:n])
+    feats0 = torch.from_numpy(g["voxel_features"][:n])
+    net = scn_unet.UNetSCN3D(num_input_features=13, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
+                             model_cfg=dict(SCALING_RATIO=1), ds_factor=8, us_factor=8)
+    shape = np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.eval()
+    out = net(dict(voxel_features=feats0.clone(), voxel_coords=coords, batch_size=1, input_shape=shape))["conv_point_features"]
+    out.sum().backward()
+    missing = [k for k, p in net.named_parameters() if p.dim() == 5 and p.grad is None and not k.startswith("conv_out")]
+    assert not missing, missing
+    assert net.conv_input[0].weight.grad.abs().sum() > 0
+    net.eval()
+    with torch.no_grad():
+        ref = net(dict(voxel_features=feats0.clone(), voxel_coords=coords, batch_size=1, input_shape=shape))["conv_point_features"]
+    f = feats0.clone().requires_grad_(True)
+    got = net(dict(voxel_features=f, voxel_coords=coords, batch_size=1, input_shape=shape))["conv_point_features"]
+    got.sum().backward()
+    assert f.grad is not None and float(f.grad.abs().sum()) > 0
+    np.testing.assert_allclose(got.detach().numpy(), ref.numpy(), rtol=0, atol=1e-4 * max(1.0, float(ref.abs().max())))
