@@ -169,6 +169,20 @@ void orc_three_interpolate(int c, int m, int n, const float *feat, const int32_t
   }
 }
 
+/* grad_points[c, idx[n,j]] += grad_out[c,n] * weight[n,j]
+ * det3d/ops/pointnet2_batch/src/interpolate_gpu.cu:127-149 (atomicAdd: the reference's order is not defined; this
+ * restatement adds in point order, j = 0,1,2).  grad_points must be zeroed (pointnet2_utils.py:146). */
+void orc_three_interpolate_grad(int c, int n, int m, const float *grad_out, const int32_t *idx, const float *weight,
+                                float *grad_points) {
+#pragma omp parallel for schedule(static)
+  for (int ch = 0; ch < c; ++ch) {
+    float *g = grad_points + (size_t)ch * m;
+    const float *go = grad_out + (size_t)ch * n;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < 3; ++j) g[idx[3 * i + j]] += go[i] * weight[3 * i + j];
+  }
+}
+
 /* gather-GEMM-scatter sparse convolution over an explicit pair list (spconv v1.x native algorithm,
  * SURVEY.md §2.3): out[o] += W[k]^T in[i] for each pair (i,o) of offset k.
  * pairs_in/pairs_out: concatenated per-offset lists, pair_off[k]..pair_off[k+1] delimits offset k.

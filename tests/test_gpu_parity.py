@@ -904,3 +904,26 @@ def test_unet_tile_path_equals_gather_path_120k():
     scale = float(outs[False].abs().max())
     assert float((outs[True] - outs[False]).abs().max()) <= 3e-6 * scale
     assert float((outs[True].argmax(1) == outs[False].argmax(1)).float().mean()) >= 0.9999
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x8"])
+def test_spconv_modules_equal_dense_convolution_on_device(prec):
+    """lidarseg3d_amd.spconv on the MI355X against dense convolutions of the densified grids (tests/dense_cases.py): SubM, strided
+    (incl. padding (0,1,1), kernel (3,1,1)/stride (2,1,1), stride (2,2,1), k = 2), inverse, asymmetric Cylinder3D kernel shapes"""
+    from tests import dense_cases as dc
+    from tests.test_spconv_dense_equivalence import run_modules
+    try:
+        ops.set_precision(prec)
+        for name, ks, st, pd, grid in dc.CASES:
+            for what, err in run_modules(name, ks, st, pd, grid, DEV).items():
+                assert err <= 2e-6, (prec, name, what, err)
+    finally:
+        ops.set_precision("f32")
+
+
+def test_pointnet2_utils_dropin_forward_and_backward_vs_oracle_gpu():
+    """the literal replacement of det3d/ops/pointnet2_batch/pointnet2_utils.py on the device, incl. a
+    frame-sized case"""
+    from tests import pointnet2_cases
+    pointnet2_cases.run(DEV)
+    pointnet2_cases.run(DEV, b=1, n=20000, m=6000, c=32, seed=3)

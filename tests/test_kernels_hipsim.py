@@ -889,3 +889,9 @@ def test_frozen_batchnorm_and_eval_mode_input_gradients_keep_the_graph():
     got.sum().backward()
     assert f.grad is not None and float(f.grad.abs().sum()) > 0
     np.testing.assert_allclose(got.detach().numpy(), ref.numpy(), rtol=0, atol=1e-4 * max(1.0, float(ref.abs().max())))
+
+
+def test_pointnet2_utils_dropin_forward_and_backward_vs_oracle():
+    """ls3d_three_interpolate / _grad and pointnet2_utils.ThreeNN / ThreeInterpolate had no test"""
+    from tests import pointnet2_cases
+    pointnet2_cases.run("cpu")
