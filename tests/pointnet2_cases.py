@@ -37,8 +37,8 @@ def run(device, b=2, n=300, m=70, c=11, seed=0):
         got = f.grad[i].cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)               # atomic / point-order f32 sums
     # the raw C-ABI entry points too (what INTEGRATION.md binds), incl. m < 3 and empty batches
-    d2s, ixs = ops.three_nn(T(unknown[:, :4]), T(known[:, :2]))
-    d2o, ixo = orc.three_nn(unknown[0, :4], known[0, :2])
+    d2s, ixs = ops.three_nn(T(np.ascontiguousarray(unknown[:, :4])), T(np.ascontiguousarray(known[:, :2])))
+    d2o, ixo = orc.three_nn(np.ascontiguousarray(unknown[0, :4]), np.ascontiguousarray(known[0, :2]))
     assert np.array_equal(ixs[0].cpu().numpy(), ixo) and np.array_equal(d2s[0].cpu().numpy(), d2o)
     g = ops.three_interpolate_grad(T(gout), idx, weight, m)
     assert torch.allclose(g, f.grad, rtol=0, atol=2e-5)
