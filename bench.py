@@ -8,17 +8,25 @@ Weights are random-init of the reference architecture (no checkpoints offline); 
 Multi-GPU: frames shard one-per-GPU, no data-path collective (scaling "weak"); the only collectives are the
 timing barrier and the max-over-ranks of the elapsed time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--points 120000] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points 120000] [--precision bf16x8|f32|...] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Arithmetic of `value` (--precision, default "bf16x8"): the SubM layers run on the tile-halo kernel with every f32 operand split
+EXACTLY into three bf16 planes and 8 of the 9 plane products accumulated in f32 (head x head in its own accumulator); the strided
+and inverse convolutions and every dense layer run exact-f32 MFMA.  This mode is f32-grade — its end-to-end error against a
+float64 evaluation is BELOW the exact-f32 MFMA path's own (tests/test_gpu_parity.py::test_sdseg3d_every_arithmetic_vs_float64_...,
+DESIGN.md 4.1) — and the exact-f32 path is timed beside it (`exact_f32_mode`).
+
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     — the dominant kernel (k_gather_gemm, the sparse-conv gather-GEMM): algorithmic pair-model bytes
-                 sum_l P_l*(Cin+Cout)*4 (SURVEY.md §8d) over the summed HIP-event durations of those launches;
-  cpu_baseline — the CPU oracle (oracle/ref.py, kind "port") timed on the host cores on a bounded sample.
+  roofline     — the sparse-conv stack (37 launches, contiguous on the main stream, bracketed by ONE HIP-event pair per frame):
+                 algorithmic pair-model bytes sum_l P_l*(Cin+Cout)*4 (SURVEY.md §8d) over its measured duration;
+  cpu_baseline — the CPU oracle (oracle/ref.py, kind "port") timed on the host cores on a bounded sample;
+  stages_ms    — per-stage HIP-event breakdown of a frame; latency — median / p95 of the per-step wall time.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,6 +40,14 @@ if ROOT not in sys.path:
 F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
 
+DTYPES = {
+    "f32": "f32",
+    "bf16x8": "f32 (f32-grade: SubM layers on exact 3-plane bf16 splits, 8 of 9 plane products on bf16 MFMA with f32 accumulation; "
+              "everything else exact-f32 MFMA)",
+    "bf16x6": "f32 via exact 3-way bf16 split (6 bf16 MFMAs per product, f32 accumulate)",
+    "bf16x3": "f32 via split-bf16 (bf16x3 MFMA, f32 accumulate)",
+}
+
 
 def build_model(dev, seed=5, kind="sdseg3d"):
     import lidarseg3d_amd as L
@@ -44,61 +60,70 @@ def build_model(dev, seed=5, kind="sdseg3d"):
     return model.to(dev), sd
 
 
-class ConvTimer:
-    """HIP-event brackets around every sparse-conv gather-GEMM launch (installed as ops.gather_gemm wrapper)."""
+class ConvCensus:
+    """one untimed frame with ops.gather_gemm / ops.tile_conv wrapped: which sparse-conv launches run, their pair counts and
+    channel widths -> algorithmic bytes and flops of the stack (pair model)"""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.orig_tile = ops, ops.gather_gemm, ops.tile_conv
-        self.events, self.algo_bytes, self.flops, self.enabled = [], 0.0, 0.0, False
-        self.pairs_cache = {}
+        self.ops, self.meta = ops, []
 
-    def install(self):
-        def wrapped(x, w, tbl=None, **kw):
-            if not self.enabled or tbl is None:
-                return self.orig(x, w, tbl=tbl, **kw)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            out = self.orig(x, w, tbl=tbl, **kw)
-            b.record()
-            self.events.append((a, b))
+    def run(self, step):
+        ops, g, t = self.ops, self.ops.gather_gemm, self.ops.tile_conv
+
+        def wg(x, w, tbl=None, **kw):
+            if tbl is not None:
+                self.meta.append((tbl, w.shape[1], kw.get("cout") or w.cout, "gather"))
+            return g(x, w, tbl=tbl, **kw)
+
+        def wt(x, w, plan, **kw):
+            self.meta.append((plan.tbl, w.shape[1], kw.get("cout") or w.cout, "tile"))
+            return t(x, w, plan, **kw)
+        ops.gather_gemm, ops.tile_conv = wg, wt
+        try:
+            with torch.no_grad():
+                step()
+            torch.cuda.synchronize()
+        finally:
+            ops.gather_gemm, ops.tile_conv = g, t
+        pairs, algo, flops = {}, 0.0, 0.0
+        for tbl, cin, cout, _ in self.meta:
             key = (tbl.data_ptr(), tbl.shape[0])
-            if key not in self.pairs_cache:
-                self.pairs_cache[key] = None  # filled after the timed region (needs a sync)
-            self.meta.append((key, tbl, w.shape[1], kw.get("cout") or w.cout))
-            return out
-        def wrapped_tile(x, w, plan, **kw):
-            if not self.enabled:
-                return self.orig_tile(x, w, plan, **kw)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            out = self.orig_tile(x, w, plan, **kw)
-            b.record()
-            self.events.append((a, b))
-            self.meta.append(((plan.tbl.data_ptr(), plan.tbl.shape[0]), plan.tbl, w.shape[1], kw.get("cout") or w.cout))
-            return out
-        self.meta = []
-        self.ops.gather_gemm = wrapped
-        self.ops.tile_conv = wrapped_tile
-        # modules imported `ops` as a module, so they see the replacement
-        return self
-
-    def summarize(self):
-        torch.cuda.synchronize()
-        total_ms = sum(a.elapsed_time(b) for a, b in self.events)
-        pairs = {}
-        algo = flops = 0.0
-        for key, tbl, cin, cout in self.meta:
             if key not in pairs:
                 pairs[key] = int((tbl >= 0).sum().item())
-            p = pairs[key]
-            algo += p * (cin + cout) * 4.0
-            flops += 2.0 * p * cin * cout
-        n = max(len(self.events), 1)
-        return dict(launches=len(self.events), total_ms=total_ms, avg_us=1e3 * total_ms / n, algo_bytes=algo, flops=flops)
+            algo += pairs[key] * (cin + cout) * 4.0
+            flops += 2.0 * pairs[key] * cin * cout
+        return dict(launches=len(self.meta), tile_launches=sum(1 for m in self.meta if m[3] == "tile"), algo_bytes=algo, flops=flops)
 
 
-def cpu_baseline_worker(n_points, seed, threads):
-    """runs in a child process: the CPU oracle's full SDSeg3D forward on one frame, timed"""
+def timed_steps(step, steps, warmup, dist=None, dev=None):
+    """W untimed steps, then K steps bracketed by barrier + synchronize; per-step HIP events for median / p95"""
+    with torch.no_grad():
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            step()
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    return elapsed, dict(median_ms=statistics.median(per), p95_ms=per[min(len(per) - 1, int(round(0.95 * (len(per) - 1))))], min_ms=per[0],
+                         max_ms=per[-1])
+
+
+def cpu_baseline_worker(n_points, seed, threads, repeats):
+    """runs in a child process: the CPU oracle's full SDSeg3D forward on one frame, timed `repeats` times"""
     from lidarseg3d_amd import synth
     from oracle import ref as orc
     torch.set_num_threads(threads)
@@ -109,29 +134,77 @@ def cpu_baseline_worker(n_points, seed, threads):
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, 5).items()}
     frame = synth.lidar_frame(n_points, seed=seed, **synth.NUSC)
-    t0 = time.time()
-    orc.sdseg3d_forward(sd, [frame], synth.NUSC["voxel_size"], synth.NUSC["pc_range"])
-    print(json.dumps({"seconds": time.time() - t0}))
+    orc.sdseg3d_forward(sd, [synth.lidar_frame(2000, seed=1, **synth.NUSC)], synth.NUSC["voxel_size"], synth.NUSC["pc_range"])  # warm-up
+    ts = []
+    for _ in range(repeats):
+        t0 = time.time()
+        orc.sdseg3d_forward(sd, [frame], synth.NUSC["voxel_size"], synth.NUSC["pc_range"])
+        ts.append(time.time() - t0)
+    print(json.dumps({"seconds": ts}))
 
 
-def cpu_baseline(n_points, seed, timeout_s=420):
-    """the CPU oracle (oracle/ref.py, a port: the reference has no CPU forward) on ONE frame of the same workload,
-    rank 0 / N=1 only.  Thread count capped: torch-CPU index_add_/mm of the restatement does not scale past a few
-    dozen threads (on a 256-thread host the uncapped run is >10x slower)."""
+def _cpu_run(n_points, seed, threads, repeats, timeout_s):
     import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(n_points), str(seed), str(threads), str(repeats)],
+                       env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+    return json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
+
+
+def cpu_baseline(n_points, seed):
+    """the CPU oracle (oracle/ref.py, a port: the reference has no CPU forward), rank 0 / N=1 only, bounded: median of 3 warmed
+    runs of ONE full-size frame on min(cores, 32) threads (torch-CPU index_add_/mm of the restatement stops scaling there: on a
+    256-thread host the uncapped run is >10x slower), plus a 1-thread figure on a 1/8-size frame"""
     cores = os.cpu_count() or 1
     threads = min(cores, 32)
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(n_points), str(seed), str(threads)],
-                           env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
-        dt = json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
+        ts = _cpu_run(n_points, seed, threads, 3, 300)
+        med = statistics.median(ts)
+        out = dict(value=1.0 / med, unit="frames/s", cores=threads, kind="port",
+                   sample="median of 3 warmed runs of 1 frame of %d points (%s s), full SDSeg3D forward incl. CPU voxelization, %d of %d host "
+                          "threads; oracle/ref.py (torch-CPU gather-mm-scatter spconv restatement, OpenMP C exact 3-NN)"
+                          % (n_points, "/".join("%.1f" % t for t in ts), threads, cores))
     except Exception as e:  # never let the baseline take the bench down
         return dict(value=None, unit="frames/s", cores=threads, kind="port", sample="failed: %r" % (e,))
-    return dict(value=1.0 / dt, unit="frames/s", cores=threads, kind="port",
-                sample="1 frame of %d points, full SDSeg3D forward incl. CPU voxelization, %.1f s on %d of %d host threads; "
-                       "oracle/ref.py (torch-CPU gather-mm-scatter spconv restatement, OpenMP C exact 3-NN)"
-                       % (n_points, dt, threads, cores))
+    try:
+        small = max(n_points // 8, 1000)
+        t1 = _cpu_run(small, seed, 1, 1, 200)[0]
+        out["single_thread"] = dict(seconds=t1, points=small, frames_per_s_scaled_to_full_frame=1.0 / (t1 * n_points / small),
+                                    note="1 thread, 1/8-size frame, scaled linearly in the point count")
+    except Exception as e:
+        out["single_thread"] = dict(error=repr(e))
+    return out
+
+
+def stage_breakdown(model, pts, B, frames=5):
+    """HIP events at the stage boundaries of SegNet.forward on the main stream (geometry runs beside the reader on a side stream;
+    `backbone` includes the wait for it).  Median over a few extra frames."""
+    acc = {k: [] for k in ("voxelize", "reader", "backbone", "head+argmax")}
+    hooks, ev = [], {}
+
+    def mark(tag):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev[tag] = e
+
+    hooks.append(model.reader.register_forward_pre_hook(lambda m, a: mark("r0")))
+    hooks.append(model.reader.register_forward_hook(lambda m, a, o: mark("r1")))
+    hooks.append(model.backbone.register_forward_hook(lambda m, a, o: mark("b1")))
+    try:
+        with torch.no_grad():
+            for _ in range(frames):
+                mark("s")
+                model(dict(points=pts, batch_size=B), return_loss=False)
+                mark("e")
+                torch.cuda.synchronize()
+                acc["voxelize"].append(ev["s"].elapsed_time(ev["r0"]))
+                acc["reader"].append(ev["r0"].elapsed_time(ev["r1"]))
+                acc["backbone"].append(ev["r1"].elapsed_time(ev["b1"]))
+                acc["head+argmax"].append(ev["b1"].elapsed_time(ev["e"]))
+    finally:
+        for h in hooks:
+            h.remove()
+    return {k: statistics.median(v) for k, v in acc.items()}
 
 
 def main():
@@ -142,23 +215,23 @@ def main():
     ap.add_argument("--points", type=int, default=120000)
     ap.add_argument("--cpu-points", type=int, default=None, help="points of the CPU-baseline frame (default: --points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["f32", "bf16x8", "bf16x6", "bf16x3"], default="f32",
-                    help="gather-GEMM arithmetic: f32 = exact f32 MFMA (default, the parity configuration); bf16x3 = split-bf16 "
-                         "(3 bf16 MFMAs per product, ~1e-5 relative error)")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra bf16x3 measurement")
+    ap.add_argument("--precision", choices=list(DTYPES), default="bf16x8",
+                    help="arithmetic of the sparse convolutions (see the module docstring); f32 = exact-f32 MFMA everywhere")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the extra legs (exact f32, bf16x3, two streams, MSeg3D)")
+    ap.add_argument("--no-fast-mode", action="store_true", help=argparse.SUPPRESS)  # round-1 spelling of --no-extra-modes
     ap.add_argument("--streams", type=int, default=1,
-                    help="throughput mode: a step = this many frames, each a batch of one on its own HIP stream (the reader / head / "
-                         "rulebook kernels of one frame run beside the conv stack of another); SDSeg3D only")
+                    help="throughput mode: a step = this many frames, each a batch of one on its own HIP stream; SDSeg3D only")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames collated into one forward per GPU per step (1 = the reference's --speed_test batch size)")
     ap.add_argument("--row-order", choices=["mask", "none"], default="mask")
     ap.add_argument("--model", choices=["sdseg3d", "mseg3d"], default="sdseg3d",
                     help="sdseg3d = BASELINE configs[1] (the metric's config); mseg3d = configs[2] (LiDAR + 6-camera features)")
-    ap.add_argument("--cpu-baseline-worker", nargs=3, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-worker", nargs=4, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(*[int(v) for v in args.cpu_baseline_worker])
         return
+    extra_modes = not (args.no_extra_modes or args.no_fast_mode)
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -173,158 +246,157 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://")
 
-    from lidarseg3d_amd import ops, synth
+    from lidarseg3d_amd import ops, scn_unet, synth
     ops.set_precision(args.precision)
     ops.set_row_order(args.row_order)
     model, sd = build_model(dev, kind=args.model)
     B = max(1, args.frames_per_step)
-    frames = [synth.lidar_frame(args.points, seed=100 + rank * B + b, **synth.NUSC) for b in range(B)]
-    pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1)
-                                           for b, f in enumerate(frames)])).to(dev)
-    extra = {}
-    if args.model == "mseg3d":  # HRNet-w18 feature maps of 6 cameras at 1/4 resolution + camera class embeddings (inputs of the path)
-        img, emb, cuv = synth.camera_inputs(args.points * B, seed=100 + rank, ncam=6, c_img=48, h=160, w=240, batch=B)
-        extra = dict(points_cuv=torch.from_numpy(cuv).to(dev), image_features=torch.from_numpy(img).to(dev),
-                     camera_semantic_embeddings=torch.from_numpy(emb).to(dev))
-    timer = ConvTimer(ops).install()
-
     S = max(1, args.streams)
-    TP = 2 if (args.model == "sdseg3d" and B == 1 and S == 1 and world == 1 and not args.no_fast_mode) else 0  # extra throughput legs
-    if S > 1 or TP:
+    TP = 2 if (args.model == "sdseg3d" and B == 1 and S == 1 and world == 1 and extra_modes) else 0
+
+    def make_inputs(kind, n_streams):
+        frames = [synth.lidar_frame(args.points, seed=100 + rank * B + b, **synth.NUSC) for b in range(B)]
+        pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1)
+                                               for b, f in enumerate(frames)])).to(dev)
+        extra = {}
+        if kind == "mseg3d":  # HRNet-w18 feature maps of 6 cameras at 1/4 resolution + camera class embeddings (inputs of the path)
+            img, emb, cuv = synth.camera_inputs(args.points * B, seed=100 + rank, ncam=6, c_img=48, h=160, w=240, batch=B)
+            extra = dict(points_cuv=torch.from_numpy(cuv).to(dev), image_features=torch.from_numpy(img).to(dev),
+                         camera_semantic_embeddings=torch.from_numpy(emb).to(dev))
+        spts, streams = [], []
+        if n_streams > 1:
+            sframes = [synth.lidar_frame(args.points, seed=100 + rank * n_streams + i, **synth.NUSC) for i in range(n_streams)]
+            spts = [torch.from_numpy(np.concatenate([np.zeros((f.shape[0], 1), np.float32), f], 1)).to(dev) for f in sframes]
+            streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+        return pts, extra, spts, streams
+
+    pts, extra, spts, streams = make_inputs(args.model, max(S, TP))
+    if S > 1:
         assert args.model == "sdseg3d" and B == 1, "--streams: SDSeg3D, one frame per stream"
-        nS = max(S, TP)
-        sframes = [synth.lidar_frame(args.points, seed=100 + rank * nS + i, **synth.NUSC) for i in range(nS)]
-        spts = [torch.from_numpy(np.concatenate([np.zeros((f.shape[0], 1), np.float32), f], 1)).to(dev) for f in sframes]
-        streams = [torch.cuda.Stream(dev) for _ in range(nS)]
 
-    def step(n_streams=None):
-        n_streams = S if n_streams is None else n_streams
+    def make_step(m, pts_, extra_, n_streams):
         if n_streams == 1:
-            ret = model(dict(points=pts, batch_size=B, **extra), return_loss=False)
-            return ret[0]["pred_point_sem_labels"]
-        cur = torch.cuda.current_stream(dev)
-        labels = None
-        for st, p in zip(streams[:n_streams], spts[:n_streams]):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                labels = model(dict(points=p, batch_size=1), return_loss=False)[0]["pred_point_sem_labels"]
-        for st in streams[:n_streams]:
-            cur.wait_stream(st)
-        return labels
+            return lambda: m(dict(points=pts_, batch_size=B, **extra_), return_loss=False)[0]["pred_point_sem_labels"]
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        timer.enabled = True
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            labels = step()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        timer.enabled = False
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def step_n():
+            cur = torch.cuda.current_stream(dev)
+            labels = None
+            for st, p in zip(streams[:n_streams], spts[:n_streams]):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    labels = m(dict(points=p, batch_size=1), return_loss=False)[0]["pred_point_sem_labels"]
+            for st in streams[:n_streams]:
+                cur.wait_stream(st)
+            return labels
+        return step_n
 
-    conv = timer.summarize()
-    alt = {}
-    if args.precision == "f32" and not args.no_fast_mode and world == 1:
-        # the same step in the split-bf16 arithmetics: reported beside, never as, `value`
-        ref_logits = model.point_head.forward_ret_dict["out_logits"].clone()
-        for prec, label in (("bf16x8", "bf16x8 (exact 3-way bf16 split, 8 of 9 plane products: f32-grade; SubM layers on the tile-halo kernel)"),
-                            ("bf16x6", "bf16x6 (exact 3-way bf16 split, 6 partial products per f32 product: f32-grade results)"),
-                            ("bf16x3", "bf16x3 (split-bf16 MFMA, f32 accumulate)")):
-            ops.set_precision(prec)
-            timer2 = ConvTimer(ops)
-            timer2.orig, timer2.orig_tile = timer.orig, timer.orig_tile
-            timer2.install()
+    def measure(prec, steps, warmup, n_streams, with_dist):
+        """one leg: W untimed + K timed steps; with one stream also the conv-stack event brackets of the timed steps"""
+        ops.set_precision(prec)
+        st = make_step(model, pts, extra, n_streams)
+        census = ConvCensus(ops).run(make_step(model, pts, extra, 1)) if n_streams == 1 else None
+        events = []
+        scn_unet.UNetSCN3D.conv_stack_events = events if n_streams == 1 else None
+        try:
             with torch.no_grad():
-                for _ in range(args.warmup):
-                    step()
-                torch.cuda.synchronize()
-                timer2.enabled = True
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    step()
-                torch.cuda.synchronize()
-                el2 = time.perf_counter() - t0
-                timer2.enabled = False
-            c2 = timer2.summarize()
+                for _ in range(warmup):
+                    st()
+            torch.cuda.synchronize()
+            del events[:]  # the brackets of the warm-up steps
+            elapsed, lat = timed_steps(st, steps, 0, dist if with_dist else None, dev)
+        finally:
+            scn_unet.UNetSCN3D.conv_stack_events = None
+        out = dict(precision=prec, frames_per_s=world * B * n_streams * steps / elapsed, ms_per_step=1e3 * elapsed / steps, latency=lat)
+        if census is not None and events:
+            stack_ms = sorted(a.elapsed_time(b) for a, b in events)
+            mean = sum(stack_ms) / len(stack_ms)
+            out.update(census=census, conv_stack_ms=dict(mean=mean, median=statistics.median(stack_ms),
+                                                         p95=stack_ms[min(len(stack_ms) - 1, int(round(0.95 * (len(stack_ms) - 1))))]),
+                       roofline_frac=census["algo_bytes"] / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, tflops=census["flops"] / (mean * 1e-3) / 1e12)
+        return out
+
+    main_leg = measure(args.precision, args.steps, args.warmup, S, True)
+    ref_logits = model.point_head.forward_ret_dict["out_logits"].clone()
+    stages = stage_breakdown(model, pts, B) if (S == 1 and args.model == "sdseg3d") else None
+
+    legs = {}
+    if extra_modes and world == 1 and S == 1 and B == 1:
+        for prec in [p for p in ("f32", "bf16x8", "bf16x3") if p != args.precision]:
+            leg = measure(prec, args.steps, max(2, args.warmup), 1, False)
             got = model.point_head.forward_ret_dict["out_logits"]
-            alt[prec] = dict(precision=label, value=B * S * args.steps / el2, ms_per_step=1e3 * el2 / args.steps,
-                             sparse_conv_ms_per_frame=c2["total_ms"] / max(args.steps * S, 1),
-                             roofline_frac=(c2["algo_bytes"] / (c2["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if c2["total_ms"] > 0 else 0.0,
-                             max_rel_logit_diff_vs_f32=float((got - ref_logits).abs().max() / ref_logits.abs().max()),
-                             argmax_agreement_vs_f32=float((got.argmax(1) == ref_logits.argmax(1)).float().mean()))
-        ops.set_precision("f32")
-    fast = alt.get("bf16x3")
+            leg["max_rel_logit_diff_vs_value_mode"] = float((got - ref_logits).abs().max() / ref_logits.abs().max())
+            leg["argmax_agreement_vs_value_mode"] = float((got.argmax(1) == ref_logits.argmax(1)).float().mean())
+            legs[prec] = leg
     throughput = None
     if TP:
-        # two frames in flight per GPU, one HIP stream each: the kernels of the two frames fill each other's idle slots (launch
-        # tails, latency-bound reader / head kernels beside the matrix-bound convs).  Reported beside `value`: per-kernel event
-        # timings (and with them the roofline line) are not defined while kernels of two streams overlap.
+        # two frames in flight per GPU, one HIP stream each: the host-side launch work of one frame (the start of a frame is
+        # launch-bound) and its latency-bound reader / head kernels run beside the conv stack of the other
         throughput = {"streams": TP, "frames_in_flight": TP}
-        with torch.no_grad():
-            for prec in ("f32", "bf16x8", "bf16x6", "bf16x3"):
-                ops.set_precision(prec)
-                for _ in range(max(2, args.warmup // 2)):
-                    step(TP)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    step(TP)
-                torch.cuda.synchronize()
-                throughput[prec + "_frames_per_s"] = TP * args.steps / (time.perf_counter() - t0)
-        ops.set_precision("f32")
-    frd = model.point_head.forward_ret_dict
-    V = int((frd["conv_logits"] if "conv_logits" in frd else frd["voxel_logits"]).shape[0])
+        for prec in sorted({args.precision, "f32"}):
+            throughput[prec + "_frames_per_s"] = measure(prec, args.steps, max(2, args.warmup // 2), TP, False)["frames_per_s"]
+    mseg = None
+    if extra_modes and world == 1 and args.model == "sdseg3d" and S == 1 and B == 1:
+        # BASELINE configs[2] in the same driver-timed run: MSeg3D = + 6-camera feature maps, GF-/SF-Phase head
+        del model
+        torch.cuda.empty_cache()
+        ops.set_precision(args.precision)
+        m2, _ = build_model(dev, kind="mseg3d")
+        p2, e2, _, _ = make_inputs("mseg3d", 1)
+        n2 = max(args.steps // 2, 5)
+        el2, lat2 = timed_steps(make_step(m2, p2, e2, 1), n2, 3)
+        mseg = dict(metric="frames/sec, MSeg3D forward (LiDAR + 6-cam HRNet-w18 features [1,6,48,160,240], GF+SF-Phase), 120k-pt frame",
+                    precision=args.precision, value=n2 / el2, ms_per_step=1e3 * el2 / n2, latency=lat2, steps=n2)
+        del m2
+    ops.set_precision(args.precision)
+
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        achieved = conv["algo_bytes"] / (conv["total_ms"] * 1e-3) / 1e9 if conv["total_ms"] > 0 else 0.0
+        c = main_leg.get("census") or {}
+        stack = main_leg.get("conv_stack_ms") or {}
+        mean_ms = stack.get("mean", 0.0)
+        achieved = c["algo_bytes"] / (mean_ms * 1e-3) / 1e9 if mean_ms else 0.0
         out = {
             "metric": "frames/sec, SDSeg3D forward, 120k-pt nuScenes-style frame",
-            "value": world * B * S * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x8": "f32 via exact 3-way bf16 split (8 bf16 MFMAs per product, f32 accumulate)", "bf16x6": "f32 via exact 3-way bf16 split (6 bf16 MFMAs per product, f32 accumulate)", "bf16x3": "f32 via split-bf16 (bf16x3 MFMA, f32 accumulate)"}[args.precision], "data": "synthetic",
+            "value": main_leg["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead), "
                                    "%d pts/frame, voxel [0.1,0.1,0.2], range [-51.2,-51.2,-5,51.2,51.2,3], 17 classes, "
                                    "1 frame per GPU per step, GPU voxelization included" % args.points,
-                       "active_voxels": V, "frames_per_gpu_per_step": B * S, "streams": S, "parallelism": "frames sharded 1/GPU (dp%d)" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_gather_gemm (sparse-conv gather-GEMM, %d launches/frame)"
-                                  % (conv["launches"] // max(args.steps, 1)),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_us": conv["avg_us"],
-                         "algo_bytes_per_frame": conv["algo_bytes"] / max(args.steps, 1),
-                         "tflops": conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0,
-                         "sparse_conv_ms_per_frame": conv["total_ms"] / max(args.steps * S, 1),
-                         # the same launches against the matrix pipe: useful (pair) flops only, exact-f32 MFMA peak
-                         # (v_mfma_f32_32x32x2_f32: 256 CUs x 4 SIMDs x 4096 flop / 64 cycles x 2.4 GHz)
-                         "mfma": None if args.precision != "f32" else {"achieved_tflops": conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 if conv["total_ms"] > 0 else 0.0,
-                                  "peak_tflops": F32_MFMA_PEAK_TFLOPS,
-                                  "frac": (conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if conv["total_ms"] > 0 else 0.0,
-                                  "counter_evidence": "profiles/round1_pmc_sq.md (SQ_VALU_MFMA_BUSY_CYCLES: 51 % of SIMD cycles)"}},
+                       "precision": args.precision, "frames_per_gpu_per_step": B * S, "streams": S,
+                       "parallelism": "frames sharded 1/GPU (dp%d)" % world},
+            "latency": main_leg["latency"],
         }
-        pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")
-        if args.model == "sdseg3d" and args.precision == "f32" and args.points == 120000 and os.path.exists(pmc):
-            # HBM-side bytes per sparse-conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-            # same command (profiles/round1_pmc.md; counters cannot be collected from inside the timed run)
-            out["roofline"]["traffic"] = json.load(open(pmc))["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/round1_pmc.json (2*FETCH_SIZE+WRITE_SIZE, KiB, corrected per MI355X_MICROARCH.md)"
-        out["roofline"]["algo_bytes_per_launch"] = conv["algo_bytes"] / max(conv["launches"], 1)
-        if fast is not None:
-            out["fast_mode"] = fast
-        if "bf16x6" in alt:
-            out["f32_grade_mode"] = alt["bf16x6"]
-        if "bf16x8" in alt:
-            out["bf16x8_mode"] = alt["bf16x8"]
+        if c:
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "sparse-conv stack: %d launches/frame (%d k_tile_conv + %d k_gather_gemm), one HIP-event bracket per frame"
+                                          % (c["launches"], c["tile_launches"], c["launches"] - c["tile_launches"]),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": 1e3 * mean_ms / max(c["launches"], 1), "algo_bytes_per_frame": c["algo_bytes"],
+                "algo_bytes_per_launch": c["algo_bytes"] / max(c["launches"], 1), "tflops_useful": main_leg.get("tflops"),
+                "sparse_conv_ms_per_frame": stack,
+            }
+            pmc = os.path.join(ROOT, "profiles", "round2_pmc.json")
+            if args.model == "sdseg3d" and args.points == 120000 and os.path.exists(pmc):
+                # HBM-side bytes per sparse-conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+                # command (profiles/round2_pmc.md; counters cannot be collected from inside the timed run)
+                j = json.load(open(pmc))
+                if args.precision in j:
+                    out["roofline"]["traffic"] = j[args.precision]["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/round2_pmc.json (2*FETCH_SIZE+WRITE_SIZE, KiB, corrected per MI355X_MICROARCH.md)"
+        if stages is not None:
+            out["stages_ms"] = stages
+        for prec, leg in legs.items():
+            key = {"f32": "exact_f32_mode", "bf16x3": "fast_mode", "bf16x8": "f32_grade_mode"}[prec]
+            out[key] = dict(precision=DTYPES[prec], value=leg["frames_per_s"], ms_per_step=leg["ms_per_step"], latency=leg["latency"],
+                            sparse_conv_ms_per_frame=leg.get("conv_stack_ms"), roofline_frac=leg.get("roofline_frac"),
+                            max_rel_logit_diff_vs_value_mode=leg["max_rel_logit_diff_vs_value_mode"],
+                            argmax_agreement_vs_value_mode=leg["argmax_agreement_vs_value_mode"])
+            if prec == "f32" and leg.get("tflops"):
+                out[key]["mfma"] = dict(achieved_tflops=leg["tflops"], peak_tflops=F32_MFMA_PEAK_TFLOPS, frac=leg["tflops"] / F32_MFMA_PEAK_TFLOPS)
         if throughput is not None:
             out["throughput_mode"] = throughput
+        if mseg is not None:
+            out["mseg3d"] = mseg
         if args.model == "mseg3d":
             out["metric"] = "frames/sec, MSeg3D forward (LiDAR + 6-cam features), 120k-pt nuScenes-style frame"
             out["config"]["workload"] = out["config"]["workload"].replace(

@@ -30,12 +30,28 @@ def _voxel_inputs(example, voxel_cfg):
     batch_size = int(example["batch_size"]) if "batch_size" in example else int(points[:, 0].max().item()) + 1
     mv = voxel_cfg.get("max_voxel_num", 300000)
     mv = mv[1] if isinstance(mv, (list, tuple)) else mv
-    v, c, n, nv = ops.voxelize_hard(points, voxel_cfg["voxel_size"], voxel_cfg["range"], voxel_cfg.get("max_points_in_voxel", 5),
-                                    int(mv) * batch_size, batched=True)
-    V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it
+    mp = voxel_cfg.get("max_points_in_voxel", 5)
     _, grid = ops.make_grid(voxel_cfg["voxel_size"], voxel_cfg["range"])
-    example["num_voxels"] = ops.frame_offsets(c[:V], batch_size).diff()
-    return v[:V], c[:V], n[:V], batch_size, np.asarray(grid)
+    if points.shape[0] <= int(mv) or batch_size == 1:
+        # no frame can reach the dataloader's per-frame cap (a frame has at most as many voxels as points): one batched launch
+        # is bit-identical to voxelising frame by frame
+        v, c, n, nv = ops.voxelize_hard(points, voxel_cfg["voxel_size"], voxel_cfg["range"], mp, int(mv) * batch_size, batched=True)
+        V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it
+        v, c, n = v[:V], c[:V], n[:V]
+    else:
+        # a frame may overflow max_voxel_num: the reference caps EACH frame (segpreprocess.py:148-177 runs per sample), so the
+        # frames are voxelised one by one with that cap and concatenated as collate_kitti does (collate.py:141-150)
+        off = ops.frame_offsets(points, batch_size).tolist()
+        parts = []
+        for b in range(batch_size):
+            fv, fc, fn, fnv = ops.voxelize_hard(points[off[b]:off[b + 1]].contiguous(), voxel_cfg["voxel_size"], voxel_cfg["range"], mp, int(mv),
+                                                batched=True)
+            k = int(fnv.item())
+            parts.append((fv[:k], fc[:k], fn[:k]))
+        v, c, n = (torch.cat([p[i] for p in parts]) for i in range(3))
+        V = c.shape[0]
+    example["num_voxels"] = ops.frame_offsets(c, batch_size).diff()
+    return v, c, n, batch_size, np.asarray(grid)
 
 
 class SingleStageDetector(nn.Module):

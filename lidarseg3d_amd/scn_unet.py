@@ -65,9 +65,10 @@ class _GeometryStream(object):
     on exit the current stream waits for it.  hand_over() tells the caching allocator that tensors created inside are used
     on the main stream from now on.  A no-op for CPU tensors (tests/hipsim) and with LS3D_OVERLAP=0."""
 
-    def __init__(self, like, ready=None):
+    def __init__(self, like, ready=None, join=True):
         import os
         self.ready = ready
+        self.released = not join  # join=False: the main stream does not wait at the end of the block (pick up finish_event())
         self.on = like.is_cuda and os.environ.get("LS3D_OVERLAP", "1") != "0"
         self.dev = like.device
 
@@ -123,7 +124,7 @@ class _GeometryStream(object):
     def __exit__(self, *exc):
         if self.on:
             self.ctx.__exit__(*exc)
-            if not getattr(self, "released", False):
+            if not self.released:
                 self.main.wait_stream(self.side)
         return False
 
@@ -224,11 +225,15 @@ class UNetSCN3D(nn.Module):
         voxel_features, voxel_coords = batch_dict["voxel_features"], batch_dict["voxel_coords"]
         batch_size = batch_dict["batch_size"]
         sparse_shape = np.array(batch_dict["input_shape"][::-1]) + [1, 0, 0]
-        x = spconv.SparseConvTensor(voxel_features, voxel_coords.int().contiguous(), sparse_shape, batch_size)
+        vc = voxel_coords.int().contiguous()
+        x = spconv.SparseConvTensor(voxel_features, vc, sparse_shape, batch_size)
+        # the "coordinates ready" event covers the tensor the reader's caller recorded it for; a converted copy (int64 / strided
+        # coordinates from a custom loader) is written by a kernel enqueued AFTER that event: wait for the main stream instead
+        ready = batch_dict.get("voxel_coords_ready") if vc.data_ptr() == voxel_coords.data_ptr() else None
         # All geometry of the frame up front.  It depends on the voxel COORDINATES only, so it runs on a side stream while the
         # main stream is still busy with the reader that produces voxel_features (k_transvfe: one LDS-bound workgroup per CU,
         # the small latency-bound rulebook kernels fit beside it); the conv stack then waits for the side stream.
-        with _GeometryStream(x.indices, batch_dict.get("voxel_coords_ready")) as gs:
+        with _GeometryStream(x.indices, ready) as gs:
             # the four strided rulebooks of the encoder in one go (one host sync instead of four)
             strided = [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
             spconv.prebuild_conv_rulebooks(x, strided)
@@ -241,11 +246,14 @@ class UNetSCN3D(nn.Module):
             spconv.prebuild_orders(x, self.modules())
             gs.hand_over(x.indice_dict.values())
             gs.release()
-            # ... and the neighbour search of the devoxelization (points -> 3 nearest voxel centres + weights): geometry as
-            # well, so it keeps running beside the conv stack; the point head only interpolates (point_heads._devoxelize)
-            self._start_devox_search(batch_dict, x, gs)
+        ev0 = self._stack_event()
         x = self.conv_input(x)
         x_conv1 = self.conv1(x)
+        # ... and the neighbour search of the devoxelization (points -> 3 nearest voxel centres + weights): geometry as well, so
+        # it runs on the side stream beside the conv stack; the point head only interpolates (point_heads._devoxelize).  Its
+        # launches are issued AFTER the first conv launches: the host is the bottleneck at the start of a frame.
+        with _GeometryStream(x.indices, ready, join=False) as gs2:
+            self._start_devox_search(batch_dict, x, gs2)
         x_conv2 = self.conv2(x_conv1)
         x_conv3 = self.conv3(x_conv2)
         x_conv4 = self.conv4(x_conv3)
@@ -257,6 +265,7 @@ class UNetSCN3D(nn.Module):
             x_up3 = self.UR_block_forward_train(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3)
             x_up2 = self.UR_block_forward_train(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2)
             x_up1 = self.UR_block_forward_train(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5)
+            self._stack_event(ev0)
             return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
         dev = voxel_features.device
         cats = [torch.empty((t.features.shape[0], 2 * t.features.shape[1]), dtype=torch.float32, device=dev)
@@ -265,7 +274,21 @@ class UNetSCN3D(nn.Module):
         x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1])
         x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2])
         x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2])
+        self._stack_event(ev0)
         return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
+
+    conv_stack_events = None  # measurement hook (bench.py): a list that receives one (start, end) HIP-event pair per forward
+
+    def _stack_event(self, start=None):
+        """bracket of the sparse-conv stack (its 37 launches are contiguous on the main stream): two events per frame instead
+        of two per launch, which cost ~10 us of idle GPU each"""
+        if self.conv_stack_events is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if start is not None:
+            self.conv_stack_events.append((start, ev))
+        return ev
 
     def _start_devox_search(self, batch_dict, x, gs):
         pts = batch_dict.get("points")

@@ -895,3 +895,20 @@ def test_pointnet2_utils_dropin_forward_and_backward_vs_oracle():
     """ls3d_three_interpolate / _grad and pointnet2_utils.ThreeNN / ThreeInterpolate had no test"""
     from tests import pointnet2_cases
     pointnet2_cases.run("cpu")
+
+
+def test_voxel_cap_applies_per_frame_like_the_dataloader():
+    """max_voxel_num caps EACH frame (the dataloader voxelises per sample); a batch in which one frame overflows and the
+    total does not must drop exactly the voxels the reference drops"""
+    from lidarseg3d_amd import detectors
+    cfg = synth.NUSC
+    frames = [synth.lidar_frame(900, seed=31, **cfg), synth.lidar_frame(60, seed=32, **cfg)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    mv = 200  # frame 0 has more voxels than this, frame 1 fewer
+    vcfg = dict(range=cfg["pc_range"], voxel_size=cfg["voxel_size"], max_points_in_voxel=5, max_voxel_num=[mv, mv])
+    ex = dict(points=torch.from_numpy(pts), batch_size=2)
+    v, c, n, bs, grid = detectors._voxel_inputs(ex, vcfg)
+    want = orc.collate_frames(frames, cfg["voxel_size"], cfg["pc_range"], 5, mv)
+    assert int((want["coordinates"][:, 0] == 0).sum()) == mv  # the cap did bite on frame 0
+    assert torch.equal(c, want["coordinates"]) and torch.equal(n, want["num_points"]) and torch.equal(v, want["voxels"])
+    assert ex["num_voxels"].tolist() == [mv, int((want["coordinates"][:, 0] == 1).sum())]
