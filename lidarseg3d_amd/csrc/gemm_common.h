@@ -176,6 +176,23 @@ __device__ __forceinline__ void ls3d_split_pair3(float a, float b, unsigned &h, 
   m = (ma >> 16) | mb;
   l = ls3d_bf16_rne(ra - __uint_as_float(ma)) | (ls3d_bf16_rne(rb - __uint_as_float(mb)) << 16);
 }
+// the same exact split with round-to-nearest planes (a = h + m + l still holds exactly: every remainder has <= 16, then <= 8
+// significant bits), written with __bf16 conversions: two-element converts compile to v_cvt_pk_bf16_f32 on gfx950, ~1/3 of the
+// VALU work of the bit-twiddling version.  Used where the split runs once per staged element (tileconv.hip).
+typedef __bf16 ls3d_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ls3d_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ls3d_split_pair3_rne(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  const ls3d_f32x2 v = {a, b};
+  const ls3d_bf16x2 hh = __builtin_convertvector(v, ls3d_bf16x2);
+  const ls3d_f32x2 r1 = v - __builtin_convertvector(hh, ls3d_f32x2);
+  const ls3d_bf16x2 mm = __builtin_convertvector(r1, ls3d_bf16x2);
+  const ls3d_f32x2 r2 = r1 - __builtin_convertvector(mm, ls3d_f32x2);
+  const ls3d_bf16x2 ll = __builtin_convertvector(r2, ls3d_bf16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  m = __builtin_bit_cast(unsigned, mm);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+
 __device__ __forceinline__ void ls3d_split8x3(const float4 &f0, const float4 &f1, uint4 &h, uint4 &m, uint4 &l) {
   ls3d_split_pair3(f0.x, f0.y, h.x, m.x, l.x);
   ls3d_split_pair3(f0.z, f0.w, h.y, m.y, l.y);

@@ -384,8 +384,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
             const int i = tid + j * TC_THREADS, hrow = i >> 2, q = i & 3;
             if (hrow < nh) {
               uint2 h, m, l;
-              ls3d_split_pair3(hv[j].x, hv[j].y, h.x, m.x, l.x);
-              ls3d_split_pair3(hv[j].z, hv[j].w, h.y, m.y, l.y);
+              ls3d_split_pair3_rne(hv[j].x, hv[j].y, h.x, m.x, l.x);
+              ls3d_split_pair3_rne(hv[j].z, hv[j].w, h.y, m.y, l.y);
               char *dst = smem + hrow * 32 + q * 8;
               *(uint2 *)(dst) = h;
               *(uint2 *)(dst + TC_PLANE_BYTES) = m;
