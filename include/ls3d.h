@@ -223,6 +223,7 @@ int ls3d_rulebook_masks(const int32_t *tbl, int n, const int32_t *n_dev, int kvo
 int ls3d_rulebook_sort_keys(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int segment, int descending, int32_t *keys,
                             ls3d_stream_t stream);
 int ls3d_segment_local_index(const int64_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream);
+int ls3d_segment_local_index32(const int32_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream);
 
 /* tuning knob: workgroup -> (tile, column slab) mapping of ls3d_gather_gemm; results are identical for every value.
  * 0 (default): the slabs of a tile run on one XCD, tiles interleaved over the 8 XCDs; bit 0: each XCD takes a
@@ -304,6 +305,19 @@ int ls3d_tile_keys(const int32_t *coords /*[n,4] b,z,y,x*/, int n, const int32_t
 size_t ls3d_tile_plan_bytes(int n_rows, int kvol);
 int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_rows_dev, int kvol, const int32_t *spatial_order, void *plan,
                     size_t plan_bytes, ls3d_stream_t stream);
+/* keys -> sort -> plan in one call (what a caller does for every table of a frame): ls3d_tile_keys, the in-library stable radix
+ * sort, ls3d_tile_build back to back on `stream`.  workspace: ls3d_tile_plan_workspace_bytes(n_rows) bytes, 16-byte aligned; it
+ * holds the spatial order at byte offset roundup(4 n_rows, 256) afterwards. */
+size_t ls3d_tile_plan_workspace_bytes(int n_rows);
+int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_rows, const int32_t *n_rows_dev, int kvol,
+                   const int32_t shape_zyx_host[3], int batch, void *workspace, size_t workspace_bytes, void *plan, size_t plan_bytes,
+                   ls3d_stream_t stream);
+/* stable LSD radix sort of (uint32 key, int32 value) pairs by the low `bits` key bits, ascending; vals == NULL: the values are
+ * the positions 0..n-1 (the result is the sorting permutation).  keys_out may be NULL.  Not in place.  Replaces torch.argsort
+ * for the row orders of the sparse convolutions (spatial tile keys, neighbour-mask keys). */
+size_t ls3d_radix_sort_workspace_bytes(int n);
+int ls3d_radix_sort(const uint32_t *keys, const int32_t *vals, int n, int bits, uint32_t *keys_out, int32_t *vals_out, void *workspace,
+                    size_t workspace_bytes, ls3d_stream_t stream);
 size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout);
 int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream);
 int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout,

@@ -162,11 +162,12 @@ __global__ __launch_bounds__(256) void k_tbl_sortkey(const int32_t *tbl, int n, 
 
 // positions in the concatenation of several segments -> positions inside the own segment (int64 -> int32)
 struct SegOffsets { int32_t off[17]; int32_t nseg; };
-__global__ __launch_bounds__(256) void k_segment_local(const int64_t *perm, int n, SegOffsets so, int32_t *out) {
+template <typename T>
+__global__ __launch_bounds__(256) void k_segment_local(const T *perm, int n, SegOffsets so, int32_t *out) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     int s = 0;
     while (s + 1 < so.nseg && i >= so.off[s + 1]) ++s;
-    out[i] = (int32_t)(perm[i] - (int64_t)so.off[s]);
+    out[i] = (int32_t)(perm[i] - (T)so.off[s]);
   }
 }
 
@@ -224,7 +225,18 @@ extern "C" int ls3d_segment_local_index(const int64_t *perm, int n, const int32_
   SegOffsets so;
   for (int s = 0; s <= nseg; ++s) so.off[s] = seg_offsets_host[s];
   so.nseg = nseg;
-  hipLaunchKernelGGL(k_segment_local, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, perm, n, so, out);
+  hipLaunchKernelGGL(k_segment_local<int64_t>, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, perm, n, so, out);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_segment_local_index32(const int32_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream) {
+  if (!perm || !out || !seg_offsets_host || n < 0 || nseg < 1 || nseg > 16) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  SegOffsets so;
+  for (int s = 0; s <= nseg; ++s) so.off[s] = seg_offsets_host[s];
+  so.nseg = nseg;
+  hipLaunchKernelGGL(k_segment_local<int32_t>, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, perm, n, so, out);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

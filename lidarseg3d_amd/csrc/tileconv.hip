@@ -50,21 +50,28 @@ __global__ __launch_bounds__(256) void k_tile_keys(const int32_t *__restrict__ c
   }
 }
 
-extern "C" int ls3d_tile_keys(const int32_t *coords, int n, const int32_t *n_dev, const int32_t shape_zyx[3], int batch, uint32_t *keys,
-                              ls3d_stream_t stream) {
-  if (!coords || !keys || !shape_zyx || n < 0 || batch < 1) return LS3D_ERR_ARG;
-  if (n == 0) return LS3D_OK;
+static int tc_key_layout(const int32_t shape_zyx[3], int batch, int &shift, int &mbits) {
   int bbits = 0;
   while ((1 << bbits) < batch) ++bbits;
   const int ext = shape_zyx[1] > shape_zyx[2] ? shape_zyx[1] : shape_zyx[2];
-  int shift = 2, cbits;  // 4x4 (y,x) columns; coarser only if the key would not fit 31 bits
+  int cbits;
+  shift = 2;  // 4x4 (y,x) columns; coarser only if the key would not fit 31 bits
   for (;; ++shift) {
     cbits = 0;
     while ((1 << cbits) < ((ext + (1 << shift) - 1) >> shift)) ++cbits;
     if (2 * cbits + bbits <= 31) break;
   }
-  if (cbits > 16) return LS3D_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_tile_keys, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, coords, n, n_dev, shift, 2 * cbits, keys);
+  mbits = 2 * cbits;
+  return cbits > 16 ? -1 : mbits + bbits;  // number of key bits
+}
+
+extern "C" int ls3d_tile_keys(const int32_t *coords, int n, const int32_t *n_dev, const int32_t shape_zyx[3], int batch, uint32_t *keys,
+                              ls3d_stream_t stream) {
+  if (!coords || !keys || !shape_zyx || n < 0 || batch < 1) return LS3D_ERR_ARG;
+  if (n == 0) return LS3D_OK;
+  int shift, mbits;
+  if (tc_key_layout(shape_zyx, batch, shift, mbits) < 0) return LS3D_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_tile_keys, ls3d_grid(n), dim3(256), 0, (hipStream_t)stream, coords, n, n_dev, shift, mbits, keys);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
@@ -101,13 +108,16 @@ extern "C" size_t ls3d_tile_plan_bytes(int n_rows, int kvol) {
   return tc_align(t * TC_TR * 4) + tc_align(t * TC_META * 4) + tc_align(t * kvol * TC_TR * 4) + tc_align(t * kvol * TC_TR * 2);
 }
 
-// one workgroup per tile
+// one workgroup per tile.  The tile's distinct input rows: the <= kvol*128 table entries go through an LDS hash set (insertion
+// order is arbitrary, the SET is not), the occupied slots are compacted and only that list (a few hundred rows) is sorted
+// (bitonic), so the halo list, and with it every local index, is the same on every run.
 __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ tbl, int n, const int32_t *n_dev, int kvol,
                                                     const int32_t *__restrict__ sorder, TilePlan p) {
   constexpr int NC = TC_KMAX * TC_TR;  // 4096 candidate slots
+  constexpr int HS = 2 * NC;           // hash slots
   __shared__ int s_row[TC_TR], s_srow[TC_TR];
   __shared__ unsigned s_mask[TC_TR], s_smask[TC_TR];
-  __shared__ int s_key[NC];
+  __shared__ int s_hash[HS];
   __shared__ int s_uniq[NC];
   __shared__ int s_scan[2][256];
   const int tid = threadIdx.x;
@@ -119,14 +129,25 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
       s_row[tid] = r < N ? sorder[r] : -1;
       s_mask[tid] = 0u;
     }
+    for (int i = tid; i < HS; i += 256) s_hash[i] = -1;
     __syncthreads();
-    {  // neighbour masks: two threads per slot
+    {  // neighbour masks + hash-set insertion of every neighbour: two threads per slot
       const int slot = tid & (TC_TR - 1), part = tid >> 7;
       const int row = s_row[slot];
       unsigned m = 0u;
       if (row >= 0)
-        for (int k = part; k < kvol; k += 2)
-          if (tbl[(size_t)row * kvol + k] >= 0) m |= 1u << k;
+        for (int k = part; k < kvol; k += 2) {
+          const int v = tbl[(size_t)row * kvol + k];
+          if (v >= 0) {
+            m |= 1u << k;
+            unsigned h = ((unsigned)v * 2654435761u) >> 19;  // 13 bits
+            for (;;) {
+              const int prev = atomicCAS(&s_hash[h], -1, v);
+              if (prev == -1 || prev == v) break;
+              h = (h + 1) & (HS - 1);
+            }
+          }
+        }
       if (m) atomicOr(&s_mask[slot], m);
     }
     __syncthreads();
@@ -142,34 +163,10 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
       s_srow[rank] = s_row[tid];
       s_smask[rank] = mine;
     }
-    __syncthreads();
-    for (int c = tid; c < NC; c += 256) {
-      const int k = c >> 7, s = c & (TC_TR - 1);
-      const int row = s_srow[s];
-      const int v = (k < kvol && row >= 0) ? tbl[(size_t)row * kvol + k] : -1;
-      s_key[c] = v >= 0 ? v : 0x7FFFFFFF;
-    }
-    __syncthreads();
-    // bitonic sort, ascending
-    for (int kk = 2; kk <= NC; kk <<= 1)
-      for (int j = kk >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < NC / 2; t += 256) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower index of the pair
-          const int q = i | j;
-          const bool up = (i & kk) == 0;
-          const int a = s_key[i], b = s_key[q];
-          if ((a > b) == up) { s_key[i] = b; s_key[q] = a; }
-        }
-        __syncthreads();
-      }
-    // unique values -> s_uniq, H
-    constexpr int PER = NC / 256;
+    // compact the occupied hash slots -> s_uniq (unsorted), H
+    constexpr int PER = HS / 256;
     int cnt = 0;
-    for (int u = 0; u < PER; ++u) {
-      const int i = tid * PER + u;
-      const int v = s_key[i];
-      cnt += (v != 0x7FFFFFFF) && (i == 0 || v != s_key[i - 1]);
-    }
+    for (int u = 0; u < PER; ++u) cnt += s_hash[tid * PER + u] >= 0;
     s_scan[0][tid] = cnt;
     __syncthreads();
     int src = 0;
@@ -181,15 +178,29 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
     const int H = s_scan[src][255];
     int pos = s_scan[src][tid] - cnt;
     for (int u = 0; u < PER; ++u) {
-      const int i = tid * PER + u;
-      const int v = s_key[i];
-      if ((v != 0x7FFFFFFF) && (i == 0 || v != s_key[i - 1])) s_uniq[pos++] = v;
+      const int v = s_hash[tid * PER + u];
+      if (v >= 0) s_uniq[pos++] = v;
     }
+    int np2 = 2;
+    while (np2 < H) np2 <<= 1;
     __syncthreads();
+    for (int i = H + tid; i < np2; i += 256) s_uniq[i] = 0x7FFFFFFF;
+    __syncthreads();
+    for (int kk = 2; kk <= np2; kk <<= 1)  // bitonic sort of the unique list, ascending
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < np2 / 2; t += 256) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower index of the pair
+          const int q = i | j;
+          const bool up = (i & kk) == 0;
+          const int a = s_uniq[i], b = s_uniq[q];
+          if ((a > b) == up) { s_uniq[i] = b; s_uniq[q] = a; }
+        }
+        __syncthreads();
+      }
     for (int i = tid; i < H; i += 256) p.thalo[(size_t)tile * p.hs + i] = s_uniq[i];
     for (int c = tid; c < kvol * TC_TR; c += 256) {
-      const int k = c >> 7, s = c & (TC_TR - 1);
-      const int row = s_srow[s];
+      const int k = c >> 7, s2 = c & (TC_TR - 1);
+      const int row = s_srow[s2];
       const int v = row >= 0 ? tbl[(size_t)row * kvol + k] : -1;
       unsigned li = 0xFFFFu;
       if (v >= 0) {
@@ -200,15 +211,15 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
         }
         li = (unsigned)lo;
       }
-      p.tloc[((size_t)tile * kvol + k) * TC_TR + s] = (uint16_t)li;
+      p.tloc[((size_t)tile * kvol + k) * TC_TR + s2] = (uint16_t)li;
     }
     if (tid < TC_TR) p.trow[(size_t)tile * TC_TR + tid] = s_srow[tid];
     if (tid < 8) {
       int v = 0;
       if (tid == 0) v = H;
-      else if (tid == 1) { unsigned m = 0u; for (int s = 0; s < TC_TR; ++s) m |= s_smask[s]; v = (int)m; }
-      else if (tid < 6) { unsigned m = 0u; for (int s = 0; s < 32; ++s) m |= s_smask[(tid - 2) * 32 + s]; v = (int)m; }
-      else if (tid == 6) { int c2 = 0; for (int s = 0; s < TC_TR; ++s) c2 += s_srow[s] >= 0; v = c2; }
+      else if (tid == 1) { unsigned m = 0u; for (int s2 = 0; s2 < TC_TR; ++s2) m |= s_smask[s2]; v = (int)m; }
+      else if (tid < 6) { unsigned m = 0u; for (int s2 = 0; s2 < 32; ++s2) m |= s_smask[(tid - 2) * 32 + s2]; v = (int)m; }
+      else if (tid == 6) { int c2 = 0; for (int s2 = 0; s2 < TC_TR; ++s2) c2 += s_srow[s2] >= 0; v = c2; }
       p.tmeta[(size_t)tile * TC_META + tid] = v;
     }
   }
@@ -224,6 +235,41 @@ extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_
   TilePlan p = tc_plan(plan, n_rows, kvol);
   hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, (hipStream_t)stream, tbl, n_rows, n_rows_dev,
                      kvol, spatial_order, p);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, int bits, uint32_t *keys_out, int32_t *vals_out, void *workspace,
+                          size_t workspace_bytes, hipStream_t stream);
+extern "C" size_t ls3d_radix_sort_workspace_bytes(int n);
+
+extern "C" size_t ls3d_tile_plan_workspace_bytes(int n_rows) {
+  return ((size_t)n_rows * 4 + 255) / 256 * 256 * 2 + ls3d_radix_sort_workspace_bytes(n_rows);  // keys, order, sort buffers
+}
+
+// keys -> stable radix sort -> plan, back to back on `stream`: what a caller does for every table of a frame
+extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_rows, const int32_t *n_rows_dev, int kvol,
+                              const int32_t shape_zyx[3], int batch, void *workspace, size_t workspace_bytes, void *plan, size_t plan_bytes,
+                              ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!tbl || !coords || !shape_zyx || !workspace || !plan || n_rows < 0 || kvol < 1 || batch < 1) return LS3D_ERR_ARG;
+  if (kvol > TC_KMAX) return LS3D_ERR_UNSUPPORTED;
+  if (workspace_bytes < ls3d_tile_plan_workspace_bytes(n_rows) || plan_bytes < ls3d_tile_plan_bytes(n_rows, kvol)) return LS3D_ERR_WORKSPACE;
+  if (((uintptr_t)plan & 15) || ((uintptr_t)workspace & 15)) return LS3D_ERR_ARG;
+  if (n_rows == 0) return LS3D_OK;
+  int shift, mbits;
+  const int bits = tc_key_layout(shape_zyx, batch, shift, mbits);
+  if (bits < 0) return LS3D_ERR_UNSUPPORTED;
+  const size_t seg = ((size_t)n_rows * 4 + 255) / 256 * 256;
+  uint32_t *keys = (uint32_t *)workspace;
+  int32_t *order = (int32_t *)((char *)workspace + seg);
+  void *sort_ws = (char *)workspace + 2 * seg;
+  hipLaunchKernelGGL(k_tile_keys, ls3d_grid(n_rows), dim3(256), 0, stream, coords, n_rows, n_rows_dev, shift, mbits, keys);
+  int rc = ls3d_radix_sort_pairs(keys, nullptr, n_rows, bits, nullptr, order, sort_ws, workspace_bytes - 2 * seg, stream);
+  if (rc != LS3D_OK) return rc;
+  TilePlan p = tc_plan(plan, n_rows, kvol);
+  hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, stream, tbl, n_rows, n_rows_dev, kvol,
+                     (const int32_t *)order, p);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

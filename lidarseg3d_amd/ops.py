@@ -318,11 +318,7 @@ def rulebook_order(tbl, coords=None):
     n, kvol = tbl.shape
     if n == 0 or kvol > 31 or _ROW_ORDER == "none":
         return None
-    mask = torch.empty((n,), dtype=_i32, device=tbl.device)
-    check(_L().ls3d_rulebook_masks(_ptr(tbl), n, None, kvol, _ptr(mask), _stream(tbl)), "ls3d_rulebook_masks")
-    # descending: tiles with the most active offsets (the longest-running workgroups) are dispatched first, the short
-    # ones fill the tail of the launch
-    return torch.argsort(mask, descending=_os_environ_get("LS3D_ORDER_ASC", "0") != "1").to(_i32)
+    return rulebook_orders([tbl])[0]
 
 
 F32, BF16X3, BF16X6, BF16X8 = 0, 1, 2, 3
@@ -384,6 +380,16 @@ def choose_geometry(cout, n_rows, target_blocks=None):
     return nt, wc
 
 
+def radix_argsort(keys, bits=32):
+    """stable ascending argsort of int32/uint32 keys by their low `bits` bits -> int32 permutation (ls3d_radix_sort)"""
+    n = keys.shape[0]
+    L = _L()
+    perm = torch.empty((n,), dtype=_i32, device=keys.device)
+    ws = _ws(L.ls3d_radix_sort_workspace_bytes(n), keys)
+    check(L.ls3d_radix_sort(_ptr(keys), None, n, int(bits), None, _ptr(perm), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(keys)), "ls3d_radix_sort")
+    return perm
+
+
 def rulebook_orders(tbls):
     """rulebook_order for several tables at once: one batched sort (keys carry the table number in their top bits) instead
     of one sort per table - the sorts are launch-bound (~10 small kernels each).  -> list of int32 orders (None where a
@@ -403,10 +409,10 @@ def rulebook_orders(tbls):
             t = tbls[i]
             check(L.ls3d_rulebook_sort_keys(_ptr(t), t.shape[0], None, t.shape[1], s, 1 if descending else 0,
                                             ctypes.c_void_p(keys.data_ptr() + 4 * offs[s]), _stream(t)), "ls3d_rulebook_sort_keys")
-        perm = torch.argsort(keys)  # plumbing (rocPRIM radix sort inside torch); int64 positions
+        perm = radix_argsort(keys, 27 + max(len(grp) - 1, 1).bit_length())  # in-library stable radix sort (csrc/sort.hip)
         local = torch.empty((offs[-1],), dtype=_i32, device=dev)
-        check(L.ls3d_segment_local_index(_ptr(perm), offs[-1], (ctypes.c_int32 * len(offs))(*offs), len(grp), _ptr(local), _stream(perm)),
-              "ls3d_segment_local_index")
+        check(L.ls3d_segment_local_index32(_ptr(perm), offs[-1], (ctypes.c_int32 * len(offs))(*offs), len(grp), _ptr(local), _stream(perm)),
+              "ls3d_segment_local_index32")
         for s, i in enumerate(grp):
             out[i] = local[offs[s]:offs[s + 1]]
     return out
@@ -529,6 +535,8 @@ class TilePlan(object):
 
     def record_stream(self, s):
         self.buf.record_stream(s)
+        if self.order is not None and self.order.is_cuda:
+            self.order.record_stream(s)
 
 
 def tile_keys(coords, shape_zyx, batch):
@@ -542,12 +550,18 @@ def tile_plan(tbl, coords, shape_zyx, batch, order=None):
     """plan for table tbl[n, kvol] whose output sites are coords[n, 4] (b, z, y, x).  `order`: a precomputed spatial row
     order (int32 permutation); default = stable sort of ls3d_tile_keys (torch.sort: plumbing)."""
     n, kvol = tbl.shape
-    if order is None:
-        order = torch.sort(tile_keys(coords, shape_zyx, batch), stable=True)[1].to(_i32)
     L = _L()
     p = TilePlan()
-    p.n_rows, p.kvol, p.order, p.tbl = n, kvol, order, tbl
+    p.n_rows, p.kvol, p.tbl = n, kvol, tbl
     p.buf = torch.empty((max(int(L.ls3d_tile_plan_bytes(n, kvol)), 256),), dtype=torch.uint8, device=tbl.device)
+    if order is None:  # keys -> in-library radix sort -> plan: one C call (ls3d_tile_plan)
+        ws = _ws(L.ls3d_tile_plan_workspace_bytes(n), tbl)
+        check(L.ls3d_tile_plan(_ptr(tbl), _ptr(coords), n, None, kvol, _i3(shape_zyx), int(batch), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(p.buf),
+                               ctypes.c_size_t(p.buf.numel()), _stream(tbl)), "ls3d_tile_plan")
+        seg = (n * 4 + 255) // 256 * 256
+        p.order = ws[seg:seg + 4 * n].view(_i32)
+        return p
+    p.order = order
     check(L.ls3d_tile_build(_ptr(tbl), n, None, kvol, _ptr(order), _ptr(p.buf), ctypes.c_size_t(p.buf.numel()), _stream(tbl)), "ls3d_tile_build")
     return p
 

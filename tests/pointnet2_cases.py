@@ -13,7 +13,7 @@ def run(device, b=2, n=300, m=70, c=11, seed=0):
     unknown = rng.uniform(-5, 5, size=(b, n, 3)).astype(np.float32)
     known = rng.uniform(-5, 5, size=(b, m, 3)).astype(np.float32)
     known[0, 5] = known[0, 3]  # a duplicated centre: the lower index must win the tie
-    unknown[1, 7] = known[1, 2]  # a query on top of a centre: distance 0
+    unknown[b - 1, 7] = known[b - 1, 2]  # a query on top of a centre: distance 0
     feats = rng.normal(size=(b, c, m)).astype(np.float32)
     T = lambda a: torch.from_numpy(a).to(device)
     dist, idx = pu.three_nn(T(unknown), T(known))

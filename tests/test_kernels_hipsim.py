@@ -912,3 +912,12 @@ def test_voxel_cap_applies_per_frame_like_the_dataloader():
     assert int((want["coordinates"][:, 0] == 0).sum()) == mv  # the cap did bite on frame 0
     assert torch.equal(c, want["coordinates"]) and torch.equal(n, want["num_points"]) and torch.equal(v, want["voxels"])
     assert ex["num_voxels"].tolist() == [mv, int((want["coordinates"][:, 0] == 1).sum())]
+
+
+@pytest.mark.parametrize("n,bits", [(1, 8), (255, 8), (2049, 13), (5000, 20), (4097, 31)])
+def test_radix_sort_is_a_stable_argsort(n, bits):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 1 << bits, size=n, dtype=np.int64).astype(np.uint32)
+    keys[: n // 3] = keys[0]  # many ties: stability matters
+    perm = ops.radix_argsort(torch.from_numpy(keys.astype(np.int32)), bits).numpy()
+    assert np.array_equal(perm, np.argsort(keys, kind="stable"))
