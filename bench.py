@@ -18,7 +18,7 @@ float64 evaluation is BELOW the exact-f32 MFMA path's own (tests/test_gpu_parity
 DESIGN.md 4.1) — and the exact-f32 path is timed beside it (`exact_f32_mode`).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     — the sparse-conv stack (37 launches, contiguous on the main stream, bracketed by ONE HIP-event pair per frame):
+  roofline     — the sparse-conv stack (37 launches, contiguous on the main stream, bracketed by two HIP-event pairs per frame: level 1 | the rest):
                  algorithmic pair-model bytes sum_l P_l*(Cin+Cout)*4 (SURVEY.md §8d) over its measured duration;
   cpu_baseline — the CPU oracle (oracle/ref.py, kind "port") timed on the host cores on a bounded sample;
   stages_ms    — per-stage HIP-event breakdown of a frame; latency — median / p95 of the per-step wall time.
@@ -308,7 +308,9 @@ def main():
             scn_unet.UNetSCN3D.conv_stack_events = None
         out = dict(precision=prec, frames_per_s=world * B * n_streams * steps / elapsed, ms_per_step=1e3 * elapsed / steps, latency=lat)
         if census is not None and events:
-            stack_ms = sorted(a.elapsed_time(b) for a, b in events)
+            per = max(len(events) // steps, 1)  # (start, end) pairs per frame: the stack is bracketed in contiguous pieces
+            ms = [a.elapsed_time(b) for a, b in events]
+            stack_ms = sorted(sum(ms[i:i + per]) for i in range(0, len(ms) - per + 1, per))
             mean = sum(stack_ms) / len(stack_ms)
             out.update(census=census, conv_stack_ms=dict(mean=mean, median=statistics.median(stack_ms),
                                                          p95=stack_ms[min(len(stack_ms) - 1, int(round(0.95 * (len(stack_ms) - 1))))]),
@@ -368,7 +370,7 @@ def main():
         }
         if c:
             out["roofline"] = {
-                "bound": "hbm", "kernel": "sparse-conv stack: %d launches/frame (%d k_tile_conv + %d k_gather_gemm), one HIP-event bracket per frame"
+                "bound": "hbm", "kernel": "sparse-conv stack: %d launches/frame (%d k_tile_conv + %d k_gather_gemm), two HIP-event brackets per frame"
                                           % (c["launches"], c["tile_launches"], c["launches"] - c["tile_launches"]),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": 1e3 * mean_ms / max(c["launches"], 1), "algo_bytes_per_frame": c["algo_bytes"],

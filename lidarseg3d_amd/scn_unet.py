@@ -230,28 +230,33 @@ class UNetSCN3D(nn.Module):
         # the "coordinates ready" event covers the tensor the reader's caller recorded it for; a converted copy (int64 / strided
         # coordinates from a custom loader) is written by a kernel enqueued AFTER that event: wait for the main stream instead
         ready = batch_dict.get("voxel_coords_ready") if vc.data_ptr() == voxel_coords.data_ptr() else None
-        # All geometry of the frame up front.  It depends on the voxel COORDINATES only, so it runs on a side stream while the
-        # main stream is still busy with the reader that produces voxel_features (k_transvfe: one LDS-bound workgroup per CU,
-        # the small latency-bound rulebook kernels fit beside it); the conv stack then waits for the side stream.
+        # The geometry of the frame depends on the voxel COORDINATES only, so it is built on a side stream while the main stream is
+        # still busy with the reader that produces voxel_features (k_transvfe: one LDS-bound workgroup per CU, the small
+        # latency-bound rulebook kernels fit beside it) - in two stages, so that the main stream never waits for more than it needs:
+        # stage 1 = the level-1 SubM rulebook and its tile plan (sizes known on the host: no sync) ...
         with _GeometryStream(x.indices, ready) as gs:
-            # the four strided rulebooks of the encoder in one go (one host sync instead of four)
-            strided = [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
-            spconv.prebuild_conv_rulebooks(x, strided)
-            # ... then every SubM rulebook and, with one batched sort, every mask-sorted row order: after this point the conv
-            # stack is only gather-GEMM launches
-            for key, src in (("subm1", None), ("subm2", "spconv2"), ("subm3", "spconv3"), ("subm4", "spconv4")):
-                rb = x.find_indice_pair(src)
-                x.indice_dict[key] = spconv.subm_rulebook(x.indices if rb is None else rb.out_indices,
-                                                          x.spatial_shape if rb is None else rb.out_shape, 3, x.batch_size)
+            x.indice_dict["subm1"] = spconv.subm_rulebook(x.indices, x.spatial_shape, 3, x.batch_size)
             spconv.prebuild_orders(x, self.modules())
             gs.hand_over(x.indice_dict.values())
             gs.release()
         ev0 = self._stack_event()
-        x = self.conv_input(x)
+        x = self.conv_input(x)  # ... the five level-1 launches are queued behind it ...
         x_conv1 = self.conv1(x)
+        ev1 = self._stack_event(ev0)
+        # ... stage 2 = everything else: the four strided rulebooks of the encoder chained on device counts (ONE host sync for
+        # their sizes; the level-1 convolutions run meanwhile), the other SubM rulebooks, every tile plan and mask-sorted row order
+        with _GeometryStream(x.indices, ready) as gs:
+            strided = [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
+            spconv.prebuild_conv_rulebooks(x, strided)
+            for key, src in (("subm2", "spconv2"), ("subm3", "spconv3"), ("subm4", "spconv4")):
+                rb = x.find_indice_pair(src)
+                x.indice_dict[key] = spconv.subm_rulebook(rb.out_indices, rb.out_shape, 3, x.batch_size)
+            spconv.prebuild_orders(x, self.modules())
+            gs.hand_over(x.indice_dict.values())
+            gs.release()
+        ev0 = self._stack_event() if ev1 is not None else None
         # ... and the neighbour search of the devoxelization (points -> 3 nearest voxel centres + weights): geometry as well, so
-        # it runs on the side stream beside the conv stack; the point head only interpolates (point_heads._devoxelize).  Its
-        # launches are issued AFTER the first conv launches: the host is the bottleneck at the start of a frame.
+        # it runs on the side stream beside the conv stack; the point head only interpolates (point_heads._devoxelize)
         with _GeometryStream(x.indices, ready, join=False) as gs2:
             self._start_devox_search(batch_dict, x, gs2)
         x_conv2 = self.conv2(x_conv1)
@@ -277,11 +282,12 @@ class UNetSCN3D(nn.Module):
         self._stack_event(ev0)
         return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
 
-    conv_stack_events = None  # measurement hook (bench.py): a list that receives one (start, end) HIP-event pair per forward
+    conv_stack_events = None  # measurement hook (bench.py): a list that receives the (start, end) HIP-event pairs of a forward
 
     def _stack_event(self, start=None):
-        """bracket of the sparse-conv stack (its 37 launches are contiguous on the main stream): two events per frame instead
-        of two per launch, which cost ~10 us of idle GPU each"""
+        """brackets of the sparse-conv stack: its 37 launches are contiguous on the main stream except for one wait for the second
+        geometry stage, so two (start, end) pairs per frame (level 1 | the rest) instead of one pair per launch, which cost
+        ~10 us of idle GPU each"""
         if self.conv_stack_events is None:
             return None
         ev = torch.cuda.Event(enable_timing=True)
