@@ -424,6 +424,33 @@ int ls3d_complete_concat(const float *lidar, int c_l, const float *camera, const
 int ls3d_sfam(const float *feats, int feat_ld, int c, const float *logits, int cls, const int32_t *vx_off, int batch,
               int max_frame_voxels, float *workspace, float *emb /*[batch,cls,c]*/, ls3d_stream_t stream);
 
+/* The point side of the SF-Phase decoder as ONE kernel (SemanticFeatureFusionModule.forward, context_module.py:89-117, over
+ * TransformerDecoderLayer.forward_post :211-250 and SparsePointCorssAttention :320-376): out[n, d_model] = norm_tgt(decoder(
+ * input_proj_point(x))) with the points attending to the L class embeddings of their frame.  The embedding side does not depend on
+ * the points: the caller passes, per layer, k and v exactly as ls3d_cross_attn takes them: kv = [num_layers][2 (k, v)][batch][d_model][L].
+ * Every weight matrix is an (in, out) matrix of 96 output columns in the layout of ls3d_gather_gemm_pack(nt = 3, F32): w_in
+ * [d_in x 96]; per layer wq, wo [96 x 96], the FFN as column halves of linear1 (w1a, w1b: [96 x 96] each, b1: all 192 biases) and
+ * row halves of linear2 (w2a, w2b).  Supported: d_model 96, 4 heads, ffn 192, L <= 64 (matrix-pipe attention for L <= 36), d_in in
+ * {32, 64, 96}, num_layers <= 8;
+ * anything else returns LS3D_ERR_UNSUPPORTED and the caller composes the decoder from ls3d_gather_gemm / ls3d_cross_attn. */
+typedef struct {
+  const float *wq, *bq, *wo, *bo, *w1a, *w1b, *b1, *w2a, *w2b, *b2;
+  const float *n2_gamma, *n2_beta, *n3_gamma, *n3_beta;
+  float n2_eps, n3_eps;
+} ls3d_sffm_layer_t;
+typedef struct {
+  const float *w_in, *b_in;
+  const ls3d_sffm_layer_t *layers; /* HOST array */
+  int32_t num_layers, d_in, d_model, heads, ffn;
+  const float *norm_gamma, *norm_beta; /* decoder.norm_tgt, or NULL */
+  float norm_eps;
+} ls3d_sffm_t;
+/* arithmetic of the decoder's point -> class-embedding attention (QK^T and PV): 0 (default) exact f32 on v_mfma_f32_32x32x2_f32,
+ * 1 operands rounded to bf16 on v_mfma_f32_32x32x16_bf16 with f32 accumulation and softmax (BASELINE configs[4]), 2 the vector pipe. */
+void ls3d_set_sffm_attention(int mode);
+int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
+                      const ls3d_sffm_t *model_host, float *out, int out_ld, ls3d_stream_t stream);
+
 /* SparsePointCorssAttention core (context_module.py:339-372): q[n,embed] (already projected), per-frame
  * k,v[batch, heads, embed/heads, L] (Conv1d outputs reshaped as the reference does), softmax(q.k*scale) v
  * -> out[n, embed].  frame of point p = (int)points[p*pt_stride]. */

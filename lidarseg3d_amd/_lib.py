@@ -22,7 +22,7 @@ EXPORTS = [
     "ls3d_tile_keys", "ls3d_tile_plan_bytes", "ls3d_tile_build", "ls3d_tile_plan", "ls3d_tile_plan_workspace_bytes", "ls3d_radix_sort",
     "ls3d_radix_sort_workspace_bytes", "ls3d_tile_conv_packed_bytes", "ls3d_tile_conv_pack", "ls3d_tile_conv", "ls3d_set_tile_map",
     "ls3d_voxel_centers", "ls3d_frame_offsets", "ls3d_three_nn", "ls3d_three_interpolate", "ls3d_three_interpolate_grad",
-    "ls3d_devoxelize", "ls3d_devoxelize_grid", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_interpolate_rows", "ls3d_grid_gather", "ls3d_nchw_to_nhwc", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn", "ls3d_points_cp", "ls3d_points_cuv",
+    "ls3d_devoxelize", "ls3d_devoxelize_grid", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_interpolate_rows", "ls3d_grid_gather", "ls3d_nchw_to_nhwc", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn", "ls3d_sffm_decoder", "ls3d_set_sffm_attention", "ls3d_points_cp", "ls3d_points_cuv",
 ]
 
 
@@ -50,6 +50,17 @@ class TransVFE(ctypes.Structure):
     _fields_ = [("w_embed", ctypes.c_void_p), ("b_embed", ctypes.c_void_p), ("w_compress", ctypes.c_void_p), ("b_compress", ctypes.c_void_p),
                 ("layers", ctypes.POINTER(TransVFELayer)), ("num_layers", ctypes.c_int32), ("num_compressed", ctypes.c_int32),
                 ("embed", ctypes.c_int32), ("heads", ctypes.c_int32), ("ffn", ctypes.c_int32), ("token_ld", ctypes.c_int32)]
+
+
+class SffmLayer(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("wq", "bq", "wo", "bo", "w1a", "w1b", "b1", "w2a", "w2b", "b2", "n2_gamma", "n2_beta", "n3_gamma",
+                                                "n3_beta")] + [("n2_eps", ctypes.c_float), ("n3_eps", ctypes.c_float)]
+
+
+class Sffm(ctypes.Structure):
+    _fields_ = [("w_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p), ("layers", ctypes.POINTER(SffmLayer)), ("num_layers", ctypes.c_int32),
+                ("d_in", ctypes.c_int32), ("d_model", ctypes.c_int32), ("heads", ctypes.c_int32), ("ffn", ctypes.c_int32),
+                ("norm_gamma", ctypes.c_void_p), ("norm_beta", ctypes.c_void_p), ("norm_eps", ctypes.c_float)]
 
 
 class LibraryMissing(RuntimeError):

@@ -771,6 +771,45 @@ def camera_sfam(feats, probs, batch_size):
     return emb.permute(0, 2, 1).contiguous().unsqueeze(3)
 
 
+class SffmModel(object):
+    """device weights + the host-side descriptor of ls3d_sffm_decoder.  `layers`: dicts of packing.PackedWeight / tensors"""
+
+    def __init__(self, w_in, b_in, layers, norm, d_in, d_model, heads, ffn):
+        from ._lib import Sffm, SffmLayer
+        F = lambda pw: pw.for_nt(3, F32)
+        self.keep = [F(w_in), b_in]
+        arr = (SffmLayer * max(len(layers), 1))()
+        for i, l in enumerate(layers):
+            t = dict(wq=F(l["wq"]), bq=l["bq"], wo=F(l["wo"]), bo=l["bo"], w1a=F(l["w1a"]), w1b=F(l["w1b"]), b1=l["b1"], w2a=F(l["w2a"]),
+                     w2b=F(l["w2b"]), b2=l["b2"], n2_gamma=l["n2"][0], n2_beta=l["n2"][1], n3_gamma=l["n3"][0], n3_beta=l["n3"][1])
+            self.keep.extend(t.values())
+            for k, v in t.items():
+                setattr(arr[i], k, v.data_ptr())
+            arr[i].n2_eps, arr[i].n3_eps = float(l["n2"][2]), float(l["n3"][2])
+        self.layers = arr
+        self.keep.extend([norm[0], norm[1]] if norm is not None else [])
+        self.c = Sffm(self.keep[0].data_ptr(), b_in.data_ptr(), arr, len(layers), int(d_in), int(d_model), int(heads), int(ffn),
+                      norm[0].data_ptr() if norm is not None else None, norm[1].data_ptr() if norm is not None else None,
+                      float(norm[2]) if norm is not None else 0.0)
+
+
+def set_sffm_attention(mode):
+    """"f32" (default: exact-f32 MFMA), "bf16" (bf16 MFMA operands, f32 accumulation / softmax) or "valu" (vector pipe)"""
+    _L().ls3d_set_sffm_attention({"f32": 0, "bf16": 1, "valu": 2}[mode])
+
+
+def sffm_decoder(x, points, kv, L, batch, model):
+    """fused point side of the SF-Phase decoder (ls3d_sffm_decoder); returns None when the shape is not supported"""
+    n = x.shape[0]
+    out = torch.empty((n, model.c.d_model), dtype=torch.float32, device=x.device)
+    rc = _L().ls3d_sffm_decoder(_ptr(x), x.shape[1], n, _ptr(points), points.shape[1] if points.dim() == 2 else 1, _ptr(kv), int(L), int(batch),
+                                ctypes.byref(model.c), _ptr(out), out.shape[1], _stream(x))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "ls3d_sffm_decoder")
+    return out
+
+
 def cross_attn(q, k, v, batch, heads, points):
     n, e = q.shape
     L = k.numel() // (batch * e)

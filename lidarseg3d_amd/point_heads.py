@@ -239,6 +239,16 @@ class TransformerDecoder(nn.Module):
         self.norm_mem = norm_mem
 
 
+import os as _os
+_FUSED_SFFM = _os.environ.get("LS3D_FUSED_SFFM", "1") != "0"
+
+
+def set_fused_sffm(on):
+    """A/B switch: the point side of the SF-Phase decoder as one kernel (default) or layer by layer"""
+    global _FUSED_SFFM
+    _FUSED_SFFM = bool(on)
+
+
 class SemanticFeatureFusionModule(PackedModule):
     """SFFM (context_module.py:56-117): points attend to the 2*num_cls class embeddings (camera + LiDAR) of their
     frame through num_decoder_layers post-norm decoder layers; the embeddings self-attend between layers."""
@@ -273,6 +283,16 @@ class SemanticFeatureFusionModule(PackedModule):
                 v=pack_linear(ca.v_proj.weight, ca.v_proj.bias), o=pack_linear(ca.out_proj.weight, ca.out_proj.bias),
                 ff1=pack_linear(l.linear1.weight, l.linear1.bias), ff2=pack_linear(l.linear2.weight, l.linear2.bias),
                 n1=ln(l.norm1), n2=ln(l.norm2), n3=ln(l.norm3)))
+        E, ffn, d_in = self.d_model, self.decoder.layers[0].linear1.out_features if len(self.decoder.layers) else 0, self.input_proj_point.in_features
+        if E == 96 and self.nhead == 4 and ffn == 2 * E and d_in % 32 == 0 and 32 <= d_in <= E and len(self.decoder.layers) <= 8:
+            t = lambda w: w.detach().float().contiguous()
+            fl = []
+            for l, lp in zip(self.decoder.layers, p["layers"]):
+                w1, w2 = l.linear1.weight.detach(), l.linear2.weight.detach()
+                fl.append(dict(wq=lp["q"][0], bq=t(l.crossocr_attn.q_proj.bias), wo=lp["o"][0], bo=t(l.crossocr_attn.out_proj.bias),
+                               w1a=pack_linear(w1[:E])[0], w1b=pack_linear(w1[E:])[0], b1=t(l.linear1.bias),
+                               w2a=pack_linear(w2[:, :E])[0], w2b=pack_linear(w2[:, E:])[0], b2=t(l.linear2.bias), n2=lp["n2"], n3=lp["n3"]))
+            p["fused"] = ops.SffmModel(p["point"][0], t(self.input_proj_point.bias), fl, p["norm_tgt"], d_in, E, self.nhead, ffn)
         return p
 
     def forward(self, input_point_features, input_sem_embeddings1, input_sem_embeddings2, batch_idx, batch_size,
@@ -297,6 +317,20 @@ class SemanticFeatureFusionModule(PackedModule):
         mem[:, :cls] = _lin(e1.reshape(B * cls, -1), pk["emb1"]).view(B, cls, E)
         mem[:, cls:] = _lin(e2.reshape(B * cls, -1), pk["emb2"]).view(B, cls, E)
         mem = mem.view(B * L, E)
+        if _FUSED_SFFM and "fused" in pk and not return_context and L <= 64:
+            # the class-embedding side of every layer first (2*cls rows per frame; it never sees the points), then ONE kernel for
+            # the point side of the whole decoder (ls3d_sffm_decoder)
+            kvs, mf = [], mem
+            for lp in pk["layers"]:
+                att = ops.mha_core(_lin(mf, lp["sa_qkv"]), B, L, E, H)
+                mf = _lin(att, lp["sa_out"], res=mf, ln=lp["n1"])
+                kvs.append(_lin(mf, lp["k"]).view(B, L, E).permute(0, 2, 1))
+                kvs.append(_lin(mf, lp["v"]).view(B, L, E).permute(0, 2, 1))
+            kv = torch.stack(kvs).contiguous()  # [layers * 2, B, E, L]
+            x = input_point_features if input_point_features.is_contiguous() else input_point_features.contiguous()
+            tgt = ops.sffm_decoder(x, points, kv, L, B, pk["fused"])
+            if tgt is not None:
+                return tgt
         tgt = _lin(input_point_features, pk["point"])
         for lp in pk["layers"]:
             att = ops.mha_core(_lin(mem, lp["sa_qkv"]), B, L, E, H)

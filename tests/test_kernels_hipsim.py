@@ -921,3 +921,42 @@ def test_radix_sort_is_a_stable_argsort(n, bits):
     keys[: n // 3] = keys[0]  # many ties: stability matters
     perm = ops.radix_argsort(torch.from_numpy(keys.astype(np.int32)), bits).numpy()
     assert np.array_equal(perm, np.argsort(keys, kind="stable"))
+
+
+def test_fused_sffm_decoder_equals_layer_by_layer_and_oracle():
+    """ls3d_sffm_decoder (the point side of the SF-Phase decoder as one kernel) against the layer-by-layer composition of the same
+    module and against the oracle's SFFM (pinned to the reference class), two ragged frames: a 128-point tile straddles the frame
+    boundary, the last tile is partial"""
+    torch.manual_seed(3)
+    m = point_heads.SemanticFeatureFusionModule(64, 48, 64, d_model=96, nhead=4, num_decoder_layers=3, dim_feedforward=192).eval()
+    n0, n1, cls = 200, 77, 17
+    x = torch.randn(n0 + n1, 64)
+    e1, e2 = torch.randn(2, 48, cls, 1), torch.randn(2, 64, cls, 1)
+    bidx = torch.cat([torch.zeros(n0), torch.ones(n1)])
+    pts = torch.cat([bidx[:, None], torch.randn(n0 + n1, 3)], 1).contiguous()
+    calls = []
+    orig = ops.sffm_decoder
+    ops.sffm_decoder = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            fused = m(x, e1, e2, bidx, 2, points=pts)
+            point_heads.set_fused_sffm(False)
+            ref = m(x, e1, e2, bidx, 2, points=pts)
+    finally:
+        point_heads.set_fused_sffm(True)
+        ops.sffm_decoder = orig
+    assert len(calls) == 1
+    np.testing.assert_allclose(fused.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    try:  # the other attention arithmetics of the fused kernel
+        with torch.no_grad():
+            ops.set_sffm_attention("valu")
+            np.testing.assert_allclose(m(x, e1, e2, bidx, 2, points=pts).numpy(), ref.numpy(), rtol=0, atol=2e-5)
+            ops.set_sffm_attention("bf16")
+            b16 = m(x, e1, e2, bidx, 2, points=pts)
+    finally:
+        ops.set_sffm_attention("f32")
+    # bf16 QK^T / PV operands (8 mantissa bits), f32 accumulation and softmax; outputs are LayerNorm'd (unit scale)
+    assert float((b16 - ref).abs().max()) <= 3e-2 and float((b16 - ref).pow(2).mean().sqrt()) <= 4e-3
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    want = orc.sffm(sd, "", x, e1, e2, bidx, 2, 4)
+    np.testing.assert_allclose(fused.numpy(), want.numpy(), rtol=0, atol=5e-5)
