@@ -446,7 +446,8 @@ typedef struct {
   float norm_eps;
 } ls3d_sffm_t;
 /* arithmetic of the decoder's point -> class-embedding attention (QK^T and PV): 0 (default) exact f32 on v_mfma_f32_32x32x2_f32,
- * 1 operands rounded to bf16 on v_mfma_f32_32x32x16_bf16 with f32 accumulation and softmax (BASELINE configs[4]), 2 the vector pipe. */
+ * 1 operands rounded to bf16 on v_mfma_f32_32x32x16_bf16, 3 operands rounded to OCP e4m3 on v_mfma_f32_32x32x16_fp8_fp8 - both with
+ * f32 accumulation and f32 softmax (BASELINE configs[4]); 2 the vector pipe (A/B). */
 void ls3d_set_sffm_attention(int mode);
 int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
                       const ls3d_sffm_t *model_host, float *out, int out_ld, ls3d_stream_t stream);

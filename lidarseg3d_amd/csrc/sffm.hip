@@ -203,11 +203,22 @@ __device__ __forceinline__ void sf_attention_valu(float *T, const float *kvs, in
 // plus one shuffle.  The second product O^T[d][point] = sum_token V_h[token][d] P[token][point] then takes P straight from those
 // registers as its B operand (the MFMA's K index is a free permutation: step s, half kk <-> the token register s of half kk
 // holds), with V_h^T as the A operand from LDS.  Tokens 32..L-1 (two of the 34 on nuScenes) go through the vector pipe.
-// BF16 = false: v_mfma_f32_32x32x2_f32 (exact f32 products: the same arithmetic as the vector-pipe version up to summation order);
-// BF16 = true: v_mfma_f32_32x32x16_bf16, operands rounded to bf16, f32 accumulation and softmax (BASELINE configs[4]).
+// MODE 0: v_mfma_f32_32x32x2_f32 (exact f32 products: the same arithmetic as the vector-pipe version up to summation order);
+// MODE 1: v_mfma_f32_32x32x16_bf16, operands rounded to bf16; MODE 2: v_mfma_f32_32x32x16_fp8_fp8, operands rounded to OCP e4m3
+// (the probabilities scaled by 256 so that small ones do not underflow) - f32 accumulation and f32 softmax in both (BASELINE configs[4]).
 // Requires all 32 points in frame fs (staged K / V) and L <= SF_LMAX.
-template <bool BF16>
-__device__ __forceinline__ void sf_attention_mfma(float *T, const float *kvs, int L) {
+__device__ __forceinline__ long sf_pack_fp8(const float (&v)[8]) {
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+  return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int MODE>
+__device__ __forceinline__ void sf_attention_mfma(float *T, const float *kvs, int L, const unsigned *kvmax) {
+  constexpr bool BF16 = MODE != 0;  // the two reduced-precision forms share the K = 16 operand walk
+  constexpr float F8_TOP = 240.0f;  // e4m3 operands are scaled so that their largest magnitude lands here (max normal 448)
   const int lane = threadIdx.x & 63, col = lane & 31, kk = lane >> 5;
   const float scale = 1.0f / sqrtf((float)SF_HD);
   const int nx = L > 32 ? L - 32 : 0;  // tokens handled on the vector pipe (<= 4)
@@ -218,6 +229,17 @@ __device__ __forceinline__ void sf_attention_mfma(float *T, const float *kvs, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
     const int tok = col < L ? col : 0;  // this lane's key row of the A operand (rows >= L are masked below)
+    float ksc = 1.0f, qsc = 1.0f, vsc = 1.0f, unscale = 1.0f;
+    if constexpr (MODE == 2) {  // e4m3: per-head scale for K and V, per-point scale for q (both lanes of a point agree by one shuffle)
+      const float km = __uint_as_float(kvmax[h]), vm = __uint_as_float(kvmax[4 + h]);
+      float qm = 0.0f;
+#pragma unroll
+      for (int d = 0; d < SF_HD; ++d) qm = fmaxf(qm, fabsf(qrow[d]));
+      ksc = km > 0.0f ? F8_TOP / km : 1.0f;
+      vsc = vm > 0.0f ? F8_TOP / vm : 1.0f;
+      qsc = qm > 0.0f ? F8_TOP / qm : 1.0f;
+      unscale = 1.0f / (ksc * qsc);
+    }
     if constexpr (!BF16) {
       const float4 *ka = (const float4 *)(Kh + tok * SF_HD + kk * 12), *qb = (const float4 *)(qrow + kk * 12);
       const float4 k0 = ka[0], k1 = ka[1], k2 = ka[2], q0 = qb[0], q1 = qb[1], q2 = qb[2];
@@ -228,14 +250,21 @@ __device__ __forceinline__ void sf_attention_mfma(float *T, const float *kvs, in
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {  // dims 16 t + 8 kk + j, zero beyond 24
-        sf_bf16x8 a, b;
+        float af[8], bf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int d = 16 * t + 8 * kk + j;
-          a[j] = (__bf16)(d < SF_HD ? Kh[tok * SF_HD + d] : 0.0f);
-          b[j] = (__bf16)(d < SF_HD ? qrow[d] : 0.0f);
+          af[j] = d < SF_HD ? Kh[tok * SF_HD + d] * ksc : 0.0f;
+          bf[j] = d < SF_HD ? qrow[d] * qsc : 0.0f;
         }
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, sc, 0, 0, 0);
+        if constexpr (MODE == 1) {
+          sf_bf16x8 a, b;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { a[j] = (__bf16)af[j]; b[j] = (__bf16)bf[j]; }
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, sc, 0, 0, 0);
+        } else {
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(sf_pack_fp8(af), sf_pack_fp8(bf), sc, 0, 0, 0);
+        }
       }
     }
     // extra tokens 32 + kk + 2 j on the vector pipe
@@ -254,7 +283,7 @@ __device__ __forceinline__ void sf_attention_mfma(float *T, const float *kvs, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int token = (r & 3) + 8 * (r >> 2) + 4 * kk;
-      sc[r] = token < L ? sc[r] * scale : -3.0e38f;
+      sc[r] = token < L ? sc[r] * (scale * unscale) : -3.0e38f;
       m = fmaxf(m, sc[r]);
     }
     m = fmaxf(m, __shfl_xor(m, 32));
@@ -287,14 +316,25 @@ __device__ __forceinline__ void sf_attention_mfma(float *T, const float *kvs, in
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        sf_bf16x8 a, b;
+        float af[8], bf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int s2 = 8 * t + j, token = (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
-          a[j] = (__bf16)(token < L ? Vh[token * SF_HD + dv] : 0.0f);
-          b[j] = (__bf16)sc[s2];
+          af[j] = token < L ? Vh[token * SF_HD + dv] * vsc : 0.0f;
+          bf[j] = MODE == 2 ? sc[s2] * 256.0f : sc[s2];
         }
-        oc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, oc, 0, 0, 0);
+        if constexpr (MODE == 1) {
+          sf_bf16x8 a, b;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { a[j] = (__bf16)af[j]; b[j] = (__bf16)bf[j]; }
+          oc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, oc, 0, 0, 0);
+        } else {
+          oc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(sf_pack_fp8(af), sf_pack_fp8(bf), oc, 0, 0, 0);
+        }
+      }
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oc[r] *= (1.0f / 256.0f) / vsc;
       }
     }
     // the extra tokens' share: this lane holds p of tokens 32 + kk + 2 j, its partner those of 32 + (1 - kk) + 2 j
@@ -329,6 +369,7 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
   float *Bs = smem + 4 * SF_WAVE_FLOATS;         // [2][SF_BCHUNK]
   float *KVs = Bs + 2 * SF_BCHUNK;               // [2][H][L][HD]
   int *s_frame = (int *)(KVs + SF_KV);           // [128] frame of each point (-1 beyond n)
+  unsigned *s_kvmax = (unsigned *)(s_frame + 128);  // [8] max |K_h|, max |V_h| of the staged frame and layer (bit patterns)
   const size_t kv_layer = (size_t)2 * batch * SF_E * L;  // floats per layer: k[batch][E][L] then v[batch][E][L]
   for (int p0 = blockIdx.x * 128; p0 < n; p0 += gridDim.x * 128) {
     __syncthreads();
@@ -357,13 +398,20 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
       // ---- K / V of the layer and the tile's first frame, transposed: source [h][d][l] -> LDS [h][l][d]
       __syncthreads();  // every wave is past the previous layer's attention (KVs) and has written its q
       const bool staged = L <= SF_LMAX;  // more class embeddings than the LDS window holds: K / V are read from L2
+      if (tid < 8) s_kvmax[tid] = 0u;
       if (staged) {
+        if (att_mode == 3) __syncthreads();
         const float *kb0 = kg + (size_t)fs * SF_E * L, *vb0 = vg + (size_t)fs * SF_E * L;
         for (int i = tid; i < SF_E * L; i += 256) {
           const int ll = i % L, hd = i / L, h = hd / SF_HD, d = hd - h * SF_HD;
           const int o = (h * L + ll) * SF_HD + d;
-          KVs[o] = kb0[i];
-          KVs[SF_E * L + o] = vb0[i];
+          const float kx = kb0[i], vx = vb0[i];
+          KVs[o] = kx;
+          KVs[SF_E * L + o] = vx;
+          if (att_mode == 3) {  // per-head magnitudes for the e4m3 operand scaling (bit patterns of non-negative floats order like uints)
+            atomicMax(&s_kvmax[h], __float_as_uint(fabsf(kx)));
+            atomicMax(&s_kvmax[4 + h], __float_as_uint(fabsf(vx)));
+          }
         }
       }
       __syncthreads();
@@ -373,8 +421,9 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
         const int fr = s_frame[wave * 32 + col];
         const bool mixed = __any(fr >= 0 && fr != fs);
         if (!mixed && att_mode != 2 && staged) {
-          if (att_mode == 1) sf_attention_mfma<true>(T, KVs, L);
-          else sf_attention_mfma<false>(T, KVs, L);
+          if (att_mode == 1) sf_attention_mfma<1>(T, KVs, L, s_kvmax);
+          else if (att_mode == 3) sf_attention_mfma<2>(T, KVs, L, s_kvmax);
+          else sf_attention_mfma<0>(T, KVs, L, s_kvmax);
         } else {
           sf_attention_valu(T, staged ? KVs : nullptr, fs, kg, vg, L, s_frame, wave);
         }
@@ -414,8 +463,8 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
   }
 }
 
-static int g_sffm_attention = 0;  // 0: exact-f32 MFMA attention, 1: bf16 MFMA attention, 2: vector-pipe attention (A/B)
-extern "C" void ls3d_set_sffm_attention(int mode) { g_sffm_attention = (mode >= 0 && mode <= 2) ? mode : 0; }
+static int g_sffm_attention = 0;  // 0: exact-f32 MFMA attention, 1: bf16 MFMA, 2: vector pipe (A/B), 3: fp8 (e4m3) MFMA
+extern "C" void ls3d_set_sffm_attention(int mode) { g_sffm_attention = (mode >= 0 && mode <= 3) ? mode : 0; }
 
 extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
                                  const ls3d_sffm_t *m, float *out, int out_ld, ls3d_stream_t stream_) {
@@ -436,7 +485,7 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
       return LS3D_ERR_ARG;
     prm.layer[l] = SfLayer{s.wq, s.bq, s.wo, s.bo, s.w1a, s.w1b, s.b1, s.w2a, s.w2b, s.b2, s.n2_gamma, s.n2_beta, s.n3_gamma, s.n3_beta, s.n2_eps, s.n3_eps};
   }
-  const int lds = (4 * SF_WAVE_FLOATS + 2 * SF_BCHUNK + SF_KV) * (int)sizeof(float) + 128 * (int)sizeof(int);
+  const int lds = (4 * SF_WAVE_FLOATS + 2 * SF_BCHUNK + SF_KV) * (int)sizeof(float) + (128 + 8) * (int)sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_sffm_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;

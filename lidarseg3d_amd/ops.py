@@ -794,8 +794,9 @@ class SffmModel(object):
 
 
 def set_sffm_attention(mode):
-    """"f32" (default: exact-f32 MFMA), "bf16" (bf16 MFMA operands, f32 accumulation / softmax) or "valu" (vector pipe)"""
-    _L().ls3d_set_sffm_attention({"f32": 0, "bf16": 1, "valu": 2}[mode])
+    """"f32" (default: exact-f32 MFMA), "bf16" / "fp8" (MFMA operands rounded to bf16 / OCP e4m3, f32 accumulation and softmax) or
+    "valu" (vector pipe)"""
+    _L().ls3d_set_sffm_attention({"f32": 0, "bf16": 1, "valu": 2, "fp8": 3}[mode])
 
 
 def sffm_decoder(x, points, kv, L, batch, model):

@@ -182,5 +182,10 @@ hipsim_f32x16 hipsim_mfma_32x32x2f32(float a, float b, hipsim_f32x16 c, int, int
 typedef __bf16 hipsim_bf16x8 __attribute__((ext_vector_type(8)));
 hipsim_f32x16 hipsim_mfma_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim_f32x16 c, int, int, int);
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipsim_mfma_32x32x16_bf16
+// fp8 (OCP e4m3fn, the gfx950 format): 8 values per lane packed in an int64, same A / B / C layout as the bf16 form
+hipsim_f32x16 hipsim_mfma_32x32x16_fp8(long a, long b, hipsim_f32x16 c, int, int, int);
+#define __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8 hipsim_mfma_32x32x16_fp8
+int hipsim_cvt_pk_fp8_f32(float a, float b, int old, bool word_sel);  // two e4m3 bytes into the low / high half of `old`
+#define __builtin_amdgcn_cvt_pk_fp8_f32 hipsim_cvt_pk_fp8_f32
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

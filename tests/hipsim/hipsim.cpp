@@ -239,3 +239,59 @@ hipsim_f32x16 hipsim_mfma_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim
   hipsim::wave_barrier();
   return d;
 }
+
+// ---- fp8 e4m3fn (OCP): 1 sign, 4 exponent (bias 7), 3 mantissa bits; max 448, no inf, 0x7F / 0xFF = NaN; round to nearest even,
+//      saturating (the hardware convert saturates by default)
+static uint8_t hipsim_f32_to_e4m3(float f) {
+  if (f != f) return 0x7F;
+  const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+  float a = fabsf(f);
+  if (a >= 448.0f) return sign | 0x7E;
+  if (a < 0.0009765625f) return sign;  // below half the smallest subnormal (2^-9 / 2): zero
+  int e;
+  frexpf(a, &e);  // a = m * 2^e, m in [0.5, 1)
+  int E = e - 1;  // a = 1.x * 2^E
+  if (E < -6) E = -6;  // subnormal range: fixed exponent
+  const float q = ldexpf(a, 3 - E);  // in units of the last mantissa bit
+  float r = nearbyintf(q);  // RNE (default rounding mode)
+  int mant = (int)r;
+  if (E == -6 && mant < 8) return sign | (uint8_t)mant;  // subnormal (or 0)
+  if (mant == 16) { mant = 8; ++E; }
+  if (E > 8 || (E == 8 && mant > 14)) return sign | 0x7E;
+  return sign | (uint8_t)(((E + 7) << 3) | (mant - 8));
+}
+static float hipsim_e4m3_to_f32(uint8_t v) {
+  const int sign = v >> 7, ex = (v >> 3) & 15, m = v & 7;
+  float r;
+  if (ex == 15 && m == 7) r = NAN;
+  else if (ex == 0) r = ldexpf((float)m, -9);
+  else r = ldexpf(1.0f + m / 8.0f, ex - 7);
+  return sign ? -r : r;
+}
+int hipsim_cvt_pk_fp8_f32(float a, float b, int old, bool word_sel) {
+  const unsigned pk = (unsigned)hipsim_f32_to_e4m3(a) | ((unsigned)hipsim_f32_to_e4m3(b) << 8);
+  const unsigned o = (unsigned)old;
+  return (int)(word_sel ? ((o & 0x0000FFFFu) | (pk << 16)) : ((o & 0xFFFF0000u) | pk));
+}
+hipsim_f32x16 hipsim_mfma_32x32x16_fp8(long a, long b, hipsim_f32x16 c, int, int, int) {
+  static float A[16][32][16], B[16][16][32];
+  int w = hipsim::wave(), l = hipsim::lane();
+  uint8_t ra[8], rb[8];
+  memcpy(ra, &a, 8);
+  memcpy(rb, &b, 8);
+  for (int j = 0; j < 8; ++j) {
+    A[w][l & 31][8 * (l >> 5) + j] = hipsim_e4m3_to_f32(ra[j]);
+    B[w][8 * (l >> 5) + j][l & 31] = hipsim_e4m3_to_f32(rb[j]);
+  }
+  hipsim::wave_barrier();
+  hipsim_f32x16 d = c;
+  int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) acc = fmaf(A[w][row][k], B[w][k][col], acc);
+    d[r] = acc;
+  }
+  hipsim::wave_barrier();
+  return d;
+}

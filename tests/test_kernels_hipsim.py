@@ -953,10 +953,15 @@ def test_fused_sffm_decoder_equals_layer_by_layer_and_oracle():
             np.testing.assert_allclose(m(x, e1, e2, bidx, 2, points=pts).numpy(), ref.numpy(), rtol=0, atol=2e-5)
             ops.set_sffm_attention("bf16")
             b16 = m(x, e1, e2, bidx, 2, points=pts)
+            ops.set_sffm_attention("fp8")
+            f8 = m(x, e1, e2, bidx, 2, points=pts)
     finally:
         ops.set_sffm_attention("f32")
     # bf16 QK^T / PV operands (8 mantissa bits), f32 accumulation and softmax; outputs are LayerNorm'd (unit scale)
     assert float((b16 - ref).abs().max()) <= 3e-2 and float((b16 - ref).pow(2).mean().sqrt()) <= 4e-3
+    # e4m3 operands (3 mantissa bits): a coarse but usable attention
+    print("fp8 attention: max %.3g rms %.3g" % (float((f8 - ref).abs().max()), float((f8 - ref).pow(2).mean().sqrt())))
+    assert float((f8 - ref).abs().max()) <= 0.5 and float((f8 - ref).pow(2).mean().sqrt()) <= 6e-2
     sd = {k: v.detach() for k, v in m.state_dict().items()}
     want = orc.sffm(sd, "", x, e1, e2, bidx, 2, 4)
     np.testing.assert_allclose(fused.numpy(), want.numpy(), rtol=0, atol=5e-5)
