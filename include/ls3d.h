@@ -113,7 +113,7 @@ int ls3d_dynamic_scatter_backward(const float *grad_voxels, const int32_t *point
                                   const float *feats_in, const float *feats_out, void *workspace, size_t workspace_bytes,
                                   float *grad_points, ls3d_stream_t stream);
 
-size_t ls3d_segment_reduce_workspace_bytes(int n_seg);
+size_t ls3d_segment_reduce_workspace_bytes(int n, int n_seg);
 
 /* Segment mean / max over dim 0: out[n_seg,n_feat] from src[n,n_feat] and one int64 segment id per row (mode 0 = mean,
  * 1 = max with arg_out[n_seg,n_feat] = lowest row index attaining it, may be NULL).  Segments without rows give 0 (arg = n).

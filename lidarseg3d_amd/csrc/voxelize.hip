@@ -301,10 +301,72 @@ extern "C" int ls3d_voxelize_hard(const float *points, int n, const ls3d_points_
   return LS3D_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ ordered segmented mean
+// Points-in-voxel pooling without float atomics: rows are sorted by segment id with the stable radix sort (csrc/sort.hip), so the
+// rows of a segment sit together in their input order (= the slot order of the reference's padded [V, M, C] tensor,
+// scatter_points.py:85-98, scatter_points_cpu.cpp:8-60); one thread per (segment, channel) adds them sequentially in f32.  The
+// result is the slot-order sum divided by the count: bit-reproducible and bit-equal to that serial evaluation.
+int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, int bits, uint32_t *keys_out, int32_t *vals_out, void *workspace,
+                          size_t workspace_bytes, hipStream_t stream);
+extern "C" size_t ls3d_radix_sort_workspace_bytes(int n);
+
+struct SegWs { uint32_t *keys, *skeys; int32_t *perm, *start, *end; void *sort_ws; size_t sort_bytes, bytes; };
+static SegWs seg_ws_layout(char *base, int n, int n_seg) {
+  SegWs w;
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += align256(b); return base + o; };
+  w.keys = (uint32_t *)take((size_t)n * 4);
+  w.skeys = (uint32_t *)take((size_t)n * 4);
+  w.perm = (int32_t *)take((size_t)n * 4);
+  w.start = (int32_t *)take((size_t)(n_seg + 1) * 4);
+  w.end = (int32_t *)take((size_t)(n_seg + 1) * 4);
+  w.sort_bytes = ls3d_radix_sort_workspace_bytes(n);
+  w.sort_ws = take(w.sort_bytes);
+  w.bytes = off;
+  return w;
+}
+
+__global__ __launch_bounds__(256) void k_seg_bounds(const uint32_t *skeys, int n, int n_seg, int32_t *start, int32_t *end) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t k = skeys[i];
+    if (k >= (uint32_t)n_seg) continue;
+    if (i == 0 || skeys[i - 1] != k) start[k] = i;
+    if (i == n - 1 || skeys[i + 1] != k) end[k] = i + 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_seg_mean_ordered(const float *src, int C, const int32_t *perm, const int32_t *start, const int32_t *end,
+                                                         int n_seg, const int32_t *n_seg_dev, float *out, int32_t *counts) {
+  const int S = ls3d_count(n_seg, n_seg_dev);
+  const long long work = (long long)S * C;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int sg = (int)(t / C), c = (int)(t % C);
+    const int a = start[sg], b = end[sg];
+    float acc = 0.0f;
+    for (int p = a; p < b; ++p) acc = __fadd_rn(acc, src[(size_t)perm[p] * C + c]);
+    out[t] = b > a ? __fdiv_rn(acc, (float)(b - a)) : 0.0f;
+    if (c == 0 && counts) counts[sg] = b - a;
+  }
+}
+
+// ids[n] (uint32, >= n_seg = not in any segment) -> out[n_seg, C] = ordered mean; counts (optional) [n_seg]
+static int seg_mean_ordered(const float *src, int n, int C, int n_seg, const int32_t *n_seg_dev, SegWs &w, float *out, int32_t *counts, hipStream_t stream) {
+  int bits = 1;
+  while ((1u << bits) <= (unsigned)n_seg && bits < 31) ++bits;
+  int rc = ls3d_radix_sort_pairs(w.keys, nullptr, n, bits, w.skeys, w.perm, w.sort_ws, w.sort_bytes, stream);
+  if (rc != LS3D_OK) return rc;
+  hipMemsetAsync(w.start, 0, (size_t)(n_seg + 1) * 4, stream);
+  hipMemsetAsync(w.end, 0, (size_t)(n_seg + 1) * 4, stream);
+  hipLaunchKernelGGL(k_seg_bounds, ls3d_grid(n), dim3(256), 0, stream, (const uint32_t *)w.skeys, n, n_seg, w.start, w.end);
+  hipLaunchKernelGGL(k_seg_mean_ordered, ls3d_grid((long long)n_seg * C), dim3(256), 0, stream, src, C, (const int32_t *)w.perm,
+                     (const int32_t *)w.start, (const int32_t *)w.end, n_seg, n_seg_dev, out, counts);
+  return LS3D_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ dynamic scatter
-// DynamicScatter: all points of a voxel are reduced (no cap).  Mean uses f32 atomicAdd (summation order
-// differs from the reference's slot order; the reference documents ~5e-7 CPU/GPU differences itself,
-// det3d/ops/voxel/scatter_points.py:74-76); max uses an order-preserving integer atomicMax.
+// DynamicScatter: all points of a voxel are reduced (no cap).  Mean: the ordered segmented mean above (slot-order f32 sum, no
+// atomics, bit-reproducible); max uses an order-preserving integer atomicMax (exact, order-independent).
 __device__ __forceinline__ int f2ord(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
@@ -336,17 +398,17 @@ __global__ __launch_bounds__(256) void k_ds_assign(int n, const int32_t *flag, c
 }
 
 __global__ __launch_bounds__(256) void k_ds_reduce(const float *feats, int n, int C, const int32_t *slot_of_pt, const int32_t *slot_vid,
-                                                  int mode, float *out, int32_t *counts, int32_t *point2voxel) {
+                                                  int mode, float *out, int32_t *counts, int32_t *point2voxel, uint32_t *keys) {
   const long long work = (long long)n * C;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
     const int i = (int)(t / C), c = (int)(t % C);
     const int s = slot_of_pt[i];
     const int v = s >= 0 ? slot_vid[s] : -1;
     if (c == 0 && point2voxel) point2voxel[i] = v;
-    if (v < 0) continue;
+    if (c == 0 && keys) keys[i] = v >= 0 ? (uint32_t)v : 0x7FFFFFFFu;
+    if (v < 0 || mode == 0) continue;  // mode 0 (mean) only needs the segment keys here
     const float x = feats[t];
-    if (mode == 0) atomicAdd(&out[(size_t)v * C + c], x);
-    else atomicMax((int *)&out[(size_t)v * C + c], f2ord(x));
+    atomicMax((int *)&out[(size_t)v * C + c], f2ord(x));
     if (c == 0) atomicAdd(&counts[v], 1);
   }
 }
@@ -379,7 +441,7 @@ __global__ __launch_bounds__(256) void k_fill_i32(int32_t *p, long long n, int32
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) p[t] = v;
 }
 
-struct DsWs { uint64_t *keys; int32_t *first_pt, *slot_vid, *slot_of_pt, *flag, *vid, *scan_tmp, *counts, *total, *maxcnt; uint32_t cap; size_t bytes; };
+struct DsWs { uint64_t *keys; int32_t *first_pt, *slot_vid, *slot_of_pt, *flag, *vid, *scan_tmp, *counts, *total, *maxcnt; uint32_t cap; size_t bytes; SegWs seg; };
 static DsWs ds_ws_layout(char *base, int n) {
   DsWs w; w.cap = hash_cap_for(n);
   size_t off = 0;
@@ -394,6 +456,8 @@ static DsWs ds_ws_layout(char *base, int n) {
   w.counts = (int32_t *)take((size_t)n * 4);
   w.total = (int32_t *)take(4);
   w.maxcnt = (int32_t *)take(4);
+  w.seg = seg_ws_layout(base ? base + off : nullptr, n, n);
+  off += w.seg.bytes;
   w.bytes = off;
   return w;
 }
@@ -425,7 +489,13 @@ extern "C" int ls3d_dynamic_scatter(const float *feats_in, int n, int n_feat, co
   hipLaunchKernelGGL(k_ds_assign, gp, blk, 0, stream, n, (const int32_t *)w.flag, (const int32_t *)w.vid, (const int32_t *)w.slot_of_pt,
                      coors, coors_cols, w.slot_vid, voxel_coors, (const int32_t *)w.total, num_voxels_dev);
   hipLaunchKernelGGL(k_ds_reduce, ls3d_grid((long long)n * n_feat), blk, 0, stream, feats_in, n, n_feat, (const int32_t *)w.slot_of_pt,
-                     (const int32_t *)w.slot_vid, mode, feats_out, w.counts, point2voxel);
+                     (const int32_t *)w.slot_vid, mode, feats_out, w.counts, point2voxel, mode == 0 ? w.seg.keys : nullptr);
+  if (mode == 0) {  // ordered mean: rows beyond *num_voxels_dev stay zero (the memset above)
+    rc = seg_mean_ordered(feats_in, n, n_feat, n, num_voxels_dev, w.seg, feats_out, nullptr, stream);
+    if (rc != LS3D_OK) return rc;
+    LS3D_RETURN_IF_LAUNCH_FAILED();
+    return LS3D_OK;
+  }
   hipLaunchKernelGGL(k_ds_maxcount, gp, blk, 0, stream, n, (const int32_t *)num_voxels_dev, (const int32_t *)w.counts, w.maxcnt);
   hipLaunchKernelGGL(k_ds_finish, ls3d_grid((long long)n * n_feat), blk, 0, stream, feats_out, n, (const int32_t *)num_voxels_dev, n_feat,
                      mode, (const int32_t *)w.counts, (const int32_t *)w.maxcnt);
@@ -499,8 +569,17 @@ extern "C" int ls3d_dynamic_scatter_backward(const float *grad_voxels, const int
 // What the dynamic readers (det3d/models/readers/voxel_encoder.py:366-372,451-456,594-600,682-686) ask of torch_scatter
 // (third-party, absent from the reference tree: scatter_mean / scatter_max over dim 0 with an int64 segment id per row, e.g.
 // torch.unique's inverse).  out[n_seg,C]; segments without rows give 0 (and arg = n), as torch_scatter does.
-// mean: f32 atomicAdd (run-to-run summation order, like torch_scatter's CUDA path) / count; max: order-preserving integer atomicMax,
-// arg = the LOWEST row index attaining it (torch_scatter leaves ties to a race).
+// mean: the ordered segmented mean (rows added in input order, no atomics: bit-reproducible, unlike torch_scatter's CUDA path);
+// max: order-preserving integer atomicMax, arg = the LOWEST row index attaining it (torch_scatter leaves ties to a race).
+__global__ __launch_bounds__(256) void k_seg_keys(const int64_t *index, int n, int n_seg, uint32_t *keys, int32_t *bad) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int64_t sg = index[i];
+    const bool ok = sg >= 0 && sg < n_seg;
+    if (!ok) *bad = 1;
+    keys[i] = ok ? (uint32_t)sg : 0x7FFFFFFFu;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_seg_accum(const float *src, const int64_t *index, int n, int C, int n_seg, int mode, float *out,
                                                   int32_t *counts, int32_t *bad) {
   const long long work = (long long)n * C;
@@ -538,7 +617,9 @@ __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long *p, long lo
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) p[t] = v;
 }
 
-extern "C" size_t ls3d_segment_reduce_workspace_bytes(int n_seg) { return align256((size_t)(n_seg > 0 ? n_seg : 1) * 4) + 256; }
+extern "C" size_t ls3d_segment_reduce_workspace_bytes(int n, int n_seg) {
+  return align256((size_t)(n_seg > 0 ? n_seg : 1) * 4) + 256 + seg_ws_layout(nullptr, n > 0 ? n : 1, n_seg > 0 ? n_seg : 1).bytes;
+}
 
 extern "C" int ls3d_segment_reduce(const float *src, const int64_t *index, int n, int n_feat, int n_seg, int mode, void *workspace,
                                    size_t workspace_bytes, float *out, int64_t *arg_out, ls3d_stream_t stream_) {
@@ -546,9 +627,19 @@ extern "C" int ls3d_segment_reduce(const float *src, const int64_t *index, int n
   if (!out || !workspace || n < 0 || n_feat < 1 || n_seg < 0 || (mode != 0 && mode != 1)) return LS3D_ERR_ARG;
   if (n > 0 && (!src || !index)) return LS3D_ERR_ARG;
   if (n_seg == 0) return LS3D_OK;
-  if (workspace_bytes < ls3d_segment_reduce_workspace_bytes(n_seg)) return LS3D_ERR_WORKSPACE;
+  if (workspace_bytes < ls3d_segment_reduce_workspace_bytes(n, n_seg)) return LS3D_ERR_WORKSPACE;
   int32_t *counts = (int32_t *)workspace;
   int32_t *bad = (int32_t *)((char *)workspace + align256((size_t)n_seg * 4));
+  if (mode == 0) {
+    hipMemsetAsync(bad, 0, 4, stream);
+    if (n == 0) { hipMemsetAsync(out, 0, (size_t)n_seg * n_feat * 4, stream); return LS3D_OK; }
+    SegWs sw = seg_ws_layout((char *)workspace + align256((size_t)n_seg * 4) + 256, n, n_seg);
+    hipLaunchKernelGGL(k_seg_keys, ls3d_grid(n), dim3(256), 0, stream, index, n, n_seg, sw.keys, bad);
+    int rc = seg_mean_ordered(src, n, n_feat, n_seg, nullptr, sw, out, counts, stream);
+    if (rc != LS3D_OK) return rc;
+    LS3D_RETURN_IF_LAUNCH_FAILED();
+    return LS3D_OK;
+  }
   const dim3 blk(256);
   const long long cells = (long long)n_seg * n_feat;
   hipMemsetAsync(counts, 0, (size_t)n_seg * 4, stream);

@@ -153,7 +153,7 @@ def segment_reduce(src, index, n_seg, mode="mean", want_arg=False):
     out = torch.empty((n_seg, c), dtype=torch.float32, device=dev)
     arg = torch.empty((n_seg, c), dtype=torch.int64, device=dev) if (want_arg and mode == "max") else None
     L = _L()
-    ws = _ws(L.ls3d_segment_reduce_workspace_bytes(n_seg), src)
+    ws = _ws(L.ls3d_segment_reduce_workspace_bytes(n, n_seg), src)
     check(L.ls3d_segment_reduce(_ptr(src), _ptr(index), n, c, n_seg, 0 if mode == "mean" else 1, _ptr(ws), ctypes.c_size_t(ws.numel()),
                                 _ptr(out), _ptr(arg), _stream(src)), "ls3d_segment_reduce")
     return (out, arg) if arg is not None else out

@@ -969,3 +969,26 @@ def test_mseg3d_config5_bf16_and_fp8_attention_vs_oracle():
     assert rec["f32"]["max_abs"] <= 1e-3
     assert rec["bf16"]["max_abs"] <= 0.03 and rec["bf16"]["argmax"] >= 0.995, rec
     assert rec["fp8"]["max_abs"] <= 0.5 and rec["fp8"]["argmax"] >= 0.99, rec
+
+
+def test_points_in_voxel_mean_is_deterministic_and_slot_ordered_gpu():
+    """DynamicScatter mean / segment mean on the device: no float atomics - bit-equal to the serial slot-order f32 sum and
+    bit-reproducible (120k points)"""
+    from tests.test_kernels_hipsim import _slot_order_mean
+    cfg = synth.NUSC
+    pts = synth.lidar_frame(120000, seed=8, **cfg)
+    coors = ops.voxelize_dynamic(cu(pts), cfg["voxel_size"], cfg["pc_range"])
+    gs = orc.grid_size(cfg["voxel_size"], cfg["pc_range"])
+    shape = [int(gs[2]), int(gs[1]), int(gs[0])]
+    f, vc, p2v, nv = ops.dynamic_scatter(cu(pts), coors, shape, "mean")
+    V = int(nv)
+    want = _slot_order_mean(pts, p2v.cpu().numpy(), V)
+    assert np.array_equal(f[:V].cpu().numpy(), want)
+    for _ in range(3):
+        f2, _, _, _ = ops.dynamic_scatter(cu(pts), coors, shape, "mean")
+        assert torch.equal(f2[:V], f[:V])
+    rng = np.random.default_rng(4)
+    big = (rng.normal(size=(50000, 8)) * np.exp(rng.normal(size=(50000, 8)) * 6)).astype(np.float32)
+    idx = rng.integers(0, 40, size=50000).astype(np.int64)
+    got = ops.segment_reduce(cu(big), cu(idx), 41, "mean").cpu().numpy()
+    assert np.array_equal(got, _slot_order_mean(big, idx, 41))

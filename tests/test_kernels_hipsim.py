@@ -965,3 +965,39 @@ def test_fused_sffm_decoder_equals_layer_by_layer_and_oracle():
     sd = {k: v.detach() for k, v in m.state_dict().items()}
     want = orc.sffm(sd, "", x, e1, e2, bidx, 2, 4)
     np.testing.assert_allclose(fused.numpy(), want.numpy(), rtol=0, atol=5e-5)
+
+
+def _slot_order_mean(feats, ids, n_seg):
+    """serial f32 restatement: rows of a segment added in input (= slot) order, then divided by the count"""
+    out = np.zeros((n_seg, feats.shape[1]), np.float32)
+    cnt = np.zeros(n_seg, np.int64)
+    acc = np.zeros((n_seg, feats.shape[1]), np.float32)
+    for i, s in enumerate(ids):
+        if 0 <= s < n_seg:
+            acc[s] = acc[s] + feats[i]
+            cnt[s] += 1
+    nz = cnt > 0
+    out[nz] = acc[nz] / cnt[nz, None].astype(np.float32)
+    return out
+
+
+def test_points_in_voxel_mean_is_the_slot_order_sum_bit_for_bit():
+    """DynamicScatter mean / segment mean without float atomics: bit-equal to the serial slot-order f32 sum of the
+    reference's padded tensor (scatter_points.py:85-98) and bit-reproducible"""
+    g = golden("voxelize_nusc.npz")
+    gs = orc.grid_size(g["voxel_size"], g["pc_range"])
+    shape = [int(gs[2]), int(gs[1]), int(gs[0])]
+    pts, coors = torch.from_numpy(g["points"]), torch.from_numpy(g["cpp_dyn_coors"])
+    f, vc, p2v, nv = ops.dynamic_scatter(pts, coors, shape, "mean")
+    V = int(nv)
+    want = _slot_order_mean(g["points"], p2v.numpy(), V)
+    assert np.array_equal(f[:V].numpy(), want)
+    f2, _, _, _ = ops.dynamic_scatter(pts, coors, shape, "mean")
+    assert torch.equal(f2[:V], f[:V])
+    # a voxel with many points of very different magnitudes: the order of the additions matters, and it is the slot order
+    rng = np.random.default_rng(4)
+    big = (rng.normal(size=(3000, 4)) * np.exp(rng.normal(size=(3000, 4)) * 6)).astype(np.float32)
+    idx = rng.integers(0, 7, size=3000).astype(np.int64)
+    idx[::11] = 9  # segment 7, 8 empty, 9 sparse
+    got = ops.segment_reduce(torch.from_numpy(big), torch.from_numpy(idx), 10, "mean").numpy()
+    assert np.array_equal(got, _slot_order_mean(big, idx, 10))
