@@ -992,3 +992,27 @@ def test_points_in_voxel_mean_is_deterministic_and_slot_ordered_gpu():
     idx = rng.integers(0, 40, size=50000).astype(np.int64)
     got = ops.segment_reduce(cu(big), cu(idx), 41, "mean").cpu().numpy()
     assert np.array_equal(got, _slot_order_mean(big, idx, 41))
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x8"])
+def test_other_backbones_conv_calls_on_device(prec):
+    """SURVEY 8f rank 4 on the MI355X: the sparse-conv calls of the reference's Cylinder3D_Asymm_3d_spconv and SpMiddleResNetFHD
+    (fixtures: tests/golden/make_golden_f4.py) replayed on lidarseg3d_amd.spconv: asymmetric (1,3,3)/(3,1,3)/(3,1,1) kernels, layers
+    of different kernel shapes under one indice_key, stride-(2,2,1) convolutions and their inverses, a biased logits convolution;
+    plus SparseConvTensor.dense()"""
+    from lidarseg3d_amd import spconv
+    from tests import f4_cases
+    try:
+        ops.set_precision(prec)
+        seen, worst = f4_cases.replay("f4_cylinder3d_asymm.npz", DEV)
+        assert {(0, (1, 3, 3), (1, 1, 1)), (0, (3, 1, 3), (1, 1, 1)), (0, (3, 1, 1), (1, 1, 1)), (1, (3, 3, 3), (2, 2, 1)), (2, (3, 3, 3), (1, 1, 1))} <= seen
+        seen2, worst2 = f4_cases.replay("f4_spmiddleresnetfhd.npz", DEV)
+        assert (1, (3, 1, 1), (2, 1, 1)) in seen2
+        print("f4 replay %s: worst relative deviation %.2g / %.2g" % (prec, worst, worst2))
+    finally:
+        ops.set_precision("f32")
+    g = golden("f4_cylinder3d_asymm.npz")
+    x = spconv.SparseConvTensor(cu(g["c00_in_feats"]), cu(g["c00_in_idx"]), [int(v) for v in g["c00_in_shape"]], 2)
+    d = x.dense()
+    i = cu(g["c00_in_idx"]).long()
+    assert torch.equal(d[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]], x.features) and float(d.abs().sum()) == float(x.features.abs().sum())

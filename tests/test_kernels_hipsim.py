@@ -1001,3 +1001,13 @@ def test_points_in_voxel_mean_is_the_slot_order_sum_bit_for_bit():
     idx[::11] = 9  # segment 7, 8 empty, 9 sparse
     got = ops.segment_reduce(torch.from_numpy(big), torch.from_numpy(idx), 10, "mean").numpy()
     assert np.array_equal(got, _slot_order_mean(big, idx, 10))
+
+
+def test_other_backbones_conv_calls_replayed_on_our_spconv():
+    """every sparse-conv call of the reference's Cylinder3D_Asymm_3d_spconv and SpMiddleResNetFHD (fixtures from the reference's
+    files over the oracle shim): asymmetric kernels, several kernel shapes under one indice_key, stride (2,2,1), inverse, bias"""
+    from tests import f4_cases
+    seen, _ = f4_cases.replay("f4_cylinder3d_asymm.npz", "cpu")
+    assert {(0, (1, 3, 3), (1, 1, 1)), (0, (3, 1, 3), (1, 1, 1)), (0, (3, 1, 1), (1, 1, 1)), (1, (3, 3, 3), (2, 2, 1)), (2, (3, 3, 3), (1, 1, 1))} <= seen
+    seen, _ = f4_cases.replay("f4_spmiddleresnetfhd.npz", "cpu")
+    assert (1, (3, 1, 1), (2, 1, 1)) in seen
