@@ -1,69 +1,85 @@
 #!/usr/bin/env python
-"""Turn the rocprofv3 counter passes of tests/run_gpu_checks.sh (PMC=1) into profiles/round1_pmc.{md,json}.
+"""Turn the rocprofv3 counter passes of tests/run_gpu_checks.sh (PMC=1) into profiles/round2_pmc.{md,json} and round2_pmc_sq.md.
 
-  python profiles/summarize_pmc.py gpurun_out          # reads gpurun_out/pmc_FETCH_SIZE, gpurun_out/pmc_WRITE_SIZE
+  python profiles/summarize_pmc.py gpurun_out
 
 HBM-side bytes per kernel = 2 x FETCH_SIZE + WRITE_SIZE (KiB), the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md
-(FETCH_SIZE reports half of the bytes of wide coalesced reads).  The bench command runs the f32 leg and the fast_mode
-(split-bf16) legs, `frames` frames each (warm-up + steps)."""
+(FETCH_SIZE reports half of the bytes of wide coalesced reads); the counters sit on the L2 -> fabric side, Infinity-Cache hits are
+included: an upper bound of DRAM traffic.  Sparse-conv kernels = k_tile_conv<*> and k_gather_gemm<*, true> (the table-driven
+launches); bytes per launch = their summed bytes / their launch count, per precision mode of `bench.py --precision P`."""
 import json
 import os
 import sys
 
 import pandas as pd
 
+SPARSE = r"k_tile_conv<|k_gather_gemm<.*true>"
 
-def load(d, counter):
-    df = pd.read_csv(os.path.join(d, "pmc_%s" % counter, "bench_counter_collection.csv"))
-    df = df[df.Counter_Name == counter]
+
+def load(d, sub, counter):
+    df = pd.read_csv(os.path.join(d, sub, "bench_counter_collection.csv"))
+    df = df[df.Counter_Name == counter].copy()
     df["k"] = df.Kernel_Name.str.replace(r"\(.*", "", regex=True).str.replace("void ", "").str.slice(0, 60)
-    return df.groupby("k").Counter_Value.agg(["sum", "count"])
+    return df
 
 
-def main(d, frames=5, algo_bytes_per_frame=None):
-    f, w = load(d, "FETCH_SIZE"), load(d, "WRITE_SIZE")
-    t = f.join(w, lsuffix="_f", rsuffix="_w", how="outer").fillna(0.0)
-    t["launches"] = t["count_f"] / frames
-    t["fetch_kib"] = t["sum_f"] / frames
-    t["write_kib"] = t["sum_w"] / frames
-    t["bytes"] = (2 * t.fetch_kib + t.write_kib) * 1024
-    t = t.sort_values("bytes", ascending=False)
-    sp32 = t[t.index.str.contains(r"k_gather_gemm<.*true>")]
-    spbf = t[t.index.str.contains(r"k_gather_gemm_bf16x3<.*true, 2>")]   # 2 planes = bf16x3
-    spb6 = t[t.index.str.contains(r"k_gather_gemm_bf16x3<.*true, 3>")]   # 3 planes = bf16x6
-    out = {
-        "kernel": "k_gather_gemm<*, true> (sparse conv, f32 mode)",
-        "launches_per_frame": float(sp32.launches.sum()),
-        "fetch_size_kib_per_frame": float(sp32.fetch_kib.sum()),
-        "write_size_kib_per_frame": float(sp32.write_kib.sum()),
-        "traffic_bytes_per_launch": float(sp32.bytes.sum() / max(sp32.launches.sum(), 1)),
-        "bf16x3_traffic_bytes_per_launch": float(spbf.bytes.sum() / max(spbf.launches.sum(), 1)),
-        "bf16x6_traffic_bytes_per_launch": float(spb6.bytes.sum() / max(spb6.launches.sum(), 1)),
-        "correction": "(2*FETCH_SIZE+WRITE_SIZE)*1024 (MI355X_MICROARCH.md HBM section)",
-        "command": "python bench.py --steps 3 --warmup 2 --no-cpu-baseline",
-    }
+def main(d):
     here = os.path.dirname(os.path.abspath(__file__))
-    json.dump(out, open(os.path.join(here, "round1_pmc.json"), "w"), indent=1)
-    lines = ["# HBM-side traffic counters (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)", "",
-             "Generated by profiles/summarize_pmc.py from the passes of `PMC=1 bash tests/run_gpu_checks.sh`",
-             "(`python bench.py --steps 3 --warmup 2 --no-cpu-baseline`: 120k-pt SDSeg3D frame, the f32 leg and the fast_mode (bf16x3) leg run",
-             "%d frames each).  Counters are KiB.  On gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read" % frames,
-             "(MI355X_MICROARCH.md, HBM section): bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024.  The counters sit on the L2 -> fabric side:",
-             "Infinity-Cache hits are included, so this is an upper bound of DRAM traffic.", "",
-             "| kernel | launches/frame | FETCH_SIZE KiB/frame | WRITE_SIZE KiB/frame | MB/frame |", "|---|---|---|---|---|"]
-    for k, r in t.head(22).iterrows():
-        lines.append("| `%s` | %.1f | %.0f | %.0f | %.1f |" % (k, r.launches, r.fetch_kib, r.write_kib, r.bytes / 1e6))
-    lines += ["", "Sparse-conv launches, f32 mode (`k_gather_gemm<..., true>`): %.0f per frame, **%.2f GB/frame = %.1f MB/launch**."
-              % (out["launches_per_frame"], sp32.bytes.sum() / 1e9, out["traffic_bytes_per_launch"] / 1e6),
-              "Split-bf16 mode (`k_gather_gemm_bf16x3<..., true>`): %.0f per frame, **%.2f GB/frame = %.1f MB/launch**."
-              % (spbf.launches.sum(), spbf.bytes.sum() / 1e9, out["bf16x3_traffic_bytes_per_launch"] / 1e6),
-              "3-plane split-bf16 (bf16x6, `k_gather_gemm_bf16x3<..., true, 3>`): %.0f per frame, **%.2f GB/frame = %.1f MB/launch**."
-              % (spb6.launches.sum(), spb6.bytes.sum() / 1e9, out["bf16x6_traffic_bytes_per_launch"] / 1e6)]
-    if algo_bytes_per_frame:
-        lines.append("Algorithmic pair-model bytes: %.2f GB/frame." % (algo_bytes_per_frame / 1e9))
-    open(os.path.join(here, "round1_pmc.md"), "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[-3:]))
+    out, lines = {}, ["# HBM-side traffic of the sparse-conv launches (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes)", "",
+                      "`python bench.py --precision P --steps 3 --warmup 2 --no-cpu-baseline --no-extra-modes` (120k-pt SDSeg3D frame).  bytes = (2 x FETCH_SIZE +",
+                      "WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section).  Algorithmic pair-model bytes: 24.4 GB/frame = 659 MB/launch.", ""]
+    for prec in ("bf16x8", "f32"):
+        try:
+            f, w = load(d, "pmc_FETCH_SIZE_" + prec, "FETCH_SIZE"), load(d, "pmc_WRITE_SIZE_" + prec, "WRITE_SIZE")
+        except Exception as e:
+            lines.append("%s: passes missing (%r)" % (prec, e))
+            continue
+        fk, wk = f.groupby("k").Counter_Value.agg(["sum", "count"]), w.groupby("k").Counter_Value.agg(["sum", "count"])
+        t = fk.join(wk, lsuffix="_f", rsuffix="_w", how="outer").fillna(0.0)
+        t["bytes"] = (2 * t.sum_f + t.sum_w) * 1024
+        sp = t[t.index.str.contains(SPARSE)]
+        launches = float(sp.count_f.sum())
+        out[prec] = dict(traffic_bytes_per_launch=float(sp.bytes.sum() / max(launches, 1)), sparse_launches_counted=launches,
+                         correction="(2*FETCH_SIZE+WRITE_SIZE)*1024 (MI355X_MICROARCH.md HBM section)")
+        lines += ["## precision %s: %.1f MB per sparse-conv launch (%d launches counted)" % (prec, out[prec]["traffic_bytes_per_launch"] / 1e6, launches), "",
+                  "| kernel | launches | FETCH_SIZE KiB / launch | WRITE_SIZE KiB / launch | MB / launch |", "|---|---|---|---|---|"]
+        for k, r in t.sort_values("bytes", ascending=False).head(14).iterrows():
+            n = max(r.count_f, 1)
+            lines.append("| `%s` | %d | %.0f | %.0f | %.1f |" % (k, r.count_f, r.sum_f / n, r.sum_w / max(r.count_w, 1), r.bytes / n / 1e6))
+        lines.append("")
+    json.dump(out, open(os.path.join(here, "round2_pmc.json"), "w"), indent=1)
+    open(os.path.join(here, "round2_pmc.md"), "w").write("\n".join(lines) + "\n")
+    # ---- SQ counters: MFMA busy etc. per kernel
+    sq = ["# SQ counters of the sparse-conv kernels (rocprofv3 --kernel-trace --pmc ..., bench.py --steps 3 --warmup 2, MI355X)", "",
+          "SIMD cycles available = kernel time x clock (GRBM_GUI_ACTIVE / 8 XCDs / time) x 1024 SIMDs.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count",
+          "quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts cycles (MI355X_MICROARCH.md).", "",
+          "| precision | kernel | launches | total ms | clock GHz | MFMA busy / SIMD cycles | waves/SIMD resident | WAIT_ANY | WAIT_INST_ANY | ACTIVE |", "|---|---|---|---|---|---|---|---|---|---|"]
+    for prec in ("bf16x8", "f32"):
+        try:
+            sub = "pmc_SQ_" + prec
+            df = pd.read_csv(os.path.join(d, sub, "bench_counter_collection.csv"))
+            kt = pd.read_csv(os.path.join(d, sub, "bench_kernel_trace.csv"))
+        except Exception as e:
+            sq.append("| %s | passes missing (%r) |" % (prec, e))
+            continue
+        kt["dur"] = kt.End_Timestamp - kt.Start_Timestamp
+        dur = kt.set_index("Dispatch_Id").dur
+        df["k"] = df.Kernel_Name.str.replace(r"\(.*", "", regex=True).str.replace("void ", "").str.slice(0, 60)
+        piv = df.pivot_table(index=["Dispatch_Id", "k"], columns="Counter_Name", values="Counter_Value", aggfunc="sum").reset_index()
+        piv["dur"] = piv.Dispatch_Id.map(dur)
+        for k, g in piv[piv.k.str.contains(SPARSE + "|k_transvfe|k_sffm")].groupby("k"):
+            t_ns = g.dur.sum()
+            clk = g.GRBM_GUI_ACTIVE.sum() / 8.0 / t_ns  # GHz
+            simd_cycles = t_ns * clk * 1024
+            wc = 4.0 * g.SQ_WAVE_CYCLES.sum()
+            sq.append("| %s | `%s` | %d | %.2f | %.2f | %.1f %% | %.2f | %.0f %% | %.0f %% | %.0f %% |" % (
+                prec, k, len(g), t_ns / 1e6, clk, 100 * g.SQ_VALU_MFMA_BUSY_CYCLES.sum() / simd_cycles, wc / simd_cycles,
+                100 * g.SQ_WAIT_ANY.sum() / g.SQ_WAVE_CYCLES.sum(), 100 * g.SQ_WAIT_INST_ANY.sum() / g.SQ_WAVE_CYCLES.sum(),
+                100 * g.SQ_ACTIVE_INST_ANY.sum() / g.SQ_WAVE_CYCLES.sum()))
+    open(os.path.join(here, "round2_pmc_sq.md"), "w").write("\n".join(sq) + "\n")
+    print("\n".join(lines[-20:]))
+    print("\n".join(sq))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", algo_bytes_per_frame=float(sys.argv[2]) if len(sys.argv) > 2 else None)
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")

@@ -225,3 +225,95 @@ def test_seg_loss_vs_reference():
     l0 = losses.lovasz_softmax(torch.softmax(lg2, -1), z, ignore=0)
     l0.backward()
     assert float(l0) == 0.0 and float(lg2.grad.abs().max()) == 0.0
+
+
+_DDP_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipsim"))
+from lidarseg3d_amd import _lib, ops, scn_unet, synth, syncbn
+import build_sim
+_lib.use_library_for_testing(build_sim.build())
+ops.set_sim(True)
+from oracle import ref as orc
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+cfg = synth.NUSC
+shape = np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))
+
+def frame(seed, n):  # voxel coordinates + 16 input features of one frame
+    pts = synth.lidar_frame(n, seed=seed, **cfg)
+    v, c, num, nv = ops.voxelize_hard(torch.from_numpy(pts), cfg["voxel_size"], cfg["pc_range"], 5, 20000)
+    V = int(nv)
+    g = torch.Generator().manual_seed(seed)
+    return c[:V], torch.randn(V, 16, generator=g)
+
+frames = [frame(11, 150), frame(12, 90)]  # DIFFERENT voxel counts: the statistics must be weighted by row count
+torch.manual_seed(0)
+net = scn_unet.UNetSCN3D(num_input_features=16, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
+                         model_cfg=dict(SCALING_RATIO=1, RETURN_ENCODED_TENSOR=False), ds_factor=8, us_factor=8)
+net = syncbn.convert_sync_batchnorm(net).train()
+sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+
+def run(model, parts, weights):
+    """loss = sum_k weights[k] * mean(features of part k ^ 2) over ONE forward of the concatenated parts"""
+    coords = torch.cat([torch.cat([torch.full((c.shape[0], 1), b, dtype=torch.int32), c], 1) for b, (c, f) in enumerate(parts)])
+    feats = torch.cat([f for c, f in parts])
+    out = model(dict(voxel_features=feats, voxel_coords=coords, batch_size=len(parts), input_shape=shape))["conv_point_features"]
+    off, loss = 0, 0.0
+    for (c, f), w in zip(parts, weights):
+        loss = loss + w * out[off:off + c.shape[0]].pow(2).mean()
+        off += c.shape[0]
+    return loss
+
+# ---- 2 ranks, one frame each, DDP + count-weighted SyncBN
+ddp = torch.nn.parallel.DistributedDataParallel(net)
+loss = run(ddp, [frames[rank]], [1.0])
+loss.backward()
+g_ddp = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+rm_ddp = net.conv_input[1].running_mean.clone()
+# ---- the same weights, ONE process, both frames in one batch, plain BatchNorm statistics over all rows, loss = average of the frames' losses
+if rank == 0:
+    ref = scn_unet.UNetSCN3D(num_input_features=16, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
+                             model_cfg=dict(SCALING_RATIO=1, RETURN_ENCODED_TENSOR=False), ds_factor=8, us_factor=8).train()
+    ref.load_state_dict(sd0)
+    run(ref, frames, [0.5, 0.5]).backward()
+    devs, num, den = [], 0.0, 0.0
+    for k, p in ref.named_parameters():
+        assert (p.grad is None) == (k not in g_ddp), k
+        if p.grad is not None:
+            devs.append(float((g_ddp[k] - p.grad).abs().max() / p.grad.abs().max().clamp_min(1e-12)))
+            num += float((g_ddp[k] - p.grad).double().pow(2).sum())
+            den += float(p.grad.double().pow(2).sum())
+    devs = np.sort(np.asarray(devs))
+    rel_l2 = (num / den) ** 0.5
+    # f32 noise only: the whole gradient vector agrees to 1e-4 of its norm and the typical parameter to 1e-5 of its largest entry.  The
+    # maximum is NOT bounded tightly: one of the 77312 pre-activations of conv_up_t4.bn1 is 4.6e-7 (row 324, channel 44), below the 4e-6
+    # f32 difference of the two forward summation orders, so its ReLU gate flips between the runs -- ONE of the 64 channels of that
+    # layer's gradient moves by 1.4e-2 of the largest entry, the level-4 layers it back-propagates into by ~1e-3, all others <= 5e-4.
+    assert rel_l2 <= 1e-4, rel_l2
+    assert np.median(devs) <= 2e-5 and devs[int(0.9 * len(devs))] <= 2e-3 and devs[-1] <= 5e-2, (np.median(devs), devs[-8:])
+    worst = rel_l2
+    assert torch.allclose(rm_ddp, ref.conv_input[1].running_mean, rtol=0, atol=1e-6)
+    print("OK ddp == two-frame single process, relative L2 gradient deviation %.2e, median / max per parameter %.1e / %.1e" % (worst, np.median(devs), devs[-1]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_ddp_with_count_weighted_syncbn_equals_one_rank_two_frames(tmp_path):
+    """BASELINE configs[3] machinery on gloo (world_size 2, kernels on tests/hipsim): UNetSCN3D in train mode, one frame per rank with
+    DIFFERENT voxel counts, CountSyncBatchNorm1d (train.py:313-321's SyncBN, count weighted) + DistributedDataParallel gradient
+    all-reduce == the gradients of ONE process holding both frames in a batch with the averaged loss"""
+    script = tmp_path / "ddp.py"
+    script.write_text(_DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(script), ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "OK ddp == two-frame" in out.stdout
