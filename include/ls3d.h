@@ -323,7 +323,8 @@ int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad
 int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout,
                    int products, const ls3d_epilogue_t *epi_host, float *out, int out_ld, ls3d_stream_t stream);
 /* tuning knob (A/B measurements).  bit 0: each XCD walks a contiguous range of tiles instead of tile = workgroup index (results
- * identical); bits 2-4: timing ablations for profiling (skip the MFMAs / the weight DMA / the halo staging: results invalid). */
+ * identical); bits 2-4: timing ablations for profiling (skip the MFMAs / the weight DMA / the halo staging: results invalid);
+ * bit 5: ls3d_tile_conv_pack splits the weights into truncated instead of round-to-nearest planes (accuracy A/B; both exact). */
 void ls3d_set_tile_map(int flags);
 
 /* Backward of the sparse convolutions (spconv v1.x indice_conv_backward).

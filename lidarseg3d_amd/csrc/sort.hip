@@ -4,7 +4,7 @@
 // ~20 rocPRIM launches per sort + index conversions).
 //
 // Per pass three launches: block histograms (LDS atomics: counts are order-independent) -> one-workgroup scan of the
-// [digit][block] counters -> stable scatter (each block walks its chunk in order, 256 elements per round; inside a round the
+// [block][digit] counters in (digit, block) order -> stable scatter (each block walks its chunk in order, 256 elements per round; inside a round the
 // rank of an element among equal digits comes from wave ballots over the 8 digit bits plus per-wave counters in LDS).
 // Deterministic and stable: equal keys keep their input order, so the plans built on the orders are reproducible.
 #include "common.h"
@@ -22,21 +22,38 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t *__restrict__ ke
   hist[blk * 256 + tid] = s_h[tid];  // [block][digit]: coalesced here, in the scan and in the scatter
 }
 
-// exclusive scan of the counters in (digit, block) order over the [block][digit] array: one workgroup, thread d owns digit d;
-// every iteration is one coalesced 1 KB access and the loads of a loop are independent of each other
-__global__ __launch_bounds__(256) void k_rs_scan(int32_t *hist, int nb) {
+// exclusive scan of the counters in (digit, block) order over the [block][digit] array: one workgroup of 1024 threads = 4 block
+// groups x 256 digits; group g owns blocks [g*q, (g+1)*q), every access is a coalesced 1 KB row and the loads are issued 8 deep
+// (the loop is latency bound: ~1 us per dependent row with one load in flight)
+__global__ __launch_bounds__(1024) void k_rs_scan(int32_t *hist, int nb) {
+  __shared__ int s_part[4][256];
   __shared__ int s_tot[256];
-  const int d = threadIdx.x;
+  const int d = threadIdx.x & 255, g = threadIdx.x >> 8;
+  const int q = (nb + 3) / 4, b0 = g * q, b1 = b0 + q < nb ? b0 + q : nb;
   int sum = 0;
-  for (int b = 0; b < nb; ++b) sum += hist[b * 256 + d];
-  s_tot[d] = sum;
+  for (int b = b0; b < b1; b += 8) {
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = b + j < b1 ? hist[(b + j) * 256 + d] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += v[j];
+  }
+  s_part[g][d] = sum;
+  __syncthreads();
+  if (g == 0) s_tot[d] = s_part[0][d] + s_part[1][d] + s_part[2][d] + s_part[3][d];
   __syncthreads();
   int base = 0;
   for (int j = 0; j < d; ++j) base += s_tot[j];
-  for (int b = 0; b < nb; ++b) {
-    const int c = hist[b * 256 + d];
-    hist[b * 256 + d] = base;
-    base += c;
+  for (int j = 0; j < g; ++j) base += s_part[j][d];
+  for (int b = b0; b < b1; b += 8) {
+    int v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = b + j < b1 ? hist[(b + j) * 256 + d] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (b + j < b1) hist[(b + j) * 256 + d] = base;
+      base += v[j];
+    }
   }
 }
 
@@ -101,7 +118,7 @@ int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n
     uint32_t *kdst = last && keys_out ? keys_out : kbuf[p & 1];
     int32_t *vdst = last ? vals_out : vbuf[p & 1];
     hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, stream, ksrc, n, 8 * p, nb, hist);
-    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, stream, hist, nb);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, stream, hist, nb);
     hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(256), 0, stream, ksrc, vsrc, n, 8 * p, nb, (const int32_t *)hist, kdst, vdst);
     ksrc = kdst;
     vsrc = vdst;

@@ -278,7 +278,7 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
 // weights: plain [kvol][cin_src][cout] f32 -> [kvol][cin_pad/16][nt][plane 3][kk 2][col 32] x (8 bf16), the exact 3-way split
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src, int kvol, int cin_src, int cin_pad, int cout, int nt,
-                                                   uint4 *__restrict__ dst) {
+                                                   int trunc_split, uint4 *__restrict__ dst) {
   const int nchunk = cin_pad / 16;
   const long long total = (long long)kvol * nchunk * nt * 3 * 64;
   for (long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; t_ < total; t_ += (long long)gridDim.x * blockDim.x) {
@@ -298,9 +298,11 @@ __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src
       for (int e2 = 0; e2 < 2; ++e2) {
         const int c = ch * 16 + kk * 8 + pr * 2 + e2;
         const float v = (c < cin_src && oc < cout) ? src[((size_t)k * cin_src + c) * cout + oc] : 0.0f;
-        const unsigned hb = __float_as_uint(v) & 0xFFFF0000u;
+        // round-to-nearest planes (v = h + m + l exactly, as for the activations): the remainders carry no sign bias, so the
+        // products a mode leaves out (bf16x6: a_m w_l + a_l w_m, weight 2^-24) are zero-mean
+        const unsigned hb = trunc_split ? (__float_as_uint(v) & 0xFFFF0000u) : (ls3d_bf16_rne(v) << 16);
         const float r1 = v - __uint_as_float(hb);
-        const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+        const unsigned mb = trunc_split ? (__float_as_uint(r1) & 0xFFFF0000u) : (ls3d_bf16_rne(r1) << 16);
         half[e2] = pl == 0 ? (hb >> 16) : pl == 1 ? (mb >> 16) : ls3d_bf16_rne(r1 - __uint_as_float(mb));
       }
       wds[pr] = half[0] | (half[1] << 16);
@@ -311,6 +313,8 @@ __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src
   }
 }
 
+static int g_tile_trunc_split = 0;  // measurement switch (ls3d_set_tile_map bit 5): truncated weight planes as in round 2's first version
+
 extern "C" size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout) {
   return (size_t)kvol * cin_pad * (cout <= 32 ? 32 : cout <= 64 ? 64 : 128) * 6;
 }
@@ -320,7 +324,8 @@ extern "C" int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, 
   if (cout > 128) return LS3D_ERR_UNSUPPORTED;
   const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;  // column blocks of the kernel variant that will run (zero padded)
   const long long total = (long long)kvol * (cin_pad / 16) * nt * 3 * 64;
-  hipLaunchKernelGGL(k_tile_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt, (uint4 *)w_packed);
+  hipLaunchKernelGGL(k_tile_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt,
+                     g_tile_trunc_split, (uint4 *)w_packed);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
@@ -504,7 +509,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 static int g_tile_flat_map = 1, g_tile_ablate = 0;
 extern "C" void ls3d_set_tile_map(int flags) {
   g_tile_flat_map = (flags & 1) ? 0 : 1;
-  g_tile_ablate = flags & 28;  // bits 2-4: timing ablations (no MFMA / no weight DMA / no halo staging): results invalid
+  g_tile_ablate = flags & 28;
+  g_tile_trunc_split = (flags >> 5) & 1;  // bits 2-4: timing ablations (no MFMA / no weight DMA / no halo staging): results invalid
 }
 
 template <int NT, int NP>

@@ -327,10 +327,11 @@ _PREC_NAMES = {"f32": F32, "bf16x3": BF16X3, "bf16x6": BF16X6, "bf16x8": BF16X8}
 
 
 def set_precision(name):
-    """arithmetic of the sparse convolutions whose cin is a multiple of 32: "f32" (default; exact f32 MFMA), "bf16x8" (exact
-    3-way bf16 split of both operands, every plane product except tail x tail: f32-grade, half the matrix time), "bf16x6"
-    (the 6 products of weight >= 2^-16: 2.7x less matrix time) or "bf16x3" (2-way split, 3 products: ~1e-5 relative error
-    per layer, 5.3x less matrix time).  The 3-plane modes run the SubM layers on the tile-halo kernel (ls3d_tile_conv)."""
+    """arithmetic of the sparse convolutions: "f32" (default; exact f32 MFMA), the f32-grade 3-plane modes "bf16x8" / "bf16x6" (exact
+    3-way bf16 split of both operands with round-to-nearest planes; every plane product except tail x tail / the 6 products of weight
+    >= 2^-16, head x head in its own accumulator; SubM layers on the tile-halo kernel ls3d_tile_conv, strided and inverse layers exact
+    f32; measured end-to-end logit error against float64: 0.6x / 0.8x of the exact-f32 path's rms) or "bf16x3" (2-way split, 3
+    products on the gather-GEMM: ~1e-5 relative error per layer)."""
     global _PRECISION
     _PRECISION = _PREC_NAMES[name]
 
@@ -462,9 +463,10 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     # split-bf16 only where it pays and where its error budget is spent wisely: the sparse convolutions (matrix-pipe
     # bound).  Dense Linear layers (TransVFE, heads, SF-Phase) are memory-bound and stay in exact f32.
     prec = _PRECISION if (_PRECISION != F32 and cin % 32 == 0 and tbl is not None) else F32
-    if prec == BF16X8:
-        # "bf16x8" = tile-halo kernel (ls3d_tile_conv, 8 plane products, head x head in its own accumulator) for the layers that take
-        # it; every other sparse layer (strided / inverse convolutions: 3 neighbours per row, mask-sorted gathers win) runs exact f32
+    if prec == BF16X8 or (prec == BF16X6 and _TILE):
+        # the 3-plane modes = tile-halo kernel (ls3d_tile_conv, 8 / 6 plane products, head x head in its own accumulator) for the layers
+        # that take it; every other sparse layer (strided / inverse convolutions: 3 neighbours per row, mask-sorted gathers win) runs
+        # exact f32.  (With the tile path switched off, "bf16x6" is round 1's 6-product gather-GEMM.)
         prec = F32
     pipe = pipeline_geometry(cout, rows_hint, prec) if (_PIPELINE and tbl is not None and cin % 32 == 0 and kvol <= 32 and ln is None) else None
     if pipe is not None:

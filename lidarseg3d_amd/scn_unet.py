@@ -243,37 +243,37 @@ class UNetSCN3D(nn.Module):
         x = self.conv_input(x)  # ... the five level-1 launches are queued behind it ...
         x_conv1 = self.conv1(x)
         ev1 = self._stack_event(ev0)
-        # ... stage 2 = everything else, in the order the main stream needs it, with one event per level instead of one join at the
-        # end: the four strided rulebooks of the encoder chained on device counts (ONE host sync for their sizes; the level-1
-        # convolutions run meanwhile), then per level the SubM rulebook, its tile plan and the mask-sorted row order of the strided
-        # layer that enters the level; last the orders of the inverse convolutions.  The main stream waits for level k's event just
-        # before level k's first launch, so conv2 starts as soon as ITS geometry is there (round 2 trace: ~0.6 ms of idle main
-        # stream per frame with a single join).
+        # ... stage 2 = the four strided rulebooks of the encoder chained on device counts (ONE host sync for their sizes; the
+        # level-1 convolutions run meanwhile) ...
         with _GeometryStream(x.indices, ready, join=False) as gs:
             strided = [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
             spconv.prebuild_conv_rulebooks(x, strided)
-            level_ready = []
-            for key, src, stage in (("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4)):
+        # ... then level by level: SubM rulebook, tile plan and the mask-sorted row order of the strided layer that enters the level
+        # on the side stream, one event, the level's convolutions behind that event on the main stream.  The HOST alternates between
+        # the two streams: submitting a level's ~30 small geometry launches takes longer than running them, so the main stream
+        # gets level k's convolutions (a millisecond of GPU work) before the host turns to level k+1's geometry (round-2 trace with
+        # all geometry submitted first: 0.6 ms of idle main stream per frame, all of it host submission time).
+        ev0, x_enc = None, x_conv1
+        for lvl, (key, src, stage) in enumerate((("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4))):
+            with _GeometryStream(x.indices, ready, join=False) as gs:
                 rb = x.find_indice_pair(src)
                 x.indice_dict[key] = spconv.subm_rulebook(rb.out_indices, rb.out_shape, 3, x.batch_size)
-                spconv.prebuild_orders(x, stage.modules())
-                gs.hand_over((rb, x.indice_dict[key]))
-                level_ready.append(gs.finish_event())
-            spconv.prebuild_orders(x, self.modules())
-            gs.hand_over(x.indice_dict.values())
-            level_ready.append(gs.finish_event())
-        self._wait(x, level_ready[0])
-        ev0 = self._stack_event() if ev1 is not None else None
-        # ... and the neighbour search of the devoxelization (points -> 3 nearest voxel centres + weights): geometry as well, so
-        # it runs on the side stream beside the conv stack; the point head only interpolates (point_heads._devoxelize)
+                spconv.prebuild_orders(x, stage.modules() if lvl < 2 else self.modules())  # the last event covers the decoder's orders
+                gs.hand_over(x.indice_dict.values())
+                level_ready = gs.finish_event()
+            self._wait(x, level_ready)
+            if lvl == 0:
+                ev0 = self._stack_event() if ev1 is not None else None
+            x_enc = stage(x_enc)
+            if lvl == 0:
+                x_conv2 = x_enc
+            elif lvl == 1:
+                x_conv3 = x_enc
+        x_conv4 = x_enc
+        # the neighbour search of the devoxelization (points -> 3 nearest voxel centres + weights) is geometry as well: it runs on the
+        # side stream beside the decoder; the point head only interpolates (point_heads._devoxelize)
         with _GeometryStream(x.indices, ready, join=False) as gs2:
             self._start_devox_search(batch_dict, x, gs2)
-        x_conv2 = self.conv2(x_conv1)
-        self._wait(x, level_ready[1])
-        x_conv3 = self.conv3(x_conv2)
-        self._wait(x, level_ready[2])
-        x_conv4 = self.conv4(x_conv3)
-        self._wait(x, level_ready[3])
         if self.conv_out is not None:
             batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
             batch_dict["encoded_spconv_tensor_stride"] = 8

@@ -28,7 +28,7 @@ def main(d):
     out, lines = {}, ["# HBM-side traffic of the sparse-conv launches (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes)", "",
                       "`python bench.py --precision P --steps 3 --warmup 2 --no-cpu-baseline --no-extra-modes` (120k-pt SDSeg3D frame).  bytes = (2 x FETCH_SIZE +",
                       "WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section).  Algorithmic pair-model bytes: 24.4 GB/frame = 659 MB/launch.", ""]
-    for prec in ("bf16x8", "f32"):
+    for prec in ("bf16x6", "bf16x8", "f32"):
         try:
             f, w = load(d, "pmc_FETCH_SIZE_" + prec, "FETCH_SIZE"), load(d, "pmc_WRITE_SIZE_" + prec, "WRITE_SIZE")
         except Exception as e:
@@ -54,7 +54,7 @@ def main(d):
           "SIMD cycles available = kernel time x clock (GRBM_GUI_ACTIVE / 8 XCDs / time) x 1024 SIMDs.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count",
           "quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts cycles (MI355X_MICROARCH.md).", "",
           "| precision | kernel | launches | total ms | clock GHz | MFMA busy / SIMD cycles | waves/SIMD resident | WAIT_ANY | WAIT_INST_ANY | ACTIVE |", "|---|---|---|---|---|---|---|---|---|---|"]
-    for prec in ("bf16x8", "f32"):
+    for prec in ("bf16x6", "bf16x8", "f32"):
         try:
             sub = "pmc_SQ_" + prec
             df = pd.read_csv(os.path.join(d, sub, "bench_counter_collection.csv"))

@@ -13,14 +13,14 @@ timeout 900 python bench.py --steps ${STEPS:-20} --warmup 5 > $OUT/bench.log 2> 
 timeout 600 python bench.py --model mseg3d --no-cpu-baseline --no-extra-modes --steps ${STEPS:-20} --warmup 5 > $OUT/bench_mseg3d.log 2> $OUT/bench_mseg3d.err; echo "bench mseg3d rc=$?" >> $OUT/summary.txt
 if [ "${PROFILE:-1}" = "1" ]; then
   cd /tmp
-  for P in bf16x8 f32; do
+  for P in bf16x6 f32; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$P -o bench -- python $R/bench.py --precision $P --steps 10 --warmup 3 --no-cpu-baseline --no-extra-modes > $OUT/prof_$P.log 2>&1
     echo "rocprof $P rc=$?" >> $OUT/summary.txt
   done
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_mseg3d -o bench -- python $R/bench.py --model mseg3d --steps 10 --warmup 3 --no-cpu-baseline --no-extra-modes > $OUT/prof_mseg3d.log 2>&1
   if [ "${PMC:-0}" = "1" ]; then
     # counters in their own passes, kernel-trace only (FETCH_SIZE takes 3 of the 4 TCC slots)
-    for P in bf16x8 f32; do
+    for P in bf16x6 f32; do
       timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_SQ_$P -o bench -- python $R/bench.py --precision $P --steps 3 --warmup 2 --no-cpu-baseline --no-extra-modes > $OUT/pmc_SQ_$P.log 2>&1
       echo "pmc SQ $P rc=$?" >> $OUT/summary.txt
       for c in FETCH_SIZE WRITE_SIZE; do

@@ -363,6 +363,7 @@ def test_bf16x3_gemm_and_end_to_end():
         got = model.point_head.forward_ret_dict["out_logits"].cpu()
     finally:
         ops.set_precision("f32")
+        ops.set_tile(True)
     wantl = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])["out_logits"]
     scale = float(wantl.abs().max())
     err = float((got - wantl).abs().max())
@@ -579,11 +580,13 @@ def test_bf16x6_is_f32_grade_gemm_and_end_to_end():
     pw = PackedWeight(cu(b).reshape(1, 128, 128).contiguous(), 1, 128, 128, 128)
     errs = {}
     try:
+        ops.set_tile(False)  # tile path off: "bf16x6" = the 6-product gather-GEMM (with it on, gather layers run exact f32)
         for prec in ("f32", "bf16x6"):
             ops.set_precision(prec)
             out = ops.gather_gemm(cu(a), pw, tbl=ident, cout=128)
             errs[prec] = float((np.abs(out.cpu().numpy() - want) / mag).max())
-        assert errs["bf16x6"] <= 4 * errs["f32"] + 2.0 ** -22, errs
+        ops.set_tile(True)
+        assert errs["bf16x6"] <= 4 * errs["f32"] + 2.0 ** -22 and errs["bf16x6"] != errs["f32"], errs
         cfg = synth.NUSC
         model, sd = _model(models_cfg.sdseg3d())
         frames = [synth.lidar_frame(20000, seed=1, **cfg)]
@@ -592,6 +595,7 @@ def test_bf16x6_is_f32_grade_gemm_and_end_to_end():
         got = model.point_head.forward_ret_dict["out_logits"].cpu()
     finally:
         ops.set_precision("f32")
+        ops.set_tile(True)
     wantl = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])["out_logits"]
     scale = float(wantl.abs().max())
     err = float((got - wantl).abs().max())
@@ -812,8 +816,8 @@ def _scale_logits(sd, key_w, key_b, factor):
 
 def test_sdseg3d_every_arithmetic_vs_float64_and_absolute_tolerance():
     """End-to-end logits of a 30k-point frame, weights scaled so that |logit|max ~ 10 (the scale at which the contract '<= 1e-3
-    fp32' means something): every mode within 1e-3 ABSOLUTE of the CPU oracle (f32) and of the float64 evaluation; the bf16x8
-    mode is f32-grade: its error against float64 is not larger than the exact-f32 MFMA path's own."""
+    fp32' means something): every mode within 1e-3 ABSOLUTE of the CPU oracle (f32) and of the float64 evaluation; the 3-plane
+    modes (bf16x8, bf16x6) are f32-grade: their error against float64 is not larger than the exact-f32 MFMA path's own."""
     import json
     import os
     cfg = synth.NUSC
@@ -850,12 +854,41 @@ def test_sdseg3d_every_arithmetic_vs_float64_and_absolute_tolerance():
         assert rec[prec]["max_abs_vs_oracle_f32"] <= 1e-3 and rec[prec]["max_abs_vs_f64"] <= 1e-3, (prec, rec[prec])
         assert rec[prec]["argmax_vs_f64"] >= 0.9995
     assert rec["bf16x3"]["max_abs_vs_f64"] <= 5e-3
-    # bf16x8 (tile-halo kernel with head x head in its own accumulator + exact f32 for the strided / inverse layers) is f32-grade:
-    # its error against float64 is not above the exact-f32 path's (measured: 0.73x on the rms).  bf16x6 drops two products of
-    # weight 2^-24 and accumulates everything in one accumulator: ~3x the f32 path's error, still 300x inside the contract.
-    assert rec["bf16x8"]["rms_vs_f64"] <= 1.0 * rec["f32"]["rms_vs_f64"], rec
-    assert rec["bf16x8"]["max_abs_vs_f64"] <= 1.1 * rec["f32"]["max_abs_vs_f64"], rec
-    assert rec["bf16x6"]["rms_vs_f64"] <= 6.0 * rec["f32"]["rms_vs_f64"], rec
+    # the 3-plane modes (tile-halo kernel with head x head in its own accumulator + exact f32 for the strided / inverse layers) are
+    # f32-grade: their error against float64 is not above the exact-f32 path's (measured: 0.6x on the rms, 0.6-0.8x on the max, both
+    # with 8 and with 6 plane products; the two products bf16x6 leaves out have weight 2^-24 and, with round-to-nearest planes, no
+    # sign bias)
+    for prec in ("bf16x8", "bf16x6"):
+        assert rec[prec]["rms_vs_f64"] <= 1.0 * rec["f32"]["rms_vs_f64"], rec
+        assert rec[prec]["max_abs_vs_f64"] <= 1.1 * rec["f32"]["max_abs_vs_f64"], rec
+
+
+@pytest.mark.parametrize("seed,n", [(5, 30000), (7, 60000), (21, 45000)])
+def test_three_plane_modes_are_f32_grade_on_other_frames(seed, n):
+    """the f32-grade claim of bench.py's `value` arithmetic on more frames (unscaled random-init logits, errors relative to |logit|max):
+    rms error against the float64 evaluation <= the exact-f32 MFMA path's, max error <= 1.1x"""
+    import json
+    import os
+    cfg = synth.NUSC
+    model, sd = _model(models_cfg.sdseg3d())
+    frame = synth.lidar_frame(n, seed=seed, **cfg)
+    want64, _ = _f64_sdseg3d(sd, frame, cfg)
+    pts = cu(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1))
+    rec = {}
+    try:
+        for prec in ("f32", "bf16x8", "bf16x6"):
+            ops.set_precision(prec)
+            with torch.no_grad():
+                model(dict(points=pts, batch_size=1), return_loss=False)
+            d = (model.point_head.forward_ret_dict["out_logits"].double().cpu() - want64) / float(want64.abs().max())
+            rec[prec] = dict(rms=float(d.pow(2).mean().sqrt()), max=float(d.abs().max()), signed_mean=float(d.mean()))
+    finally:
+        ops.set_precision("f32")
+    print(json.dumps({"seed": seed, "points": n, **rec}))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rec, open("gpurun_out/accuracy_e2e_seed%d.json" % seed, "w"), indent=1)
+    for prec in ("bf16x8", "bf16x6"):
+        assert rec[prec]["rms"] <= rec["f32"]["rms"] and rec[prec]["max"] <= 1.1 * rec["f32"]["max"], rec
 
 
 def test_mseg3d_absolute_tolerance_at_logit_scale_10():

@@ -440,12 +440,14 @@ def test_gather_gemm_bf16x6_is_f32_grade(m, k, n, nt, monkeypatch):
     mag = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)  # the scale rounding errors live on
     errs = {}
     try:
+        ops.set_tile(False)  # with the tile path off "bf16x6" is the 6-product gather-GEMM (with it on, these layers run exact f32)
         for prec in ("f32", "bf16x6"):
             ops.set_precision(prec)
             out = ops.gather_gemm(torch.from_numpy(a), pw, tbl=ident, cout=n)
             errs[prec] = float((np.abs(out.numpy() - want) / mag).max())
     finally:
         ops.set_precision("f32")
+        ops.set_tile(True)
     assert errs["bf16x6"] <= 4 * 2.0 ** -24 * np.sqrt(k) + 3 * 2.0 ** -24, errs  # f32-grade: a few ulp of the |a||b| scale
     assert errs["bf16x6"] <= 8 * errs["f32"] + 2.0 ** -22, errs
 
