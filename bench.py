@@ -87,14 +87,17 @@ class ConvCensus:
             torch.cuda.synchronize()
         finally:
             ops.gather_gemm, ops.tile_conv = g, t
-        pairs, algo, flops = {}, 0.0, 0.0
+        pairs, uniq, algo, flops, bmin = {}, {}, 0.0, 0.0, 0.0
         for tbl, cin, cout, _ in self.meta:
             key = (tbl.data_ptr(), tbl.shape[0])
             if key not in pairs:
                 pairs[key] = int((tbl >= 0).sum().item())
+                uniq[key] = int(torch.unique(tbl[tbl >= 0]).numel())
             algo += pairs[key] * (cin + cout) * 4.0
             flops += 2.0 * pairs[key] * cin * cout
-        return dict(launches=len(self.meta), tile_launches=sum(1 for m in self.meta if m[3] == "tile"), algo_bytes=algo, flops=flops)
+            # B_min: what a launch cannot avoid moving: every referenced input row once, every output row once, the weights once
+            bmin += (uniq[key] * cin + tbl.shape[0] * cout + tbl.shape[1] * cin * cout) * 4.0
+        return dict(launches=len(self.meta), tile_launches=sum(1 for m in self.meta if m[3] == "tile"), algo_bytes=algo, flops=flops, b_min_bytes=bmin)
 
 
 def timed_steps(step, steps, warmup, dist=None, dev=None):
@@ -378,6 +381,12 @@ def main():
                 "avg_launch_us": 1e3 * mean_ms / max(c["launches"], 1), "algo_bytes_per_frame": c["algo_bytes"],
                 "algo_bytes_per_launch": c["algo_bytes"] / max(c["launches"], 1), "tflops_useful": main_leg.get("tflops"),
                 "sparse_conv_ms_per_frame": stack,
+                # the traffic no kernel can avoid (each referenced input row, each output row and the weights once per launch) and the
+                # HBM time it stands for: the stack is matrix-pipe work far above it (the pair model above prices the gather traffic
+                # of SURVEY.md 8d, which the tile-halo kernel no longer moves)
+                "b_min": {"bytes_per_frame": c["b_min_bytes"], "ms_at_hbm_peak": 1e3 * c["b_min_bytes"] / (HBM_PEAK_GBS * 1e9),
+                          "achieved_GBps": c["b_min_bytes"] / (mean_ms * 1e-3) / 1e9 if mean_ms else 0.0,
+                          "frac": c["b_min_bytes"] / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if mean_ms else 0.0},
             }
             pmc = os.path.join(ROOT, "profiles", "round2_pmc.json")
             if args.model == "sdseg3d" and args.points == 120000 and os.path.exists(pmc):

@@ -299,7 +299,11 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
  *   ls3d_tile_conv : out[r, 0..cout) = epilogue(sum_k W[k]^T in[tbl[r,k]]) for the rows of the plan.  products = 8: every
  *                    plane product except tail x tail (2^-32 relative) — f32-grade: the result differs from exact f32
  *                    arithmetic by less than f32 summation-order noise; products = 6: the BF16X6 arithmetic.
- *                    cin % 16 == 0, in_ld % 4 == 0, cout <= 128.  Summation order per output row is fixed by the plan. */
+ *                    cin % 16 == 0, in_ld % 4 == 0, cout <= 128.  Summation order per output row is fixed by the plan.
+ *                    workspace (optional, ls3d_tile_conv_workspace_bytes(n_rows, cout) bytes, 16-byte aligned): lets launches of
+ *                    cin >= 64 and up to 512 tiles (fewer tiles than the 2 x 256 workgroup slots of the chip) run TWO work units per tile, each over half of the input channels; the unit
+ *                    that finishes second adds the other's partial sums (a + b == b + a: results do not depend on which) and
+ *                    runs the epilogue.  The plan carries the per-tile arrival counters: one launch at a time per plan. */
 int ls3d_tile_keys(const int32_t *coords /*[n,4] b,z,y,x*/, int n, const int32_t *n_dev, const int32_t shape_zyx_host[3], int batch,
                    uint32_t *keys, ls3d_stream_t stream);
 size_t ls3d_tile_plan_bytes(int n_rows, int kvol);
@@ -320,11 +324,15 @@ int ls3d_radix_sort(const uint32_t *keys, const int32_t *vals, int n, int bits, 
                     size_t workspace_bytes, ls3d_stream_t stream);
 size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout);
 int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream);
+size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout);
 int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout,
-                   int products, const ls3d_epilogue_t *epi_host, float *out, int out_ld, ls3d_stream_t stream);
+                   int products, const ls3d_epilogue_t *epi_host, float *out, int out_ld, void *workspace, size_t workspace_bytes,
+                   ls3d_stream_t stream);
 /* tuning knob (A/B measurements).  bit 0: each XCD walks a contiguous range of tiles instead of tile = workgroup index (results
  * identical); bits 2-4: timing ablations for profiling (skip the MFMAs / the weight DMA / the halo staging: results invalid);
- * bit 5: ls3d_tile_conv_pack splits the weights into truncated instead of round-to-nearest planes (accuracy A/B; both exact). */
+ * bit 5: ls3d_tile_conv_pack splits the weights into truncated instead of round-to-nearest planes (accuracy A/B; both exact);
+ * bits 6-7: split over the input channels 0 = default rule, 1 = never, 2 = whenever a workspace is given; bits 8+: tile limit of
+ * the default rule. */
 void ls3d_set_tile_map(int flags);
 
 /* Backward of the sparse convolutions (spconv v1.x indice_conv_backward).

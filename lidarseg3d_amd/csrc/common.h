@@ -44,6 +44,8 @@ __device__ __forceinline__ void ls3d_glds16x3(const void *gbase, unsigned voff0,
   memcpy((char *)lds_wave_base + 1024 + hipsim::lane() * 16, (const char *)gbase + voff1, 16);
   memcpy((char *)lds_wave_base + 2048 + hipsim::lane() * 16, (const char *)gbase + voff2, 16);
 }
+__device__ __forceinline__ float ls3d_load_agent(const float *p) { return *p; }
+__device__ __forceinline__ void ls3d_store_agent(float *p, float v) { *p = v; }
 #define LS3D_WAIT_VMCNT(n) ((void)0)
 #define LS3D_SCHED_FENCE() ((void)0)
 #define LS3D_RAW_BARRIER() __syncthreads()
@@ -65,6 +67,11 @@ __device__ __forceinline__ void ls3d_glds16x3(const void *gbase, unsigned voff0,
       "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %4\n\ts_mov_b32 m0, %0"
       : "=&s"(keep) : "v"(voff0), "v"(voff1), "v"(voff2), "s"(gbase), "s"(dst) : "memory", "scc");
 }
+// agent-scope relaxed atomics on plain floats: they go through to the point where every XCD's L2 agrees (the L2s of the eight XCDs
+// are not coherent with each other inside a kernel for ordinary cached accesses), without the L2 write-back / invalidate that a
+// release / acquire fence pair would cost every other workgroup of the XCD
+__device__ __forceinline__ float ls3d_load_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ls3d_store_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #define LS3D_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define LS3D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  /* nothing is scheduled across: e.g. keeps a batch of ds_reads together */
 #define LS3D_RAW_BARRIER()                          \

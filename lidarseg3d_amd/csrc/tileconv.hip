@@ -351,7 +351,8 @@ constexpr int TC_THREADS = 256;
 // NP = plane products per f32 product (6 or 8).
 template <int NT, int NP>
 __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in, int in_ld, TilePlan p, const uint4 *__restrict__ wpk,
-                                                             int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int flat_map, int ablate) {
+                                                             int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int flat_map, int ablate,
+                                                             int ksplit, float *partial) {
   constexpr int PU = NT * 192;             // 16-byte units of one (offset, chunk) weight piece
   constexpr int PB = NT * 3;               // ... in 1 KB LDS-DMA blocks
   constexpr int G = 4 / NT;                // offsets per step
@@ -373,13 +374,17 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   const unsigned voff0 = (unsigned)lane * 16u, voff1 = voff0 + 1024u, voff2 = voff0 + 2048u;
   const uint16_t *loc_w = s_loc + wave * 32 + col;
   uint4 *const dma_lds0 = Bs + dma_g * PU + dma_j * 64, *const dma_lds1 = dma_lds0 + TC_WBUF_UNITS;
-  const int t8 = (p.ntiles + 7) / 8;
+  // ksplit == 2: a tile is two work units, each over half of the 16-channel chunks; the unit that finishes second adds the other's
+  // partial sums (through `partial`, [tile][part][NT * 16][256] floats) and runs the epilogue.  Half-size units fill the tail of a
+  // launch (677 tiles on 512 workgroup slots = one full round + a third of one) and give the small levels two workgroups per CU.
+  const int units = p.ntiles * ksplit, t8 = (units + 7) / 8;
   for (int b = blockIdx.x; b < t8 * 8; b += gridDim.x) {
-    // tile = workgroup index: neighbouring tiles (unequal work: dense near the sensor) are spread over the XCDs.  The
+    // unit = workgroup index: neighbouring tiles (unequal work: dense near the sensor) are spread over the XCDs.  The
     // alternative (flat_map == 0: each XCD walks a contiguous range, halos of neighbours meet in one L2) measured 0-40 % slower:
     // the halo is staged once per tile anyway, balance matters more (profiles/round2_experiments.md)
-    const int tile = flat_map ? b : (b & 7) * t8 + (b >> 3);
-    if (tile >= p.ntiles) continue;
+    const int unit = flat_map ? b : (b & 7) * t8 + (b >> 3);
+    if (unit >= units) continue;
+    const int tile = ksplit == 2 ? unit >> 1 : unit, part = ksplit == 2 ? unit & 1 : 0;
     const int *meta = p.tmeta + (size_t)tile * TC_META;
     const int H = meta[0];
     const unsigned kmask = (unsigned)meta[1];
@@ -400,10 +405,25 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     for (int seg = 0; seg < (kmask ? nseg : 0); ++seg) {
       const int seg_lo = seg * TC_HCAP;
       const int nh = (H - seg_lo) < TC_HCAP ? (H - seg_lo) : TC_HCAP;
-      __syncthreads();  // the previous pass is done with s_hid and the halo buffer
+      __syncthreads();  // the previous pass (or the previous tile's epilogue) is done with s_hid and the halo buffer
       for (int i = tid; i < nh; i += TC_THREADS) s_hid[i] = p.thalo[(size_t)tile * p.hs + seg_lo + i];
-      for (int c = 0; c < nchunk; ++c) {
-        __syncthreads();  // s_hid visible / the previous chunk's MFMAs have read their fragments
+      __syncthreads();
+      // The halo chunk goes global f32 -> registers -> three bf16 planes in LDS, software-pipelined over the chunks: the loads of
+      // chunk c + 1 are issued when chunk c's MFMA steps start and land while they run (the first step's wait for its weight DMA
+      // also waits for them: they have had that step's MFMAs to arrive), so only the split + LDS writes of a chunk stay exposed.
+      // Branch-free loads (rows past the end re-read the last one): under a per-load condition hipcc waits for each load before it
+      // issues the next, i.e. HPT memory latencies instead of one.
+      float4 hv[HPT];
+#define TC_LOAD_HALO(c_)                                                                  \
+  _Pragma("unroll") for (int j = 0; j < HPT; ++j) {                                       \
+    const int i = tid + j * TC_THREADS, hrow = i >> 2, q = i & 3;                         \
+    const int hr = hrow < nh ? hrow : nh - 1;                                             \
+    hv[j] = *(const float4 *)(in + (size_t)s_hid[hr] * in_ld + (c_) * 16 + q * 4);        \
+  }
+      const int c_lo = nchunk * part / ksplit, c_hi = nchunk * (part + 1) / ksplit;
+      if (!(ablate & 16)) { TC_LOAD_HALO(c_lo) }
+      for (int c = c_lo; c < c_hi; ++c) {
+        if (c > c_lo) __syncthreads();  // the previous chunk's MFMAs have read their fragments
         unsigned rem = kmask;
         int ks[G], kn[G];
 #define TC_NEXT_GROUP(dst_)                                                       \
@@ -419,17 +439,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     ls3d_glds16x3(wchunk + (unsigned)kg_[dma_g] * kstride, voff0, voff1, voff2, (buf_) ? dma_lds1 : dma_lds0);
         TC_NEXT_GROUP(ks)
         TC_DMA_GROUP(ks, 0)
-        // ---- stage the halo chunk: global f32 -> three bf16 planes in LDS
         if (!(ablate & 16)) {
-          float4 hv[HPT];
-#pragma unroll
-          for (int j = 0; j < HPT; ++j) {
-            const int i = tid + j * TC_THREADS, hrow = i >> 2, q = i & 3;
-            // branch-free (rows past the end re-read the last one): under a per-load condition hipcc waits for each load
-            // before issuing the next, i.e. HPT memory latencies per chunk instead of one
-            const int hr = hrow < nh ? hrow : nh - 1;
-            hv[j] = *(const float4 *)(in + (size_t)s_hid[hr] * in_ld + c * 16 + q * 4);
-          }
 #pragma unroll
           for (int j = 0; j < HPT; ++j) {
             const int i = tid + j * TC_THREADS, hrow = i >> 2, q = i & 3;
@@ -446,6 +456,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         }
         LS3D_WAIT_VMCNT(0);
         __syncthreads();
+        if (c + 1 < c_hi && !(ablate & 16)) { TC_LOAD_HALO(c + 1) }
         int buf = 0;
         int lc[G], ln[G];  // raw local indices of this lane's row: current step / next step
 #pragma unroll
@@ -463,27 +474,33 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
               const int lz = ((unsigned)li < (unsigned)TC_HCAP) ? li : TC_HCAP;  // absent / other pass -> the zero row
               const uint4 *hp = (const uint4 *)smem + lz * 2 + kk;
               const uint4 *bs = Bs + buf * TC_WBUF_UNITS + g * PU + lane;
-              uint4 bfr[3][NT];  // [plane][column block]
+              // weight fragments plane by plane (the MFMAs are grouped by the weight plane they need): plane 2 is read after plane
+              // 0's MFMAs are issued and takes over its registers: 32 instead of 48 VGPRs of fragments
+              uint4 b0[NT], b1[NT];
 #pragma unroll
-              for (int pl = 0; pl < 3; ++pl)
+              for (int n = 0; n < NT; ++n) b0[n] = bs[(n * 3 + 0) * 64];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bfr[pl][n] = bs[(n * 3 + pl) * 64];
+              for (int n = 0; n < NT; ++n) b1[n] = bs[(n * 3 + 1) * 64];
               const bf16x8 ah = __builtin_bit_cast(bf16x8, hp[0]);
               const bf16x8 am = __builtin_bit_cast(bf16x8, hp[TC_PLANE_BYTES / 16]);
               const bf16x8 al = __builtin_bit_cast(bf16x8, hp[2 * (TC_PLANE_BYTES / 16)]);
-              // product-major: consecutive MFMAs go to different accumulators; products grouped by the weight plane they need
-#define TC_MFMA(dst_, a_, pl_)                                                                          \
+              // product-major: consecutive MFMAs go to different accumulators
+#define TC_MFMA(dst_, a_, b_)                                                                           \
   _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                        \
-      dst_[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, __builtin_bit_cast(bf16x8, bfr[pl_][n]), dst_[n], 0, 0, 0);
+      dst_[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, __builtin_bit_cast(bf16x8, b_[n]), dst_[n], 0, 0, 0);
               // head x head (99.6 % of the value) goes to `acc`, the seven (five) small products to `acs`: the bf16 MFMA's
               // accumulate is not round-to-nearest (measured: ~1e-3 ulp of the accumulator lost towards zero per MFMA), and
               // eight MFMAs per step into one accumulator made the end-to-end error 3.3x the exact-f32 path's.  With the small
               // terms kept apart the large accumulator sees one MFMA per step and the bias of the small one is 2^-8 of its own.
-              TC_MFMA(acs, al, 0) TC_MFMA(acs, am, 0) TC_MFMA(acc, ah, 0)
-              if constexpr (NP >= 8) { TC_MFMA(acs, al, 1) }
-              TC_MFMA(acs, am, 1) TC_MFMA(acs, ah, 1)
-              if constexpr (NP >= 8) { TC_MFMA(acs, am, 2) }
-              TC_MFMA(acs, ah, 2)
+              TC_MFMA(acs, al, b0) TC_MFMA(acs, am, b0) TC_MFMA(acc, ah, b0)
+              LS3D_SCHED_FENCE();
+              uint4 b2[NT];
+#pragma unroll
+              for (int n = 0; n < NT; ++n) b2[n] = bs[(n * 3 + 2) * 64];
+              if constexpr (NP >= 8) { TC_MFMA(acs, al, b1) }
+              TC_MFMA(acs, am, b1) TC_MFMA(acs, ah, b1)
+              if constexpr (NP >= 8) { TC_MFMA(acs, am, b2) }
+              TC_MFMA(acs, ah, b2)
 #undef TC_MFMA
             }
           }
@@ -496,39 +513,67 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         }
 #undef TC_NEXT_GROUP
 #undef TC_DMA_GROUP
+#undef TC_LOAD_HALO
       }
     }
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] += acs[n][r];
+    if (ksplit == 2) {
+      float *mine = partial + ((size_t)tile * 2 + part) * (NT * 16 * TC_THREADS) + tid;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ls3d_store_agent(mine + (n * 16 + r) * TC_THREADS, acc[n][r]);
+      LS3D_WAIT_VMCNT(0);  // the stores are at the coherence point ...
+      __syncthreads();     // ... for every thread of the unit, before the counter says so
+      if (tid == 0) s_hid[0] = atomicAdd(p.tmeta + (size_t)tile * TC_META + 7, 1);
+      __syncthreads();
+      if (s_hid[0] == 0) continue;  // first of the two: the other unit finishes the tile
+      const float *other = partial + ((size_t)tile * 2 + (part ^ 1)) * (NT * 16 * TC_THREADS) + tid;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] += ls3d_load_agent(other + (n * 16 + r) * TC_THREADS);  // a + b == b + a: order-independent
+      if (tid == 0) p.tmeta[(size_t)tile * TC_META + 7] = 0;  // ready for the next launch on this plan
+    }
     gg_epilogue<NT, 1, TC_TR, 64, TC_THREADS>(acc, (float *)smem, s_rows, s_stat, wave, 0, kk, col, 0, cout, e, out, out_ld);
   }
 }
 
-static int g_tile_flat_map = 1, g_tile_ablate = 0;
+static int g_tile_flat_map = 1, g_tile_ablate = 0, g_tile_ksplit = 0, g_tile_ksplit_max_tiles = 512;
 extern "C" void ls3d_set_tile_map(int flags) {
   g_tile_flat_map = (flags & 1) ? 0 : 1;
   g_tile_ablate = flags & 28;
-  g_tile_trunc_split = (flags >> 5) & 1;  // bits 2-4: timing ablations (no MFMA / no weight DMA / no halo staging): results invalid
+  g_tile_trunc_split = (flags >> 5) & 1;
+  g_tile_ksplit = (flags >> 6) & 3;                            // bits 6-7: channel split 0 = auto, 1 = off, 2 = always
+  if (flags >> 8) g_tile_ksplit_max_tiles = flags >> 8;        // bits 8+: auto applies up to this many tiles  // bits 2-4: timing ablations (no MFMA / no weight DMA / no halo staging): results invalid
 }
 
 template <int NT, int NP>
 static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TilePlan &p, const uint4 *wpk, int cin, int cout, const EpiDev &e, float *out,
-                     int out_ld) {
+                     int out_ld, int ksplit, float *partial) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
-  const int nwg = (p.ntiles + 7) / 8 * 8;
+  const int nwg = (p.ntiles * ksplit + 7) / 8 * 8;
   hipLaunchKernelGGL((k_tile_conv<NT, NP>), dim3((unsigned)nwg), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout, e, out, out_ld,
-                     g_tile_flat_map, g_tile_ablate);
+                     g_tile_flat_map, g_tile_ablate, ksplit, partial);
   return LS3D_OK;
 }
 
+// workspace of ls3d_tile_conv for the split over the input channels: two partial accumulator sets per tile
+extern "C" size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout) {
+  if (n_rows <= 0 || cout < 1 || cout > 128) return 0;
+  const size_t nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;
+  return (size_t)((n_rows + TC_TR - 1) / TC_TR) * 2 * nt * 16 * TC_THREADS * sizeof(float);
+}
+
 extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout, int products,
-                              const ls3d_epilogue_t *epi, float *out, int out_ld, ls3d_stream_t stream_) {
+                              const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !plan || !w_packed || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
@@ -544,9 +589,16 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
     if ((e.ln_gamma != nullptr) != (e.ln_beta != nullptr) || (e.ln_gamma && e.pair)) return LS3D_ERR_ARG;
   }
   const TilePlan p = tc_plan(const_cast<void *>(plan), n_rows, kvol);
+  // split over the input channels (two units per tile) when the caller provides the workspace, the layer has >= 4 chunks and the
+  // launch is small enough for the granularity to matter (g_tile_ksplit: 0 = this rule, 1 = never, 2 = whenever possible)
+  int ksplit = 1;
+  if (workspace && workspace_bytes >= ls3d_tile_conv_workspace_bytes(n_rows, cout) && cin >= 64 && g_tile_ksplit != 1 &&
+      (g_tile_ksplit == 2 || p.ntiles <= g_tile_ksplit_max_tiles))
+    ksplit = 2;
+  float *partial = (float *)workspace;
   int rc;
-#define TC_GO(NTW_) (products == 8 ? tc_launch<NTW_, 8>(stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld) \
-                                   : tc_launch<NTW_, 6>(stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld))
+#define TC_GO(NTW_) (products == 8 ? tc_launch<NTW_, 8>(stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ksplit, partial) \
+                                   : tc_launch<NTW_, 6>(stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ksplit, partial))
   if (cout <= 32) rc = TC_GO(1);        // weights packed with 1 column block
   else if (cout <= 64) rc = TC_GO(2);   // ... with 2
   else rc = TC_GO(4);                   // ... with 4

@@ -516,7 +516,22 @@ def set_tile(on, kinds=None, min_cc=None):
 
 def set_tile_map(flags):
     """A/B knob of ls3d_tile_conv (include/ls3d.h: ls3d_set_tile_map)"""
+    global _TILE_FLAGS_SENT
+    _TILE_FLAGS_SENT = True
     _L().ls3d_set_tile_map(int(flags))
+
+
+_TILE_FLAGS_SENT = False
+
+
+def _tile_flags_from_env():
+    """LS3D_TILE_FLAGS=<int>: ls3d_set_tile_map flags for A/B runs of unmodified scripts (applied at the first tile launch)"""
+    global _TILE_FLAGS_SENT
+    if not _TILE_FLAGS_SENT:
+        _TILE_FLAGS_SENT = True
+        f = int(_os.environ.get("LS3D_TILE_FLAGS", "0"))
+        if f:
+            _L().ls3d_set_tile_map(f)
 
 
 def tile_products():
@@ -591,9 +606,26 @@ def tile_conv(x, w, plan, cout=None, products=None, scale=None, shift=None, res_
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0, _vp(ln[0]) if ln is not None else ctypes.c_void_p(0),
                    _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
+    _tile_flags_from_env()
+    ws = _tile_ws(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout), x) if (_TILE_KSPLIT and cin >= 64) else None
     check(_L().ls3d_tile_conv(_ptr(x), in_ld, _ptr(plan.buf), plan.n_rows, kvol, _ptr(w.for_tile()), cin, cout, products, ctypes.byref(epi),
-                              _vp_any(out), out_ld, _stream(x)), "ls3d_tile_conv")
+                              _vp_any(out), out_ld, _vp(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), _stream(x)), "ls3d_tile_conv")
     return out
+
+
+_TILE_KSPLIT = _os.environ.get("LS3D_TILE_KSPLIT", "1") != "0"  # hand ls3d_tile_conv the workspace for its split over the input channels
+_TILE_WS = {}
+
+
+def _tile_ws(nbytes, like):
+    """grow-only scratch per (device, stream): the launches of a stream run one after the other, so they share it"""
+    if not like.is_cuda:
+        return _ws(nbytes, like)
+    key = (like.device, torch.cuda.current_stream(like.device).cuda_stream)
+    buf = _TILE_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _TILE_WS[key] = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=like.device)
+    return buf
 
 
 def spconv_wgrad(x, grad_out, tbl, order, cin, cout):
