@@ -10,9 +10,12 @@
 // two rows feed one v_mfma_f32_32x32x2_f32: lane (i, half) supplies in[tbl[o_half][k]][ci0 + i] as the A operand and
 // grad_out[o_half][co0 + i] as the B operand (32 consecutive floats of a row per half wave: coalesced 128-byte reads, no
 // LDS staging).  A wave owns a 32 x (32 COB) block of grad_W[k] in COB accumulators and walks its share of the rows in
-// mask-sorted order, skipping row pairs without a neighbour at k; the 4 waves of a workgroup take interleaved row pairs
-// and are summed through LDS in a fixed order; row chunks are summed by a second kernel: deterministic, no atomics.
-// Exact f32 (fmaf chain per element); bound by the f32 matrix pipe like the forward (same flops).
+// mask-sorted order, skipping row pairs without a neighbour at k.  The 4 waves of a workgroup are CIW x RG: CIW = min(4, cin/32)
+// waves side by side along cin over the SAME row pairs (they share the grad_out rows through the L1: grad_out is read kvol times
+// per layer instead of kvol x cin/32 times - round 2 measured the layout with one 32-channel block per workgroup at 1.9 ms per
+// 128 -> 128 layer on 241k rows, bound by those re-reads) and RG = 4 / CIW groups of interleaved row pairs, summed through LDS
+// in a fixed order; row chunks are summed by a second kernel: deterministic, no atomics.
+// Exact f32 (fmaf chain per element).
 #include "common.h"
 
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
@@ -37,13 +40,16 @@ template <int COB>
 __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ in, int in_ld, const float *__restrict__ gout, int go_ld,
                                                       const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_t, int kvol, int cin,
                                                       int cout, int n_rows, const int32_t *n_rows_dev, int nchunks, float *__restrict__ partial) {
-  __shared__ float red[32 * 32 * COB];     // one wave's partial tile at a time
+  __shared__ float red[32 * 32 * COB * 2];  // the tiles handed over in one round: one per cin block of the workgroup with RG > 1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, half = lane >> 5;
   const int N = ls3d_count(n_rows, n_rows_dev);
   const int ci_blocks = (cin + 31) / 32;
+  const int CIW = ci_blocks >= 4 ? 4 : ci_blocks >= 2 ? 2 : 1, RG = 4 / CIW;
+  const int ci_groups = (ci_blocks + CIW - 1) / CIW;
+  const int cw = wave % CIW, rg = wave / CIW;
   const int k = blockIdx.y;
-  const int chunk = blockIdx.x / ci_blocks, cb = blockIdx.x % ci_blocks;
+  const int chunk = blockIdx.x / ci_groups, cb = (blockIdx.x % ci_groups) * CIW + cw;
   const int ci = cb * 32 + i;
   const int npairs = (N + 1) / 2;
   const int per_chunk = (npairs + nchunks - 1) / nchunks;
@@ -75,11 +81,12 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ 
     _Pragma("unroll") for (int n = 0; n < COB; ++n)                                           \
         b_c[u][n] = (on_ && n * 32 + i < cout) ? gout[(size_t)o_n[u] * go_ld + n * 32 + i] : 0.0f; \
   }
-  int p = p0 + wave * WG_UNROLL;
+  const int pstep = RG * WG_UNROLL;
+  int p = p0 + rg * WG_UNROLL;
   WG_LOAD_IDX(p)
   WG_LOAD_OPS()
-  if (p + 4 * WG_UNROLL < p1) { WG_LOAD_IDX(p + 4 * WG_UNROLL) }
-  for (; p < p1; p += 4 * WG_UNROLL) {
+  if (p + pstep < p1) { WG_LOAD_IDX(p + pstep) }
+  for (; p < p1; p += pstep) {
     float a[WG_UNROLL], bb[WG_UNROLL][COB];
     const unsigned any = any_c;
 #pragma unroll
@@ -88,9 +95,9 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ 
 #pragma unroll
       for (int n = 0; n < COB; ++n) bb[u][n] = b_c[u][n];
     }
-    if (p + 4 * WG_UNROLL < p1) {
-      WG_LOAD_OPS()                                                       // operands of the next group (indices already here)
-      if (p + 8 * WG_UNROLL < p1) { WG_LOAD_IDX(p + 8 * WG_UNROLL) }      // indices of the group after it
+    if (p + pstep < p1) {
+      WG_LOAD_OPS()                                                // operands of the next group (indices already here)
+      if (p + 2 * pstep < p1) { WG_LOAD_IDX(p + 2 * pstep) }       // indices of the group after it
     }
 #pragma unroll
     for (int u = 0; u < WG_UNROLL; ++u) {
@@ -102,25 +109,27 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ 
   }
 #undef WG_LOAD_IDX
 #undef WG_LOAD_OPS
-  // ---- waves 1..3 hand their tiles to wave 0 one after the other (fixed order, 16 KB of LDS instead of 48: the LDS footprint,
-  //      not the registers, was limiting the resident workgroups), which then writes the chunk's partial [32][cout] block
-  for (int w2 = 1; w2 < 4; ++w2) {
-    if (wave == w2) {
+  // ---- the row groups 1..RG-1 of a cin block hand their tiles to row group 0 one after the other (fixed order; at most two
+  //      tiles in flight: the LDS footprint, not the registers, limits the resident workgroups), which then writes the chunk's
+  //      partial [32][cout] block
+  for (int r2 = 1; r2 < RG; ++r2) {
+    float *slot = red + (CIW == 2 ? cw * (32 * 32 * COB) : 0);
+    if (rg == r2) {
 #pragma unroll
       for (int n = 0; n < COB; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(n * 16 + r) * 64 + lane] = acc[n][r];
+        for (int r = 0; r < 16; ++r) slot[(n * 16 + r) * 64 + lane] = acc[n][r];
     }
     __syncthreads();
-    if (wave == 0) {
+    if (rg == 0) {
 #pragma unroll
       for (int n = 0; n < COB; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] += red[(n * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[n][r] += slot[(n * 16 + r) * 64 + lane];
     }
     __syncthreads();
   }
-  if (wave == 0) {
+  if (rg == 0 && cb < ci_blocks) {
     float *dst = partial + (((size_t)chunk * kvol + k) * cin) * cout;
 #pragma unroll
     for (int n = 0; n < COB; ++n)
@@ -140,14 +149,19 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *partial, int 
   }
 }
 
+static inline int wg_ci_groups(int cin) {
+  const int ci_blocks = (cin + 31) / 32, ciw = ci_blocks >= 4 ? 4 : ci_blocks >= 2 ? 2 : 1;
+  return (ci_blocks + ciw - 1) / ciw;
+}
+
 static inline int wg_chunks(int n_rows, int kvol, int cin) {
   // enough workgroups for 256 CUs x ~8, at least ~256 row pairs per chunk
-  const int ci_blocks = (cin + 31) / 32;
-  long long want = (2048 + (long long)kvol * ci_blocks - 1) / ((long long)kvol * ci_blocks);
+  const long long per = (long long)kvol * wg_ci_groups(cin);
+  long long want = (2048 + per - 1) / per;
   long long cap = ((long long)n_rows / 2 + 255) / 256;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
-  if (want > 64) want = 64;
+  if (want > 96) want = 96;
   return (int)want;
 }
 
@@ -170,12 +184,11 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
     return LS3D_OK;
   }
   const int nchunks = wg_chunks(n_rows, kvol, cin);
-  const int ci_blocks = (cin + 31) / 32;
   float *partial = (float *)workspace;
   int32_t *tbl_t = (int32_t *)((char *)workspace + wg_align((size_t)nchunks * kvol * cin * cout * sizeof(float)));
   int32_t *o_t = tbl_t + (size_t)kvol * n_rows;
   hipLaunchKernelGGL(k_tbl_transpose, ls3d_grid((long long)n_rows * kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, tbl_t, o_t);
-  const dim3 grid((unsigned)(nchunks * ci_blocks), (unsigned)kvol);
+  const dim3 grid((unsigned)(nchunks * wg_ci_groups(cin)), (unsigned)kvol);
   const int cob = (cout + 31) / 32;
 #define LS3D_WG(COB_) hipLaunchKernelGGL((k_spconv_wgrad<COB_>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, (const int32_t *)tbl_t, \
                                           (const int32_t *)o_t, kvol, cin, cout, n_rows, n_rows_dev, nchunks, partial)

@@ -464,7 +464,9 @@ class PointSegMSeg3DHead(PackedModule):
         vo = vx_off.tolist()
         for b in range(B):  # SFAM (context_module.py:25-53): softmax over the voxels of a frame, per class
             sl = slice(vo[b], vo[b + 1])
-            lemb.append(torch.softmax(voxel_logits[sl], dim=0).t() @ vf[sl])
+            # on the transposed [classes, voxels] copy: a softmax over the last dimension (over dim 0 of [V, C] torch picks its strided
+            # "spatial" kernel: 4.4 ms per frame on 120k voxels, 2 % of the whole training step)
+            lemb.append(torch.softmax(voxel_logits[sl].t().contiguous(), dim=1) @ vf[sl])
         lemb = torch.stack(lemb, 0).permute(0, 2, 1).unsqueeze(3)
         sem = self.sffm._forward_train(fused, batch_dict["camera_semantic_embeddings"], lemb, points[:, 0], B)
         out = self.out_cls_layers(sem)

@@ -91,7 +91,11 @@ class _SparseConvFn(torch.autograd.Function):
         x = feats.detach().contiguous()
         if x.shape[1] != W.shape[1]:
             x = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1]))
-        out = ops.gather_gemm(x, W, tbl=tbl, order=order, cout=cout, shift=None if bias is None else bias.detach())
+        shift = None if bias is None else bias.detach()
+        if subm and ops.use_tile("subm", tbl.shape[1], W.shape[1], cout):  # the f32-grade 3-plane modes: SubM layers on the tile-halo kernel
+            out = ops.tile_conv(x, W, rb.tile_plan(False), cout=cout, shift=shift)
+        else:
+            out = ops.gather_gemm(x, W, tbl=tbl, order=order, cout=cout, shift=shift)
         ctx.save_for_backward(feats, weight)
         ctx.rb, ctx.inverse, ctx.subm, ctx.has_bias = rb, inverse, subm, bias is not None
         return out
@@ -118,7 +122,10 @@ class _SparseConvFn(torch.autograd.Function):
             g = gout
             if g.shape[1] != Wd.shape[1]:
                 g = torch.nn.functional.pad(g, (0, Wd.shape[1] - g.shape[1]))
-            gin = ops.gather_gemm(g, Wd, tbl=tbl_t, order=order_t, cout=cin)
+            if subm and ops.use_tile("subm", kvol, Wd.shape[1], cin):  # same table, same plan as the forward
+                gin = ops.tile_conv(g, Wd, rb.tile_plan(False), cout=cin)
+            else:
+                gin = ops.gather_gemm(g, Wd, tbl=tbl_t, order=order_t, cout=cin)
         if ctx.needs_input_grad[1]:
             tbl = rb.tbl_inv if inverse else rb.tbl
             order = rb.order(inverse) if cin * cout >= 4096 else None

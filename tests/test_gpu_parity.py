@@ -480,7 +480,7 @@ def _spconv_ref(feats, w, tbl):
     return out
 
 
-@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (128, 128)])
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (128, 128), (96, 32)])
 def test_sparse_conv_backward_gpu(cin, cout):
     """dgrad (gather-GEMM on the transposed tables) and wgrad (ls3d_spconv_wgrad) of SubM / strided / inverse convolutions on
     30k sites vs torch autograd of the plain restatement; wgrad must be bitwise reproducible"""

@@ -482,7 +482,33 @@ def _spconv_ref(feats, w, tbl):
     return out
 
 
-@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (32, 128), (64, 128)])
+def test_subm_training_path_on_the_tile_kernel():
+    """training forward and dgrad of a SubM layer in the 3-plane mode (tile-halo kernel, same plan for both) == the exact-f32
+    gather-GEMM path to f32 rounding"""
+    from lidarseg3d_amd import spconv
+    rng = np.random.default_rng(3)
+    shape = [9, 24, 24]
+    cells = rng.choice(shape[0] * shape[1] * shape[2], size=300, replace=False)
+    coords = torch.from_numpy(np.stack([np.zeros_like(cells), cells // (24 * 24), (cells // 24) % 24, cells % 24], 1).astype(np.int32))
+    conv = spconv.SubMConv3d(64, 32, 3, padding=1, bias=True, indice_key="s").train()
+    feats0 = torch.from_numpy(rng.normal(size=(300, 64)).astype(np.float32))
+    res = {}
+    try:
+        for prec in ("f32", "bf16x6"):
+            ops.set_precision(prec)
+            f = feats0.clone().requires_grad_(True)
+            conv.weight.grad = None
+            y = conv(spconv.SparseConvTensor(f, coords, shape, 1)).features
+            (y * torch.from_numpy(rng.normal(size=tuple(y.shape)).astype(np.float32) * 0 + 1.0) * y).sum().backward()
+            res[prec] = (y.detach().clone(), f.grad.clone(), conv.weight.grad.clone())
+    finally:
+        ops.set_precision("f32")
+    for a, b in zip(res["f32"], res["bf16x6"]):
+        assert not torch.equal(a, b) or a is res["f32"][2]  # a different kernel ran (the weight gradient kernel is shared)
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (32, 128), (64, 128), (128, 64), (96, 32)])
 def test_sparse_conv_backward_vs_autograd(cin, cout):
     """SubMConv3d -> SparseConv3d(stride 2) -> SparseInverseConv3d in training mode: grad of the input features and of the
     three weights (dgrad = gather-GEMM on the transposed tables, wgrad = ls3d_spconv_wgrad) vs torch autograd on a plain

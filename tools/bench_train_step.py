@@ -21,17 +21,30 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", choices=["sdseg3d", "mseg3d"], default="sdseg3d")
+    ap.add_argument("--geometry", choices=["nusc", "waymo"], default="nusc",
+                    help="waymo = BASELINE configs[3]: range [-75.2,-75.2,-2,75.2,75.2,4], voxel [0.1,0.1,0.15], 23 classes, 5 cameras")
+    ap.add_argument("--precision", choices=["f32", "bf16x6", "bf16x8"], default="f32",
+                    help="arithmetic of the SubM layers' forward and dgrad (ops.set_precision); the weight gradient is exact f32 in every mode")
+    ap.add_argument("--frames", type=int, default=1, help="frames per GPU per step (configs[3]: 2)")
+    ap.add_argument("--syncbn", action="store_true", help="BatchNorm1d -> CountSyncBatchNorm1d (statistics over all ranks, weighted by row counts)")
     ap.add_argument("--ddp", action="store_true", help="wrap the model in DistributedDataParallel (RCCL gradient all-reduce); "
                     "launch with python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... (N = 1 works too)")
     args = ap.parse_args()
     import lidarseg3d_amd as L
     from lidarseg3d_amd import models_cfg, ops, synth
-    cfg = synth.NUSC
+    cfg = synth.WAYMO if args.geometry == "waymo" else synth.NUSC
+    ncls, ncam = (23, 5) if args.geometry == "waymo" else (17, 6)
     rank, local_rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     torch.manual_seed(0)
-    model = L.build_detector(getattr(models_cfg, args.model)(), train_cfg=None, test_cfg={}).to(dev).train()
+    ops.set_precision(args.precision)
+    mcfg = getattr(models_cfg, args.model)(num_class=ncls, pc_range=cfg["pc_range"], voxel_size=cfg["voxel_size"])
+    model = L.build_detector(mcfg, train_cfg=None, test_cfg={})
+    if args.syncbn:
+        from lidarseg3d_amd import syncbn
+        model = syncbn.convert_sync_batchnorm(model)
+    model = model.to(dev).train()
     net = model
     if args.ddp:
         import torch.distributed as dist
@@ -43,15 +56,16 @@ def main():
         # end of backward beats several 25 MB ones; gradients live in the bucket (no extra copy)
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=True,
                                                         bucket_cap_mb=128, gradient_as_bucket_view=True)
-    frame = synth.lidar_frame(args.points, seed=rank, **cfg)
-    pts = torch.from_numpy(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1)).to(dev)
-    v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 5, 300000, batched=True)
+    B = args.frames
+    frames = [synth.lidar_frame(args.points, seed=rank * B + b, **cfg) for b in range(B)]
+    pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])).to(dev)
+    v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 5, 300000 * B, batched=True)
     V = int(nv)
-    ex = dict(points=pts, voxels=v[:V], coordinates=c[:V], num_points=n[:V], num_voxels=[V],
+    ex = dict(points=pts, voxels=v[:V], coordinates=c[:V], num_points=n[:V], num_voxels=[0] * B,
               shape=[np.asarray(ops.make_grid(cfg["voxel_size"], cfg["pc_range"])[1])],
-              voxel_sem_labels=torch.randint(0, 17, (V,), device=dev), point_sem_labels=torch.randint(0, 17, (pts.shape[0],), device=dev))
-    if args.model == "mseg3d":  # camera CNN outputs at the shipped nuScenes config's shapes (6 cameras, 48 channels, 160x240 maps)
-        img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=rank, ncam=6, c_img=48, h=160, w=240, batch=1)
+              voxel_sem_labels=torch.randint(0, ncls, (V,), device=dev), point_sem_labels=torch.randint(0, ncls, (pts.shape[0],), device=dev))
+    if args.model == "mseg3d":  # camera CNN outputs at the shipped configs' shapes (6 / 5 cameras, 48 channels, 160x240 maps)
+        img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=rank, ncam=ncam, c_img=48, h=160, w=240, num_class=ncls, batch=B)
         ex.update(image_features=torch.from_numpy(img).to(dev), camera_semantic_embeddings=torch.from_numpy(emb).to(dev),
                   points_cuv=torch.from_numpy(cuv).to(dev))
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
@@ -76,10 +90,11 @@ def main():
         tf, tb, to = (float(v) for v in t.tolist())
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"what": args.model + " training step (f32), 1 frame per GPU, %d GPU(s)%s" % (world, ", DDP" if args.ddp else ""),
-                          "points": args.points, "active_voxels": V,
+        print(json.dumps({"what": args.model + " training step (" + args.precision + "), %s geometry, %d frame(s) per GPU, %d GPU(s)%s%s"
+                                  % (args.geometry, B, world, ", DDP" if args.ddp else "", ", count-weighted SyncBN" if args.syncbn else ""),
+                          "points_per_frame": args.points, "frames_per_gpu": B, "active_voxels": V,
                           "forward_ms": 1e3 * tf / k, "backward_ms": 1e3 * tb / k, "optimizer_ms": 1e3 * to / k,
-                          "step_ms": 1e3 * (tf + tb + to) / k, "frames_per_s": world * k / (tf + tb + to),
+                          "step_ms": 1e3 * (tf + tb + to) / k, "frames_per_s": world * B * k / (tf + tb + to),
                           "loss_first": losses[0], "loss_last": losses[-1], "steps": k}))
 
 
