@@ -17,6 +17,7 @@
 // in a fixed order; row chunks are summed by a second kernel: deterministic, no atomics.
 // Exact f32 (fmaf chain per element).
 #include "common.h"
+#include "gemm_common.h"
 
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -141,6 +142,122 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ 
   }
 }
 
+// The same sums on the exact 3-plane bf16 split: 16 rows feed one v_mfma_f32_32x32x16_bf16 per plane product.  Lane
+// (i, half) loads the 8 rows [8 half, 8 half + 8) of the group for channel i of its cin block (A, M = cin) and of each cout block (B,
+// N = cout), splits them into round-to-nearest planes in registers and issues NP products per cout block: head x head into `acc`, the
+// small ones into `acs` (the bf16 MFMA's accumulate is biased towards zero, see tileconv.hip).  NP = 6 or 8: f32-grade like the forward.
+template <int COB, int NP>
+__global__ __launch_bounds__(256, 2) void k_spconv_wgrad_planes(const float *__restrict__ in, int in_ld, const float *__restrict__ gout, int go_ld,
+                                                                const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_t, int kvol, int cin,
+                                                                int cout, int n_rows, const int32_t *n_rows_dev, int nchunks,
+                                                                float *__restrict__ partial) {
+  __shared__ float red[32 * 32 * COB * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int N = ls3d_count(n_rows, n_rows_dev);
+  const int ci_blocks = (cin + 31) / 32;
+  const int CIW = ci_blocks >= 4 ? 4 : ci_blocks >= 2 ? 2 : 1, RG = 4 / CIW;
+  const int ci_groups = (ci_blocks + CIW - 1) / CIW;
+  const int cw = wave % CIW, rg = wave / CIW;
+  const int k = blockIdx.y;
+  const int chunk = blockIdx.x / ci_groups, cb = (blockIdx.x % ci_groups) * CIW + cw;
+  const int ci = cb * 32 + i;
+  const int ngroups = (N + 15) / 16;                       // groups of 16 rows of the processing order
+  const int per_chunk = (ngroups + nchunks - 1) / nchunks;
+  const int g0 = chunk * per_chunk, g1 = min(ngroups, g0 + per_chunk);
+  const int32_t *tk = tbl_t + (size_t)k * n_rows;
+  f32x16 acc[COB], acs[COB];
+#pragma unroll
+  for (int n = 0; n < COB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = acs[n][r] = 0.0f;
+  int idx[8], orow[8];
+#define WGP_LOAD_IDX(g_)                                              \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                     \
+    const int r_ = (g_) * 16 + half * 8 + j;                          \
+    const bool ok_ = (g_) < g1 && r_ < N;                             \
+    idx[j] = ok_ ? tk[r_] : -1;                                       \
+    orow[j] = ok_ ? o_t[r_] : 0;                                      \
+  }
+  int g = g0 + rg;
+  WGP_LOAD_IDX(g)
+  for (; g < g1; g += RG) {
+    bool mine = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine |= idx[j] >= 0;
+    const bool any = __any(mine);
+    float a[8], b[COB][8];
+    if (any) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = (idx[j] >= 0 && ci < cin) ? in[(size_t)idx[j] * in_ld + ci] : 0.0f;
+#pragma unroll
+      for (int n = 0; n < COB; ++n)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[n][j] = (idx[j] >= 0 && n * 32 + i < cout) ? gout[(size_t)orow[j] * go_ld + n * 32 + i] : 0.0f;
+    }
+    WGP_LOAD_IDX(g + RG)  // the next group's (contiguous) indices while this group's operands are in flight
+    if (any) {
+      uint4 ah, am, al;
+      ls3d_split_pair3_rne(a[0], a[1], ah.x, am.x, al.x);
+      ls3d_split_pair3_rne(a[2], a[3], ah.y, am.y, al.y);
+      ls3d_split_pair3_rne(a[4], a[5], ah.z, am.z, al.z);
+      ls3d_split_pair3_rne(a[6], a[7], ah.w, am.w, al.w);
+      const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+      for (int n = 0; n < COB; ++n) {
+        uint4 bh, bm, bl;
+        ls3d_split_pair3_rne(b[n][0], b[n][1], bh.x, bm.x, bl.x);
+        ls3d_split_pair3_rne(b[n][2], b[n][3], bh.y, bm.y, bl.y);
+        ls3d_split_pair3_rne(b[n][4], b[n][5], bh.z, bm.z, bl.z);
+        ls3d_split_pair3_rne(b[n][6], b[n][7], bh.w, bm.w, bl.w);
+        const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bm = __builtin_bit_cast(bf16x8, bm), Bl = __builtin_bit_cast(bf16x8, bl);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acs[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acs[n], 0, 0, 0);
+        if constexpr (NP >= 8) {
+          acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bm, acs[n], 0, 0, 0);
+          acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bl, acs[n], 0, 0, 0);
+        }
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acs[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acs[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acs[n], 0, 0, 0);
+      }
+    }
+  }
+#undef WGP_LOAD_IDX
+#pragma unroll
+  for (int n = 0; n < COB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] += acs[n][r];
+  for (int r2 = 1; r2 < RG; ++r2) {
+    float *slot = red + (CIW == 2 ? cw * (32 * 32 * COB) : 0);
+    if (rg == r2) {
+#pragma unroll
+      for (int n = 0; n < COB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[(n * 16 + r) * 64 + lane] = acc[n][r];
+    }
+    __syncthreads();
+    if (rg == 0) {
+#pragma unroll
+      for (int n = 0; n < COB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] += slot[(n * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (rg == 0 && cb < ci_blocks) {
+    float *dst = partial + (((size_t)chunk * kvol + k) * cin) * cout;
+#pragma unroll
+    for (int n = 0; n < COB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, col = n * 32 + i;
+        if (row < cin && col < cout) dst[(size_t)row * cout + col] = acc[n][r];
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *partial, int nchunks, long long elems, float *gw) {
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < elems; t += (long long)gridDim.x * blockDim.x) {
     float s = 0.0f;
@@ -171,12 +288,13 @@ extern "C" size_t ls3d_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout,
 }
 
 extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int go_ld, const int32_t *tbl, const int32_t *row_order,
-                                 int kvol, int cin, int cout, int n_rows, const int32_t *n_rows_dev, void *workspace, size_t workspace_bytes,
-                                 float *grad_w, ls3d_stream_t stream_) {
+                                 int kvol, int cin, int cout, int n_rows, const int32_t *n_rows_dev, int products, void *workspace,
+                                 size_t workspace_bytes, float *grad_w, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!in || !grad_out || !tbl || !grad_w || !workspace || kvol < 1 || cin < 1 || cout < 1 || n_rows < 0) return LS3D_ERR_ARG;
   if (in_ld < cin || go_ld < cout) return LS3D_ERR_ARG;
   if (cout > 128) return LS3D_ERR_UNSUPPORTED;
+  if (products != 0 && products != 6 && products != 8) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_spconv_wgrad_workspace_bytes(kvol, cin, cout, n_rows)) return LS3D_ERR_WORKSPACE;
   const long long elems = (long long)kvol * cin * cout;
   if (n_rows == 0) {
@@ -192,10 +310,23 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
   const int cob = (cout + 31) / 32;
 #define LS3D_WG(COB_) hipLaunchKernelGGL((k_spconv_wgrad<COB_>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, (const int32_t *)tbl_t, \
                                           (const int32_t *)o_t, kvol, cin, cout, n_rows, n_rows_dev, nchunks, partial)
-  if (cob == 1) LS3D_WG(1);
-  else if (cob == 2) LS3D_WG(2);
-  else LS3D_WG(4);
+#define LS3D_WGP(COB_, NP_) hipLaunchKernelGGL((k_spconv_wgrad_planes<COB_, NP_>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld,      \
+                                               (const int32_t *)tbl_t, (const int32_t *)o_t, kvol, cin, cout, n_rows, n_rows_dev, nchunks, partial)
+  if (products == 0) {
+    if (cob == 1) LS3D_WG(1);
+    else if (cob == 2) LS3D_WG(2);
+    else LS3D_WG(4);
+  } else if (products == 6) {
+    if (cob == 1) LS3D_WGP(1, 6);
+    else if (cob == 2) LS3D_WGP(2, 6);
+    else LS3D_WGP(4, 6);
+  } else {
+    if (cob == 1) LS3D_WGP(1, 8);
+    else if (cob == 2) LS3D_WGP(2, 8);
+    else LS3D_WGP(4, 8);
+  }
 #undef LS3D_WG
+#undef LS3D_WGP
   hipLaunchKernelGGL(k_wgrad_reduce, ls3d_grid(elems), dim3(256), 0, stream, (const float *)partial, nchunks, elems, grad_w);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;

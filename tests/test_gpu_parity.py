@@ -480,6 +480,33 @@ def _spconv_ref(feats, w, tbl):
     return out
 
 
+@pytest.mark.parametrize("cin,cout,products", [(128, 128, 6), (128, 128, 8), (64, 128, 6), (256, 128, 6), (32, 32, 6)])
+def test_wgrad_on_bf16_planes_is_f32_grade_gpu(cin, cout, products):
+    """ls3d_spconv_wgrad on the exact 3-plane bf16 split against float64 at a real size (60k rows, SubM-like density): error not above
+    the exact-f32 kernel's, bitwise reproducible"""
+    rng = np.random.default_rng(cin + cout + products)
+    n_in, n_out, kvol = 60000, 60000, 27
+    x = np.maximum(rng.normal(size=(n_in, cin)), 0).astype(np.float32)  # post-ReLU-like activations
+    go = (rng.normal(size=(n_out, cout)) * 0.1).astype(np.float32)
+    tbl = rng.integers(0, n_in, size=(n_out, kvol)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.4] = -1
+    X, G, T = cu(x), cu(go), cu(tbl)
+    want = torch.zeros((kvol, cin, cout), dtype=torch.float64, device=DEV)
+    for k in range(kvol):
+        o = torch.nonzero(T[:, k] >= 0)[:, 0]
+        want[k] = X[T[o, k].long()].double().t() @ G[o].double()
+    scale = float(want.abs().max())
+    order = ops.rulebook_order(T, None) if hasattr(ops, "rulebook_order") else None
+    got32 = ops.spconv_wgrad(X, G, T, None, cin, cout, products=0).double()
+    gotp = ops.spconv_wgrad(X, G, T, None, cin, cout, products=products)
+    assert torch.equal(gotp, ops.spconv_wgrad(X, G, T, None, cin, cout, products=products))
+    e32 = float((got32 - want).pow(2).mean().sqrt()) / scale
+    ep = float((gotp.double() - want).pow(2).mean().sqrt()) / scale
+    m32, mp = float((got32 - want).abs().max()) / scale, float((gotp.double() - want).abs().max()) / scale
+    print("wgrad %d->%d x%d: rms %.2e max %.2e | exact f32: rms %.2e max %.2e" % (cin, cout, products, ep, mp, e32, m32))
+    assert ep <= 1.05 * e32 + 1e-9 and mp <= 1.5 * m32 + 1e-8, (ep, e32, mp, m32)
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (128, 128), (96, 32)])
 def test_sparse_conv_backward_gpu(cin, cout):
     """dgrad (gather-GEMM on the transposed tables) and wgrad (ls3d_spconv_wgrad) of SubM / strided / inverse convolutions on

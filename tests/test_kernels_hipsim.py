@@ -482,6 +482,34 @@ def _spconv_ref(feats, w, tbl):
     return out
 
 
+@pytest.mark.parametrize("cin,cout,products", [(64, 128, 6), (128, 64, 8), (32, 32, 6), (96, 48, 6), (16, 16, 8)])
+def test_wgrad_on_bf16_planes_is_f32_grade(cin, cout, products):
+    """ls3d_spconv_wgrad with the exact 3-plane split (16 rows per bf16 MFMA, head x head in its own accumulator) against float64:
+    not worse than the exact-f32 kernel (up to the emulation's per-product rounding), ragged row counts, absent neighbours"""
+    rng = np.random.default_rng(cin * 7 + cout)
+    n_in, n_out, kvol = 211, 173, 5
+    x = (rng.normal(size=(n_in, cin)) * np.exp(rng.normal(size=(n_in, cin)))).astype(np.float32)
+    go = (rng.normal(size=(n_out, cout)) * np.exp(rng.normal(size=(n_out, cout)))).astype(np.float32)
+    tbl = rng.integers(0, n_in, size=(n_out, kvol)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.4] = -1
+    tbl[40:80, 3] = -1
+    want = np.zeros((kvol, cin, cout))
+    for k in range(kvol):
+        o = np.nonzero(tbl[:, k] >= 0)[0]
+        want[k] = x[tbl[o, k]].astype(np.float64).T @ go[o].astype(np.float64)
+    mag = np.zeros((kvol, cin, cout))
+    for k in range(kvol):
+        o = np.nonzero(tbl[:, k] >= 0)[0]
+        mag[k] = np.abs(x[tbl[o, k]]).astype(np.float64).T @ np.abs(go[o]).astype(np.float64)
+    tx, tg, tt = torch.from_numpy(x), torch.from_numpy(go), torch.from_numpy(tbl)
+    order = torch.from_numpy(rng.permutation(n_out).astype(np.int32))
+    err = {}
+    for name, pr, od in (("f32", 0, None), ("planes", products, None), ("planes_ordered", products, order)):
+        got = ops.spconv_wgrad(tx, tg, tt, od, cin, cout, products=pr).numpy()
+        err[name] = float((np.abs(got - want) / np.maximum(mag, 1e-30)).max())
+    assert err["planes"] <= 4 * err["f32"] + 2.0 ** -22 and err["planes_ordered"] <= 4 * err["f32"] + 2.0 ** -22, err
+
+
 def test_subm_training_path_on_the_tile_kernel():
     """training forward and dgrad of a SubM layer in the 3-plane mode (tile-halo kernel, same plan for both) == the exact-f32
     gather-GEMM path to f32 rounding"""
