@@ -628,19 +628,20 @@ def _tile_ws(nbytes, like):
     return buf
 
 
-_WGRAD_PLANES = _os.environ.get("LS3D_WGRAD_PLANES", "0") == "1"
+_WGRAD_PLANES = _os.environ.get("LS3D_WGRAD_PLANES", "1") != "0"
 
 
 def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None):
     """grad_w[kvol, cin, cout] of a sparse convolution: x = the forward input features (rows indexed by tbl), grad_out on the
-    forward output rows, tbl/order = the table and row order of the forward launch.  products: 0 = exact-f32 MFMA kernel (default), 6 / 8 =
-    the exact 3-plane bf16 split (f32-grade, currently slower); None = 0 unless LS3D_WGRAD_PLANES=1, then ops.set_precision's product count."""
+    forward output rows, tbl/order = the table and row order of the forward launch.  products: 0 = exact-f32 MFMA kernel, 6 / 8 = the exact
+    3-plane bf16 split (f32-grade; the library uses it for layers with >= 8 output blocks of 32 x 32 and the exact-f32 kernel below that);
+    None = ops.set_precision's product count (0 in "f32" / "bf16x3"; LS3D_WGRAD_PLANES=0 forces 0)."""
     n, kvol = tbl.shape
     gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
     L = _L()
     ws = _ws(L.ls3d_spconv_wgrad_workspace_bytes(kvol, cin, cout, n), x)
-    if products is None:  # measured (profiles/round2_experiments.md): the plane kernel is f32-grade but 2.4x slower than the exact-f32 one -> opt-in
-        products = tile_products() if (_WGRAD_PLANES and cin >= 16 and cout >= 16) else 0
+    if products is None:
+        products = tile_products() if _WGRAD_PLANES else 0
     check(L.ls3d_spconv_wgrad(_ptr(x), x.shape[1], _ptr(grad_out), grad_out.shape[1], _ptr(tbl), _ptr(order), kvol, cin, cout, n, None,
                               int(products), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(gw), _stream(x)), "ls3d_spconv_wgrad")
     return gw

@@ -482,7 +482,7 @@ def _spconv_ref(feats, w, tbl):
     return out
 
 
-@pytest.mark.parametrize("cin,cout,products", [(64, 128, 6), (128, 64, 8), (32, 32, 6), (96, 48, 6), (16, 16, 8)])
+@pytest.mark.parametrize("cin,cout,products", [(64, 128, 6), (128, 64, 8), (32, 32, 6), (96, 48, 6), (16, 16, 8), (160, 64, 6)])
 def test_wgrad_on_bf16_planes_is_f32_grade(cin, cout, products):
     """ls3d_spconv_wgrad with the exact 3-plane split (16 rows per bf16 MFMA, head x head in its own accumulator) against float64:
     not worse than the exact-f32 kernel (up to the emulation's per-product rounding), ragged row counts, absent neighbours"""
