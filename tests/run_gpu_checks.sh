@@ -11,6 +11,14 @@ if [ "${TESTS:-1}" = "1" ]; then
 fi
 timeout 900 python bench.py --steps ${STEPS:-20} --warmup 5 > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/summary.txt
 timeout 600 python bench.py --model mseg3d --no-cpu-baseline --no-extra-modes --steps ${STEPS:-20} --warmup 5 > $OUT/bench_mseg3d.log 2> $OUT/bench_mseg3d.err; echo "bench mseg3d rc=$?" >> $OUT/summary.txt
+if [ "${TRAIN:-1}" = "1" ]; then  # BASELINE configs[3]: Waymo-geometry MSeg3D training step, 2 x 180k points per GPU (+ the nuScenes SDSeg3D step)
+  for P in f32 bf16x6; do
+    timeout 300 python tools/bench_train_step.py --steps 5 --warmup 2 --precision $P > $OUT/train_nusc_$P.json 2> $OUT/train.err
+    timeout 400 python tools/bench_train_step.py --model mseg3d --geometry waymo --points 180000 --frames 2 --steps 5 --warmup 2 --precision $P > $OUT/train_waymo_$P.json 2>> $OUT/train.err
+  done
+  timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 tools/bench_train_step.py --model mseg3d --geometry waymo --points 180000 --frames 2 --steps 5 --warmup 2 --precision bf16x6 --ddp --syncbn > $OUT/train_waymo_ddp_syncbn_bf16x6.json 2>> $OUT/train.err
+  echo "train rc=$?" >> $OUT/summary.txt
+fi
 if [ "${PROFILE:-1}" = "1" ]; then
   cd /tmp
   for P in bf16x6 f32; do
