@@ -101,6 +101,7 @@ extern "C" size_t ls3d_radix_sort_workspace_bytes(int n) {
 // sorting permutation).  keys_out / vals_out receive the result (keys_out may be NULL).  In-place is not supported.
 int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, int bits, uint32_t *keys_out, int32_t *vals_out, void *workspace,
                           size_t workspace_bytes, hipStream_t stream) {
+  if (n == 0 && bits >= 1 && bits <= 32) return LS3D_OK;
   if (!keys_in || !vals_out || !workspace || n < 0 || bits < 1 || bits > 32) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_radix_sort_workspace_bytes(n)) return LS3D_ERR_WORKSPACE;
   if (n == 0) return LS3D_OK;

@@ -303,6 +303,10 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
                                  int kvol, int cin, int cout, int n_rows, const int32_t *n_rows_dev, int products, void *workspace,
                                  size_t workspace_bytes, float *grad_w, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows == 0 && grad_w && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128) {  // empty tensors have no storage: the gradient is zero
+    hipMemsetAsync(grad_w, 0, (size_t)kvol * cin * cout * sizeof(float), stream);
+    return LS3D_OK;
+  }
   if (!in || !grad_out || !tbl || !grad_w || !workspace || kvol < 1 || cin < 1 || cout < 1 || n_rows < 0) return LS3D_ERR_ARG;
   if (in_ld < cin || go_ld < cout) return LS3D_ERR_ARG;
   if (cout > 128) return LS3D_ERR_UNSUPPORTED;

@@ -67,6 +67,7 @@ static int tc_key_layout(const int32_t shape_zyx[3], int batch, int &shift, int 
 
 extern "C" int ls3d_tile_keys(const int32_t *coords, int n, const int32_t *n_dev, const int32_t shape_zyx[3], int batch, uint32_t *keys,
                               ls3d_stream_t stream) {
+  if (n == 0 && shape_zyx && batch >= 1) return LS3D_OK;  // nothing to do: empty tensors have no storage
   if (!coords || !keys || !shape_zyx || n < 0 || batch < 1) return LS3D_ERR_ARG;
   if (n == 0) return LS3D_OK;
   int shift, mbits;
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
 
 extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_rows_dev, int kvol, const int32_t *spatial_order, void *plan,
                                size_t plan_bytes, ls3d_stream_t stream) {
+  if (n_rows == 0 && kvol >= 1 && kvol <= TC_KMAX) return LS3D_OK;
   if (!tbl || !spatial_order || !plan || n_rows < 0 || kvol < 1) return LS3D_ERR_ARG;
   if (kvol > TC_KMAX) return LS3D_ERR_UNSUPPORTED;
   if (plan_bytes < ls3d_tile_plan_bytes(n_rows, kvol)) return LS3D_ERR_WORKSPACE;
@@ -252,6 +254,7 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
                               const int32_t shape_zyx[3], int batch, void *workspace, size_t workspace_bytes, void *plan, size_t plan_bytes,
                               ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows == 0 && shape_zyx && kvol >= 1 && kvol <= TC_KMAX && batch >= 1) return LS3D_OK;
   if (!tbl || !coords || !shape_zyx || !workspace || !plan || n_rows < 0 || kvol < 1 || batch < 1) return LS3D_ERR_ARG;
   if (kvol > TC_KMAX) return LS3D_ERR_UNSUPPORTED;
   if (workspace_bytes < ls3d_tile_plan_workspace_bytes(n_rows) || plan_bytes < ls3d_tile_plan_bytes(n_rows, kvol)) return LS3D_ERR_WORKSPACE;
@@ -575,6 +578,8 @@ extern "C" size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout) {
 extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout, int products,
                               const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows == 0 && w_packed && kvol >= 1 && kvol <= TC_KMAX && cin >= 16 && !(cin % 16) && cout >= 1 && cout <= 128 && (products == 6 || products == 8))
+    return LS3D_OK;
   if (!in || !plan || !w_packed || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
   if (((uintptr_t)in & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)plan & 15)) return LS3D_ERR_ARG;

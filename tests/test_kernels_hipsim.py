@@ -868,6 +868,46 @@ def test_tile_conv_matches_float64_and_gather_gemm(cin, cout, products):
     assert torch.equal(again, raw)
 
 
+def test_round2_entry_points_on_empty_and_degenerate_inputs():
+    """empty and degenerate inputs of the round-2 entry points: zero rows, one row, a table with no neighbour at all, a tile whose
+    rows all lack an offset, zero points into the fused decoder, an empty segment list"""
+    from lidarseg3d_amd.packing import PackedWeight
+    rng = np.random.default_rng(0)
+    w = torch.from_numpy((rng.normal(size=(27, 64, 64)) * 0.1).astype(np.float32))
+    pw = PackedWeight(w, 27, 64, 64, 64)
+    # zero rows
+    tbl0 = torch.empty((0, 27), dtype=torch.int32)
+    plan0 = ops.tile_plan(tbl0, torch.empty((0, 4), dtype=torch.int32), (4, 8, 8), 1)
+    out0 = ops.tile_conv(torch.empty((0, 64)), pw, plan0, cout=64, products=6)
+    assert tuple(out0.shape) == (0, 64)
+    assert ops.radix_argsort(torch.empty((0,), dtype=torch.int32), 16).numel() == 0
+    assert ops.radix_argsort(torch.tensor([5], dtype=torch.int32), 16).tolist() == [0]
+    # one row that is its own (centre) neighbour, and rows with NO neighbour: bias / shift only
+    x = torch.from_numpy(rng.normal(size=(3, 64)).astype(np.float32))
+    tbl = torch.full((3, 27), -1, dtype=torch.int32)
+    tbl[0, 13] = 0
+    coords = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 4], [0, 3, 7, 7]], dtype=torch.int32)
+    plan = ops.tile_plan(tbl, coords, (4, 8, 8), 1)
+    shift = torch.from_numpy(rng.normal(size=(64,)).astype(np.float32))
+    got = ops.tile_conv(x, pw, plan, cout=64, products=8, shift=shift)
+    want = torch.zeros((3, 64), dtype=torch.float64)
+    want[0] = x[0].double() @ w[13].double()
+    want += shift.double()
+    assert float((got.double() - want).abs().max()) <= 1e-5
+    # weight gradient of an empty / neighbour-free table is zero
+    gw = ops.spconv_wgrad(x, torch.ones((3, 64)), torch.full((3, 27), -1, dtype=torch.int32), None, 64, 64, products=6)
+    assert float(gw.abs().max()) == 0.0
+    gw = ops.spconv_wgrad(torch.empty((0, 128)), torch.empty((0, 128)), torch.empty((0, 27), dtype=torch.int32), None, 128, 128, products=6)
+    assert tuple(gw.shape) == (27, 128, 128) and float(gw.abs().max()) == 0.0
+    # segment mean with empty segments in between
+    src = torch.from_numpy(rng.normal(size=(5, 4)).astype(np.float32))
+    seg = torch.tensor([3, 3, 0, 3, 6], dtype=torch.int32)
+    from lidarseg3d_amd import scatter
+    m = scatter.scatter_mean(src, seg.long(), dim=0, dim_size=8)
+    assert torch.equal(m[0], src[2]) and float(m[[1, 2, 4, 5, 7]].abs().max()) == 0.0
+    np.testing.assert_allclose(m[3].numpy(), ((src[0] + src[1]) + src[3]).numpy() / 3.0, rtol=1e-6)
+
+
 def test_tile_conv_any_row_order_gives_the_same_rows():
     """tiles only group rows: with single-pass halos the per-row summation order (chunks outer, offsets inner) does not depend
     on the tiling, so two different spatial orders give bit-identical outputs"""
