@@ -153,6 +153,39 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ 
 // group's rows are in flight while this group's MFMAs run.  head x head goes into `acc`, the small products into `acs` (tileconv.hip).
 constexpr int WGL_ROWS = 16;
 template <int NP>
+__device__ __forceinline__ void wgl_multiply(const uint4 (*sa)[128][2], const uint4 (*sb)[128][2], f32x16 *acc, f32x16 *acs, int wave, int i, int half,
+                                             int nblk, int NB) {
+  int nb_prev = -1;
+  bf16x8 Bh, Bm, Bl;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int blk = wave + 4 * t;
+    if (blk < nblk) {
+      const int cb = blk / NB, nb = blk % NB;
+      if (nb != nb_prev) {
+        Bh = __builtin_bit_cast(bf16x8, sb[0][nb * 32 + i][half]);
+        Bm = __builtin_bit_cast(bf16x8, sb[1][nb * 32 + i][half]);
+        Bl = __builtin_bit_cast(bf16x8, sb[2][nb * 32 + i][half]);
+        nb_prev = nb;
+      }
+      const bf16x8 Ah = __builtin_bit_cast(bf16x8, sa[0][cb * 32 + i][half]);
+      const bf16x8 Am = __builtin_bit_cast(bf16x8, sa[1][cb * 32 + i][half]);
+      const bf16x8 Al = __builtin_bit_cast(bf16x8, sa[2][cb * 32 + i][half]);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[t], 0, 0, 0);
+      acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acs[t], 0, 0, 0);
+      acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acs[t], 0, 0, 0);
+      if constexpr (NP >= 8) {
+        acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bm, acs[t], 0, 0, 0);
+        acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bl, acs[t], 0, 0, 0);
+      }
+      acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acs[t], 0, 0, 0);
+      acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acs[t], 0, 0, 0);
+      acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acs[t], 0, 0, 0);
+    }
+  }
+}
+
+template <int NP>
 __global__ __launch_bounds__(256, 2) void k_spconv_wgrad_lds(const float *__restrict__ in, int in_ld, const float *__restrict__ gout, int go_ld,
                                                              const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_t, int kvol, int cin,
                                                              int cout, int n_rows, const int32_t *n_rows_dev, int nchunks, float *__restrict__ partial) {
@@ -172,89 +205,86 @@ __global__ __launch_bounds__(256, 2) void k_spconv_wgrad_lds(const float *__rest
   const int g0 = chunk * per_chunk, g1 = min(ngroups, g0 + per_chunk);
   const int32_t *tk = tbl_t + (size_t)k * n_rows;
   const bool a_live = c < CB * 32, b_live = c < NB * 32, a_in = ci0 + c < cin, b_in = c < cout;
+  const int ca = a_in ? ci0 + c : cin - 1, cbc = b_in ? c : cout - 1;  // clamped columns: every load address is valid
   f32x16 acc[4], acs[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = acs[t][r] = 0.0f;
-  float ra[8], rb[8];
-  bool any_n = false;
-  // rows of group g_ this thread stages: indices are wave-uniform (scalar loads), the values one float per row
-#define WGL_LOAD(g_)                                                                             \
+  // Row pipeline.  The 16 row indices of a group come with ONE unconditional vector load each (lane l holds row l & 15; rows past the end
+  // re-read row 0 and are masked) and are handed out with v_readlane - written as scalar loads under `r < N` conditions hipcc waited for
+  // each one before issuing the next: ~3 us per group, 8x the group's MFMA time.  The row loads are branch-free for the same reason
+  // (absent rows / channels past the end read a valid address and are zeroed afterwards).  Indices run three groups ahead of the MFMAs,
+  // rows two (two register sets in rotation): index latency, row latency and the MFMAs of a group overlap.
+  float ra0[8], rb0[8], ra1[8], rb1[8];
+  bool any0 = false, any1 = false, anyp = false;
+  int tkp = -1, op = 0;
+#define WGL_IDX(g_)                                                                              \
   {                                                                                              \
-    any_n = false;                                                                               \
-    if ((g_) < g1) {                                                                             \
-      _Pragma("unroll") for (int j = 0; j < WGL_ROWS; ++j) {                                     \
-        const int r_ = (g_) * WGL_ROWS + j;                                                      \
-        any_n |= r_ < N && tk[r_] >= 0;                                                          \
+    const int r16_ = (g_) * WGL_ROWS + (lane & 15);                                              \
+    const bool v16_ = (g_) < g1 && r16_ < N;                                                     \
+    tkp = tk[v16_ ? r16_ : 0];                                                                   \
+    op = o_t[v16_ ? r16_ : 0];                                                                   \
+    if (!v16_) tkp = -1;                                                                         \
+  }
+#define WGL_ROWS_LOAD(RA, RB, ANY)                                                               \
+  {                                                                                              \
+    ANY = __any(tkp >= 0);                                                                       \
+    if (ANY) {                                                                                   \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+        const int idx_ = __builtin_amdgcn_readlane(tkp, rg * 8 + j);                             \
+        const int o_ = __builtin_amdgcn_readlane(op, rg * 8 + j);                                \
+        const float *arow_ = in + (size_t)(idx_ >= 0 ? idx_ : 0) * in_ld;                        \
+        const float *brow_ = gout + (size_t)o_ * go_ld;                                          \
+        const float av_ = arow_[ca], bv_ = brow_[cbc];                                           \
+        RA[j] = (idx_ >= 0 && a_in) ? av_ : 0.0f;                                                \
+        RB[j] = (idx_ >= 0 && b_in) ? bv_ : 0.0f;                                                \
       }                                                                                          \
     }                                                                                            \
-    if (any_n) {                                                                                 \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
-        const int r_ = (g_) * WGL_ROWS + rg * 8 + j;                                             \
-        const int idx_ = r_ < N ? tk[r_] : -1;                                                   \
-        const int o_ = r_ < N ? o_t[r_] : 0;                                                     \
-        ra[j] = (idx_ >= 0 && a_in) ? in[(size_t)idx_ * in_ld + ci0 + c] : 0.0f;                 \
-        rb[j] = (idx_ >= 0 && b_in) ? gout[(size_t)o_ * go_ld + c] : 0.0f;                       \
+  }
+  // one group: split this set's rows into LDS, refill the set with the rows of the group whose indices are pending, fetch the
+  // indices of group gi_, multiply
+#define WGL_STEP(RA, RB, ANY, gi_)                                                               \
+  {                                                                                              \
+    const bool any = ANY;                                                                        \
+    if (any) {                                                                                   \
+      uint4 h, m, l;                                                                             \
+      if (a_live) {                                                                              \
+        ls3d_split_pair3_rne(RA[0], RA[1], h.x, m.x, l.x);                                       \
+        ls3d_split_pair3_rne(RA[2], RA[3], h.y, m.y, l.y);                                       \
+        ls3d_split_pair3_rne(RA[4], RA[5], h.z, m.z, l.z);                                       \
+        ls3d_split_pair3_rne(RA[6], RA[7], h.w, m.w, l.w);                                       \
+        sA[buf][0][c][rg] = h; sA[buf][1][c][rg] = m; sA[buf][2][c][rg] = l;                     \
       }                                                                                          \
+      if (b_live) {                                                                              \
+        ls3d_split_pair3_rne(RB[0], RB[1], h.x, m.x, l.x);                                       \
+        ls3d_split_pair3_rne(RB[2], RB[3], h.y, m.y, l.y);                                       \
+        ls3d_split_pair3_rne(RB[4], RB[5], h.z, m.z, l.z);                                       \
+        ls3d_split_pair3_rne(RB[6], RB[7], h.w, m.w, l.w);                                       \
+        sB[buf][0][c][rg] = h; sB[buf][1][c][rg] = m; sB[buf][2][c][rg] = l;                     \
+      }                                                                                          \
+    }                                                                                            \
+    WGL_ROWS_LOAD(RA, RB, ANY)                                                                   \
+    WGL_IDX(gi_)                                                                                 \
+    if (any) {                                                                                   \
+      __syncthreads();                                                                           \
+      wgl_multiply<NP>(sA[buf], sB[buf], acc, acs, wave, i, half, nblk, NB);                     \
+      buf ^= 1;                                                                                  \
     }                                                                                            \
   }
   int buf = 0;
-  WGL_LOAD(g0)
-  for (int g = g0; g < g1; ++g) {
-    const bool any = any_n;
-    if (any) {
-      uint4 h, m, l;
-      if (a_live) {
-        ls3d_split_pair3_rne(ra[0], ra[1], h.x, m.x, l.x);
-        ls3d_split_pair3_rne(ra[2], ra[3], h.y, m.y, l.y);
-        ls3d_split_pair3_rne(ra[4], ra[5], h.z, m.z, l.z);
-        ls3d_split_pair3_rne(ra[6], ra[7], h.w, m.w, l.w);
-        sA[buf][0][c][rg] = h; sA[buf][1][c][rg] = m; sA[buf][2][c][rg] = l;
-      }
-      if (b_live) {
-        ls3d_split_pair3_rne(rb[0], rb[1], h.x, m.x, l.x);
-        ls3d_split_pair3_rne(rb[2], rb[3], h.y, m.y, l.y);
-        ls3d_split_pair3_rne(rb[4], rb[5], h.z, m.z, l.z);
-        ls3d_split_pair3_rne(rb[6], rb[7], h.w, m.w, l.w);
-        sB[buf][0][c][rg] = h; sB[buf][1][c][rg] = m; sB[buf][2][c][rg] = l;
-      }
-    }
-    WGL_LOAD(g + 1)  // in flight during this group's MFMAs
-    if (any) {
-      __syncthreads();
-      int nb_prev = -1;
-      bf16x8 Bh, Bm, Bl;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int blk = wave + 4 * t;
-        if (blk < nblk) {
-          const int cb = blk / NB, nb = blk % NB;
-          if (nb != nb_prev) {
-            Bh = __builtin_bit_cast(bf16x8, sB[buf][0][nb * 32 + i][half]);
-            Bm = __builtin_bit_cast(bf16x8, sB[buf][1][nb * 32 + i][half]);
-            Bl = __builtin_bit_cast(bf16x8, sB[buf][2][nb * 32 + i][half]);
-            nb_prev = nb;
-          }
-          const bf16x8 Ah = __builtin_bit_cast(bf16x8, sA[buf][0][cb * 32 + i][half]);
-          const bf16x8 Am = __builtin_bit_cast(bf16x8, sA[buf][1][cb * 32 + i][half]);
-          const bf16x8 Al = __builtin_bit_cast(bf16x8, sA[buf][2][cb * 32 + i][half]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[t], 0, 0, 0);
-          acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acs[t], 0, 0, 0);
-          acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acs[t], 0, 0, 0);
-          if constexpr (NP >= 8) {
-            acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bm, acs[t], 0, 0, 0);
-            acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bl, acs[t], 0, 0, 0);
-          }
-          acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acs[t], 0, 0, 0);
-          acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acs[t], 0, 0, 0);
-          acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acs[t], 0, 0, 0);
-        }
-      }
-      buf ^= 1;
-    }
+  WGL_IDX(g0)
+  WGL_ROWS_LOAD(ra0, rb0, any0)
+  WGL_IDX(g0 + 1)
+  WGL_ROWS_LOAD(ra1, rb1, any1)
+  WGL_IDX(g0 + 2)
+  for (int g = g0; g < g1; g += 2) {
+    WGL_STEP(ra0, rb0, any0, g + 3)
+    WGL_STEP(ra1, rb1, any1, g + 4)
   }
-#undef WGL_LOAD
+#undef WGL_STEP
+#undef WGL_ROWS_LOAD
+#undef WGL_IDX
   float *dst = partial + (((size_t)chunk * kvol + k) * cin) * cout;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {

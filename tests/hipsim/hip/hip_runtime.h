@@ -158,6 +158,8 @@ inline float __expf(float a) { return expf(a); }
 inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 inline int __builtin_amdgcn_readfirstlane_sim(int v) { return __shfl(v, 0); }
 #define __builtin_amdgcn_readfirstlane __builtin_amdgcn_readfirstlane_sim
+inline int __builtin_amdgcn_readlane_sim(int v, int l) { return __shfl(v, l); }
+#define __builtin_amdgcn_readlane __builtin_amdgcn_readlane_sim
 
 using std::max;
 using std::min;
