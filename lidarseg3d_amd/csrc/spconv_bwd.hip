@@ -148,12 +148,12 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ 
 // channels and all <= 128 output channels for a chunk of the rows.  Per group of 16 rows: thread (c, rg) loads rows [8 rg, 8 rg + 8) of
 // channel c of the gathered input rows and of grad_out (lanes run along the channels: every load instruction reads whole 256-byte row
 // segments), splits its 8 + 8 values into three round-to-nearest bf16 planes in registers and writes each plane with ONE 16-byte LDS store
-// at [plane][channel][8 rg ..] - which is exactly the MFMA operand layout, so every wave fetches its fragments with ds_read_b128.  The
+// at [plane][row half rg][channel] - which is exactly the MFMA operand layout, so every wave fetches its fragments with ds_read_b128.  The
 // (cin / 32) x (cout / 32) output blocks are dealt to the 4 waves (<= 4 each); LDS is double buffered (one barrier per group) and the next
 // group's rows are in flight while this group's MFMAs run.  head x head goes into `acc`, the small products into `acs` (tileconv.hip).
 constexpr int WGL_ROWS = 16;
 template <int NP>
-__device__ __forceinline__ void wgl_multiply(const uint4 (*sa)[128][2], const uint4 (*sb)[128][2], f32x16 *acc, f32x16 *acs, int wave, int i, int half,
+__device__ __forceinline__ void wgl_multiply(const uint4 (*sa)[2][128], const uint4 (*sb)[2][128], f32x16 *acc, f32x16 *acs, int wave, int i, int half,
                                              int nblk, int NB) {
   int nb_prev = -1;
   bf16x8 Bh, Bm, Bl;
@@ -163,14 +163,14 @@ __device__ __forceinline__ void wgl_multiply(const uint4 (*sa)[128][2], const ui
     if (blk < nblk) {
       const int cb = blk / NB, nb = blk % NB;
       if (nb != nb_prev) {
-        Bh = __builtin_bit_cast(bf16x8, sb[0][nb * 32 + i][half]);
-        Bm = __builtin_bit_cast(bf16x8, sb[1][nb * 32 + i][half]);
-        Bl = __builtin_bit_cast(bf16x8, sb[2][nb * 32 + i][half]);
+        Bh = __builtin_bit_cast(bf16x8, sb[0][half][nb * 32 + i]);
+        Bm = __builtin_bit_cast(bf16x8, sb[1][half][nb * 32 + i]);
+        Bl = __builtin_bit_cast(bf16x8, sb[2][half][nb * 32 + i]);
         nb_prev = nb;
       }
-      const bf16x8 Ah = __builtin_bit_cast(bf16x8, sa[0][cb * 32 + i][half]);
-      const bf16x8 Am = __builtin_bit_cast(bf16x8, sa[1][cb * 32 + i][half]);
-      const bf16x8 Al = __builtin_bit_cast(bf16x8, sa[2][cb * 32 + i][half]);
+      const bf16x8 Ah = __builtin_bit_cast(bf16x8, sa[0][half][cb * 32 + i]);
+      const bf16x8 Am = __builtin_bit_cast(bf16x8, sa[1][half][cb * 32 + i]);
+      const bf16x8 Al = __builtin_bit_cast(bf16x8, sa[2][half][cb * 32 + i]);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[t], 0, 0, 0);
       acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acs[t], 0, 0, 0);
       acs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acs[t], 0, 0, 0);
@@ -189,8 +189,9 @@ template <int NP>
 __global__ __launch_bounds__(256, 2) void k_spconv_wgrad_lds(const float *__restrict__ in, int in_ld, const float *__restrict__ gout, int go_ld,
                                                              const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_t, int kvol, int cin,
                                                              int cout, int n_rows, const int32_t *n_rows_dev, int nchunks, float *__restrict__ partial) {
-  __shared__ uint4 sA[2][3][128][2];  // [buffer][plane][channel][row half] x 8 bf16 (rows 8 h .. 8 h + 8 of the group)
-  __shared__ uint4 sB[2][3][128][2];
+  __shared__ uint4 sA[2][3][2][128];  // [buffer][plane][row half][channel] x 8 bf16 (rows 8 h .. 8 h + 8 of the group): lanes run along the
+                                      // channels in the staging stores and in the fragment reads alike -> consecutive 16-byte words, no bank conflicts
+  __shared__ uint4 sB[2][3][2][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, half = lane >> 5;
   const int c = tid & 127, rg = __builtin_amdgcn_readfirstlane(tid >> 7);
@@ -254,14 +255,14 @@ __global__ __launch_bounds__(256, 2) void k_spconv_wgrad_lds(const float *__rest
         ls3d_split_pair3_rne(RA[2], RA[3], h.y, m.y, l.y);                                       \
         ls3d_split_pair3_rne(RA[4], RA[5], h.z, m.z, l.z);                                       \
         ls3d_split_pair3_rne(RA[6], RA[7], h.w, m.w, l.w);                                       \
-        sA[buf][0][c][rg] = h; sA[buf][1][c][rg] = m; sA[buf][2][c][rg] = l;                     \
+        sA[buf][0][rg][c] = h; sA[buf][1][rg][c] = m; sA[buf][2][rg][c] = l;                     \
       }                                                                                          \
       if (b_live) {                                                                              \
         ls3d_split_pair3_rne(RB[0], RB[1], h.x, m.x, l.x);                                       \
         ls3d_split_pair3_rne(RB[2], RB[3], h.y, m.y, l.y);                                       \
         ls3d_split_pair3_rne(RB[4], RB[5], h.z, m.z, l.z);                                       \
         ls3d_split_pair3_rne(RB[6], RB[7], h.w, m.w, l.w);                                       \
-        sB[buf][0][c][rg] = h; sB[buf][1][c][rg] = m; sB[buf][2][c][rg] = l;                     \
+        sB[buf][0][rg][c] = h; sB[buf][1][rg][c] = m; sB[buf][2][rg][c] = l;                     \
       }                                                                                          \
     }                                                                                            \
     WGL_ROWS_LOAD(RA, RB, ANY)                                                                   \
