@@ -243,11 +243,12 @@ class UNetSCN3D(nn.Module):
         x = self.conv_input(x)  # ... the five level-1 launches are queued behind it ...
         x_conv1 = self.conv1(x)
         ev1 = self._stack_event(ev0)
-        # ... stage 2 = the four strided rulebooks of the encoder chained on device counts (ONE host sync for their sizes; the
-        # level-1 convolutions run meanwhile) ...
+        # ... stage 2 = the strided rulebooks of the encoder (the first one now, the other three chained on device counts behind the
+        # level-2 convolutions: two host syncs for their sizes, both while the main stream is busy) ...
         with _GeometryStream(x.indices, ready, join=False) as gs:
-            strided = [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
-            spconv.prebuild_conv_rulebooks(x, strided)
+            # the first strided rulebook on its own (one host sync for its size): level 2's geometry and convolutions do not wait for the
+            # other three, which follow - chained on device counts, one more sync - while the level-2 convolutions run
+            spconv.prebuild_conv_rulebooks(x, [self.conv2[0][0]])
         # ... then level by level: SubM rulebook, tile plan and the mask-sorted row order of the strided layer that enters the level
         # on the side stream, one event, the level's convolutions behind that event on the main stream.  The HOST alternates between
         # the two streams: submitting a level's ~30 small geometry launches takes longer than running them, so the main stream
@@ -267,6 +268,10 @@ class UNetSCN3D(nn.Module):
             x_enc = stage(x_enc)
             if lvl == 0:
                 x_conv2 = x_enc
+                with _GeometryStream(x.indices, ready, join=False) as gs:
+                    rb2 = x.find_indice_pair("spconv2")
+                    rest = [self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
+                    spconv.prebuild_conv_rulebooks(x, rest, coords=rb2.out_indices, shape=rb2.out_shape)
             elif lvl == 1:
                 x_conv3 = x_enc
         x_conv4 = x_enc

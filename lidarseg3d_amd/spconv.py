@@ -273,12 +273,15 @@ def prebuild_orders(x, layers):
             rb._orders[inv] = o
 
 
-def prebuild_conv_rulebooks(x, convs):
+def prebuild_conv_rulebooks(x, convs, coords=None, shape=None):
     """Rulebooks of a chain of strided SparseConv3d layers (each one's output sites are the next one's input sites, as in a
     UNet encoder) built back to back on device-side site counts, with ONE host synchronisation for all their sizes instead
     of one per layer.  Intermediate tables are allocated for the worst case (min(8 x inputs, grid cells)) and sliced once
-    the counts are known.  The rulebooks are registered under the layers' indice_keys."""
-    pend, coords, n_dev, shape = [], x.indices, None, list(x.spatial_shape)
+    the counts are known.  The rulebooks are registered under the layers' indice_keys.  coords / shape: the input sites of the first layer
+    when the chain does not start at x's own sites (a chain continued after an earlier call)."""
+    coords = x.indices if coords is None else coords
+    first_coords = coords
+    pend, n_dev, shape = [], None, list(x.spatial_shape if shape is None else shape)
     for c in convs:
         assert not c.subm and not c.inverse and c.indice_key is not None
         oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(coords, x.batch_size, shape, c.kernel_size, c.stride, c.padding,
@@ -286,7 +289,7 @@ def prebuild_conv_rulebooks(x, convs):
         pend.append((c, coords, shape, oc, cnt, nbr_out, nbr_inv, oshape))
         coords, n_dev, shape = oc, cnt, oshape
     counts = torch.stack([p[4] for p in pend]).tolist()  # host sync: tensor shapes need the counts
-    n_in = x.indices.shape[0]
+    n_in = first_coords.shape[0]
     for (c, icoords, ishape, oc, cnt, nbr_out, nbr_inv, oshape), (n_out, overflow) in zip(pend, counts):
         assert not overflow
         rb = _Rulebook()
