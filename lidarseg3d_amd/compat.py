@@ -49,8 +49,10 @@ def install(force=False):
     sys.modules["det3d.ops.pointnet2_batch.pointnet2_utils"] = pointnet2_utils
     mod("det3d.ops.voxel", Voxelization=voxel_ops.Voxelization, DynamicScatter=voxel_ops.DynamicScatter)
     from . import img_heads
-    mod("det3d.models.img_heads", CameraSemanticFeatureAggregationModule=img_heads.CameraSemanticFeatureAggregationModule)
-    mod("det3d.models.img_heads.fcn_mseg3d_head", CameraSemanticFeatureAggregationModule=img_heads.CameraSemanticFeatureAggregationModule)
+    mod("det3d.models.img_heads", CameraSemanticFeatureAggregationModule=img_heads.CameraSemanticFeatureAggregationModule,
+        FCNMSeg3DHead=img_heads.FCNMSeg3DHead)
+    mod("det3d.models.img_heads.fcn_mseg3d_head", CameraSemanticFeatureAggregationModule=img_heads.CameraSemanticFeatureAggregationModule,
+        FCNMSeg3DHead=img_heads.FCNMSeg3DHead)
     sys.modules["spconv"] = spconv
     spconv.__ls3d_alias__ = True
     try:  # the dynamic readers' scatter_mean / scatter_max

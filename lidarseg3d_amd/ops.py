@@ -795,6 +795,18 @@ def sfam(feats, logits, vx_off, batch, max_frame_voxels, c=None):
     return emb
 
 
+def sim_mode():
+    return _SIM
+
+
+def nchw_to_nhwc(x):
+    """[n, c, h, w] -> channels-last rows [n * h * w, c] (ls3d_nchw_to_nhwc)"""
+    n, c, h, w = x.shape
+    out = torch.empty((n * h * w, c), dtype=torch.float32, device=x.device)
+    check(_L().ls3d_nchw_to_nhwc(_ptr(x), n, c, h * w, _ptr(out), _stream(x)), "ls3d_nchw_to_nhwc")
+    return out
+
+
 def camera_sfam(feats, probs, batch_size):
     """CameraSemanticFeatureAggregationModule (fcn_mseg3d_head.py:23-51): feats [B*ncam, C, h, w], probs [B*ncam, cls, h, w]
     -> semantic embeddings [B, C, cls, 1].  The maps go channels-last once; then it is the LiDAR SFAM kernels with

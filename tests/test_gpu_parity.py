@@ -387,6 +387,54 @@ def test_semantickitti_config_end_to_end():
     assert float((got.argmax(1) == want["out_logits"].argmax(1)).float().mean()) >= 0.999
 
 
+def test_semantickitti_config_at_5cm_voxels_end_to_end():
+    """BASELINE configs[0] as worded (SemanticKITTI SDSeg3D at voxel 0.05 m -> grid 3008 x 3008 x 120, sparse shape [121, 3008, 3008]): the
+    hash index, the strided rulebooks' site maps, the tile keys and the 3-NN grid on a 1.09e9-cell lattice, two frames, against the oracle"""
+    cfg = dict(synth.KITTI)
+    cfg["voxel_size"] = [0.05, 0.05, 0.05]
+    assert list(orc.grid_size(cfg["voxel_size"], cfg["pc_range"])) == [3008, 3008, 120]
+    model, sd = _model(models_cfg.sdseg3d(num_class=20, cp=4, pc_range=cfg["pc_range"], voxel_size=cfg["voxel_size"]), seed=3)
+    frames = [synth.lidar_frame(5000, seed=33, **cfg), synth.lidar_frame(2500, seed=34, **cfg)]
+    pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    want = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])
+    scale = float(want["out_logits"].abs().max())
+    try:
+        for prec in ("f32", "bf16x6"):
+            ops.set_precision(prec)
+            model(dict(points=cu(pts), batch_size=2), return_loss=False)
+            got = model.point_head.forward_ret_dict["out_logits"].cpu()
+            assert got.shape == (7500, 20)
+            assert float((got - want["out_logits"]).abs().max()) <= 1e-3 + 2e-5 * scale, prec
+            assert float((got.argmax(1) == want["out_logits"].argmax(1)).float().mean()) >= 0.999
+    finally:
+        ops.set_precision("f32")
+
+
+def test_collate_points_on_device_equals_reference_layout():
+    """collate.collate_points on the device == the `points` entry of the reference's collate_kitti (frame index in column 0, frames
+    concatenated in order, torchie/parallel/collate.py:141-150), and the batched tensor voxelises to the oracle's coordinates"""
+    from lidarseg3d_amd import collate
+    cfg = synth.NUSC
+    frames = [synth.lidar_frame(n, seed=60 + i, **cfg) for i, n in enumerate((7000, 1, 3000))]
+    dev_pts = collate.collate_points([cu(f) for f in frames])
+    want = np.concatenate([np.pad(f, ((0, 0), (1, 0)), mode="constant", constant_values=i) for i, f in enumerate(frames)], 0)
+    assert dev_pts.dtype == torch.float32 and np.array_equal(dev_pts.cpu().numpy(), want)
+    v, c, n, nv = ops.voxelize_hard(dev_pts, cfg["voxel_size"], cfg["pc_range"], 5, 90000, batched=True)
+    ex = orc.collate_frames(frames, cfg["voxel_size"], cfg["pc_range"], 5, 30000)
+    V = int(nv)
+    assert V == ex["coordinates"].shape[0] and torch.equal(c[:V].cpu(), ex["coordinates"])
+
+
+def test_fcn_mseg3d_head_full_size_gpu():
+    """the FCN head's 1x1 convolutions, classifier and camera SFAM at the shipped size (6 cameras, 160 x 240 maps of HRNet-w18's 18 / 36 / 72 /
+    144 channels: 230 400 pixels x 270 -> 48 -> 48 -> 17) on the HIP kernels == the torch composition of the same modules"""
+    from tests.fcn_head_cases import fcn_head_case, fcn_head_check
+    head, inputs = fcn_head_case(DEV, ncam=6, h=160, w=240, batch=1)
+    fcn_head_check(head, inputs, 1)
+    head, inputs = fcn_head_case(DEV, ncam=5, h=40, w=60, batch=2, seed=3)
+    fcn_head_check(head, inputs, 2)
+
+
 def test_waymo_config_mseg3d_end_to_end():
     """BASELINE configs[3] geometry (Waymo MSeg3D: 5 cameras, 23 classes, range [-75.2,-75.2,-2,75.2,75.2,4], 2 frames)"""
     cfg = synth.WAYMO

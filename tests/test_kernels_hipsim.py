@@ -625,6 +625,25 @@ def test_unet_training_forward_backward_vs_autograd(monkeypatch):
                 and np.sum(d > 1e-3) <= max(1, 0.03 * d.size)), (k, np.median(d), d.max(), np.sum(d > 1e-3))
 
 
+def test_fcn_mseg3d_head_1x1_convs_vs_torch_composition():
+    """fcn_mseg3d_head.py:54-200 at the shipped shape (resize_concat of 4 levels -> 2 x [1x1 conv + BN + ReLU] -> 1x1 classifier -> camera
+    SFAM) on the HIP GEMM / SFAM kernels == the torch composition of the same modules; checkpoint key layout of the mmcv ConvModules"""
+    from tests.fcn_head_cases import fcn_head_case, fcn_head_check
+    head, inputs = fcn_head_case("cpu", ncam=3, h=8, w=12, batch=2)
+    keys = set(head.state_dict())
+    assert {"convs.0.conv.weight", "convs.0.bn.weight", "convs.0.bn.bias", "convs.0.bn.running_mean", "convs.0.bn.running_var",
+            "convs.1.conv.weight", "convs.1.bn.running_var", "conv_seg.weight", "conv_seg.bias"} <= keys
+    assert tuple(head.convs[0].conv.weight.shape) == (48, 270, 1, 1) and tuple(head.conv_seg.weight.shape) == (17, 48, 1, 1)
+    fcn_head_check(head, inputs, 2)
+    # the loss: weighted cross-entropy on the logits resized to the label maps
+    labels = torch.randint(0, 17, (6, 1, 16, 24))
+    head(dict(inputs=inputs, batch_size=2, images_sem_labels=labels), return_loss=True)
+    loss, parts = head.get_loss()
+    want = 0.5 * torch.nn.functional.cross_entropy(torch.nn.functional.interpolate(head.forward_ret_dict["image_logits"], size=(16, 24), mode="bilinear",
+                                                                                   align_corners=False), labels.squeeze(1), ignore_index=0)
+    assert abs(float(loss) - float(want)) <= 1e-6 and set(parts) == {"image_ce_loss"}
+
+
 def test_camera_sfam_vs_reference():
     from lidarseg3d_amd import img_heads
     g = golden("camera_sfam.npz")
