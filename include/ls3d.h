@@ -166,7 +166,11 @@ typedef struct {
   const float *w_embed, *b_embed, *w_compress, *b_compress;
   const ls3d_transvfe_layer_t *layers; /* host array [num_layers] */
   int num_layers, num_compressed, embed, heads, ffn, token_ld;
+  int planes; /* 0: f32 MFMA, the five GEMM weights (w_embed, wqkv, wo, w1, w2) in the packed nt = 2 layout of ls3d_gather_gemm_pack;
+               * 6 | 8: the exact 3-plane bf16 split (f32-grade, see ls3d_tile_conv), the five weights converted by ls3d_transvfe_pack_planes */
 } ls3d_transvfe_t;
+size_t ls3d_transvfe_planes_bytes(int K, int N);
+int ls3d_transvfe_pack_planes(const float *w_packed_nt2 /*K x N*/, int K, int N, void *out, ls3d_stream_t stream);
 int ls3d_transvfe(const float *voxels /*[n,P,C]*/, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
                   const ls3d_transvfe_t *model, float *out, int out_ld, ls3d_stream_t stream);
 

@@ -20,6 +20,7 @@
 // bound by the f32 matrix pipe (1568 MFMAs per 32-token tile for 3 layers; measured 1.08 ms for 65.9k voxels = 45 % of
 // the matrix-pipe bound, vs 1.75 ms for the layer-by-layer version).
 #include "common.h"
+#include "gemm_common.h"
 #include "vfe_descriptor.h"
 
 typedef float tv_f32x16 __attribute__((ext_vector_type(16)));
@@ -53,12 +54,87 @@ constexpr int TV_BCHUNK = 32 * 64;       // floats in one staged weight chunk
 // DIRECT: no LDS staging and no workgroup barrier - every wave reads its B fragments (float2 per lane, 512 contiguous bytes per
 // MFMA pair) straight from the L2-resident packed weights, one chunk ahead in registers; the 4 waves of a workgroup then never wait
 // for each other.  Experimental (ls3d_set_transvfe_direct), same arithmetic in the same order.
-template <bool DIRECT, typename Epi>
+// MODE 0: f32 MFMA, weights staged through LDS.  MODE 1: f32 MFMA, weights straight from L2 (experimental).  MODE 6 / 8: the exact
+// 3-plane bf16 split of both operands - Wp then points at the plane-packed weights of ls3d_transvfe_pack_planes
+// (per chunk [column block 2][K step 2][plane 3][kk 2][col 32] x 8 bf16 = 12 KB), the A fragment (the same 16 contiguous floats per
+// lane) is split in registers, 6 / 8 v_mfma_f32_32x32x16_bf16 per (column block, K step) with head x head in its own accumulator:
+// 24 / 32 MFMAs of 32 cycles per chunk instead of 32 of 64.
+constexpr int TV_PCHUNK = 768;  // uint4 per plane-packed chunk
+template <int MODE, typename Epi>
 __device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, const float *__restrict__ Wp, float *Bs, Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int col = lane & 31, kk = lane >> 5;
   const int nslab = N / 64, nkc = K / 32, nchunks = nslab * nkc;
-  if (DIRECT) {
+  if constexpr (MODE >= 6) {
+    const uint4 *Wq = (const uint4 *)Wp;
+    uint4 *Bq = (uint4 *)Bs;
+    uint4 r0 = Wq[tid], r1 = Wq[tid + 256], r2 = Wq[tid + 512];
+    __syncthreads();  // previous users of Bs are done
+    Bq[tid] = r0; Bq[tid + 256] = r1; Bq[tid + 512] = r2;
+    __syncthreads();
+    tv_f32x16 acc0, acc1, acs0, acs1;
+    int buf = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int slab = c / nkc, kc = c - slab * nkc;
+      if (kc == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; acs0[r] = 0.0f; acs1[r] = 0.0f; }
+      }
+      if (c + 1 < nchunks) {
+        const uint4 *src = Wq + (size_t)(c + 1) * TV_PCHUNK;
+        r0 = src[tid]; r1 = src[tid + 256]; r2 = src[tid + 512];
+      }
+      {
+        const float4 *ap = (const float4 *)(A + col * lda + kc * 32 + kk * 16);
+        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+        uint4 ah[2], am[2], al[2];  // [K step]: floats [8 s, 8 s + 8) of the lane's 16
+        ls3d_split_pair3_rne(a0.x, a0.y, ah[0].x, am[0].x, al[0].x);
+        ls3d_split_pair3_rne(a0.z, a0.w, ah[0].y, am[0].y, al[0].y);
+        ls3d_split_pair3_rne(a1.x, a1.y, ah[0].z, am[0].z, al[0].z);
+        ls3d_split_pair3_rne(a1.z, a1.w, ah[0].w, am[0].w, al[0].w);
+        ls3d_split_pair3_rne(a2.x, a2.y, ah[1].x, am[1].x, al[1].x);
+        ls3d_split_pair3_rne(a2.z, a2.w, ah[1].y, am[1].y, al[1].y);
+        ls3d_split_pair3_rne(a3.x, a3.y, ah[1].z, am[1].z, al[1].z);
+        ls3d_split_pair3_rne(a3.z, a3.w, ah[1].w, am[1].w, al[1].w);
+        const uint4 *bs = Bq + buf * TV_PCHUNK + lane;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah[st]), Am = __builtin_bit_cast(bf16x8, am[st]), Al = __builtin_bit_cast(bf16x8, al[st]);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const bf16x8 Bh = __builtin_bit_cast(bf16x8, bs[((nb * 2 + st) * 3 + 0) * 64]);
+            const bf16x8 Bm = __builtin_bit_cast(bf16x8, bs[((nb * 2 + st) * 3 + 1) * 64]);
+            const bf16x8 Bl = __builtin_bit_cast(bf16x8, bs[((nb * 2 + st) * 3 + 2) * 64]);
+            tv_f32x16 &hh = nb ? acc1 : acc0, &sm = nb ? acs1 : acs0;
+            hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, hh, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, sm, 0, 0, 0);
+            if constexpr (MODE >= 8) {
+              sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bm, sm, 0, 0, 0);
+              sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bl, sm, 0, 0, 0);
+            }
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, sm, 0, 0, 0);
+          }
+        }
+      }
+      if (kc == nkc - 1) {
+        tv_f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = acc0[r] + acs0[r]; o1[r] = acc1[r] + acs1[r]; }
+        epi(slab, o0, o1);
+      }
+      if (c + 1 < nchunks) {
+        uint4 *dst = Bq + (buf ^ 1) * TV_PCHUNK;
+        dst[tid] = r0; dst[tid + 256] = r1; dst[tid + 512] = r2;
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    return;
+  }
+  if constexpr (MODE == 1) {
     const float2 *wl = (const float2 *)Wp + kk * 16 * 32 + col;  // chunk c starts c * 1024 float2 further: chunks are contiguous
     float2 bc[16], bn[16];
 #pragma unroll
@@ -166,7 +242,7 @@ __device__ __forceinline__ void tv_layernorm(float *X, const float *g, const flo
   }
 }
 
-template <bool DIRECT>
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ voxels, const int32_t *__restrict__ num, int n,
                                                      const int32_t *n_dev, int P, int C, TvParams prm, float *__restrict__ out, int out_ld) {
   HIP_DYNAMIC_SHARED(float, smem)
@@ -174,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
   const int col = lane & 31, kk = lane >> 5;
   float *X = smem + wave * TV_WAVE_FLOATS;     // [32][TV_XS]
   float *T = X + 32 * TV_XS;                   // [32][TV_TS]
-  float *Bs = smem + 4 * TV_WAVE_FLOATS;       // [2][TV_BCHUNK]
+  float *Bs = smem + 4 * TV_WAVE_FLOATS;       // [2][TV_BCHUNK] floats, or [2][TV_PCHUNK] uint4 in the plane modes
   const int N = ls3d_count(n, n_dev);
   const int G = 32 / P;                        // voxels per wave tile
   const int per_block = 4 * G;
@@ -200,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
     }
     TV_WAVE_SYNC();
     // ---- embedding (+ norm1 of layer 0)
-    tv_gemm<DIRECT>(T, TV_TS, TV_KT, TV_E, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+    tv_gemm<MODE>(T, TV_TS, TV_KT, TV_E, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
       const float b0 = prm.be[col], b1 = prm.be[32 + col];
       TV_FOR_ACC(r, row) {
         X[row * TV_XS + col] = a0[r] + b0;
@@ -213,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
     for (int l = 0; l < prm.num_layers; ++l) {
       const TvLayer &L = prm.layer[l];
       // ---- QKV -> T[:, 0:192]
-      tv_gemm<DIRECT>(X, TV_XS, TV_E, 3 * TV_E, L.wqkv, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<MODE>(X, TV_XS, TV_E, 3 * TV_E, L.wqkv, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.bqkv[slab * 64 + col], b1 = L.bqkv[slab * 64 + 32 + col];
         TV_FOR_ACC(r, row) {
           T[row * TV_TS + slab * 64 + col] = a0[r] + b0;
@@ -263,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       }
       TV_WAVE_SYNC();
       // ---- out-proj + residual (from the normed X) -> X, then norm2
-      tv_gemm<DIRECT>(T, TV_TS, TV_E, TV_E, L.wo, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<MODE>(T, TV_TS, TV_E, TV_E, L.wo, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.bo[col], b1 = L.bo[32 + col];
         TV_FOR_ACC(r, row) {
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
@@ -274,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       tv_layernorm(X, L.n2g, L.n2b, L.n2eps);
       TV_WAVE_SYNC();
       // ---- FF1 + ReLU -> T[:, 0:128]
-      tv_gemm<DIRECT>(X, TV_XS, TV_E, TV_FF, L.w1, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<MODE>(X, TV_XS, TV_E, TV_FF, L.w1, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.b1[slab * 64 + col], b1 = L.b1[slab * 64 + 32 + col];
         TV_FOR_ACC(r, row) {
           T[row * TV_TS + slab * 64 + col] = fmaxf(a0[r] + b0, 0.0f);
@@ -283,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       });
       TV_WAVE_SYNC();
       // ---- FF2 + residual -> X, then norm1 of the next layer
-      tv_gemm<DIRECT>(T, TV_TS, TV_FF, TV_E, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<MODE>(T, TV_TS, TV_FF, TV_E, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.b2[col], b1 = L.b2[32 + col];
         TV_FOR_ACC(r, row) {
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
@@ -323,11 +399,67 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
 static int g_tv_direct = 0;
 extern "C" void ls3d_set_transvfe_direct(int on) { g_tv_direct = on ? 1 : 0; }
 
+// packed nt = 2 weights ([slab][K][32][2] floats: W[k][slab * 64 + nb * 32 + col] at ((slab * K + k) * 32 + col) * 2 + nb) -> plane chunks
+__global__ __launch_bounds__(256) void k_tv_pack_planes(const float *__restrict__ w, int K, int N, uint4 *__restrict__ out) {
+  const int nkc = K / 32;
+  const long long total = (long long)(N / 64) * nkc * TV_PCHUNK;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    long long r = t;
+    const int lane = (int)(r % 64); r /= 64;
+    const int pl = (int)(r % 3); r /= 3;
+    const int st = (int)(r % 2); r /= 2;
+    const int nb = (int)(r % 2); r /= 2;
+    const int kc = (int)(r % nkc); r /= nkc;
+    const int slab = (int)r;
+    const int col = lane & 31, kk = lane >> 5;
+    unsigned wd[4];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      unsigned hm[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = kc * 32 + kk * 16 + st * 8 + pr * 2 + e;
+        const float v = w[(((size_t)slab * K + k) * 32 + col) * 2 + nb];
+        const unsigned hb = ls3d_bf16_rne(v) << 16;
+        const float r1 = v - __uint_as_float(hb);
+        const unsigned mb = ls3d_bf16_rne(r1) << 16;
+        hm[e] = pl == 0 ? (hb >> 16) : pl == 1 ? (mb >> 16) : ls3d_bf16_rne(r1 - __uint_as_float(mb));
+      }
+      wd[pr] = hm[0] | (hm[1] << 16);
+    }
+    uint4 o; o.x = wd[0]; o.y = wd[1]; o.z = wd[2]; o.w = wd[3];
+    out[t] = o;
+  }
+}
+
+extern "C" size_t ls3d_transvfe_planes_bytes(int K, int N) { return (K % 32 || N % 64 || K < 32 || N < 64) ? 0 : (size_t)(N / 64) * (K / 32) * TV_PCHUNK * 16; }
+
+extern "C" int ls3d_transvfe_pack_planes(const float *w_packed_nt2, int K, int N, void *out, ls3d_stream_t stream) {
+  if (!w_packed_nt2 || !out || K < 32 || N < 64 || (K % 32) || (N % 64)) return LS3D_ERR_ARG;
+  const long long total = (long long)(N / 64) * (K / 32) * TV_PCHUNK;
+  hipLaunchKernelGGL(k_tv_pack_planes, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_packed_nt2, K, N, (uint4 *)out);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+template <int MODE>
+static int tv_launch(hipStream_t stream, long long blocks, int lds, const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
+                     const TvParams &prm, float *out, int out_ld) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)k_transvfe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_transvfe<MODE>, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  return LS3D_OK;
+}
+
 extern "C" int ls3d_transvfe(const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
                              const ls3d_transvfe_t *m, float *out, int out_ld, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!voxels || !num_points || !m || !out || n < 0 || P < 1 || C < 3) return LS3D_ERR_ARG;
   if (!m->w_embed || !m->b_embed || (m->num_layers > 0 && !m->layers)) return LS3D_ERR_ARG;
+  if (m->planes != 0 && m->planes != 6 && m->planes != 8) return LS3D_ERR_ARG;
   // the fused kernel is specialised for the reference's configuration (num_embed 64, 4 heads, FF 128, <= 32-wide tokens)
   if (m->embed != TV_E || m->heads != TV_H || m->ffn != TV_FF || m->token_ld != TV_KT || 2 * C + 8 > TV_KT || C > LS3D_MAX_FEAT || P > 32 ||
       m->num_layers < 0 || m->num_layers > TV_MAX_LAYERS || (m->w_compress && (m->num_compressed < 1 || m->num_compressed > 64)))
@@ -344,21 +476,17 @@ extern "C" int ls3d_transvfe(const float *voxels, const int32_t *num_points, int
     prm.layer[l] = TvLayer{s.wqkv, s.bqkv, s.wo, s.bo, s.w1, s.b1, s.w2, s.b2, s.n1_gamma, s.n1_beta, s.n2_gamma, s.n2_beta, s.n1_eps, s.n2_eps};
   }
   if (m->w_compress && !m->b_compress) return LS3D_ERR_ARG;
-  const int lds = (4 * TV_WAVE_FLOATS + 2 * TV_BCHUNK) * (int)sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_transvfe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_transvfe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return LS3D_ERR_LAUNCH;
-    attr_set = true;
-  }
+  const int lds_f32 = (4 * TV_WAVE_FLOATS + 2 * TV_BCHUNK) * (int)sizeof(float);
+  const int lds_planes = 4 * TV_WAVE_FLOATS * (int)sizeof(float) + 2 * TV_PCHUNK * 16;
   const int per_block = 4 * (32 / P);
   long long blocks = ((long long)n + per_block - 1) / per_block;
   if (blocks > 65536) blocks = 65536;
-  if (g_tv_direct)
-    hipLaunchKernelGGL(k_transvfe<true>, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
-  else
-    hipLaunchKernelGGL(k_transvfe<false>, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  int rc;
+  if (m->planes == 6) rc = tv_launch<6>(stream, blocks, lds_planes, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  else if (m->planes == 8) rc = tv_launch<8>(stream, blocks, lds_planes, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  else if (g_tv_direct) rc = tv_launch<1>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  else rc = tv_launch<0>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  if (rc != LS3D_OK) return rc;
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

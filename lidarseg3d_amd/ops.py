@@ -6,6 +6,7 @@ computation in Python and no fallback: tensors must live on the GPU (the only ex
 ``_lib.use_library_for_testing`` which swaps in tests/hipsim's host build of the same kernels and then
 requires CPU tensors).
 """
+import os as _os
 import ctypes
 
 import numpy as np
@@ -192,10 +193,13 @@ def vfe_tokens(voxels, num_points, tok_ld, n_dev=None):
 class TransVFEModel(object):
     """kernel-side description of a TransformerVoxelFeatureExtractor (keeps the packed tensors alive)"""
 
-    def __init__(self, embed, layers, compress, num_embed, num_head, ffn, token_ld):
+    def __init__(self, embed, layers, compress, num_embed, num_head, ffn, token_ld, planes=0):
         """embed: (w_packed_nt2, bias); layers: dicts with wqkv,bqkv,wo,bo,w1,b1,w2,b2 (packed nt=2 / biases), n1/n2 =
-        (gamma, beta, eps); compress: (plain weight [out, in], bias) or None"""
+        (gamma, beta, eps); compress: (plain weight [out, in], bias) or None.  planes = 6 | 8: the GEMM weights are the plane-packed
+        buffers of ls3d_transvfe_pack_planes (for_planes builds that variant from an f32 model)."""
         self._keep = [embed, layers, compress]
+        self._args = (num_embed, num_head, ffn, token_ld)
+        self._variants = {}
         arr = (_lib.TransVFELayer * max(len(layers), 1))()
         for i, l in enumerate(layers):
             for k in ("wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2"):
@@ -206,16 +210,40 @@ class TransVFEModel(object):
         self.num_out = compress[0].shape[0] if compress is not None else num_embed
         self.c = _lib.TransVFE(embed[0].data_ptr(), embed[1].data_ptr(), compress[0].data_ptr() if compress is not None else None,
                                compress[1].data_ptr() if compress is not None else None, arr, len(layers),
-                               compress[0].shape[0] if compress is not None else 0, num_embed, num_head, ffn, token_ld)
+                               compress[0].shape[0] if compress is not None else 0, num_embed, num_head, ffn, token_ld, int(planes))
+
+    def for_planes(self, products):
+        """the same reader on the exact 3-plane bf16 split with `products` (6 | 8) plane products per f32 product (built once)"""
+        v = self._variants.get(products)
+        if v is None:
+            embed, layers, compress = self._keep
+            num_embed, num_head, ffn, token_ld = self._args
+
+            def conv(w, K, N):
+                L = _L()
+                out = torch.empty((int(L.ls3d_transvfe_planes_bytes(K, N)),), dtype=torch.uint8, device=w.device)
+                check(L.ls3d_transvfe_pack_planes(_ptr(w), K, N, _ptr(out), _stream(w)), "ls3d_transvfe_pack_planes")
+                return out
+            e2 = (conv(embed[0], token_ld, num_embed), embed[1])
+            l2 = [dict(l, wqkv=conv(l["wqkv"], num_embed, 3 * num_embed), wo=conv(l["wo"], num_embed, num_embed), w1=conv(l["w1"], num_embed, ffn),
+                       w2=conv(l["w2"], ffn, num_embed)) for l in layers]
+            v = self._variants[products] = TransVFEModel(e2, l2, compress, num_embed, num_head, ffn, token_ld, planes=products)
+        return v
+
+
+_TRANSVFE_PLANES = _os.environ.get("LS3D_TRANSVFE_PLANES", "1") != "0"
 
 
 def transvfe(voxels, num_points, model):
     """the whole TransformerVoxelFeatureExtractor in one kernel; returns None if the configuration is not the one the fused
-    kernel is specialised for (the caller then composes the layer from the individual ops)"""
+    kernel is specialised for (the caller then composes the layer from the individual ops).  In the 3-plane modes of
+    ops.set_precision the reader's GEMMs run on the same exact bf16 split as the SubM convolutions."""
     n, p, c = voxels.shape
     _ptr(voxels)  # device / contiguity checks
+    products = tile_products() if _TRANSVFE_PLANES else 0
+    m = model.for_planes(products) if products else model
     out = torch.empty((n, model.num_out), dtype=torch.float32, device=voxels.device)
-    rc = _L().ls3d_transvfe(_ptr(voxels), _ptr(num_points), n, None, p, c, ctypes.byref(model.c), _ptr(out), model.num_out, _stream(voxels))
+    rc = _L().ls3d_transvfe(_ptr(voxels), _ptr(num_points), n, None, p, c, ctypes.byref(m.c), _ptr(out), model.num_out, _stream(voxels))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "ls3d_transvfe")
@@ -349,7 +377,6 @@ def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0, precision=F32):
     return out
 
 
-import os as _os
 _TARGET_BLOCKS = int(_os.environ.get("LS3D_TARGET_BLOCKS", "0"))
 
 

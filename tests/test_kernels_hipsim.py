@@ -317,6 +317,16 @@ def test_vfe_readers_vs_reference():
         assert np.array_equal(tv(vx, num).numpy(), fused) and np.array_equal(tv(vx[:7], num[:7]).numpy(), fused[:7])
     finally:
         ops.set_transvfe_direct(False)
+    try:  # the reader's GEMMs on the exact 3-plane bf16 split (what the 3-plane modes of ops.set_precision select): same golden
+        for prec in ("bf16x6", "bf16x8"):
+            ops.set_precision(prec)
+            planes = tv(vx, num).numpy()
+            assert not np.array_equal(planes, fused)  # another kernel variant ran ...
+            np.testing.assert_allclose(planes, g["trans"][sel], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(planes, fused, rtol=0, atol=2e-5)  # ... with f32-grade results
+            np.testing.assert_allclose(tv(vx[:7], num[:7]).numpy(), g["trans"][:7], rtol=0, atol=1e-4)
+    finally:
+        ops.set_precision("f32")
     try:  # and the layer-by-layer composition of the same module (configurations the fused kernel does not cover)
         readers._FUSED = False
         np.testing.assert_allclose(tv(vx, num).numpy(), g["trans"][sel], rtol=0, atol=1e-4)
