@@ -218,6 +218,9 @@ class TransVFEModel(object):
         if v is None:
             embed, layers, compress = self._keep
             num_embed, num_head, ffn, token_ld = self._args
+            if token_ld % 32 or num_embed % 64 or ffn % 64:  # not a shape of the fused kernel: ls3d_transvfe answers UNSUPPORTED either way
+                self._variants[products] = self
+                return self
 
             def conv(w, K, N):
                 L = _L()

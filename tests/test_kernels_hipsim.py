@@ -344,6 +344,15 @@ def test_vfe_readers_vs_reference():
         readers._FUSED = True
     assert a.shape == (50, 64)
     np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=1e-4)
+    # 4 point features (SemanticKITTI): 16-wide tokens are not a shape of the fused kernel -> the composed path, in every arithmetic
+    tv3 = readers.TransformerVoxelFeatureExtractor(4, 16, 64, 4, 2).eval()
+    c = tv3(vx[:20, :, :4].contiguous(), num[:20])
+    try:
+        ops.set_precision("bf16x6")
+        d = tv3(vx[:20, :, :4].contiguous(), num[:20])
+    finally:
+        ops.set_precision("f32")
+    assert c.shape == (20, 16) and torch.equal(c, d)
 
 
 def test_unet_small_vs_oracle():
