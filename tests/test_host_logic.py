@@ -305,6 +305,57 @@ dist.destroy_process_group()
 '''
 
 
+_SYNCBN_WORKER = r'''
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from lidarseg3d_amd import syncbn
+dist.init_process_group("gloo", init_method="env://")
+rank = dist.get_rank()
+for case, rows in enumerate(((70, 31), (5, 0), (1, 1))):  # unequal counts; a rank WITHOUT rows; one row each
+    g = torch.Generator().manual_seed(100 + case)
+    full = torch.randn(sum(rows), 6, generator=g) * 3 + torch.arange(6.0)
+    wgt = torch.randn(sum(rows), 6, generator=g)
+    lo = sum(rows[:rank])
+    x = full[lo:lo + rows[rank]].clone().requires_grad_(True)
+    bn = syncbn.CountSyncBatchNorm1d(6, eps=1e-3, momentum=0.01).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 6)); bn.bias.copy_(torch.linspace(-1, 1, 6))
+    y = bn(x)
+    (y * wgt[lo:lo + rows[rank]]).sum().backward()
+    gw = bn.weight.grad.clone(); dist.all_reduce(gw)   # what DDP's averaging sees, times the world size
+    ref = torch.nn.BatchNorm1d(6, eps=1e-3, momentum=0.01).train()
+    with torch.no_grad():
+        ref.weight.copy_(bn.weight); ref.bias.copy_(bn.bias)
+    xf = full.clone().requires_grad_(True)
+    yf = ref(xf) if sum(rows) > 1 else None
+    if yf is not None:
+        (yf * wgt).sum().backward()
+        assert torch.allclose(y, yf[lo:lo + rows[rank]].detach(), atol=2e-6), case
+        assert torch.allclose(x.grad, xf.grad[lo:lo + rows[rank]], atol=2e-5), case
+        assert torch.allclose(gw, ref.weight.grad, atol=2e-4), case
+        assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-6) and torch.allclose(bn.running_var, ref.running_var, atol=1e-5), case
+if rank == 0:
+    print("OK syncbn")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_count_weighted_syncbn_two_ranks_equals_batchnorm_on_all_rows(tmp_path):
+    """CountSyncBatchNorm1d on gloo, world_size 2: output, input gradient, parameter gradient and running statistics == nn.BatchNorm1d on the
+    concatenated rows, with unequal row counts and with a rank that holds NO rows"""
+    script = tmp_path / "sbn.py"
+    script.write_text(_SYNCBN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", str(script), ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "OK syncbn" in out.stdout
+
+
 def test_two_rank_ddp_with_count_weighted_syncbn_equals_one_rank_two_frames(tmp_path):
     """BASELINE configs[3] machinery on gloo (world_size 2, kernels on tests/hipsim): UNetSCN3D in train mode, one frame per rank with
     DIFFERENT voxel counts, CountSyncBatchNorm1d (train.py:313-321's SyncBN, count weighted) + DistributedDataParallel gradient
