@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
                                                     const int32_t *__restrict__ sorder, TilePlan p) {
   constexpr int NC = TC_KMAX * TC_TR;  // 4096 candidate slots
   constexpr int HS = 2 * NC;           // hash slots
-  __shared__ int s_row[TC_TR], s_srow[TC_TR];
+  __shared__ int s_row[TC_TR], s_srow[TC_TR], s_rank[TC_TR];
   __shared__ unsigned s_mask[TC_TR], s_smask[TC_TR];
   __shared__ int s_hash[HS];
   __shared__ int s_uniq[NC];
@@ -132,23 +132,36 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
     }
     for (int i = tid; i < HS; i += 256) s_hash[i] = -1;
     __syncthreads();
-    {  // neighbour masks + hash-set insertion of every neighbour: two threads per slot
-      const int slot = tid & (TC_TR - 1), part = tid >> 7;
+    // neighbour masks + hash-set insertion of every neighbour: two threads per slot.  The thread's <= 16 table entries are fetched with
+    // unconditional loads first (clamped addresses, masked afterwards: one memory latency instead of one per entry - under a condition
+    // hipcc waits for each load before the next) and stay in registers for the local-index pass at the end (no second read of the table).
+    constexpr int KPT = TC_KMAX / 2;
+    const int slot = tid & (TC_TR - 1), part = tid >> 7;
+    int vals[KPT];
+    {
       const int row = s_row[slot];
+      const int32_t *trow = tbl + (size_t)(row >= 0 ? row : 0) * kvol;
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const int k = part + 2 * i;
+        vals[i] = trow[k < kvol ? k : kvol - 1];
+      }
       unsigned m = 0u;
-      if (row >= 0)
-        for (int k = part; k < kvol; k += 2) {
-          const int v = tbl[(size_t)row * kvol + k];
-          if (v >= 0) {
-            m |= 1u << k;
-            unsigned h = ((unsigned)v * 2654435761u) >> 19;  // 13 bits
-            for (;;) {
-              const int prev = atomicCAS(&s_hash[h], -1, v);
-              if (prev == -1 || prev == v) break;
-              h = (h + 1) & (HS - 1);
-            }
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const int k = part + 2 * i;
+        if (row < 0 || k >= kvol) vals[i] = -1;
+        const int v = vals[i];
+        if (v >= 0) {
+          m |= 1u << k;
+          unsigned h = ((unsigned)v * 2654435761u) >> 19;  // 13 bits
+          for (;;) {
+            const int prev = atomicCAS(&s_hash[h], -1, v);
+            if (prev == -1 || prev == v) break;
+            h = (h + 1) & (HS - 1);
           }
         }
+      }
       if (m) atomicOr(&s_mask[slot], m);
     }
     __syncthreads();
@@ -163,6 +176,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
       }
       s_srow[rank] = s_row[tid];
       s_smask[rank] = mine;
+      s_rank[tid] = rank;
     }
     // compact the occupied hash slots -> s_uniq (unsorted), H
     constexpr int PER = HS / 256;
@@ -199,20 +213,25 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
         __syncthreads();
       }
     for (int i = tid; i < H; i += 256) p.thalo[(size_t)tile * p.hs + i] = s_uniq[i];
-    for (int c = tid; c < kvol * TC_TR; c += 256) {
-      const int k = c >> 7, s2 = c & (TC_TR - 1);
-      const int row = s_srow[s2];
-      const int v = row >= 0 ? tbl[(size_t)row * kvol + k] : -1;
-      unsigned li = 0xFFFFu;
-      if (v >= 0) {
-        int lo = 0, hi = H;  // lower bound of v in s_uniq (it is present)
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (s_uniq[mid] < v) lo = mid + 1; else hi = mid;
+    {  // local indices of the thread's own table entries (still in registers), written at the slot's position in the mask order
+      const int s2 = s_rank[slot];
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const int k = part + 2 * i;
+        if (k < kvol) {
+          const int v = vals[i];
+          unsigned li = 0xFFFFu;
+          if (v >= 0) {
+            int lo = 0, hi = H;  // lower bound of v in s_uniq (it is present)
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (s_uniq[mid] < v) lo = mid + 1; else hi = mid;
+            }
+            li = (unsigned)lo;
+          }
+          p.tloc[((size_t)tile * kvol + k) * TC_TR + s2] = (uint16_t)li;
         }
-        li = (unsigned)lo;
       }
-      p.tloc[((size_t)tile * kvol + k) * TC_TR + s2] = (uint16_t)li;
     }
     if (tid < TC_TR) p.trow[(size_t)tile * TC_TR + tid] = s_srow[tid];
     if (tid < 8) {
