@@ -13,8 +13,9 @@ timing barrier and the max-over-ranks of the elapsed time.
 
 Arithmetic of `value` (--precision, default "bf16x6"): the SubM layers run on the tile-halo kernel with every f32 operand split
 EXACTLY into three round-to-nearest bf16 planes and the 6 plane products of weight >= 2^-16 accumulated in f32 (head x head in its
-own accumulator); the strided and inverse convolutions and every dense layer run exact-f32 MFMA.  This mode is f32-grade — its
-end-to-end logit error against a float64 evaluation is BELOW the exact-f32 MFMA path's own, rms (0.6x) and max, on every frame
+own accumulator; the strided / inverse convolutions on the 6-product gather-GEMM, the TransVFE reader's GEMMs likewise); every other dense
+layer runs exact-f32 MFMA.  This mode is f32-grade — its
+end-to-end logit error against a float64 evaluation is BELOW the exact-f32 MFMA path's own, rms (0.4x) and max, on every frame
 measured (tests/test_gpu_parity.py::test_sdseg3d_every_arithmetic_vs_float64_..., profiles/round2_accuracy_*.json, DESIGN.md 4.1) —
 and the 8-product variant (`f32_grade_8_product_mode`) and the exact-f32 path (`exact_f32_mode`) are timed beside it.
 
@@ -45,8 +46,8 @@ DTYPES = {
     "f32": "f32",
     "bf16x8": "f32 (f32-grade: SubM layers on exact 3-plane bf16 splits, 8 of 9 plane products on bf16 MFMA with f32 accumulation; "
               "everything else exact-f32 MFMA)",
-    "bf16x6": "f32 (f32-grade: SubM layers on exact 3-plane bf16 splits, the 6 plane products of weight >= 2^-16 on bf16 MFMA with f32 "
-              "accumulation; everything else exact-f32 MFMA)",
+    "bf16x6": "f32 (f32-grade: sparse convolutions and the reader's GEMMs on exact 3-plane bf16 splits, the 6 plane products of weight >= 2^-16 on "
+              "bf16 MFMA with f32 accumulation, head x head in its own accumulator; the head's dense layers exact-f32 MFMA)",
     "bf16x3": "f32 via split-bf16 (bf16x3 MFMA, f32 accumulate)",
 }
 

@@ -281,10 +281,15 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
     __syncthreads();
     unsigned long long rem = s_kmask;
     f32x16 acc[NT];
+    f32x16 acs[PL == 3 ? NT : 1];  // PL == 3: the five small products (head x head alone in `acc`: the bf16 MFMA's accumulate is biased, tileconv.hip)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+#pragma unroll
+    for (int n = 0; n < (PL == 3 ? NT : 1); ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acs[n][r] = 0.0f;
     if (rem) {
       int k_cur = __ffsll((long long)rem) - 1;
       rem &= rem - 1;
@@ -365,9 +370,15 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
               acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bh1, acc[n], 0, 0, 0);
             }
           } else {
-            uint4 a0[3], a1[3];  // [plane]: head / middle / tail
-            ls3d_split8x3(a_cur[0], a_cur[1], a0[0], a0[1], a0[2]);
-            ls3d_split8x3(a_cur[2], a_cur[3], a1[0], a1[1], a1[2]);
+            uint4 a0[3], a1[3];  // [plane]: head / middle / tail, round-to-nearest planes (the products left out are zero-mean)
+            ls3d_split_pair3_rne(a_cur[0].x, a_cur[0].y, a0[0].x, a0[1].x, a0[2].x);
+            ls3d_split_pair3_rne(a_cur[0].z, a_cur[0].w, a0[0].y, a0[1].y, a0[2].y);
+            ls3d_split_pair3_rne(a_cur[1].x, a_cur[1].y, a0[0].z, a0[1].z, a0[2].z);
+            ls3d_split_pair3_rne(a_cur[1].z, a_cur[1].w, a0[0].w, a0[1].w, a0[2].w);
+            ls3d_split_pair3_rne(a_cur[2].x, a_cur[2].y, a1[0].x, a1[1].x, a1[2].x);
+            ls3d_split_pair3_rne(a_cur[2].z, a_cur[2].w, a1[0].y, a1[1].y, a1[2].y);
+            ls3d_split_pair3_rne(a_cur[3].x, a_cur[3].y, a1[0].z, a1[1].z, a1[2].z);
+            ls3d_split_pair3_rne(a_cur[3].z, a_cur[3].w, a1[0].w, a1[1].w, a1[2].w);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -378,11 +389,11 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
                 const bf16x8 bm = __builtin_bit_cast(bf16x8, bs[((n * 2 + t) * 3 + 1) * 64]);
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, bs[((n * 2 + t) * 3 + 2) * 64]);
                 // the six products of weight >= 2^-16, smallest first
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
+                acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acs[n], 0, 0, 0);
+                acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acs[n], 0, 0, 0);
+                acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acs[n], 0, 0, 0);
+                acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acs[n], 0, 0, 0);
+                acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acs[n], 0, 0, 0);
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
               }
             }
@@ -410,6 +421,12 @@ __global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__re
 #undef LS3D_B_LD
 #undef LS3D_B_ST
 #undef LS3D_STORE_B
+    if constexpr (PL == 3) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] += acs[n][r];
+    }
     gg_epilogue<NT, 1, TR, 64>(acc, &Bs[0][0], s_rows, s_stat, wave, 0, kk, col, n0, cout, e, out, out_ld);
   }
 }

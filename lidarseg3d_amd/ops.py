@@ -235,6 +235,7 @@ class TransVFEModel(object):
 
 
 _TRANSVFE_PLANES = _os.environ.get("LS3D_TRANSVFE_PLANES", "1") != "0"
+_GATHER_X6 = _os.environ.get("LS3D_GATHER_X6", "1") != "0"  # bf16x6: strided / inverse layers on the 6-product gather-GEMM (split accumulators); 0: exact f32
 
 
 def transvfe(voxels, num_points, model):
@@ -493,10 +494,13 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     # split-bf16 only where it pays and where its error budget is spent wisely: the sparse convolutions (matrix-pipe
     # bound).  Dense Linear layers (TransVFE, heads, SF-Phase) are memory-bound and stay in exact f32.
     prec = _PRECISION if (_PRECISION != F32 and cin % 32 == 0 and tbl is not None) else F32
-    if prec == BF16X8 or (prec == BF16X6 and _TILE):
+    if prec == BF16X8 or (prec == BF16X6 and _TILE and not _GATHER_X6):
         # the 3-plane modes = tile-halo kernel (ls3d_tile_conv, 8 / 6 plane products, head x head in its own accumulator) for the layers
-        # that take it; every other sparse layer (strided / inverse convolutions: 3 neighbours per row, mask-sorted gathers win) runs
-        # exact f32.  (With the tile path switched off, "bf16x6" is round 1's 6-product gather-GEMM.)
+        # that take it.  The other sparse layers (strided / inverse convolutions: 1.6 pairs per output row, mask-sorted gathers win):
+        # "bf16x8" runs them exact f32; "bf16x6" on the 6-product gather-GEMM, which since round 2 also keeps head x head in its own
+        # accumulator and splits with round-to-nearest planes (measured: end-to-end error 0.38x of the exact-f32 path's, 0.53x with
+        # these layers in exact f32; LS3D_GATHER_X6=0 restores that).  (With the tile path switched off, "bf16x6" is that gather-GEMM
+        # for every layer.)
         prec = F32
     pipe = pipeline_geometry(cout, rows_hint, prec) if (_PIPELINE and tbl is not None and cin % 32 == 0 and kvol <= 32 and ln is None) else None
     if pipe is not None:
