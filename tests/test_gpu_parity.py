@@ -655,7 +655,7 @@ def test_bf16x6_is_f32_grade_gemm_and_end_to_end():
     pw = PackedWeight(cu(b).reshape(1, 128, 128).contiguous(), 1, 128, 128, 128)
     errs = {}
     try:
-        ops.set_tile(False)  # tile path off: "bf16x6" = the 6-product gather-GEMM for every layer, dense ones included
+        ops.set_tile(False)  # tile path off: "bf16x6" = the 6-product gather-GEMM for every sparse layer
         for prec in ("f32", "bf16x6"):
             ops.set_precision(prec)
             out = ops.gather_gemm(cu(a), pw, tbl=ident, cout=128)

@@ -459,7 +459,7 @@ def test_gather_gemm_bf16x6_is_f32_grade(m, k, n, nt, monkeypatch):
     mag = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)  # the scale rounding errors live on
     errs = {}
     try:
-        ops.set_tile(False)  # with the tile path off "bf16x6" is the 6-product gather-GEMM for every layer, dense ones included
+        ops.set_tile(False)  # with the tile path off "bf16x6" is the 6-product gather-GEMM for every sparse layer
         for prec in ("f32", "bf16x6"):
             ops.set_precision(prec)
             out = ops.gather_gemm(torch.from_numpy(a), pw, tbl=ident, cout=n)
