@@ -128,8 +128,9 @@ def timed_steps(step, steps, warmup, dist=None, dev=None):
                          max_ms=per[-1])
 
 
-def cpu_baseline_worker(n_points, seed, threads, repeats):
-    """runs in a child process: the CPU oracle's full SDSeg3D forward on one frame, timed `repeats` times"""
+def cpu_baseline_worker(n_points, seed, threads, repeats, dump=None):
+    """runs in a child process: the CPU oracle's full SDSeg3D forward on one frame, timed `repeats` times; `dump`: .npy path that
+    receives the logits of the last run (the parity check of the frame the GPU legs time)"""
     from lidarseg3d_amd import synth
     from oracle import ref as orc
     torch.set_num_threads(threads)
@@ -144,27 +145,48 @@ def cpu_baseline_worker(n_points, seed, threads, repeats):
     ts = []
     for _ in range(repeats):
         t0 = time.time()
-        orc.sdseg3d_forward(sd, [frame], synth.NUSC["voxel_size"], synth.NUSC["pc_range"])
+        ret = orc.sdseg3d_forward(sd, [frame], synth.NUSC["voxel_size"], synth.NUSC["pc_range"])
         ts.append(time.time() - t0)
+    if dump:
+        np.save(dump, ret["out_logits"].numpy())
     print(json.dumps({"seconds": ts}))
 
 
-def _cpu_run(n_points, seed, threads, repeats, timeout_s):
+def _cpu_run(n_points, seed, threads, repeats, timeout_s, dump=None):
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(n_points), str(seed), str(threads), str(repeats)],
-                       env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(n_points), str(seed), str(threads), str(repeats)]
+                       + ([dump] if dump else []), env=env, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
     return json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
 
 
-def cpu_baseline(n_points, seed):
+def parity_vs_cpu(gpu_logits, cpu_logits, num_class=17):
+    """the GPU logits of the timed frame against the CPU oracle's logits of the same frame and weights (BASELINE metric: frames/sec
+    + per-point mIoU-parity).  Random-init logits reach several thousand, so the absolute figure is also given at the |logit|max = 10
+    scale the north_star's 1e-3 tolerance is tested at (tests/test_gpu_parity.py::test_sdseg3d_120k_frame_logits_and_miou_vs_oracle)"""
+    from oracle import ref as orc
+    g, c = gpu_logits.double(), torch.from_numpy(cpu_logits).double()
+    scale = float(c.abs().max())
+    d = (g - c).abs()
+    pg, pc = g.argmax(1).numpy(), c.argmax(1).numpy()
+    return dict(points=int(c.shape[0]), logit_abs_max=scale, max_abs_diff=float(d.max()), max_rel_diff=float(d.max()) / scale,
+                max_abs_diff_at_logit_scale_10=10.0 * float(d.max()) / scale, rms_rel_diff=float(d.pow(2).mean().sqrt()) / scale,
+                argmax_agreement=float((pg == pc).mean()), miou_gpu_labels_vs_cpu_labels=orc.miou(pg, pc, num_class),
+                within_1e3_at_scale_10=bool(10.0 * float(d.max()) / scale <= 1e-3))
+
+
+def cpu_baseline(n_points, seed, gpu_logits=None):
     """the CPU oracle (oracle/ref.py, a port: the reference has no CPU forward), rank 0 / N=1 only, bounded: median of 3 warmed
     runs of ONE full-size frame on min(cores, 32) threads (torch-CPU index_add_/mm of the restatement stops scaling there: on a
     256-thread host the uncapped run is >10x slower), plus a 1-thread figure on a 1/8-size frame"""
     cores = os.cpu_count() or 1
     threads = min(cores, 32)
+    dump = None
+    if gpu_logits is not None and gpu_logits.shape[0] == n_points:
+        import tempfile
+        dump = os.path.join(tempfile.gettempdir(), "ls3d_cpu_logits_%d.npy" % os.getpid())
     try:
-        ts = _cpu_run(n_points, seed, threads, 3, 300)
+        ts = _cpu_run(n_points, seed, threads, 3, 300, dump)
         med = statistics.median(ts)
         out = dict(value=1.0 / med, unit="frames/s", cores=threads, kind="port",
                    sample="median of 3 warmed runs of 1 frame of %d points (%s s), full SDSeg3D forward incl. CPU voxelization, %d of %d host "
@@ -172,6 +194,14 @@ def cpu_baseline(n_points, seed):
                           % (n_points, "/".join("%.1f" % t for t in ts), threads, cores))
     except Exception as e:  # never let the baseline take the bench down
         return dict(value=None, unit="frames/s", cores=threads, kind="port", sample="failed: %r" % (e,))
+    if dump is not None:
+        try:
+            out["parity"] = parity_vs_cpu(gpu_logits, np.load(dump))
+        except Exception as e:
+            out["parity"] = dict(error=repr(e))
+        finally:
+            if os.path.exists(dump):
+                os.remove(dump)
     try:
         small = max(n_points // 8, 1000)
         t1 = _cpu_run(small, seed, 1, 1, 200)[0]
@@ -232,10 +262,11 @@ def main():
     ap.add_argument("--row-order", choices=["mask", "none"], default="mask")
     ap.add_argument("--model", choices=["sdseg3d", "mseg3d"], default="sdseg3d",
                     help="sdseg3d = BASELINE configs[1] (the metric's config); mseg3d = configs[2] (LiDAR + 6-camera features)")
-    ap.add_argument("--cpu-baseline-worker", nargs=4, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-worker", nargs="+", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        cpu_baseline_worker(*[int(v) for v in args.cpu_baseline_worker])
+        w = args.cpu_baseline_worker
+        cpu_baseline_worker(*[int(v) for v in w[:4]], dump=(w[4] if len(w) > 4 else None))
         return
     extra_modes = not (args.no_extra_modes or args.no_fast_mode)
 
@@ -325,6 +356,7 @@ def main():
 
     main_leg = measure(args.precision, args.steps, args.warmup, S, True)
     ref_logits = model.point_head.forward_ret_dict["out_logits"].clone()
+    value_logits_cpu = ref_logits[:args.points].cpu() if (B == 1 and S == 1) else None  # frame 0 of rank 0 = the CPU baseline's frame
     stages = stage_breakdown(model, pts, B) if (S == 1 and args.model == "sdseg3d") else None
 
     legs = {}
@@ -417,7 +449,9 @@ def main():
                 "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead)",
                 "nuScenes MSeg3D (ImprovedMeanVFE->UNetSCN3D->PointSegMSeg3DHead GF+SF-Phase, image_features [1,6,48,160,240])")
         if world == 1 and not args.no_cpu_baseline and args.model == "sdseg3d":
-            out["cpu_baseline"] = cpu_baseline(args.cpu_points or args.points, 100)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_points or args.points, 100, value_logits_cpu)
+            if "parity" in out["cpu_baseline"]:  # GPU logits of the TIMED frame (value's arithmetic) vs the CPU oracle's
+                out["parity_vs_cpu"] = out["cpu_baseline"].pop("parity")
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
