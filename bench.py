@@ -40,7 +40,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
+PMC_RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_pmc.json")  # tools/collect_profiles.sh -> profiles/summarize_pmc.py
+PLANE_PRODUCTS = {"bf16x6": 6, "bf16x8": 8, "bf16x3": 3}
 
 DTYPES = {
     "f32": "f32",
@@ -407,28 +410,45 @@ def main():
             "latency": main_leg["latency"],
         }
         if c:
+            np_ = PLANE_PRODUCTS.get(args.precision)
+            # the matrix-pipe view of the same stack: every f32 product of the pair model is `np_` bf16 plane products on
+            # v_mfma_f32_32x32x16_bf16 (exact f32: one product on v_mfma_f32_32x32x2_f32); "useful" counts the pairs of the rulebooks,
+            # not the dense-over-pairs work the tiles execute on absent neighbours
+            if np_:
+                mfma = dict(unit="TFLOP/s", dtype="bf16", plane_products_per_f32_product=np_, achieved=np_ * main_leg["tflops"], peak=BF16_MFMA_PEAK_TFLOPS,
+                            frac=np_ * main_leg["tflops"] / BF16_MFMA_PEAK_TFLOPS, f32_equivalent_tflops=main_leg["tflops"])
+            else:
+                mfma = dict(unit="TFLOP/s", dtype="f32", achieved=main_leg["tflops"], peak=F32_MFMA_PEAK_TFLOPS, frac=main_leg["tflops"] / F32_MFMA_PEAK_TFLOPS)
             out["roofline"] = {
-                "bound": "hbm", "kernel": "sparse-conv stack: %d launches/frame (%d k_tile_conv + %d k_gather_gemm), two HIP-event brackets per frame"
-                                          % (c["launches"], c["tile_launches"], c["launches"] - c["tile_launches"]),
+                # what the counters say (profiles/round3_pmc_sq.md): the stack is bound by the matrix pipe + its LDS operand feed, HBM moves
+                # ~0.2x of the pair model.  achieved / peak / frac stay SURVEY.md 8(d)'s pair-model figure (algorithmic gather bytes over
+                # the measured duration against the HBM peak), the headline the scope table defines; `mfma` and `hbm_physical_GBps` are the
+                # physical utilisations of the two units.
+                "bound": "mfma", "kernel": "sparse-conv stack: %d launches/frame (%d k_tile_conv + %d k_gather_gemm), two HIP-event brackets per frame"
+                                           % (c["launches"], c["tile_launches"], c["launches"] - c["tile_launches"]),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "model": "pair model, SURVEY.md 8(d): sum over the layers of P_l * (Cin + Cout) * 4 bytes",
                 "avg_launch_us": 1e3 * mean_ms / max(c["launches"], 1), "algo_bytes_per_frame": c["algo_bytes"],
                 "algo_bytes_per_launch": c["algo_bytes"] / max(c["launches"], 1), "tflops_useful": main_leg.get("tflops"),
-                "sparse_conv_ms_per_frame": stack,
+                "sparse_conv_ms_per_frame": stack, "mfma": mfma, "hbm_physical_GBps": None,
                 # the traffic no kernel can avoid (each referenced input row, each output row and the weights once per launch) and the
-                # HBM time it stands for: the stack is matrix-pipe work far above it (the pair model above prices the gather traffic
-                # of SURVEY.md 8d, which the tile-halo kernel no longer moves)
+                # HBM time it stands for
                 "b_min": {"bytes_per_frame": c["b_min_bytes"], "ms_at_hbm_peak": 1e3 * c["b_min_bytes"] / (HBM_PEAK_GBS * 1e9),
                           "achieved_GBps": c["b_min_bytes"] / (mean_ms * 1e-3) / 1e9 if mean_ms else 0.0,
                           "frac": c["b_min_bytes"] / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if mean_ms else 0.0},
             }
-            pmc = os.path.join(ROOT, "profiles", "round2_pmc.json")
-            if args.model == "sdseg3d" and args.points == 120000 and os.path.exists(pmc):
-                # HBM-side bytes per sparse-conv launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-                # command (profiles/round2_pmc.md; counters cannot be collected from inside the timed run)
-                j = json.load(open(pmc))
-                if args.precision in j:
-                    out["roofline"]["traffic"] = j[args.precision]["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/round2_pmc.json (2*FETCH_SIZE+WRITE_SIZE, KiB, corrected per MI355X_MICROARCH.md)"
+            if args.model == "sdseg3d" and args.points == 120000 and os.path.exists(PMC_RECORD):
+                # counters cannot be collected from inside the timed run: separate rocprofv3 --pmc passes of this same command on the
+                # same build (tools/collect_profiles.sh; the record names the commit and the kernels it saw)
+                j = json.load(open(PMC_RECORD))
+                r = j.get(args.precision)
+                if r:
+                    out["roofline"]["traffic"] = r["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/round3_pmc.json: (2*FETCH_SIZE+WRITE_SIZE)*1024 per sparse-conv launch, corrected per MI355X_MICROARCH.md; kernels " + ", ".join(r.get("kernels", []))
+                    out["roofline"]["hbm_physical_GBps"] = r["traffic_bytes_per_launch"] * c["launches"] / (mean_ms * 1e-3) / 1e9 if mean_ms else None
+                    if r.get("mfma_busy") is not None:
+                        out["roofline"]["mfma"]["mfma_busy"] = r["mfma_busy"]
+                        out["roofline"]["mfma"]["mfma_busy_source"] = "profiles/round3_pmc_sq.md: SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, time-weighted over the stack's kernels"
         if stages is not None:
             out["stages_ms"] = stages
         for prec, leg in legs.items():

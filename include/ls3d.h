@@ -304,22 +304,35 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
  *                    plane product except tail x tail (2^-32 relative) — f32-grade: the result differs from exact f32
  *                    arithmetic by less than f32 summation-order noise; products = 6: the BF16X6 arithmetic.
  *                    cin % 16 == 0, in_ld % 4 == 0, cout <= 128.  Summation order per output row is fixed by the plan.
- *                    workspace (optional, ls3d_tile_conv_workspace_bytes(n_rows, cout) bytes, 16-byte aligned): lets launches of
- *                    cin >= 64 and up to 512 tiles (fewer tiles than the 2 x 256 workgroup slots of the chip) run TWO work units per tile, each over half of the input channels; the unit
- *                    that finishes second adds the other's partial sums (a + b == b + a: results do not depend on which) and
- *                    runs the epilogue.  The plan carries the per-tile arrival counters: one launch at a time per plan. */
+ *                    Workgroups are dispatched in the plan's most-expensive-tile-first order (ls3d_tile_build's last step).
+ *                    workspace (optional, ls3d_tile_conv_workspace_bytes(n_rows, cout) bytes, 16-byte aligned, per call) +
+ *                    counters (optional, ls3d_tile_conv_counter_bytes() bytes): let layers of cin >= 64 in launches of <= 512
+ *                    tiles (fewer than the 2 x 256 workgroup slots of the chip) run TWO work units per tile, each over half of
+ *                    the input channels; the unit that finishes second adds the other's partial sums (a + b == b + a: results do
+ *                    not depend on which) and runs the epilogue.  The counters are caller-owned: zeroed ONCE, then handed to
+ *                    any number of calls that are ordered one after the other (one array per stream); a completed call leaves
+ *                    every counter even, nothing is reset.  A plan is read-only for ls3d_tile_conv: one plan may serve
+ *                    concurrent launches on different streams, each with its own workspace and counters.  Which tiles are
+ *                    split is a function of the plan and of `flags` only, so results are bit-reproducible.
+ *                    flags (per call, 0 = defaults): bits 2-4 timing ablations for profiling (skip the MFMAs / the weight DMA /
+ *                    the halo staging: results invalid); bits 6-7 channel split (0 = the rule above, 1 = never, 2 = as many
+ *                    tiles as the workspace allows); bits 8-19: number of split tiles (the last ones of the dispatch order) + 1
+ *                    for any launch; bits 20-29: number of split tiles + 1 for launches of more than 512 tiles (default: none -
+ *                    measured without gain); bit 30: halo planes in LDS without the bank swizzle.  Every flag value gives the
+ *                    same bits for the rows of unsplit tiles.
+ *   ls3d_tile_build / ls3d_tile_plan flags: bit 0 = dispatch the tiles in plan (spatial) order instead of most expensive first. */
 int ls3d_tile_keys(const int32_t *coords /*[n,4] b,z,y,x*/, int n, const int32_t *n_dev, const int32_t shape_zyx_host[3], int batch,
                    uint32_t *keys, ls3d_stream_t stream);
 size_t ls3d_tile_plan_bytes(int n_rows, int kvol);
 int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_rows_dev, int kvol, const int32_t *spatial_order, void *plan,
-                    size_t plan_bytes, ls3d_stream_t stream);
+                    size_t plan_bytes, int flags, ls3d_stream_t stream);
 /* keys -> sort -> plan in one call (what a caller does for every table of a frame): ls3d_tile_keys, the in-library stable radix
  * sort, ls3d_tile_build back to back on `stream`.  workspace: ls3d_tile_plan_workspace_bytes(n_rows) bytes, 16-byte aligned; it
  * holds the spatial order at byte offset roundup(4 n_rows, 256) afterwards. */
 size_t ls3d_tile_plan_workspace_bytes(int n_rows);
 int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_rows, const int32_t *n_rows_dev, int kvol,
                    const int32_t shape_zyx_host[3], int batch, void *workspace, size_t workspace_bytes, void *plan, size_t plan_bytes,
-                   ls3d_stream_t stream);
+                   int flags, ls3d_stream_t stream);
 /* stable LSD radix sort of (uint32 key, int32 value) pairs by the low `bits` key bits, ascending; vals == NULL: the values are
  * the positions 0..n-1 (the result is the sorting permutation).  keys_out may be NULL.  Not in place.  Replaces torch.argsort
  * for the row orders of the sparse convolutions (spatial tile keys, neighbour-mask keys). */
@@ -329,15 +342,10 @@ int ls3d_radix_sort(const uint32_t *keys, const int32_t *vals, int n, int bits, 
 size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout);
 int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream);
 size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout);
+size_t ls3d_tile_conv_counter_bytes(void);
 int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout,
                    int products, const ls3d_epilogue_t *epi_host, float *out, int out_ld, void *workspace, size_t workspace_bytes,
-                   ls3d_stream_t stream);
-/* tuning knob (A/B measurements).  bit 0: each XCD walks a contiguous range of tiles instead of tile = workgroup index (results
- * identical); bits 2-4: timing ablations for profiling (skip the MFMAs / the weight DMA / the halo staging: results invalid);
- * bit 5: ls3d_tile_conv_pack splits the weights into truncated instead of round-to-nearest planes (accuracy A/B; both exact);
- * bits 6-7: split over the input channels 0 = default rule, 1 = never, 2 = whenever a workspace is given; bits 8+: tile limit of
- * the default rule. */
-void ls3d_set_tile_map(int flags);
+                   int32_t *counters, int flags, ls3d_stream_t stream);
 
 /* Backward of the sparse convolutions (spconv v1.x indice_conv_backward).
  *   grad_in : ls3d_gather_gemm on grad_out with the TRANSPOSED table (SubM: the same table; SparseConv3d: nbr_inv;

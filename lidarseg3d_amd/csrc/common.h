@@ -47,6 +47,7 @@ __device__ __forceinline__ void ls3d_glds16x3(const void *gbase, unsigned voff0,
 __device__ __forceinline__ float ls3d_load_agent(const float *p) { return *p; }
 __device__ __forceinline__ void ls3d_store_agent(float *p, float v) { *p = v; }
 #define LS3D_WAIT_VMCNT(n) ((void)0)
+#define LS3D_WAIT_LGKMCNT0() ((void)0)
 #define LS3D_SCHED_FENCE() ((void)0)
 #define LS3D_RAW_BARRIER() __syncthreads()
 #else
@@ -73,6 +74,7 @@ __device__ __forceinline__ void ls3d_glds16x3(const void *gbase, unsigned voff0,
 __device__ __forceinline__ float ls3d_load_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ls3d_store_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #define LS3D_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define LS3D_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  /* every LDS read issued so far has returned */
 #define LS3D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  /* nothing is scheduled across: e.g. keeps a batch of ds_reads together */
 #define LS3D_RAW_BARRIER()                          \
   do {                                              \

@@ -15,7 +15,9 @@ struct EpiDev {
 //      lane (col,kk) = output row (r&3) + 8*(r>>2) + 4*kk, column col) are transposed into row-major tiles in the weight
 //      buffer, then all NTH threads apply scale/shift, residual, ReLU, pair-sum, optionally a row LayerNorm (whole row in
 //      this workgroup's slab), and store whole rows with float4.
-template <int NT, int WC, int TR, int RPP, int NTH = 256>
+//      CS = false: acc[n] = column block n of the wave's 32 rows (wave = row block wr, column slab wc of WC);
+//      CS = true (column-stationary waves, k_tile_conv_cs; WC = 1): acc[i] = row block wr * NT + i, column block wc of the NT.
+template <int NT, int WC, int TR, int RPP, int NTH = 256, bool CS = false>
 __device__ __forceinline__ void gg_epilogue(f32x16 (&acc)[NT], float *stage, const int *s_rows, float *s_stat, int wr, int wc, int kk,
                                             int col, int n0, int cout, const EpiDev &e, float *__restrict__ out, int out_ld) {
   constexpr int WSLAB = NT * 32, SLAB = WSLAB * WC;
@@ -24,7 +26,18 @@ __device__ __forceinline__ void gg_epilogue(f32x16 (&acc)[NT], float *stage, con
 #pragma unroll
   for (int pass = 0; pass < TR / RPP; ++pass) {
     __syncthreads();  // previous readers of the buffer (MFMA loop or previous pass) are done
-    if ((wr * 32) / RPP == pass) {
+    if constexpr (CS) {
+      static_assert(WC == 1, "column-stationary waves: one slab");
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int r0 = (wr * NT + i) * 32;
+        if (r0 / RPP == pass) {
+          float *dst = stage + (r0 % RPP + 4 * kk) * SLAB + wc * 32 + col;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB] = acc[i][r];
+        }
+      }
+    } else if ((wr * 32) / RPP == pass) {
       float *dst = stage + ((wr * 32) % RPP + 4 * kk) * SLAB + wc * WSLAB + col;
 #pragma unroll
       for (int n = 0; n < NT; ++n)

@@ -86,6 +86,7 @@ struct TilePlan {
   int32_t *tmeta;   // [T][TC_META]
   int32_t *thalo;   // [T][hs]       unique input rows of the tile, ascending
   uint16_t *tloc;   // [T][kvol][128] position of tbl[row][k] in the tile's halo, 0xFFFF = no neighbour
+  int32_t *torder;  // [T]           dispatch order of the tiles: most expensive first (k_tile_order)
 };
 
 static inline size_t tc_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -99,14 +100,15 @@ static TilePlan tc_plan(void *buf, int n_rows, int kvol) {
   p.trow = (int32_t *)b; b += tc_align((size_t)p.ntiles * TC_TR * 4);
   p.tmeta = (int32_t *)b; b += tc_align((size_t)p.ntiles * TC_META * 4);
   p.thalo = (int32_t *)b; b += tc_align((size_t)p.ntiles * p.hs * 4);
-  p.tloc = (uint16_t *)b;
+  p.tloc = (uint16_t *)b; b += tc_align((size_t)p.ntiles * kvol * TC_TR * 2);
+  p.torder = (int32_t *)b;
   return p;
 }
 
 extern "C" size_t ls3d_tile_plan_bytes(int n_rows, int kvol) {
   if (n_rows < 0 || kvol < 1) return 0;
   const size_t t = (size_t)(n_rows + TC_TR - 1) / TC_TR;
-  return tc_align(t * TC_TR * 4) + tc_align(t * TC_META * 4) + tc_align(t * kvol * TC_TR * 4) + tc_align(t * kvol * TC_TR * 2);
+  return tc_align(t * TC_TR * 4) + tc_align(t * TC_META * 4) + tc_align(t * kvol * TC_TR * 4) + tc_align(t * kvol * TC_TR * 2) + tc_align(t * 4);
 }
 
 // one workgroup per tile.  The tile's distinct input rows: the <= kvol*128 table entries go through an LDS hash set (insertion
@@ -245,8 +247,63 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
   }
 }
 
+// Dispatch order of the tiles of a plan: most expensive first (cost = LDS passes x active kernel offsets, what the tile's MFMA
+// time is proportional to), so that the last workgroups of a launch are the cheap ones; ties keep the spatial order.  One
+// workgroup, stable counting sort on 256 cost levels: the rank of a tile among the equal keys of its round of 1024 comes from
+// wave ballots over the key bits (as in k_rs_scatter) - no atomics on the placement, so the order (and with it the choice of the
+// tiles that ls3d_tile_conv splits over the input channels) is the same on every run.
+__global__ __launch_bounds__(1024) void k_tile_order(TilePlan p, int lpt) {
+  __shared__ int s_base[256];
+  __shared__ int s_cnt[16][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = p.ntiles;
+  auto key_of = [&](int t) -> unsigned {
+    if (!lpt) return 0u;
+    const int32_t *m = p.tmeta + (size_t)t * TC_META;
+    const int nseg = (m[0] + TC_HCAP - 1) / TC_HCAP;
+    int cost = m[6] ? nseg * __popc((unsigned)m[1]) : 0;
+    return 255u - (unsigned)(cost < 255 ? cost : 255);
+  };
+  if (tid < 256) s_base[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) atomicAdd(&s_base[key_of(t)], 1);  // counts are order-independent
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int d = 0; d < 256; ++d) { const int c = s_base[d]; s_base[d] = run; run += c; }
+  }
+  __syncthreads();
+  for (int r0 = 0; r0 < T; r0 += 1024) {
+    const int t = r0 + tid;
+    const bool live = t < T;
+    for (int w = 0; w < 16; ++w) if (tid < 256) s_cnt[w][tid] = 0;
+    __syncthreads();
+    const unsigned d = live ? key_of(t) : 0u;
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long m = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? m : ~m;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (live && rank == 0) s_cnt[wave][d] = __popcll(peers);
+    __syncthreads();
+    if (live) {
+      int off = s_base[d] + rank;
+      for (int w = 0; w < wave; ++w) off += s_cnt[w][d];
+      p.torder[off] = t;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      int c = 0;
+      for (int w = 0; w < 16; ++w) c += s_cnt[w][tid];
+      s_base[tid] += c;
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_rows_dev, int kvol, const int32_t *spatial_order, void *plan,
-                               size_t plan_bytes, ls3d_stream_t stream) {
+                               size_t plan_bytes, int flags, ls3d_stream_t stream) {
   if (n_rows == 0 && kvol >= 1 && kvol <= TC_KMAX) return LS3D_OK;
   if (!tbl || !spatial_order || !plan || n_rows < 0 || kvol < 1) return LS3D_ERR_ARG;
   if (kvol > TC_KMAX) return LS3D_ERR_UNSUPPORTED;
@@ -256,6 +313,7 @@ extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_
   TilePlan p = tc_plan(plan, n_rows, kvol);
   hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, (hipStream_t)stream, tbl, n_rows, n_rows_dev,
                      kvol, spatial_order, p);
+  hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, (flags & 1) ? 0 : 1);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
@@ -271,7 +329,7 @@ extern "C" size_t ls3d_tile_plan_workspace_bytes(int n_rows) {
 // keys -> stable radix sort -> plan, back to back on `stream`: what a caller does for every table of a frame
 extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_rows, const int32_t *n_rows_dev, int kvol,
                               const int32_t shape_zyx[3], int batch, void *workspace, size_t workspace_bytes, void *plan, size_t plan_bytes,
-                              ls3d_stream_t stream_) {
+                              int flags, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows == 0 && shape_zyx && kvol >= 1 && kvol <= TC_KMAX && batch >= 1) return LS3D_OK;
   if (!tbl || !coords || !shape_zyx || !workspace || !plan || n_rows < 0 || kvol < 1 || batch < 1) return LS3D_ERR_ARG;
@@ -292,6 +350,7 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
   TilePlan p = tc_plan(plan, n_rows, kvol);
   hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, stream, tbl, n_rows, n_rows_dev, kvol,
                      (const int32_t *)order, p);
+  hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, p, (flags & 1) ? 0 : 1);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
@@ -335,8 +394,6 @@ __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src
   }
 }
 
-static int g_tile_trunc_split = 0;  // measurement switch (ls3d_set_tile_map bit 5): truncated weight planes as in round 2's first version
-
 extern "C" size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout) {
   return (size_t)kvol * cin_pad * (cout <= 32 ? 32 : cout <= 64 ? 64 : 128) * 6;
 }
@@ -347,7 +404,7 @@ extern "C" int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, 
   const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;  // column blocks of the kernel variant that will run (zero padded)
   const long long total = (long long)kvol * (cin_pad / 16) * nt * 3 * 64;
   hipLaunchKernelGGL(k_tile_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt,
-                     g_tile_trunc_split, (uint4 *)w_packed);
+                     0, (uint4 *)w_packed);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
@@ -373,8 +430,8 @@ constexpr int TC_THREADS = 256;
 // NP = plane products per f32 product (6 or 8).
 template <int NT, int NP>
 __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in, int in_ld, TilePlan p, const uint4 *__restrict__ wpk,
-                                                             int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int flat_map, int ablate,
-                                                             int ksplit, float *partial) {
+                                                             int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int ablate, int swz,
+                                                             int n_split, float *partial, int *counters) {
   constexpr int PU = NT * 192;             // 16-byte units of one (offset, chunk) weight piece
   constexpr int PB = NT * 3;               // ... in 1 KB LDS-DMA blocks
   constexpr int G = 4 / NT;                // offsets per step
@@ -396,22 +453,28 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   const unsigned voff0 = (unsigned)lane * 16u, voff1 = voff0 + 1024u, voff2 = voff0 + 2048u;
   const uint16_t *loc_w = s_loc + wave * 32 + col;
   uint4 *const dma_lds0 = Bs + dma_g * PU + dma_j * 64, *const dma_lds1 = dma_lds0 + TC_WBUF_UNITS;
-  // ksplit == 2: a tile is two work units, each over half of the 16-channel chunks; the unit that finishes second adds the other's
-  // partial sums (through `partial`, [tile][part][NT * 16][256] floats) and runs the epilogue.  Half-size units fill the tail of a
-  // launch (677 tiles on 512 workgroup slots = one full round + a third of one) and give the small levels two workgroups per CU.
-  const int units = p.ntiles * ksplit, t8 = (units + 7) / 8;
-  for (int b = blockIdx.x; b < t8 * 8; b += gridDim.x) {
-    // unit = workgroup index: neighbouring tiles (unequal work: dense near the sensor) are spread over the XCDs.  The
-    // alternative (flat_map == 0: each XCD walks a contiguous range, halos of neighbours meet in one L2) measured 0-40 % slower:
-    // the halo is staged once per tile anyway, balance matters more (profiles/round2_experiments.md)
-    const int unit = flat_map ? b : (b & 7) * t8 + (b >> 3);
-    if (unit >= units) continue;
-    const int tile = ksplit == 2 ? unit >> 1 : unit, part = ksplit == 2 ? unit & 1 : 0;
+  // One workgroup per work unit, dispatched in the plan's most-expensive-first order (p.torder).  The LAST n_split tiles of that
+  // order - the cheapest ones, the tail of the launch - are two units each, over half of the 16-channel chunks: the unit that
+  // finishes second adds the other's partial sums (through `partial`, [split tile][part][NT * 16][256] floats) and runs the
+  // epilogue.  Half-size units at the end of the dispatch order keep the last round of a launch from running full-size tiles alone
+  // on their CUs (677 tiles on 512 workgroup slots), and give launches of fewer tiles than slots two workgroups per CU.
+  const int nfull = p.ntiles - n_split;
+  {
+    int tile, part = 0, ksplit = 1, sidx = 0;
+    if ((int)blockIdx.x < nfull) {
+      tile = p.torder[blockIdx.x];
+    } else {
+      const int v = (int)blockIdx.x - nfull;
+      sidx = v >> 1;
+      tile = p.torder[nfull + sidx];
+      part = v & 1;
+      ksplit = 2;
+    }
     const int *meta = p.tmeta + (size_t)tile * TC_META;
     const int H = meta[0];
     const unsigned kmask = (unsigned)meta[1];
     const unsigned wmask = (unsigned)__builtin_amdgcn_readfirstlane(meta[2 + wave]);
-    if (meta[6] == 0) continue;
+    if (meta[6] == 0) return;
     if (tid < TC_TR) s_rows[tid] = p.trow[(size_t)tile * TC_TR + tid];
     {
       const uint4 *src = (const uint4 *)(p.tloc + (size_t)tile * kvol * TC_TR);
@@ -469,7 +532,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
               uint2 h, m, l;
               ls3d_split_pair3_rne(hv[j].x, hv[j].y, h.x, m.x, l.x);
               ls3d_split_pair3_rne(hv[j].z, hv[j].w, h.y, m.y, l.y);
-              char *dst = smem + hrow * 32 + q * 8;
+              char *dst = smem + hrow * 32 + ((q * 8) ^ (((hrow >> 3) & swz) << 4));  // TC_SWZ: see tc_frag
               *(uint2 *)(dst) = h;
               *(uint2 *)(dst + TC_PLANE_BYTES) = m;
               *(uint2 *)(dst + 2 * TC_PLANE_BYTES) = l;
@@ -494,7 +557,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
             if (k >= 0 && ((wmask >> k) & 1u) && !(ablate & 4)) {
               const int li = lc[g] - seg_lo;
               const int lz = ((unsigned)li < (unsigned)TC_HCAP) ? li : TC_HCAP;  // absent / other pass -> the zero row
-              const uint4 *hp = (const uint4 *)smem + lz * 2 + kk;
+              const uint4 *hp = (const uint4 *)smem + lz * 2 + (kk ^ ((lz >> 3) & swz));
               const uint4 *bs = Bs + buf * TC_WBUF_UNITS + g * PU + lane;
               // weight fragments plane by plane (the MFMAs are grouped by the weight plane they need): plane 2 is read after plane
               // 0's MFMAs are issued and takes over its registers: 32 instead of 48 VGPRs of fragments
@@ -543,65 +606,64 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] += acs[n][r];
     if (ksplit == 2) {
-      float *mine = partial + ((size_t)tile * 2 + part) * (NT * 16 * TC_THREADS) + tid;
+      float *mine = partial + ((size_t)sidx * 2 + part) * (NT * 16 * TC_THREADS) + tid;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ls3d_store_agent(mine + (n * 16 + r) * TC_THREADS, acc[n][r]);
       LS3D_WAIT_VMCNT(0);  // the stores are at the coherence point ...
       __syncthreads();     // ... for every thread of the unit, before the counter says so
-      if (tid == 0) s_hid[0] = atomicAdd(p.tmeta + (size_t)tile * TC_META + 7, 1);
+      // arrival counter of the split tile: never reset - the first unit of a launch finds it even, the second odd (the caller
+      // provides the counters zeroed once; every completed launch leaves them even)
+      if (tid == 0) s_hid[0] = atomicAdd(counters + sidx, 1) & 1;
       __syncthreads();
-      if (s_hid[0] == 0) continue;  // first of the two: the other unit finishes the tile
-      const float *other = partial + ((size_t)tile * 2 + (part ^ 1)) * (NT * 16 * TC_THREADS) + tid;
+      if (s_hid[0] == 0) return;  // first of the two: the other unit finishes the tile
+      const float *other = partial + ((size_t)sidx * 2 + (part ^ 1)) * (NT * 16 * TC_THREADS) + tid;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] += ls3d_load_agent(other + (n * 16 + r) * TC_THREADS);  // a + b == b + a: order-independent
-      if (tid == 0) p.tmeta[(size_t)tile * TC_META + 7] = 0;  // ready for the next launch on this plan
     }
     gg_epilogue<NT, 1, TC_TR, 64, TC_THREADS>(acc, (float *)smem, s_rows, s_stat, wave, 0, kk, col, 0, cout, e, out, out_ld);
   }
 }
 
-static int g_tile_flat_map = 1, g_tile_ablate = 0, g_tile_ksplit = 0, g_tile_ksplit_max_tiles = 512;
-extern "C" void ls3d_set_tile_map(int flags) {
-  g_tile_flat_map = (flags & 1) ? 0 : 1;
-  g_tile_ablate = flags & 28;
-  g_tile_trunc_split = (flags >> 5) & 1;
-  g_tile_ksplit = (flags >> 6) & 3;                            // bits 6-7: channel split 0 = auto, 1 = off, 2 = always
-  if (flags >> 8) g_tile_ksplit_max_tiles = flags >> 8;        // bits 8+: auto applies up to this many tiles  // bits 2-4: timing ablations (no MFMA / no weight DMA / no halo staging): results invalid
-}
-
 template <int NT, int NP>
 static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TilePlan &p, const uint4 *wpk, int cin, int cout, const EpiDev &e, float *out,
-                     int out_ld, int ksplit, float *partial) {
+                     int out_ld, int ablate, int swz, int n_split, float *partial, int *counters) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
-  const int nwg = (p.ntiles * ksplit + 7) / 8 * 8;
-  hipLaunchKernelGGL((k_tile_conv<NT, NP>), dim3((unsigned)nwg), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout, e, out, out_ld,
-                     g_tile_flat_map, g_tile_ablate, ksplit, partial);
+  hipLaunchKernelGGL((k_tile_conv<NT, NP>), dim3((unsigned)(p.ntiles + n_split)), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout,
+                     e, out, out_ld, ablate, swz, n_split, partial, counters);
   return LS3D_OK;
 }
 
-// workspace of ls3d_tile_conv for the split over the input channels: two partial accumulator sets per tile
+// the split over the input channels: two partial accumulator sets per split tile in the per-call workspace, one arrival counter per
+// split tile in a caller-owned, zeroed-once array of TC_SPLIT_MAX ints
+constexpr int TC_SPLIT_MAX = 512;       // = the chip's workgroup slots for this kernel (2 per CU x 256 CUs)
+static inline size_t tc_partial_bytes(int n_split, int nt) { return tc_align((size_t)n_split * 2 * nt * 16 * TC_THREADS * sizeof(float)); }
+
 extern "C" size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout) {
   if (n_rows <= 0 || cout < 1 || cout > 128) return 0;
-  const size_t nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;
-  return (size_t)((n_rows + TC_TR - 1) / TC_TR) * 2 * nt * 16 * TC_THREADS * sizeof(float);
+  const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;
+  const int t = (n_rows + TC_TR - 1) / TC_TR, ns = t < TC_SPLIT_MAX ? t : TC_SPLIT_MAX;
+  return tc_partial_bytes(ns, nt);
 }
 
+extern "C" size_t ls3d_tile_conv_counter_bytes(void) { return (size_t)TC_SPLIT_MAX * sizeof(int32_t); }
+
 extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout, int products,
-                              const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, ls3d_stream_t stream_) {
+                              const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, int32_t *counters, int flags,
+                              ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows == 0 && w_packed && kvol >= 1 && kvol <= TC_KMAX && cin >= 16 && !(cin % 16) && cout >= 1 && cout <= 128 && (products == 6 || products == 8))
     return LS3D_OK;
   if (!in || !plan || !w_packed || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
-  if (((uintptr_t)in & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)plan & 15)) return LS3D_ERR_ARG;
+  if (((uintptr_t)in & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)plan & 15) || ((uintptr_t)workspace & 15)) return LS3D_ERR_ARG;
   if (kvol > TC_KMAX || cout > 128) return LS3D_ERR_UNSUPPORTED;
   if (products != 6 && products != 8) return LS3D_ERR_ARG;
   if (n_rows == 0) return LS3D_OK;
@@ -613,20 +675,29 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
     if ((e.ln_gamma != nullptr) != (e.ln_beta != nullptr) || (e.ln_gamma && e.pair)) return LS3D_ERR_ARG;
   }
   const TilePlan p = tc_plan(const_cast<void *>(plan), n_rows, kvol);
-  // split over the input channels (two units per tile) when the caller provides the workspace, the layer has >= 4 chunks and the
-  // launch is small enough for the granularity to matter (g_tile_ksplit: 0 = this rule, 1 = never, 2 = whenever possible)
-  int ksplit = 1;
-  if (workspace && workspace_bytes >= ls3d_tile_conv_workspace_bytes(n_rows, cout) && cin >= 64 && g_tile_ksplit != 1 &&
-      (g_tile_ksplit == 2 || p.ntiles <= g_tile_ksplit_max_tiles))
-    ksplit = 2;
+  const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;  // column blocks of the kernel variant (the weights are packed for it)
+  const int ablate = flags & 28, split_mode = (flags >> 6) & 3, forced = (flags >> 8) & 0xFFF, tail = (flags >> 20) & 0x3FF;
+  // Split over the input channels (two work units per tile, each over half of the 16-channel chunks) when the caller provides the
+  // workspace and the counters and the layer has >= 4 chunks: every tile of a launch that does not fill the chip's TC_SPLIT_MAX
+  // workgroup slots (level 4 of the 120k frame: 160 -> 125 us per layer).  Larger launches: the `tail` tiles at the end of the
+  // dispatch order when flags ask for it (measured on the 677- and 1071-tile levels: no gain over LPT dispatch alone, so off by default).
+  int n_split = 0;
+  if (workspace && counters && cin >= 64 && split_mode != 1) {
+    n_split = p.ntiles <= TC_SPLIT_MAX ? p.ntiles : (tail ? tail - 1 : 0);
+    if (forced) n_split = forced - 1;
+    if (split_mode == 2) n_split = p.ntiles;
+    if (n_split > TC_SPLIT_MAX) n_split = TC_SPLIT_MAX;
+    if (n_split > p.ntiles) n_split = p.ntiles;
+    if (workspace_bytes < tc_partial_bytes(n_split, nt)) return LS3D_ERR_WORKSPACE;
+  }
   float *partial = (float *)workspace;
+  const int swz = (flags >> 30) & 1 ? 0 : 1;
   int rc;
-#define TC_GO(NTW_) (products == 8 ? tc_launch<NTW_, 8>(stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ksplit, partial) \
-                                   : tc_launch<NTW_, 6>(stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ksplit, partial))
-  if (cout <= 32) rc = TC_GO(1);        // weights packed with 1 column block
-  else if (cout <= 64) rc = TC_GO(2);   // ... with 2
-  else rc = TC_GO(4);                   // ... with 4
-#undef TC_GO
+#define TC_ARGS stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ablate, swz, n_split, partial, (int *)counters
+  rc = nt == 1 ? (products == 8 ? tc_launch<1, 8>(TC_ARGS) : tc_launch<1, 6>(TC_ARGS))
+     : nt == 2 ? (products == 8 ? tc_launch<2, 8>(TC_ARGS) : tc_launch<2, 6>(TC_ARGS))
+               : (products == 8 ? tc_launch<4, 8>(TC_ARGS) : tc_launch<4, 6>(TC_ARGS));
+#undef TC_ARGS
   if (rc != LS3D_OK) return rc;
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;

@@ -548,24 +548,17 @@ def set_tile(on, kinds=None, min_cc=None):
         _TILE_MIN_CC = int(min_cc)
 
 
-def set_tile_map(flags):
-    """A/B knob of ls3d_tile_conv (include/ls3d.h: ls3d_set_tile_map)"""
-    global _TILE_FLAGS_SENT
-    _TILE_FLAGS_SENT = True
-    _L().ls3d_set_tile_map(int(flags))
+_TILE_FLAGS = int(_os.environ.get("LS3D_TILE_FLAGS", "0"))       # per-call flags of ls3d_tile_conv (include/ls3d.h), for A/B runs of unmodified scripts
+_TILE_PLAN_FLAGS = int(_os.environ.get("LS3D_TILE_PLAN_FLAGS", "0"))  # ... of ls3d_tile_plan / ls3d_tile_build
 
 
-_TILE_FLAGS_SENT = False
-
-
-def _tile_flags_from_env():
-    """LS3D_TILE_FLAGS=<int>: ls3d_set_tile_map flags for A/B runs of unmodified scripts (applied at the first tile launch)"""
-    global _TILE_FLAGS_SENT
-    if not _TILE_FLAGS_SENT:
-        _TILE_FLAGS_SENT = True
-        f = int(_os.environ.get("LS3D_TILE_FLAGS", "0"))
-        if f:
-            _L().ls3d_set_tile_map(f)
+def set_tile_flags(conv=None, plan=None):
+    """A/B knobs: the `flags` argument that tile_conv / tile_plan pass to ls3d_tile_conv / ls3d_tile_plan (include/ls3d.h)"""
+    global _TILE_FLAGS, _TILE_PLAN_FLAGS
+    if conv is not None:
+        _TILE_FLAGS = int(conv)
+    if plan is not None:
+        _TILE_PLAN_FLAGS = int(plan)
 
 
 def tile_products():
@@ -608,12 +601,12 @@ def tile_plan(tbl, coords, shape_zyx, batch, order=None):
     if order is None:  # keys -> in-library radix sort -> plan: one C call (ls3d_tile_plan)
         ws = _ws(L.ls3d_tile_plan_workspace_bytes(n), tbl)
         check(L.ls3d_tile_plan(_ptr(tbl), _ptr(coords), n, None, kvol, _i3(shape_zyx), int(batch), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(p.buf),
-                               ctypes.c_size_t(p.buf.numel()), _stream(tbl)), "ls3d_tile_plan")
-        seg = (n * 4 + 255) // 256 * 256
-        p.order = ws[seg:seg + 4 * n].view(_i32)
+                               ctypes.c_size_t(p.buf.numel()), _TILE_PLAN_FLAGS, _stream(tbl)), "ls3d_tile_plan")
+        p.order = None  # the spatial order lives in the call's workspace and is not needed once the plan is built
         return p
     p.order = order
-    check(L.ls3d_tile_build(_ptr(tbl), n, None, kvol, _ptr(order), _ptr(p.buf), ctypes.c_size_t(p.buf.numel()), _stream(tbl)), "ls3d_tile_build")
+    check(L.ls3d_tile_build(_ptr(tbl), n, None, kvol, _ptr(order), _ptr(p.buf), ctypes.c_size_t(p.buf.numel()), _TILE_PLAN_FLAGS, _stream(tbl)),
+          "ls3d_tile_build")
     return p
 
 
@@ -640,26 +633,33 @@ def tile_conv(x, w, plan, cout=None, products=None, scale=None, shift=None, res_
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0, _vp(ln[0]) if ln is not None else ctypes.c_void_p(0),
                    _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
-    _tile_flags_from_env()
-    ws = _tile_ws(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout), x) if (_TILE_KSPLIT and cin >= 64) else None
+    split = _TILE_KSPLIT and cin >= 64
+    ws = _tile_ws(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout), x) if split else None
     check(_L().ls3d_tile_conv(_ptr(x), in_ld, _ptr(plan.buf), plan.n_rows, kvol, _ptr(w.for_tile()), cin, cout, products, ctypes.byref(epi),
-                              _vp_any(out), out_ld, _vp(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), _stream(x)), "ls3d_tile_conv")
+                              _vp_any(out), out_ld, _vp(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
+                              _vp(_tile_counters(x) if split else None), _TILE_FLAGS, _stream(x)), "ls3d_tile_conv")
     return out
 
 
 _TILE_KSPLIT = _os.environ.get("LS3D_TILE_KSPLIT", "1") != "0"  # hand ls3d_tile_conv the workspace for its split over the input channels
-_TILE_WS = {}
+_TILE_COUNTERS = {}
+
+
+def _tile_counters(like):
+    """arrival counters of ls3d_tile_conv's channel split: one zeroed-once array per (device, stream) - the launches of a stream
+    run one after the other, which is all the counters need (include/ls3d.h).  A recycled stream handle finds an all-even array:
+    harmless."""
+    key = (like.device, torch.cuda.current_stream(like.device).cuda_stream) if like.is_cuda else "host-emulation"
+    buf = _TILE_COUNTERS.get(key)
+    if buf is None:
+        buf = _TILE_COUNTERS[key] = torch.zeros((int(_L().ls3d_tile_conv_counter_bytes()) // 4,), dtype=_i32, device=like.device)
+    return buf
 
 
 def _tile_ws(nbytes, like):
-    """grow-only scratch per (device, stream): the launches of a stream run one after the other, so they share it"""
-    if not like.is_cuda:
-        return _ws(nbytes, like)
-    key = (like.device, torch.cuda.current_stream(like.device).cuda_stream)
-    buf = _TILE_WS.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = _TILE_WS[key] = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=like.device)
-    return buf
+    """per-call scratch from torch's stream-ordered caching allocator: no host synchronisation, the block is reused by the next
+    launch on the stream (round 2 kept a grow-only buffer keyed by the raw stream handle, which a destroyed stream can hand on)"""
+    return _ws(nbytes, like)
 
 
 _WGRAD_PLANES = _os.environ.get("LS3D_WGRAD_PLANES", "1") != "0"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Turn the rocprofv3 counter passes of tests/run_gpu_checks.sh (PMC=1) into profiles/round2_pmc.{md,json} and round2_pmc_sq.md.
+"""Turn the rocprofv3 counter passes of tests/run_gpu_checks.sh (PMC=1) into profiles/round<N>_pmc.{md,json} and round<N>_pmc_sq.md.
 
-  python profiles/summarize_pmc.py gpurun_out
+  python profiles/summarize_pmc.py gpurun_out [N=3] [commit]
 
 HBM-side bytes per kernel = 2 x FETCH_SIZE + WRITE_SIZE (KiB), the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md
 (FETCH_SIZE reports half of the bytes of wide coalesced reads); the counters sit on the L2 -> fabric side, Infinity-Cache hits are
@@ -23,8 +23,9 @@ def load(d, sub, counter):
     return df
 
 
-def main(d):
-    here = os.path.dirname(os.path.abspath(__file__))
+def main(d, rnd="3", commit=""):
+    here = os.environ.get("LS3D_PROFILE_OUT") or os.path.dirname(os.path.abspath(__file__))  # on the GPU box: a directory under gpurun_out/
+    os.makedirs(here, exist_ok=True)
     out, lines = {}, ["# HBM-side traffic of the sparse-conv launches (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes)", "",
                       "`python bench.py --precision P --steps 3 --warmup 2 --no-cpu-baseline --no-extra-modes` (120k-pt SDSeg3D frame).  bytes = (2 x FETCH_SIZE +",
                       "WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section).  Algorithmic pair-model bytes: 24.4 GB/frame = 659 MB/launch.", ""]
@@ -39,15 +40,15 @@ def main(d):
         sp = t[t.index.str.contains(SPARSE)]
         launches = float(sp.count_f.sum())
         out[prec] = dict(traffic_bytes_per_launch=float(sp.bytes.sum() / max(launches, 1)), sparse_launches_counted=launches,
-                         correction="(2*FETCH_SIZE+WRITE_SIZE)*1024 (MI355X_MICROARCH.md HBM section)")
+                         correction="(2*FETCH_SIZE+WRITE_SIZE)*1024 (MI355X_MICROARCH.md HBM section)", kernels=sorted(sp.index.tolist()),
+                         commit=commit)
         lines += ["## precision %s: %.1f MB per sparse-conv launch (%d launches counted)" % (prec, out[prec]["traffic_bytes_per_launch"] / 1e6, launches), "",
                   "| kernel | launches | FETCH_SIZE KiB / launch | WRITE_SIZE KiB / launch | MB / launch |", "|---|---|---|---|---|"]
         for k, r in t.sort_values("bytes", ascending=False).head(14).iterrows():
             n = max(r.count_f, 1)
             lines.append("| `%s` | %d | %.0f | %.0f | %.1f |" % (k, r.count_f, r.sum_f / n, r.sum_w / max(r.count_w, 1), r.bytes / n / 1e6))
         lines.append("")
-    json.dump(out, open(os.path.join(here, "round2_pmc.json"), "w"), indent=1)
-    open(os.path.join(here, "round2_pmc.md"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(here, "round%s_pmc.md" % rnd), "w").write("\n".join(lines) + "\n")
     # ---- SQ counters: MFMA busy etc. per kernel
     sq = ["# SQ counters of the sparse-conv kernels (rocprofv3 --kernel-trace --pmc ..., bench.py --steps 3 --warmup 2, MI355X)", "",
           "SIMD cycles available = kernel time x clock (GRBM_GUI_ACTIVE / 8 XCDs / time) x 1024 SIMDs.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count",
@@ -65,6 +66,12 @@ def main(d):
         df["k"] = df.Kernel_Name.str.replace(r"\(.*", "", regex=True).str.replace("void ", "").str.slice(0, 60)
         piv = df.pivot_table(index=["Dispatch_Id", "k"], columns="Counter_Name", values="Counter_Value", aggfunc="sum").reset_index()
         piv["dur"] = piv.Dispatch_Id.map(dur)
+        sel = piv[piv.k.str.contains(SPARSE)]
+        if len(sel) and prec in out:  # time-weighted MFMA busy of the sparse-conv stack (bench.py: roofline.mfma.mfma_busy)
+            t_all = sel.dur.sum()
+            clk_all = sel.GRBM_GUI_ACTIVE.sum() / 8.0 / t_all
+            out[prec]["mfma_busy"] = float(sel.SQ_VALU_MFMA_BUSY_CYCLES.sum() / (t_all * clk_all * 1024))
+            out[prec]["clock_ghz"] = float(clk_all)
         for k, g in piv[piv.k.str.contains(SPARSE + "|k_transvfe|k_sffm")].groupby("k"):
             t_ns = g.dur.sum()
             clk = g.GRBM_GUI_ACTIVE.sum() / 8.0 / t_ns  # GHz
@@ -74,10 +81,11 @@ def main(d):
                 prec, k, len(g), t_ns / 1e6, clk, 100 * g.SQ_VALU_MFMA_BUSY_CYCLES.sum() / simd_cycles, wc / simd_cycles,
                 100 * g.SQ_WAIT_ANY.sum() / g.SQ_WAVE_CYCLES.sum(), 100 * g.SQ_WAIT_INST_ANY.sum() / g.SQ_WAVE_CYCLES.sum(),
                 100 * g.SQ_ACTIVE_INST_ANY.sum() / g.SQ_WAVE_CYCLES.sum()))
-    open(os.path.join(here, "round2_pmc_sq.md"), "w").write("\n".join(sq) + "\n")
+    open(os.path.join(here, "round%s_pmc_sq.md" % rnd), "w").write("\n".join(sq) + "\n")
+    json.dump(out, open(os.path.join(here, "round%s_pmc.json" % rnd), "w"), indent=1)
     print("\n".join(lines[-20:]))
     print("\n".join(sq))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "3", sys.argv[3] if len(sys.argv) > 3 else "")

@@ -857,16 +857,59 @@ def test_mseg3d_training_step_gpu():
     assert l1 < l0
 
 
+class _GateTape(object):
+    """records the ReLU gates (x > 0) of one training step and replays them in another: with the gates pinned, two f32 evaluations
+    of the same step route their gradients identically, and what remains between them is arithmetic"""
+
+    def __init__(self):
+        self.masks, self.mode, self.i, self.flips, self.total = [], None, 0, 0, 0
+        self._relu, self._frelu = torch.relu, torch.nn.functional.relu
+
+    def _apply(self, x):
+        if self.mode == "record":
+            self.masks.append(x.detach() > 0)
+            return self._relu(x)
+        if self.mode == "replay":
+            m = self.masks[self.i]
+            self.i += 1
+            self.flips += int(((x.detach() > 0) != m).sum())
+            self.total += m.numel()
+            return x * m.to(x.dtype)
+        return self._relu(x)
+
+    def __enter__(self):
+        torch.relu = lambda x: self._apply(x)
+        torch.nn.functional.relu = lambda x, inplace=False: self._apply(x)
+        return self
+
+    def __exit__(self, *exc):
+        torch.relu, torch.nn.functional.relu = self._relu, self._frelu
+        return False
+
+    def start(self, mode):
+        self.mode, self.i, self.flips, self.total = mode, 0, 0, 0
+        if mode == "record":
+            self.masks = []
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16x6"])
 def test_waymo_mseg3d_two_frame_training_step_ddp_syncbn_gpu(prec):
     """BASELINE configs[3] as a test, on one GPU: Waymo geometry (range [-75.2,-75.2,-2,75.2,75.2,4], voxel [0.1,0.1,0.15], 5 cameras,
     23 classes; configs/semanticwaymo/MSeg3D/semwaymo_avgvfe_unetscn3d_hrnetw18_lr1en2_e12.py:59-60,231), 2 frames per GPU of >= 32k
     points each, SegMSeg3DNet.train() with return_loss=True, `convert_sync_batchnorm` + DistributedDataParallel on a 1-rank RCCL
-    ("nccl") group as det3d/torchie/apis/train.py:312-352 builds it.  The loss and EVERY parameter's gradient are compared with the
-    same step on the torch restatement of the sparse convolutions: relative L2 <= 1e-4 per tensor.  A tensor may exceed that only
-    as far as the restatement itself moves when nothing but its f32 summation order changes (kernel offsets summed in reverse):
-    batch-statistics BatchNorm + ReLU make single gates flip between two f32 evaluations of the same function, and a gradient
-    tensor that depends on few rows (the deepest level) shows it.  Records gpurun_out/train_waymo_grad_<prec>.json."""
+    ("nccl") group as det3d/torchie/apis/train.py:312-352 builds it.  Evaluations of the same step:
+      B   the torch f32 restatement of the sparse convolutions (the reference graph); its ReLU gates are recorded;
+      A   the product (HIP forward, dgrad, wgrad) with B's gates replayed -> relative L2 of EVERY parameter gradient vs B <= 1e-4;
+      D   B's forward arithmetic with the product's BACKWARD kernels                          -> <= 1e-4 per tensor as well;
+      A0  the product with its own gates, and C, the restatement with float64 accumulation inside every convolution (another correct
+          f32 evaluation), both free-running: recorded, not held to 1e-4.  Why the gates are pinned for the 1e-4 criterion: batch-
+          statistics BatchNorm + ReLU let a pre-activation within f32 rounding of zero open in one evaluation and close in the other;
+          ONE such gate moves a gradient tensor by ~1/sqrt(rows x channels) ~ 1e-3 and everything upstream of it.  Measured here: B vs C
+          (both pure torch) differ by up to 6.6e-4 per tensor with a handful of gates flipped out of ~1e8; A0 vs B likewise.  The
+          number of flipped gates is recorded and bounded.
+    Tensors whose true gradient is zero (the bias of a Linear that feeds a BatchNorm, the K-projection bias of an attention) hold
+    rounding noise in every evaluation; they are identified by B vs C and only required to be negligible.
+    Records gpurun_out/train_waymo_grad_<prec>.json (every tensor, all figures)."""
     import json
     import os
     import tempfile
@@ -885,34 +928,63 @@ def test_waymo_mseg3d_two_frame_training_step_ddp_syncbn_gpu(prec):
     if own:
         dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="ls3d_pg_"), rank=0, world_size=1)
     orig = spconv._SparseConvFn
+    tape = _GateTape()
     try:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True, bucket_cap_mb=128,
                                                         gradient_as_bucket_view=True)
 
-        def run():
+        def run(mode=None):
             torch.manual_seed(7)  # the voxel classifier's Dropout(0.25) draws the same mask in every run
             net.zero_grad(set_to_none=True)
+            tape.start(mode)
             out = net(dict(ex), return_loss=True)
             loss = out["loss"][0]
             loss.backward()
             torch.cuda.synchronize()
-            return float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}, out
+            if mode == "replay":
+                assert tape.i == len(tape.masks), "the two graphs call ReLU a different number of times"
+            logits = model.point_head.forward_ret_dict.get("out_logits")
+            return (float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}, out,
+                    None if logits is None else logits.detach().clone())
 
-        def restated(reverse):
+        def restated(f64):
             class RefFn(object):
                 @staticmethod
                 def apply(feats, weight, bias, rb, inverse, subm):
-                    y = _spconv_ref(feats, weight, (rb.tbl_inv if inverse else rb.tbl), reverse)
+                    tbl = rb.tbl_inv if inverse else rb.tbl
+                    y = _spconv_ref(feats.double(), weight.double(), tbl).float() if f64 else _spconv_ref(feats, weight, tbl)
                     return y if bias is None else y + bias
             return RefFn
 
-        ops.set_precision(prec)
-        la, ga, out = run()
-        ops.set_precision("f32")
-        spconv._SparseConvFn = restated(False)
-        lb, gb, _ = run()
-        spconv._SparseConvFn = restated(True)
-        lc, gc, _ = run()
+        class Hybrid(torch.autograd.Function):
+            """forward: the restatement's arithmetic; backward: the product's (spconv._SparseConvFn.backward: HIP dgrad + wgrad)"""
+            @staticmethod
+            def forward(ctx, feats, weight, bias, rb, inverse, subm):
+                with torch.no_grad():
+                    y = _spconv_ref(feats, weight, rb.tbl_inv if inverse else rb.tbl)
+                    if bias is not None:
+                        y = y + bias
+                ctx.save_for_backward(feats, weight)
+                ctx.rb, ctx.inverse, ctx.subm, ctx.has_bias = rb, inverse, subm, bias is not None
+                return y
+            backward = staticmethod(orig.backward)
+
+        with tape:
+            spconv._SparseConvFn = restated(False)
+            lb, gb, _, yb = run("record")
+            gates = sum(m.numel() for m in tape.masks)
+            spconv._SparseConvFn = orig
+            ops.set_precision(prec)
+            la, ga, out, ya = run("replay")
+            flips_a = tape.flips
+            la0, ga0, _, ya0 = run()
+            spconv._SparseConvFn = Hybrid
+            ld, gd, _, yd = run()
+            ops.set_precision("f32")
+            spconv._SparseConvFn = restated(True)
+            lc, gc, _, yc = run("replay")  # replayed only to COUNT its flipped gates ...
+            flips_c = tape.flips
+            lc, gc, _, yc = run()          # ... the figures are the free-running ones
     finally:
         spconv._SparseConvFn = orig
         ops.set_precision("f32")
@@ -920,22 +992,37 @@ def test_waymo_mseg3d_two_frame_training_step_ddp_syncbn_gpu(prec):
             dist.destroy_process_group()
     assert np.isfinite(la)
     assert set(out) == {"loss", "voxel_ce_loss", "voxel_lovasz_loss", "out_ce_loss", "out_lovasz_loss", "out_mimic_loss"}
-    assert set(ga) == set(gb) == set(gc) and len(ga) > 150
+    assert set(ga) == set(gb) == set(gc) == set(gd) == set(ga0) and len(ga) > 150
     assert all(k.startswith("backbone.conv_out") for k, p in model.named_parameters() if p.grad is None)
 
     def rel(x, y):
         return float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30))
-    rec = {k: dict(hip_vs_restated=rel(ga[k], gb[k]), reordered_vs_restated=rel(gc[k], gb[k]), numel=ga[k].numel()) for k in sorted(gb)}
-    worst = max(rec, key=lambda k: rec[k]["hip_vs_restated"])
-    over = {k: r for k, r in rec.items() if r["hip_vs_restated"] > 1e-4}
-    summary = dict(precision=prec, loss_hip=la, loss_restated=lb, loss_reordered=lc, tensors=len(rec), worst=worst, worst_value=rec[worst],
-                   over_1e4=over, points=int(ex["points"].shape[0]), voxels=int(ex["voxels"].shape[0]))
+    rec = {k: dict(product_pinned_gates=rel(ga[k], gb[k]), hip_backward_on_restated_forward=rel(gd[k], gb[k]),
+                   product_free=rel(ga0[k], gb[k]), f64acc_free=rel(gc[k], gb[k]), norm=float(gb[k].norm()), numel=ga[k].numel())
+           for k in sorted(gb)}
+    noise = [k for k, r in rec.items() if r["f64acc_free"] > 0.05]  # zero-true-gradient tensors: rounding noise in every evaluation
+    real = [k for k in rec if k not in noise]
+    worst = max(real, key=lambda k: rec[k]["product_pinned_gates"])
+    worst_bwd = max(real, key=lambda k: rec[k]["hip_backward_on_restated_forward"])
+    summary = dict(precision=prec, loss_restated=lb, loss_product_pinned=la, loss_product_free=la0, loss_f64acc=lc, loss_hybrid=ld,
+                   tensors=len(rec), noise_tensors=noise, relu_gates=gates, flipped_gates_product=flips_a, flipped_gates_f64acc=flips_c,
+                   logits=dict(product_pinned=rel(ya, yb), product_free=rel(ya0, yb), f64acc=rel(yc, yb), hybrid=rel(yd, yb)),
+                   worst_product_pinned=dict(tensor=worst, **rec[worst]), worst_backward_kernel=dict(tensor=worst_bwd, **rec[worst_bwd]),
+                   max_product_free=max(rec[k]["product_free"] for k in real), max_f64acc_free=max(rec[k]["f64acc_free"] for k in real),
+                   points=int(ex["points"].shape[0]), voxels=int(ex["voxels"].shape[0]))
     print(json.dumps(summary))
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(dict(summary=summary, per_tensor=rec), open("gpurun_out/train_waymo_grad_%s.json" % prec, "w"), indent=1)
-    assert abs(la - lb) <= 1e-5 * abs(lb) + 3 * abs(lc - lb), (la, lb, lc)
-    for k, r in rec.items():
-        assert r["hip_vs_restated"] <= max(1e-4, 3.0 * r["reordered_vs_restated"]), (k, r)
+    assert len(noise) <= 12 and all(k.endswith(".bias") for k in noise), noise
+    for k in noise:  # negligible next to the gradient of the weight it belongs to
+        assert float(ga[k].norm()) <= 1e-3 * float(gb[k[:-4] + "weight"].norm()) + 1e-12, k
+    assert abs(la - lb) <= 1e-5 * abs(lb) and abs(la0 - lb) <= 1e-5 * abs(lb), (la, la0, lb)
+    assert ld == lb or abs(ld - lb) <= 1e-6 * abs(lb)  # same forward arithmetic
+    assert flips_a <= max(50, 1e-6 * gates) and flips_a <= 10 * max(flips_c, 5), (flips_a, flips_c, gates)
+    for k in real:
+        assert rec[k]["hip_backward_on_restated_forward"] <= 1e-4, (k, rec[k])
+        assert rec[k]["product_pinned_gates"] <= 1e-4, (k, rec[k])
+        assert rec[k]["product_free"] <= 1e-2, (k, rec[k])
 
 
 # ------------------------------------------------------------------------------------------------ tile-halo convolution, round 2
@@ -987,6 +1074,23 @@ def test_tile_conv_full_size_vs_gather_gemm_and_float64(cin, cout, products):
     wantf = torch.relu(want * scale.double() + shift.double() + res.double())
     assert float((fused.double() - wantf).abs().max()) <= 2e-5 * float(wantf.abs().max()) + 1e-5
     assert torch.equal(ops.tile_conv(x, pw, plan, cout=cout, products=products), got)
+    # dispatch order / LDS bank swizzle / channel split at the full size (1071 tiles: no tile is split by default): bit-identical
+    # without the swizzle and in plan order; a split tail changes only its own tiles' rows, by f32 rounding of two partial sums
+    NEVER = 1 << 6
+    try:
+        for fl, pf in ((NEVER, 0), (1 << 30, 0), (0, 1)):
+            ops.set_tile_flags(conv=fl, plan=pf)
+            pl = plan if pf == 0 else ops.tile_plan(tbl, c2, oshape, 1)
+            assert torch.equal(ops.tile_conv(x, pw, pl, cout=cout, products=products), got), (fl, pf)
+        if cin >= 64:
+            ops.set_tile_flags(conv=(256 + 1) << 20, plan=0)  # the 256 tiles at the end of the dispatch order in two units each
+            tail = ops.tile_conv(x, pw, plan, cout=cout, products=products)
+            assert torch.equal(ops.tile_conv(x, pw, plan, cout=cout, products=products), tail)
+            changed = int((tail != got).any(1).sum())
+            assert 0 < changed <= 256 * 128, changed
+            assert float(((tail - got).abs() / mag.float()).max()) <= 2.0 ** -20
+    finally:
+        ops.set_tile_flags(conv=0, plan=0)
     # the plan partitions the rows: every row written exactly once (NaN canary)
     canary = torch.full((n2, cout), float("nan"), device=DEV)
     ops.tile_conv(x, pw, plan, cout=cout, products=products, out=canary)

@@ -823,6 +823,13 @@ def _plan_views(plan):
     return trow, meta, halo, loc
 
 
+def _plan_torder(plan):
+    al = lambda v: (v + 255) // 256 * 256
+    t, kvol = (plan.n_rows + 127) // 128, plan.kvol
+    o = al(t * 128 * 4) + al(t * 8 * 4) + al(t * kvol * 128 * 4) + al(t * kvol * 128 * 2)
+    return plan.buf.numpy()[o:o + t * 4].view(np.int32).copy()
+
+
 def _sparse_ref(x, w, tbl):
     acc = np.zeros((tbl.shape[0], w.shape[2]), np.float64)
     for k in range(tbl.shape[1]):
@@ -846,7 +853,14 @@ def test_tile_plan_structure_on_a_subm_rulebook():
     tb = tbl.numpy()
     assert sorted(trow[trow >= 0].tolist()) == list(range(V))
     keys = ops.tile_keys(coords, shape, 1).numpy()
-    assert np.array_equal(plan.order.numpy(), np.argsort(keys, kind="stable"))
+    order = np.argsort(keys, kind="stable")  # tiles are consecutive runs of 128 rows of the stable spatial order
+    for t in range(trow.shape[0]):
+        assert sorted(trow[t][trow[t] >= 0].tolist()) == sorted(order[128 * t:128 * t + 128].tolist())
+    # dispatch order: a permutation of the tiles, most expensive (LDS passes x active offsets) first, ties in plan order
+    torder = _plan_torder(plan)
+    assert sorted(torder.tolist()) == list(range(trow.shape[0]))
+    cost = np.array([((meta[t, 0] + 447) // 448) * bin(int(meta[t, 1]) & 0xFFFFFFFF).count("1") if meta[t, 6] else 0 for t in range(trow.shape[0])])
+    assert all((cost[a] > cost[b]) or (cost[a] == cost[b] and a < b) for a, b in zip(torder[:-1], torder[1:]))
     for t in range(trow.shape[0]):
         rows = trow[t]
         live = rows >= 0
@@ -944,6 +958,63 @@ def test_round2_entry_points_on_empty_and_degenerate_inputs():
     m = scatter.scatter_mean(src, seg.long(), dim=0, dim_size=8)
     assert torch.equal(m[0], src[2]) and float(m[[1, 2, 4, 5, 7]].abs().max()) == 0.0
     np.testing.assert_allclose(m[3].numpy(), ((src[0] + src[1]) + src[3]).numpy() / 3.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout,products", [(64, 128, 6), (64, 64, 6), (64, 32, 8), (128, 96, 6)])
+def test_tile_conv_flags_and_channel_splits_are_bit_identical_where_they_must_be(cin, cout, products):
+    """ls3d_tile_conv's `flags`: dispatching the tiles in plan order instead of most-expensive-first and the LDS bank swizzle change
+    nothing; splitting tiles over the input channels changes only the split tiles' rows (two partial sums added at the end), is
+    reproducible, and the arrival counters survive any number of launches without a reset; the fused epilogue runs on split and
+    unsplit tiles.  5 tiles (one of them partial, one with rows that have no neighbour at some offsets)."""
+    rng = np.random.default_rng(cin * 3 + cout)
+    vin, vout, kvol = 500, 560, 27
+    x = rng.normal(size=(vin, cin)).astype(np.float32)
+    w = rng.normal(size=(kvol, cin, cout)).astype(np.float32) * 0.1
+    # neighbours from a window around the row: halos stay inside one LDS pass
+    tbl = (np.arange(vout)[:, None] * vin // vout + rng.integers(-20, 20, size=(vout, kvol))).clip(0, vin - 1).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.4] = -1
+    tbl[200:330, 5] = -1
+    tbl[130:162, 9:] = -1
+    T = torch.from_numpy
+    pw = PackedWeight(T(w), kvol, cin, cin, cout)
+    coords = T(np.stack([np.zeros(vout), np.zeros(vout), np.arange(vout) // 32, np.arange(vout) % 32], 1).astype(np.int32))
+    scale, shift = T(rng.uniform(0.5, 1.5, cout).astype(np.float32)), T(rng.normal(size=cout).astype(np.float32))
+    res = T(rng.normal(size=(vout, cout)).astype(np.float32))
+    counters = torch.zeros((512,), dtype=torch.int32)  # one array for every launch of this test: never reset
+
+    def run(conv_flags, plan_flags=0, **kw):
+        ops.set_tile_flags(conv=conv_flags, plan=plan_flags)
+        orig = ops._tile_counters
+        ops._tile_counters = lambda like: counters
+        try:
+            plan = ops.tile_plan(T(tbl), coords, (1, 32, 32), 1)
+            return ops.tile_conv(T(x), pw, plan, cout=cout, products=products, **kw), plan
+        finally:
+            ops.set_tile_flags(conv=0, plan=0)
+            ops._tile_counters = orig
+
+    NEVER, ALL = 1 << 6, 2 << 6
+    base, plan = run(NEVER)
+    assert _plan_views(plan)[1][:, 0].max() <= 448
+    np.testing.assert_allclose(base.numpy(), _sparse_ref(x, w, tbl), rtol=0, atol=2e-4)
+    assert torch.equal(run(NEVER | (1 << 30))[0], base)         # no LDS bank swizzle
+    assert torch.equal(run(NEVER, plan_flags=1)[0], base)       # plan-order dispatch
+    allsplit, _ = run(0)                                        # 5 tiles <= 512: every tile is split
+    assert torch.equal(run(ALL)[0], allsplit) and torch.equal(run(1 << 30)[0], allsplit)
+    assert torch.equal(run(0)[0], allsplit)                     # reproducible, counters left even by every launch
+    assert int((counters % 2).sum()) == 0 and int(counters[:5].min()) >= 8
+    np.testing.assert_allclose(allsplit.numpy(), base.numpy(), rtol=0, atol=2e-5)
+    two, plan2 = run((2 + 1) << 8)                              # only the two tiles at the end of the dispatch order are split
+    torder, trow = _plan_torder(plan2), _plan_views(plan2)[0]
+    split_rows = np.concatenate([trow[t][trow[t] >= 0] for t in torder[-2:]])
+    keep_rows = np.setdiff1d(np.arange(vout), split_rows)
+    assert torch.equal(two[keep_rows], base[keep_rows]) and torch.equal(two[split_rows], allsplit[split_rows])
+    if cin >= 128:
+        assert not torch.equal(allsplit, base)                  # the split really happened
+    for fl in (0, NEVER):
+        a = run(fl, scale=scale, shift=shift, res_pre=res, relu=True)[0]
+        np.testing.assert_allclose(a.numpy(), np.maximum((allsplit if fl != NEVER else base).numpy() * scale.numpy() + shift.numpy() + res.numpy(), 0),
+                                   rtol=0, atol=1e-5)
 
 
 def test_tile_conv_any_row_order_gives_the_same_rows():
