@@ -78,11 +78,11 @@ class ConvCensus:
 
         def wg(x, w, tbl=None, **kw):
             if tbl is not None:
-                self.meta.append((tbl, w.shape[1], kw.get("cout") or w.cout, "gather"))
+                self.meta.append((tbl, w.shape[1], kw.get("cout") or w.cout, "gather", kw.get("n_dev")))
             return g(x, w, tbl=tbl, **kw)
 
         def wt(x, w, plan, **kw):
-            self.meta.append((plan.tbl, w.shape[1], kw.get("cout") or w.cout, "tile"))
+            self.meta.append((plan.tbl, w.shape[1], kw.get("cout") or w.cout, "tile", plan.n_dev))
             return t(x, w, plan, **kw)
         ops.gather_gemm, ops.tile_conv = wg, wt
         try:
@@ -91,16 +91,19 @@ class ConvCensus:
             torch.cuda.synchronize()
         finally:
             ops.gather_gemm, ops.tile_conv = g, t
-        pairs, uniq, algo, flops, bmin = {}, {}, 0.0, 0.0, 0.0
-        for tbl, cin, cout, _ in self.meta:
+        pairs, uniq, rows, algo, flops, bmin = {}, {}, {}, 0.0, 0.0, 0.0
+        for tbl, cin, cout, _, n_dev in self.meta:
             key = (tbl.data_ptr(), tbl.shape[0])
             if key not in pairs:
+                if n_dev is not None:  # capacity mode: the table has spare rows beyond the device count
+                    tbl = tbl[:int(n_dev.item())]
                 pairs[key] = int((tbl >= 0).sum().item())
                 uniq[key] = int(torch.unique(tbl[tbl >= 0]).numel())
+                rows[key] = tbl.shape[0]
             algo += pairs[key] * (cin + cout) * 4.0
             flops += 2.0 * pairs[key] * cin * cout
             # B_min: what a launch cannot avoid moving: every referenced input row once, every output row once, the weights once
-            bmin += (uniq[key] * cin + tbl.shape[0] * cout + tbl.shape[1] * cin * cout) * 4.0
+            bmin += (uniq[key] * cin + rows[key] * cout + tbl.shape[1] * cin * cout) * 4.0
         return dict(launches=len(self.meta), tile_launches=sum(1 for m in self.meta if m[3] == "tile"), algo_bytes=algo, flops=flops, b_min_bytes=bmin)
 
 
@@ -286,7 +289,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://")
 
-    from lidarseg3d_amd import ops, scn_unet, synth
+    from lidarseg3d_amd import detectors, ops, scn_unet, synth
     ops.set_precision(args.precision)
     ops.set_row_order(args.row_order)
     model, sd = build_model(dev, kind=args.model)
@@ -406,6 +409,8 @@ def main():
                                    "%d pts/frame, voxel [0.1,0.1,0.2], range [-51.2,-51.2,-5,51.2,51.2,3], 17 classes, "
                                    "1 frame per GPU per step, GPU voxelization included" % args.points,
                        "precision": args.precision, "frames_per_gpu_per_step": B * S, "streams": S,
+                       "host_syncs_per_frame": ("0 blocking (capacity mode: device-side row counts; one wait for the frame's rulebook counts, "
+                                                "which are ready early in the frame)" if detectors.CAPACITY_MODE else "3 (host-side row counts)"),
                        "parallelism": "frames sharded 1/GPU (dp%d)" % world},
             "latency": main_leg["latency"],
         }

@@ -168,15 +168,13 @@ typedef struct {
   int num_layers, num_compressed, embed, heads, ffn, token_ld;
   int planes; /* 0: f32 MFMA, the five GEMM weights (w_embed, wqkv, wo, w1, w2) in the packed nt = 2 layout of ls3d_gather_gemm_pack;
                * 6 | 8: the exact 3-plane bf16 split (f32-grade, see ls3d_tile_conv), the five weights converted by ls3d_transvfe_pack_planes */
+  int flags;  /* bit 0 (planes == 0 only): experimental variant with the B fragments straight from the L2-resident weights instead of
+               * LDS staging, no workgroup barriers - same results, measured slower (profiles/round2_experiments.md) */
 } ls3d_transvfe_t;
 size_t ls3d_transvfe_planes_bytes(int K, int N);
 int ls3d_transvfe_pack_planes(const float *w_packed_nt2 /*K x N*/, int K, int N, void *out, ls3d_stream_t stream);
 int ls3d_transvfe(const float *voxels /*[n,P,C]*/, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
                   const ls3d_transvfe_t *model, float *out, int out_ld, ls3d_stream_t stream);
-
-/* Experimental variant of the fused reader: B fragments straight from the L2-resident weights instead of LDS staging, no workgroup
- * barriers (0 = off, the default).  Same results; a process-wide switch like ls3d_set_gather_pipeline. */
-void ls3d_set_transvfe_direct(int on);
 
 /* y = LayerNorm(x (+ res)) * gamma + beta over the last dim c (<= 256); ld = c for all */
 int ls3d_layernorm(const float *x, const float *res, const float *gamma, const float *beta, float eps, int rows,
@@ -229,15 +227,8 @@ int ls3d_rulebook_sort_keys(const int32_t *tbl, int n, const int32_t *n_dev, int
 int ls3d_segment_local_index(const int64_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream);
 int ls3d_segment_local_index32(const int32_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream);
 
-/* tuning knob: workgroup -> (tile, column slab) mapping of ls3d_gather_gemm; results are identical for every value.
- * 0 (default): the slabs of a tile run on one XCD, tiles interleaved over the 8 XCDs; bit 0: each XCD takes a
- * contiguous range of tiles; bit 1: slab-major dispatch (every slab re-gathers its rows from HBM). */
-void ls3d_set_xcd_map(int flags);
-
-/* tuning knob (default 0: measured 10-20 % slower on the 120k-point frame, profiles/round1_experiments.md): sparse launches of ls3d_gather_gemm with cin % 32 == 0 and (nt, wc) in {(1,1), (1,2), (2,2)} use
- * the LDS-DMA pipelined kernel (a ring of staged steps; wc = column groups of an 8-wave workgroup sharing the gathered
- * rows); 0 sends every launch to the register-prefetch kernels.  Results differ only by f32 summation order: none. */
-void ls3d_set_gather_pipeline(int on);
+/* (The library has no process-global switches: every A/B knob is an argument of the call or a field of the model descriptor it
+ * applies to, so two models or two threads in one process never see each other's settings.) */
 
 /* Fused epilogue of the gather-GEMM (all optional):
  *   v = acc * scale[c] + shift[c]           (folded eval BatchNorm / bias)
@@ -279,12 +270,15 @@ int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_p
  * 32*(4/wc) rows x 32*nt*wc columns (nt*wc <= 4, must divide roundup(cout,32)/32; wc == 0 means 1).  The weights must
  * have been packed with the same nt.
  * row_order (optional, int32[n_rows]): tile slot i processes output row row_order[i] (see ls3d_rulebook_masks).
+ * flags (per call; results are identical for every value): bits 0-1 = workgroup -> (tile, column slab) mapping, 0 (default): the
+ * slabs of a tile run on one XCD, tiles interleaved over the 8 XCDs; bit 0: each XCD takes a contiguous range of tiles; bit 1:
+ * slab-major dispatch (every slab re-gathers its rows from HBM).
  * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
  * (tbl = nbr_inv) and every nn.Linear on the path. */
 int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int wc,
                      int precision /* must equal the packing's; BF16X3 / BF16X6 need cin % 32 == 0 and wc == 1 */, int cin, int cout,
                      int n_rows, const int32_t *n_rows_dev, const ls3d_epilogue_t *epi_host, float *out,
-                     int out_ld, ls3d_stream_t stream);
+                     int out_ld, int flags, ls3d_stream_t stream);
 
 /* ---- Tile-halo sparse convolution: the same operator as ls3d_gather_gemm with a rulebook table (spconv v1.x SubMConv3d /
  * SparseConv3d / SparseInverseConv3d, call sites det3d/models/backbones/scn_unet.py:15-24,34-69), organised for locality:
@@ -367,7 +361,8 @@ int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int gra
 /* Row offsets of the frames of a frame-sorted table (points [n,stride] f32 or coordinates [n,stride] int32 with the
  * batch index in column `col`): off[b] = first row with batch index >= b, b = 0..batch (off[batch] = n).  Replaces the
  * reference's per-frame boolean masks (`coords[:, 0] == i`, point_utils.py:20-21, context_module.py:39,350). */
-int ls3d_frame_offsets(const void *table, int is_float, int stride, int col, int n, int batch, int32_t *off, ls3d_stream_t stream);
+int ls3d_frame_offsets(const void *table, int is_float, int stride, int col, int n, const int32_t *n_dev, int batch, int32_t *off,
+                       ls3d_stream_t stream);
 
 /* voxel centres: out[v] = (b, (x+.5)*vx+x0, (y+.5)*vy+y0, (z+.5)*vz+z0), f32 mul then add (unfused),
  * det3d/core/utils/common_utils.py:74-90 + scn_unet.py:243-247. */
@@ -467,11 +462,10 @@ typedef struct {
   int32_t num_layers, d_in, d_model, heads, ffn;
   const float *norm_gamma, *norm_beta; /* decoder.norm_tgt, or NULL */
   float norm_eps;
+  int32_t attention; /* arithmetic of the decoder's point -> class-embedding attention (QK^T and PV): 0 (default) exact f32 on
+                      * v_mfma_f32_32x32x2_f32, 1 operands rounded to bf16 on v_mfma_f32_32x32x16_bf16, 3 operands rounded to OCP e4m3 on
+                      * v_mfma_f32_32x32x16_fp8_fp8 - both with f32 accumulation and f32 softmax (BASELINE configs[4]); 2 the vector pipe (A/B) */
 } ls3d_sffm_t;
-/* arithmetic of the decoder's point -> class-embedding attention (QK^T and PV): 0 (default) exact f32 on v_mfma_f32_32x32x2_f32,
- * 1 operands rounded to bf16 on v_mfma_f32_32x32x16_bf16, 3 operands rounded to OCP e4m3 on v_mfma_f32_32x32x16_fp8_fp8 - both with
- * f32 accumulation and f32 softmax (BASELINE configs[4]); 2 the vector pipe (A/B). */
-void ls3d_set_sffm_attention(int mode);
 int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
                       const ls3d_sffm_t *model_host, float *out, int out_ld, ls3d_stream_t stream);
 

@@ -17,12 +17,12 @@ EXPORTS = [
     "ls3d_version", "ls3d_voxelize_dynamic", "ls3d_voxelize_hard_workspace_bytes", "ls3d_voxelize_hard",
     "ls3d_dynamic_scatter_workspace_bytes", "ls3d_dynamic_scatter", "ls3d_dynamic_scatter_backward_workspace_bytes",
     "ls3d_dynamic_scatter_backward", "ls3d_segment_reduce_workspace_bytes", "ls3d_segment_reduce", "ls3d_vfe_mean", "ls3d_vfe_improved_mean",
-    "ls3d_vfe_tokens", "ls3d_transvfe", "ls3d_set_transvfe_direct", "ls3d_mha_core", "ls3d_group_max", "ls3d_layernorm", "ls3d_index_build",
-    "ls3d_rulebook_subm", "ls3d_rulebook_conv_workspace_bytes", "ls3d_rulebook_conv", "ls3d_rulebook_masks", "ls3d_rulebook_sort_keys", "ls3d_segment_local_index", "ls3d_segment_local_index32", "ls3d_gather_gemm", "ls3d_gather_gemm_pack", "ls3d_gather_gemm_packed_floats", "ls3d_gather_gemm_default_nt", "ls3d_spconv_wgrad_workspace_bytes", "ls3d_spconv_wgrad", "ls3d_set_xcd_map", "ls3d_set_gather_pipeline",
+    "ls3d_vfe_tokens", "ls3d_transvfe", "ls3d_mha_core", "ls3d_group_max", "ls3d_layernorm", "ls3d_index_build",
+    "ls3d_rulebook_subm", "ls3d_rulebook_conv_workspace_bytes", "ls3d_rulebook_conv", "ls3d_rulebook_masks", "ls3d_rulebook_sort_keys", "ls3d_segment_local_index", "ls3d_segment_local_index32", "ls3d_gather_gemm", "ls3d_gather_gemm_pack", "ls3d_gather_gemm_packed_floats", "ls3d_gather_gemm_default_nt", "ls3d_spconv_wgrad_workspace_bytes", "ls3d_spconv_wgrad", 
     "ls3d_tile_keys", "ls3d_tile_plan_bytes", "ls3d_tile_build", "ls3d_tile_plan", "ls3d_tile_plan_workspace_bytes", "ls3d_radix_sort",
     "ls3d_radix_sort_workspace_bytes", "ls3d_tile_conv_packed_bytes", "ls3d_tile_conv_pack", "ls3d_tile_conv", "ls3d_tile_conv_workspace_bytes", "ls3d_tile_conv_counter_bytes", "ls3d_transvfe_planes_bytes", "ls3d_transvfe_pack_planes",
     "ls3d_voxel_centers", "ls3d_frame_offsets", "ls3d_three_nn", "ls3d_three_interpolate", "ls3d_three_interpolate_grad",
-    "ls3d_devoxelize", "ls3d_devoxelize_grid", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_interpolate_rows", "ls3d_grid_gather", "ls3d_nchw_to_nhwc", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn", "ls3d_sffm_decoder", "ls3d_set_sffm_attention", "ls3d_points_cp", "ls3d_points_cuv",
+    "ls3d_devoxelize", "ls3d_devoxelize_grid", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_interpolate_rows", "ls3d_grid_gather", "ls3d_nchw_to_nhwc", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn", "ls3d_sffm_decoder", "ls3d_points_cp", "ls3d_points_cuv",
 ]
 
 
@@ -50,7 +50,7 @@ class TransVFE(ctypes.Structure):
     _fields_ = [("w_embed", ctypes.c_void_p), ("b_embed", ctypes.c_void_p), ("w_compress", ctypes.c_void_p), ("b_compress", ctypes.c_void_p),
                 ("layers", ctypes.POINTER(TransVFELayer)), ("num_layers", ctypes.c_int32), ("num_compressed", ctypes.c_int32),
                 ("embed", ctypes.c_int32), ("heads", ctypes.c_int32), ("ffn", ctypes.c_int32), ("token_ld", ctypes.c_int32),
-                ("planes", ctypes.c_int32)]
+                ("planes", ctypes.c_int32), ("flags", ctypes.c_int32)]
 
 
 class SffmLayer(ctypes.Structure):
@@ -61,7 +61,7 @@ class SffmLayer(ctypes.Structure):
 class Sffm(ctypes.Structure):
     _fields_ = [("w_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p), ("layers", ctypes.POINTER(SffmLayer)), ("num_layers", ctypes.c_int32),
                 ("d_in", ctypes.c_int32), ("d_model", ctypes.c_int32), ("heads", ctypes.c_int32), ("ffn", ctypes.c_int32),
-                ("norm_gamma", ctypes.c_void_p), ("norm_beta", ctypes.c_void_p), ("norm_eps", ctypes.c_float)]
+                ("norm_gamma", ctypes.c_void_p), ("norm_beta", ctypes.c_void_p), ("norm_eps", ctypes.c_float), ("attention", ctypes.c_int32)]
 
 
 class LibraryMissing(RuntimeError):

@@ -576,10 +576,10 @@ extern "C" int ls3d_interpolate_rows(const float *feat, int feat_ld, int c, cons
 }
 
 // off[b] = first row whose batch index (column `col` of a frame-sorted table) is >= b, b = 0..batch  (binary search)
-__global__ void k_frame_offsets(const void *table, int is_float, int stride, int col, int n, int batch, int32_t *off) {
+__global__ void k_frame_offsets(const void *table, int is_float, int stride, int col, int n, const int32_t *n_dev, int batch, int32_t *off) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b > batch) return;
-  int lo = 0, hi = n;
+  int lo = 0, hi = ls3d_count(n, n_dev);
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     const int v = is_float ? (int)((const float *)table)[(size_t)mid * stride + col] : ((const int32_t *)table)[(size_t)mid * stride + col];
@@ -588,9 +588,10 @@ __global__ void k_frame_offsets(const void *table, int is_float, int stride, int
   off[b] = lo;
 }
 
-extern "C" int ls3d_frame_offsets(const void *table, int is_float, int stride, int col, int n, int batch, int32_t *off, ls3d_stream_t stream) {
+extern "C" int ls3d_frame_offsets(const void *table, int is_float, int stride, int col, int n, const int32_t *n_dev, int batch, int32_t *off,
+                                  ls3d_stream_t stream) {
   if (!table || !off || n < 0 || batch < 1 || stride < 1 || col < 0 || col >= stride) return LS3D_ERR_ARG;
-  hipLaunchKernelGGL(k_frame_offsets, dim3((batch + 1 + 63) / 64), dim3(64), 0, (hipStream_t)stream, table, is_float, stride, col, n, batch, off);
+  hipLaunchKernelGGL(k_frame_offsets, dim3((batch + 1 + 63) / 64), dim3(64), 0, (hipStream_t)stream, table, is_float, stride, col, n, n_dev, batch, off);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

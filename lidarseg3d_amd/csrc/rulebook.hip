@@ -153,9 +153,12 @@ __global__ __launch_bounds__(256) void k_tbl_mask(const int32_t *tbl, int n, con
 __global__ __launch_bounds__(256) void k_tbl_sortkey(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, uint32_t seg_bits, uint32_t flip,
                                                      int32_t *keys) {
   const int N = ls3d_count(n, n_dev);
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) {
-    uint32_t m = 0;
-    for (int k = 0; k < kvol; ++k) m |= (tbl[(size_t)r * kvol + k] >= 0 ? 1u : 0u) << k;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    uint32_t m = 0x7FFFFFFu ^ flip;  // rows beyond the device count: the largest key of the segment, they sort last
+    if (r < N) {
+      m = 0;
+      for (int k = 0; k < kvol; ++k) m |= (tbl[(size_t)r * kvol + k] >= 0 ? 1u : 0u) << k;
+    }
     keys[r] = (int32_t)(seg_bits | (m ^ flip));
   }
 }

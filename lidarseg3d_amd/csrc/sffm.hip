@@ -463,9 +463,6 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
   }
 }
 
-static int g_sffm_attention = 0;  // 0: exact-f32 MFMA attention, 1: bf16 MFMA, 2: vector pipe (A/B), 3: fp8 (e4m3) MFMA
-extern "C" void ls3d_set_sffm_attention(int mode) { g_sffm_attention = (mode >= 0 && mode <= 3) ? mode : 0; }
-
 extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
                                  const ls3d_sffm_t *m, float *out, int out_ld, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -493,7 +490,7 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
   }
   long long blocks = ((long long)n + 127) / 128;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(k_sffm_decoder, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, g_sffm_attention);
+  hipLaunchKernelGGL(k_sffm_decoder, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, (m->attention >= 0 && m->attention <= 3) ? m->attention : 0);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

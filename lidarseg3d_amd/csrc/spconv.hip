@@ -23,9 +23,9 @@
 
 #include "gemm_common.h"
 
-static int g_xcd_map = 0;  // workgroup -> (tile, slab) mapping flags (see k_gather_gemm); 0 = slabs of a tile share an XCD, tiles
-                           // interleaved over the XCDs.  LS3D_XCD_MAP=<flags> selects the alternatives for A/B measurements
-extern "C" void ls3d_set_xcd_map(int on) { g_xcd_map = on & 3; }
+// workgroup -> (tile, slab) mapping: ls3d_gather_gemm's per-call `flags` bits 0-1 (see k_gather_gemm); 0 = slabs of a tile share an
+// XCD, tiles interleaved over the XCDs.  (Round 1's LDS-DMA pipelined variant k_gg_pipe - 10-20 % slower on every layer,
+// profiles/round1_experiments.md - and its process-global switch are gone since round 3.)
 
 
 // Template parameters
@@ -472,279 +472,10 @@ __global__ __launch_bounds__(256) void k_gg_pack_bf16x3(const float *src, int kv
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Pipelined sparse gather-GEMM (k_gg_pipe): the same tile / fragment / packed-weight conventions as the two kernels
-// above, but the operands of step i + S - 1 are already on their way while step i runs on the matrix pipe:
-//   * a step = (active kernel offset k, 32-channel chunk c0): 128 gathered rows x 128 B (A) + the KC x SLAB weight chunk (B);
-//   * both go global -> LDS by LDS-DMA (ls3d_glds16: no staging VGPRs, asynchronous), into a ring of S stages; the gather
-//     is 8 lanes per row (one 128-byte line per row and step), its 16-byte pieces XOR-swizzled on the SOURCE side with
-//     (row >> 1) & 7 so that the ds_read_b128 of the MFMA fragments (lane = row, 4 consecutive pieces) is conflict-free;
-//   * per step and wave: s_waitcnt vmcnt(#DMAs issued after this step's) -> raw s_barrier -> issue the DMAs of step
-//     i + S - 1 into the stage step i - 1 just released -> LDS reads + MFMAs of step i.  A __syncthreads() in this loop
-//     would drain the DMA queue (vmcnt(0)) and reduce the ring to depth 1;
-//   * the neighbour indices of the tile's 128 rows are staged once in LDS (s_idx[k][row]) so that no compiler-issued
-//     global load (and its conservative vmcnt(0)) sits in the pipelined loop; absent neighbours fetch row 0 and are
-//     zeroed in registers;
-//   * workgroup = 4 * WCOL waves: wave (wr, wc) owns rows [32 wr, 32 wr + 32) and the NTW 32-column blocks of column
-//     group wc; with WCOL = 2 the 8 waves (2 per SIMD) share one copy of the gathered rows in LDS, i.e. a 128-column
-//     layer gathers its input once instead of once per column slab.
-// Why: rocprofv3 counters of the register-prefetch kernels (profiles/round1_pmc_sq.md): L2 hit rate of the gathers 50 %,
-// waves parked on s_waitcnt/barrier 42 % (f32) / 59 % (split-bf16) of their cycles, MFMA busy 51 % / 18 % — one chunk
-// of prefetch (0.3-0.45 us of MFMA work) does not cover an L2 miss.
-template <int NTW, int WCOL, bool BF16, int S>
-__global__ __launch_bounds__(256 * WCOL, 1) void k_gg_pipe(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
-                                                           const int32_t *__restrict__ order, int kvol, const float *__restrict__ w,
-                                                           int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
-                                                           float *__restrict__ out, int out_ld, int xcd_map, int *tile_counter) {
-  constexpr int KC = 32, TR = 128, NW = 4 * WCOL, NTH = 64 * NW;
-  constexpr int WSLAB = NTW * 32, SLAB = WSLAB * WCOL;
-  constexpr int A_BYTES = TR * KC * 4;                 // 16 KB of gathered rows per step
-  constexpr int B_BYTES = KC * SLAB * 4;               // weight chunk per step (f32, or bf16 heads + tails: same bytes)
-  constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int A_DMA = (A_BYTES / 1024) / NW;         // LDS-DMA instructions per wave and step (1 KB each)
-  constexpr int B_DMA = (B_BYTES / 1024) / NW;
-  constexpr int LPS = A_DMA + B_DMA;
-  constexpr int PIECE_BLKS = KC * WSLAB * 4 / 1024;    // 1 KB blocks in one column group's weight piece
-  static_assert(S >= 2 && S <= 5 && (S - 2) * LPS <= 63, "ring depth");
-  static_assert(S * STAGE >= TR * SLAB * 4, "the epilogue transposes the whole tile through the ring");
-  struct alignas(NTW == 3 ? 4 : 4 * NTW) BVec { float v[NTW]; };
-  // ALL of this kernel's LDS is the dynamic allocation, so that the ring starts at LDS offset 0: behind static __shared__
-  // variables it started at byte 1544 and every ds_read_b128 / 16-byte DMA was 8-byte misaligned (SQ_LDS_UNALIGNED_STALL on
-  // 80 % of the LDS cycles, 2x slower than the register-prefetch kernels).
-  HIP_DYNAMIC_SHARED(char, smem)                       // [S][A | B], s_rows[TR], s_stat[2 TR], s_kmask, s_idx[kvol][TR]
-  int *s_rows = (int *)(smem + S * STAGE);
-  float *s_stat = (float *)(s_rows + TR);
-  unsigned long long *s_kmask_p = (unsigned long long *)(s_stat + 2 * TR);
-  int *s_idx = (int *)(s_kmask_p + 2);
-#define s_kmask (*s_kmask_p)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave & 3, wc = wave >> 2;
-  const int col = lane & 31, kk = lane >> 5;
-  const int N = ls3d_count(n_rows, n_rows_dev);
-  const int ntiles = (N + TR - 1) / TR;
-  const int nwslab = w_ld / WSLAB;                     // packed: [kvol][wslab][cin][32][NTW] / [kvol][wslab][cin/32][chunk]
-  const int nslab = w_ld / SLAB;
-  const int nchunk = cin / KC;
-  const int tiles_per_xcd = (ntiles + 7) / 8;          // work item -> (tile, slab): see k_gather_gemm
-  // Persistent workgroups take work items from a global counter: with ~1 resident workgroup per CU a static grid of 680
-  // tiles on 256 CUs runs 3 waves of workgroups for 2.66 of work (measured: SIMDs without a wave 24 % of the time).
-  // Items are handed out in order, i.e. (mask-sorted rows) densest tiles first.
-  for (;;) {
-    __syncthreads();                                   // the previous item's epilogue has read s_rows / the ring
-    if (tid == 0) *(int *)s_kmask_p = atomicAdd(tile_counter, 1);
-    __syncthreads();
-    const int b = *(volatile int *)s_kmask_p;
-    if (b >= tiles_per_xcd * 8 * nslab) break;
-    __syncthreads();                                   // everyone has read the ticket before s_kmask is reused
-    int tile, slab;
-    if (xcd_map & 2) {
-      tile = b % (tiles_per_xcd * 8); slab = b / (tiles_per_xcd * 8);
-    } else {
-      const int xcd = b & 7, j = b >> 3;
-      slab = j % nslab;
-      tile = (xcd_map & 1) ? xcd * tiles_per_xcd + j / nslab : (j / nslab) * 8 + xcd;
-    }
-    if (tile >= ntiles) continue;
-    const int n0 = slab * SLAB;
-    const float *wbase = w + (size_t)slab * WCOL * cin * WSLAB;
-    // ---- tile prologue: output rows, their neighbour indices (LDS), per-lane / per-wave / per-tile offset masks
-    if (tid == 0) s_kmask = 0ull;
-    if (tid < TR) {
-      const int r = tile * TR + tid;
-      s_rows[tid] = r < N ? (order ? order[r] : r) : -1;
-    }
-    __syncthreads();
-    for (int i = tid; i < TR * kvol; i += NTH) {
-      const int r = i / kvol, k = i - r * kvol;
-      const int row = s_rows[r];
-      s_idx[k * TR + r] = row >= 0 ? tbl[(size_t)row * kvol + k] : -1;
-    }
-    __syncthreads();
-    unsigned vbits = 0u;                               // offsets at which THIS lane's row has a neighbour
-    unsigned long long wmask = 0ull;                   // ... at which any row of this wave has one
-    for (int k = 0; k < kvol; ++k) {
-      const int idx = s_idx[k * TR + wr * 32 + col];
-      if (idx >= 0) vbits |= 1u << k;
-      if (__any(idx >= 0)) wmask |= 1ull << k;
-    }
-    if (lane == 0 && wmask && wc == 0) atomicOr(&s_kmask, wmask);
-    __syncthreads();
-    f32x16 acc[NTW];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-    unsigned long long remI = s_kmask, remC = remI;
-    const int nsteps = __popcll(remI) * nchunk;
-    int kI = remI ? __ffsll((long long)remI) - 1 : 0, cI = 0;   // issue cursor
-    int kC = kI, cC = 0;                                         // compute cursor
-// ---- the DMAs of the step under the issue cursor, into ring stage st_
-#define LS3D_PIPE_ISSUE(st_)                                                                          \
-  do {                                                                                                \
-    char *stg_ = smem + (st_)*STAGE;                                                                  \
-    _Pragma("unroll") for (int j_ = 0; j_ < A_DMA; ++j_) {                                            \
-      const int blk_ = wave * A_DMA + j_;              /* 1 KB = 8 tile rows x 128 B */               \
-      const int r_ = blk_ * 8 + (lane >> 3);                                                          \
-      const int idx_ = s_idx[kI * TR + r_];                                                           \
-      const int pc_ = (lane & 7) ^ ((r_ >> 1) & 7);                                                   \
-      ls3d_glds16(in + (size_t)(idx_ >= 0 ? idx_ : 0) * in_ld + cI + pc_ * 4, stg_ + blk_ * 1024);    \
-    }                                                                                                 \
-    const float *wk_ = wbase + ((size_t)kI * cin * nwslab + cI) * WSLAB;                              \
-    _Pragma("unroll") for (int q_ = 0; q_ < B_DMA; ++q_) {                                            \
-      const int blk_ = wave * B_DMA + q_;                                                             \
-      const int p_ = blk_ / PIECE_BLKS, o_ = blk_ % PIECE_BLKS;                                       \
-      ls3d_glds16(wk_ + (size_t)p_ * cin * WSLAB + o_ * 256 + lane * 4, stg_ + A_BYTES + blk_ * 1024); \
-    }                                                                                                 \
-    cI += KC;                                                                                         \
-    if (cI >= cin) {                                                                                  \
-      cI = 0; remI &= remI - 1;                                                                       \
-      kI = remI ? __ffsll((long long)remI) - 1 : 0;                                                   \
-    }                                                                                                 \
-  } while (0)
-#pragma unroll
-    for (int s0 = 0; s0 < S - 2; ++s0)                // steps 0 .. S-3; iteration i of the loop below issues step i + S - 1
-      if (s0 < nsteps) LS3D_PIPE_ISSUE(s0);
-    // ---- MFMA fragments of one step, register resident: the 16 floats of this lane's row (channels [16 kk, 16 kk + 16) of
-    //      the chunk) and the weight values of the wave's NTW column blocks.  They are read from LDS one step AHEAD, while
-    //      the MFMAs of the current step run: the 8 waves of a workgroup leave the barrier together, so without this every
-    //      step opens with a 96 KB LDS read burst during which all four matrix pipes idle.
-    struct Frag {
-      float4 a0, a1, a2, a3;
-      uint4 bw[BF16 ? NTW : 1][4];                     // split-bf16: [n][t*2+h] heads / tails of k-step t
-      BVec bf[BF16 ? 1 : 16];                          // f32: one NTW-vector per k-step
-    };
-#define LS3D_PIPE_LOAD(fr_, st_)                                                                      \
-  do {                                                                                                \
-    const char *stg_ = smem + (st_)*STAGE;                                                            \
-    const int r_ = wr * 32 + col, sw_ = (r_ >> 1) & 7;                                                \
-    const float4 *ap_ = (const float4 *)(stg_ + r_ * 128);                                            \
-    fr_.a0 = ap_[(kk * 4 + 0) ^ sw_]; fr_.a1 = ap_[(kk * 4 + 1) ^ sw_];                               \
-    fr_.a2 = ap_[(kk * 4 + 2) ^ sw_]; fr_.a3 = ap_[(kk * 4 + 3) ^ sw_];                               \
-    if constexpr (BF16) {                                                                             \
-      const uint4 *bs_ = (const uint4 *)(stg_ + A_BYTES + wc * (KC * WSLAB * 4)) + kk * 32 + col;     \
-      _Pragma("unroll") for (int n_ = 0; n_ < NTW; ++n_)                                              \
-          _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) fr_.bw[n_][u_] = bs_[(n_ * 4 + u_) * 64];  \
-    } else {                                                                                          \
-      const float *bs_ = (const float *)(stg_ + A_BYTES) + wc * (KC * WSLAB) + (kk * 16 * 32 + col) * NTW; \
-      _Pragma("unroll") for (int u_ = 0; u_ < 16; ++u_) fr_.bf[u_] = *(const BVec *)(bs_ + u_ * 32 * NTW); \
-    }                                                                                                 \
-  } while (0)
-    Frag cur, nxt;
-    int kN = kC, cN = 0;                               // cursor of step i + 1 (the compute cursor kC, cC follows it)
-    unsigned long long remN = remC;
-#define LS3D_PIPE_ADVANCE(k_, c_, rem_)                                                               \
-  do {                                                                                                \
-    c_ += KC;                                                                                         \
-    if (c_ >= cin) {                                                                                  \
-      c_ = 0; rem_ &= rem_ - 1;                                                                       \
-      k_ = rem_ ? __ffsll((long long)rem_) - 1 : 0;                                                   \
-    }                                                                                                 \
-  } while (0)
-    int stN = 0, stI = S - 2;                          // ring stage of step i + 1 / of step i + S - 1
-    // iteration i: MFMAs of step i on `cur` while the fragments of step i + 1 travel LDS -> `nxt` and the DMAs of step
-    // i + S - 1 are issued.  Iteration -1 only loads the fragments of step 0 (one code path for every fragment load keeps
-    // hipcc's lgkmcnt bookkeeping at the loop head trivial: `cur` is always the product of the copy at the loop tail).
-    for (int i = -1; i < nsteps; ++i) {
-      // step i + 1 must have landed; steps issued after it so far: min(S - 3, nsteps - 2 - i)
-      if (i + 1 < nsteps) {
-        if (S >= 5 && nsteps - 2 - i >= 2) LS3D_WAIT_VMCNT(2 * LPS);
-        else if (S >= 4 && nsteps - 2 - i >= 1) LS3D_WAIT_VMCNT(1 * LPS);
-        else LS3D_WAIT_VMCNT(0);
-      }
-      LS3D_RAW_BARRIER();                              // step i+1 landed for every wave; the stage of step i-1 is free
-      if (i + S - 1 < nsteps) LS3D_PIPE_ISSUE(stI);
-      // unconditional (a wave that skips step i + 1, or the last iteration, reads bytes it never uses): a conditional load
-      // turns `nxt` into a phi and hipcc then copies every fragment register right behind its ds_read, i.e. waits for it
-      LS3D_PIPE_LOAD(nxt, stN);
-      LS3D_SCHED_FENCE();                              // the reads stay in flight under the MFMAs; `cur = nxt` (and its wait) after them
-      const bool act = i >= 0 && ((wmask >> kC) & 1ull);
-      if (act) {
-        const bool keep = (vbits >> kC) & 1u;
-        float4 z0 = cur.a0, z1 = cur.a1, z2 = cur.a2, z3 = cur.a3;
-        if (!keep) z0 = z1 = z2 = z3 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (BF16) {
-          uint4 ah0, al0, ah1, al1;
-          ls3d_split8(z0, z1, ah0, al0);
-          ls3d_split8(z2, z3, ah1, al1);
-          const bf16x8 vah0 = __builtin_bit_cast(bf16x8, ah0), val0 = __builtin_bit_cast(bf16x8, al0);
-          const bf16x8 vah1 = __builtin_bit_cast(bf16x8, ah1), val1 = __builtin_bit_cast(bf16x8, al1);
-#pragma unroll
-          for (int n = 0; n < NTW; ++n) {
-            const bf16x8 bh0 = __builtin_bit_cast(bf16x8, cur.bw[n][0]), bl0 = __builtin_bit_cast(bf16x8, cur.bw[n][1]);
-            const bf16x8 bh1 = __builtin_bit_cast(bf16x8, cur.bw[n][2]), bl1 = __builtin_bit_cast(bf16x8, cur.bw[n][3]);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val0, bh0, acc[n], 0, 0, 0);  // small terms first
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah0, bl0, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val1, bh1, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bl1, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah0, bh0, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah1, bh1, acc[n], 0, 0, 0);
-          }
-        } else {
-          const float av[16] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w, z2.x, z2.y, z2.z, z2.w, z3.x, z3.y, z3.z, z3.w};
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int n = 0; n < NTW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], cur.bf[u].v[n], acc[n], 0, 0, 0);
-        }
-      }
-      LS3D_SCHED_FENCE();
-      cur = nxt;
-      kC = kN; cC = cN; remC = remN;
-      if (i + 1 < nsteps) LS3D_PIPE_ADVANCE(kN, cN, remN);
-      stN = stN + 1 == S ? 0 : stN + 1;
-      stI = stI + 1 == S ? 0 : stI + 1;
-    }
-#undef LS3D_PIPE_LOAD
-#undef LS3D_PIPE_ADVANCE
-#undef LS3D_PIPE_ISSUE
-    gg_epilogue<NTW, WCOL, TR, TR, NTH>(acc, (float *)smem, s_rows, s_stat, wr, wc, kk, col, n0, cout, e, out, out_ld);
-  }
-}
-
-#undef s_kmask
-
-static int g_pipe = 0;  // 1: k_gg_pipe where it applies.  Off by default: on MI355X it is 10-20 % slower than the register-prefetch
-                        // kernels on every layer of the 120k-point frame (profiles/round1_experiments.md)
-extern "C" void ls3d_set_gather_pipeline(int on) { g_pipe = on ? 1 : 0; }
-
-// work-item counters of the persistent k_gg_pipe launches: a small device-resident ring, one slot per launch, zeroed on the
-// launch's own stream right before the kernel
-static int *g_pipe_counters = nullptr;
-static unsigned g_pipe_launches = 0;
-static int g_num_cus = 0;
-constexpr int LS3D_PIPE_COUNTER_SLOTS = 1024;
-
-template <int NTW, int WCOL, bool BF16, int S>
-static int launch_pipe(long long work_items, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
-                       const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
-  constexpr int STAGE = 128 * 32 * 4 + 32 * NTW * 32 * WCOL * 4;
-  constexpr int FIXED = 128 * 4 + 2 * 128 * 4 + 16;  // s_rows, s_stat, s_kmask
-  const size_t lds = (size_t)S * STAGE + FIXED + (size_t)kvol * 128 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_gg_pipe<NTW, WCOL, BF16, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S * STAGE + FIXED + 32 * 128 * 4)) != hipSuccess)
-      return LS3D_ERR_LAUNCH;
-    attr_set = true;
-  }
-  if (!g_pipe_counters) {
-    if (hipMalloc((void **)&g_pipe_counters, LS3D_PIPE_COUNTER_SLOTS * sizeof(int)) != hipSuccess) return LS3D_ERR_LAUNCH;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_num_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_num_cus < 1)
-      g_num_cus = 256;
-  }
-  int *counter = g_pipe_counters + (g_pipe_launches++ % LS3D_PIPE_COUNTER_SLOTS);
-  if (hipMemsetAsync(counter, 0, sizeof(int), stream) != hipSuccess) return LS3D_ERR_LAUNCH;
-  const int per_cu = (160 * 1024) / (int)(lds + 512) > 0 ? (160 * 1024) / (int)(lds + 512) : 1;  // resident workgroups per CU (LDS-limited)
-  long long nblk = (long long)g_num_cus * per_cu;
-  if (nblk > work_items) nblk = work_items;
-  hipLaunchKernelGGL((k_gg_pipe<NTW, WCOL, BF16, S>), dim3((unsigned)nblk), dim3(256 * WCOL), lds, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld,
-                     cout, n_rows, n_rows_dev, e, out, out_ld, g_xcd_map, counter);
-  return LS3D_OK;
-}
-
 template <int NT, int PL>
 static void launch_gg3(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
-                       const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
+                       const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld,
+                       int g_xcd_map) {
   if (tbl)
     hipLaunchKernelGGL((k_gather_gemm_bf16x3<NT, true, PL>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout, n_rows,
                        n_rows_dev, e, out, out_ld, g_xcd_map);
@@ -755,7 +486,8 @@ static void launch_gg3(dim3 grid, hipStream_t stream, const float *in, int in_ld
 
 template <int KC, int NT, int WC>
 static void launch_gg(dim3 grid, hipStream_t stream, const float *in, int in_ld, const int32_t *tbl, const int32_t *order, int kvol,
-                      const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld) {
+                      const float *w, int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e, float *out, int out_ld,
+                      int g_xcd_map) {
   if (tbl)
     hipLaunchKernelGGL((k_gather_gemm<KC, NT, WC, true>), grid, dim3(256), 0, stream, in, in_ld, tbl, order, kvol, w, cin, w_ld, cout,
                        n_rows, n_rows_dev, e, out, out_ld, g_xcd_map);
@@ -819,8 +551,9 @@ extern "C" int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src
 
 extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt,
                                 int wc, int precision, int cin, int cout, int n_rows, const int32_t *n_rows_dev,
-                                const ls3d_epilogue_t *epi, float *out, int out_ld, ls3d_stream_t stream_) {
+                                const ls3d_epilogue_t *epi, float *out, int out_ld, int flags, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int xcd_map = flags & 3;
   if (!in || !w || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
   if ((!tbl && kvol != 1) || kvol > 64) return LS3D_ERR_ARG;
@@ -840,31 +573,13 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   if (!gg_nt_ok(cout, nt) || (wc != 1 && wc != 2 && wc != 4) || (nt_total % (nt * wc)) || nt * wc > 4) return LS3D_ERR_ARG;
   const int slabs = nt_total / (nt * wc);
   if (e.ln_gamma && slabs != 1) return LS3D_ERR_ARG;  // the LayerNorm epilogue needs the whole row in one workgroup
-  // ---- sparse convolutions with cin % 32 == 0: the LDS-DMA pipelined kernel (geometries (nt, wc) = (1,1), (1,2), (2,2);
-  //      wc there = column groups of an 8-wave workgroup over a 128-row tile)
-  if (g_pipe && tbl && (cin % 32) == 0 && kvol <= 32 && !e.ln_gamma && (precision == LS3D_PRECISION_F32 || precision == LS3D_PRECISION_BF16X3) &&
-      ((nt == 1 && (wc == 1 || wc == 2)) || (nt == 2 && wc == 2))) {
-    const int ntiles_p = (n_rows + 127) / 128;
-    const long long nwg_p = (long long)((ntiles_p + 7) / 8) * 8 * slabs;
-    const bool bf = precision == LS3D_PRECISION_BF16X3;
-    int rc;
-#define LS3D_PIPE(NTW, WCOL, S) (bf ? launch_pipe<NTW, WCOL, true, S>(nwg_p, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld) \
-                                    : launch_pipe<NTW, WCOL, false, S>(nwg_p, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld))
-    if (nt == 1 && wc == 1) rc = LS3D_PIPE(1, 1, 3);
-    else if (nt == 1) rc = LS3D_PIPE(1, 2, 4);
-    else rc = LS3D_PIPE(2, 2, 4);
-#undef LS3D_PIPE
-    if (rc != LS3D_OK) return rc;
-    LS3D_RETURN_IF_LAUNCH_FAILED();
-    return LS3D_OK;
-  }
   const int tr = 32 * (4 / wc);
   const int ntiles = (n_rows + tr - 1) / tr;
   const long long nwg = (long long)((ntiles + 7) / 8) * 8 * slabs;  // one workgroup per (tile, slab), see the kernels
   dim3 grid((unsigned)(nwg < (1 << 20) ? nwg : (1 << 20)));
   if (precision == LS3D_PRECISION_BF16X3 || precision == LS3D_PRECISION_BF16X6) {
     if ((cin % 32) || wc != 1) return LS3D_ERR_ARG;
-#define LS3D_GG3(NT_, PL_) launch_gg3<NT_, PL_>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld)
+#define LS3D_GG3(NT_, PL_) launch_gg3<NT_, PL_>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld, xcd_map)
     if (precision == LS3D_PRECISION_BF16X3) {
       switch (nt) {
         case 1: LS3D_GG3(1, 2); break;
@@ -886,7 +601,7 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
   }
   if (precision != LS3D_PRECISION_F32) return LS3D_ERR_ARG;
   const bool k32 = (cin % 32) == 0;
-#define LS3D_GG(KC, NT, WC) launch_gg<KC, NT, WC>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld)
+#define LS3D_GG(KC, NT, WC) launch_gg<KC, NT, WC>(grid, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld, xcd_map)
 #define LS3D_GG_K(KC)                                              \
   switch (nt * 10 + wc) {                                          \
     case 11: LS3D_GG(KC, 1, 1); break;                             \

@@ -86,7 +86,8 @@ struct TilePlan {
   int32_t *tmeta;   // [T][TC_META]
   int32_t *thalo;   // [T][hs]       unique input rows of the tile, ascending
   uint16_t *tloc;   // [T][kvol][128] position of tbl[row][k] in the tile's halo, 0xFFFF = no neighbour
-  int32_t *torder;  // [T]           dispatch order of the tiles: most expensive first (k_tile_order)
+  int32_t *torder;  // [T + 1]       dispatch order of the tiles: most expensive first (k_tile_order); torder[T] = number of LIVE tiles (tiles
+                    //               with at least one row below the device row count)
 };
 
 static inline size_t tc_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -108,7 +109,7 @@ static TilePlan tc_plan(void *buf, int n_rows, int kvol) {
 extern "C" size_t ls3d_tile_plan_bytes(int n_rows, int kvol) {
   if (n_rows < 0 || kvol < 1) return 0;
   const size_t t = (size_t)(n_rows + TC_TR - 1) / TC_TR;
-  return tc_align(t * TC_TR * 4) + tc_align(t * TC_META * 4) + tc_align(t * kvol * TC_TR * 4) + tc_align(t * kvol * TC_TR * 2) + tc_align(t * 4);
+  return tc_align(t * TC_TR * 4) + tc_align(t * TC_META * 4) + tc_align(t * kvol * TC_TR * 4) + tc_align(t * kvol * TC_TR * 2) + tc_align((t + 1) * 4);
 }
 
 // one workgroup per tile.  The tile's distinct input rows: the <= kvol*128 table entries go through an LDS hash set (insertion
@@ -263,13 +264,19 @@ __global__ __launch_bounds__(1024) void k_tile_order(TilePlan p, int lpt) {
     int cost = m[6] ? nseg * __popc((unsigned)m[1]) : 0;
     return 255u - (unsigned)(cost < 255 ? cost : 255);
   };
+  __shared__ int s_live;
   if (tid < 256) s_base[tid] = 0;
+  if (tid == 0) s_live = 0;
   __syncthreads();
-  for (int t = tid; t < T; t += 1024) atomicAdd(&s_base[key_of(t)], 1);  // counts are order-independent
+  for (int t = tid; t < T; t += 1024) {
+    atomicAdd(&s_base[key_of(t)], 1);  // counts are order-independent
+    if (p.tmeta[(size_t)t * TC_META + 6]) atomicAdd(&s_live, 1);
+  }
   __syncthreads();
   if (tid == 0) {
     int run = 0;
     for (int d = 0; d < 256; ++d) { const int c = s_base[d]; s_base[d] = run; run += c; }
+    p.torder[T] = s_live;
   }
   __syncthreads();
   for (int r0 = 0; r0 < T; r0 += 1024) {
@@ -431,7 +438,7 @@ constexpr int TC_THREADS = 256;
 template <int NT, int NP>
 __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in, int in_ld, TilePlan p, const uint4 *__restrict__ wpk,
                                                              int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int ablate, int swz,
-                                                             int n_split, float *partial, int *counters) {
+                                                             int split_small, int split_tail, int split_forced, float *partial, int *counters) {
   constexpr int PU = NT * 192;             // 16-byte units of one (offset, chunk) weight piece
   constexpr int PB = NT * 3;               // ... in 1 KB LDS-DMA blocks
   constexpr int G = 4 / NT;                // offsets per step
@@ -458,7 +465,14 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   // finishes second adds the other's partial sums (through `partial`, [split tile][part][NT * 16][256] floats) and runs the
   // epilogue.  Half-size units at the end of the dispatch order keep the last round of a launch from running full-size tiles alone
   // on their CUs (677 tiles on 512 workgroup slots), and give launches of fewer tiles than slots two workgroups per CU.
-  const int nfull = p.ntiles - n_split;
+  // The split is decided HERE, from the plan's LIVE tile count (tiles with rows below the device row count), not from the table's
+  // capacity: a plan built on spare rows (capacity mode) and the plan of the exact table run the same units on the same tiles.
+  // The launch covers the worst case; workgroups beyond the units of the live tiles leave at once.
+  const int tlive = p.torder[p.ntiles];
+  int n_split = split_forced >= 0 ? split_forced : (tlive <= split_small ? tlive : split_tail);  // scalar
+  if (n_split > tlive) n_split = tlive;
+  const int nfull = tlive - n_split;
+  if ((int)blockIdx.x >= nfull + 2 * n_split) return;
   {
     int tile, part = 0, ksplit = 1, sidx = 0;
     if ((int)blockIdx.x < nfull) {
@@ -630,14 +644,14 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 
 template <int NT, int NP>
 static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TilePlan &p, const uint4 *wpk, int cin, int cout, const EpiDev &e, float *out,
-                     int out_ld, int ablate, int swz, int n_split, float *partial, int *counters) {
+                     int out_ld, int ablate, int swz, int max_units, int split_small, int split_tail, int split_forced, float *partial, int *counters) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tile_conv<NT, NP>), dim3((unsigned)(p.ntiles + n_split)), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout,
-                     e, out, out_ld, ablate, swz, n_split, partial, counters);
+  hipLaunchKernelGGL((k_tile_conv<NT, NP>), dim3((unsigned)max_units), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout,
+                     e, out, out_ld, ablate, swz, split_small, split_tail, split_forced, partial, counters);
   return LS3D_OK;
 }
 
@@ -678,22 +692,25 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
   const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;  // column blocks of the kernel variant (the weights are packed for it)
   const int ablate = flags & 28, split_mode = (flags >> 6) & 3, forced = (flags >> 8) & 0xFFF, tail = (flags >> 20) & 0x3FF;
   // Split over the input channels (two work units per tile, each over half of the 16-channel chunks) when the caller provides the
-  // workspace and the counters and the layer has >= 4 chunks: every tile of a launch that does not fill the chip's TC_SPLIT_MAX
-  // workgroup slots (level 4 of the 120k frame: 160 -> 125 us per layer).  Larger launches: the `tail` tiles at the end of the
-  // dispatch order when flags ask for it (measured on the 677- and 1071-tile levels: no gain over LPT dispatch alone, so off by default).
-  int n_split = 0;
+  // workspace and the counters and the layer has >= 4 chunks: every tile of a launch whose LIVE tiles do not fill the chip's
+  // TC_SPLIT_MAX workgroup slots (level 4 of the 120k frame: 160 -> 125 us per layer).  Larger launches: the `tail` tiles at the
+  // end of the dispatch order when flags ask for it (measured on the 677- and 1071-tile levels: no gain, so off by default).  The
+  // kernel applies the rule to the plan's live tile count; the host only sizes the grid for the worst case.
+  int split_small = 0, split_tail = 0, split_forced = -1, ns_grid = 0;
   if (workspace && counters && cin >= 64 && split_mode != 1) {
-    n_split = p.ntiles <= TC_SPLIT_MAX ? p.ntiles : (tail ? tail - 1 : 0);
-    if (forced) n_split = forced - 1;
-    if (split_mode == 2) n_split = p.ntiles;
-    if (n_split > TC_SPLIT_MAX) n_split = TC_SPLIT_MAX;
-    if (n_split > p.ntiles) n_split = p.ntiles;
-    if (workspace_bytes < tc_partial_bytes(n_split, nt)) return LS3D_ERR_WORKSPACE;
+    split_small = TC_SPLIT_MAX;                          // every tile when the live tiles do not fill the workgroup slots
+    split_tail = tail ? tail - 1 : 0;                    // otherwise this many at the end of the dispatch order
+    if (forced) split_forced = forced - 1;               // exactly this many, whatever the tile count
+    if (split_mode == 2) split_forced = TC_SPLIT_MAX;
+    if (split_tail > TC_SPLIT_MAX) split_tail = TC_SPLIT_MAX;
+    if (split_forced > TC_SPLIT_MAX) split_forced = TC_SPLIT_MAX;
+    ns_grid = p.ntiles < TC_SPLIT_MAX ? p.ntiles : TC_SPLIT_MAX;
+    if (workspace_bytes < tc_partial_bytes(ns_grid, nt)) return LS3D_ERR_WORKSPACE;
   }
   float *partial = (float *)workspace;
   const int swz = (flags >> 30) & 1 ? 0 : 1;
   int rc;
-#define TC_ARGS stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ablate, swz, n_split, partial, (int *)counters
+#define TC_ARGS stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ablate, swz, p.ntiles + ns_grid, split_small, split_tail, split_forced, partial, (int *)counters
   rc = nt == 1 ? (products == 8 ? tc_launch<1, 8>(TC_ARGS) : tc_launch<1, 6>(TC_ARGS))
      : nt == 2 ? (products == 8 ? tc_launch<2, 8>(TC_ARGS) : tc_launch<2, 6>(TC_ARGS))
                : (products == 8 ? tc_launch<4, 8>(TC_ARGS) : tc_launch<4, 6>(TC_ARGS));

@@ -396,8 +396,6 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
   }
 }
 
-static int g_tv_direct = 0;
-extern "C" void ls3d_set_transvfe_direct(int on) { g_tv_direct = on ? 1 : 0; }
 
 // packed nt = 2 weights ([slab][K][32][2] floats: W[k][slab * 64 + nb * 32 + col] at ((slab * K + k) * 32 + col) * 2 + nb) -> plane chunks
 __global__ __launch_bounds__(256) void k_tv_pack_planes(const float *__restrict__ w, int K, int N, uint4 *__restrict__ out) {
@@ -484,7 +482,7 @@ extern "C" int ls3d_transvfe(const float *voxels, const int32_t *num_points, int
   int rc;
   if (m->planes == 6) rc = tv_launch<6>(stream, blocks, lds_planes, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
   else if (m->planes == 8) rc = tv_launch<8>(stream, blocks, lds_planes, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
-  else if (g_tv_direct) rc = tv_launch<1>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  else if (m->flags & 1) rc = tv_launch<1>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
   else rc = tv_launch<0>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
   if (rc != LS3D_OK) return rc;
   LS3D_RETURN_IF_LAUNCH_FAILED();

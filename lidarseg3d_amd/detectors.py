@@ -18,12 +18,20 @@ from . import builder, ops
 from .registry import DETECTORS
 
 
-def _voxel_inputs(example, voxel_cfg):
-    """-> voxels, coordinates[V,4], num_points, batch_size, input_shape(x,y,z)"""
+import os as _os
+# Capacity mode (inference from `points`): the frame runs on device-side row counts - voxel count, strided-rulebook counts - with
+# tensors sized by capacities, so the host never waits for the GPU inside a frame and can submit the next frame while this one
+# runs.  LS3D_CAPACITY_MODE=0 restores host-side counts (three synchronisations per frame).  Results are bit-identical.
+CAPACITY_MODE = _os.environ.get("LS3D_CAPACITY_MODE", "1") != "0"
+
+
+def _voxel_inputs(example, voxel_cfg, capacity=False):
+    """-> voxels, coordinates[V,4], num_points, batch_size, input_shape(x,y,z), n_dev (device voxel count when the tensors carry
+    spare rows - capacity mode - else None)"""
     if "voxels" in example:
         shape = example["shape"][0] if "shape" in example else ops.make_grid(voxel_cfg["voxel_size"], voxel_cfg["range"])[1]
         return (example["voxels"], example["coordinates"], example["num_points"], len(example["num_voxels"]),
-                np.asarray(shape))
+                np.asarray(shape), None)
     if voxel_cfg is None:
         raise KeyError("example has no 'voxels' and the detector was built without a voxel_generator cfg")
     points = example["points"].contiguous()
@@ -32,16 +40,22 @@ def _voxel_inputs(example, voxel_cfg):
     mv = mv[1] if isinstance(mv, (list, tuple)) else mv
     mp = voxel_cfg.get("max_points_in_voxel", 5)
     _, grid = ops.make_grid(voxel_cfg["voxel_size"], voxel_cfg["range"])
-    if points.shape[0] <= int(mv) or batch_size == 1:
+    off = None
+    if points.shape[0] > int(mv) and batch_size > 1:
+        off = ops.frame_offsets(points, batch_size).tolist()  # one host sync: can any single frame reach the per-frame cap?
+    if off is None or max(b - a for a, b in zip(off[:-1], off[1:])) <= int(mv):
         # no frame can reach the dataloader's per-frame cap (a frame has at most as many voxels as points): one batched launch
         # is bit-identical to voxelising frame by frame
         v, c, n, nv = ops.voxelize_hard(points, voxel_cfg["voxel_size"], voxel_cfg["range"], mp, int(mv) * batch_size, batched=True)
+        if capacity and off is None:
+            # capacity mode: all min(N, cap) rows stay, the count stays on the device
+            example["num_voxels"] = ops.frame_offsets(c, batch_size, n_dev=nv).diff()
+            return v, c, n, batch_size, np.asarray(grid), nv
         V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it
         v, c, n = v[:V], c[:V], n[:V]
     else:
         # a frame may overflow max_voxel_num: the reference caps EACH frame (segpreprocess.py:148-177 runs per sample), so the
         # frames are voxelised one by one with that cap and concatenated as collate_kitti does (collate.py:141-150)
-        off = ops.frame_offsets(points, batch_size).tolist()
         parts = []
         for b in range(batch_size):
             fv, fc, fn, fnv = ops.voxelize_hard(points[off[b]:off[b + 1]].contiguous(), voxel_cfg["voxel_size"], voxel_cfg["range"], mp, int(mv),
@@ -51,7 +65,7 @@ def _voxel_inputs(example, voxel_cfg):
         v, c, n = (torch.cat([p[i] for p in parts]) for i in range(3))
         V = c.shape[0]
     example["num_voxels"] = ops.frame_offsets(c, batch_size).diff()
-    return v, c, n, batch_size, np.asarray(grid)
+    return v, c, n, batch_size, np.asarray(grid), None
 
 
 class SingleStageDetector(nn.Module):
@@ -70,6 +84,28 @@ class SingleStageDetector(nn.Module):
             return
         from .checkpoint import load_checkpoint
         load_checkpoint(self, pretrained, strict=False)
+
+
+def _capacity_ok(model, example, return_loss):
+    """capacity mode applies to inference from raw points on the device (or under the host emulation of the tests)"""
+    return (CAPACITY_MODE and not return_loss and not model.training and "voxels" not in example
+            and "points" in example and hasattr(model.backbone, "geometry_check") and getattr(model, "voxel_generator", None) is not None)
+
+
+def _capacity_forward(model, example, features):
+    """one inference frame on device-side row counts.  -> predict()'s list, or None when the frame has to be run again with host-side
+    counts (a stage without capacity support, or a rulebook that overflowed the capacity learned from earlier frames - the next
+    frames start from the worst case again)"""
+    ex = dict(example)
+    try:
+        data = features(ex)
+        model.point_head(batch_dict=data, return_loss=False)
+    except ops.CapacityModeUnsupported:
+        return None
+    if not model.backbone.geometry_check(data):
+        return None
+    example["num_voxels"] = ex["num_voxels"]
+    return model.point_head.predict(example=example, test_cfg=model.test_cfg)
 
 
 def _coords_ready(coords):
@@ -91,15 +127,23 @@ class SegNet(SingleStageDetector):
         self.voxel_generator = voxel_generator
         self.init_weights(pretrained=pretrained)
 
-    def forward_features(self, example):
-        voxels, coords, num, batch_size, shape = _voxel_inputs(example, self.voxel_generator)
+    def forward_features(self, example, capacity=False):
+        voxels, coords, num, batch_size, shape, n_dev = _voxel_inputs(example, self.voxel_generator, capacity)
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
                     points=example["points"][:, 0:4].contiguous())
         data["voxel_coords_ready"] = _coords_ready(coords)
-        data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
+        if n_dev is not None:
+            data["num_active_voxels_dev"] = n_dev
+            data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"], n_dev=n_dev)
+        else:
+            data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
         return self.backbone(data)
 
     def forward(self, example, return_loss=True, **kwargs):
+        if _capacity_ok(self, example, return_loss):
+            ret = _capacity_forward(self, example, lambda ex: self.forward_features(ex, capacity=True))
+            if ret is not None:
+                return ret
         data = self.forward_features(example)
         if return_loss:  # seg_net.py:86-103: labels in, per-task loss list + detached parts for the logger out
             data["voxel_sem_labels"], data["point_sem_labels"] = example["voxel_sem_labels"], example["point_sem_labels"]
@@ -123,6 +167,20 @@ class SegMSeg3DNet(SingleStageDetector):
         self.voxel_generator = voxel_generator
         self.init_weights(pretrained=pretrained)
 
+    def _capacity_features(self, example):
+        voxels, coords, num, batch_size, shape, n_dev = _voxel_inputs(example, self.voxel_generator, True)
+        data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
+                    points=example["points"][:, 0:4].contiguous())
+        data["voxel_coords_ready"] = _coords_ready(coords)
+        if n_dev is None:
+            raise ops.CapacityModeUnsupported("frame-by-frame voxelization")
+        data["num_active_voxels_dev"] = n_dev
+        data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"], n_dev=n_dev)
+        data = self.backbone(data)
+        data.update(points_cuv=example["points_cuv"], image_features=example["image_features"],
+                    camera_semantic_embeddings=example["camera_semantic_embeddings"], metadata=example.get("metadata"))
+        return data
+
     @staticmethod
     def _build_camera(build, cfg):
         """the camera CNN (HRNet / FCN head) is not part of this package: an unregistered type degrades to "features
@@ -138,7 +196,11 @@ class SegMSeg3DNet(SingleStageDetector):
             return None
 
     def forward(self, example, return_loss=True, **kwargs):
-        voxels, coords, num, batch_size, shape = _voxel_inputs(example, self.voxel_generator)
+        if _capacity_ok(self, example, return_loss) and (self.img_backbone is None or "image_features" in example):
+            ret = _capacity_forward(self, example, self._capacity_features)
+            if ret is not None:
+                return ret
+        voxels, coords, num, batch_size, shape, _ = _voxel_inputs(example, self.voxel_generator)
         if self.img_backbone is not None and "image_features" not in example:
             images = example["images"]
             ncam, hi, wi = images.shape[1], images.shape[3], images.shape[4]

@@ -96,7 +96,10 @@ class FCNMSeg3DHead(PackedModule):
         x = self._transform_inputs(batch_dict["inputs"])
         bn, _, h, w = x.shape
         bs = int(batch_dict["batch_size"])
-        if self.kernel_size == 1 and not self.training and (x.is_cuda or ops.sim_mode()):
+        # the fused HIP path is not differentiable: a frozen head in eval mode whose input carries a gradient (camera backbone being
+        # trained, input-gradient analysis) takes the torch composition below
+        wants_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()) and self.training)
+        if self.kernel_size == 1 and not self.training and not wants_grad and (x.is_cuda or ops.sim_mode()):
             pk = self.packed()
             rows0 = ops.nchw_to_nhwc(x.contiguous())  # [bn * h * w, Cin]: pixels are rows from here on
             rows = rows0
@@ -108,8 +111,9 @@ class FCNMSeg3DHead(PackedModule):
             per = (bn // bs) * h * w
             off = torch.arange(0, (bs + 1) * per, per, dtype=torch.int32, device=x.device)
             emb = ops.sfam(rows, logit_rows, off, bs, per).permute(0, 2, 1).contiguous().unsqueeze(3)
-            feature = rows.view(bn, h, w, self.channels).permute(0, 3, 1, 2)       # NCHW views of the channels-last rows
-            output = logit_rows.view(bn, h, w, self.num_classes).permute(0, 3, 1, 2)
+            # contiguous NCHW like the reference's outputs (fcn_mseg3d_head.py:175-200): downstream .view() calls work
+            feature = rows.view(bn, h, w, self.channels).permute(0, 3, 1, 2).contiguous()
+            output = logit_rows.view(bn, h, w, self.num_classes).permute(0, 3, 1, 2).contiguous()
         else:
             feature = self.convs(x)
             if self.concat_input:

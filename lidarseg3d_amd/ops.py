@@ -19,23 +19,17 @@ _i32 = torch.int32
 _SIM = False
 
 
-_XCD_SET = False
-
-
 def _L():
-    global _XCD_SET
-    L = _lib.load()
-    if not _XCD_SET:
-        _XCD_SET = True
-        L.ls3d_set_xcd_map(int(_os_environ_get("LS3D_XCD_MAP", "0")))
-        L.ls3d_set_gather_pipeline(1 if _PIPELINE else 0)
-        L.ls3d_set_transvfe_direct(1 if _os_environ_get("LS3D_TRANSVFE_DIRECT", "0") != "0" else 0)
-    return L
+    return _lib.load()
 
 
 def _os_environ_get(k, d):
     import os
     return os.environ.get(k, d)
+
+
+class CapacityModeUnsupported(RuntimeError):
+    """raised by a stage that cannot run on device-side row counts; the detector then runs the frame with host-side counts"""
 
 
 def set_sim(flag):
@@ -210,7 +204,7 @@ class TransVFEModel(object):
         self.num_out = compress[0].shape[0] if compress is not None else num_embed
         self.c = _lib.TransVFE(embed[0].data_ptr(), embed[1].data_ptr(), compress[0].data_ptr() if compress is not None else None,
                                compress[1].data_ptr() if compress is not None else None, arr, len(layers),
-                               compress[0].shape[0] if compress is not None else 0, num_embed, num_head, ffn, token_ld, int(planes))
+                               compress[0].shape[0] if compress is not None else 0, num_embed, num_head, ffn, token_ld, int(planes), 0)
 
     def for_planes(self, products):
         """the same reader on the exact 3-plane bf16 split with `products` (6 | 8) plane products per f32 product (built once)"""
@@ -238,7 +232,7 @@ _TRANSVFE_PLANES = _os.environ.get("LS3D_TRANSVFE_PLANES", "1") != "0"
 _GATHER_X6 = _os.environ.get("LS3D_GATHER_X6", "1") != "0"  # bf16x6: strided / inverse layers on the 6-product gather-GEMM (split accumulators); 0: exact f32
 
 
-def transvfe(voxels, num_points, model):
+def transvfe(voxels, num_points, model, n_dev=None):
     """the whole TransformerVoxelFeatureExtractor in one kernel; returns None if the configuration is not the one the fused
     kernel is specialised for (the caller then composes the layer from the individual ops).  In the 3-plane modes of
     ops.set_precision the reader's GEMMs run on the same exact bf16 split as the SubM convolutions."""
@@ -247,7 +241,8 @@ def transvfe(voxels, num_points, model):
     products = tile_products() if _TRANSVFE_PLANES else 0
     m = model.for_planes(products) if products else model
     out = torch.empty((n, model.num_out), dtype=torch.float32, device=voxels.device)
-    rc = _L().ls3d_transvfe(_ptr(voxels), _ptr(num_points), n, None, p, c, ctypes.byref(m.c), _ptr(out), model.num_out, _stream(voxels))
+    m.c.flags = 1 if _TRANSVFE_DIRECT else 0
+    rc = _L().ls3d_transvfe(_ptr(voxels), _ptr(num_points), n, _ndev(n_dev), p, c, ctypes.byref(m.c), _ptr(out), model.num_out, _stream(voxels))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "ls3d_transvfe")
@@ -283,22 +278,24 @@ def hash_capacity(n):
     return c
 
 
-def index_build(coords, shape_zyx):
+def index_build(coords, shape_zyx, n_dev=None):
+    """n_dev (here and in the functions below): optional device int32 holding the number of valid rows; coords.shape[0] is then a
+    capacity and rows beyond the count are ignored / left unwritten (include/ls3d.h: producer -> consumer chains without host syncs)"""
     n = coords.shape[0]
     cap = hash_capacity(n)
     keys = torch.empty((cap,), dtype=torch.int64, device=coords.device)
     vals = torch.empty((cap,), dtype=_i32, device=coords.device)
-    check(_L().ls3d_index_build(_ptr(coords), n, None, _i3(shape_zyx), _ptr(keys), _ptr(vals), cap, _stream(coords)),
+    check(_L().ls3d_index_build(_ptr(coords), n, _ndev(n_dev), _i3(shape_zyx), _ptr(keys), _ptr(vals), cap, _stream(coords)),
           "ls3d_index_build")
     return keys, vals
 
 
-def rulebook_subm(coords, shape_zyx, ksize, index=None):
+def rulebook_subm(coords, shape_zyx, ksize, index=None, n_dev=None):
     n = coords.shape[0]
-    keys, vals = index if index is not None else index_build(coords, shape_zyx)
+    keys, vals = index if index is not None else index_build(coords, shape_zyx, n_dev)
     kvol = int(ksize[0] * ksize[1] * ksize[2])
     nbr = torch.empty((n, kvol), dtype=_i32, device=coords.device)
-    check(_L().ls3d_rulebook_subm(_ptr(coords), n, None, _i3(shape_zyx), _i3(ksize), _ptr(keys), _ptr(vals),
+    check(_L().ls3d_rulebook_subm(_ptr(coords), n, _ndev(n_dev), _i3(shape_zyx), _i3(ksize), _ptr(keys), _ptr(vals),
                                   keys.numel(), _ptr(nbr), _stream(coords)), "ls3d_rulebook_subm")
     return nbr
 
@@ -343,27 +340,30 @@ def set_row_order(kind):
     _ROW_ORDER = kind
 
 
-def rulebook_order(tbl, coords=None):
+def rulebook_order(tbl, coords=None, n_dev=None):
     """processing order of a rulebook table's rows: sorted by neighbour bitmask, densest rows first (kernel
     ls3d_rulebook_masks; the sort itself is torch.argsort - plumbing; rulebook_orders below does several tables with one sort).
     `coords` is unused (a region-blocked order was measured slower, profiles/round1_experiments.md)."""
     n, kvol = tbl.shape
     if n == 0 or kvol > 31 or _ROW_ORDER == "none":
         return None
-    return rulebook_orders([tbl])[0]
+    return rulebook_orders([tbl], [n_dev])[0]
 
 
 F32, BF16X3, BF16X6, BF16X8 = 0, 1, 2, 3
-_PRECISION = F32
 _PREC_NAMES = {"f32": F32, "bf16x3": BF16X3, "bf16x6": BF16X6, "bf16x8": BF16X8}
+# Default since round 3: "bf16x6", the f32-grade arithmetic whose end-to-end error against float64 is BELOW the exact-f32 MFMA path's own
+# on every frame measured (DESIGN.md 4.1; asserted by tests/test_gpu_parity.py::test_sdseg3d_every_arithmetic_vs_float64_... and
+# ..._are_f32_grade_on_other_frames) at 1.5x its speed.  LS3D_PRECISION=f32 (or set_precision("f32")) selects exact-f32 MFMA everywhere.
+_PRECISION = _PREC_NAMES[_os.environ.get("LS3D_PRECISION", "bf16x6")]
 
 
 def set_precision(name):
-    """arithmetic of the sparse convolutions: "f32" (default; exact f32 MFMA), the f32-grade 3-plane modes "bf16x8" / "bf16x6" (exact
-    3-way bf16 split of both operands with round-to-nearest planes; every plane product except tail x tail / the 6 products of weight
-    >= 2^-16, head x head in its own accumulator; SubM layers on the tile-halo kernel ls3d_tile_conv, strided and inverse layers exact
-    f32; measured end-to-end logit error against float64: 0.6x / 0.8x of the exact-f32 path's rms) or "bf16x3" (2-way split, 3
-    products on the gather-GEMM: ~1e-5 relative error per layer)."""
+    """arithmetic of the sparse convolutions: "bf16x6" (default) / "bf16x8": the f32-grade 3-plane modes (exact 3-way bf16 split of both
+    operands with round-to-nearest planes; the 6 plane products of weight >= 2^-16 / every product except tail x tail, head x head in
+    its own accumulator; SubM layers on the tile-halo kernel ls3d_tile_conv, strided and inverse layers on the 6-product gather-GEMM /
+    exact f32; measured end-to-end logit error against float64: 0.4x / 0.6x of the exact-f32 path's rms), "f32" (exact f32 MFMA
+    everywhere) or "bf16x3" (2-way split, 3 products on the gather-GEMM: ~1e-5 relative error per layer, NOT f32-grade)."""
     global _PRECISION
     _PRECISION = _PREC_NAMES[name]
 
@@ -422,7 +422,7 @@ def radix_argsort(keys, bits=32):
     return perm
 
 
-def rulebook_orders(tbls):
+def rulebook_orders(tbls, n_devs=None):
     """rulebook_order for several tables at once: one batched sort (keys carry the table number in their top bits) instead
     of one sort per table - the sorts are launch-bound (~10 small kernels each).  -> list of int32 orders (None where a
     table has no rows / too many offsets / row order is disabled)."""
@@ -439,7 +439,7 @@ def rulebook_orders(tbls):
         L = _L()
         for s, i in enumerate(grp):
             t = tbls[i]
-            check(L.ls3d_rulebook_sort_keys(_ptr(t), t.shape[0], None, t.shape[1], s, 1 if descending else 0,
+            check(L.ls3d_rulebook_sort_keys(_ptr(t), t.shape[0], _ndev(n_devs[i]) if n_devs is not None else None, t.shape[1], s, 1 if descending else 0,
                                             ctypes.c_void_p(keys.data_ptr() + 4 * offs[s]), _stream(t)), "ls3d_rulebook_sort_keys")
         perm = radix_argsort(keys, 27 + max(len(grp) - 1, 1).bit_length())  # in-library stable radix sort (csrc/sort.hip)
         local = torch.empty((offs[-1],), dtype=_i32, device=dev)
@@ -450,39 +450,25 @@ def rulebook_orders(tbls):
     return out
 
 
-_PIPELINE = _os.environ.get("LS3D_PIPELINE", "0") != "0"  # measured slower than the register-prefetch kernels (profiles/round1_experiments.md)
-_PIPE_WIDE_ROWS = int(_os.environ.get("LS3D_PIPE_WIDE_ROWS", "0"))
-
-
-def set_pipeline(on):
-    """sparse convolutions with cin % 32 == 0 on the LDS-DMA pipelined kernel, or (default) on the register-prefetch kernels"""
-    global _PIPELINE
-    _PIPELINE = bool(on)
-    _L().ls3d_set_gather_pipeline(1 if on else 0)
+_TRANSVFE_DIRECT = _os.environ.get("LS3D_TRANSVFE_DIRECT", "0") != "0"
+_GEMM_FLAGS = int(_os.environ.get("LS3D_XCD_MAP", "0")) & 3  # per-call flags of ls3d_gather_gemm (workgroup -> tile mapping, A/B)
 
 
 def set_transvfe_direct(on):
-    """fused TransVFE reader with its weights read straight from L2 (no LDS staging, no workgroup barriers): experimental, not yet
-    measured on the device (env LS3D_TRANSVFE_DIRECT=1 sets it at start-up)"""
-    _L().ls3d_set_transvfe_direct(1 if on else 0)
+    """fused TransVFE reader with its weights read straight from L2 (no LDS staging, no workgroup barriers): experimental, measured
+    slower (descriptor flag of ls3d_transvfe; env LS3D_TRANSVFE_DIRECT=1 sets it at start-up)"""
+    global _TRANSVFE_DIRECT
+    _TRANSVFE_DIRECT = bool(on)
 
 
-def pipeline_geometry(cout, n_rows, prec):
-    """(nt, wc) for the pipelined kernel, or None if the column count has no pipelined geometry: <= 32 columns (1,1);
-    <= 64 (1,2); 128 -> (2,2) (one 8-wave workgroup per 128-row tile covers the whole row, the gathered rows are staged
-    once) when the launch still has >= LS3D_PIPE_WIDE_ROWS rows, else two (1,2) slabs"""
-    total = (cout + 31) // 32
-    if total == 1:
-        return 1, 1
-    if total == 2:
-        return 1, 2
-    if total == 4:
-        return (2, 2) if n_rows >= _PIPE_WIDE_ROWS else (1, 2)
-    return None
+def set_gemm_flags(flags):
+    """per-call flags of ls3d_gather_gemm (include/ls3d.h): workgroup -> (tile, slab) mapping for A/B runs; results identical"""
+    global _GEMM_FLAGS
+    _GEMM_FLAGS = int(flags) & 3
 
 
 def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,
-                out=None, out_ld=None, in_ld=None, cin=None, ln=None):
+                out=None, out_ld=None, in_ld=None, cin=None, ln=None, n_dev=None):
     """out[r, :cout] = epilogue(sum_k W[k]^T x[tbl[r,k]]).  w: packing.PackedWeight."""
     kvol, wcin, wld = w.shape
     cin = cin or wcin
@@ -502,16 +488,12 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
         # these layers in exact f32; LS3D_GATHER_X6=0 restores that).  (With the tile path switched off, "bf16x6" is that gather-GEMM
         # for every layer.)
         prec = F32
-    pipe = pipeline_geometry(cout, rows_hint, prec) if (_PIPELINE and tbl is not None and cin % 32 == 0 and kvol <= 32 and ln is None) else None
-    if pipe is not None:
-        nt, wc = pipe
-    else:
-        nt, wc = choose_geometry(cout, rows_hint)
-        if ln is not None:  # LayerNorm epilogue: the whole row must sit in one workgroup slab
-            assert cout <= 128, "LayerNorm epilogue supports up to 128 columns"
-            nt, wc = (cout + 31) // 32, 1
-        if prec != F32:
-            wc = 1
+    nt, wc = choose_geometry(cout, rows_hint)
+    if ln is not None:  # LayerNorm epilogue: the whole row must sit in one workgroup slab
+        assert cout <= 128, "LayerNorm epilogue supports up to 128 columns"
+        nt, wc = (cout + 31) // 32, 1
+    if prec != F32:
+        wc = 1
     wdata = w.for_nt(nt, prec)
     if tbl is not None:
         n_rows = tbl.shape[0] if n_rows is None else n_rows
@@ -528,8 +510,8 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0, _vp(ln[0]) if ln is not None else ctypes.c_void_p(0),
                    _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
-    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, wc, prec, cin, cout, n_rows, None, ctypes.byref(epi),
-                                _vp_any(out_view), out_ld, _stream(x)), "ls3d_gather_gemm")
+    check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, wc, prec, cin, cout, n_rows, _ndev(n_dev), ctypes.byref(epi),
+                                _vp_any(out_view), out_ld, _GEMM_FLAGS, _stream(x)), "ls3d_gather_gemm")
     return out
 
 
@@ -574,8 +556,8 @@ def use_tile(kind, kvol, cin, cout):
 
 
 class TilePlan(object):
-    """device-resident plan of ls3d_tile_build for one rulebook table"""
-    __slots__ = ("buf", "n_rows", "kvol", "order", "tbl")
+    """device-resident plan of ls3d_tile_build for one rulebook table (n_dev: device count of the table's valid rows, or None)"""
+    __slots__ = ("buf", "n_rows", "kvol", "order", "tbl", "n_dev")
 
     def record_stream(self, s):
         self.buf.record_stream(s)
@@ -583,29 +565,29 @@ class TilePlan(object):
             self.order.record_stream(s)
 
 
-def tile_keys(coords, shape_zyx, batch):
+def tile_keys(coords, shape_zyx, batch, n_dev=None):
     n = coords.shape[0]
     keys = torch.empty((n,), dtype=_i32, device=coords.device)
-    check(_L().ls3d_tile_keys(_ptr(coords), n, None, _i3(shape_zyx), int(batch), _ptr(keys), _stream(coords)), "ls3d_tile_keys")
+    check(_L().ls3d_tile_keys(_ptr(coords), n, _ndev(n_dev), _i3(shape_zyx), int(batch), _ptr(keys), _stream(coords)), "ls3d_tile_keys")
     return keys
 
 
-def tile_plan(tbl, coords, shape_zyx, batch, order=None):
+def tile_plan(tbl, coords, shape_zyx, batch, order=None, n_dev=None):
     """plan for table tbl[n, kvol] whose output sites are coords[n, 4] (b, z, y, x).  `order`: a precomputed spatial row
     order (int32 permutation); default = stable sort of ls3d_tile_keys (torch.sort: plumbing)."""
     n, kvol = tbl.shape
     L = _L()
     p = TilePlan()
-    p.n_rows, p.kvol, p.tbl = n, kvol, tbl
+    p.n_rows, p.kvol, p.tbl, p.n_dev = n, kvol, tbl, n_dev
     p.buf = torch.empty((max(int(L.ls3d_tile_plan_bytes(n, kvol)), 256),), dtype=torch.uint8, device=tbl.device)
     if order is None:  # keys -> in-library radix sort -> plan: one C call (ls3d_tile_plan)
         ws = _ws(L.ls3d_tile_plan_workspace_bytes(n), tbl)
-        check(L.ls3d_tile_plan(_ptr(tbl), _ptr(coords), n, None, kvol, _i3(shape_zyx), int(batch), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(p.buf),
+        check(L.ls3d_tile_plan(_ptr(tbl), _ptr(coords), n, _ndev(n_dev), kvol, _i3(shape_zyx), int(batch), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(p.buf),
                                ctypes.c_size_t(p.buf.numel()), _TILE_PLAN_FLAGS, _stream(tbl)), "ls3d_tile_plan")
         p.order = None  # the spatial order lives in the call's workspace and is not needed once the plan is built
         return p
     p.order = order
-    check(L.ls3d_tile_build(_ptr(tbl), n, None, kvol, _ptr(order), _ptr(p.buf), ctypes.c_size_t(p.buf.numel()), _TILE_PLAN_FLAGS, _stream(tbl)),
+    check(L.ls3d_tile_build(_ptr(tbl), n, _ndev(n_dev), kvol, _ptr(order), _ptr(p.buf), ctypes.c_size_t(p.buf.numel()), _TILE_PLAN_FLAGS, _stream(tbl)),
           "ls3d_tile_build")
     return p
 
@@ -696,10 +678,10 @@ def _vp_any(t):
 
 
 # ---------------------------------------------------------------------------------------------- devoxelization
-def voxel_centers(coords, voxel_size, pc_range):
+def voxel_centers(coords, voxel_size, pc_range, n_dev=None):
     n = coords.shape[0]
     out = torch.empty((n, 4), dtype=torch.float32, device=coords.device)
-    check(_L().ls3d_voxel_centers(_ptr(coords), n, None, _f3(voxel_size), _f3(pc_range[:3]), _ptr(out), _stream(coords)),
+    check(_L().ls3d_voxel_centers(_ptr(coords), n, _ndev(n_dev), _f3(voxel_size), _f3(pc_range[:3]), _ptr(out), _stream(coords)),
           "ls3d_voxel_centers")
     return out
 
@@ -731,7 +713,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return g
 
 
-def frame_offsets(table, batch_size, col=0):
+def frame_offsets(table, batch_size, col=0, n_dev=None):
     """[B+1] int32 device offsets of the frames of a frame-sorted table (f32 points or int32 coordinates, batch index in
     column `col`); a 1-D tensor is taken as the batch column itself.  One tiny kernel, no host sync."""
     if table.dim() == 1:
@@ -742,7 +724,7 @@ def frame_offsets(table, batch_size, col=0):
     if not is_float and table.dtype != _i32:
         table = table.to(_i32)
     off = torch.empty((batch_size + 1,), dtype=_i32, device=table.device)
-    check(_L().ls3d_frame_offsets(_ptr(table), is_float, table.shape[1], col, table.shape[0], batch_size, _ptr(off), _stream(table)),
+    check(_L().ls3d_frame_offsets(_ptr(table), is_float, table.shape[1], col, table.shape[0], _ndev(n_dev), batch_size, _ptr(off), _stream(table)),
           "ls3d_frame_offsets")
     return off
 
@@ -758,7 +740,7 @@ def devoxelize(points, pt_off, centers, vx_off, batch, max_frame_points, feat, c
     return (out, idx) if return_idx else out
 
 
-def devoxelize_grid(points, pt_off, coords, centers, vx_off, batch, voxel_size, pc_range, feat, c=None, return_idx=False):
+def devoxelize_grid(points, pt_off, coords, centers, vx_off, batch, voxel_size, pc_range, feat, c=None, return_idx=False, n_dev=None):
     """grid-accelerated exact 3-NN devoxelization (known points = voxel centres on the voxel lattice).
     feat=None: the neighbour search only -> (idx [n,3] int32 frame-local, weight [n,3]); finish with interpolate_rows."""
     n = points.shape[0]
@@ -778,7 +760,7 @@ def devoxelize_grid(points, pt_off, coords, centers, vx_off, batch, voxel_size, 
     L = _L()
     V = coords.shape[0]
     ws = _ws(L.ls3d_devoxelize_grid_workspace_bytes(n, V, batch, _i3(grid)), points)
-    check(L.ls3d_devoxelize_grid(_ptr(points), points.shape[1], n, _ptr(pt_off), n, _ptr(coords), _ptr(centers), V, None, _ptr(vx_off), batch,
+    check(L.ls3d_devoxelize_grid(_ptr(points), points.shape[1], n, _ptr(pt_off), n, _ptr(coords), _ptr(centers), V, _ndev(n_dev), _ptr(vx_off), batch,
                                  _f3(voxel_size), _f3(pc_range[:3]), _i3(grid), _ptr(feat), feat_ld, c, _ptr(out), c,
                                  _ptr(idx), _ptr(w), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(points)), "ls3d_devoxelize_grid")
     if search_only:
@@ -877,19 +859,24 @@ class SffmModel(object):
         self.keep.extend([norm[0], norm[1]] if norm is not None else [])
         self.c = Sffm(self.keep[0].data_ptr(), b_in.data_ptr(), arr, len(layers), int(d_in), int(d_model), int(heads), int(ffn),
                       norm[0].data_ptr() if norm is not None else None, norm[1].data_ptr() if norm is not None else None,
-                      float(norm[2]) if norm is not None else 0.0)
+                      float(norm[2]) if norm is not None else 0.0, 0)
+
+
+_SFFM_ATTENTION = 0
 
 
 def set_sffm_attention(mode):
     """"f32" (default: exact-f32 MFMA), "bf16" / "fp8" (MFMA operands rounded to bf16 / OCP e4m3, f32 accumulation and softmax) or
-    "valu" (vector pipe)"""
-    _L().ls3d_set_sffm_attention({"f32": 0, "bf16": 1, "valu": 2, "fp8": 3}[mode])
+    "valu" (vector pipe): the `attention` field of the ls3d_sffm_t descriptor that sffm_decoder passes with each call"""
+    global _SFFM_ATTENTION
+    _SFFM_ATTENTION = {"f32": 0, "bf16": 1, "valu": 2, "fp8": 3}[mode]
 
 
 def sffm_decoder(x, points, kv, L, batch, model):
     """fused point side of the SF-Phase decoder (ls3d_sffm_decoder); returns None when the shape is not supported"""
     n = x.shape[0]
     out = torch.empty((n, model.c.d_model), dtype=torch.float32, device=x.device)
+    model.c.attention = _SFFM_ATTENTION
     rc = _L().ls3d_sffm_decoder(_ptr(x), x.shape[1], n, _ptr(points), points.shape[1] if points.dim() == 2 else 1, _ptr(kv), int(L), int(batch),
                                 ctypes.byref(model.c), _ptr(out), out.shape[1], _stream(x))
     if rc == _lib.ERR_UNSUPPORTED:

@@ -54,9 +54,9 @@ def _make_convcls_head(fc_cfg, input_channels, output_channels, dp_ratio=0):
     return nn.Sequential(*layers)
 
 
-def _frame_layout(points, conv_point_coords, batch_size):
-    """device offsets of the frame-sorted point / voxel rows + host upper bounds for the launch grids"""
-    return ops.frame_offsets(points, batch_size), ops.frame_offsets(conv_point_coords, batch_size)
+def _frame_layout(points, conv_point_coords, batch_size, n_dev=None):
+    """device offsets of the frame-sorted point / voxel rows (n_dev: device count of the valid voxel rows in capacity mode)"""
+    return ops.frame_offsets(points, batch_size), ops.frame_offsets(conv_point_coords, batch_size, n_dev=n_dev)
 
 
 def _devoxelize(batch_dict, points, centers, feat, batch_size):
@@ -66,10 +66,11 @@ def _devoxelize(batch_dict, points, centers, feat, batch_size):
     if ds is not None and ds["centers"] is centers and ds["points"] is points:
         # the backbone already ran the neighbour search (geometry only) beside its conv stack: interpolate
         return ops.interpolate_rows(feat, ds["idx"], ds["weight"], points, ds["vx_off"]), ds["vx_off"]
-    pt_off, vx_off = _frame_layout(points, centers, batch_size)
+    n_dev = batch_dict.get("num_active_voxels_dev")
+    pt_off, vx_off = _frame_layout(points, centers, batch_size, n_dev)
     if "conv_point_indices" in batch_dict and "voxel_geometry" in batch_dict:
         vs, rng = batch_dict["voxel_geometry"]
-        return ops.devoxelize_grid(points, pt_off, batch_dict["conv_point_indices"], centers, vx_off, batch_size, vs, rng, feat), vx_off
+        return ops.devoxelize_grid(points, pt_off, batch_dict["conv_point_indices"], centers, vx_off, batch_size, vs, rng, feat, n_dev=n_dev), vx_off
     return ops.devoxelize(points, pt_off, centers, vx_off, batch_size, points.shape[0], feat), vx_off
 
 
@@ -78,9 +79,10 @@ def _devox_search(batch_dict, points, centers, batch_size):
     ds = batch_dict.get("devox_search")
     if ds is not None and ds["centers"] is centers and ds["points"] is points:
         return ds["idx"], ds["weight"], ds["vx_off"]
-    pt_off, vx_off = _frame_layout(points, centers, batch_size)
+    n_dev = batch_dict.get("num_active_voxels_dev")
+    pt_off, vx_off = _frame_layout(points, centers, batch_size, n_dev)
     vs, rng = batch_dict["voxel_geometry"]
-    idx, w = ops.devoxelize_grid(points, pt_off, batch_dict["conv_point_indices"], centers, vx_off, batch_size, vs, rng, None)
+    idx, w = ops.devoxelize_grid(points, pt_off, batch_dict["conv_point_indices"], centers, vx_off, batch_size, vs, rng, None, n_dev=n_dev)
     return idx, w, vx_off
 
 

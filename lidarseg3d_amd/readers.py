@@ -23,9 +23,10 @@ class MeanVoxelFeatureExtractor(nn.Module):
         self.name = name
         self.num_input_features = num_input_features
 
-    def forward(self, features, num_voxels, coors=None):
+    def forward(self, features, num_voxels, coors=None, n_dev=None):
+        """n_dev (all readers; not in the reference): device count of the valid voxels when `features` has spare rows (capacity mode)"""
         assert self.num_input_features == features.shape[-1]
-        return ops.vfe_mean(features.contiguous(), num_voxels.to(torch.int32).contiguous())
+        return ops.vfe_mean(features.contiguous(), num_voxels.to(torch.int32).contiguous(), n_dev=n_dev)
 
 
 @READERS.register_module
@@ -37,9 +38,9 @@ class ImprovedMeanVoxelFeatureExtractor(nn.Module):
         self.name = name
         self.num_input_features = num_input_features
 
-    def forward(self, features, num_voxels, coors=None, out_ld=None):
+    def forward(self, features, num_voxels, coors=None, out_ld=None, n_dev=None):
         assert self.num_input_features == features.shape[-1]
-        return ops.vfe_improved_mean(features.contiguous(), num_voxels.to(torch.int32).contiguous(), out_ld=out_ld)
+        return ops.vfe_improved_mean(features.contiguous(), num_voxels.to(torch.int32).contiguous(), out_ld=out_ld, n_dev=n_dev)
 
 
 class TransformerEncoderLayerPreNorm(nn.Module):
@@ -143,7 +144,7 @@ class TransformerVoxelFeatureExtractor(PackedModule):
         x = x.max(dim=0)[0]
         return self.compress_layer(x) if self.compress_layer is not None else x
 
-    def forward(self, features, num_voxels, coors=None):
+    def forward(self, features, num_voxels, coors=None, n_dev=None):
         assert self.num_input_features == features.shape[-1]
         if self.training:
             return self._forward_train(features, num_voxels)
@@ -152,9 +153,11 @@ class TransformerVoxelFeatureExtractor(PackedModule):
         V, P, C = features.shape
         E, H = self.num_embed, self.num_head
         if pk["fused"] is not None and _FUSED:
-            y = ops.transvfe(features.contiguous(), num_voxels.to(torch.int32).contiguous(), pk["fused"])
+            y = ops.transvfe(features.contiguous(), num_voxels.to(torch.int32).contiguous(), pk["fused"], n_dev=n_dev)
             if y is not None:
                 return y
+        if n_dev is not None:
+            raise ops.CapacityModeUnsupported("the layer-by-layer TransVFE path needs the voxel count on the host")
         # configurations the fused kernel is not specialised for: the same computation layer by layer
         tok = ops.vfe_tokens(features.contiguous(), num_voxels.to(torch.int32).contiguous(), pk["embed"][0].shape[1])
         # every LayerNorm runs in the epilogue of the GEMM that produces its input (norm1 of layer l+1 in layer l's

@@ -202,7 +202,7 @@ class UNetSCN3D(nn.Module):
         s, t = spconv.cached_bn_scale_shift(inv, bn)
         cout = inv.out_channels
         inv.conv(x, rbi, scale=s, shift=t, relu=True, out=next_cat[:, :cout], out_ld=next_cat.shape[1])
-        return x._like(next_cat[:, :cout], rbi.in_indices, rbi.in_shape)
+        return x._like(next_cat[:, :cout], rbi.in_indices, rbi.in_shape, n_dev=rbi.rows_dev(True))
 
     def UR_block_forward_train(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv):
         """scn_unet.py:163-171 as written (training: every step is a differentiable op)"""
@@ -226,6 +226,9 @@ class UNetSCN3D(nn.Module):
         batch_size = batch_dict["batch_size"]
         sparse_shape = np.array(batch_dict["input_shape"][::-1]) + [1, 0, 0]
         vc = voxel_coords.int().contiguous()
+        n_dev = batch_dict.get("num_active_voxels_dev")  # capacity mode (detectors.py): rows beyond this device count are spare
+        if n_dev is not None:
+            return self._forward_capacity(batch_dict, voxel_features, vc, sparse_shape, batch_size, n_dev)
         x = spconv.SparseConvTensor(voxel_features, vc, sparse_shape, batch_size)
         # the "coordinates ready" event covers the tensor the reader's caller recorded it for; a converted copy (int64 / strided
         # coordinates from a custom loader) is written by a kernel enqueued AFTER that event: wait for the main stream instead
@@ -299,6 +302,116 @@ class UNetSCN3D(nn.Module):
         self._stack_event(ev0)
         return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
 
+    # ---------------------------------------------------------------------------------------------- capacity mode (no host syncs)
+    _caps = None  # {strided layer key: [capacity of its output sites, largest count seen]} - adapted from the frames seen so far
+
+    def _strided_chain(self):
+        return [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
+
+    def _capacities(self, n_in_cap, batch_size, shape):
+        """output capacities of the encoder's strided convolutions for an input capacity of n_in_cap rows.  Worst case (every input
+        site feeds 8 outputs, bounded by the output grid) until counts have been seen; then 1.3x the largest count seen so far for
+        this input capacity, rounded up to 4096 - a frame that overflows is run again with the worst case (geometry_check)."""
+        worst, n, sh = [], n_in_cap, list(shape)
+        for c in self._strided_chain():
+            osh = ops.conv_out_shape(sh, c.kernel_size, c.stride, c.padding)
+            per_in = 1
+            for a in range(3):
+                per_in *= -(-c.kernel_size[a] // c.stride[a])
+            n = max(1, min(n * per_in, batch_size * osh[0] * osh[1] * osh[2]))
+            worst.append(n)
+            sh = osh
+        if self._caps is None:
+            self._caps = {}
+        seen = self._caps.get((n_in_cap, batch_size))
+        if seen is None:
+            return worst
+        return [min(w, max(4096, -(-int(1.3 * m) // 4096) * 4096)) for w, m in zip(worst, seen)]
+
+    def geometry_check(self, batch_dict):
+        """capacity mode: wait (host) for this frame's strided-rulebook counts - they are produced early in the frame, on the
+        geometry stream, so this returns while the GPU is still busy with the frame's convolutions: no bubble, and the host can
+        submit the next frame meanwhile.  Updates the capacities from the counts; returns False when a table overflowed its capacity
+        (the caller runs the frame again: the capacities are back at the worst case then)."""
+        rec = batch_dict.pop("geometry_record", None)
+        if rec is None:
+            return True
+        host, ev, key = rec
+        if ev is not None:
+            ev.synchronize()
+        cnt = host.tolist()  # [[n_out, overflow], ...]
+        if any(o for _, o in cnt):
+            self._caps.pop(key, None)
+            return False
+        seen = self._caps.get(key)
+        self._caps[key] = [n for n, _ in cnt] if seen is None else [max(a, n) for a, (n, _) in zip(seen, cnt)]
+        return True
+
+    def _forward_capacity(self, batch_dict, voxel_features, vc, sparse_shape, batch_size, n_dev):
+        """forward() with device-side row counts: the same launches in the same order on the same two streams, tensors sized by
+        capacities, every kernel bounded by its device count - no host synchronisation inside the frame ("avoid host
+        syncs for V").  Results are bit-identical to forward(): spare rows sort behind the valid ones in every order, so tiles, row
+        orders and summation orders of the valid rows are the same."""
+        if self.training or (torch.is_grad_enabled() and voxel_features.requires_grad):
+            raise ops.CapacityModeUnsupported("capacity mode is an inference path")
+        x = spconv.SparseConvTensor(voxel_features, vc, sparse_shape, batch_size, n_dev=n_dev)
+        ready = batch_dict.get("voxel_coords_ready")
+        chain = self._strided_chain()
+        caps = self._capacities(vc.shape[0], batch_size, x.spatial_shape)
+        with _GeometryStream(x.indices, ready) as gs:
+            x.indice_dict["subm1"] = spconv.subm_rulebook(x.indices, x.spatial_shape, 3, x.batch_size, n_dev=n_dev)
+            spconv.prebuild_orders(x, self.modules())
+            gs.hand_over(x.indice_dict.values())
+            gs.release()
+        ev0 = self._stack_event()
+        x = self.conv_input(x)
+        x_conv1 = self.conv1(x)
+        ev1 = self._stack_event(ev0)
+        with _GeometryStream(x.indices, ready, join=False) as gs:
+            # all strided rulebooks of the encoder, chained on device counts; their counts and overflow flags go to pinned host
+            # memory right behind them (read in geometry_check)
+            spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps)
+            cnts = torch.stack([torch.cat([x.indice_dict[c.indice_key].n_out_dev, x.indice_dict[c.indice_key].overflow_dev]) for c in chain])
+            if cnts.is_cuda:
+                host = torch.empty(cnts.shape, dtype=cnts.dtype, pin_memory=True)
+                host.copy_(cnts, non_blocking=True)
+                batch_dict["geometry_record"] = (host, gs.finish_event(), (vc.shape[0], batch_size))
+                gs.keep(cnts)
+            else:
+                batch_dict["geometry_record"] = (cnts, None, (vc.shape[0], batch_size))
+        ev0, x_enc = None, x_conv1
+        for lvl, (key, src, stage) in enumerate((("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4))):
+            with _GeometryStream(x.indices, ready, join=False) as gs:
+                rb = x.find_indice_pair(src)
+                x.indice_dict[key] = spconv.subm_rulebook(rb.out_indices, rb.out_shape, 3, x.batch_size, n_dev=rb.n_out_dev)
+                spconv.prebuild_orders(x, stage.modules() if lvl < 2 else self.modules())
+                gs.hand_over(x.indice_dict.values())
+                level_ready = gs.finish_event()
+            self._wait(x, level_ready)
+            if lvl == 0:
+                ev0 = self._stack_event() if ev1 is not None else None
+            x_enc = stage(x_enc)
+            if lvl == 0:
+                x_conv2 = x_enc
+            elif lvl == 1:
+                x_conv3 = x_enc
+        x_conv4 = x_enc
+        with _GeometryStream(x.indices, ready, join=False) as gs2:
+            self._start_devox_search(batch_dict, x, gs2)
+        if self.conv_out is not None:
+            batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
+            batch_dict["encoded_spconv_tensor_stride"] = 8
+        dev = voxel_features.device
+        cats = [torch.empty((t.features.shape[0], 2 * t.features.shape[1]), dtype=torch.float32, device=dev)
+                for t in (x_conv3, x_conv2, x_conv1)]
+        x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4, next_cat=cats[0])
+        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1])
+        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2])
+        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2])
+        self._stack_event(ev0)
+        batch_dict["num_active_voxels_dev"] = x_up1.n_dev
+        return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
+
     @staticmethod
     def _wait(x, ev):
         if ev is not None:
@@ -323,9 +436,10 @@ class UNetSCN3D(nn.Module):
         if pts is None or pts.dim() != 2 or pts.shape[1] < 4 or pts.device != x.indices.device or not pts.is_contiguous():
             return
         bs = int(batch_dict["batch_size"])
-        centers = ops.voxel_centers(x.indices, self.voxel_size, self.point_cloud_range)
-        pt_off, vx_off = ops.frame_offsets(pts, bs), ops.frame_offsets(centers, bs)
-        idx, w = ops.devoxelize_grid(pts, pt_off, x.indices, centers, vx_off, bs, list(self.voxel_size), list(self.point_cloud_range), None)
+        centers = ops.voxel_centers(x.indices, self.voxel_size, self.point_cloud_range, n_dev=x.n_dev)
+        pt_off, vx_off = ops.frame_offsets(pts, bs), ops.frame_offsets(centers, bs, n_dev=x.n_dev)
+        idx, w = ops.devoxelize_grid(pts, pt_off, x.indices, centers, vx_off, bs, list(self.voxel_size), list(self.point_cloud_range), None,
+                                     n_dev=x.n_dev)
         gs.keep(centers, pt_off, vx_off, idx, w)
         batch_dict["devox_search"] = dict(points=pts, indices=x.indices, centers=centers, pt_off=pt_off, vx_off=vx_off, idx=idx, weight=w,
                                           event=gs.finish_event())
@@ -340,7 +454,7 @@ class UNetSCN3D(nn.Module):
             batch_dict["conv_point_coords"] = ds["centers"]
         else:
             batch_dict.pop("devox_search", None)
-            batch_dict["conv_point_coords"] = ops.voxel_centers(x_up1.indices, self.voxel_size, self.point_cloud_range)
+            batch_dict["conv_point_coords"] = ops.voxel_centers(x_up1.indices, self.voxel_size, self.point_cloud_range, n_dev=x_up1.n_dev)
         # extra keys (not in the reference): integer lattice coordinates + geometry of the output voxels, which let
         # the point heads use the grid-accelerated exact 3-NN instead of the O(N*V) scan
         batch_dict["conv_point_indices"] = x_up1.indices

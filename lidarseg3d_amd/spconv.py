@@ -24,17 +24,21 @@ class SparseConvTensor(object):
     """features [V,C] f32, indices [V,4] int32 (batch,z,y,x), spatial_shape (Z,Y,X), batch_size.
     `indice_dict` is shared by reference by every tensor derived from this one (as in spconv)."""
 
-    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, n_dev=None):
         self.features = features
         self.indices = indices if indices.dtype == torch.int32 else indices.int()
         self.spatial_shape = [int(v) for v in spatial_shape]
         self.batch_size = int(batch_size)
         self.indice_dict = {}
         self.grid = grid
+        # capacity mode (not in spconv): n_dev = device int32 with the number of VALID rows; features / indices then have a
+        # capacity's worth of rows and every kernel stops at the count - no host synchronisation for tensor shapes
+        self.n_dev = n_dev
 
-    def _like(self, features, indices=None, spatial_shape=None):
+    def _like(self, features, indices=None, spatial_shape=None, n_dev="same"):
         t = SparseConvTensor(features, self.indices if indices is None else indices,
-                             self.spatial_shape if spatial_shape is None else spatial_shape, self.batch_size)
+                             self.spatial_shape if spatial_shape is None else spatial_shape, self.batch_size,
+                             n_dev=self.n_dev if isinstance(n_dev, str) else n_dev)
         t.indice_dict = self.indice_dict
         return t
 
@@ -55,7 +59,12 @@ class SparseModule(nn.Module):
 
 
 class _Rulebook(object):
-    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index", "_orders", "_plans", "batch_size")
+    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index", "_orders", "_plans", "batch_size",
+                 "n_in_dev", "n_out_dev", "overflow_dev")
+
+    def rows_dev(self, inverse):
+        """device count of the rows of the (inverse) table = the output rows of a launch on it (None: the table has no spare rows)"""
+        return getattr(self, "n_in_dev", None) if inverse else getattr(self, "n_out_dev", None)
 
     def tile_plan(self, inverse):
         """tile-halo plan (ops.tile_plan) of the (inverse) table, built once per rulebook"""
@@ -64,7 +73,8 @@ class _Rulebook(object):
         if inverse not in self._plans:
             tbl = self.tbl_inv if inverse else self.tbl
             sites, shape = (self.in_indices, self.in_shape) if inverse else (self.out_indices, self.out_shape)
-            self._plans[inverse] = ops.tile_plan(tbl, sites[:tbl.shape[0]], shape, getattr(self, "batch_size", None) or 256)
+            self._plans[inverse] = ops.tile_plan(tbl, sites[:tbl.shape[0]], shape, getattr(self, "batch_size", None) or 256,
+                                                 n_dev=self.rows_dev(inverse))
         return self._plans[inverse]
 
     def order(self, inverse):
@@ -73,7 +83,7 @@ class _Rulebook(object):
             self._orders = {}
         if inverse not in self._orders:
             self._orders[inverse] = ops.rulebook_order(self.tbl_inv if inverse else self.tbl,
-                                                       self.in_indices if inverse else self.out_indices)
+                                                       self.in_indices if inverse else self.out_indices, n_dev=self.rows_dev(inverse))
         return self._orders[inverse]
 
 
@@ -183,11 +193,16 @@ class SparseConvolution(PackedModule, SparseModule):
         if rb is not None and (self.subm or rb.kind == "conv"):
             return rb  # spconv semantics: layers with one indice_key share the pairs (also prebuild_conv_rulebooks below)
         if self.subm:
-            rb = subm_rulebook(x.indices, x.spatial_shape, self.kernel_size, x.batch_size)
+            rb = subm_rulebook(x.indices, x.spatial_shape, self.kernel_size, x.batch_size, n_dev=x.n_dev)
+        elif x.n_dev is not None:  # capacity mode: no host sync, worst-case output capacity (cannot overflow)
+            assert self.indice_key is not None, "capacity mode needs an indice_key on strided convolutions"
+            prebuild_conv_rulebooks(x, [self], nosync=True)
+            return x.find_indice_pair(self.indice_key)
         else:
             rb = _Rulebook()
             rb._orders = rb._plans = None
             rb.batch_size = x.batch_size
+            rb.n_in_dev = rb.n_out_dev = rb.overflow_dev = None
             rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)
             rb.kind = "conv"
             oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(x.indices, x.batch_size, x.spatial_shape,
@@ -220,7 +235,7 @@ class SparseConvolution(PackedModule, SparseModule):
         # mask-sorted processing order only for the layers whose matrix work can repay the sort (>= 64x64 channels)
         order = rb.order(self.inverse) if self.in_channels * self.out_channels >= 4096 else None
         return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, order=order, cout=cout, scale=scale, shift=shift, relu=relu,
-                               res_pre=res_pre, pair=pair, out=out, out_ld=out_ld)
+                               res_pre=res_pre, pair=pair, out=out, out_ld=out_ld, n_dev=rb.rows_dev(bool(self.inverse)))
 
     def forward(self, x):
         rb = self.rulebook(x)
@@ -230,17 +245,19 @@ class SparseConvolution(PackedModule, SparseModule):
         else:
             f = self.conv(x, rb)
         if self.inverse:
-            return x._like(f, rb.in_indices, rb.in_shape)
-        return x._like(f, rb.out_indices, rb.out_shape)
+            return x._like(f, rb.in_indices, rb.in_shape, n_dev=rb.rows_dev(True))
+        return x._like(f, rb.out_indices, rb.out_shape, n_dev=rb.rows_dev(False))
 
 
-def subm_rulebook(indices, spatial_shape, kernel_size, batch_size=None):
+def subm_rulebook(indices, spatial_shape, kernel_size, batch_size=None, n_dev=None):
     rb = _Rulebook()
     rb._orders = rb._plans = None
     rb.batch_size = batch_size
     rb.kind = "subm"
+    rb.n_in_dev = rb.n_out_dev = n_dev
+    rb.overflow_dev = None
     rb.in_indices, rb.in_shape = indices, list(spatial_shape)
-    rb.tbl = ops.rulebook_subm(indices, spatial_shape, _triple(kernel_size))
+    rb.tbl = ops.rulebook_subm(indices, spatial_shape, _triple(kernel_size), n_dev=n_dev)
     rb.out_indices, rb.out_shape, rb.tbl_inv = indices, list(spatial_shape), None
     return rb
 
@@ -269,25 +286,40 @@ def prebuild_orders(x, layers):
             continue
         want.append((rb, inv))
     if want:
-        for (rb, inv), o in zip(want, ops.rulebook_orders([rb.tbl_inv if inv else rb.tbl for rb, inv in want])):
+        for (rb, inv), o in zip(want, ops.rulebook_orders([rb.tbl_inv if inv else rb.tbl for rb, inv in want], [rb.rows_dev(inv) for rb, inv in want])):
             rb._orders[inv] = o
 
 
-def prebuild_conv_rulebooks(x, convs, coords=None, shape=None):
+def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, caps=None, n_dev=None):
     """Rulebooks of a chain of strided SparseConv3d layers (each one's output sites are the next one's input sites, as in a
     UNet encoder) built back to back on device-side site counts, with ONE host synchronisation for all their sizes instead
     of one per layer.  Intermediate tables are allocated for the worst case (min(8 x inputs, grid cells)) and sliced once
     the counts are known.  The rulebooks are registered under the layers' indice_keys.  coords / shape: the input sites of the first layer
     when the chain does not start at x's own sites (a chain continued after an earlier call)."""
-    coords = x.indices if coords is None else coords
+    if coords is None:
+        coords, n_dev = x.indices, (x.n_dev if n_dev is None else n_dev)
     first_coords = coords
-    pend, n_dev, shape = [], None, list(x.spatial_shape if shape is None else shape)
-    for c in convs:
+    pend, shape = [], list(x.spatial_shape if shape is None else shape)
+    for li, c in enumerate(convs):
         assert not c.subm and not c.inverse and c.indice_key is not None
         oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(coords, x.batch_size, shape, c.kernel_size, c.stride, c.padding,
-                                                               n_dev=n_dev)
-        pend.append((c, coords, shape, oc, cnt, nbr_out, nbr_inv, oshape))
+                                                               out_cap=(caps[li] if caps else None), n_dev=n_dev)
+        pend.append((c, coords, shape, oc, cnt, nbr_out, nbr_inv, oshape, n_dev))
         coords, n_dev, shape = oc, cnt, oshape
+    if nosync:
+        # capacity mode: every table keeps its capacity's worth of rows, the counts stay on the device ([n_out, overflow] per layer);
+        # the caller checks the overflow flags once per frame (UNetSCN3D.geometry_record)
+        for c, icoords, ishape, oc, cnt, nbr_out, nbr_inv, oshape, n_in_dev in pend:
+            rb = _Rulebook()
+            rb._orders = rb._plans = None
+            rb.batch_size = x.batch_size
+            rb.kind, rb.in_indices, rb.in_shape = "conv", icoords, list(ishape)
+            rb.out_indices, rb.out_shape = oc, oshape
+            rb.tbl, rb.tbl_inv = nbr_out, nbr_inv
+            rb.n_in_dev, rb.n_out_dev, rb.overflow_dev = n_in_dev, cnt[0:1], cnt[1:2]
+            x.indice_dict[c.indice_key] = rb
+        return
+    pend = [p[:8] for p in pend]
     counts = torch.stack([p[4] for p in pend]).tolist()  # host sync: tensor shapes need the counts
     n_in = first_coords.shape[0]
     for (c, icoords, ishape, oc, cnt, nbr_out, nbr_inv, oshape), (n_out, overflow) in zip(pend, counts):
@@ -295,6 +327,7 @@ def prebuild_conv_rulebooks(x, convs, coords=None, shape=None):
         rb = _Rulebook()
         rb._orders = rb._plans = None
         rb.batch_size = x.batch_size
+        rb.n_in_dev = rb.n_out_dev = rb.overflow_dev = None
         rb.kind, rb.in_indices, rb.in_shape = "conv", (icoords if n_in == icoords.shape[0] else icoords[:n_in]), list(ishape)
         rb.out_indices, rb.out_shape = oc[:n_out], oshape
         rb.tbl, rb.tbl_inv = nbr_out[:n_out], nbr_inv[:n_in]
@@ -403,5 +436,5 @@ def conv_bn_act(conv, bn, x, relu=True, res_pre=None, pair=None):
     rb = conv.rulebook(x)
     f = conv.conv(x, rb, scale=scale, shift=shift, relu=relu, res_pre=res_pre, pair=pair)
     if conv.inverse:
-        return x._like(f, rb.in_indices, rb.in_shape)
-    return x._like(f, rb.out_indices, rb.out_shape)
+        return x._like(f, rb.in_indices, rb.in_shape, n_dev=rb.rows_dev(True))
+    return x._like(f, rb.out_indices, rb.out_shape, n_dev=rb.rows_dev(False))

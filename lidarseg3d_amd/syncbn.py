@@ -18,6 +18,8 @@ def _active(group):
 
 
 class _SyncBNFn(torch.autograd.Function):
+    """x: [rows, C] (the 2-d / 3-d variants flatten N, H, W[, D] into rows first)"""
+
     @staticmethod
     def forward(ctx, x, weight, bias, eps, group):
         c = x.shape[1]
@@ -30,7 +32,7 @@ class _SyncBNFn(torch.autograd.Function):
         dist.all_gather(parts, local, group=group)
         allp = torch.stack(parts)  # [world, 2C+1], the same on every rank: identical statistics everywhere
         cnt = allp[:, -1:]
-        n = cnt.sum()
+        n = cnt.sum().clamp_min(1.0)  # every rank empty (e.g. a level without active voxels): statistics 0 / eps, no NaN
         mean = (allp[:, :c] * cnt).sum(0) / n
         var = (allp[:, c:2 * c] + cnt * (allp[:, :c] - mean) ** 2).sum(0) / n
         invstd = torch.rsqrt(var + eps)
@@ -71,17 +73,52 @@ class CountSyncBatchNorm1d(nn.BatchNorm1d):
         return y
 
 
+class _CountSyncBatchNormNd(object):
+    """forward of the 2-d / 3-d variants: channels-first [N, C, ...] flattened to rows, the same statistics code"""
+
+    def forward(self, x):
+        if not (self.training and _active(self.process_group)):
+            return super().forward(x)
+        c = x.shape[1]
+        rows = x.movedim(1, -1).reshape(-1, c)
+        y, mean, var, n = _SyncBNFn.apply(rows, self.weight, self.bias, self.eps, self.process_group)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                self.running_var.mul_(1 - m).add_(var * (n / (n - 1).clamp_min(1)), alpha=m)
+        return y.reshape(*x.movedim(1, -1).shape).movedim(-1, 1)
+
+
+class CountSyncBatchNorm2d(_CountSyncBatchNormNd, nn.BatchNorm2d):
+    def __init__(self, *a, process_group=None, **k):
+        nn.BatchNorm2d.__init__(self, *a, **k)
+        self.process_group = process_group
+
+
+class CountSyncBatchNorm3d(_CountSyncBatchNormNd, nn.BatchNorm3d):
+    def __init__(self, *a, process_group=None, **k):
+        nn.BatchNorm3d.__init__(self, *a, **k)
+        self.process_group = process_group
+
+
+_SYNC = ((nn.BatchNorm1d, CountSyncBatchNorm1d), (nn.BatchNorm2d, CountSyncBatchNorm2d), (nn.BatchNorm3d, CountSyncBatchNorm3d))
+
+
 def convert_sync_batchnorm(module, process_group=None):
-    """nn.SyncBatchNorm.convert_sync_batchnorm for this path (train.py:313-321): every nn.BatchNorm1d -> CountSyncBatchNorm1d with
-    the same parameters / buffers / state_dict keys"""
+    """nn.SyncBatchNorm.convert_sync_batchnorm for this path (train.py:313-321): EVERY _BatchNorm - the BatchNorm1d of the sparse
+    backbone / readers / point heads, the BatchNorm2d of the camera head's ConvModules (img_heads.py) and of a user's camera
+    backbone, BatchNorm3d - becomes its count-weighted synchronised variant with the same parameters / buffers / state_dict keys"""
     out = module
-    if isinstance(module, nn.BatchNorm1d) and not isinstance(module, CountSyncBatchNorm1d):
-        out = CountSyncBatchNorm1d(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats,
-                                   process_group=process_group)
-        if module.affine:
-            out.weight, out.bias = module.weight, module.bias
-        out.running_mean, out.running_var, out.num_batches_tracked = module.running_mean, module.running_var, module.num_batches_tracked
-        out.training = module.training
+    for plain, synced in _SYNC:
+        if isinstance(module, plain) and not isinstance(module, (CountSyncBatchNorm1d, CountSyncBatchNorm2d, CountSyncBatchNorm3d)):
+            out = synced(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats, process_group=process_group)
+            if module.affine:
+                out.weight, out.bias = module.weight, module.bias
+            out.running_mean, out.running_var, out.num_batches_tracked = module.running_mean, module.running_var, module.num_batches_tracked
+            out.training = module.training
+            break
     for name, child in module.named_children():
         out.add_module(name, convert_sync_batchnorm(child, process_group))
     return out

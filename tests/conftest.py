@@ -9,9 +9,19 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
-    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on a GPU box)")
 
 
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _exact_f32_baseline():
+    """every test starts from the exact-f32 arithmetic (the baseline the parity tolerances are written against) and says so when it
+    wants one of the f32-grade plane modes; the library's own default is "bf16x6" (lidarseg3d_amd/ops.py)"""
+    from lidarseg3d_amd import ops
+    ops.set_precision("f32")
+    yield
+    ops.set_precision("f32")

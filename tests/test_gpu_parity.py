@@ -326,6 +326,57 @@ def test_sdseg3d_120k_frame_logits_and_miou_vs_oracle():
         assert r["argmax"] >= 0.999 and r["miou"] >= 0.999, (prec, r)
 
 
+@pytest.mark.parametrize("kind", ["sdseg3d", "mseg3d"])
+def test_capacity_mode_equals_host_count_mode_full_size(kind, monkeypatch):
+    """inference on device-side row counts (detectors.CAPACITY_MODE, the default: no host synchronisation inside a frame) vs
+    host-side counts at BASELINE size - a 120k-point frame, then a two-frame batch (120k + 34k): bit-identical logits in exact f32
+    and in the bf16x6 arithmetic, from the first frame (worst-case capacities) and after the capacities have adapted; the capacity
+    path really runs and issues no synchronising torch call (sync debug mode = error)"""
+    from lidarseg3d_amd import detectors
+    cfg = synth.NUSC
+    model, _ = _model(getattr(models_cfg, kind)())
+    bb = model.backbone
+    seen = []
+    orig = bb._forward_capacity
+    monkeypatch.setattr(bb, "_forward_capacity", lambda *a, **k: (seen.append(1), orig(*a, **k))[1])
+    batches = [[synth.lidar_frame(120000, seed=7, **cfg)], [synth.lidar_frame(120000, seed=8, **cfg), synth.lidar_frame(34000, seed=9, **cfg)]]
+
+    def example(frames):
+        pts = cu(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)]))
+        ex = dict(points=pts, batch_size=len(frames))
+        if kind == "mseg3d":
+            img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=5, ncam=6, c_img=48, h=40, w=60, batch=len(frames))
+            ex.update(points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
+        return ex
+
+    def run(ex, capacity, strict=False):
+        monkeypatch.setattr(detectors, "CAPACITY_MODE", capacity)
+        if strict:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            with torch.no_grad():
+                model(dict(ex), return_loss=False)
+            out = model.point_head.forward_ret_dict["out_logits"]
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        return out.clone()
+
+    try:
+        for prec in ("f32", "bf16x6"):
+            ops.set_precision(prec)
+            for frames in batches:
+                ex = example(frames)
+                want = run(ex, False)
+                del seen[:]
+                bb._caps = None                       # first frame: worst-case capacities
+                first = run(ex, True)
+                again = run(ex, True, strict=len(frames) == 1)  # capacities adapted to the counts of the first frame (predict() splits a batch by boolean masks: that torch indexing synchronises)
+                assert len(seen) == 2 and torch.isfinite(first).all()
+                assert torch.equal(first, want) and torch.equal(again, want), (prec, len(frames))
+    finally:
+        ops.set_precision("f32")
+
+
 def test_devoxelize_grid_equals_brute_force_120k():
     """the coarse-grid 3-NN must return exactly the brute-force neighbours, also for points far outside the range"""
     cfg = synth.NUSC
@@ -518,9 +569,9 @@ def test_drop_in_mode_with_dataloader_voxels():
 
 @pytest.mark.parametrize("cin,cout,wide", [(32, 32, True), (64, 64, True), (128, 128, True), (128, 128, False), (64, 16, True)])
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
-def test_gather_gemm_pipelined_kernel_gpu(cin, cout, wide, prec, monkeypatch):
-    """the LDS-DMA pipelined kernel on the device (asynchronous DMA ring: the hipsim run of the same test cannot see a missing
-    wait) vs a float64 reference and vs the register-prefetch kernel; 100 launches must be bitwise reproducible"""
+def test_gather_gemm_sparse_tables_vs_float64_gpu(cin, cout, wide, prec, monkeypatch):
+    """the table-driven gather-GEMM on the device vs a float64 reference (natural and mask-sorted order, fused epilogue, one wide or
+    several 32-column slabs); 100 launches must be bitwise reproducible"""
     from lidarseg3d_amd.packing import PackedWeight
     rng = np.random.default_rng(cin * 1000 + cout)
     vin, vout, kvol = 30000, 20011, 27
@@ -539,19 +590,15 @@ def test_gather_gemm_pipelined_kernel_gpu(cin, cout, wide, prec, monkeypatch):
         acc[o] += x[tbl[o, kk]].astype(np.float64) @ w[kk].astype(np.float64)
     want = np.maximum(acc * scale + shift + res, 0)
     pw = PackedWeight(cu(w), kvol, cin, cin, cout)
-    monkeypatch.setattr(ops, "_PIPE_WIDE_ROWS", 0 if wide else 10 ** 9)
+    if not wide:
+        monkeypatch.setattr(ops, "choose_geometry", lambda c, rows, target_blocks=None: (1, 1))  # one 32-column slab per workgroup
     tol = 3e-4 if prec == "f32" else 3e-3
     X, TB, SC, SH, RS = cu(x), cu(tbl), cu(scale), cu(shift), cu(res)
     try:
         ops.set_precision(prec)
-        outs = {}
-        for pipe in (True, False):
-            ops.set_pipeline(pipe)
-            for order in (None, ops.rulebook_order(TB)):
-                out = ops.gather_gemm(X, pw, tbl=TB, order=order, cout=cout, scale=SC, shift=SH, res_pre=RS, relu=True)
-                np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=tol)
-                outs[(pipe, order is None)] = out
-        ops.set_pipeline(True)
+        for order in (None, ops.rulebook_order(TB)):
+            out = ops.gather_gemm(X, pw, tbl=TB, order=order, cout=cout, scale=SC, shift=SH, res_pre=RS, relu=True)
+            np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=tol)
         order = ops.rulebook_order(TB)
         first = ops.gather_gemm(X, pw, tbl=TB, order=order, cout=cout, scale=SC, shift=SH, res_pre=RS, relu=True)
         for _ in range(100):
@@ -559,7 +606,6 @@ def test_gather_gemm_pipelined_kernel_gpu(cin, cout, wide, prec, monkeypatch):
             assert torch.equal(first, again)
     finally:
         ops.set_precision("f32")
-        ops.set_pipeline(False)  # the default
 
 
 def _spconv_ref(feats, w, tbl, reverse=False):

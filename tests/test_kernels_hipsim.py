@@ -183,7 +183,7 @@ def test_gather_gemm_dense_all_geometries(m, k, n, nt, wc, monkeypatch):
 
 
 def test_gather_gemm_workgroup_mapping_flags_do_not_change_results(monkeypatch):
-    """ls3d_set_xcd_map only permutes which workgroup takes which (tile, slab): bitwise identical output (1300 rows = 11 tiles
+    """ls3d_gather_gemm's mapping flags only permute which workgroup takes which (tile, slab): bitwise identical output (1300 rows = 11 tiles
     over 8 XCD lanes, 4 column slabs; f32 and split-bf16 kernels)"""
     rng = np.random.default_rng(11)
     m, k, n = 1300, 32, 128
@@ -196,22 +196,21 @@ def test_gather_gemm_workgroup_mapping_flags_do_not_change_results(monkeypatch):
             ops.set_precision(prec)
             outs = []
             for flags in (0, 1, 2, 3):
-                _lib.load().ls3d_set_xcd_map(flags)
+                ops.set_gemm_flags(flags)
                 outs.append(ops.gather_gemm(torch.from_numpy(a), pw, tbl=tbl, cout=n).numpy().copy())
             for o in outs[1:]:
                 assert np.array_equal(o, outs[0])
             np.testing.assert_allclose(outs[0], a.astype(np.float64) @ b.astype(np.float64), rtol=0, atol=2e-3)
     finally:
         ops.set_precision("f32")
-        _lib.load().ls3d_set_xcd_map(0)
+        ops.set_gemm_flags(0)
 
 
 @pytest.mark.parametrize("cin,cout,wide", [(32, 32, True), (64, 64, True), (32, 128, True), (96, 128, False), (128, 16, True)])
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
-def test_gather_gemm_pipelined_kernel(cin, cout, wide, prec, monkeypatch):
-    """the LDS-DMA pipelined kernel (ring of staged steps, 4- and 8-wave workgroups, swizzled gather) against a float64
-    reference and against the register-prefetch kernel: every geometry, multi-chunk K, rows without neighbours, a tile with
-    a single active offset, ragged last tile, mask-sorted order, fused epilogue"""
+def test_gather_gemm_sparse_tables_vs_float64(cin, cout, wide, prec, monkeypatch):
+    """the table-driven gather-GEMM against a float64 reference: multi-chunk K, rows without neighbours, a tile with a single active
+    offset, ragged last tile, natural and mask-sorted order, fused epilogue"""
     rng = np.random.default_rng(cin * 1000 + cout)
     vin, vout, kvol = 500, 333, 27
     x = rng.normal(size=(vin, cin)).astype(np.float32)
@@ -230,23 +229,17 @@ def test_gather_gemm_pipelined_kernel(cin, cout, wide, prec, monkeypatch):
     want = np.maximum(acc * scale + shift + res, 0)
     T = torch.from_numpy
     pw = PackedWeight(T(w), kvol, cin, cin, cout)
-    monkeypatch.setattr(ops, "_PIPE_WIDE_ROWS", 0 if wide else 10 ** 9)
+    if not wide:
+        monkeypatch.setattr(ops, "choose_geometry", lambda c, rows, target_blocks=None: (1, 1))  # one 32-column slab per workgroup
     tol = 2e-4 if prec == "f32" else 2e-3
     try:
         ops.set_precision(prec)
-        outs = {}
-        for pipe in (True, False):
-            ops.set_pipeline(pipe)
-            for order in (None, ops.rulebook_order(T(tbl))):
-                out = ops.gather_gemm(T(x), pw, tbl=T(tbl), order=order, cout=cout, scale=T(scale), shift=T(shift), res_pre=T(res),
-                                      relu=True).numpy()
-                np.testing.assert_allclose(out, want, rtol=0, atol=tol)
-                outs[(pipe, order is None)] = out
-        # same arithmetic, different summation order only
-        np.testing.assert_allclose(outs[(True, True)], outs[(False, True)], rtol=0, atol=tol)
+        for order in (None, ops.rulebook_order(T(tbl))):
+            out = ops.gather_gemm(T(x), pw, tbl=T(tbl), order=order, cout=cout, scale=T(scale), shift=T(shift), res_pre=T(res),
+                                  relu=True).numpy()
+            np.testing.assert_allclose(out, want, rtol=0, atol=tol)
     finally:
         ops.set_precision("f32")
-        ops.set_pipeline(False)  # the default
 
 
 def test_rulebook_orders_batched_sort():
@@ -1120,11 +1113,68 @@ def test_voxel_cap_applies_per_frame_like_the_dataloader():
     mv = 200  # frame 0 has more voxels than this, frame 1 fewer
     vcfg = dict(range=cfg["pc_range"], voxel_size=cfg["voxel_size"], max_points_in_voxel=5, max_voxel_num=[mv, mv])
     ex = dict(points=torch.from_numpy(pts), batch_size=2)
-    v, c, n, bs, grid = detectors._voxel_inputs(ex, vcfg)
+    v, c, n, bs, grid, n_dev = detectors._voxel_inputs(ex, vcfg)
+    assert n_dev is None
     want = orc.collate_frames(frames, cfg["voxel_size"], cfg["pc_range"], 5, mv)
     assert int((want["coordinates"][:, 0] == 0).sum()) == mv  # the cap did bite on frame 0
     assert torch.equal(c, want["coordinates"]) and torch.equal(n, want["num_points"]) and torch.equal(v, want["voxels"])
     assert ex["num_voxels"].tolist() == [mv, int((want["coordinates"][:, 0] == 1).sum())]
+
+
+@pytest.mark.parametrize("kind,precs", [("sdseg3d", ("f32", "bf16x6")), ("mseg3d", ("f32",))])
+def test_capacity_mode_equals_host_count_mode_bit_for_bit(kind, precs, monkeypatch):
+    """inference from raw points on device-side row counts (detectors.CAPACITY_MODE: tensors sized by capacities, no host
+    synchronisation inside the frame) against the same frames with host-side counts: identical logits and labels, for exact f32 and
+    for the tile-halo arithmetic; a rulebook that overflows its capacity sends the frame through the host-count path (same results)
+    and makes the backbone forget the capacities it learned; two ragged frames, one of them tiny"""
+    import lidarseg3d_amd as L
+    from lidarseg3d_amd import detectors, models_cfg
+    cfg = synth.NUSC
+    mcfg = getattr(models_cfg, kind)()
+    mcfg["backbone"]["model_cfg"] = dict(SCALING_RATIO=1)  # 16/32/64/64 channels: a quarter of the emulated MFMA work
+    mcfg["point_head"]["model_cfg"]["CONV_IN_DIM" if kind == "sdseg3d" else "VOXEL_IN_DIM"] = 16
+    model = L.build_detector(mcfg, train_cfg=None, test_cfg={}).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, 7).items()})
+    frames = [synth.lidar_frame(110, seed=41, **cfg), synth.lidar_frame(25, seed=42, **cfg)]
+    pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)]))
+    ex = dict(points=pts, batch_size=2)
+    if kind == "mseg3d":
+        img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=3, ncam=6, c_img=48, h=8, w=12, batch=2)
+        ex.update(points_cuv=torch.from_numpy(cuv), image_features=torch.from_numpy(img), camera_semantic_embeddings=torch.from_numpy(emb))
+    bb = model.backbone
+    seen = []
+    orig_fc, orig_caps = bb._forward_capacity, bb._capacities
+    monkeypatch.setattr(bb, "_forward_capacity", lambda *a, **k: (seen.append(1), orig_fc(*a, **k))[1])
+    # the worst case (x8 per level) is 50k spare rows at the deepest level of these tiny frames: minutes on the host emulation
+    roomy = lambda n, b, sh: [min(w, 6 * n) for w in orig_caps(n, b, sh)]
+
+    def run(capacity, caps=roomy):
+        monkeypatch.setattr(detectors, "CAPACITY_MODE", capacity)
+        monkeypatch.setattr(bb, "_capacities", caps)
+        with torch.no_grad():
+            ret = model(dict(ex), return_loss=False)
+        return model.point_head.forward_ret_dict["out_logits"].clone(), [r["pred_point_sem_labels"].clone() for r in ret]
+
+    for prec in precs:
+        ops.set_precision(prec)
+        if prec == "bf16x6":
+            ops.set_tile(True, min_cc=256)
+        try:
+            del seen[:]
+            want, wl = run(False)
+            assert not seen
+            got, gl = run(True)
+            assert len(seen) == 1 and torch.isfinite(got).all()
+            assert torch.equal(got, want) and all(torch.equal(a, b) for a, b in zip(gl, wl))
+            learned = dict(bb._caps)
+            assert len(learned) == 1 and all(m > 0 for m in list(learned.values())[0])
+            if prec == precs[0] and kind == "sdseg3d":
+                got3, _ = run(True, caps=lambda n, b, sh: [8] * len(orig_caps(n, b, sh)))  # every strided rulebook overflows
+                assert torch.equal(got3, want) and len(seen) == 2 and not bb._caps   # ran again on host counts, capacities forgotten
+        finally:
+            ops.set_precision("f32")
+            ops.set_tile(True, min_cc=512)
 
 
 @pytest.mark.parametrize("n,bits", [(1, 8), (255, 8), (2049, 13), (5000, 20), (4097, 31)])
