@@ -305,7 +305,7 @@ def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, cap
         oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(coords, x.batch_size, shape, c.kernel_size, c.stride, c.padding,
                                                                out_cap=(caps[li] if caps else None), n_dev=n_dev)
         pend.append((c, coords, shape, oc, cnt, nbr_out, nbr_inv, oshape, n_dev))
-        coords, n_dev, shape = oc, cnt, oshape
+        coords, n_dev, shape = oc, cnt[0:1], oshape  # cnt = [n_out, overflow]
     if nosync:
         # capacity mode: every table keeps its capacity's worth of rows, the counts stay on the device ([n_out, overflow] per layer);
         # the caller checks the overflow flags once per frame (UNetSCN3D.geometry_record)
