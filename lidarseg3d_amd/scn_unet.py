@@ -90,9 +90,11 @@ class _GeometryStream(object):
         if not self.on:
             return
         for rb in rulebooks:
-            for name in ("tbl", "tbl_inv", "in_indices", "out_indices"):
+            # everything allocated on the side stream that main-stream kernels read - in capacity mode also the device-side row
+            # counts, which the convolutions of the whole frame dereference long after the geometry stream has moved on
+            for name in ("tbl", "tbl_inv", "in_indices", "out_indices", "n_in_dev", "n_out_dev", "overflow_dev"):
                 t = getattr(rb, name, None)
-                if t is not None:
+                if t is not None and t.is_cuda:
                     t.record_stream(self.main)
             for o in (getattr(rb, "_orders", None) or {}).values():
                 if o is not None:
