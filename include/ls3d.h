@@ -169,12 +169,19 @@ typedef struct {
   int planes; /* 0: f32 MFMA, the five GEMM weights (w_embed, wqkv, wo, w1, w2) in the packed nt = 2 layout of ls3d_gather_gemm_pack;
                * 6 | 8: the exact 3-plane bf16 split (f32-grade, see ls3d_tile_conv), the five weights converted by ls3d_transvfe_pack_planes */
   int flags;  /* bit 0 (planes == 0 only): experimental variant with the B fragments straight from the L2-resident weights instead of
-               * LDS staging, no workgroup barriers - same results, measured slower (profiles/round2_experiments.md) */
+               * LDS staging, no workgroup barriers - same results, measured slower (profiles/round2_experiments.md);
+               * bit 1: no token deduplication even when ls3d_transvfe gets a workspace (A/B) */
 } ls3d_transvfe_t;
 size_t ls3d_transvfe_planes_bytes(int K, int N);
 int ls3d_transvfe_pack_planes(const float *w_packed_nt2 /*K x N*/, int K, int N, void *out, ls3d_stream_t stream);
+/* workspace (optional, ls3d_transvfe_workspace_bytes(n, P) bytes, 16-byte aligned): enables the token deduplication - the zero-padded
+ * slots of a voxel are identical tokens in the reference's unmasked transformer (voxel_encoder.py:154-161), so a voxel with k < P
+ * points is computed on k + 1 rows, the padding row's key weighted P - k in the softmax; voxels are grouped by k with one stable
+ * radix pass.  Same result up to the summation order inside the softmax; 2.1x fewer 32-row tiles on LiDAR data.  Voxels whose slots
+ * beyond num_points are not all zero keep all P rows. */
+size_t ls3d_transvfe_workspace_bytes(int n, int P);
 int ls3d_transvfe(const float *voxels /*[n,P,C]*/, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
-                  const ls3d_transvfe_t *model, float *out, int out_ld, ls3d_stream_t stream);
+                  const ls3d_transvfe_t *model, float *out, int out_ld, void *workspace, size_t workspace_bytes, ls3d_stream_t stream);
 
 /* y = LayerNorm(x (+ res)) * gamma + beta over the last dim c (<= 256); ld = c for all */
 int ls3d_layernorm(const float *x, const float *res, const float *gamma, const float *beta, float eps, int rows,
@@ -328,11 +335,12 @@ int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_rows, const 
                    const int32_t shape_zyx_host[3], int batch, void *workspace, size_t workspace_bytes, void *plan, size_t plan_bytes,
                    int flags, ls3d_stream_t stream);
 /* stable LSD radix sort of (uint32 key, int32 value) pairs by the low `bits` key bits, ascending; vals == NULL: the values are
- * the positions 0..n-1 (the result is the sorting permutation).  keys_out may be NULL.  Not in place.  Replaces torch.argsort
+ * the positions 0..n-1 (the result is the sorting permutation).  keys_out may be NULL.  Not in place.  n_dev (optional): only the
+ * first min(*n_dev, n) pairs are sorted, into the first positions of the outputs (the rest is unspecified).  Replaces torch.argsort
  * for the row orders of the sparse convolutions (spatial tile keys, neighbour-mask keys). */
 size_t ls3d_radix_sort_workspace_bytes(int n);
-int ls3d_radix_sort(const uint32_t *keys, const int32_t *vals, int n, int bits, uint32_t *keys_out, int32_t *vals_out, void *workspace,
-                    size_t workspace_bytes, ls3d_stream_t stream);
+int ls3d_radix_sort(const uint32_t *keys, const int32_t *vals, int n, const int32_t *n_dev, int bits, uint32_t *keys_out, int32_t *vals_out,
+                    void *workspace, size_t workspace_bytes, ls3d_stream_t stream);
 size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout);
 int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream);
 size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout);

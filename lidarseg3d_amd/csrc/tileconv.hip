@@ -325,8 +325,8 @@ extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_
   return LS3D_OK;
 }
 
-int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, int bits, uint32_t *keys_out, int32_t *vals_out, void *workspace,
-                          size_t workspace_bytes, hipStream_t stream);
+int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, const int32_t *n_dev, int bits, uint32_t *keys_out, int32_t *vals_out,
+                          void *workspace, size_t workspace_bytes, hipStream_t stream);
 extern "C" size_t ls3d_radix_sort_workspace_bytes(int n);
 
 extern "C" size_t ls3d_tile_plan_workspace_bytes(int n_rows) {
@@ -352,7 +352,7 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
   int32_t *order = (int32_t *)((char *)workspace + seg);
   void *sort_ws = (char *)workspace + 2 * seg;
   hipLaunchKernelGGL(k_tile_keys, ls3d_grid(n_rows), dim3(256), 0, stream, coords, n_rows, n_rows_dev, shift, mbits, keys);
-  int rc = ls3d_radix_sort_pairs(keys, nullptr, n_rows, bits, nullptr, order, sort_ws, workspace_bytes - 2 * seg, stream);
+  int rc = ls3d_radix_sort_pairs(keys, nullptr, n_rows, n_rows_dev, bits, nullptr, order, sort_ws, workspace_bytes - 2 * seg, stream);
   if (rc != LS3D_OK) return rc;
   TilePlan p = tc_plan(plan, n_rows, kvol);
   hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, stream, tbl, n_rows, n_rows_dev, kvol,

@@ -242,9 +242,19 @@ __device__ __forceinline__ void tv_layernorm(float *X, const float *g, const flo
   }
 }
 
+// Token deduplication (cls != NULL).  The reference runs the transformer over all P point slots of a voxel, zero padding included
+// and unmasked (voxel_encoder.py:154-161), so the padding slots of a voxel are IDENTICAL tokens (zero point + the voxel's descriptor)
+// and stay identical through every layer (the layers are permutation-equivariant).  A voxel with k < P points therefore has k + 1
+// distinct rows: its k points and ONE padding row that stands for the P - k copies - in the softmax of the attention its key counts
+// P - k times, everywhere else (GEMMs, LayerNorm, residuals, max over the slots) a copy changes nothing.  Voxels are grouped by
+// k (ls3d_transvfe sorts them: cls = [perm[n] | off[P + 2]], off[k] = first position of class k in perm) and a 32-row wave tile takes
+// floor(32 / (k + 1)) voxels of one class instead of floor(32 / P): on LiDAR data (1.4 points per voxel after the 5-point cap) 2.1x
+// fewer tiles for the same result up to summation order inside the softmax.  A voxel whose slots beyond num_points are not all zero is
+// put in class P (every slot a row of its own), so the deduplication never assumes what it has not checked.
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ voxels, const int32_t *__restrict__ num, int n,
-                                                     const int32_t *n_dev, int P, int C, TvParams prm, float *__restrict__ out, int out_ld) {
+                                                     const int32_t *n_dev, int P, int C, TvParams prm, float *__restrict__ out, int out_ld,
+                                                     const int32_t *__restrict__ cls) {
   HIP_DYNAMIC_SHARED(float, smem)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kk = lane >> 5;
@@ -252,21 +262,43 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
   float *T = X + 32 * TV_XS;                   // [32][TV_TS]
   float *Bs = smem + 4 * TV_WAVE_FLOATS;       // [2][TV_BCHUNK] floats, or [2][TV_PCHUNK] uint4 in the plane modes
   const int N = ls3d_count(n, n_dev);
-  const int G = 32 / P;                        // voxels per wave tile
-  const int per_block = 4 * G;
-  for (int v0 = blockIdx.x * per_block; v0 < N; v0 += gridDim.x * per_block) {
-    const int vw = v0 + wave * G;              // first voxel of this wave
-    // ---- tokens -> T[:, 0:KT]: row g * P + p = [point p of voxel g | descriptor of voxel g | 0...]
+  const int32_t *perm = cls, *coff = cls ? cls + n : nullptr;
+  int ntiles = 0;
+  if (cls) {
+    for (int c = 0; c <= P; ++c) {
+      const int pb = 4 * (32 / (c < P ? c + 1 : P));
+      ntiles += (coff[c + 1] - coff[c] + pb - 1) / pb;
+    }
+  } else {
+    ntiles = (N + 4 * (32 / P) - 1) / (4 * (32 / P));
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // this tile: voxels perm[base + wave * G + g] (or base + wave * G + g), g < G, of class `kpts` points; R rows per voxel
+    int kpts = P, R = P, base = tile * 4 * (32 / P), lim = N;
+    if (cls) {
+      int t = tile;
+      for (int c = 0; c <= P; ++c) {
+        const int rc = c < P ? c + 1 : P, pb = 4 * (32 / rc), tc = (coff[c + 1] - coff[c] + pb - 1) / pb;
+        if (t < tc) { kpts = c; R = rc; base = coff[c] + t * pb; lim = coff[c + 1]; break; }
+        t -= tc;
+      }
+    }
+    const int G = 32 / R;                      // voxels per wave tile
+    const int vw = base + wave * G;            // position of this wave's first voxel
+    const float wpad = (float)(P - kpts);      // weight of the padding row's key in the softmax (kpts < P)
+#define TV_VOXEL(g_) (((g_) < G && vw + (g_) < lim) ? (perm ? perm[vw + (g_)] : vw + (g_)) : -1)
+    // ---- tokens -> T[:, 0:KT]: row g * R + p = [point p of voxel g (zeros for the padding row) | descriptor of voxel g | 0...]
     {
       const int row = lane & 31;
-      const int g = row / P, p = row - g * P, v = vw + g;
+      const int g = row / R, p = row - g * R, v = TV_VOXEL(g);
       float *t = T + row * TV_TS;
       if (lane < 32) {
-        if (g < G && v < N) {
+        if (v >= 0) {
           const float *vox = voxels + (size_t)v * P * C;
           float desc[LS3D_MAX_FEAT + 8];
           vfe_descriptor(vox, P, C, num[v], desc);
-          for (int c = 0; c < C; ++c) t[c] = vox[p * C + c];
+          const bool pad = p >= kpts;
+          for (int c = 0; c < C; ++c) t[c] = pad ? 0.0f : vox[p * C + c];
           for (int c = 0; c < C + 8; ++c) t[C + c] = desc[c];
           for (int c = 2 * C + 8; c < TV_KT; ++c) t[c] = 0.0f;
         } else {
@@ -300,32 +332,33 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       // ---- attention inside each voxel: one lane per (voxel g, head h, query token t); output over the query's slice
       {
         const float scale = 1.0f / sqrtf((float)TV_HD);
-        const int items = G * TV_H * P;
+        const int items = G * TV_H * R;
         for (int ps = 0; ps * 64 < items; ++ps) {
           const int it = lane + 64 * ps;
           const bool on = it < items;
-          const int g = on ? it / (TV_H * P) : 0, rem = on ? it - g * TV_H * P : 0;
-          const int h = rem / P, t = rem - h * P;
-          float *qp = T + (g * P + t) * TV_TS + h * TV_HD;
+          const int g = on ? it / (TV_H * R) : 0, rem = on ? it - g * TV_H * R : 0;
+          const int h = rem / R, t = rem - h * R;
+          float *qp = T + (g * R + t) * TV_TS + h * TV_HD;
           float q[TV_HD], o[TV_HD];
 #pragma unroll
           for (int d = 0; d < TV_HD; ++d) { q[d] = qp[d] * scale; o[d] = 0.0f; }
           float m = -3.0e38f;
-          for (int j = 0; j < P; ++j) {
-            const float *kp = T + (g * P + j) * TV_TS + TV_E + h * TV_HD;
+          for (int j = 0; j < R; ++j) {
+            const float *kp = T + (g * R + j) * TV_TS + TV_E + h * TV_HD;
             float s = 0.0f;
 #pragma unroll
             for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
             m = fmaxf(m, s);
           }
           float den = 0.0f;
-          for (int j = 0; j < P; ++j) {
-            const float *kp = T + (g * P + j) * TV_TS + TV_E + h * TV_HD;
+          for (int j = 0; j < R; ++j) {
+            const float *kp = T + (g * R + j) * TV_TS + TV_E + h * TV_HD;
             const float *vp = kp + TV_E;
             float s = 0.0f;
 #pragma unroll
             for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
-            const float pr = expf(s - m);
+            float pr = expf(s - m);
+            if (j >= kpts) pr *= wpad;  // the padding row stands for P - kpts identical keys
             den += pr;
 #pragma unroll
             for (int d = 0; d < TV_HD; ++d) o[d] = fmaf(pr, vp[d], o[d]);
@@ -374,8 +407,8 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
     }
     // ---- max over the P token slots (padding slots take part, as in the reference) -> T[g][0:64]
     for (int g = 0; g < G; ++g) {
-      float m = X[(g * P) * TV_XS + lane];
-      for (int p = 1; p < P; ++p) m = fmaxf(m, X[(g * P + p) * TV_XS + lane]);
+      float m = X[(g * R) * TV_XS + lane];
+      for (int p = 1; p < R; ++p) m = fmaxf(m, X[(g * R + p) * TV_XS + lane]);
       T[g * TV_TS + lane] = m;
     }
     TV_WAVE_SYNC();
@@ -386,13 +419,31 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
         float s = 0.0f;
         for (int c = 0; c < TV_E; ++c) s = fmaf(x[c], w[c], s);
         s = fmaxf(s + prm.bc[o], 0.0f);
-        if (vw + g < N) out[(size_t)(vw + g) * out_ld + o] = s;
+        const int v = TV_VOXEL(g);
+        if (v >= 0) out[(size_t)v * out_ld + o] = s;
       }
     } else {
-      for (int g = 0; g < G; ++g)
-        if (vw + g < N) out[(size_t)(vw + g) * out_ld + lane] = T[g * TV_TS + lane];
+      for (int g = 0; g < G; ++g) {
+        const int v = TV_VOXEL(g);
+        if (v >= 0) out[(size_t)v * out_ld + lane] = T[g * TV_TS + lane];
+      }
     }
     TV_WAVE_SYNC();
+#undef TV_VOXEL
+  }
+}
+
+// class of a voxel for the token deduplication: its point count k (clamped to [0, P]) when the slots beyond it are all zero, else P
+__global__ __launch_bounds__(256) void k_tv_class_keys(const float *__restrict__ voxels, const int32_t *__restrict__ num, int n, const int32_t *n_dev,
+                                                       int P, int C, uint32_t *__restrict__ keys) {
+  const int N = ls3d_count(n, n_dev);
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < N; v += gridDim.x * blockDim.x) {
+    int k = num[v];
+    k = k < 0 ? 0 : (k > P ? P : k);
+    const float *vox = voxels + (size_t)v * P * C;
+    bool zero = true;
+    for (int i = k * C; i < P * C; ++i) zero = zero && (vox[i] == 0.0f);
+    keys[v] = (uint32_t)(zero ? k : P);
   }
 }
 
@@ -440,20 +491,33 @@ extern "C" int ls3d_transvfe_pack_planes(const float *w_packed_nt2, int K, int N
   return LS3D_OK;
 }
 
+int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, const int32_t *n_dev, int bits, uint32_t *keys_out, int32_t *vals_out,
+                          void *workspace, size_t workspace_bytes, hipStream_t stream);
+extern "C" size_t ls3d_radix_sort_workspace_bytes(int n);
+extern "C" int ls3d_frame_offsets(const void *table, int is_float, int stride, int col, int n, const int32_t *n_dev, int batch, int32_t *off,
+                                  ls3d_stream_t stream);
+
+static inline size_t tv_align(size_t v) { return (v + 255) & ~(size_t)255; }
+// workspace of the token deduplication: class keys, sorted keys, [perm | class offsets], sort buffers
+extern "C" size_t ls3d_transvfe_workspace_bytes(int n, int P) {
+  if (n <= 0 || P < 1 || P > 32) return 0;
+  return 2 * tv_align((size_t)n * 4) + tv_align(((size_t)n + P + 2) * 4) + ls3d_radix_sort_workspace_bytes(n);
+}
+
 template <int MODE>
 static int tv_launch(hipStream_t stream, long long blocks, int lds, const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
-                     const TvParams &prm, float *out, int out_ld) {
+                     const TvParams &prm, float *out, int out_ld, const int32_t *cls) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_transvfe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_transvfe<MODE>, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  hipLaunchKernelGGL(k_transvfe<MODE>, dim3((unsigned)blocks), dim3(256), lds, stream, voxels, num_points, n, n_dev, P, C, prm, out, out_ld, cls);
   return LS3D_OK;
 }
 
 extern "C" int ls3d_transvfe(const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
-                             const ls3d_transvfe_t *m, float *out, int out_ld, ls3d_stream_t stream_) {
+                             const ls3d_transvfe_t *m, float *out, int out_ld, void *workspace, size_t workspace_bytes, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!voxels || !num_points || !m || !out || n < 0 || P < 1 || C < 3) return LS3D_ERR_ARG;
   if (!m->w_embed || !m->b_embed || (m->num_layers > 0 && !m->layers)) return LS3D_ERR_ARG;
@@ -478,12 +542,31 @@ extern "C" int ls3d_transvfe(const float *voxels, const int32_t *num_points, int
   const int lds_planes = 4 * TV_WAVE_FLOATS * (int)sizeof(float) + 2 * TV_PCHUNK * 16;
   const int per_block = 4 * (32 / P);
   long long blocks = ((long long)n + per_block - 1) / per_block;
+  // token deduplication (see k_transvfe) when the caller provides the workspace and does not switch it off (flags bit 1): class keys ->
+  // one stable radix pass -> positions of the classes; 4 small launches in front of the reader
+  const int32_t *cls = nullptr;
+  if (workspace && !(m->flags & 2) && P > 1) {
+    if (workspace_bytes < ls3d_transvfe_workspace_bytes(n, P) || ((uintptr_t)workspace & 15)) return LS3D_ERR_WORKSPACE;
+    char *ws = (char *)workspace;
+    uint32_t *keys = (uint32_t *)ws, *skeys = (uint32_t *)(ws + tv_align((size_t)n * 4));
+    int32_t *pc = (int32_t *)(ws + 2 * tv_align((size_t)n * 4));
+    void *sort_ws = ws + 2 * tv_align((size_t)n * 4) + tv_align(((size_t)n + P + 2) * 4);
+    int bits = 1;
+    while ((1 << bits) <= P) ++bits;
+    hipLaunchKernelGGL(k_tv_class_keys, ls3d_grid(n), dim3(256), 0, stream, voxels, num_points, n, n_dev, P, C, keys);
+    int rc2 = ls3d_radix_sort_pairs(keys, nullptr, n, n_dev, bits, skeys, pc, sort_ws, ls3d_radix_sort_workspace_bytes(n), stream);
+    if (rc2 != LS3D_OK) return rc2;
+    rc2 = ls3d_frame_offsets(skeys, 0, 1, 0, n, n_dev, P + 1, pc + n, stream_);  // off[c] = first position with class >= c, off[P + 1] = count
+    if (rc2 != LS3D_OK) return rc2;
+    cls = pc;
+    blocks += P + 1;  // every class may end in a partial tile
+  }
   if (blocks > 65536) blocks = 65536;
   int rc;
-  if (m->planes == 6) rc = tv_launch<6>(stream, blocks, lds_planes, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
-  else if (m->planes == 8) rc = tv_launch<8>(stream, blocks, lds_planes, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
-  else if (m->flags & 1) rc = tv_launch<1>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
-  else rc = tv_launch<0>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld);
+  if (m->planes == 6) rc = tv_launch<6>(stream, blocks, lds_planes, voxels, num_points, n, n_dev, P, C, prm, out, out_ld, cls);
+  else if (m->planes == 8) rc = tv_launch<8>(stream, blocks, lds_planes, voxels, num_points, n, n_dev, P, C, prm, out, out_ld, cls);
+  else if (m->flags & 1) rc = tv_launch<1>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld, cls);
+  else rc = tv_launch<0>(stream, blocks, lds_f32, voxels, num_points, n, n_dev, P, C, prm, out, out_ld, cls);
   if (rc != LS3D_OK) return rc;
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;

@@ -307,8 +307,8 @@ extern "C" int ls3d_voxelize_hard(const float *points, int n, const ls3d_points_
 // rows of a segment sit together in their input order (= the slot order of the reference's padded [V, M, C] tensor,
 // scatter_points.py:85-98, scatter_points_cpu.cpp:8-60); one thread per (segment, channel) adds them sequentially in f32.  The
 // result is the slot-order sum divided by the count: bit-reproducible and bit-equal to that serial evaluation.
-int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, int bits, uint32_t *keys_out, int32_t *vals_out, void *workspace,
-                          size_t workspace_bytes, hipStream_t stream);
+int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, const int32_t *n_dev, int bits, uint32_t *keys_out, int32_t *vals_out,
+                          void *workspace, size_t workspace_bytes, hipStream_t stream);
 extern "C" size_t ls3d_radix_sort_workspace_bytes(int n);
 
 struct SegWs { uint32_t *keys, *skeys; int32_t *perm, *start, *end; void *sort_ws; size_t sort_bytes, bytes; };
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_seg_mean_ordered(const float *src, int 
 static int seg_mean_ordered(const float *src, int n, int C, int n_seg, const int32_t *n_seg_dev, SegWs &w, float *out, int32_t *counts, hipStream_t stream) {
   int bits = 1;
   while ((1u << bits) <= (unsigned)n_seg && bits < 31) ++bits;
-  int rc = ls3d_radix_sort_pairs(w.keys, nullptr, n, bits, w.skeys, w.perm, w.sort_ws, w.sort_bytes, stream);
+  int rc = ls3d_radix_sort_pairs(w.keys, nullptr, n, nullptr, bits, w.skeys, w.perm, w.sort_ws, w.sort_bytes, stream);
   if (rc != LS3D_OK) return rc;
   hipMemsetAsync(w.start, 0, (size_t)(n_seg + 1) * 4, stream);
   hipMemsetAsync(w.end, 0, (size_t)(n_seg + 1) * 4, stream);

@@ -241,8 +241,11 @@ def transvfe(voxels, num_points, model, n_dev=None):
     products = tile_products() if _TRANSVFE_PLANES else 0
     m = model.for_planes(products) if products else model
     out = torch.empty((n, model.num_out), dtype=torch.float32, device=voxels.device)
-    m.c.flags = 1 if _TRANSVFE_DIRECT else 0
-    rc = _L().ls3d_transvfe(_ptr(voxels), _ptr(num_points), n, _ndev(n_dev), p, c, ctypes.byref(m.c), _ptr(out), model.num_out, _stream(voxels))
+    m.c.flags = (1 if _TRANSVFE_DIRECT else 0) | (0 if _TRANSVFE_DEDUP else 2)
+    L = _L()
+    ws = _ws(L.ls3d_transvfe_workspace_bytes(n, p), voxels) if (_TRANSVFE_DEDUP and n > 0) else None
+    rc = L.ls3d_transvfe(_ptr(voxels), _ptr(num_points), n, _ndev(n_dev), p, c, ctypes.byref(m.c), _ptr(out), model.num_out,
+                         _vp(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0), _stream(voxels))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "ls3d_transvfe")
@@ -412,13 +415,15 @@ def choose_geometry(cout, n_rows, target_blocks=None):
     return nt, wc
 
 
-def radix_argsort(keys, bits=32):
-    """stable ascending argsort of int32/uint32 keys by their low `bits` bits -> int32 permutation (ls3d_radix_sort)"""
+def radix_argsort(keys, bits=32, n_dev=None):
+    """stable ascending argsort of int32/uint32 keys by their low `bits` bits -> int32 permutation (ls3d_radix_sort); n_dev: only
+    the first *n_dev keys are sorted (the rest of the permutation is unspecified)"""
     n = keys.shape[0]
     L = _L()
     perm = torch.empty((n,), dtype=_i32, device=keys.device)
     ws = _ws(L.ls3d_radix_sort_workspace_bytes(n), keys)
-    check(L.ls3d_radix_sort(_ptr(keys), None, n, int(bits), None, _ptr(perm), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(keys)), "ls3d_radix_sort")
+    check(L.ls3d_radix_sort(_ptr(keys), None, n, _ndev(n_dev), int(bits), None, _ptr(perm), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(keys)),
+          "ls3d_radix_sort")
     return perm
 
 
@@ -451,6 +456,7 @@ def rulebook_orders(tbls, n_devs=None):
 
 
 _TRANSVFE_DIRECT = _os.environ.get("LS3D_TRANSVFE_DIRECT", "0") != "0"
+_TRANSVFE_DEDUP = _os.environ.get("LS3D_TRANSVFE_DEDUP", "1") != "0"  # identical padding tokens of a voxel computed once (ls3d_transvfe)
 _GEMM_FLAGS = int(_os.environ.get("LS3D_XCD_MAP", "0")) & 3  # per-call flags of ls3d_gather_gemm (workgroup -> tile mapping, A/B)
 
 
@@ -459,6 +465,12 @@ def set_transvfe_direct(on):
     slower (descriptor flag of ls3d_transvfe; env LS3D_TRANSVFE_DIRECT=1 sets it at start-up)"""
     global _TRANSVFE_DIRECT
     _TRANSVFE_DIRECT = bool(on)
+
+
+def set_transvfe_dedup(on):
+    """token deduplication of the fused TransVFE reader (include/ls3d.h: ls3d_transvfe's workspace) on / off (A/B, tests)"""
+    global _TRANSVFE_DEDUP
+    _TRANSVFE_DEDUP = bool(on)
 
 
 def set_gemm_flags(flags):

@@ -377,6 +377,29 @@ def test_capacity_mode_equals_host_count_mode_full_size(kind, monkeypatch):
         ops.set_precision("f32")
 
 
+def test_bench_under_rccl_process_group_one_rank():
+    """multi-GPU readiness on one GPU: bench.py's distributed path (RCCL init over env://, barrier before and after the timed steps,
+    MAX all-reduce of the elapsed time, value = world x frames / time) with LS3D_BENCH_FORCE_DIST=1 and world size 1, exactly as
+    the driver launches it per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LS3D_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-extra-modes"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "weak" and j["unit"] == "frames/s"
+    assert j["value"] > 50 and abs(j["value"] * j["ms_per_step"] * 1e-3 - 1.0) < 1e-6  # frames/s x s/frame == 1 at one frame per step and rank
+    assert j["roofline"]["bound"] in ("mfma", "hbm") and 0.0 < j["roofline"]["frac"] < 1.0
+
+
 def test_devoxelize_grid_equals_brute_force_120k():
     """the coarse-grid 3-NN must return exactly the brute-force neighbours, also for points far outside the range"""
     cfg = synth.NUSC

@@ -305,6 +305,23 @@ def test_vfe_readers_vs_reference():
     fused = tv.eval()(vx, num).numpy()  # the one-kernel path (ls3d_transvfe)
     assert ops.transvfe(vx.contiguous(), num.to(torch.int32), tv.packed()["fused"]) is not None  # ... is really taken
     np.testing.assert_allclose(fused, g["trans"][sel], rtol=0, atol=1e-4)
+    try:  # token deduplication (the default) vs every padding slot as a row of its own: the same function, f32 rounding of the softmax apart
+        ops.set_transvfe_dedup(False)
+        full = tv(vx, num).numpy()
+        assert not np.array_equal(full, fused)
+        np.testing.assert_allclose(full, g["trans"][sel], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(fused, full, rtol=0, atol=2e-5)
+        # a voxel whose padding slots are NOT zero is not deduplicated: with garbage in the padding of every voxel the two paths agree bit for bit
+        dirty = vx.clone()
+        for i in range(dirty.shape[0]):
+            dirty[i, int(num[i]):] = 0.25
+        want = tv(dirty, num).numpy()
+        ops.set_transvfe_dedup(True)
+        assert np.array_equal(tv(dirty, num).numpy(), want)
+        # classes of every size incl. full voxels and a ragged tail
+        assert sorted(set(int(v) for v in num.tolist())) == [1, 2, 3, 4, 5] or len(set(num.tolist())) >= 3
+    finally:
+        ops.set_transvfe_dedup(True)
     try:  # experimental variant: weights straight from memory, no workgroup barriers - the same arithmetic in the same order
         ops.set_transvfe_direct(True)
         assert np.array_equal(tv(vx, num).numpy(), fused) and np.array_equal(tv(vx[:7], num[:7]).numpy(), fused[:7])
