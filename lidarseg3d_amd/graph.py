@@ -1,0 +1,86 @@
+"""One inference frame = one hipGraph ("avoid host syncs for V"; the reference's own per-frame host round trips are
+det3d/ops/voxel/src/scatter_points_cuda.cu:218-221 and the dataloader's CPU voxelization).
+
+A frame of this path is ~220 small and large kernel launches on two HIP streams.  Submitted from Python they cost ~10 us of host time
+each, and the latency-bound geometry chain (4 strided rulebooks, 4 SubM rulebooks, 4 tile plans: ~100 launches of 2-80 us) is then
+bound by the host, not by the GPU: the convolutions of level 2 wait ~0.6 ms per frame for it (profiles/round3_timeline_eager.txt).
+Capacity mode (detectors.CAPACITY_MODE) removed every host synchronisation from the frame and gave every tensor a shape that does not
+depend on the data; that makes the whole frame capturable: FrameGraph records one capacity-mode forward - both streams - into a
+hipGraph (torch.cuda.CUDAGraph: PyTorch is the plumbing for streams and memory here) and replays it per frame.
+
+    fg = FrameGraph(model, example)      # example: the collated dict with `points` [N, 1 + C] on the device (+ the camera inputs of MSeg3D)
+    ret = fg(example)                    # same list of dicts as model(example, return_loss=False)
+
+Correctness contract: a replay runs exactly the launches of the eager capacity-mode frame (bit-identical results).  The capacities of the
+strided rulebooks are the ones learned from the warm-up frames (1.3x the largest count seen); every replay copies the frame's counts and
+overflow flags to pinned host memory, and __call__ checks them after the frame: an overflowing frame is computed again by the eager
+path (host-side counts, always correct) and the graph is captured again with the new capacities.  Inputs of another shape than the
+captured one go to the eager path as well (a graph is a fixed-shape object: one FrameGraph per point-count bucket)."""
+import torch
+
+from . import detectors
+
+
+class FrameGraph(object):
+    def __init__(self, model, example, warmup=3):
+        if model.training:
+            raise ValueError("FrameGraph is an inference path: model.eval() first")
+        if int(example.get("batch_size", 1)) != 1:
+            raise ValueError("FrameGraph captures single-frame batches (predict() splits larger batches with synchronising boolean masks)")
+        if not detectors.CAPACITY_MODE:
+            raise ValueError("FrameGraph needs capacity mode (LS3D_CAPACITY_MODE=0 is set)")
+        self.model, self.warmup = model, int(warmup)
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example.items()}
+        self.shapes = {k: (tuple(v.shape), v.dtype) for k, v in example.items() if torch.is_tensor(v)}
+        self.graph, self.ret, self.record, self.recaptures, self.fallbacks = None, None, None, 0, 0
+        self._capture()
+
+    def _capture(self):
+        model, bb = self.model, self.model.backbone
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.warmup):  # packs the weights, sets the kernels' attributes, learns the capacities
+                model(dict(self.static), return_loss=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        bb.__dict__.pop("_captured_record", None)
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g):
+            ret = model(dict(self.static), return_loss=False)
+        rec = bb.__dict__.pop("_captured_record", None)
+        if rec is None:
+            raise RuntimeError("the captured forward did not take the capacity path (see detectors._capacity_ok)")
+        self.graph, self.ret, self.record = g, ret, rec
+        self.logits = model.point_head.forward_ret_dict.get("out_logits")
+
+    def matches(self, example):
+        return all(k in example and torch.is_tensor(example[k]) and tuple(example[k].shape) == s and example[k].dtype == d
+                   for k, (s, d) in self.shapes.items()) and int(example.get("batch_size", 1)) == 1
+
+    def __call__(self, example, clone=True):
+        """-> model(example, return_loss=False).  clone=False returns the graph's own output tensors (overwritten by the next call)"""
+        if not self.matches(example):
+            self.fallbacks += 1
+            with torch.no_grad():
+                return self.model(example, return_loss=False)
+        for k in self.shapes:
+            self.static[k].copy_(example[k], non_blocking=True)
+        self.graph.replay()
+        torch.cuda.current_stream().synchronize()  # the frame is done: its counts are on the host, its outputs can be handed out
+        host, key = self.record
+        if not self.model.backbone.apply_counts(host.tolist(), key):
+            # a rulebook overflowed the captured capacity: this frame on host-side counts, then a new graph on relearned capacities
+            self.fallbacks += 1
+            cap, detectors.CAPACITY_MODE = detectors.CAPACITY_MODE, False
+            try:
+                with torch.no_grad():
+                    out = self.model(example, return_loss=False)
+            finally:
+                detectors.CAPACITY_MODE = cap
+            self.recaptures += 1
+            self._capture()
+            return out
+        if not clone:
+            return self.ret
+        return [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()} for r in self.ret]

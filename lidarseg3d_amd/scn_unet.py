@@ -339,9 +339,15 @@ class UNetSCN3D(nn.Module):
         if rec is None:
             return True
         host, ev, key = rec
+        if host.is_pinned() and torch.cuda.is_current_stream_capturing():
+            self.__dict__["_captured_record"] = (host, key)  # graph.FrameGraph reads the counts after each replay
+            return True
         if ev is not None:
             ev.synchronize()
-        cnt = host.tolist()  # [[n_out, overflow], ...]
+        return self.apply_counts(host.tolist(), key)
+
+    def apply_counts(self, cnt, key):
+        """cnt = [[n_out, overflow], ...] of the strided rulebooks of a frame: learn the capacities, or forget them after an overflow"""
         if any(o for _, o in cnt):
             self._caps.pop(key, None)
             return False
@@ -375,7 +381,11 @@ class UNetSCN3D(nn.Module):
             spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps)
             cnts = torch.stack([torch.cat([x.indice_dict[c.indice_key].n_out_dev, x.indice_dict[c.indice_key].overflow_dev]) for c in chain])
             if cnts.is_cuda:
-                host = torch.empty(cnts.shape, dtype=cnts.dtype, pin_memory=True)
+                # one pinned buffer per model: a frame's counts are read (geometry_check) before the next frame is submitted, and a
+                # captured frame (graph.FrameGraph) needs the same host address on every replay
+                host = self.__dict__.get("_pinned_counts")
+                if host is None or host.shape != cnts.shape:
+                    host = self.__dict__["_pinned_counts"] = torch.empty(cnts.shape, dtype=cnts.dtype, pin_memory=True)
                 host.copy_(cnts, non_blocking=True)
                 batch_dict["geometry_record"] = (host, gs.finish_event(), (vc.shape[0], batch_size))
                 gs.keep(cnts)

@@ -377,6 +377,51 @@ def test_capacity_mode_equals_host_count_mode_full_size(kind, monkeypatch):
         ops.set_precision("f32")
 
 
+@pytest.mark.parametrize("kind", ["sdseg3d", "mseg3d"])
+def test_frame_graph_equals_eager_forward_120k(kind):
+    """graph.FrameGraph: one capacity-mode frame captured into a hipGraph (both streams) and replayed - bit-identical logits and labels
+    to the eager forward on the captured frame AND on other frames of the same shape; a frame of another shape goes to the eager
+    path; a replay whose rulebooks overflow the captured capacities is recomputed on host-side counts and the graph is captured again"""
+    from lidarseg3d_amd import graph
+    cfg = synth.NUSC
+    model, _ = _model(getattr(models_cfg, kind)())
+    ops.set_precision("bf16x6")
+    try:
+        def example(n, seed):
+            f = synth.lidar_frame(n, seed=seed, **cfg)
+            ex = dict(points=cu(np.concatenate([np.zeros((n, 1), np.float32), f], 1)), batch_size=1)
+            if kind == "mseg3d":
+                img, emb, cuv = synth.camera_inputs(n, seed=seed, ncam=6, c_img=48, h=40, w=60, batch=1)
+                ex.update(points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
+            return ex
+
+        def eager(ex):
+            with torch.no_grad():
+                ret = model(dict(ex), return_loss=False)
+            return model.point_head.forward_ret_dict["out_logits"].clone(), ret[0]["pred_point_sem_labels"].clone()
+
+        ex0, ex1, ex2 = example(120000, 7), example(120000, 8), example(90000, 9)
+        want = [eager(e) for e in (ex0, ex1, ex2)]
+        fg = graph.FrameGraph(model, ex0)
+        for e, (wl, wp) in ((ex0, want[0]), (ex1, want[1]), (ex0, want[0])):
+            ret = fg(e)
+            assert torch.equal(ret[0]["pred_point_sem_labels"], wp) and torch.equal(fg.logits, wl)
+        assert fg.fallbacks == 0 and fg.recaptures == 0
+        ret = fg(ex2)  # another point count: eager path
+        assert fg.fallbacks == 1 and torch.equal(ret[0]["pred_point_sem_labels"], want[2][1])
+        # overflow: capture a graph on capacities far below this frame's counts
+        bb = model.backbone
+        key = next(iter(bb._caps))
+        bb._caps[key] = [100] * len(bb._caps[key])
+        fg2 = graph.FrameGraph(model, ex0, warmup=0)
+        ret = fg2(ex1)
+        assert fg2.recaptures == 1 and torch.equal(ret[0]["pred_point_sem_labels"], want[1][1])
+        ret = fg2(ex0)
+        assert fg2.recaptures == 1 and torch.equal(ret[0]["pred_point_sem_labels"], want[0][1]) and torch.equal(fg2.logits, want[0][0])
+    finally:
+        ops.set_precision("f32")
+
+
 def test_bench_under_rccl_process_group_one_rank():
     """multi-GPU readiness on one GPU: bench.py's distributed path (RCCL init over env://, barrier before and after the timed steps,
     MAX all-reduce of the elapsed time, value = world x frames / time) with LS3D_BENCH_FORCE_DIST=1 and world size 1, exactly as
