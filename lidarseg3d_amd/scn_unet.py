@@ -65,23 +65,28 @@ class _GeometryStream(object):
     on exit the current stream waits for it.  hand_over() tells the caching allocator that tensors created inside are used
     on the main stream from now on.  A no-op for CPU tensors (tests/hipsim) and with LS3D_OVERLAP=0."""
 
-    def __init__(self, like, ready=None, join=True):
+    def __init__(self, like, ready=None, join=True, index=0, after=()):
+        """index: which of the device's side streams (capacity mode builds the levels' geometry on several, side by side);
+        after: events of other side streams this block depends on"""
         import os
         self.ready = ready
         self.released = not join  # join=False: the main stream does not wait at the end of the block (pick up finish_event())
         self.on = like.is_cuda and os.environ.get("LS3D_OVERLAP", "1") != "0"
-        self.dev = like.device
+        self.dev, self.index, self.after = like.device, index, after
 
     def __enter__(self):
         if self.on:
             self.main = torch.cuda.current_stream(self.dev)
-            self.side = _SIDE_STREAMS.get(self.dev)
+            self.side = _SIDE_STREAMS.get((self.dev, self.index))
             if self.side is None:
-                self.side = _SIDE_STREAMS[self.dev] = torch.cuda.Stream(self.dev)
+                self.side = _SIDE_STREAMS[(self.dev, self.index)] = torch.cuda.Stream(self.dev)
             if self.ready is not None:
                 self.side.wait_event(self.ready)  # only the coordinates, not the reader that was launched after them
             else:
                 self.side.wait_stream(self.main)
+            for ev in self.after:
+                if ev is not None:
+                    self.side.wait_event(ev)
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
         return self
@@ -366,19 +371,18 @@ class UNetSCN3D(nn.Module):
         ready = batch_dict.get("voxel_coords_ready")
         chain = self._strided_chain()
         caps = self._capacities(vc.shape[0], batch_size, x.spatial_shape)
-        with _GeometryStream(x.indices, ready) as gs:
-            x.indice_dict["subm1"] = spconv.subm_rulebook(x.indices, x.spatial_shape, 3, x.batch_size, n_dev=n_dev)
-            spconv.prebuild_orders(x, self.modules())
-            gs.hand_over(x.indice_dict.values())
-            gs.release()
-        ev0 = self._stack_event()
-        x = self.conv_input(x)
-        x_conv1 = self.conv1(x)
-        ev1 = self._stack_event(ev0)
-        with _GeometryStream(x.indices, ready, join=False) as gs:
-            # all strided rulebooks of the encoder, chained on device counts; their counts and overflow flags go to pinned host
-            # memory right behind them (read in geometry_check)
-            spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps)
+        # Nothing here needs a count on the host, so the WHOLE geometry of the frame is submitted up front, on three side streams that
+        # run side by side behind the "coordinates ready" event (a chain of ~100 dependent 2-80 us kernels on ONE stream takes
+        # ~1.2 ms of GPU time however early it is submitted - the level-2 convolutions used to wait 0.6 ms for it,
+        # profiles/round3_timeline_eager.txt):
+        #   stream 1: all strided rulebooks of the encoder, chained on device counts; their counts and overflow flags go to pinned
+        #             host memory right behind them (read in geometry_check);
+        #   streams 0 / 2, alternating: per level the SubM rulebook, the tile plan and the row orders, each behind the event of the
+        #             strided rulebook that creates the level's sites; the devoxelization's neighbour search at the end.
+        # The main stream picks the levels up one event at a time.
+        with _GeometryStream(x.indices, ready, join=False, index=1) as gs:
+            rb_events = []
+            spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps, after_each=lambda: rb_events.append(gs.finish_event()))
             cnts = torch.stack([torch.cat([x.indice_dict[c.indice_key].n_out_dev, x.indice_dict[c.indice_key].overflow_dev]) for c in chain])
             if cnts.is_cuda:
                 # one pinned buffer per model: a frame's counts are read (geometry_check) before the next frame is submitted, and a
@@ -391,15 +395,33 @@ class UNetSCN3D(nn.Module):
                 gs.keep(cnts)
             else:
                 batch_dict["geometry_record"] = (cnts, None, (vc.shape[0], batch_size))
-        ev0, x_enc = None, x_conv1
+            counts_copied = gs.finish_event()
+        level_ready = []
+        with _GeometryStream(x.indices, ready, join=False, index=0) as gs:
+            x.indice_dict["subm1"] = spconv.subm_rulebook(x.indices, x.spatial_shape, 3, x.batch_size, n_dev=n_dev)
+            spconv.prebuild_orders(x, list(self.conv_input.modules()) + list(self.conv1.modules()))
+            gs.hand_over(x.indice_dict.values())
+            level_ready.append(gs.finish_event())
         for lvl, (key, src, stage) in enumerate((("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4))):
-            with _GeometryStream(x.indices, ready, join=False) as gs:
+            # the last level's block also builds what is left - the decoder's row orders (the inverse tables of EVERY strided rulebook,
+            # conv_out's included) - so it waits for the whole chain
+            deps = rb_events[lvl:lvl + 1] + (rb_events[-1:] if lvl == 2 else [])
+            with _GeometryStream(x.indices, ready, join=False, index=(2 if lvl % 2 == 0 else 0), after=deps) as gs:
                 rb = x.find_indice_pair(src)
                 x.indice_dict[key] = spconv.subm_rulebook(rb.out_indices, rb.out_shape, 3, x.batch_size, n_dev=rb.n_out_dev)
                 spconv.prebuild_orders(x, stage.modules() if lvl < 2 else self.modules())
                 gs.hand_over(x.indice_dict.values())
-                level_ready = gs.finish_event()
-            self._wait(x, level_ready)
+                level_ready.append(gs.finish_event())
+        with _GeometryStream(x.indices, ready, join=False, index=0) as gs2:
+            self._start_devox_search(batch_dict, x, gs2)
+        ev0 = self._stack_event()
+        self._wait(x, level_ready[0])
+        x = self.conv_input(x)
+        x_conv1 = self.conv1(x)
+        ev1 = self._stack_event(ev0)
+        ev0, x_enc = None, x_conv1
+        for lvl, stage in enumerate((self.conv2, self.conv3, self.conv4)):
+            self._wait(x, level_ready[lvl + 1])
             if lvl == 0:
                 ev0 = self._stack_event() if ev1 is not None else None
             x_enc = stage(x_enc)
@@ -408,8 +430,7 @@ class UNetSCN3D(nn.Module):
             elif lvl == 1:
                 x_conv3 = x_enc
         x_conv4 = x_enc
-        with _GeometryStream(x.indices, ready, join=False) as gs2:
-            self._start_devox_search(batch_dict, x, gs2)
+        self._wait(x, counts_copied)  # joins stream 1 (matters for a captured frame: no unjoined work at the end of the capture)
         if self.conv_out is not None:
             batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
             batch_dict["encoded_spconv_tensor_stride"] = 8

@@ -290,7 +290,7 @@ def prebuild_orders(x, layers):
             rb._orders[inv] = o
 
 
-def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, caps=None, n_dev=None):
+def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, caps=None, n_dev=None, after_each=None):
     """Rulebooks of a chain of strided SparseConv3d layers (each one's output sites are the next one's input sites, as in a
     UNet encoder) built back to back on device-side site counts, with ONE host synchronisation for all their sizes instead
     of one per layer.  Intermediate tables are allocated for the worst case (min(8 x inputs, grid cells)) and sliced once
@@ -306,6 +306,8 @@ def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, cap
                                                                out_cap=(caps[li] if caps else None), n_dev=n_dev)
         pend.append((c, coords, shape, oc, cnt, nbr_out, nbr_inv, oshape, n_dev))
         coords, n_dev, shape = oc, cnt[0:1], oshape  # cnt = [n_out, overflow]
+        if after_each is not None:
+            after_each()  # e.g. an event per layer: consumers of this layer's sites need not wait for the rest of the chain
     if nosync:
         # capacity mode: every table keeps its capacity's worth of rows, the counts stay on the device ([n_out, overflow] per layer);
         # the caller checks the overflow flags once per frame (UNetSCN3D.geometry_record)
