@@ -58,6 +58,10 @@ class SparseBasicBlock(spconv.SparseModule):
 
 
 _SIDE_STREAMS = {}
+import os as _os
+# side streams of the capacity-mode geometry: 2 = {strided-rulebook chain | per-level rulebooks, plans, orders, devoxelization search}
+# (measured on MI355X, one hipGraph per frame: 7.40 ms; 3 streams 7.63 ms; everything on one chain 7.84 ms)
+_N_SIDE = int(_os.environ.get("LS3D_GEOM_STREAMS", "2"))
 
 
 class _GeometryStream(object):
@@ -77,15 +81,17 @@ class _GeometryStream(object):
     def __enter__(self):
         if self.on:
             self.main = torch.cuda.current_stream(self.dev)
-            self.side = _SIDE_STREAMS.get((self.dev, self.index))
+            idx = min(self.index, _N_SIDE - 1) if _N_SIDE < 3 else self.index  # fewer side streams: 2 -> {strided chain | rest}, 1 -> one chain
+            idx = 0 if (_N_SIDE == 2 and self.index == 2) else idx
+            self.side = _SIDE_STREAMS.get((self.dev, idx))
             if self.side is None:
-                self.side = _SIDE_STREAMS[(self.dev, self.index)] = torch.cuda.Stream(self.dev)
+                self.side = _SIDE_STREAMS[(self.dev, idx)] = torch.cuda.Stream(self.dev)
             if self.ready is not None:
                 self.side.wait_event(self.ready)  # only the coordinates, not the reader that was launched after them
             else:
                 self.side.wait_stream(self.main)
             for ev in self.after:
-                if ev is not None:
+                if ev is not None and getattr(ev, "_ls3d_stream", None) is not self.side:  # in-order on its own stream anyway
                     self.side.wait_event(ev)
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
@@ -121,6 +127,7 @@ class _GeometryStream(object):
             return None
         ev = torch.cuda.Event()
         ev.record(self.side)
+        ev._ls3d_stream = self.side
         return ev
 
     def keep(self, *tensors):
