@@ -303,7 +303,8 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
  *                    (ls3d_tile_conv_packed_bytes bytes); cout <= 128.
  *   ls3d_tile_conv : out[r, 0..cout) = epilogue(sum_k W[k]^T in[tbl[r,k]]) for the rows of the plan.  products = 8: every
  *                    plane product except tail x tail (2^-32 relative) — f32-grade: the result differs from exact f32
- *                    arithmetic by less than f32 summation-order noise; products = 6: the BF16X6 arithmetic.
+ *                    arithmetic by less than f32 summation-order noise; products = 6: the BF16X6 arithmetic; products = 1: plain
+ *                    bf16 operands (the head plane of both), f32 accumulation - NOT f32-grade (BASELINE configs[4]).
  *                    cin % 16 == 0, in_ld % 4 == 0, cout <= 128.  Summation order per output row is fixed by the plan.
  *                    Workgroups are dispatched in the plan's most-expensive-tile-first order (ls3d_tile_build's last step).
  *                    workspace (optional, ls3d_tile_conv_workspace_bytes(n_rows, cout) bytes, 16-byte aligned, per call) +

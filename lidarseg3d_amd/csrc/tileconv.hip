@@ -546,10 +546,14 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
               uint2 h, m, l;
               ls3d_split_pair3_rne(hv[j].x, hv[j].y, h.x, m.x, l.x);
               ls3d_split_pair3_rne(hv[j].z, hv[j].w, h.y, m.y, l.y);
-              char *dst = smem + hrow * 32 + ((q * 8) ^ (((hrow >> 3) & swz) << 4));  // TC_SWZ: see tc_frag
+              // LDS bank swizzle: a fragment read takes one 16-byte half of 16 gathered rows per lane group; with the halves of
+              // rows r and r + 8 swapped the 16 lanes use all 16 slots of the 256-byte bank row instead of 8 (tools/sim_lds_conflicts.py)
+              char *dst = smem + hrow * 32 + ((q * 8) ^ (((hrow >> 3) & swz) << 4));
               *(uint2 *)(dst) = h;
-              *(uint2 *)(dst + TC_PLANE_BYTES) = m;
-              *(uint2 *)(dst + 2 * TC_PLANE_BYTES) = l;
+              if constexpr (NP > 1) {  // NP == 1 (plain bf16 arithmetic, BASELINE configs[4]): the head plane is all there is
+                *(uint2 *)(dst + TC_PLANE_BYTES) = m;
+                *(uint2 *)(dst + 2 * TC_PLANE_BYTES) = l;
+              }
             }
           }
         }
@@ -578,9 +582,15 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
               uint4 b0[NT], b1[NT];
 #pragma unroll
               for (int n = 0; n < NT; ++n) b0[n] = bs[(n * 3 + 0) * 64];
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, hp[0]);
+              if constexpr (NP == 1) {  // bf16 x bf16 -> f32: one product per f32 product, operands rounded to bf16
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                  acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, b0[n]), acc[n], 0, 0, 0);
+                continue;
+              }
 #pragma unroll
               for (int n = 0; n < NT; ++n) b1[n] = bs[(n * 3 + 1) * 64];
-              const bf16x8 ah = __builtin_bit_cast(bf16x8, hp[0]);
               const bf16x8 am = __builtin_bit_cast(bf16x8, hp[TC_PLANE_BYTES / 16]);
               const bf16x8 al = __builtin_bit_cast(bf16x8, hp[2 * (TC_PLANE_BYTES / 16)]);
               // product-major: consecutive MFMAs go to different accumulators
@@ -673,13 +683,13 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
                               const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, int32_t *counters, int flags,
                               ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (n_rows == 0 && w_packed && kvol >= 1 && kvol <= TC_KMAX && cin >= 16 && !(cin % 16) && cout >= 1 && cout <= 128 && (products == 6 || products == 8))
+  if (n_rows == 0 && w_packed && kvol >= 1 && kvol <= TC_KMAX && cin >= 16 && !(cin % 16) && cout >= 1 && cout <= 128 && (products == 1 || products == 6 || products == 8))
     return LS3D_OK;
   if (!in || !plan || !w_packed || !out || n_rows < 0 || kvol < 1 || cin < 16 || cout < 1) return LS3D_ERR_ARG;
   if ((cin % 16) || (in_ld % 4) || in_ld < cin || out_ld < cout) return LS3D_ERR_ARG;
   if (((uintptr_t)in & 15) || ((uintptr_t)w_packed & 15) || ((uintptr_t)plan & 15) || ((uintptr_t)workspace & 15)) return LS3D_ERR_ARG;
   if (kvol > TC_KMAX || cout > 128) return LS3D_ERR_UNSUPPORTED;
-  if (products != 6 && products != 8) return LS3D_ERR_ARG;
+  if (products != 1 && products != 6 && products != 8) return LS3D_ERR_ARG;
   if (n_rows == 0) return LS3D_OK;
   EpiDev e = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.0f};
   if (epi) {
@@ -711,9 +721,9 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
   const int swz = (flags >> 30) & 1 ? 0 : 1;
   int rc;
 #define TC_ARGS stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ablate, swz, p.ntiles + ns_grid, split_small, split_tail, split_forced, partial, (int *)counters
-  rc = nt == 1 ? (products == 8 ? tc_launch<1, 8>(TC_ARGS) : tc_launch<1, 6>(TC_ARGS))
-     : nt == 2 ? (products == 8 ? tc_launch<2, 8>(TC_ARGS) : tc_launch<2, 6>(TC_ARGS))
-               : (products == 8 ? tc_launch<4, 8>(TC_ARGS) : tc_launch<4, 6>(TC_ARGS));
+  rc = nt == 1 ? (products == 8 ? tc_launch<1, 8>(TC_ARGS) : products == 6 ? tc_launch<1, 6>(TC_ARGS) : tc_launch<1, 1>(TC_ARGS))
+     : nt == 2 ? (products == 8 ? tc_launch<2, 8>(TC_ARGS) : products == 6 ? tc_launch<2, 6>(TC_ARGS) : tc_launch<2, 1>(TC_ARGS))
+               : (products == 8 ? tc_launch<4, 8>(TC_ARGS) : products == 6 ? tc_launch<4, 6>(TC_ARGS) : tc_launch<4, 1>(TC_ARGS));
 #undef TC_ARGS
   if (rc != LS3D_OK) return rc;
   LS3D_RETURN_IF_LAUNCH_FAILED();

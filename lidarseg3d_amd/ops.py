@@ -239,6 +239,7 @@ def transvfe(voxels, num_points, model, n_dev=None):
     n, p, c = voxels.shape
     _ptr(voxels)  # device / contiguity checks
     products = tile_products() if _TRANSVFE_PLANES else 0
+    products = 6 if products == 1 else products  # plain-bf16 mode: the reader stays on its f32-grade planes
     m = model.for_planes(products) if products else model
     out = torch.empty((n, model.num_out), dtype=torch.float32, device=voxels.device)
     m.c.flags = (1 if _TRANSVFE_DIRECT else 0) | (0 if _TRANSVFE_DEDUP else 2)
@@ -353,8 +354,8 @@ def rulebook_order(tbl, coords=None, n_dev=None):
     return rulebook_orders([tbl], [n_dev])[0]
 
 
-F32, BF16X3, BF16X6, BF16X8 = 0, 1, 2, 3
-_PREC_NAMES = {"f32": F32, "bf16x3": BF16X3, "bf16x6": BF16X6, "bf16x8": BF16X8}
+F32, BF16X3, BF16X6, BF16X8, BF16 = 0, 1, 2, 3, 4
+_PREC_NAMES = {"f32": F32, "bf16x3": BF16X3, "bf16x6": BF16X6, "bf16x8": BF16X8, "bf16": BF16}
 # Default since round 3: "bf16x6", the f32-grade arithmetic whose end-to-end error against float64 is BELOW the exact-f32 MFMA path's own
 # on every frame measured (asserted by tests/test_gpu_parity.py::test_sdseg3d_every_arithmetic_vs_float64_... and
 # ..._are_f32_grade_on_other_frames) at 1.5x its speed.  LS3D_PRECISION=f32 (or set_precision("f32")) selects exact-f32 MFMA everywhere.
@@ -366,7 +367,10 @@ def set_precision(name):
     operands with round-to-nearest planes; the 6 plane products of weight >= 2^-16 / every product except tail x tail, head x head in
     its own accumulator; SubM layers on the tile-halo kernel ls3d_tile_conv, strided and inverse layers on the 6-product gather-GEMM /
     exact f32; measured end-to-end logit error against float64: 0.4x / 0.6x of the exact-f32 path's rms), "f32" (exact f32 MFMA
-    everywhere) or "bf16x3" (2-way split, 3 products on the gather-GEMM: ~1e-5 relative error per layer, NOT f32-grade)."""
+    everywhere), "bf16x3" (2-way split, 3 products on the gather-GEMM: ~1e-5 relative error per layer, NOT f32-grade) or "bf16"
+    (BASELINE configs[4]: SubM layers with plain bf16 operands - one MFMA per product, f32 accumulation - strided / inverse layers
+    on the bf16x3 gather-GEMM, reader on its 6-product planes; ~2^-9 relative error per layer: a throughput mode with a stated
+    tolerance, tests/test_gpu_parity.py::test_bf16_mode_tolerance_vs_oracle)."""
     global _PRECISION
     _PRECISION = _PREC_NAMES[name]
 
@@ -396,7 +400,7 @@ def choose_geometry(cout, n_rows, target_blocks=None):
         # measured on MI355X (120k-pt frame): the f32 path is matrix-pipe bound and wants many small workgroups
         # (60.5 fps at >=1500 vs 53 at 256); the split-bf16 path is bound by re-gathering the input rows once per
         # column slab and wants few, wide workgroups (84.6 fps at 128-384 vs 67.5 at 1500)
-        target_blocks = _TARGET_BLOCKS or (192 if _PRECISION == BF16X3 else 512 if _PRECISION == BF16X6 else 2000)
+        target_blocks = _TARGET_BLOCKS or (192 if _PRECISION in (BF16X3, BF16) else 512 if _PRECISION == BF16X6 else 2000)
     total = (cout + 31) // 32
     cands = []
     # measured on MI355X (profiles/): sharing gathered rows between waves (wc > 1) is slower than re-gathering them
@@ -492,6 +496,8 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
     # split-bf16 only where it pays and where its error budget is spent wisely: the sparse convolutions (matrix-pipe
     # bound).  Dense Linear layers (TransVFE, heads, SF-Phase) are memory-bound and stay in exact f32.
     prec = _PRECISION if (_PRECISION != F32 and cin % 32 == 0 and tbl is not None) else F32
+    if prec == BF16:
+        prec = BF16X3  # the layers the tile kernel does not take (strided / inverse) in the plain-bf16 mode
     if prec == BF16X8 or (prec == BF16X6 and _TILE and not _GATHER_X6):
         # the 3-plane modes = tile-halo kernel (ls3d_tile_conv, 8 / 6 plane products, head x head in its own accumulator) for the layers
         # that take it.  The other sparse layers (strided / inverse convolutions: 1.6 pairs per output row, mask-sorted gathers win):
@@ -559,7 +565,7 @@ def tile_products():
     """plane products per f32 product on the tile path, or 0 when the current precision does not use it"""
     if not _TILE:
         return 0
-    return 8 if _PRECISION == BF16X8 else 6 if _PRECISION == BF16X6 else 0
+    return 8 if _PRECISION == BF16X8 else 6 if _PRECISION == BF16X6 else 1 if _PRECISION == BF16 else 0
 
 
 def use_tile(kind, kvol, cin, cout):
@@ -670,6 +676,7 @@ def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None):
     ws = _ws(L.ls3d_spconv_wgrad_workspace_bytes(kvol, cin, cout, n), x)
     if products is None:
         products = tile_products() if _WGRAD_PLANES else 0
+        products = 0 if products == 1 else products  # no plain-bf16 weight gradient: exact f32
     check(L.ls3d_spconv_wgrad(_ptr(x), x.shape[1], _ptr(grad_out), grad_out.shape[1], _ptr(tbl), _ptr(order), kvol, cin, cout, n, None,
                               int(products), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(gw), _stream(x)), "ls3d_spconv_wgrad")
     return gw
