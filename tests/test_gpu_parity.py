@@ -471,7 +471,7 @@ def test_bf16_mode_tolerance_vs_oracle():
         if "/bf16x6+" in k:
             assert r["max_abs"] <= 1e-3 and r["argmax"] >= 0.9995, (k, r)
         else:
-            assert r["max_abs"] <= 0.5 and r["rms"] <= 0.05 and r["argmax"] >= 0.98, (k, r)
+            assert r["max_abs"] <= 0.5 and r["rms"] <= 0.05 and r["argmax"] >= 0.98, (k, r)  # measured: 0.046 / 0.0036 / 99.5 % (SDSeg3D), 0.18 / 0.039 / 100 % (MSeg3D + fp8)
 
 
 def test_bench_under_rccl_process_group_one_rank():
