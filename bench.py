@@ -560,9 +560,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_points or args.points, 100, value_logits_cpu)
             if "parity" in out["cpu_baseline"]:  # GPU logits of the TIMED frame (value's arithmetic) vs the CPU oracle's
                 out["parity_vs_cpu"] = out["cpu_baseline"].pop("parity")
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed AFTER this line at exit: flush it
+        # first so that the JSON record is the last line of the output
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -491,7 +491,9 @@ def test_bench_under_rccl_process_group_one_rank():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
                         "--no-extra-modes"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1].startswith("{"), lines[-3:]  # the record is the LAST line (RCCL's banner is flushed before it)
+    j = json.loads(lines[-1])
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "weak" and j["unit"] == "frames/s"
     assert j["value"] > 50 and abs(j["value"] * j["ms_per_step"] * 1e-3 - 1.0) < 1e-6  # frames/s x s/frame == 1 at one frame per step and rank
     assert j["roofline"]["bound"] in ("mfma", "hbm") and 0.0 < j["roofline"]["frac"] < 1.0
