@@ -86,6 +86,16 @@ class SingleStageDetector(nn.Module):
         load_checkpoint(self, pretrained, strict=False)
 
 
+def _with_training_kernels(model, example, return_loss):
+    """training forward (autograd records): the tall-skinny weight gradients of the nn.Linear layers - reader tokens, head and
+    decoder MLPs: 10^5..10^6 rows reduced into <= 256 x 256 matrices - go to ls3d_spconv_wgrad instead of hipBLASLt's 32 x 32 macro
+    tiles (ops.fast_linear_backward patches torch.nn.functional.linear for the duration of the forward)"""
+    if (return_loss or model.training) and torch.is_grad_enabled():
+        with ops.fast_linear_backward():
+            return model._forward(example, return_loss)
+    return model._forward(example, return_loss)
+
+
 def _capacity_ok(model, example, return_loss):
     """capacity mode applies to inference from raw points on the device (or under the host emulation of the tests)"""
     return (CAPACITY_MODE and not return_loss and not model.training and "voxels" not in example
@@ -140,6 +150,9 @@ class SegNet(SingleStageDetector):
         return self.backbone(data)
 
     def forward(self, example, return_loss=True, **kwargs):
+        return _with_training_kernels(self, example, return_loss)
+
+    def _forward(self, example, return_loss):
         if _capacity_ok(self, example, return_loss):
             ret = _capacity_forward(self, example, lambda ex: self.forward_features(ex, capacity=True))
             if ret is not None:
@@ -196,6 +209,9 @@ class SegMSeg3DNet(SingleStageDetector):
             return None
 
     def forward(self, example, return_loss=True, **kwargs):
+        return _with_training_kernels(self, example, return_loss)
+
+    def _forward(self, example, return_loss):
         if _capacity_ok(self, example, return_loss) and (self.img_backbone is None or "image_features" in example):
             ret = _capacity_forward(self, example, self._capacity_features)
             if ret is not None:

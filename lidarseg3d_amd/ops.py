@@ -682,6 +682,87 @@ def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None):
     return gw
 
 
+_ARANGE = {}
+
+
+def linear_wgrad(x, gy, products=0):
+    """grad_W [cout, cin] = gy^T x of a Linear layer over many rows (x [n, cin], gy [n, cout], both row-major): the tall-skinny GEMM
+    (n = 10^5..10^6 rows reduced into a <= 256 x 256 matrix) that hipBLASLt serves with 32 x 32 macro tiles at ~10 TFLOP/s - here it is
+    ls3d_spconv_wgrad on the identity table (one kernel offset), whose row-pair MFMA reduction is built for exactly this shape.
+    Output columns beyond 128 are done in slices of 128 (the kernel's limit).  products: 0 = exact f32 (default), 6 / 8 = bf16 planes."""
+    n, cin = x.shape
+    cout = gy.shape[1]
+    key = (x.device, n)
+    tbl = _ARANGE.get(key)
+    if tbl is None:
+        if len(_ARANGE) > 8:
+            _ARANGE.clear()
+        tbl = _ARANGE[key] = torch.arange(n, dtype=_i32, device=x.device).unsqueeze(1).contiguous()
+    L = _L()
+    gw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
+    for c0 in range(0, cout, 128):
+        c1 = min(c0 + 128, cout)
+        part = torch.empty((1, cin, c1 - c0), dtype=torch.float32, device=x.device)
+        ws = _ws(L.ls3d_spconv_wgrad_workspace_bytes(1, cin, c1 - c0, n), x)
+        check(L.ls3d_spconv_wgrad(_ptr(x), x.shape[1], ctypes.c_void_p(gy.data_ptr() + 4 * c0), gy.shape[1], _ptr(tbl), None, 1, cin, c1 - c0, n, None,
+                                  int(products), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(part), _stream(x)), "ls3d_spconv_wgrad")
+        gw[c0:c1] = part[0].t()
+    return gw
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with the weight gradient on ls3d_spconv_wgrad (linear_wgrad); everything else is the library GEMM"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias) if _ORIG_LINEAR is None else _ORIG_LINEAR(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = linear_wgrad(x.detach().contiguous(), gy) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+_ORIG_LINEAR = None
+_FAST_LINEAR_MIN_ROWS = int(_os.environ.get("LS3D_FAST_LINEAR_MIN_ROWS", "32768"))
+
+
+class fast_linear_backward(object):
+    """`with ops.fast_linear_backward():` - inside, torch.nn.functional.linear (hence nn.Linear, nn.MultiheadAttention's projections)
+    records _LinearFn for the tall-skinny case: >= 32768 rows on the device, both dimensions <= 256, a gradient wanted.  The training
+    forward of the detectors runs under it; LS3D_FAST_LINEAR=0 switches it off."""
+
+    def __enter__(self):
+        global _ORIG_LINEAR
+        self.on = _os.environ.get("LS3D_FAST_LINEAR", "1") != "0" and _ORIG_LINEAR is None
+        if self.on:
+            _ORIG_LINEAR = torch.nn.functional.linear
+            orig = _ORIG_LINEAR
+
+            def linear(input, weight, bias=None):
+                rows = input.numel() // max(input.shape[-1], 1)
+                if (input.is_cuda and rows >= _FAST_LINEAR_MIN_ROWS and weight.shape[0] <= 256 and weight.shape[1] <= 256 and weight.shape[1] >= 16
+                        and torch.is_grad_enabled() and weight.requires_grad and input.dtype == torch.float32):
+                    y = _LinearFn.apply(input.reshape(rows, input.shape[-1]), weight, bias)
+                    return y.reshape(*input.shape[:-1], weight.shape[0])
+                return orig(input, weight, bias)
+            torch.nn.functional.linear = linear
+        return self
+
+    def __exit__(self, *exc):
+        global _ORIG_LINEAR
+        if self.on:
+            torch.nn.functional.linear = _ORIG_LINEAR
+            _ORIG_LINEAR = None
+        return False
+
+
 def _vp(t):
     p = _ptr(t)
     return p if p is not None else ctypes.c_void_p(0)

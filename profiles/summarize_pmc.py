@@ -5,7 +5,7 @@
 
 HBM-side bytes per kernel = 2 x FETCH_SIZE + WRITE_SIZE (KiB), the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md
 (FETCH_SIZE reports half of the bytes of wide coalesced reads); the counters sit on the L2 -> fabric side, Infinity-Cache hits are
-included: an upper bound of DRAM traffic.  Sparse-conv kernels = k_tile_conv<*> and k_gather_gemm<*, true> (the table-driven
+included: an upper bound of DRAM traffic.  Sparse-conv kernels = k_tile_conv<*>, k_gather_gemm<*, true> and k_gather_gemm_bf16x3<*, true, *> (the table-driven
 launches); bytes per launch = their summed bytes / their launch count, per precision mode of `bench.py --precision P`."""
 import json
 import os
@@ -13,7 +13,7 @@ import sys
 
 import pandas as pd
 
-SPARSE = r"k_tile_conv<|k_gather_gemm<.*true>"
+SPARSE = r"k_tile_conv<|k_gather_gemm(_bf16x3)?<.*true"
 
 
 def load(d, sub, counter):

@@ -565,6 +565,27 @@ def test_subm_training_path_on_the_tile_kernel():
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
 
 
+@pytest.mark.parametrize("n,cin,cout", [(300, 96, 192), (257, 64, 23), (1000, 32, 130)])
+def test_linear_weight_gradient_on_the_wgrad_kernel(n, cin, cout):
+    """ops.linear_wgrad / ops._LinearFn: the tall-skinny weight gradient of nn.Linear (gy^T x over many rows) on ls3d_spconv_wgrad with the
+    identity table, output columns beyond 128 in slices; everything against torch autograd of F.linear"""
+    rng = np.random.default_rng(n + cin + cout)
+    x = torch.from_numpy(rng.normal(size=(n, cin)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy((rng.normal(size=(cout, cin)) * 0.1).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rng.normal(size=(cout,)).astype(np.float32)).requires_grad_(True)
+    r = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32))
+    (torch.nn.functional.linear(x, w, b) * r).sum().backward()
+    want = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    y = ops._LinearFn.apply(x, w, b)
+    assert torch.equal(y, torch.nn.functional.linear(x, w, b))
+    (y * r).sum().backward()
+    for g, t in zip(want, (x, w, b)):
+        assert float((t.grad - g).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-6
+    np.testing.assert_allclose(ops.linear_wgrad(x.detach(), r).numpy(), (r.double().t() @ x.detach().double()).numpy(), rtol=0, atol=1e-3)
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (32, 128), (64, 128), (128, 64), (96, 32)])
 def test_sparse_conv_backward_vs_autograd(cin, cout):
     """SubMConv3d -> SparseConv3d(stride 2) -> SparseInverseConv3d in training mode: grad of the input features and of the
