@@ -685,13 +685,17 @@ def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None):
 _ARANGE = {}
 
 
-def linear_wgrad(x, gy, products=0):
+def linear_wgrad(x, gy, products=None):
     """grad_W [cout, cin] = gy^T x of a Linear layer over many rows (x [n, cin], gy [n, cout], both row-major): the tall-skinny GEMM
     (n = 10^5..10^6 rows reduced into a <= 256 x 256 matrix) that hipBLASLt serves with 32 x 32 macro tiles at ~10 TFLOP/s - here it is
     ls3d_spconv_wgrad on the identity table (one kernel offset), whose row-pair MFMA reduction is built for exactly this shape.
-    Output columns beyond 128 are done in slices of 128 (the kernel's limit).  products: 0 = exact f32 (default), 6 / 8 = bf16 planes."""
+    Output columns beyond 128 are done in slices of 128 (the kernel's limit).  products: 0 = exact f32, 6 / 8 = the exact bf16 planes
+    (f32-grade); None = what is faster (measured, tools/probe_linear_wgrad.py: planes from 128 input channels on - 192 -> 96 on 360k
+    rows: torch 0.76 ms, exact f32 0.63, planes 0.43; 96 -> 96: 0.67 / 0.35 / 0.42)."""
     n, cin = x.shape
     cout = gy.shape[1]
+    if products is None:
+        products = 6 if cin >= 128 else 0
     key = (x.device, n)
     tbl = _ARANGE.get(key)
     if tbl is None:
@@ -747,7 +751,10 @@ class fast_linear_backward(object):
 
             def linear(input, weight, bias=None):
                 rows = input.numel() // max(input.shape[-1], 1)
-                if (input.is_cuda and rows >= _FAST_LINEAR_MIN_ROWS and weight.shape[0] <= 256 and weight.shape[1] <= 256 and weight.shape[1] >= 16
+                # more than 128 output columns run as two slices that both read x: only worth it from ~96 input channels on (64 -> 192 on
+                # 1.2M rows: torch 1.79 ms, here 2.17; 96 -> 192 on 360k rows: 0.76 / 0.71)
+                if (input.is_cuda and rows >= _FAST_LINEAR_MIN_ROWS and weight.shape[0] <= 256 and 16 <= weight.shape[1] <= 256
+                        and (weight.shape[0] <= 128 or weight.shape[1] >= 96)
                         and torch.is_grad_enabled() and weight.requires_grad and input.dtype == torch.float32):
                     y = _LinearFn.apply(input.reshape(rows, input.shape[-1]), weight, bias)
                     return y.reshape(*input.shape[:-1], weight.shape[0])
