@@ -753,7 +753,7 @@ class fast_linear_backward(object):
                 rows = input.numel() // max(input.shape[-1], 1)
                 # more than 128 output columns run as two slices that both read x: only worth it from ~96 input channels on (64 -> 192 on
                 # 1.2M rows: torch 1.79 ms, here 2.17; 96 -> 192 on 360k rows: 0.76 / 0.71)
-                if (input.is_cuda and rows >= _FAST_LINEAR_MIN_ROWS and weight.shape[0] <= 256 and 16 <= weight.shape[1] <= 256
+                if (input.is_cuda and input.is_contiguous() and rows >= _FAST_LINEAR_MIN_ROWS and weight.shape[0] <= 256 and 16 <= weight.shape[1] <= 256
                         and (weight.shape[0] <= 128 or weight.shape[1] >= 96)
                         and torch.is_grad_enabled() and weight.requires_grad and input.dtype == torch.float32):
                     y = _LinearFn.apply(input.reshape(rows, input.shape[-1]), weight, bias)
