@@ -321,7 +321,12 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
  *                    tiles as the workspace allows); bits 8-19: number of split tiles (the last ones of the dispatch order) + 1
  *                    for any launch; bits 20-29: number of split tiles + 1 for launches of more than 512 tiles (default: none -
  *                    measured without gain); bit 30: halo planes in LDS without the bank swizzle.  Every flag value gives the
- *                    same bits for the rows of unsplit tiles.
+ *                    same bits for the rows of unsplit tiles.  bit 5 (products == 6): run the tracing build of the kernel - same
+ *                    results; every wave of every work unit writes a 16-word record (100 MHz wall clock at start / end, HW_ID,
+ *                    XCC_ID, tile, unit kind, halo rows, offset counts, shader cycles: total / prologue / halo staging / waits at
+ *                    the step barriers / epilogue, steps) into the workspace behind the partial sums, at byte offset
+ *                    ls3d_tile_conv_workspace_bytes(n_rows, cout): the workspace must then hold that many bytes +
+ *                    ls3d_tile_conv_trace_bytes(n_rows) (records [unit][wave][16] uint32, unit = blockIdx; tools/trace_tile.py).
  *   ls3d_tile_build / ls3d_tile_plan flags: bit 0 = dispatch the tiles in plan (spatial) order instead of most expensive first. */
 int ls3d_tile_keys(const int32_t *coords /*[n,4] b,z,y,x*/, int n, const int32_t *n_dev, const int32_t shape_zyx_host[3], int batch,
                    uint32_t *keys, ls3d_stream_t stream);
@@ -346,6 +351,7 @@ size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout);
 int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream);
 size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout);
 size_t ls3d_tile_conv_counter_bytes(void);
+size_t ls3d_tile_conv_trace_bytes(int n_rows);
 int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout,
                    int products, const ls3d_epilogue_t *epi_host, float *out, int out_ld, void *workspace, size_t workspace_bytes,
                    int32_t *counters, int flags, ls3d_stream_t stream);

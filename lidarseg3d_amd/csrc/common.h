@@ -84,6 +84,28 @@ __device__ __forceinline__ void ls3d_store_agent(float *p, float v) { __hip_atom
   } while (0)
 #endif
 
+// ---- in-kernel tracing (ls3d_tile_conv's trace flag): shader-cycle counter, the 100 MHz wall clock shared by all CUs, and where a
+//      wave runs (HW_ID: wave / SIMD / CU / SH / SE fields, XCC_ID: the XCD)
+#ifdef HIPSIM
+__device__ __forceinline__ unsigned long long ls3d_cycles() { return 0; }
+__device__ __forceinline__ unsigned long long ls3d_walltime() { return 0; }
+__device__ __forceinline__ unsigned ls3d_hw_id() { return 0; }
+__device__ __forceinline__ unsigned ls3d_xcc_id() { return 0; }
+#else
+__device__ __forceinline__ unsigned long long ls3d_cycles() { return __builtin_readcyclecounter(); }          // s_memtime
+__device__ __forceinline__ unsigned long long ls3d_walltime() { return __builtin_amdgcn_s_memrealtime(); }    // 100 MHz
+__device__ __forceinline__ unsigned ls3d_hw_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+  return v;
+}
+__device__ __forceinline__ unsigned ls3d_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v;
+}
+#endif
+
 __device__ __forceinline__ uint64_t ls3d_mix(uint64_t k) {  // 64-bit finaliser (splitmix)
   k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
   k ^= k >> 27; k *= 0x94d049bb133111ebull;

@@ -435,10 +435,15 @@ constexpr int TC_THREADS = 256;
 // of 1 KB per wave and step, issued one step ahead into the other buffer, no staging registers, no address VALU), the local
 // indices of the A fragments are read one step ahead, every per-wave decision is a scalar branch.
 // NP = plane products per f32 product (6 or 8).
-template <int NT, int NP>
+// TR = tracing build of the same kernel (flags bit 5 of ls3d_tile_conv): every wave of every unit writes one TC_TRACE_WORDS-word record -
+// when and where it ran and how its cycles split into prologue / halo staging / waits at the step barriers / epilogue (the rest is
+// the MFMA loop itself) - for tools/trace_tile.py.  The product instantiations (TR = false) carry none of it.
+constexpr int TC_TRACE_WORDS = 16;
+template <int NT, int NP, bool TR = false>
 __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in, int in_ld, TilePlan p, const uint4 *__restrict__ wpk,
                                                              int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int ablate, int swz,
-                                                             int split_small, int split_tail, int split_forced, float *partial, int *counters) {
+                                                             int split_small, int split_tail, int split_forced, float *partial, int *counters,
+                                                             unsigned *trace) {
   constexpr int PU = NT * 192;             // 16-byte units of one (offset, chunk) weight piece
   constexpr int PB = NT * 3;               // ... in 1 KB LDS-DMA blocks
   constexpr int G = 4 / NT;                // offsets per step
@@ -489,6 +494,23 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     const unsigned kmask = (unsigned)meta[1];
     const unsigned wmask = (unsigned)__builtin_amdgcn_readfirstlane(meta[2 + wave]);
     if (meta[6] == 0) return;
+    unsigned long long tr_w0 = 0, tr_t0 = 0, tr_mark = 0;
+    unsigned tr_pro = 0, tr_stage = 0, tr_bar = 0, tr_steps = 0;
+    if constexpr (TR) { tr_w0 = ls3d_walltime(); tr_t0 = ls3d_cycles(); }
+#define TC_TRACE_WRITE(done_)                                                                        \
+  if constexpr (TR) {                                                                                \
+    const unsigned long long t1_ = ls3d_cycles(), w1_ = ls3d_walltime();                             \
+    if (lane == 0) {                                                                                 \
+      unsigned *rec_ = trace + ((size_t)blockIdx.x * 4 + wave) * TC_TRACE_WORDS;                     \
+      rec_[0] = (unsigned)tr_w0; rec_[1] = (unsigned)(tr_w0 >> 32);                                  \
+      rec_[2] = (unsigned)w1_; rec_[3] = (unsigned)(w1_ >> 32);                                      \
+      rec_[4] = ls3d_hw_id(); rec_[5] = ls3d_xcc_id(); rec_[6] = (unsigned)tile;                     \
+      rec_[7] = (unsigned)part | ((unsigned)ksplit << 8) | ((unsigned)(done_) << 16);                \
+      rec_[8] = (unsigned)H; rec_[9] = (unsigned)__popc(kmask) | ((unsigned)__popc(wmask) << 8);     \
+      rec_[10] = (unsigned)(t1_ - tr_t0); rec_[11] = tr_pro; rec_[12] = tr_stage; rec_[13] = tr_bar; \
+      rec_[14] = (unsigned)(t1_ - tr_mark); rec_[15] = tr_steps;                                     \
+    }                                                                                                \
+  }
     if (tid < TC_TR) s_rows[tid] = p.trow[(size_t)tile * TC_TR + tid];
     {
       const uint4 *src = (const uint4 *)(p.tloc + (size_t)tile * kvol * TC_TR);
@@ -501,6 +523,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] = acs[n][r] = 0.0f;
     const int nseg = (H + TC_HCAP - 1) / TC_HCAP;
+    if constexpr (TR) tr_pro = (unsigned)(ls3d_cycles() - tr_t0);
     for (int seg = 0; seg < (kmask ? nseg : 0); ++seg) {
       const int seg_lo = seg * TC_HCAP;
       const int nh = (H - seg_lo) < TC_HCAP ? (H - seg_lo) : TC_HCAP;
@@ -522,6 +545,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
       const int c_lo = nchunk * part / ksplit, c_hi = nchunk * (part + 1) / ksplit;
       if (!(ablate & 16)) { TC_LOAD_HALO(c_lo) }
       for (int c = c_lo; c < c_hi; ++c) {
+        if constexpr (TR) tr_mark = ls3d_cycles();
         if (c > c_lo) __syncthreads();  // the previous chunk's MFMAs have read their fragments
         unsigned rem = kmask;
         int ks[G], kn[G];
@@ -559,6 +583,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         }
         LS3D_WAIT_VMCNT(0);
         __syncthreads();
+        if constexpr (TR) tr_stage += (unsigned)(ls3d_cycles() - tr_mark);
         if (c + 1 < c_hi && !(ablate & 16)) { TC_LOAD_HALO(c + 1) }
         int buf = 0;
         int lc[G], ln[G];  // raw local indices of this lane's row: current step / next step
@@ -613,9 +638,12 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 #undef TC_MFMA
             }
           }
+          if constexpr (TR) ++tr_steps;
           if (kn[0] < 0) break;
+          if constexpr (TR) tr_mark = ls3d_cycles();
           LS3D_WAIT_VMCNT(0);
           __syncthreads();
+          if constexpr (TR) tr_bar += (unsigned)(ls3d_cycles() - tr_mark);
           buf ^= 1;
 #pragma unroll
           for (int g = 0; g < G; ++g) { ks[g] = kn[g]; lc[g] = ln[g]; }
@@ -625,6 +653,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 #undef TC_LOAD_HALO
       }
     }
+    if constexpr (TR) tr_mark = ls3d_cycles();
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -641,7 +670,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
       // provides the counters zeroed once; every completed launch leaves them even)
       if (tid == 0) s_hid[0] = atomicAdd(counters + sidx, 1) & 1;
       __syncthreads();
-      if (s_hid[0] == 0) return;  // first of the two: the other unit finishes the tile
+      if (s_hid[0] == 0) {  // first of the two: the other unit finishes the tile
+        TC_TRACE_WRITE(0)
+        return;
+      }
       const float *other = partial + ((size_t)sidx * 2 + (part ^ 1)) * (NT * 16 * TC_THREADS) + tid;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
@@ -649,19 +681,22 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         for (int r = 0; r < 16; ++r) acc[n][r] += ls3d_load_agent(other + (n * 16 + r) * TC_THREADS);  // a + b == b + a: order-independent
     }
     gg_epilogue<NT, 1, TC_TR, 64, TC_THREADS>(acc, (float *)smem, s_rows, s_stat, wave, 0, kk, col, 0, cout, e, out, out_ld);
+    TC_TRACE_WRITE(1)
+#undef TC_TRACE_WRITE
   }
 }
 
-template <int NT, int NP>
+template <int NT, int NP, bool TR = false>
 static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TilePlan &p, const uint4 *wpk, int cin, int cout, const EpiDev &e, float *out,
-                     int out_ld, int ablate, int swz, int max_units, int split_small, int split_tail, int split_forced, float *partial, int *counters) {
+                     int out_ld, int ablate, int swz, int max_units, int split_small, int split_tail, int split_forced, float *partial, int *counters,
+                     unsigned *trace) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tile_conv<NT, NP>), dim3((unsigned)max_units), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout,
-                     e, out, out_ld, ablate, swz, split_small, split_tail, split_forced, partial, counters);
+  hipLaunchKernelGGL((k_tile_conv<NT, NP, TR>), dim3((unsigned)max_units), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout,
+                     e, out, out_ld, ablate, swz, split_small, split_tail, split_forced, partial, counters, trace);
   return LS3D_OK;
 }
 
@@ -678,6 +713,12 @@ extern "C" size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout) {
 }
 
 extern "C" size_t ls3d_tile_conv_counter_bytes(void) { return (size_t)TC_SPLIT_MAX * sizeof(int32_t); }
+
+// trace records of one launch (flags bit 5): [units][4 waves][TC_TRACE_WORDS] uint32 behind the partial sums in the workspace
+static inline size_t tc_trace_bytes(int ntiles) {
+  return (size_t)(ntiles + (ntiles < TC_SPLIT_MAX ? ntiles : TC_SPLIT_MAX)) * 4 * TC_TRACE_WORDS * sizeof(unsigned);
+}
+extern "C" size_t ls3d_tile_conv_trace_bytes(int n_rows) { return n_rows <= 0 ? 0 : tc_trace_bytes((n_rows + TC_TR - 1) / TC_TR); }
 
 extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout, int products,
                               const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, int32_t *counters, int flags,
@@ -720,7 +761,19 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
   float *partial = (float *)workspace;
   const int swz = (flags >> 30) & 1 ? 0 : 1;
   int rc;
-#define TC_ARGS stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ablate, swz, p.ntiles + ns_grid, split_small, split_tail, split_forced, partial, (int *)counters
+  unsigned *trace = nullptr;
+#define TC_ARGS stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ablate, swz, p.ntiles + ns_grid, split_small, split_tail, split_forced, partial, (int *)counters, trace
+  if (flags & 32) {  // tracing build (6-product kernels only): the records follow the partial sums of the worst-case split in the workspace
+    const size_t off = ls3d_tile_conv_workspace_bytes(n_rows, cout);
+    if (products != 6) return LS3D_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < off + tc_trace_bytes(p.ntiles)) return LS3D_ERR_WORKSPACE;
+    trace = (unsigned *)((char *)workspace + off);
+    if (hipMemsetAsync(trace, 0, tc_trace_bytes(p.ntiles), stream) != hipSuccess) return LS3D_ERR_LAUNCH;
+    rc = nt == 1 ? tc_launch<1, 6, true>(TC_ARGS) : nt == 2 ? tc_launch<2, 6, true>(TC_ARGS) : tc_launch<4, 6, true>(TC_ARGS);
+    if (rc != LS3D_OK) return rc;
+    LS3D_RETURN_IF_LAUNCH_FAILED();
+    return LS3D_OK;
+  }
   rc = nt == 1 ? (products == 8 ? tc_launch<1, 8>(TC_ARGS) : products == 6 ? tc_launch<1, 6>(TC_ARGS) : tc_launch<1, 1>(TC_ARGS))
      : nt == 2 ? (products == 8 ? tc_launch<2, 8>(TC_ARGS) : products == 6 ? tc_launch<2, 6>(TC_ARGS) : tc_launch<2, 1>(TC_ARGS))
                : (products == 8 ? tc_launch<4, 8>(TC_ARGS) : products == 6 ? tc_launch<4, 6>(TC_ARGS) : tc_launch<4, 1>(TC_ARGS));

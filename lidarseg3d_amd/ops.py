@@ -634,11 +634,30 @@ def tile_conv(x, w, plan, cout=None, products=None, scale=None, shift=None, res_
                    pair.shape[1] if pair is not None else 0, 1 if relu else 0, _vp(ln[0]) if ln is not None else ctypes.c_void_p(0),
                    _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
     split = _TILE_KSPLIT and cin >= 64
-    ws = _tile_ws(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout), x) if split else None
+    flags = _TILE_FLAGS
+    nbytes = int(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout)) if split else 0
+    if _TILE_TRACE is not None and products == 6:  # tools/trace_tile.py: the tracing build writes its records behind the partial sums
+        flags |= 32
+        off = int(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout))
+        nbytes = off + int(_L().ls3d_tile_conv_trace_bytes(plan.n_rows))
+    ws = _tile_ws(nbytes, x) if nbytes else None
     check(_L().ls3d_tile_conv(_ptr(x), in_ld, _ptr(plan.buf), plan.n_rows, kvol, _ptr(w.for_tile()), cin, cout, products, ctypes.byref(epi),
                               _vp_any(out), out_ld, _vp(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
-                              _vp(_tile_counters(x) if split else None), _TILE_FLAGS, _stream(x)), "ls3d_tile_conv")
+                              _vp(_tile_counters(x) if split else None), flags, _stream(x)), "ls3d_tile_conv")
+    if flags & 32:
+        _TILE_TRACE.append(dict(rows=plan.n_rows, kvol=kvol, cin=cin, cout=cout, records=ws[off:].view(torch.int32).view(-1, 4, 16).clone()))
     return out
+
+
+_TILE_TRACE = None
+
+
+def trace_tile_convs(on=True):
+    """tools/trace_tile.py: make every 6-product tile_conv call run the tracing build (flags bit 5 of ls3d_tile_conv) and collect its
+    per-wave records ([unit][wave][16] int32, include/ls3d.h) - returns the list they are appended to (None switches it off)"""
+    global _TILE_TRACE
+    _TILE_TRACE = [] if on else None
+    return _TILE_TRACE
 
 
 _TILE_KSPLIT = _os.environ.get("LS3D_TILE_KSPLIT", "1") != "0"  # hand ls3d_tile_conv the workspace for its split over the input channels
