@@ -316,9 +316,13 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
  *                    every counter even, nothing is reset.  A plan is read-only for ls3d_tile_conv: one plan may serve
  *                    concurrent launches on different streams, each with its own workspace and counters.  Which tiles are
  *                    split is a function of the plan and of `flags` only, so results are bit-reproducible.
- *                    flags (per call, 0 = defaults): bits 2-4 timing ablations for profiling (skip the MFMAs / the weight DMA /
+ *                    flags (per call, 0 = defaults): bit 0: the plain offset loop instead of the software-pipelined one (products
+ *                    == 6, cout > 32: fragments of the next offset are read under the current one's MFMAs, the step barrier sits in
+ *                    the middle of an offset) and bit 1: the general two-pass epilogue instead of the single-pass one - both for
+ *                    A/B runs, bit-identical results; bits 2-4 timing ablations for profiling (skip the MFMAs / the weight DMA /
  *                    the halo staging: results invalid); bits 6-7 channel split (0 = the rule above, 1 = never, 2 = as many
- *                    tiles as the workspace allows); bits 8-19: number of split tiles (the last ones of the dispatch order) + 1
+ *                    tiles as the workspace allows, 3 = the rule above + in launches of more than 512 tiles the [live tiles mod 512]
+ *                    tiles at the end of the dispatch order: measured -1 % on the 120k frame, off by default); bits 8-19: number of split tiles (the last ones of the dispatch order) + 1
  *                    for any launch; bits 20-29: number of split tiles + 1 for launches of more than 512 tiles (default: none -
  *                    measured without gain); bit 30: halo planes in LDS without the bank swizzle.  Every flag value gives the
  *                    same bits for the rows of unsplit tiles.  bit 5 (products == 6): run the tracing build of the kernel - same

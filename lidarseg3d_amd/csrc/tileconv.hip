@@ -427,6 +427,63 @@ constexpr int TC_HID_BYTES = TC_HCAP * 4;
 constexpr int TC_LDS_BYTES = TC_HALO_BYTES + 2 * TC_WBUF_UNITS * 16 + TC_LOC_BYTES + TC_HID_BYTES + TC_TR * 4 + TC_TR * 4;
 constexpr int TC_THREADS = 256;
 
+// Epilogue of a tile (no LayerNorm, float4-aligned operands): all 128 rows at once.  The accumulators are transposed through LDS
+// (the halo planes and the weight buffers are dead by now: 128 x NT*32 floats <= 64 KB fit in front of s_loc) with ONE barrier pair,
+// then every thread owns one float4 column group (its scale / shift are loaded once, before the barrier) and 128 / RPI rows, whose
+// residual / pair operands are fetched in batches of branch-free loads: one memory latency per batch.  gg_epilogue (two passes of 64
+// rows, a conditional load chain per row group) took 18 of a 128 -> 128 tile's 204 us (tools/trace_tile.py).  Same arithmetic per
+// element, in the same order: results are bit-identical to gg_epilogue's.
+template <int NT>
+__device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, const int *s_rows, int wave, int kk, int col, int cout, const EpiDev &e,
+                                            float *__restrict__ out, int out_ld) {
+  constexpr int SLAB = NT * 32, C4 = SLAB / 4, RPI = TC_THREADS / C4, ITER = TC_TR / RPI, BATCH = ITER < 8 ? ITER : 8;
+  static_assert(TC_TR * SLAB * 4 <= TC_HALO_BYTES + 2 * TC_WBUF_UNITS * 16, "the transposed tile fits in front of s_loc");
+  const int tid = threadIdx.x, c4 = tid % C4, lr0 = tid / C4, oc = c4 * 4;
+  const bool oncol = oc < cout;
+  const int occ = oncol ? oc : 0;  // clamped column of the branch-free loads
+  __syncthreads();                 // the MFMA loop's readers are done with the halo planes and the weight buffers
+  {
+    float *dst = stage + (wave * 32 + 4 * kk) * SLAB + col;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * SLAB + n * 32] = acc[n][r];
+  }
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e.scale) sc = *(const float4 *)(e.scale + occ);
+  if (e.shift) sh = *(const float4 *)(e.shift + occ);
+  __syncthreads();
+#pragma unroll
+  for (int b0 = 0; b0 < ITER; b0 += BATCH) {
+    int orow[BATCH];
+    float4 q[BATCH], p0[BATCH], p1[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) orow[j] = s_rows[lr0 + (b0 + j) * RPI];
+    if (e.res_pre) {
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) q[j] = *(const float4 *)(e.res_pre + (size_t)(orow[j] >= 0 ? orow[j] : 0) * e.res_pre_ld + occ);
+    }
+    if (e.pair) {
+#pragma unroll
+      for (int j = 0; j < BATCH; ++j) {
+        const float *pp = e.pair + (size_t)(orow[j] >= 0 ? orow[j] : 0) * e.pair_ld + 2 * occ;
+        p0[j] = *(const float4 *)pp;
+        p1[j] = *(const float4 *)(pp + 4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      float4 v = *(const float4 *)(stage + (lr0 + (b0 + j) * RPI) * SLAB + oc);
+      if (e.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+      if (e.shift) { v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w; }
+      if (e.res_pre) { v.x += q[j].x; v.y += q[j].y; v.z += q[j].z; v.w += q[j].w; }
+      if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (e.pair) { v.x += p0[j].x + p0[j].y; v.y += p0[j].z + p0[j].w; v.z += p1[j].x + p1[j].y; v.w += p1[j].z + p1[j].w; }
+      if (oncol && orow[j] >= 0) *(float4 *)(out + (size_t)orow[j] * out_ld + oc) = v;
+    }
+  }
+}
+
 // Workgroup = 4 waves over one tile: wave w owns rows [32 w, 32 w + 32) and all NT 32-column blocks (cout <= 32: NT = 1,
 // <= 64: NT = 2, <= 128: NT = 4).  Two workgroups fit a CU (LDS 79 KB).  A step = G = 4 / NT consecutive active kernel offsets of
 // one 16-channel chunk, so that every step moves the same 12 KB of weights and feeds 32 MFMAs per wave between two barriers.
@@ -438,8 +495,10 @@ constexpr int TC_THREADS = 256;
 // TR = tracing build of the same kernel (flags bit 5 of ls3d_tile_conv): every wave of every unit writes one TC_TRACE_WORDS-word record -
 // when and where it ran and how its cycles split into prologue / halo staging / waits at the step barriers / epilogue (the rest is
 // the MFMA loop itself) - for tools/trace_tile.py.  The product instantiations (TR = false) carry none of it.
+// LP = 1 (NT >= 2, NP == 6): the offset loop software-pipelined one offset ahead with the step barrier in the MIDDLE of an offset's
+// MFMAs (see the loop); LP = 0: fragments read at the start of the step that uses them (NT = 1, NP = 1 / 8, flags bit 0).
 constexpr int TC_TRACE_WORDS = 16;
-template <int NT, int NP, bool TR = false>
+template <int NT, int NP, bool TR = false, int LP = 0>
 __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in, int in_ld, TilePlan p, const uint4 *__restrict__ wpk,
                                                              int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int ablate, int swz,
                                                              int split_small, int split_tail, int split_forced, float *partial, int *counters,
@@ -474,7 +533,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   // capacity: a plan built on spare rows (capacity mode) and the plan of the exact table run the same units on the same tiles.
   // The launch covers the worst case; workgroups beyond the units of the live tiles leave at once.
   const int tlive = p.torder[p.ntiles];
-  int n_split = split_forced >= 0 ? split_forced : (tlive <= split_small ? tlive : split_tail);  // scalar
+  // split_tail < 0: the tiles beyond the last full round of TC_SPLIT_MAX workgroup slots (the tail that would run one per CU)
+  int n_split = split_forced >= 0 ? split_forced : (tlive <= split_small ? tlive : (split_tail < 0 ? tlive % 512 : split_tail));  // scalar
   if (n_split > tlive) n_split = tlive;
   const int nfull = tlive - n_split;
   if ((int)blockIdx.x >= nfull + 2 * n_split) return;
@@ -560,8 +620,25 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 #define TC_DMA_GROUP(kg_, buf_)                                                   \
   if (kg_[dma_g] >= 0 && !(ablate & 8))                                           \
     ls3d_glds16x3(wchunk + (unsigned)kg_[dma_g] * kstride, voff0, voff1, voff2, (buf_) ? dma_lds1 : dma_lds0);
-        TC_NEXT_GROUP(ks)
-        TC_DMA_GROUP(ks, 0)
+        // LP = 1: the DMA walks the active offsets with its own iterator, G per step, two steps ahead of the MFMAs
+        unsigned rem_d = kmask;
+#define TC_DMA_STEP(buf_)                                                          \
+  {                                                                               \
+    int kd_ = -1;                                                                 \
+    _Pragma("unroll") for (int g_ = 0; g_ < G; ++g_) {                            \
+      const int k_ = rem_d ? __ffs((int)rem_d) - 1 : -1;                          \
+      rem_d &= rem_d - 1;                                                         \
+      if (g_ == dma_g) kd_ = k_;                                                  \
+    }                                                                             \
+    if (kd_ >= 0 && !(ablate & 8))                                                \
+      ls3d_glds16x3(wchunk + (unsigned)kd_ * kstride, voff0, voff1, voff2, (buf_) ? dma_lds1 : dma_lds0); \
+  }
+        if constexpr (LP == 0) {
+          TC_NEXT_GROUP(ks)
+          TC_DMA_GROUP(ks, 0)
+        } else {
+          TC_DMA_STEP(0)
+        }
         if (!(ablate & 16)) {
 #pragma unroll
           for (int j = 0; j < HPT; ++j) {
@@ -586,6 +663,135 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         if constexpr (TR) tr_stage += (unsigned)(ls3d_cycles() - tr_mark);
         if (c + 1 < c_hi && !(ablate & 16)) { TC_LOAD_HALO(c + 1) }
         int buf = 0;
+        if constexpr (LP == 1) {
+          // Software-pipelined offset loop.  tools/trace_tile.py: a workgroup alone on its CU (the tail of a 677-tile launch) keeps the
+          // matrix pipe 50 % busy, two sharing a CU 70 %: with the fragments read at the top of the step that uses them every step starts
+          // with an empty pipe (barrier, bookkeeping, DMA issue, 11 LDS reads before the first MFMA), and what a wave issues between
+          // two MFMA groups is not hidden by anything when it is alone on its SIMD.  Here every non-MFMA instruction sits in the shadow
+          // of a group of NT MFMAs (NT x 32 cycles of matrix pipe):
+          //   * while offset j's MFMAs run, offset j + 1's fragments are read - the halo planes are static for the whole chunk, and the
+          //     weights of the next STEP become readable in the middle of the step's last offset: the barrier sits between the b0
+          //     products and the b1 / b2 products, after this wave's last read of the current weight buffer (b2) and after its share
+          //     of the next buffer's DMA (issued a whole step earlier) has landed; behind it the DMA of the step after next goes into
+          //     the buffer just released;
+          //   * the l and m planes of the next offset replace the current ones as soon as their last product is issued, only the head
+          //     plane is double-buffered (registers: 256 with the accumulators' 128);
+          //   * no per-wave skipping of offsets (94-99 % of the (wave, offset) blocks are active where this loop runs; an absent
+          //     neighbour reads the zero row), no conditional code inside an offset: the offsets of a step are unrolled, the last offset
+          //     of a chunk is peeled (nothing to prefetch, no barrier).
+          // Per accumulator the products are issued in the same order as in the LP = 0 loop: results are bit-identical.
+          static_assert(NP == 6 && NT >= 2, "pipelined loop: 6-product kernels with >= 2 column blocks");
+          constexpr int PL = TC_PLANE_BYTES / 16;
+          TC_DMA_STEP(1)
+          unsigned rem_c = kmask;
+#define TC_POP(dst_)                                  \
+  {                                                   \
+    dst_ = rem_c ? __ffs((int)rem_c) - 1 : -1;        \
+    rem_c &= rem_c - 1;                               \
+  }
+#define TC_HALO_PTR(raw_, dst_)                                                                        \
+  {                                                                                                    \
+    const int li_ = (raw_) - seg_lo;                                                                   \
+    const int lz_ = ((unsigned)li_ < (unsigned)TC_HCAP) ? li_ : TC_HCAP; /* absent / other pass -> the zero row */ \
+    dst_ = (const uint4 *)smem + lz_ * 2 + (kk ^ ((lz_ >> 3) & swz));                                  \
+  }
+#define TC_MFMA(dst_, a_, b_)                                                                         \
+  _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                      \
+      dst_[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, __builtin_bit_cast(bf16x8, b_[n]), dst_[n], 0, 0, 0);
+          int k1, k2;  // the next offset and the one after it (-1: none)
+          {
+            int k0;
+            TC_POP(k0) TC_POP(k1) TC_POP(k2)
+            (void)k0;
+          }
+          bf16x8 ah, am, al;
+          uint4 b0[NT], b1[NT], b2[NT];
+          const uint4 *hpn;  // this lane's row at the NEXT offset: address of its head-plane fragment
+          int loc2;          // ... at the offset after next: raw local index
+          {
+            const uint4 *hp, *bs = Bs + lane;
+            TC_HALO_PTR((int)loc_w[(__ffs((int)kmask) - 1) * TC_TR], hp)
+            ah = __builtin_bit_cast(bf16x8, hp[0]);
+            am = __builtin_bit_cast(bf16x8, hp[PL]);
+            al = __builtin_bit_cast(bf16x8, hp[2 * PL]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { b0[n] = bs[(n * 3 + 0) * 64]; b1[n] = bs[(n * 3 + 1) * 64]; }
+            TC_HALO_PTR((int)loc_w[(k1 >= 0 ? k1 : 0) * TC_TR], hpn)
+            loc2 = loc_w[(k2 >= 0 ? k2 : 0) * TC_TR];
+          }
+          // one offset.  JG_: its position in the step (compile time); BAR_: it is the last offset of a step that has a successor (barrier +
+          // DMA); PRE_: an offset follows (prefetch its fragments; JGN_ / buffer bufn_: where its weights are)
+#define TC_OFFSET(JG_, BAR_, PRE_, JGN_, bufn_)                                                                      \
+  {                                                                                                                  \
+    const uint4 *bs_ = Bs + buf * TC_WBUF_UNITS + (JG_) * PU + lane;                                                 \
+    const uint4 *bsn_ = Bs + (bufn_) * TC_WBUF_UNITS + (JGN_) * PU + lane;                                           \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) b2[n] = bs_[(n * 3 + 2) * 64];                                    \
+    LS3D_SCHED_FENCE();                                                                                              \
+    TC_MFMA(acs, al, b0)                                                                                             \
+    if (PRE_) al = __builtin_bit_cast(bf16x8, hpn[2 * PL]);                                                          \
+    LS3D_SCHED_FENCE();                                                                                              \
+    TC_MFMA(acs, am, b0)                                                                                             \
+    int k3_;                                                                                                         \
+    TC_POP(k3_)                                                                                                      \
+    const int loc3_ = (PRE_) ? (int)loc_w[(k3_ >= 0 ? k3_ : 0) * TC_TR] : 0;                                         \
+    LS3D_SCHED_FENCE();                                                                                              \
+    TC_MFMA(acc, ah, b0)                                                                                             \
+    LS3D_SCHED_FENCE();                                                                                              \
+    if constexpr (TR) ++tr_steps;                                                                                    \
+    if (BAR_) {                                                                                                      \
+      if constexpr (TR) tr_mark = ls3d_cycles();                                                                     \
+      LS3D_WAIT_VMCNT(0);                                                                                            \
+      __syncthreads(); /* every wave: done reading this step's weights, its share of the next step's has landed */   \
+      if constexpr (TR) tr_bar += (unsigned)(ls3d_cycles() - tr_mark);                                               \
+    }                                                                                                                \
+    bf16x8 ahn_ = ah;                                                                                                \
+    if (PRE_) {                                                                                                      \
+      ahn_ = __builtin_bit_cast(bf16x8, hpn[0]);                                                                     \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) b0[n] = bsn_[(n * 3 + 0) * 64];                                 \
+    }                                                                                                                \
+    LS3D_SCHED_FENCE();                                                                                              \
+    TC_MFMA(acs, am, b1)                                                                                             \
+    if (PRE_) am = __builtin_bit_cast(bf16x8, hpn[PL]);                                                              \
+    if (BAR_) TC_DMA_STEP(buf)                                                                                       \
+    LS3D_SCHED_FENCE();                                                                                              \
+    TC_MFMA(acs, ah, b1)                                                                                             \
+    if (PRE_) {                                                                                                      \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) b1[n] = bsn_[(n * 3 + 1) * 64];                                 \
+      TC_HALO_PTR(loc2, hpn)                                                                                         \
+    }                                                                                                                \
+    LS3D_SCHED_FENCE();                                                                                              \
+    TC_MFMA(acs, ah, b2)                                                                                             \
+    LS3D_SCHED_FENCE();                                                                                              \
+    ah = ahn_;                                                                                                       \
+    loc2 = loc3_;                                                                                                    \
+    k1 = k2;                                                                                                         \
+    k2 = k3_;                                                                                                        \
+  }
+          if constexpr (G == 1) {
+            while (k1 >= 0) {
+              TC_OFFSET(0, true, true, 0, buf ^ 1)
+              buf ^= 1;
+            }
+            TC_OFFSET(0, false, false, 0, buf)
+          } else {
+            static_assert(G == 2, "two column blocks: two offsets per step");
+            while (k2 >= 0) {  // a whole step with a successor
+              TC_OFFSET(0, false, true, 1, buf)
+              TC_OFFSET(1, true, true, 0, buf ^ 1)
+              buf ^= 1;
+            }
+            int jg_last = 0;   // the last step: one or two offsets (no early exits above: the accumulators stay where they are)
+            if (k1 >= 0) {
+              TC_OFFSET(0, false, true, 1, buf)
+              jg_last = 1;
+            }
+            TC_OFFSET(jg_last, false, false, 0, buf)
+          }
+#undef TC_OFFSET
+#undef TC_MFMA
+#undef TC_POP
+#undef TC_HALO_PTR
+        } else {
         int lc[G], ln[G];  // raw local indices of this lane's row: current step / next step
 #pragma unroll
         for (int g = 0; g < G; ++g) lc[g] = loc_w[(ks[g] >= 0 ? ks[g] : 0) * TC_TR];
@@ -648,8 +854,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 #pragma unroll
           for (int g = 0; g < G; ++g) { ks[g] = kn[g]; lc[g] = ln[g]; }
         }
+        }
 #undef TC_NEXT_GROUP
 #undef TC_DMA_GROUP
+#undef TC_DMA_STEP
 #undef TC_LOAD_HALO
       }
     }
@@ -680,22 +888,25 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] += ls3d_load_agent(other + (n * 16 + r) * TC_THREADS);  // a + b == b + a: order-independent
     }
-    gg_epilogue<NT, 1, TC_TR, 64, TC_THREADS>(acc, (float *)smem, s_rows, s_stat, wave, 0, kk, col, 0, cout, e, out, out_ld);
+    if (!e.ln_gamma && !(cout & 3) && !(out_ld & 3) && !(e.res_pre && (e.res_pre_ld & 3)) && !(e.pair && (e.pair_ld & 3)) && !(ablate & 2))
+      tc_epilogue<NT>(acc, (float *)smem, s_rows, wave, kk, col, cout, e, out, out_ld);
+    else  // LayerNorm epilogue, unaligned leading dimensions, or flags bit 1 (A/B): the general one
+      gg_epilogue<NT, 1, TC_TR, 64, TC_THREADS>(acc, (float *)smem, s_rows, s_stat, wave, 0, kk, col, 0, cout, e, out, out_ld);
     TC_TRACE_WRITE(1)
 #undef TC_TRACE_WRITE
   }
 }
 
-template <int NT, int NP, bool TR = false>
+template <int NT, int NP, bool TR = false, int LP = 0>
 static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TilePlan &p, const uint4 *wpk, int cin, int cout, const EpiDev &e, float *out,
                      int out_ld, int ablate, int swz, int max_units, int split_small, int split_tail, int split_forced, float *partial, int *counters,
                      unsigned *trace) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP, TR, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_tile_conv<NT, NP, TR>), dim3((unsigned)max_units), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout,
+  hipLaunchKernelGGL((k_tile_conv<NT, NP, TR, LP>), dim3((unsigned)max_units), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout,
                      e, out, out_ld, ablate, swz, split_small, split_tail, split_forced, partial, counters, trace);
   return LS3D_OK;
 }
@@ -741,7 +952,7 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
   }
   const TilePlan p = tc_plan(const_cast<void *>(plan), n_rows, kvol);
   const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;  // column blocks of the kernel variant (the weights are packed for it)
-  const int ablate = flags & 28, split_mode = (flags >> 6) & 3, forced = (flags >> 8) & 0xFFF, tail = (flags >> 20) & 0x3FF;
+  const int ablate = flags & 30, split_mode = (flags >> 6) & 3, forced = (flags >> 8) & 0xFFF, tail = (flags >> 20) & 0x3FF;
   // Split over the input channels (two work units per tile, each over half of the 16-channel chunks) when the caller provides the
   // workspace and the counters and the layer has >= 4 chunks: every tile of a launch whose LIVE tiles do not fill the chip's
   // TC_SPLIT_MAX workgroup slots (level 4 of the 120k frame: 160 -> 125 us per layer).  Larger launches: the `tail` tiles at the
@@ -753,6 +964,7 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
     split_tail = tail ? tail - 1 : 0;                    // otherwise this many at the end of the dispatch order
     if (forced) split_forced = forced - 1;               // exactly this many, whatever the tile count
     if (split_mode == 2) split_forced = TC_SPLIT_MAX;
+    if (split_mode == 3) split_tail = -1;                // the remainder of the live tiles modulo the workgroup slots
     if (split_tail > TC_SPLIT_MAX) split_tail = TC_SPLIT_MAX;
     if (split_forced > TC_SPLIT_MAX) split_forced = TC_SPLIT_MAX;
     ns_grid = p.ntiles < TC_SPLIT_MAX ? p.ntiles : TC_SPLIT_MAX;
@@ -762,6 +974,7 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
   const int swz = (flags >> 30) & 1 ? 0 : 1;
   int rc;
   unsigned *trace = nullptr;
+  const bool pipelined = products == 6 && nt >= 2 && !(flags & 1);  // the software-pipelined offset loop (flags bit 0: the plain one)
 #define TC_ARGS stream, in, in_ld, p, (const uint4 *)w_packed, cin, cout, e, out, out_ld, ablate, swz, p.ntiles + ns_grid, split_small, split_tail, split_forced, partial, (int *)counters, trace
   if (flags & 32) {  // tracing build (6-product kernels only): the records follow the partial sums of the worst-case split in the workspace
     const size_t off = ls3d_tile_conv_workspace_bytes(n_rows, cout);
@@ -769,14 +982,16 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
     if (!workspace || workspace_bytes < off + tc_trace_bytes(p.ntiles)) return LS3D_ERR_WORKSPACE;
     trace = (unsigned *)((char *)workspace + off);
     if (hipMemsetAsync(trace, 0, tc_trace_bytes(p.ntiles), stream) != hipSuccess) return LS3D_ERR_LAUNCH;
-    rc = nt == 1 ? tc_launch<1, 6, true>(TC_ARGS) : nt == 2 ? tc_launch<2, 6, true>(TC_ARGS) : tc_launch<4, 6, true>(TC_ARGS);
+    rc = nt == 1 ? tc_launch<1, 6, true>(TC_ARGS)
+       : nt == 2 ? (pipelined ? tc_launch<2, 6, true, 1>(TC_ARGS) : tc_launch<2, 6, true>(TC_ARGS))
+                 : (pipelined ? tc_launch<4, 6, true, 1>(TC_ARGS) : tc_launch<4, 6, true>(TC_ARGS));
     if (rc != LS3D_OK) return rc;
     LS3D_RETURN_IF_LAUNCH_FAILED();
     return LS3D_OK;
   }
   rc = nt == 1 ? (products == 8 ? tc_launch<1, 8>(TC_ARGS) : products == 6 ? tc_launch<1, 6>(TC_ARGS) : tc_launch<1, 1>(TC_ARGS))
-     : nt == 2 ? (products == 8 ? tc_launch<2, 8>(TC_ARGS) : products == 6 ? tc_launch<2, 6>(TC_ARGS) : tc_launch<2, 1>(TC_ARGS))
-               : (products == 8 ? tc_launch<4, 8>(TC_ARGS) : products == 6 ? tc_launch<4, 6>(TC_ARGS) : tc_launch<4, 1>(TC_ARGS));
+     : nt == 2 ? (products == 8 ? tc_launch<2, 8>(TC_ARGS) : products == 6 ? (pipelined ? tc_launch<2, 6, false, 1>(TC_ARGS) : tc_launch<2, 6>(TC_ARGS)) : tc_launch<2, 1>(TC_ARGS))
+               : (products == 8 ? tc_launch<4, 8>(TC_ARGS) : products == 6 ? (pipelined ? tc_launch<4, 6, false, 1>(TC_ARGS) : tc_launch<4, 6>(TC_ARGS)) : tc_launch<4, 1>(TC_ARGS));
 #undef TC_ARGS
   if (rc != LS3D_OK) return rc;
   LS3D_RETURN_IF_LAUNCH_FAILED();

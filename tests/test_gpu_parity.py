@@ -1204,7 +1204,7 @@ def _subm_frame(n_points, seed, level_strides=0):
     return coords, orc.spatial_shape(cfg["voxel_size"], cfg["pc_range"])
 
 
-@pytest.mark.parametrize("cin,cout,products", [(128, 128, 8), (64, 64, 8), (32, 32, 8), (256, 128, 6), (48, 96, 8)])
+@pytest.mark.parametrize("cin,cout,products", [(128, 128, 8), (64, 64, 8), (32, 32, 8), (256, 128, 6), (48, 96, 8), (128, 128, 6), (64, 64, 6)])
 def test_tile_conv_full_size_vs_gather_gemm_and_float64(cin, cout, products):
     """SubM table of a 120k-point frame's stride-2 sites (the level the 64-channel layers run on): tile-halo convolution vs the
     exact-f32 gather-GEMM (f32 summation-order noise) and both vs a float64 evaluation on the device; fused epilogue; bit-reproducible"""
@@ -1246,10 +1246,13 @@ def test_tile_conv_full_size_vs_gather_gemm_and_float64(cin, cout, products):
     # without the swizzle and in plan order; a split tail changes only its own tiles' rows, by f32 rounding of two partial sums
     NEVER = 1 << 6
     try:
-        for fl, pf in ((NEVER, 0), (1 << 30, 0), (0, 1)):
+        # ... and with the plain offset loop (bit 0) / the general epilogue (bit 1) instead of the pipelined loop / single-pass epilogue
+        for fl, pf in ((NEVER, 0), (1 << 30, 0), (0, 1), (1, 0), (2, 0), (3, 0)):
             ops.set_tile_flags(conv=fl, plan=pf)
             pl = plan if pf == 0 else ops.tile_plan(tbl, c2, oshape, 1)
             assert torch.equal(ops.tile_conv(x, pw, pl, cout=cout, products=products), got), (fl, pf)
+            if pf == 0:
+                assert torch.equal(ops.tile_conv(x, pw, pl, cout=cout, products=products, scale=scale, shift=shift, res_pre=res, relu=True), fused), fl
         if cin >= 64:
             ops.set_tile_flags(conv=(256 + 1) << 20, plan=0)  # the 256 tiles at the end of the dispatch order in two units each
             tail = ops.tile_conv(x, pw, plan, cout=cout, products=products)

@@ -1042,10 +1042,20 @@ def test_tile_conv_flags_and_channel_splits_are_bit_identical_where_they_must_be
     assert torch.equal(two[keep_rows], base[keep_rows]) and torch.equal(two[split_rows], allsplit[split_rows])
     if cin >= 128:
         assert not torch.equal(allsplit, base)                  # the split really happened
+    pair = T(rng.normal(size=(vout, 2 * cout)).astype(np.float32))
     for fl in (0, NEVER):
         a = run(fl, scale=scale, shift=shift, res_pre=res, relu=True)[0]
         np.testing.assert_allclose(a.numpy(), np.maximum((allsplit if fl != NEVER else base).numpy() * scale.numpy() + shift.numpy() + res.numpy(), 0),
                                    rtol=0, atol=1e-5)
+        # flags bit 1: the general two-pass epilogue instead of the tile kernel's single-pass one - the same arithmetic per element
+        assert torch.equal(run(fl | 2, scale=scale, shift=shift, res_pre=res, relu=True)[0], a)
+        b = run(fl, scale=scale, shift=shift, relu=True, pair=pair)[0]
+        assert torch.equal(run(fl | 2, scale=scale, shift=shift, relu=True, pair=pair)[0], b)
+        want = np.maximum((allsplit if fl != NEVER else base).numpy() * scale.numpy() + shift.numpy(), 0) + pair.numpy()[:, 0::2] + pair.numpy()[:, 1::2]
+        np.testing.assert_allclose(b.numpy(), want, rtol=0, atol=1e-5)
+    assert torch.equal(run(NEVER | 2)[0], base)
+    # flags bit 0: the plain offset loop instead of the software-pipelined one (6 products, cout > 32): the same products in the same order
+    assert torch.equal(run(NEVER | 1)[0], base) and torch.equal(run(1)[0], allsplit)
 
 
 def test_tile_conv_any_row_order_gives_the_same_rows():
