@@ -7,6 +7,7 @@ and the `indice_key` rulebook sharing are kept so that model code written agains
 checkpoints work unchanged; the arithmetic is the output-stationary gather-GEMM of csrc/spconv.hip over the
 output-major rulebooks of csrc/rulebook.hip (semantics: SURVEY.md §2.3)."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -18,6 +19,13 @@ from .packing import PackedModule, pack_spconv
 
 def _triple(v):
     return tuple(int(x) for x in v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+# mask-sorted row order (ops.rulebook_order) for the gather-GEMM layers with cin * cout >= this: only where the matrix work repays the
+# sort (>= 64 x 64 channels).  tools/bench_layers.py: sorted, the 32 -> 64 / 64 -> 32 strided layers of the 120k frame take 61 / 44 us
+# instead of 124 / 87 (~4 offsets per tile instead of ~27), but their two extra 4-pass sorts sit on the geometry stream in front of
+# the level-2 plan and the frame does not get shorter (LS3D_ORDER_MIN_CC=0: 6.08 vs 6.08 ms of convolutions) - left off.
+ORDER_MIN_CC = int(os.environ.get("LS3D_ORDER_MIN_CC", "4096"))
 
 
 class SparseConvTensor(object):
@@ -97,7 +105,7 @@ class _SparseConvFn(torch.autograd.Function):
         cin, cout = weight.shape[-2], weight.shape[-1]
         W = pack_spconv(weight)[0]
         tbl = rb.tbl_inv if inverse else rb.tbl
-        order = rb.order(inverse) if cin * cout >= 4096 else None
+        order = rb.order(inverse) if cin * cout >= ORDER_MIN_CC else None
         x = feats.detach().contiguous()
         if x.shape[1] != W.shape[1]:
             x = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1]))
@@ -125,10 +133,10 @@ class _SparseConvFn(torch.autograd.Function):
                 wd = wd.flip(0)  # input i sees output o through the mirrored offset
             Wd = PackedWeight(wd.contiguous(), kvol, cout, _pad16(cout), cin)
             if subm:
-                tbl_t, order_t = rb.tbl, (rb.order(False) if cin * cout >= 4096 else None)
+                tbl_t, order_t = rb.tbl, (rb.order(False) if cin * cout >= ORDER_MIN_CC else None)
             else:
                 tbl_t = rb.tbl if inverse else rb.tbl_inv
-                order_t = rb.order(not inverse) if cin * cout >= 4096 else None
+                order_t = rb.order(not inverse) if cin * cout >= ORDER_MIN_CC else None
             g = gout
             if g.shape[1] != Wd.shape[1]:
                 g = torch.nn.functional.pad(g, (0, Wd.shape[1] - g.shape[1]))
@@ -138,7 +146,7 @@ class _SparseConvFn(torch.autograd.Function):
                 gin = ops.gather_gemm(g, Wd, tbl=tbl_t, order=order_t, cout=cin)
         if ctx.needs_input_grad[1]:
             tbl = rb.tbl_inv if inverse else rb.tbl
-            order = rb.order(inverse) if cin * cout >= 4096 else None
+            order = rb.order(inverse) if cin * cout >= ORDER_MIN_CC else None
             gw = ops.spconv_wgrad(feats.detach().contiguous(), gout, tbl, order, cin, cout).reshape(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(0)
@@ -233,7 +241,7 @@ class SparseConvolution(PackedModule, SparseModule):
             return ops.tile_conv(feats.contiguous(), W, rb.tile_plan(bool(self.inverse)), cout=cout, scale=scale, shift=shift, relu=relu,
                                  res_pre=res_pre, pair=pair, out=out, out_ld=out_ld)
         # mask-sorted processing order only for the layers whose matrix work can repay the sort (>= 64x64 channels)
-        order = rb.order(self.inverse) if self.in_channels * self.out_channels >= 4096 else None
+        order = rb.order(self.inverse) if self.in_channels * self.out_channels >= ORDER_MIN_CC else None
         return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, order=order, cout=cout, scale=scale, shift=shift, relu=relu,
                                res_pre=res_pre, pair=pair, out=out, out_ld=out_ld, n_dev=rb.rows_dev(bool(self.inverse)))
 
@@ -277,7 +285,7 @@ def prebuild_orders(x, layers):
                         m.out_channels):
             rb.tile_plan(bool(m.inverse))
             continue
-        if m.in_channels * m.out_channels < 4096:
+        if m.in_channels * m.out_channels < ORDER_MIN_CC:
             continue
         if rb._orders is None:
             rb._orders = {}
