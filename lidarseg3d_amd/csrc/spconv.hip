@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, (NT == 1 && WC == 1) ? 5 : (NT == 2 && WC == 1
 //           ("bf16x6": dropped terms 2^-24 relative, i.e. the size of an f32 rounding error) = f32-grade results at
 //           6 x 32 MFMA cycles per K=16 instead of 8 x 64.
 template <int NT, bool SPARSE, int PL>
-__global__ __launch_bounds__(256, 2) void k_gather_gemm_bf16x3(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
+__global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather_gemm_bf16x3(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
                                                            const int32_t *__restrict__ order, int kvol, const float *__restrict__ w,
                                                            int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
                                                            float *__restrict__ out, int out_ld, int xcd_map) {
