@@ -300,12 +300,15 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
  *                    the tile's / waves' offset masks.  `plan` holds ls3d_tile_plan_bytes(n_rows, kvol) bytes, 16-byte aligned.
  *                    Deterministic.  Any table and any order are valid; only speed depends on their locality.
  *   ls3d_tile_conv_pack: plain W[kvol][cin_src][cout] f32 -> [kvol][cin_pad/16][cout32/32][plane 3][2][32] x 8 bf16
- *                    (ls3d_tile_conv_packed_bytes bytes); cout <= 128.
+ *                    (ls3d_tile_conv_packed_bytes bytes); more than 128 output columns: slab after slab of 128 columns, each in
+ *                    that layout.
  *   ls3d_tile_conv : out[r, 0..cout) = epilogue(sum_k W[k]^T in[tbl[r,k]]) for the rows of the plan.  products = 8: every
  *                    plane product except tail x tail (2^-32 relative) — f32-grade: the result differs from exact f32
  *                    arithmetic by less than f32 summation-order noise; products = 6: the BF16X6 arithmetic; products = 1: plain
  *                    bf16 operands (the head plane of both), f32 accumulation - NOT f32-grade (BASELINE configs[4]).
- *                    cin % 16 == 0, in_ld % 4 == 0, cout <= 128.  Summation order per output row is fixed by the plan.
+ *                    cin % 16 == 0, in_ld % 4 == 0.  cout > 128 (SCALING_RATIO > 2 of scn_unet.py:88-123): one launch per slab of
+ *                    128 columns on the same plan, workspace and counters (no LayerNorm epilogue then: LS3D_ERR_UNSUPPORTED).
+ *                    Summation order per output row is fixed by the plan.
  *                    Workgroups are dispatched in the plan's most-expensive-tile-first order (ls3d_tile_build's last step).
  *                    workspace (optional, ls3d_tile_conv_workspace_bytes(n_rows, cout) bytes, 16-byte aligned, per call) +
  *                    counters (optional, ls3d_tile_conv_counter_bytes() bytes): let layers of cin >= 64 in launches of <= 512
@@ -364,7 +367,8 @@ int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int
  *   grad_in : ls3d_gather_gemm on grad_out with the TRANSPOSED table (SubM: the same table; SparseConv3d: nbr_inv;
  *             SparseInverseConv3d: nbr_out) and weights W'[k] = W[k]^T (SubM: W'[k] = W[kvol-1-k]^T) - no extra entry point;
  *   grad_w  : grad_w[k][ci][co] = sum over rows o with tbl[o][k] >= 0 of in[tbl[o][k]][ci] * grad_out[o][co], tbl = the table
- *             the FORWARD launch used, plain [kvol][cin][cout] layout (the layout of the module's weight), cout <= 128.
+ *             the FORWARD launch used, plain [kvol][cin][cout] layout (the layout of the module's weight); any cout (slabs of 128
+ *             columns of grad_out over one transposed table).
  * Deterministic (fixed summation order).  products: 0 = exact f32 MFMA (two rows per v_mfma_f32_32x32x2_f32); 6 | 8 = the exact 3-plane
  * bf16 split of both operands (16 rows per v_mfma_f32_32x32x16_bf16, operands transposed through LDS, head x head in its own accumulator):
  * f32-grade like ls3d_tile_conv; used for layers with >= 8 output blocks of 32 x 32, narrower ones run the exact-f32 kernel either way. */

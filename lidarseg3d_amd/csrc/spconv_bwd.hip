@@ -301,11 +301,12 @@ __global__ __launch_bounds__(256, 2) void k_spconv_wgrad_lds(const float *__rest
   }
 }
 
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *partial, int nchunks, long long elems, float *gw) {
+// sum of the row chunks' partial gradients [chunk][kvol * cin][cw] -> columns [col0, col0 + cw) of gw[kvol * cin][cout]
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *partial, int nchunks, long long elems, int cw, int cout, int col0, float *gw) {
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < elems; t += (long long)gridDim.x * blockDim.x) {
     float s = 0.0f;
     for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * elems + t];
-    gw[t] = s;
+    gw[(t / cw) * cout + col0 + (t % cw)] = s;
   }
 }
 
@@ -327,6 +328,7 @@ static inline int wg_chunks(int n_rows, int kvol, int cin) {
 
 static inline size_t wg_align(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t ls3d_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout, int n_rows) {
+  if (cout > 128) cout = 128;  // wider layers run in slabs of 128 output columns through the same partial-sum buffer
   return wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cout * sizeof(float)) + wg_align((size_t)(kvol + 1) * (n_rows > 0 ? n_rows : 1) * 4) + 256;
 }
 
@@ -334,13 +336,12 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
                                  int kvol, int cin, int cout, int n_rows, const int32_t *n_rows_dev, int products, void *workspace,
                                  size_t workspace_bytes, float *grad_w, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (n_rows == 0 && grad_w && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128) {  // empty tensors have no storage: the gradient is zero
+  if (n_rows == 0 && grad_w && kvol >= 1 && cin >= 1 && cout >= 1) {  // empty tensors have no storage: the gradient is zero
     hipMemsetAsync(grad_w, 0, (size_t)kvol * cin * cout * sizeof(float), stream);
     return LS3D_OK;
   }
   if (!in || !grad_out || !tbl || !grad_w || !workspace || kvol < 1 || cin < 1 || cout < 1 || n_rows < 0) return LS3D_ERR_ARG;
   if (in_ld < cin || go_ld < cout) return LS3D_ERR_ARG;
-  if (cout > 128) return LS3D_ERR_UNSUPPORTED;
   if (products != 0 && products != 6 && products != 8) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_spconv_wgrad_workspace_bytes(kvol, cin, cout, n_rows)) return LS3D_ERR_WORKSPACE;
   const long long elems = (long long)kvol * cin * cout;
@@ -350,11 +351,21 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
   }
   const int nchunks = wg_chunks(n_rows, kvol, cin);
   float *partial = (float *)workspace;
-  int32_t *tbl_t = (int32_t *)((char *)workspace + wg_align((size_t)nchunks * kvol * cin * cout * sizeof(float)));
+  const int cout_all = cout, cw_max = cout < 128 ? cout : 128;
+  int32_t *tbl_t = (int32_t *)((char *)workspace + wg_align((size_t)nchunks * kvol * cin * cw_max * sizeof(float)));
   int32_t *o_t = tbl_t + (size_t)kvol * n_rows;
   hipLaunchKernelGGL(k_tbl_transpose, ls3d_grid((long long)n_rows * kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, tbl_t, o_t);
   const dim3 grid((unsigned)(nchunks * wg_ci_groups(cin)), (unsigned)kvol);
   const dim3 grid_lds((unsigned)(nchunks * ((cin + 127) / 128)), (unsigned)kvol);  // k_spconv_wgrad_lds: tiles of 128 input channels
+  const int products_all = products;
+  const float *grad_out_all = grad_out;
+  // layers wider than 128 output columns (SCALING_RATIO > 2 of the reference's UNet): one pass per slab of 128 columns of grad_out over
+  // the same transposed table; every pass reduces its chunks' partial sums into its columns of grad_w
+  for (int col0 = 0; col0 < cout_all; col0 += 128) {
+  cout = cout_all - col0 < 128 ? cout_all - col0 : 128;
+  grad_out = grad_out_all + col0;
+  products = products_all;
+  const long long elems = (long long)kvol * cin * cout;
   const int cob = (cout + 31) / 32;
 #define LS3D_WG(COB_) hipLaunchKernelGGL((k_spconv_wgrad<COB_>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, (const int32_t *)tbl_t, \
                                           (const int32_t *)o_t, kvol, cin, cout, n_rows, n_rows_dev, nchunks, partial)
@@ -375,7 +386,8 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
                        cin, cout, n_rows, n_rows_dev, nchunks, partial);
   }
 #undef LS3D_WG
-  hipLaunchKernelGGL(k_wgrad_reduce, ls3d_grid(elems), dim3(256), 0, stream, (const float *)partial, nchunks, elems, grad_w);
+  hipLaunchKernelGGL(k_wgrad_reduce, ls3d_grid(elems), dim3(256), 0, stream, (const float *)partial, nchunks, elems, cout, cout_all, col0, grad_w);
+  }
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

@@ -366,7 +366,7 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
 // weights: plain [kvol][cin_src][cout] f32 -> [kvol][cin_pad/16][nt][plane 3][kk 2][col 32] x (8 bf16), the exact 3-way split
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src, int kvol, int cin_src, int cin_pad, int cout, int nt,
-                                                   int trunc_split, uint4 *__restrict__ dst) {
+                                                   int trunc_split, int col0, int cout_all, uint4 *__restrict__ dst) {
   const int nchunk = cin_pad / 16;
   const long long total = (long long)kvol * nchunk * nt * 3 * 64;
   for (long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; t_ < total; t_ += (long long)gridDim.x * blockDim.x) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src
 #pragma unroll
       for (int e2 = 0; e2 < 2; ++e2) {
         const int c = ch * 16 + kk * 8 + pr * 2 + e2;
-        const float v = (c < cin_src && oc < cout) ? src[((size_t)k * cin_src + c) * cout + oc] : 0.0f;
+        const float v = (c < cin_src && oc < cout) ? src[((size_t)k * cin_src + c) * cout_all + col0 + oc] : 0.0f;
         // round-to-nearest planes (v = h + m + l exactly, as for the activations): the remainders carry no sign bias, so the
         // products a mode leaves out (bf16x6: a_m w_l + a_l w_m, weight 2^-24) are zero-mean
         const unsigned hb = trunc_split ? (__float_as_uint(v) & 0xFFFF0000u) : (ls3d_bf16_rne(v) << 16);
@@ -401,17 +401,26 @@ __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src
   }
 }
 
+// layers of more than 128 output columns (SCALING_RATIO > 2 of the reference's UNet) are slabs of <= 128 columns: packed slab after
+// slab, convolved launch after launch on the same plan
+static inline size_t tc_slab_packed_bytes(int kvol, int cin_pad, int cw) { return (size_t)kvol * cin_pad * (cw <= 32 ? 32 : cw <= 64 ? 64 : 128) * 6; }
 extern "C" size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout) {
-  return (size_t)kvol * cin_pad * (cout <= 32 ? 32 : cout <= 64 ? 64 : 128) * 6;
+  size_t b = 0;
+  for (int col0 = 0; col0 < cout; col0 += 128) b += tc_slab_packed_bytes(kvol, cin_pad, cout - col0 < 128 ? cout - col0 : 128);
+  return b;
 }
 
 extern "C" int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream) {
   if (!w_plain || !w_packed || kvol < 1 || cin_src < 1 || cin_pad < cin_src || (cin_pad % 16) || cout < 1) return LS3D_ERR_ARG;
-  if (cout > 128) return LS3D_ERR_UNSUPPORTED;
-  const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;  // column blocks of the kernel variant that will run (zero padded)
-  const long long total = (long long)kvol * (cin_pad / 16) * nt * 3 * 64;
-  hipLaunchKernelGGL(k_tile_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cout, nt,
-                     0, (uint4 *)w_packed);
+  char *dst = (char *)w_packed;
+  for (int col0 = 0; col0 < cout; col0 += 128) {
+    const int cw = cout - col0 < 128 ? cout - col0 : 128;
+    const int nt = cw <= 32 ? 1 : cw <= 64 ? 2 : 4;  // column blocks of the kernel variant that will run (zero padded)
+    const long long total = (long long)kvol * (cin_pad / 16) * nt * 3 * 64;
+    hipLaunchKernelGGL(k_tile_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cw, nt, 0, col0, cout,
+                       (uint4 *)dst);
+    dst += tc_slab_packed_bytes(kvol, cin_pad, cw);
+  }
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
@@ -917,7 +926,8 @@ constexpr int TC_SPLIT_MAX = 512;       // = the chip's workgroup slots for this
 static inline size_t tc_partial_bytes(int n_split, int nt) { return tc_align((size_t)n_split * 2 * nt * 16 * TC_THREADS * sizeof(float)); }
 
 extern "C" size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout) {
-  if (n_rows <= 0 || cout < 1 || cout > 128) return 0;
+  if (n_rows <= 0 || cout < 1) return 0;
+  if (cout > 128) cout = 128;  // slabs of 128 columns, one after the other through the same workspace
   const int nt = cout <= 32 ? 1 : cout <= 64 ? 2 : 4;
   const int t = (n_rows + TC_TR - 1) / TC_TR, ns = t < TC_SPLIT_MAX ? t : TC_SPLIT_MAX;
   return tc_partial_bytes(ns, nt);
@@ -931,9 +941,41 @@ static inline size_t tc_trace_bytes(int ntiles) {
 }
 extern "C" size_t ls3d_tile_conv_trace_bytes(int n_rows) { return n_rows <= 0 ? 0 : tc_trace_bytes((n_rows + TC_TR - 1) / TC_TR); }
 
+static int tc_conv_slab(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout, int products,
+                        const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, int32_t *counters, int flags,
+                        ls3d_stream_t stream_);
+
 extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout, int products,
                               const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, int32_t *counters, int flags,
                               ls3d_stream_t stream_) {
+  if (cout <= 128)
+    return tc_conv_slab(in, in_ld, plan, n_rows, kvol, w_packed, cin, cout, products, epi, out, out_ld, workspace, workspace_bytes, counters, flags, stream_);
+  // more than 128 output columns: one launch per slab of 128 on the same plan, workspace and counters (the launches are ordered on the
+  // stream); the epilogue operands move with the columns.  A row LayerNorm needs the whole row in one workgroup: not available here.
+  if (!w_packed || !out || cin < 16 || (cin % 16) || kvol < 1 || out_ld < cout) return LS3D_ERR_ARG;
+  if (epi && epi->ln_gamma) return LS3D_ERR_UNSUPPORTED;
+  const char *wp = (const char *)w_packed;
+  for (int col0 = 0; col0 < cout; col0 += 128) {
+    const int cw = cout - col0 < 128 ? cout - col0 : 128;
+    ls3d_epilogue_t e2;
+    if (epi) {
+      e2 = *epi;
+      if (e2.scale) e2.scale += col0;
+      if (e2.shift) e2.shift += col0;
+      if (e2.res_pre) e2.res_pre += col0;
+      if (e2.pair) e2.pair += 2 * col0;
+    }
+    const int rc = tc_conv_slab(in, in_ld, plan, n_rows, kvol, wp, cin, cw, products, epi ? &e2 : nullptr, out + col0, out_ld, workspace, workspace_bytes,
+                                counters, flags, stream_);
+    if (rc != LS3D_OK) return rc;
+    wp += tc_slab_packed_bytes(kvol, cin, cw);
+  }
+  return LS3D_OK;
+}
+
+static int tc_conv_slab(const float *in, int in_ld, const void *plan, int n_rows, int kvol, const void *w_packed, int cin, int cout, int products,
+                        const ls3d_epilogue_t *epi, float *out, int out_ld, void *workspace, size_t workspace_bytes, int32_t *counters, int flags,
+                        ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rows == 0 && w_packed && kvol >= 1 && kvol <= TC_KMAX && cin >= 16 && !(cin % 16) && cout >= 1 && cout <= 128 && (products == 1 || products == 6 || products == 8))
     return LS3D_OK;

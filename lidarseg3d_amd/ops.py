@@ -569,8 +569,7 @@ def tile_products():
 
 
 def use_tile(kind, kvol, cin, cout):
-    return tile_products() != 0 and kind in _TILE_KINDS.split(",") and kvol <= 32 and cout <= 128 and cin % 16 == 0 \
-        and cin * cout >= _TILE_MIN_CC
+    return tile_products() != 0 and kind in _TILE_KINDS.split(",") and kvol <= 32 and cin % 16 == 0 and cin * cout >= _TILE_MIN_CC
 
 
 class TilePlan(object):

@@ -743,7 +743,7 @@ def _spconv_ref(feats, w, tbl, reverse=False):
     return out
 
 
-@pytest.mark.parametrize("cin,cout,products", [(128, 128, 6), (128, 128, 8), (64, 128, 6), (256, 128, 6), (32, 32, 6)])
+@pytest.mark.parametrize("cin,cout,products", [(128, 128, 6), (128, 128, 8), (64, 128, 6), (256, 128, 6), (32, 32, 6), (128, 256, 6)])
 def test_wgrad_on_bf16_planes_is_f32_grade_gpu(cin, cout, products):
     """ls3d_spconv_wgrad on the exact 3-plane bf16 split against float64 at a real size (60k rows, SubM-like density): error not above
     the exact-f32 kernel's, bitwise reproducible"""
@@ -1204,7 +1204,7 @@ def _subm_frame(n_points, seed, level_strides=0):
     return coords, orc.spatial_shape(cfg["voxel_size"], cfg["pc_range"])
 
 
-@pytest.mark.parametrize("cin,cout,products", [(128, 128, 8), (64, 64, 8), (32, 32, 8), (256, 128, 6), (48, 96, 8), (128, 128, 6), (64, 64, 6)])
+@pytest.mark.parametrize("cin,cout,products", [(128, 128, 8), (64, 64, 8), (32, 32, 8), (256, 128, 6), (48, 96, 8), (128, 128, 6), (64, 64, 6), (64, 256, 6)])
 def test_tile_conv_full_size_vs_gather_gemm_and_float64(cin, cout, products):
     """SubM table of a 120k-point frame's stride-2 sites (the level the 64-channel layers run on): tile-halo convolution vs the
     exact-f32 gather-GEMM (f32 summation-order noise) and both vs a float64 evaluation on the device; fused epilogue; bit-reproducible"""

@@ -511,7 +511,7 @@ def _spconv_ref(feats, w, tbl):
     return out
 
 
-@pytest.mark.parametrize("cin,cout,products", [(64, 128, 6), (128, 64, 8), (32, 32, 6), (96, 48, 6), (16, 16, 8), (160, 64, 6)])
+@pytest.mark.parametrize("cin,cout,products", [(64, 128, 6), (128, 64, 8), (32, 32, 6), (96, 48, 6), (16, 16, 8), (160, 64, 6), (32, 160, 6), (16, 288, 6)])
 def test_wgrad_on_bf16_planes_is_f32_grade(cin, cout, products):
     """ls3d_spconv_wgrad with the exact 3-plane split (16 rows per bf16 MFMA, head x head in its own accumulator) against float64:
     not worse than the exact-f32 kernel (up to the emulation's per-product rounding), ragged row counts, absent neighbours"""
@@ -539,16 +539,18 @@ def test_wgrad_on_bf16_planes_is_f32_grade(cin, cout, products):
     assert err["planes"] <= 4 * err["f32"] + 2.0 ** -22 and err["planes_ordered"] <= 4 * err["f32"] + 2.0 ** -22, err
 
 
-def test_subm_training_path_on_the_tile_kernel():
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 160), (160, 32)])
+def test_subm_training_path_on_the_tile_kernel(cin, cout):
     """training forward and dgrad of a SubM layer in the 3-plane mode (tile-halo kernel, same plan for both) == the exact-f32
-    gather-GEMM path to f32 rounding"""
+    gather-GEMM path to f32 rounding; also with more than 128 channels on either side (slabs of 128 columns in the forward, the
+    dgrad and the weight gradient: SCALING_RATIO > 2 of the reference's UNet)"""
     from lidarseg3d_amd import spconv
     rng = np.random.default_rng(3)
     shape = [9, 24, 24]
     cells = rng.choice(shape[0] * shape[1] * shape[2], size=300, replace=False)
     coords = torch.from_numpy(np.stack([np.zeros_like(cells), cells // (24 * 24), (cells // 24) % 24, cells % 24], 1).astype(np.int32))
-    conv = spconv.SubMConv3d(64, 32, 3, padding=1, bias=True, indice_key="s").train()
-    feats0 = torch.from_numpy(rng.normal(size=(300, 64)).astype(np.float32))
+    conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=True, indice_key="s").train()
+    feats0 = torch.from_numpy(rng.normal(size=(300, cin)).astype(np.float32))
     res = {}
     try:
         for prec in ("f32", "bf16x6"):
@@ -1056,6 +1058,35 @@ def test_tile_conv_flags_and_channel_splits_are_bit_identical_where_they_must_be
     assert torch.equal(run(NEVER | 2)[0], base)
     # flags bit 0: the plain offset loop instead of the software-pipelined one (6 products, cout > 32): the same products in the same order
     assert torch.equal(run(NEVER | 1)[0], base) and torch.equal(run(1)[0], allsplit)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 160), (16, 288)])
+def test_tile_conv_more_than_128_output_columns(cin, cout):
+    """cout > 128 (SCALING_RATIO > 2 of the reference's UNet): slabs of 128 columns on one plan, fused epilogue operands moving with
+    the columns; == the gather-GEMM (which has no such limit) to f32 rounding, and the float64 sum"""
+    rng = np.random.default_rng(cout)
+    vin, vout, kvol = 150, 170, 27
+    x = rng.normal(size=(vin, cin)).astype(np.float32)
+    w = rng.normal(size=(kvol, cin, cout)).astype(np.float32) * 0.1
+    tbl = (np.arange(vout)[:, None] * vin // vout + rng.integers(-20, 20, size=(vout, kvol))).clip(0, vin - 1).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.5] = -1
+    T = torch.from_numpy
+    pw = PackedWeight(T(w), kvol, cin, cin, cout)
+    coords = T(np.stack([np.zeros(vout), np.zeros(vout), np.arange(vout) // 16, np.arange(vout) % 16], 1).astype(np.int32))
+    scale, shift = T(rng.uniform(0.5, 1.5, cout).astype(np.float32)), T(rng.normal(size=cout).astype(np.float32))
+    res, pair = T(rng.normal(size=(vout, cout)).astype(np.float32)), T(rng.normal(size=(vout, 2 * cout)).astype(np.float32))
+    plan = ops.tile_plan(T(tbl), coords, (1, 16, 16), 1)
+    want = _sparse_ref(x, w, tbl)
+    for products in (6, 8):
+        got = ops.tile_conv(T(x), pw, plan, cout=cout, products=products)
+        np.testing.assert_allclose(got.numpy(), want, rtol=0, atol=2e-4)
+    a = ops.tile_conv(T(x), pw, plan, cout=cout, products=6, scale=scale, shift=shift, res_pre=res, relu=True).numpy()
+    np.testing.assert_allclose(a, np.maximum(got.numpy() * 0 + ops.tile_conv(T(x), pw, plan, cout=cout, products=6).numpy() * scale.numpy() + shift.numpy() + res.numpy(), 0),
+                               rtol=0, atol=1e-5)
+    b = ops.tile_conv(T(x), pw, plan, cout=cout, products=6, pair=pair).numpy()
+    np.testing.assert_allclose(b, ops.tile_conv(T(x), pw, plan, cout=cout, products=6).numpy() + pair.numpy()[:, 0::2] + pair.numpy()[:, 1::2], rtol=0, atol=1e-5)
+    gg = ops.gather_gemm(T(x), pw, tbl=T(tbl), cout=cout).numpy()
+    np.testing.assert_allclose(got.numpy(), gg, rtol=0, atol=2e-5 * float(np.abs(gg).max()))
 
 
 def test_tile_conv_any_row_order_gives_the_same_rows():

@@ -29,4 +29,8 @@ for d in $RAW/pmc_*; do f=$(find $d -name 'bench_counter_collection.csv' | head 
 cd "$R"
 LS3D_PROFILE_OUT=$P3 python profiles/summarize_pmc.py $RAW 3 "${COMMIT:-unknown}" > $P3/summarize.log 2>&1
 echo "summarize rc=$?" >> $P3/summary.txt
+# in-kernel trace of the tile kernel and the per-launch table (tools/trace_tile.py, tools/bench_layers.py)
+timeout 300 python tools/trace_tile.py --flags 0 --out $P3/round3_trace_tile_pipelined > $P3/round3_trace_tile_pipelined.txt 2>&1
+rm -f $P3/round3_trace_tile_pipelined_flags0.npz
+timeout 300 python tools/bench_layers.py --out $P3/round3_layers.json > $P3/round3_layers.txt 2>&1
 cat $P3/summary.txt; tail -30 $P3/summarize.log
