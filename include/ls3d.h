@@ -517,6 +517,21 @@ int ls3d_points_cp(const float *points, int pt_stride, int xyz_col, int n, const
  * points_cp is expected in the coordinates of the res_h x res_w feature-map input. */
 int ls3d_points_cuv(const float *points_cp, int n, int ncam, int res_h, int res_w, float *points_cuv, ls3d_stream_t stream);
 
+/* Segmentation loss of the point heads: cross entropy with an ignored label + Lovasz-Softmax over the classes present, forward and
+ * backward (det3d/core/utils/loss_utils.py:217-291 lovasz_softmax(classes='present', ignore) + F.cross_entropy(ignore_index), as
+ * point_seg_batchloss_head.py:77-121 / point_seg_mseg3d_head.py:137 call them on flat [P, C] logits).  One softmax pass, ONE batched
+ * radix sort of the C x P class errors, per-class scans; no host synchronisation, deterministic.  num_classes <= 32.
+ *   forward : out2[0] = mean_i(-log softmax(logits_i)[label_i]) over label_i != ignore_index (nan when there is none, as torch),
+ *             out2[1] = mean over the classes c present of sum_j e_(j) g_j, e = |[label == c] - softmax_c| sorted descending, g = the
+ *             increments of the Jaccard index (Lovasz gradient); the workspace keeps what the backward needs.
+ *   backward: grad_logits[P, ld] = grad_ce * d ce / d logits + grad_lovasz * d lovasz / d logits (device scalars; NULL = 1), from the
+ *             workspace the forward filled for the SAME logits / labels. */
+size_t ls3d_seg_loss_workspace_bytes(int n_points, int num_classes);
+int ls3d_seg_loss_forward(const float *logits, int ld, const int32_t *labels, int n_points, int num_classes, int ignore_index, void *workspace,
+                          size_t workspace_bytes, float *out2, ls3d_stream_t stream);
+int ls3d_seg_loss_backward(const int32_t *labels, int n_points, int num_classes, int ignore_index, const void *workspace, size_t workspace_bytes,
+                           const float *grad_ce, const float *grad_lovasz, float *grad_logits, int ld, ls3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,317 @@
+// loss.hip — the segmentation loss of the point heads as a handful of launches: cross entropy with an ignored label + Lovasz-Softmax
+// (Berman, Triki, Blaschko, CVPR 2018, Alg. 1), forward and backward.
+//
+// Reference: det3d/core/utils/loss_utils.py:217-291 (lovasz_softmax / lovasz_softmax_flat / lovasz_grad, classes = 'present') as
+// point_seg_batchloss_head.py:77-121 and point_seg_mseg3d_head.py:137 apply it to flat [P, C] predictions, beside
+// F.cross_entropy(ignore_index).  The reference (and round 2's torch restatement) walks the classes in a Python loop: per class a
+// boolean mask, a host-synchronising `fg.sum() == 0` test, a sort of P errors, a cumsum and a dot product - 23 sorts and 23 host
+// round trips per prediction level of the Waymo configuration.  Here:
+//   k_loss_prep   softmax of every point once; per point the CE term and, for every class c, the sort key of its error
+//                 e = |[label == c] - p_c| (descending order = ascending order of the complemented f32 bits; ignored points get the
+//                 largest key and sort last, where they change nothing); label histogram;
+//   one batched radix sort of the C segments of P keys (sort.hip, 4 passes = 8 launches for all classes);
+//   k_lv_blocksum / k_lv_scanblocks / k_lv_grad   per class the running count of foreground points in error order -> intersection,
+//                 union, Jaccard index and its increments g_j (the Lovasz gradient), the class's loss sum_j e_j g_j, and
+//                 d loss / d p[i, c] = +-g_rank(i,c) scattered back to the points;
+//   k_loss_final  CE mean over the non-ignored points, Lovasz mean over the classes present; fixed summation orders.
+//   k_loss_bwd    (backward) d logits = g_ce (p - onehot) / n_valid + softmax backward of the Lovasz factors, in one pass.
+// No host synchronisation, no atomics on floating-point values: results are bit-reproducible.
+#include "common.h"
+
+constexpr int LS_MAXC = 32;   // classes
+constexpr int LS_BLK = 1024;  // sorted elements per block in the scan kernels
+
+int ls3d_radix_sort_batched(const uint32_t *keys_in, int n, int batch, int bits, uint32_t *keys_out, int32_t *vals_out, uint32_t *tmp_keys,
+                            int32_t *tmp_vals, int32_t *hist, hipStream_t stream);
+size_t ls3d_rs_batched_hist_ints(int n);
+
+struct LossWs {
+  float *probs;       // [P][C]
+  float *gp;          // [P][C]  d lovasz_sum / d p (before the 1 / n_present)
+  uint32_t *keys;     // [C][P]
+  uint32_t *skeys;    // [C][P]  sorted
+  int32_t *perm;      // [C][P]  point of each sorted position
+  uint32_t *tkeys;    // [C][P]  sort ping-pong
+  int32_t *tvals;     // [C][P]
+  int32_t *hist;      // sort histograms
+  float *ce_part;     // [nb1]   per-block CE sums
+  int32_t *counts;    // [0] = valid points, [1 + c] = points of class c
+  int32_t *bsum;      // [C][nb2] foreground points per block of the sorted order, then their exclusive scan
+  float *lpart;       // [C][nb2] loss partial sums
+  float *meta;        // [0] = n_valid, [1] = n_present (floats, for the backward)
+};
+
+static inline size_t ls_al(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline int ls_nb1(int P) { return (P + 255) / 256; }
+static inline int ls_nb2(int P) { return (P + LS_BLK - 1) / LS_BLK; }
+
+static size_t ls_layout(void *base, int P, int C, LossWs *w) {
+  char *b = (char *)base;
+  size_t off = 0;
+  const size_t pc = (size_t)P * C;
+#define LS_TAKE(field, type, count)            \
+  if (w) w->field = (type *)(b + off);         \
+  off += ls_al((size_t)(count) * sizeof(type));
+  LS_TAKE(probs, float, pc)
+  LS_TAKE(gp, float, pc)
+  LS_TAKE(keys, uint32_t, pc)
+  LS_TAKE(skeys, uint32_t, pc)
+  LS_TAKE(perm, int32_t, pc)
+  LS_TAKE(tkeys, uint32_t, pc)
+  LS_TAKE(tvals, int32_t, pc)
+  LS_TAKE(hist, int32_t, (size_t)C * ls3d_rs_batched_hist_ints(P))
+  LS_TAKE(ce_part, float, ls_nb1(P))
+  LS_TAKE(counts, int32_t, 1 + LS_MAXC)
+  LS_TAKE(bsum, int32_t, (size_t)C * ls_nb2(P))
+  LS_TAKE(lpart, float, (size_t)C * ls_nb2(P))
+  LS_TAKE(meta, float, 4)
+#undef LS_TAKE
+  return off;
+}
+
+extern "C" size_t ls3d_seg_loss_workspace_bytes(int n_points, int num_classes) {
+  if (n_points <= 0 || num_classes < 1 || num_classes > LS_MAXC) return 0;
+  return ls_layout(nullptr, n_points, num_classes, nullptr);
+}
+
+__global__ __launch_bounds__(256) void k_loss_prep(const float *__restrict__ logits, int ld, const int32_t *__restrict__ labels, int P, int C, int ignore,
+                                                   LossWs w) {
+  __shared__ float s_ce[256];
+  __shared__ int s_cnt[1 + LS_MAXC];
+  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  if (tid <= LS_MAXC) s_cnt[tid] = 0;
+  __syncthreads();
+  float ce = 0.0f;
+  if (i < P) {
+    const int lab = labels[i];
+    const bool valid = lab != ignore && lab >= 0 && lab < C;
+    float v[LS_MAXC];
+    float m = -3.0e38f;
+    for (int c = 0; c < C; ++c) {
+      v[c] = logits[(size_t)i * ld + c];
+      m = fmaxf(m, v[c]);
+    }
+    float sum = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      v[c] = expf(v[c] - m);
+      sum += v[c];
+    }
+    const float inv = 1.0f / sum;
+    for (int c = 0; c < C; ++c) {
+      const float p = v[c] * inv;
+      w.probs[(size_t)i * C + c] = p;
+      w.gp[(size_t)i * C + c] = 0.0f;
+      const float err = (valid && lab == c) ? 1.0f - p : p;  // |fg - p|, in [0, 1]
+      // descending errors = ascending complemented bits; ignored points: key 0xFFFFFFFF, behind every valid one
+      w.keys[(size_t)c * P + i] = valid ? ~(__float_as_uint(err) + 1u) : 0xFFFFFFFFu;
+    }
+    if (valid) {
+      ce = logf(sum) - (logits[(size_t)i * ld + lab] - m);  // -log softmax[label]
+      atomicAdd(&s_cnt[0], 1);
+      atomicAdd(&s_cnt[1 + lab], 1);
+    }
+  }
+  s_ce[tid] = ce;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {  // fixed-order tree
+    if (tid < d) s_ce[tid] += s_ce[tid + d];
+    __syncthreads();
+  }
+  if (tid == 0) w.ce_part[blockIdx.x] = s_ce[0];
+  if (tid <= C && s_cnt[tid]) atomicAdd(&w.counts[tid], s_cnt[tid]);  // integer counts: order-independent
+}
+
+// foreground flag of sorted position j of class c
+__device__ __forceinline__ int ls_fg(const LossWs &w, const int32_t *labels, int P, int c, int j) { return labels[w.perm[(size_t)c * P + j]] == c; }
+
+__global__ __launch_bounds__(256) void k_lv_blocksum(const int32_t *__restrict__ labels, int P, LossWs w, int nb2) {
+  __shared__ int s_s[256];
+  const int tid = threadIdx.x, c = blockIdx.y, b = blockIdx.x;
+  const int nvalid = w.counts[0];
+  int s = 0;
+  for (int q = 0; q < LS_BLK / 256; ++q) {
+    const int j = b * LS_BLK + q * 256 + tid;
+    if (j < nvalid) s += ls_fg(w, labels, P, c, j);
+  }
+  s_s[tid] = s;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (tid < d) s_s[tid] += s_s[tid + d];
+    __syncthreads();
+  }
+  if (tid == 0) w.bsum[(size_t)c * nb2 + b] = s_s[0];
+}
+
+// exclusive scan of a class's block sums (one workgroup per class; any number of blocks)
+__global__ __launch_bounds__(256) void k_lv_scanblocks(LossWs w, int nb2) {
+  __shared__ int s_a[256];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, c = blockIdx.x;
+  int32_t *a = w.bsum + (size_t)c * nb2;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb2; base += 256) {
+    const int v = base + tid < nb2 ? a[base + tid] : 0;
+    s_a[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int t = tid >= d ? s_a[tid - d] : 0;
+      __syncthreads();
+      s_a[tid] += t;
+      __syncthreads();
+    }
+    const int incl = s_a[tid], carry = s_carry;
+    if (base + tid < nb2) a[base + tid] = carry + incl - v;
+    __syncthreads();
+    if (tid == 255) s_carry = carry + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lv_grad(const int32_t *__restrict__ labels, int P, int C, LossWs w, int nb2) {
+  __shared__ int s_scan[256];
+  __shared__ float s_l[256];
+  const int tid = threadIdx.x, c = blockIdx.y, b = blockIdx.x;
+  const int nvalid = w.counts[0], G = w.counts[1 + c];
+  float lsum = 0.0f;
+  if (G > 0) {  // classes that are absent among the valid labels do not take part (classes = 'present')
+    // the thread's 4 CONSECUTIVE sorted positions: inclusive scan inside the thread, then across the block
+    const int j0 = b * LS_BLK + tid * 4;
+    int fg[4], run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      fg[q] = (j0 + q < nvalid) ? ls_fg(w, labels, P, c, j0 + q) : 0;
+      run += fg[q];
+    }
+    s_scan[tid] = run;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int t = tid >= d ? s_scan[tid - d] : 0;
+      __syncthreads();
+      s_scan[tid] += t;
+      __syncthreads();
+    }
+    int S = w.bsum[(size_t)c * nb2 + b] + s_scan[tid] - run;  // foreground points strictly before j0
+    const float Gf = (float)G;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + q;
+      if (j < nvalid) {
+        // Jaccard index after j + 1 positions: 1 - I / U with I = G - S (foreground points still to come), U = G + (j + 1 - S).  Its
+        // increment, in closed form instead of the difference of two nearly equal f32 quotients (the reference's jac[1:] - jac[:-1]
+        // loses ~2 % of every increment at 360k points): a foreground position leaves U and lowers I by one -> 1 / U; a background
+        // position leaves I and raises U by one -> I / (U (U - 1)); position 0 keeps the index itself.
+        S += fg[q];
+        const float I = Gf - (float)S, U = Gf + (float)(j + 1 - S);
+        const float g = j == 0 ? 1.0f - I / U : (fg[q] ? 1.0f / U : I / (U * (U - 1.0f)));
+        const uint32_t key = w.skeys[(size_t)c * P + j];
+        const float err = __uint_as_float(~key - 1u);
+        lsum += err * g;
+        w.gp[(size_t)w.perm[(size_t)c * P + j] * C + c] = fg[q] ? -g : g;  // d|fg - p| / dp = -1 for foreground, +1 otherwise
+      }
+    }
+  }
+  s_l[tid] = lsum;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (tid < d) s_l[tid] += s_l[tid + d];
+    __syncthreads();
+  }
+  if (tid == 0) w.lpart[(size_t)c * nb2 + b] = s_l[0];
+}
+
+__global__ __launch_bounds__(256) void k_loss_final(LossWs w, int P, int C, int nb1, int nb2, float *out) {
+  __shared__ float s_v[256];
+  const int tid = threadIdx.x;
+  float v = 0.0f;
+  for (int i = tid; i < nb1; i += 256) v += w.ce_part[i];
+  s_v[tid] = v;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (tid < d) s_v[tid] += s_v[tid + d];
+    __syncthreads();
+  }
+  const float ce_sum = s_v[0];
+  __syncthreads();
+  float lv = 0.0f;
+  int present = 0;
+  for (int c = 0; c < C; ++c) {  // class after class: fixed order
+    if (w.counts[1 + c] <= 0) continue;
+    float t = 0.0f;
+    for (int i = tid; i < nb2; i += 256) t += w.lpart[(size_t)c * nb2 + i];
+    s_v[tid] = t;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+      if (tid < d) s_v[tid] += s_v[tid + d];
+      __syncthreads();
+    }
+    lv += s_v[0];
+    ++present;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float nv = (float)w.counts[0];
+    out[0] = ce_sum / nv;  // no valid point: 0 / 0 = nan, as F.cross_entropy
+    out[1] = present ? lv / (float)present : 0.0f;
+    w.meta[0] = nv;
+    w.meta[1] = (float)present;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_loss_bwd(const int32_t *__restrict__ labels, int P, int C, int ignore, LossWs w, const float *g_ce, const float *g_lv,
+                                                  float *__restrict__ grad, int ld) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const int lab = labels[i];
+  const bool valid = lab != ignore && lab >= 0 && lab < C;
+  const float nv = w.meta[0], np_ = w.meta[1];
+  const float kce = valid ? (g_ce ? *g_ce : 1.0f) / nv : 0.0f;
+  const float klv = (valid && np_ > 0.0f) ? (g_lv ? *g_lv : 1.0f) / np_ : 0.0f;
+  float dot = 0.0f;
+  for (int c = 0; c < C; ++c) dot += w.gp[(size_t)i * C + c] * w.probs[(size_t)i * C + c];
+  for (int c = 0; c < C; ++c) {
+    const float p = w.probs[(size_t)i * C + c];
+    grad[(size_t)i * ld + c] = klv * p * (w.gp[(size_t)i * C + c] - dot) + kce * (p - (c == lab ? 1.0f : 0.0f));
+  }
+}
+
+extern "C" int ls3d_seg_loss_forward(const float *logits, int ld, const int32_t *labels, int n_points, int num_classes, int ignore_index, void *workspace,
+                                     size_t workspace_bytes, float *out2, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!out2 || n_points < 0 || num_classes < 1 || num_classes > LS_MAXC || ld < num_classes) return LS3D_ERR_ARG;
+  if (n_points == 0) {  // nothing to average: cross entropy nan (as torch), Lovasz 0
+    const float z[2] = {__builtin_nanf(""), 0.0f};
+    if (hipMemcpyAsync(out2, z, sizeof z, hipMemcpyHostToDevice, stream) != hipSuccess) return LS3D_ERR_LAUNCH;
+    return LS3D_OK;
+  }
+  if (!logits || !labels || !workspace) return LS3D_ERR_ARG;
+  if (workspace_bytes < ls3d_seg_loss_workspace_bytes(n_points, num_classes) || ((uintptr_t)workspace & 15)) return LS3D_ERR_WORKSPACE;
+  LossWs w;
+  ls_layout(workspace, n_points, num_classes, &w);
+  const int P = n_points, C = num_classes, nb1 = ls_nb1(P), nb2 = ls_nb2(P);
+  if (hipMemsetAsync(w.counts, 0, (1 + LS_MAXC) * sizeof(int32_t), stream) != hipSuccess) return LS3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_loss_prep, dim3(nb1), dim3(256), 0, stream, logits, ld, labels, P, C, ignore_index, w);
+  // errors lie in [0, 1]: their bits + 1 stay below 2^30, the complemented keys differ in the low 30 bits only
+  const int rc = ls3d_radix_sort_batched(w.keys, P, C, 30, w.skeys, w.perm, w.tkeys, w.tvals, w.hist, stream);
+  if (rc != LS3D_OK) return rc;
+  hipLaunchKernelGGL(k_lv_blocksum, dim3(nb2, C), dim3(256), 0, stream, labels, P, w, nb2);
+  hipLaunchKernelGGL(k_lv_scanblocks, dim3(C), dim3(256), 0, stream, w, nb2);
+  hipLaunchKernelGGL(k_lv_grad, dim3(nb2, C), dim3(256), 0, stream, labels, P, C, w, nb2);
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, stream, w, P, C, nb1, nb2, out2);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_seg_loss_backward(const int32_t *labels, int n_points, int num_classes, int ignore_index, const void *workspace, size_t workspace_bytes,
+                                      const float *grad_ce, const float *grad_lovasz, float *grad_logits, int ld, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_points == 0 && num_classes >= 1 && num_classes <= LS_MAXC) return LS3D_OK;
+  if (!labels || !workspace || !grad_logits || n_points < 0 || num_classes < 1 || num_classes > LS_MAXC || ld < num_classes) return LS3D_ERR_ARG;
+  if (workspace_bytes < ls3d_seg_loss_workspace_bytes(n_points, num_classes)) return LS3D_ERR_WORKSPACE;
+  LossWs w;
+  ls_layout(const_cast<void *>(workspace), n_points, num_classes, &w);
+  hipLaunchKernelGGL(k_loss_bwd, dim3(ls_nb1(n_points)), dim3(256), 0, stream, labels, n_points, num_classes, ignore_index, w, grad_ce, grad_lovasz,
+                     grad_logits, ld);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

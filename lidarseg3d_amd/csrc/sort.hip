@@ -17,16 +17,19 @@
 
 constexpr int RS_MAX_BLOCKS = 512;
 
-static inline int rs_epb(int n) {  // elements per block: 512, or more so that a sort never has more than RS_MAX_BLOCKS blocks
+static inline int rs_epb(int n, int max_blocks = RS_MAX_BLOCKS) {  // elements per block: 512, or more so that a sort never has more than max_blocks blocks
   int epb = 512;
-  while ((long long)epb * RS_MAX_BLOCKS < n) epb *= 2;
+  while ((long long)epb * max_blocks < n) epb *= 2;
   return epb;
 }
 
+// Batched form (ls3d_seg_loss: one segment per class): blockIdx.y = segment, `seg` elements / `hseg` histogram ints between segments.
 __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t *__restrict__ keys, int n, const int32_t *n_dev, int epb, int shift,
-                                                 int32_t *__restrict__ hist) {
+                                                 int32_t *__restrict__ hist, long long seg, int hseg) {
   __shared__ int s_h[256];
   const int tid = threadIdx.x, blk = blockIdx.x;
+  keys += (size_t)blockIdx.y * seg;
+  hist += (size_t)blockIdx.y * hseg;
   const int N = ls3d_count(n, n_dev);
   const int lo = blk * epb;
   if (lo >= N) return;
@@ -40,11 +43,16 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t *__restrict__ ke
 
 __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t *__restrict__ keys, const int32_t *__restrict__ vals, int n, const int32_t *n_dev,
                                                     int epb, int shift, const int32_t *__restrict__ hist, uint32_t *__restrict__ keys_out,
-                                                    int32_t *__restrict__ vals_out) {
+                                                    int32_t *__restrict__ vals_out, long long seg, int hseg) {
   __shared__ int s_base[256];
   __shared__ int s_tot[256];
   __shared__ int s_cnt[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+  keys += (size_t)blockIdx.y * seg;
+  if (vals) vals += (size_t)blockIdx.y * seg;
+  keys_out += (size_t)blockIdx.y * seg;
+  vals_out += (size_t)blockIdx.y * seg;
+  hist += (size_t)blockIdx.y * hseg;
   const int N = ls3d_count(n, n_dev);
   const int lo = blk * epb;
   if (lo >= N) return;
@@ -124,8 +132,38 @@ int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n
     const bool last = p == passes - 1;
     uint32_t *kdst = last && keys_out ? keys_out : kbuf[p & 1];
     int32_t *vdst = last ? vals_out : vbuf[p & 1];
-    hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, stream, ksrc, n, n_dev, epb, 8 * p, hist);
-    hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(256), 0, stream, ksrc, vsrc, n, n_dev, epb, 8 * p, (const int32_t *)hist, kdst, vdst);
+    hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, stream, ksrc, n, n_dev, epb, 8 * p, hist, 0ll, 0);
+    hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(256), 0, stream, ksrc, vsrc, n, n_dev, epb, 8 * p, (const int32_t *)hist, kdst, vdst, 0ll, 0);
+    ksrc = kdst;
+    vsrc = vdst;
+  }
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+// `batch` independent sorts of n pairs each (segment b at element offset b * n in every array), back to back in the same launches:
+// keys -> keys_out / vals_out (the sorting permutation of each segment), `tmp_keys` / `tmp_vals` = ping-pong buffers of batch * n
+// elements, `hist` = batch * rs_batched_hist_ints(n) ints.  Blocks of >= 4096 elements: every block of the scatter reads its segment's
+// whole histogram array, and with hundreds of blocks per segment times dozens of segments that read is what the pass would cost.
+constexpr int RS_BATCH_MAX_BLOCKS = 128;
+size_t ls3d_rs_batched_hist_ints(int n) { return (size_t)RS_BATCH_MAX_BLOCKS * 256; }
+int ls3d_radix_sort_batched(const uint32_t *keys_in, int n, int batch, int bits, uint32_t *keys_out, int32_t *vals_out, uint32_t *tmp_keys,
+                            int32_t *tmp_vals, int32_t *hist, hipStream_t stream) {
+  if (n <= 0 || batch <= 0) return LS3D_OK;
+  int epb = rs_epb(n, RS_BATCH_MAX_BLOCKS);
+  if (epb < 4096 && n > 4096) epb = 4096;
+  const int nb = (n + epb - 1) / epb, hseg = RS_BATCH_MAX_BLOCKS * 256;
+  const int passes = (bits + 7) / 8;
+  const uint32_t *ksrc = keys_in;
+  const int32_t *vsrc = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    // ping-pong so that the LAST pass lands in the outputs
+    const bool to_out = ((passes - 1 - p) & 1) == 0;
+    uint32_t *kdst = to_out ? keys_out : tmp_keys;
+    int32_t *vdst = to_out ? vals_out : tmp_vals;
+    hipLaunchKernelGGL(k_rs_hist, dim3(nb, batch), dim3(256), 0, stream, ksrc, n, (const int32_t *)nullptr, epb, 8 * p, hist, (long long)n, hseg);
+    hipLaunchKernelGGL(k_rs_scatter, dim3(nb, batch), dim3(256), 0, stream, ksrc, vsrc, n, (const int32_t *)nullptr, epb, 8 * p, (const int32_t *)hist, kdst,
+                       vdst, (long long)n, hseg);
     ksrc = kdst;
     vsrc = vdst;
   }

@@ -1042,3 +1042,24 @@ def points_cuv(points_cp_, ncam, res_shape):
     check(_L().ls3d_points_cuv(_ptr(points_cp_), n, int(ncam), int(res_shape[0]), int(res_shape[1]), _ptr(out), _stream(points_cp_)),
           "ls3d_points_cuv")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- segmentation loss
+def seg_loss_forward(logits, labels, ignore):
+    """(out2 = [cross entropy, Lovasz-Softmax] on the device, workspace for seg_loss_backward) of flat [P, C] f32 logits and int32 labels
+    (ls3d_seg_loss_forward)"""
+    P, C = logits.shape
+    ws = _ws(_L().ls3d_seg_loss_workspace_bytes(P, C), logits)
+    out = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    check(_L().ls3d_seg_loss_forward(_ptr(logits), logits.shape[1], _ptr(labels), P, C, int(ignore), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(out),
+                                     _stream(logits)), "ls3d_seg_loss_forward")
+    return out, ws
+
+
+def seg_loss_backward(labels, shape, ignore, ws, grad_ce, grad_lv):
+    """d (grad_ce * ce + grad_lv * lovasz) / d logits from the forward's workspace; grad_ce / grad_lv: 1-element device tensors or None (= 1)"""
+    P, C = shape
+    grad = torch.empty((P, C), dtype=torch.float32, device=labels.device)
+    check(_L().ls3d_seg_loss_backward(_ptr(labels), P, C, int(ignore), _ptr(ws), ctypes.c_size_t(ws.numel()), _vp(grad_ce), _vp(grad_lv), _ptr(grad), C,
+                                      _stream(labels)), "ls3d_seg_loss_backward")
+    return grad

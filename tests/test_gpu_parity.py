@@ -1527,3 +1527,56 @@ def test_other_backbones_conv_calls_on_device(prec):
     d = x.dense()
     i = cu(g["c00_in_idx"]).long()
     assert torch.equal(d[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]], x.features) and float(d.abs().sum()) == float(x.features.abs().sum())
+
+
+# ------------------------------------------------------------------------------------------------ fused segmentation loss, round 3
+@pytest.mark.parametrize("P,C", [(700, 17), (360000, 23), (120000, 17)])
+def test_fused_seg_loss_gpu(P, C):
+    """ls3d_seg_loss_forward / _backward on the device: the reference fixture (700 points, det3d/core/utils/loss_utils.py through
+    tests/golden/seg_loss.npz), and the Waymo / nuScenes training sizes (2 x 180k points x 23 classes, 120k x 17) against the torch
+    restatement - values, gradients, ignored points, bit-reproducible; prints the time of both"""
+    import time
+    from lidarseg3d_amd import losses
+    if P == 700:
+        g = golden("seg_loss.npz")
+        logits, labels, ignore = cu(g["logits"]), cu(g["labels"]), int(g["ignore"])
+    else:
+        gen = torch.Generator(device="cpu").manual_seed(P + C)
+        logits = (torch.randn((P, C), generator=gen) * 3).to(DEV)
+        labels = torch.randint(0, C, (P,), generator=gen).to(DEV)
+        labels[torch.rand((P,), generator=gen).to(DEV) < 0.2] = 0
+        ignore = 0
+    res, times = {}, {}
+    for name, fn in (("fused", losses.seg_loss), ("torch", losses.seg_loss_torch)):
+        for rep in range(2):
+            x = logits.clone().requires_grad_(True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ce, lv = fn(x, labels, ignore)
+            (0.5 * ce + 1.5 * lv).backward()
+            torch.cuda.synchronize(); times[name] = time.perf_counter() - t0
+        res[name] = (float(ce), float(lv), x.grad.clone())
+    f, t = res["fused"], res["torch"]
+    print("seg loss P=%d C=%d: fused %.2f ms, torch restatement %.2f ms (forward + backward)" % (P, C, 1e3 * times["fused"], 1e3 * times["torch"]))
+    assert abs(f[0] - t[0]) <= 5e-6 * max(1.0, abs(t[0])) and abs(f[1] - t[1]) <= 1e-5 * max(1.0, abs(t[1])), (f[:2], t[:2])
+    # gradients against a float64 evaluation of the restatement: the f32 restatement itself is off by the cancellation in its Jaccard
+    # increments (jac[1:] - jac[:-1]); the fused kernels (closed-form increments) must not be further from float64 than it is
+    x = logits.double().requires_grad_(True)
+    ce64, lv64 = losses.seg_loss_torch(x, labels, ignore)
+    (0.5 * ce64 + 1.5 * lv64).backward()
+    scale = float(x.grad.abs().max())
+    e_fused, e_torch = float((f[2].double() - x.grad).abs().max()) / scale, float((t[2].double() - x.grad).abs().max()) / scale
+    print("   gradient error vs float64 (of the largest entry): fused %.2e, f32 restatement %.2e" % (e_fused, e_torch))
+    assert e_fused <= max(e_torch, 2e-6), (e_fused, e_torch)
+    assert abs(f[0] - float(ce64)) <= 2e-6 * max(1.0, float(ce64)) and abs(f[1] - float(lv64)) <= 2e-6 * max(1.0, float(lv64))
+    assert float(f[2][labels == ignore].abs().max()) == 0.0
+    if P == 700:
+        assert abs(f[0] - float(g["ce"])) <= 2e-6 and abs(f[1] - float(g["lovasz"])) <= 2e-6
+        ref_grad = 0.5 * 0 + cu(g["grad"])  # fixture: d(ce + lovasz)
+        x = logits.clone().requires_grad_(True)
+        ce, lv = losses.seg_loss(x, labels, ignore)
+        (ce + lv).backward()
+        assert float((x.grad - ref_grad).abs().max()) <= 2e-7
+    x = logits.clone().requires_grad_(True)
+    ce, lv = losses.seg_loss(x, labels, ignore)
+    (0.5 * ce + 1.5 * lv).backward()
+    assert float(ce) == f[0] and float(lv) == f[1] and torch.equal(x.grad, f[2])

@@ -1353,3 +1353,66 @@ def test_other_backbones_conv_calls_replayed_on_our_spconv():
     assert {(0, (1, 3, 3), (1, 1, 1)), (0, (3, 1, 3), (1, 1, 1)), (0, (3, 1, 1), (1, 1, 1)), (1, (3, 3, 3), (2, 2, 1)), (2, (3, 3, 3), (1, 1, 1))} <= seen
     seen, _ = f4_cases.replay("f4_spmiddleresnetfhd.npz", "cpu")
     assert (1, (3, 1, 1), (2, 1, 1)) in seen
+
+
+# ------------------------------------------------------------------------------------------------ fused segmentation loss, round 3
+@pytest.mark.parametrize("P,C,ignore,case", [(3000, 17, 0, "mixed"), (5000, 23, 0, "absent_classes"), (700, 5, 255, "no_ignored"), (1500, 17, 0, "one_valid"),
+                                              (1025, 32, 0, "mixed")])
+def test_fused_seg_loss_equals_the_torch_restatement(P, C, ignore, case):
+    """ls3d_seg_loss_forward / _backward (cross entropy with an ignored label + Lovasz-Softmax over the classes present, det3d/core/utils/
+    loss_utils.py:217-291) against the class-by-class torch restatement of losses.py (itself pinned to the reference's loss_utils in
+    test_losses_equal_reference): values, gradients for arbitrary upstream weights, ties in the errors, absent classes, bit-reproducible"""
+    from lidarseg3d_amd import losses
+    rng = np.random.default_rng(P + C)
+    logits = torch.from_numpy((rng.normal(size=(P, C)) * 3).astype(np.float32))
+    labels = torch.from_numpy(rng.integers(0, C, size=P).astype(np.int64))
+    if case == "absent_classes":
+        labels[labels % 3 == 1] = 2
+    if case == "one_valid":
+        labels[:] = ignore
+        labels[77] = 3
+    if case == "mixed":
+        labels[rng.uniform(size=P) < 0.3] = ignore
+        logits[100:140] = logits[100]          # identical rows: tied errors
+        logits[200:210] = 0.0                  # uniform softmax
+    res = {}
+    for name, fn in (("fused", losses.seg_loss), ("torch", losses.seg_loss_torch)):
+        x = logits.clone().requires_grad_(True)
+        ce, lv = fn(x, labels, ignore)
+        (0.7 * ce + 1.9 * lv).backward()
+        res[name] = (float(ce), float(lv), x.grad.clone())
+    f, t = res["fused"], res["torch"]
+    assert abs(f[0] - t[0]) <= 2e-6 * max(1.0, abs(t[0])) and abs(f[1] - t[1]) <= 5e-6 * max(1.0, abs(t[1])), (f[:2], t[:2])
+    scale = float(t[2].abs().max())
+    tied = torch.zeros(P, dtype=torch.bool)
+    if case == "mixed":
+        tied[100:140] = True  # identical rows: equal errors, whose order in the sort (and with it which of them gets which Lovasz
+        tied[200:210] = True  # increment) is the sort's choice - a different subgradient; their sum per class must still agree
+        assert float((f[2][100:140].sum(0) - t[2][100:140].sum(0)).abs().max()) <= 2e-5 * scale
+        assert float((f[2][200:210].sum(0) - t[2][200:210].sum(0)).abs().max()) <= 2e-5 * scale
+    assert float((f[2] - t[2])[~tied].abs().max()) <= 2e-5 * scale + 1e-9, (float((f[2] - t[2])[~tied].abs().max()), scale)
+    assert float(f[2][labels == ignore].abs().max() if (labels == ignore).any() else 0.0) == 0.0  # ignored points get no gradient
+    x = logits.clone().requires_grad_(True)
+    ce2, lv2 = losses.seg_loss(x, labels, ignore)
+    (0.7 * ce2 + 1.9 * lv2).backward()
+    assert float(ce2) == f[0] and float(lv2) == f[1] and torch.equal(x.grad, f[2])
+    # only one of the two losses used downstream
+    x = logits.clone().requires_grad_(True)
+    losses.seg_loss(x, labels, ignore)[1].backward()
+    y = logits.clone().requires_grad_(True)
+    losses.seg_loss_torch(y, labels, ignore)[1].backward()
+    assert float((x.grad - y.grad)[~tied].abs().max()) <= 2e-5 * float(y.grad.abs().max()) + 1e-9
+
+
+def test_fused_seg_loss_vs_the_reference_fixture():
+    """the fused kernels against tests/golden/seg_loss.npz: value and gradient of CE + Lovasz-Softmax as the REFERENCE's
+    det3d/core/utils/loss_utils.py computes them on 700 points (fixture made by tests/golden/make_golden.py from the reference's file)"""
+    from lidarseg3d_amd import losses
+    from tests.util import golden
+    g = golden("seg_loss.npz")
+    lg = torch.from_numpy(g["logits"]).requires_grad_(True)
+    ce, lv = losses.seg_loss(lg, torch.from_numpy(g["labels"]), int(g["ignore"]))
+    assert isinstance(ce.grad_fn, type(losses._FusedSegLoss.apply(lg.detach().requires_grad_(True), torch.from_numpy(g["labels"]), int(g["ignore"]))[0].grad_fn))
+    assert abs(float(ce) - float(g["ce"])) <= 2e-6 and abs(float(lv) - float(g["lovasz"])) <= 2e-6
+    (ce + lv).backward()
+    np.testing.assert_allclose(lg.grad.numpy(), g["grad"], rtol=0, atol=2e-7)
