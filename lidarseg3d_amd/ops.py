@@ -7,6 +7,7 @@ computation in Python and no fallback: tensors must live on the GPU (the only ex
 requires CPU tensors).
 """
 import os as _os
+import sys as _sys
 import ctypes
 
 import numpy as np
@@ -752,6 +753,8 @@ class _LinearFn(torch.autograd.Function):
 
 
 _ORIG_LINEAR = None
+_FAST_LINEAR_DEBUG = _os.environ.get("LS3D_FAST_LINEAR_DEBUG", "0") != "0"
+_FAST_LINEAR_SEEN = set()
 _FAST_LINEAR_MIN_ROWS = int(_os.environ.get("LS3D_FAST_LINEAR_MIN_ROWS", "32768"))
 
 
@@ -776,6 +779,11 @@ class fast_linear_backward(object):
                         and torch.is_grad_enabled() and weight.requires_grad and input.dtype == torch.float32):
                     y = _LinearFn.apply(input.reshape(rows, input.shape[-1]), weight, bias)
                     return y.reshape(*input.shape[:-1], weight.shape[0])
+                if _FAST_LINEAR_DEBUG and rows >= _FAST_LINEAR_MIN_ROWS and weight.requires_grad and torch.is_grad_enabled():
+                    key = (tuple(input.shape), tuple(weight.shape), input.is_contiguous(), str(input.dtype))
+                    if key not in _FAST_LINEAR_SEEN:
+                        _FAST_LINEAR_SEEN.add(key)
+                        print("fast_linear_backward: not taken:", key, file=_sys.stderr)
                 return orig(input, weight, bias)
             torch.nn.functional.linear = linear
         return self

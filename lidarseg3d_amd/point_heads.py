@@ -350,6 +350,35 @@ class SemanticFeatureFusionModule(PackedModule):
         return tgt
 
 
+class _TokenAttention(torch.autograd.Function):
+    """softmax(q k / sqrt(hd)) v of n points against L class tokens per head (context_module.py:222-257) with the token-side gradients on
+    ls3d_spconv_wgrad: d k and d v reduce 10^5 points into hd x L matrices per head - torch hands that to hipBLASLt as [H, hd, n] x [H, n, L]
+    batched GEMMs with 32 x 32 macro tiles (0.58 + 0.40 ms per frame and layer, 11.7 ms of a Waymo step); here one tall-skinny reduction over
+    all heads' columns at once (ops.linear_wgrad), from which the H diagonal blocks are taken"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        att = torch.softmax(torch.einsum("nhd,hdl->nhl", q, k) * scale, dim=-1)
+        ctx.save_for_backward(q, k, v, att)
+        ctx.scale = scale
+        return torch.einsum("nhl,hdl->nhd", att, v)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, att = ctx.saved_tensors
+        n, H, hd = q.shape
+        L = k.shape[2]
+        dout = dout.contiguous()
+        datt = torch.einsum("nhd,hdl->nhl", dout, v)
+        ds = att * (datt - (datt * att).sum(-1, keepdim=True)) * ctx.scale
+        dq = torch.einsum("nhl,hdl->nhd", ds, k)
+
+        def blocks(x, gy):  # [H, hd, L]: block h of gy^T x over all heads' columns
+            full = ops.linear_wgrad(x.reshape(n, H * L), gy.reshape(n, H * hd))  # [H * hd, H * L]
+            return torch.stack([full[h * hd:(h + 1) * hd, h * L:(h + 1) * L] for h in range(H)], 0)
+        return dq, blocks(ds.contiguous(), q.contiguous()), blocks(att.contiguous(), dout), None
+
+
 def _sffm_forward_train(self, x, emb1, emb2, batch_idx, batch_size, return_context=False):
     """the same decoder under autograd (context_module.py:91-117, :222-257, :319-376): torch modules for the projections /
     norms / embedding self-attention; the point->class-token attention is a per-frame einsum on the frame-sorted rows"""
@@ -370,6 +399,9 @@ def _sffm_forward_train(self, x, emb1, emb2, batch_idx, batch_size, return_conte
         rows = []
         for b in range(B):
             qb = q[off[b]:off[b + 1]]
+            if qb.is_cuda and qb.shape[0] >= 32768 and torch.is_grad_enabled():
+                rows.append(_TokenAttention.apply(qb, k[b], v[b], hd ** -0.5))
+                continue
             att = torch.softmax(torch.einsum("nhd,hdl->nhl", qb, k[b]) * hd ** -0.5, dim=-1)
             rows.append(torch.einsum("nhl,hdl->nhd", att, v[b]))
         tgt = l.norm2(tgt + drop(ca.out_proj(torch.cat(rows, 0).reshape(-1, H * hd))))

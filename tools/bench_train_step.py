@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--syncbn", action="store_true", help="BatchNorm1d -> CountSyncBatchNorm1d (statistics over all ranks, weighted by row counts)")
     ap.add_argument("--ddp", action="store_true", help="wrap the model in DistributedDataParallel (RCCL gradient all-reduce); "
                     "launch with python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... (N = 1 works too)")
+    ap.add_argument("--profile-ops", type=int, default=0, help="print the N most expensive torch ops of one step with their input shapes and exit")
     args = ap.parse_args()
     import lidarseg3d_amd as L
     from lidarseg3d_amd import models_cfg, ops, synth
@@ -69,6 +70,19 @@ def main():
         ex.update(image_features=torch.from_numpy(img).to(dev), camera_semantic_embeddings=torch.from_numpy(emb).to(dev),
                   points_cuv=torch.from_numpy(cuv).to(dev))
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    if args.profile_ops:  # which torch ops (with input shapes) the step spends its GPU time in: what is left on torch autograd
+        from torch.profiler import profile, ProfilerActivity
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            net(dict(ex), return_loss=True)["loss"][0].backward()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            opt.zero_grad(set_to_none=True)
+            net(dict(ex), return_loss=True)["loss"][0].backward()
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=args.profile_ops, max_name_column_width=60,
+                                                                  max_shapes_column_width=90))
+        return
     tf = tb = to = 0.0
     losses = []
     for it in range(args.warmup + args.steps):
