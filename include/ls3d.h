@@ -532,6 +532,18 @@ int ls3d_seg_loss_forward(const float *logits, int ld, const int32_t *labels, in
 int ls3d_seg_loss_backward(const int32_t *labels, int n_points, int num_classes, int ignore_index, const void *workspace, size_t workspace_bytes,
                            const float *grad_ce, const float *grad_lovasz, float *grad_logits, int ld, ls3d_stream_t stream);
 
+/* Row LayerNorm over [n, c] (rows contiguous, c % 4 == 0, c <= 256), forward and backward, for the training step: the LayerNorms of the
+ * reader (voxel_encoder.py:149-163) and of the SF-Phase decoder (context_module.py:319-376) over 10^5 - 10^6 token rows.
+ *   forward : y = (x - mean) * rstd * gamma + beta per row, biased variance + eps as torch.nn.LayerNorm; stats[n][2] = (mean, rstd) for
+ *             the backward (may be NULL).
+ *   backward: dx, dgamma[c], dbeta[c] from x, dy, gamma and the forward's stats; workspace = ls3d_layer_norm_workspace_bytes(n, c)
+ *             bytes (per-block column sums, reduced in a fixed order: deterministic). */
+size_t ls3d_layer_norm_workspace_bytes(int n, int c);
+int ls3d_layer_norm_forward(const float *x, int n, int c, const float *gamma, const float *beta, float eps, float *y, float *stats,
+                            ls3d_stream_t stream);
+int ls3d_layer_norm_backward(const float *x, const float *dy, const float *gamma, const float *stats, int n, int c, float *dx, float *dgamma,
+                             float *dbeta, void *workspace, size_t workspace_bytes, ls3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

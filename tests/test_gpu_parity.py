@@ -1580,3 +1580,32 @@ def test_fused_seg_loss_gpu(P, C):
     ce, lv = losses.seg_loss(x, labels, ignore)
     (0.5 * ce + 1.5 * lv).backward()
     assert float(ce) == f[0] and float(lv) == f[1] and torch.equal(x.grad, f[2])
+
+
+@pytest.mark.parametrize("n,c", [(360000, 96), (241233, 64), (1000, 256)])
+def test_layer_norm_kernels_gpu(n, c):
+    """ls3d_layer_norm_forward / _backward at the training step's sizes against torch's layer_norm and its autograd; prints both times"""
+    import time
+    gen = torch.Generator(device="cpu").manual_seed(n + c)
+    x = (torch.randn((n, c), generator=gen) * 2 + 0.5).to(DEV)
+    g, b, dy = (torch.rand(c, generator=gen) + 0.5).to(DEV), torch.randn(c, generator=gen).to(DEV), torch.randn((n, c), generator=gen).to(DEV)
+    res, times = {}, {}
+    for name in ("hip", "torch"):
+        for rep in range(3):
+            xs, gs, bs = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            y = ops._LayerNormFn.apply(xs, gs, bs, 1e-5) if name == "hip" else torch.nn.functional.layer_norm(xs, (c,), gs, bs, 1e-5)
+            y.backward(dy)
+            torch.cuda.synchronize(); times[name] = time.perf_counter() - t0
+        res[name] = (y.detach(), xs.grad, gs.grad, bs.grad)
+    print("layer norm %d x %d forward + backward: hip %.3f ms, torch %.3f ms" % (n, c, 1e3 * times["hip"], 1e3 * times["torch"]))
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(x64, (c,), g64, b64, 1e-5).backward(dy.double())
+    for i, ref in enumerate((None, x64.grad, g64.grad, b64.grad)):
+        if ref is None:
+            assert float((res["hip"][0] - res["torch"][0]).abs().max()) <= 2e-6 * float(res["torch"][0].abs().max())
+            continue
+        e_hip = float((res["hip"][i].double() - ref).abs().max()) / float(ref.abs().max())
+        e_torch = float((res["torch"][i].double() - ref).abs().max()) / float(ref.abs().max())
+        assert e_hip <= max(2.0 * e_torch, 2e-6), (i, e_hip, e_torch)

@@ -1416,3 +1416,25 @@ def test_fused_seg_loss_vs_the_reference_fixture():
     assert abs(float(ce) - float(g["ce"])) <= 2e-6 and abs(float(lv) - float(g["lovasz"])) <= 2e-6
     (ce + lv).backward()
     np.testing.assert_allclose(lg.grad.numpy(), g["grad"], rtol=0, atol=2e-7)
+
+
+@pytest.mark.parametrize("n,c", [(1000, 96), (257, 64), (77, 192), (300, 256), (9, 4)])
+def test_layer_norm_forward_backward_vs_torch(n, c):
+    """ls3d_layer_norm_forward / _backward (the training step's LayerNorms) against torch.nn.functional.layer_norm and its autograd;
+    the column sums d gamma / d beta are reduced in a fixed order: bit-reproducible"""
+    rng = np.random.default_rng(n + c)
+    x = torch.from_numpy((rng.normal(size=(n, c)) * 2 + 0.5).astype(np.float32))
+    g, b = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)), torch.from_numpy(rng.normal(size=c).astype(np.float32))
+    dy = torch.from_numpy(rng.normal(size=(n, c)).astype(np.float32))
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    want = torch.nn.functional.layer_norm(xr, (c,), gr, br, 1e-5)
+    want.backward(dy)
+    xs, gs, bs = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    got = ops._LayerNormFn.apply(xs, gs, bs, 1e-5)
+    got.backward(dy)
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    assert float((xs.grad - xr.grad).abs().max()) <= 5e-6 * float(xr.grad.abs().max())
+    assert float((gs.grad - gr.grad).abs().max()) <= 2e-5 * float(gr.grad.abs().max()) and float((bs.grad - br.grad).abs().max()) <= 2e-5 * float(br.grad.abs().max())
+    xs2, gs2, bs2 = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ops._LayerNormFn.apply(xs2, gs2, bs2, 1e-5).backward(dy)
+    assert torch.equal(xs2.grad, xs.grad) and torch.equal(gs2.grad, gs.grad) and torch.equal(bs2.grad, bs.grad)
