@@ -301,11 +301,13 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
  *                    Deterministic.  Any table and any order are valid; only speed depends on their locality.
  *   ls3d_tile_conv_pack: plain W[kvol][cin_src][cout] f32 -> [kvol][cin_pad/16][cout32/32][plane 3][2][32] x 8 bf16
  *                    (ls3d_tile_conv_packed_bytes bytes); more than 128 output columns: slab after slab of 128 columns, each in
- *                    that layout.
+ *                    that layout.  ls3d_tile_conv_pack_bf16 / ls3d_tile_conv_packed_bytes_bf16: the head plane only, for products = 1
+ *                    (a third of the bytes: a 12 KB step of the kernel's weight stream then carries 3 / 6 / 12 kernel offsets).
  *   ls3d_tile_conv : out[r, 0..cout) = epilogue(sum_k W[k]^T in[tbl[r,k]]) for the rows of the plan.  products = 8: every
  *                    plane product except tail x tail (2^-32 relative) — f32-grade: the result differs from exact f32
  *                    arithmetic by less than f32 summation-order noise; products = 6: the BF16X6 arithmetic; products = 1: plain
- *                    bf16 operands (the head plane of both), f32 accumulation - NOT f32-grade (BASELINE configs[4]).
+ *                    bf16 operands (the head plane of both), f32 accumulation - NOT f32-grade (BASELINE configs[4]); w_packed
+ *                    is then the single-plane layout of ls3d_tile_conv_pack_bf16.
  *                    cin % 16 == 0, in_ld % 4 == 0.  cout > 128 (SCALING_RATIO > 2 of scn_unet.py:88-123): one launch per slab of
  *                    128 columns on the same plan, workspace and counters (no LayerNorm epilogue then: LS3D_ERR_UNSUPPORTED).
  *                    Summation order per output row is fixed by the plan.
@@ -356,6 +358,8 @@ int ls3d_radix_sort(const uint32_t *keys, const int32_t *vals, int n, const int3
                     void *workspace, size_t workspace_bytes, ls3d_stream_t stream);
 size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout);
 int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream);
+size_t ls3d_tile_conv_packed_bytes_bf16(int kvol, int cin_pad, int cout);
+int ls3d_tile_conv_pack_bf16(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream);
 size_t ls3d_tile_conv_workspace_bytes(int n_rows, int cout);
 size_t ls3d_tile_conv_counter_bytes(void);
 size_t ls3d_tile_conv_trace_bytes(int n_rows);

@@ -366,14 +366,14 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
 // weights: plain [kvol][cin_src][cout] f32 -> [kvol][cin_pad/16][nt][plane 3][kk 2][col 32] x (8 bf16), the exact 3-way split
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src, int kvol, int cin_src, int cin_pad, int cout, int nt,
-                                                   int trunc_split, int col0, int cout_all, uint4 *__restrict__ dst) {
+                                                   int trunc_split, int col0, int cout_all, int planes, uint4 *__restrict__ dst) {
   const int nchunk = cin_pad / 16;
-  const long long total = (long long)kvol * nchunk * nt * 3 * 64;
+  const long long total = (long long)kvol * nchunk * nt * planes * 64;
   for (long long t_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; t_ < total; t_ += (long long)gridDim.x * blockDim.x) {
     long long r = t_;
     const int col = (int)(r % 32); r /= 32;
     const int kk = (int)(r % 2); r /= 2;
-    const int pl = (int)(r % 3); r /= 3;
+    const int pl = (int)(r % planes); r /= planes;
     const int n = (int)(r % nt); r /= nt;
     const int ch = (int)(r % nchunk); r /= nchunk;
     const int k = (int)r;
@@ -403,26 +403,38 @@ __global__ __launch_bounds__(256) void k_tile_pack(const float *__restrict__ src
 
 // layers of more than 128 output columns (SCALING_RATIO > 2 of the reference's UNet) are slabs of <= 128 columns: packed slab after
 // slab, convolved launch after launch on the same plan
-static inline size_t tc_slab_packed_bytes(int kvol, int cin_pad, int cw) { return (size_t)kvol * cin_pad * (cw <= 32 ? 32 : cw <= 64 ? 64 : 128) * 6; }
-extern "C" size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout) {
+// planes = 3: the exact split (products 6 / 8); planes = 1: the head plane only (products 1: plain bf16 operands, BASELINE configs[4]) - a third
+// of the bytes, so that a 12 KB step of the kernel's weight stream carries three times the kernel offsets
+static inline size_t tc_slab_packed_bytes(int kvol, int cin_pad, int cw, int planes = 3) {
+  return (size_t)kvol * cin_pad * (cw <= 32 ? 32 : cw <= 64 ? 64 : 128) * 2 * planes;
+}
+static size_t tc_packed_bytes(int kvol, int cin_pad, int cout, int planes) {
   size_t b = 0;
-  for (int col0 = 0; col0 < cout; col0 += 128) b += tc_slab_packed_bytes(kvol, cin_pad, cout - col0 < 128 ? cout - col0 : 128);
+  for (int col0 = 0; col0 < cout; col0 += 128) b += tc_slab_packed_bytes(kvol, cin_pad, cout - col0 < 128 ? cout - col0 : 128, planes);
   return b;
 }
+extern "C" size_t ls3d_tile_conv_packed_bytes(int kvol, int cin_pad, int cout) { return tc_packed_bytes(kvol, cin_pad, cout, 3); }
+extern "C" size_t ls3d_tile_conv_packed_bytes_bf16(int kvol, int cin_pad, int cout) { return tc_packed_bytes(kvol, cin_pad, cout, 1); }
 
-extern "C" int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream) {
+static int tc_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, int planes, ls3d_stream_t stream) {
   if (!w_plain || !w_packed || kvol < 1 || cin_src < 1 || cin_pad < cin_src || (cin_pad % 16) || cout < 1) return LS3D_ERR_ARG;
   char *dst = (char *)w_packed;
   for (int col0 = 0; col0 < cout; col0 += 128) {
     const int cw = cout - col0 < 128 ? cout - col0 : 128;
     const int nt = cw <= 32 ? 1 : cw <= 64 ? 2 : 4;  // column blocks of the kernel variant that will run (zero padded)
-    const long long total = (long long)kvol * (cin_pad / 16) * nt * 3 * 64;
-    hipLaunchKernelGGL(k_tile_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cw, nt, 0, col0, cout,
+    const long long total = (long long)kvol * (cin_pad / 16) * nt * planes * 64;
+    hipLaunchKernelGGL(k_tile_pack, ls3d_grid(total), dim3(256), 0, (hipStream_t)stream, w_plain, kvol, cin_src, cin_pad, cw, nt, 0, col0, cout, planes,
                        (uint4 *)dst);
-    dst += tc_slab_packed_bytes(kvol, cin_pad, cw);
+    dst += tc_slab_packed_bytes(kvol, cin_pad, cw, planes);
   }
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
+}
+extern "C" int ls3d_tile_conv_pack(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream) {
+  return tc_pack(w_plain, kvol, cin_src, cin_pad, cout, w_packed, 3, stream);
+}
+extern "C" int ls3d_tile_conv_pack_bf16(const float *w_plain, int kvol, int cin_src, int cin_pad, int cout, void *w_packed, ls3d_stream_t stream) {
+  return tc_pack(w_plain, kvol, cin_src, cin_pad, cout, w_packed, 1, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -512,9 +524,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
                                                              int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int ablate, int swz,
                                                              int split_small, int split_tail, int split_forced, float *partial, int *counters,
                                                              unsigned *trace) {
-  constexpr int PU = NT * 192;             // 16-byte units of one (offset, chunk) weight piece
-  constexpr int PB = NT * 3;               // ... in 1 KB LDS-DMA blocks
-  constexpr int G = 4 / NT;                // offsets per step
+  constexpr int PLN = NP == 1 ? 1 : 3;     // weight planes in the packed layout (NP == 1: the head plane only, ls3d_tile_conv_pack_bf16)
+  constexpr int PU = NT * 64 * PLN;        // 16-byte units of one (offset, chunk) weight piece
+  constexpr int PB = NT * PLN;             // ... in 1 KB LDS-DMA blocks
+  constexpr int G = 12 / PB;               // offsets per step
   constexpr int HPT = (TC_HCAP * 4 + TC_THREADS - 1) / TC_THREADS;  // float4 items of the halo chunk per thread
   static_assert(G * PU == TC_WBUF_UNITS && G * PB == 12, "a step moves 12 KB of weights");
   static_assert(64 * NT * 32 * 4 <= TC_HALO_BYTES, "the epilogue transposes 64 rows at a time through the halo buffer");
@@ -528,7 +541,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                         // scalar: per-wave decisions are s_cbranch
   const int col = lane & 31, kk = lane >> 5;
   const int kvol = p.kvol, nchunk = cin / 16;
-  // this wave's share of a step's weight DMA: blocks [3 wave, 3 wave + 3) of the 12, all inside one offset's piece
+  // this wave's share of a step's weight DMA: blocks [3 wave, 3 wave + 3) of the 12; with three planes all inside one offset's piece
+  // (dma_g, from block dma_j on), with one plane each block in its own (offset, block) - TC_DMA_GROUP
   const int dma_g = (3 * wave) / PB, dma_j = (3 * wave) % PB;
   const unsigned voff0 = (unsigned)lane * 16u, voff1 = voff0 + 1024u, voff2 = voff0 + 2048u;
   const uint16_t *loc_w = s_loc + wave * 32 + col;
@@ -627,8 +641,17 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         const char *wchunk = (const char *)(wpk + (size_t)c * PU + dma_j * 64);
         const unsigned kstride = (unsigned)nchunk * PU * 16u;
 #define TC_DMA_GROUP(kg_, buf_)                                                   \
-  if (kg_[dma_g] >= 0 && !(ablate & 8))                                           \
-    ls3d_glds16x3(wchunk + (unsigned)kg_[dma_g] * kstride, voff0, voff1, voff2, (buf_) ? dma_lds1 : dma_lds0);
+  if constexpr (PLN == 3) {                                                       \
+    if (kg_[dma_g] >= 0 && !(ablate & 8))                                         \
+      ls3d_glds16x3(wchunk + (unsigned)kg_[dma_g] * kstride, voff0, voff1, voff2, (buf_) ? dma_lds1 : dma_lds0); \
+  } else {                                                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_) {                            \
+      const int blk_ = 3 * wave + q_, g1_ = blk_ / PB, j1_ = blk_ % PB;           \
+      if (kg_[g1_] >= 0 && !(ablate & 8))                                         \
+        ls3d_glds16((const char *)(wpk + (size_t)c * PU + j1_ * 64) + (unsigned)kg_[g1_] * kstride + voff0, \
+                    Bs + ((buf_) ? TC_WBUF_UNITS : 0) + g1_ * PU + j1_ * 64);     \
+    }                                                                             \
+  }
         // LP = 1: the DMA walks the active offsets with its own iterator, G per step, two steps ahead of the MFMAs
         unsigned rem_d = kmask;
 #define TC_DMA_STEP(buf_)                                                          \
@@ -821,7 +844,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
               // 0's MFMAs are issued and takes over its registers: 32 instead of 48 VGPRs of fragments
               uint4 b0[NT], b1[NT];
 #pragma unroll
-              for (int n = 0; n < NT; ++n) b0[n] = bs[(n * 3 + 0) * 64];
+              for (int n = 0; n < NT; ++n) b0[n] = bs[(n * PLN + 0) * 64];
               const bf16x8 ah = __builtin_bit_cast(bf16x8, hp[0]);
               if constexpr (NP == 1) {  // bf16 x bf16 -> f32: one product per f32 product, operands rounded to bf16
 #pragma unroll
@@ -968,7 +991,7 @@ extern "C" int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int 
     const int rc = tc_conv_slab(in, in_ld, plan, n_rows, kvol, wp, cin, cw, products, epi ? &e2 : nullptr, out + col0, out_ld, workspace, workspace_bytes,
                                 counters, flags, stream_);
     if (rc != LS3D_OK) return rc;
-    wp += tc_slab_packed_bytes(kvol, cin, cw);
+    wp += tc_slab_packed_bytes(kvol, cin, cw, products == 1 ? 1 : 3);
   }
   return LS3D_OK;
 }

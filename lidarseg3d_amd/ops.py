@@ -610,10 +610,12 @@ def tile_plan(tbl, coords, shape_zyx, batch, order=None, n_dev=None):
     return p
 
 
-def tile_conv_pack(w_plain, kvol, cin, cin_pad, cout):
+def tile_conv_pack(w_plain, kvol, cin, cin_pad, cout, bf16=False):
+    """packed weights of ls3d_tile_conv: the exact 3-plane split (products 6 / 8) or, bf16=True, the head plane only (products 1)"""
     L = _L()
-    out = torch.empty((int(L.ls3d_tile_conv_packed_bytes(kvol, cin_pad, cout)),), dtype=torch.uint8, device=w_plain.device)
-    check(L.ls3d_tile_conv_pack(_ptr(w_plain), kvol, cin, cin_pad, cout, _ptr(out), _stream(w_plain)), "ls3d_tile_conv_pack")
+    nbytes, pack = (L.ls3d_tile_conv_packed_bytes_bf16, L.ls3d_tile_conv_pack_bf16) if bf16 else (L.ls3d_tile_conv_packed_bytes, L.ls3d_tile_conv_pack)
+    out = torch.empty((int(nbytes(kvol, cin_pad, cout)),), dtype=torch.uint8, device=w_plain.device)
+    check(pack(_ptr(w_plain), kvol, cin, cin_pad, cout, _ptr(out), _stream(w_plain)), "ls3d_tile_conv_pack")
     return out
 
 
@@ -641,7 +643,7 @@ def tile_conv(x, w, plan, cout=None, products=None, scale=None, shift=None, res_
         off = int(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout))
         nbytes = off + int(_L().ls3d_tile_conv_trace_bytes(plan.n_rows))
     ws = _tile_ws(nbytes, x) if nbytes else None
-    check(_L().ls3d_tile_conv(_ptr(x), in_ld, _ptr(plan.buf), plan.n_rows, kvol, _ptr(w.for_tile()), cin, cout, products, ctypes.byref(epi),
+    check(_L().ls3d_tile_conv(_ptr(x), in_ld, _ptr(plan.buf), plan.n_rows, kvol, _ptr(w.for_tile(bf16=(products == 1))), cin, cout, products, ctypes.byref(epi),
                               _vp_any(out), out_ld, _vp(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
                               _vp(_tile_counters(x) if split else None), flags, _stream(x)), "ls3d_tile_conv")
     if flags & 32:

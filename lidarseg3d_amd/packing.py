@@ -45,12 +45,13 @@ class PackedWeight(object):
                                                                      precision)
         return d
 
-    def for_tile(self):
-        """layout of ls3d_tile_conv (three bf16 planes, 16-channel chunks)"""
-        d = self._by_nt.get("tile")
+    def for_tile(self, bf16=False):
+        """layout of ls3d_tile_conv (16-channel chunks): three bf16 planes, or bf16=True the head plane only (products = 1)"""
+        key = "tile_bf16" if bf16 else "tile"
+        d = self._by_nt.get(key)
         if d is None:
             from . import ops
-            d = self._by_nt["tile"] = ops.tile_conv_pack(self.plain, self.kvol, self.cin_src, self.cin, self.cout)
+            d = self._by_nt[key] = ops.tile_conv_pack(self.plain, self.kvol, self.cin_src, self.cin, self.cout, bf16=bf16)
         return d
 
     @property

@@ -1089,6 +1089,36 @@ def test_tile_conv_more_than_128_output_columns(cin, cout):
     np.testing.assert_allclose(got.numpy(), gg, rtol=0, atol=2e-5 * float(np.abs(gg).max()))
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (48, 64), (64, 128), (16, 160)])
+def test_tile_conv_plain_bf16_products_on_the_single_plane_layout(cin, cout):
+    """products = 1 (BASELINE configs[4]): bf16-rounded operands, one MFMA per product, the single-plane weight layout of
+    ls3d_tile_conv_pack_bf16 (12 / 6 / 3 kernel offsets per 12 KB step of the weight stream) == a float64 evaluation on operands rounded to
+    bf16 (round to nearest even), to f32 accumulation noise; 27 offsets with absent neighbours, partial last steps, fused epilogue"""
+    rng = np.random.default_rng(cin + cout)
+    vin, vout, kvol = 300, 330, 27
+    x = rng.normal(size=(vin, cin)).astype(np.float32)
+    w = rng.normal(size=(kvol, cin, cout)).astype(np.float32) * 0.1
+    tbl = (np.arange(vout)[:, None] * vin // vout + rng.integers(-20, 20, size=(vout, kvol))).clip(0, vin - 1).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) < 0.5] = -1
+    tbl[:, 7] = -1   # an offset nobody has: the steps of the other 26 regroup
+    T = torch.from_numpy
+
+    def bf16(a):
+        return T(a).to(torch.bfloat16).to(torch.float64).numpy()
+    pw = PackedWeight(T(w), kvol, cin, cin, cout)
+    coords = T(np.stack([np.zeros(vout), np.zeros(vout), np.arange(vout) // 32, np.arange(vout) % 32], 1).astype(np.int32))
+    plan = ops.tile_plan(T(tbl), coords, (1, 32, 32), 1)
+    got = ops.tile_conv(T(x), pw, plan, cout=cout, products=1)
+    want = _sparse_ref(bf16(x), bf16(w), tbl)
+    np.testing.assert_allclose(got.numpy(), want, rtol=0, atol=2e-5 * float(np.abs(want).max()) + 1e-5)
+    assert torch.equal(ops.tile_conv(T(x), pw, plan, cout=cout, products=1), got)
+    scale, shift = T(rng.uniform(0.5, 1.5, cout).astype(np.float32)), T(rng.normal(size=cout).astype(np.float32))
+    a = ops.tile_conv(T(x), pw, plan, cout=cout, products=1, scale=scale, shift=shift, relu=True)
+    np.testing.assert_allclose(a.numpy(), np.maximum(got.numpy() * scale.numpy() + shift.numpy(), 0), rtol=0, atol=1e-5)
+    six = ops.tile_conv(T(x), pw, plan, cout=cout, products=6)   # the same PackedWeight serves both layouts
+    np.testing.assert_allclose(six.numpy(), _sparse_ref(x, w, tbl), rtol=0, atol=2e-4)
+
+
 def test_tile_conv_any_row_order_gives_the_same_rows():
     """tiles only group rows: with single-pass halos the per-row summation order (chunks outer, offsets inner) does not depend
     on the tiling, so two different spatial orders give bit-identical outputs"""
