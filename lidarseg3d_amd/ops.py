@@ -762,8 +762,10 @@ _FAST_LINEAR_MIN_ROWS = int(_os.environ.get("LS3D_FAST_LINEAR_MIN_ROWS", "32768"
 
 class fast_linear_backward(object):
     """`with ops.fast_linear_backward():` - inside, torch.nn.functional.linear (hence nn.Linear, nn.MultiheadAttention's projections)
-    records _LinearFn for the tall-skinny case: >= 32768 rows on the device, both dimensions <= 256, a gradient wanted.  The training
-    forward of the detectors runs under it; LS3D_FAST_LINEAR=0 switches it off."""
+    records _LinearFn for the tall-skinny case (>= 32768 rows on the device, both dimensions <= 256, a gradient wanted) and
+    torch.nn.functional.layer_norm records _LayerNormFn (csrc/norm.hip) for [>= 32768, c <= 256] f32 rows.  The training forward of the
+    detectors runs under it (the backward then runs the recorded functions wherever it is called); LS3D_FAST_LINEAR=0 switches the whole
+    context off, LS3D_FAST_LAYERNORM=0 the LayerNorm part."""
 
     def __enter__(self):
         global _ORIG_LINEAR
