@@ -415,6 +415,36 @@ def main():
         throughput = {"streams": TP, "frames_in_flight": TP}
         for prec in sorted({args.precision, "f32"}):
             throughput[prec + "_frames_per_s"] = measure(prec, args.steps, max(2, args.warmup // 2), TP, False)["frames_per_s"]
+        if not args.no_graph and detectors.CAPACITY_MODE:
+            # the same with one hipGraph per frame slot, each captured on its own stream (graph.FrameGraph(stream=...)): the replays of
+            # the two slots overlap on the GPU; the logits of slot 0 are checked against the eager forward of its frame
+            try:
+                from lidarseg3d_amd import graph as lgraph
+                ops.set_precision(args.precision)
+                exs = [dict(points=p, batch_size=1) for p in spts[:TP]]
+                with torch.no_grad():
+                    model(dict(exs[0]), return_loss=False)
+                want = model.point_head.forward_ret_dict["out_logits"].clone()
+                fgs = [lgraph.FrameGraph(model, ex, stream=st) for ex, st in zip(exs, streams[:TP])]
+
+                def step_g():
+                    cur = torch.cuda.current_stream(dev)
+                    for st, fg, ex in zip(streams[:TP], fgs, exs):
+                        st.wait_stream(cur)
+                        with torch.cuda.stream(st):
+                            fg.launch(ex)
+                    labels = None
+                    for fg, ex in zip(fgs, exs):
+                        labels = fg.finish(ex, clone=False)[0]["pred_point_sem_labels"]
+                    return labels
+                elg, latg = timed_steps(step_g, args.steps, max(2, args.warmup // 2))
+                throughput["graph_" + args.precision + "_frames_per_s"] = TP * args.steps / elg
+                throughput["graph_ms_per_step_of_%d_frames" % TP] = 1e3 * elg / args.steps
+                throughput["graph_logits_bit_identical_to_eager"] = bool(torch.equal(fgs[0].logits, want))
+                throughput["graph_fallbacks"] = sum(fg.fallbacks for fg in fgs)
+                del fgs
+            except Exception as e:
+                throughput["graph_error"] = repr(e)
     mseg = None
     if extra_modes and world == 1 and args.model == "sdseg3d" and S == 1 and B == 1:
         # BASELINE configs[2] in the same driver-timed run: MSeg3D = + 6-camera feature maps, GF-/SF-Phase head

@@ -15,21 +15,25 @@ Correctness contract: a replay runs exactly the launches of the eager capacity-m
 strided rulebooks are the ones learned from the warm-up frames (1.3x the largest count seen); every replay copies the frame's counts and
 overflow flags to pinned host memory, and __call__ checks them after the frame: an overflowing frame is computed again by the eager
 path (host-side counts, always correct) and the graph is captured again with the new capacities.  Inputs of another shape than the
-captured one go to the eager path as well (a graph is a fixed-shape object: one FrameGraph per point-count bucket)."""
+captured one go to the eager path as well (a graph is a fixed-shape object: one FrameGraph per point-count bucket).
+
+Several frames in flight: one FrameGraph per frame slot, each captured on its OWN stream (`stream=`: the arrival counters of the tile
+kernel's channel split are per stream, the pinned count buffer is per capture), then per slot `with torch.cuda.stream(s): fg.launch(ex)`
+and later `fg.finish(ex)` - the replays of different slots overlap on the GPU (bench.py's `throughput_mode.graph_*`)."""
 import torch
 
 from . import detectors
 
 
 class FrameGraph(object):
-    def __init__(self, model, example, warmup=3):
+    def __init__(self, model, example, warmup=3, stream=None):
         if model.training:
             raise ValueError("FrameGraph is an inference path: model.eval() first")
         if int(example.get("batch_size", 1)) != 1:
             raise ValueError("FrameGraph captures single-frame batches (predict() splits larger batches with synchronising boolean masks)")
         if not detectors.CAPACITY_MODE:
             raise ValueError("FrameGraph needs capacity mode (LS3D_CAPACITY_MODE=0 is set)")
-        self.model, self.warmup = model, int(warmup)
+        self.model, self.warmup, self.stream = model, int(warmup), stream
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example.items()}
         self.shapes = {k: (tuple(v.shape), v.dtype) for k, v in example.items() if torch.is_tensor(v)}
         self.graph, self.ret, self.record, self.recaptures, self.fallbacks = None, None, None, 0, 0
@@ -45,8 +49,11 @@ class FrameGraph(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         bb.__dict__.pop("_captured_record", None)
+        old = bb.__dict__.get("_pinned_counts")
+        if old is not None:  # this graph's own pinned count buffer (allocated outside the capture): graphs of other frame slots keep theirs
+            bb.__dict__["_pinned_counts"] = torch.empty(old.shape, dtype=old.dtype, pin_memory=True)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g):
+        with torch.no_grad(), (torch.cuda.graph(g) if self.stream is None else torch.cuda.graph(g, stream=self.stream)):
             ret = model(dict(self.static), return_loss=False)
         rec = bb.__dict__.pop("_captured_record", None)
         if rec is None:
@@ -58,16 +65,28 @@ class FrameGraph(object):
         return all(k in example and torch.is_tensor(example[k]) and tuple(example[k].shape) == s and example[k].dtype == d
                    for k, (s, d) in self.shapes.items()) and int(example.get("batch_size", 1)) == 1
 
+    def launch(self, example):
+        """copy the inputs and replay on the CURRENT stream, without waiting (the example must match the captured shapes); finish() next"""
+        for k in self.shapes:
+            self.static[k].copy_(example[k], non_blocking=True)
+        self.graph.replay()
+        self._launched_on = torch.cuda.current_stream()
+
+    def finish(self, example, clone=True):
+        """wait for the frame launch() started, check its rulebook counts (overflow -> eager rerun + recapture) -> the frame's outputs"""
+        self._launched_on.synchronize()  # the frame is done: its counts are on the host, its outputs can be handed out
+        return self._after_replay(example, clone)
+
     def __call__(self, example, clone=True):
         """-> model(example, return_loss=False).  clone=False returns the graph's own output tensors (overwritten by the next call)"""
         if not self.matches(example):
             self.fallbacks += 1
             with torch.no_grad():
                 return self.model(example, return_loss=False)
-        for k in self.shapes:
-            self.static[k].copy_(example[k], non_blocking=True)
-        self.graph.replay()
-        torch.cuda.current_stream().synchronize()  # the frame is done: its counts are on the host, its outputs can be handed out
+        self.launch(example)
+        return self.finish(example, clone)
+
+    def _after_replay(self, example, clone):
         host, key = self.record
         if not self.model.backbone.apply_counts(host.tolist(), key):
             # a rulebook overflowed the captured capacity: this frame on host-side counts, then a new graph on relearned capacities
