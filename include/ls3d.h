@@ -524,7 +524,8 @@ int ls3d_points_cuv(const float *points_cp, int n, int ncam, int res_h, int res_
 /* Segmentation loss of the point heads: cross entropy with an ignored label + Lovasz-Softmax over the classes present, forward and
  * backward (det3d/core/utils/loss_utils.py:217-291 lovasz_softmax(classes='present', ignore) + F.cross_entropy(ignore_index), as
  * point_seg_batchloss_head.py:77-121 / point_seg_mseg3d_head.py:137 call them on flat [P, C] logits).  One softmax pass, ONE batched
- * radix sort of the C x P class errors, per-class scans; no host synchronisation, deterministic.  num_classes <= 32.
+ * radix sort of the C x P class errors, per-class scans; no host synchronisation, deterministic.  num_classes <= 32; labels outside
+ * [0, num_classes) count as ignored (torch raises for them).
  *   forward : out2[0] = mean_i(-log softmax(logits_i)[label_i]) over label_i != ignore_index (nan when there is none, as torch),
  *             out2[1] = mean over the classes c present of sum_j e_(j) g_j, e = |[label == c] - softmax_c| sorted descending, g = the
  *             increments of the Jaccard index (Lovasz gradient); the workspace keeps what the backward needs.
