@@ -23,28 +23,96 @@ typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WG_UNROLL = 4;  // row pairs in flight per wave
 
-// tbl_t[k][p] = tbl[order[p]][k] (p = position in the processing order) and o_t[p] = order[p]: one pass over the table so that
-// the wgrad workgroups of offset k read their neighbour indices as contiguous ints instead of 4-byte gathers from 108-byte rows
-__global__ __launch_bounds__(256) void k_tbl_transpose(const int32_t *tbl, const int32_t *order, int n, const int32_t *n_dev, int kvol,
-                                                      int32_t *tbl_t, int32_t *o_t) {
-  const int N = ls3d_count(n, n_dev);
-  const long long work = (long long)N * kvol;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
-    const int p = (int)(t / kvol), k = (int)(t % kvol);
-    const int o = order ? order[p] : p;
-    tbl_t[(size_t)k * n + p] = tbl[(size_t)o * kvol + k];
-    if (k == 0) o_t[p] = o;
+// Pair lists per kernel offset, compacted: pin[k][j] / pout[k][j] = input row / output row of the j-th pair of offset k in processing
+// order (j < cnt[k]).  Round 2 handed the kernels the transposed table and let them skip groups without any pair; but a group of 16
+// consecutive rows almost always has SOME row with the neighbour (pair density 0.46 / 0.65 / 0.72 on levels 2 - 4 of the 120k frame), so
+// 30 - 55 % of the rows a workgroup staged and multiplied were zero rows.  Three launches (count per block of 1024 positions, scan of the
+// block counts per offset, emit); the order of the pairs - and with it every summation order - is fixed by the table and the row order.
+constexpr int PL_BLK = 1024;
+__device__ __forceinline__ int pl_entry(const int32_t *tbl, const int32_t *order, int N, int kvol, int k, int p, int *o_out) {
+  if (p >= N) return -1;
+  const int o = order ? order[p] : p;
+  *o_out = o;
+  return tbl[(size_t)o * kvol + k];
+}
+__global__ __launch_bounds__(256) void k_pairs_count(const int32_t *tbl, const int32_t *order, int n, const int32_t *n_dev, int kvol, int nb,
+                                                    int32_t *bcount) {
+  __shared__ int s_c[256];
+  const int tid = threadIdx.x, k = blockIdx.y, b = blockIdx.x, N = ls3d_count(n, n_dev);
+  int c = 0, o;
+  for (int q = 0; q < PL_BLK / 256; ++q) c += pl_entry(tbl, order, N, kvol, k, b * PL_BLK + tid * (PL_BLK / 256) + q, &o) >= 0;
+  s_c[tid] = c;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (tid < d) s_c[tid] += s_c[tid + d];
+    __syncthreads();
   }
+  if (tid == 0) bcount[(size_t)k * nb + b] = s_c[0];
+}
+__global__ __launch_bounds__(256) void k_pairs_scan(int32_t *bcount, int nb, int32_t *cnt) {  // one workgroup per offset: exclusive scan in place
+  __shared__ int s_a[256];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, k = blockIdx.x;
+  int32_t *a = bcount + (size_t)k * nb;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 256) {
+    const int v = base + tid < nb ? a[base + tid] : 0;
+    s_a[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int t = tid >= d ? s_a[tid - d] : 0;
+      __syncthreads();
+      s_a[tid] += t;
+      __syncthreads();
+    }
+    const int incl = s_a[tid], carry = s_carry;
+    if (base + tid < nb) a[base + tid] = carry + incl - v;
+    __syncthreads();
+    if (tid == 255) s_carry = carry + incl;
+    __syncthreads();
+  }
+  if (tid == 0) cnt[k] = s_carry;
+}
+__global__ __launch_bounds__(256) void k_pairs_emit(const int32_t *tbl, const int32_t *order, int n, const int32_t *n_dev, int kvol, int nb,
+                                                   const int32_t *boff, int32_t *pin, int32_t *pout) {
+  __shared__ int s_s[256];
+  const int tid = threadIdx.x, k = blockIdx.y, b = blockIdx.x, N = ls3d_count(n, n_dev);
+  int idx[PL_BLK / 256], o[PL_BLK / 256], c = 0;
+#pragma unroll
+  for (int q = 0; q < PL_BLK / 256; ++q) {  // the thread's consecutive positions
+    o[q] = 0;
+    idx[q] = pl_entry(tbl, order, N, kvol, k, b * PL_BLK + tid * (PL_BLK / 256) + q, &o[q]);
+    c += idx[q] >= 0;
+  }
+  s_s[tid] = c;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int t = tid >= d ? s_s[tid - d] : 0;
+    __syncthreads();
+    s_s[tid] += t;
+    __syncthreads();
+  }
+  int pos = boff[(size_t)k * nb + b] + s_s[tid] - c;
+#pragma unroll
+  for (int q = 0; q < PL_BLK / 256; ++q)
+    if (idx[q] >= 0) {
+      pin[(size_t)k * n + pos] = idx[q];
+      pout[(size_t)k * n + pos] = o[q];
+      ++pos;
+    }
 }
 
 template <int COB>
 __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ in, int in_ld, const float *__restrict__ gout, int go_ld,
-                                                      const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_t, int kvol, int cin,
-                                                      int cout, int n_rows, const int32_t *n_rows_dev, int nchunks, float *__restrict__ partial) {
+                                                      const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_all, int kvol, int cin,
+                                                      int cout, int n_rows, const int32_t *__restrict__ pair_cnt, int nchunks,
+                                                      float *__restrict__ partial) {
   __shared__ float red[32 * 32 * COB * 2];  // the tiles handed over in one round: one per cin block of the workgroup with RG > 1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, half = lane >> 5;
-  const int N = ls3d_count(n_rows, n_rows_dev);
+  const int N = pair_cnt[blockIdx.y];  // pairs of this offset (compacted lists: every entry below N is a pair)
+  const int32_t *o_t = o_all + (size_t)blockIdx.y * n_rows;
   const int ci_blocks = (cin + 31) / 32;
   const int CIW = ci_blocks >= 4 ? 4 : ci_blocks >= 2 ? 2 : 1, RG = 4 / CIW;
   const int ci_groups = (ci_blocks + CIW - 1) / CIW;
@@ -187,15 +255,17 @@ __device__ __forceinline__ void wgl_multiply(const uint4 (*sa)[2][128], const ui
 
 template <int NP>
 __global__ __launch_bounds__(256, 2) void k_spconv_wgrad_lds(const float *__restrict__ in, int in_ld, const float *__restrict__ gout, int go_ld,
-                                                             const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_t, int kvol, int cin,
-                                                             int cout, int n_rows, const int32_t *n_rows_dev, int nchunks, float *__restrict__ partial) {
+                                                             const int32_t *__restrict__ tbl_t, const int32_t *__restrict__ o_all, int kvol, int cin,
+                                                             int cout, int n_rows, const int32_t *__restrict__ pair_cnt, int nchunks,
+                                                             float *__restrict__ partial) {
   __shared__ uint4 sA[2][3][2][128];  // [buffer][plane][row half][channel] x 8 bf16 (rows 8 h .. 8 h + 8 of the group): lanes run along the
                                       // channels in the staging stores and in the fragment reads alike -> consecutive 16-byte words, no bank conflicts
   __shared__ uint4 sB[2][3][2][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, half = lane >> 5;
   const int c = tid & 127, rg = __builtin_amdgcn_readfirstlane(tid >> 7);
-  const int N = ls3d_count(n_rows, n_rows_dev);
+  const int N = pair_cnt[blockIdx.y];  // pairs of this offset (compacted lists)
+  const int32_t *o_t = o_all + (size_t)blockIdx.y * n_rows;
   const int ci_tiles = (cin + 127) / 128;
   const int k = blockIdx.y;
   const int chunk = blockIdx.x / ci_tiles, ct = blockIdx.x % ci_tiles;
@@ -329,7 +399,9 @@ static inline int wg_chunks(int n_rows, int kvol, int cin) {
 static inline size_t wg_align(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t ls3d_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout, int n_rows) {
   if (cout > 128) cout = 128;  // wider layers run in slabs of 128 output columns through the same partial-sum buffer
-  return wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cout * sizeof(float)) + wg_align((size_t)(kvol + 1) * (n_rows > 0 ? n_rows : 1) * 4) + 256;
+  const size_t nr = n_rows > 0 ? n_rows : 1, nb = (nr + PL_BLK - 1) / PL_BLK;
+  return wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cout * sizeof(float)) + 2 * wg_align((size_t)kvol * nr * 4) +
+         wg_align((size_t)kvol * nb * 4) + wg_align((size_t)kvol * 4) + 256;  // partial sums, pair lists (in, out), block counts, pair counts
 }
 
 extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int go_ld, const int32_t *tbl, const int32_t *row_order,
@@ -352,9 +424,15 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
   const int nchunks = wg_chunks(n_rows, kvol, cin);
   float *partial = (float *)workspace;
   const int cout_all = cout, cw_max = cout < 128 ? cout : 128;
-  int32_t *tbl_t = (int32_t *)((char *)workspace + wg_align((size_t)nchunks * kvol * cin * cw_max * sizeof(float)));
-  int32_t *o_t = tbl_t + (size_t)kvol * n_rows;
-  hipLaunchKernelGGL(k_tbl_transpose, ls3d_grid((long long)n_rows * kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, tbl_t, o_t);
+  const int nb = (n_rows + PL_BLK - 1) / PL_BLK;
+  char *wsp = (char *)workspace + wg_align((size_t)nchunks * kvol * cin * cw_max * sizeof(float));
+  int32_t *tbl_t = (int32_t *)wsp; wsp += wg_align((size_t)kvol * n_rows * 4);   // pin[k][j]
+  int32_t *o_t = (int32_t *)wsp; wsp += wg_align((size_t)kvol * n_rows * 4);     // pout[k][j]
+  int32_t *bcount = (int32_t *)wsp; wsp += wg_align((size_t)kvol * nb * 4);
+  int32_t *pair_cnt = (int32_t *)wsp;
+  hipLaunchKernelGGL(k_pairs_count, dim3(nb, kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, nb, bcount);
+  hipLaunchKernelGGL(k_pairs_scan, dim3(kvol), dim3(256), 0, stream, bcount, nb, pair_cnt);
+  hipLaunchKernelGGL(k_pairs_emit, dim3(nb, kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, nb, (const int32_t *)bcount, tbl_t, o_t);
   const dim3 grid((unsigned)(nchunks * wg_ci_groups(cin)), (unsigned)kvol);
   const dim3 grid_lds((unsigned)(nchunks * ((cin + 127) / 128)), (unsigned)kvol);  // k_spconv_wgrad_lds: tiles of 128 input channels
   const int products_all = products;
@@ -368,7 +446,7 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
   const long long elems = (long long)kvol * cin * cout;
   const int cob = (cout + 31) / 32;
 #define LS3D_WG(COB_) hipLaunchKernelGGL((k_spconv_wgrad<COB_>), grid, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, (const int32_t *)tbl_t, \
-                                          (const int32_t *)o_t, kvol, cin, cout, n_rows, n_rows_dev, nchunks, partial)
+                                          (const int32_t *)o_t, kvol, cin, cout, n_rows, (const int32_t *)pair_cnt, nchunks, partial)
   // the plane kernel pays where a workgroup has many 32 x 32 output blocks per staged row group (measured on 241k rows: 128 -> 128 0.67 ms
   // against 1.84 ms; 32 -> 32 1.75 ms against 0.20 ms: one block leaves three waves idle behind the same staging cost) - narrower
   // layers keep the exact-f32 kernel, which is f32-grade by construction
@@ -380,10 +458,10 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
     else LS3D_WG(4);
   } else if (products == 6) {
     hipLaunchKernelGGL((k_spconv_wgrad_lds<6>), grid_lds, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, (const int32_t *)tbl_t, (const int32_t *)o_t, kvol,
-                       cin, cout, n_rows, n_rows_dev, nchunks, partial);
+                       cin, cout, n_rows, (const int32_t *)pair_cnt, nchunks, partial);
   } else {
     hipLaunchKernelGGL((k_spconv_wgrad_lds<8>), grid_lds, dim3(256), 0, stream, in, in_ld, grad_out, go_ld, (const int32_t *)tbl_t, (const int32_t *)o_t, kvol,
-                       cin, cout, n_rows, n_rows_dev, nchunks, partial);
+                       cin, cout, n_rows, (const int32_t *)pair_cnt, nchunks, partial);
   }
 #undef LS3D_WG
   hipLaunchKernelGGL(k_wgrad_reduce, ls3d_grid(elems), dim3(256), 0, stream, (const float *)partial, nchunks, elems, cout, cout_all, col0, grad_w);
