@@ -380,6 +380,17 @@ size_t ls3d_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout, int n_rows
 int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int grad_out_ld, const int32_t *tbl, const int32_t *row_order,
                       int kvol, int cin, int cout, int n_rows, const int32_t *n_rows_dev, int products, void *workspace,
                       size_t workspace_bytes, float *grad_w, ls3d_stream_t stream);
+/* The same in two steps, for layers that share one table (the SubM layers of a UNet level share their indice_key's table): the compacted
+ * (input row, output row) lists per kernel offset are built once - ls3d_spconv_pairs, an opaque 16-byte-aligned device buffer of
+ * ls3d_spconv_pairs_bytes(kvol, n_rows) - and every layer's weight gradient runs on them.  ls3d_spconv_wgrad is exactly
+ * ls3d_spconv_pairs into its own workspace followed by ls3d_spconv_wgrad_on_pairs: the two give bit-identical gradients.
+ * workspace of ls3d_spconv_wgrad_on_pairs: ls3d_spconv_wgrad_workspace_bytes (only its partial-sum part is used). */
+size_t ls3d_spconv_pairs_bytes(int kvol, int n_rows);
+int ls3d_spconv_pairs(const int32_t *tbl, const int32_t *row_order, int n_rows, const int32_t *n_rows_dev, int kvol, void *pairs,
+                      size_t pairs_bytes, ls3d_stream_t stream);
+int ls3d_spconv_wgrad_on_pairs(const float *in, int in_ld, const float *grad_out, int grad_out_ld, const void *pairs, int kvol, int cin,
+                               int cout, int n_rows, int products, void *workspace, size_t workspace_bytes, float *grad_w,
+                               ls3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Devoxelization

@@ -397,12 +397,37 @@ static inline int wg_chunks(int n_rows, int kvol, int cin) {
 }
 
 static inline size_t wg_align(size_t v) { return (v + 255) & ~(size_t)255; }
+// pair lists of one (table, row order): [pin kvol x n][pout kvol x n][block counts kvol x nb][pair counts kvol]
+extern "C" size_t ls3d_spconv_pairs_bytes(int kvol, int n_rows) {
+  const size_t nr = n_rows > 0 ? n_rows : 1, nb = (nr + PL_BLK - 1) / PL_BLK;
+  return 2 * wg_align((size_t)kvol * nr * 4) + wg_align((size_t)kvol * nb * 4) + wg_align((size_t)kvol * 4);
+}
 extern "C" size_t ls3d_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout, int n_rows) {
   if (cout > 128) cout = 128;  // wider layers run in slabs of 128 output columns through the same partial-sum buffer
-  const size_t nr = n_rows > 0 ? n_rows : 1, nb = (nr + PL_BLK - 1) / PL_BLK;
-  return wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cout * sizeof(float)) + 2 * wg_align((size_t)kvol * nr * 4) +
-         wg_align((size_t)kvol * nb * 4) + wg_align((size_t)kvol * 4) + 256;  // partial sums, pair lists (in, out), block counts, pair counts
+  return wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cout * sizeof(float)) + ls3d_spconv_pairs_bytes(kvol, n_rows) + 256;
 }
+
+extern "C" int ls3d_spconv_pairs(const int32_t *tbl, const int32_t *row_order, int n_rows, const int32_t *n_rows_dev, int kvol, void *pairs,
+                                 size_t pairs_bytes, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows == 0 && kvol >= 1) return LS3D_OK;
+  if (!tbl || !pairs || n_rows < 0 || kvol < 1) return LS3D_ERR_ARG;
+  if (pairs_bytes < ls3d_spconv_pairs_bytes(kvol, n_rows) || ((uintptr_t)pairs & 15)) return LS3D_ERR_WORKSPACE;
+  const int nb = (n_rows + PL_BLK - 1) / PL_BLK;
+  char *wsp = (char *)pairs;
+  int32_t *pin = (int32_t *)wsp; wsp += wg_align((size_t)kvol * n_rows * 4);
+  int32_t *pout = (int32_t *)wsp; wsp += wg_align((size_t)kvol * n_rows * 4);
+  int32_t *bcount = (int32_t *)wsp; wsp += wg_align((size_t)kvol * nb * 4);
+  int32_t *pair_cnt = (int32_t *)wsp;
+  hipLaunchKernelGGL(k_pairs_count, dim3(nb, kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, nb, bcount);
+  hipLaunchKernelGGL(k_pairs_scan, dim3(kvol), dim3(256), 0, stream, bcount, nb, pair_cnt);
+  hipLaunchKernelGGL(k_pairs_emit, dim3(nb, kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, nb, (const int32_t *)bcount, pin, pout);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+static int wg_on_pairs(const float *in, int in_ld, const float *grad_out, int go_ld, const void *pairs, int kvol, int cin, int cout, int n_rows,
+                       int products, void *workspace, float *grad_w, hipStream_t stream);
 
 extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int go_ld, const int32_t *tbl, const int32_t *row_order,
                                  int kvol, int cin, int cout, int n_rows, const int32_t *n_rows_dev, int products, void *workspace,
@@ -416,23 +441,41 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
   if (in_ld < cin || go_ld < cout) return LS3D_ERR_ARG;
   if (products != 0 && products != 6 && products != 8) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_spconv_wgrad_workspace_bytes(kvol, cin, cout, n_rows)) return LS3D_ERR_WORKSPACE;
-  const long long elems = (long long)kvol * cin * cout;
-  if (n_rows == 0) {
-    hipMemsetAsync(grad_w, 0, (size_t)elems * sizeof(float), stream);
+  // the pair lists go behind the partial sums of the same workspace
+  const int cw_max = cout < 128 ? cout : 128;
+  void *pairs = (char *)workspace + wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cw_max * sizeof(float));
+  const int rc = ls3d_spconv_pairs(tbl, row_order, n_rows, n_rows_dev, kvol, pairs, ls3d_spconv_pairs_bytes(kvol, n_rows), stream_);
+  if (rc != LS3D_OK) return rc;
+  return wg_on_pairs(in, in_ld, grad_out, go_ld, pairs, kvol, cin, cout, n_rows, products, workspace, grad_w, stream);
+}
+
+// the same on pair lists built once (ls3d_spconv_pairs) for every layer that shares the table: the SubM layers of a UNet level
+extern "C" int ls3d_spconv_wgrad_on_pairs(const float *in, int in_ld, const float *grad_out, int go_ld, const void *pairs, int kvol, int cin, int cout,
+                                          int n_rows, int products, void *workspace, size_t workspace_bytes, float *grad_w, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rows == 0 && grad_w && kvol >= 1 && cin >= 1 && cout >= 1) {
+    hipMemsetAsync(grad_w, 0, (size_t)kvol * cin * cout * sizeof(float), stream);
     return LS3D_OK;
   }
+  if (!in || !grad_out || !pairs || !grad_w || !workspace || kvol < 1 || cin < 1 || cout < 1 || n_rows < 0) return LS3D_ERR_ARG;
+  if (in_ld < cin || go_ld < cout) return LS3D_ERR_ARG;
+  if (products != 0 && products != 6 && products != 8) return LS3D_ERR_ARG;
+  const int cw_max = cout < 128 ? cout : 128;
+  if (workspace_bytes < wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cw_max * sizeof(float))) return LS3D_ERR_WORKSPACE;
+  return wg_on_pairs(in, in_ld, grad_out, go_ld, pairs, kvol, cin, cout, n_rows, products, workspace, grad_w, stream);
+}
+
+static int wg_on_pairs(const float *in, int in_ld, const float *grad_out, int go_ld, const void *pairs, int kvol, int cin, int cout, int n_rows,
+                       int products, void *workspace, float *grad_w, hipStream_t stream) {
   const int nchunks = wg_chunks(n_rows, kvol, cin);
   float *partial = (float *)workspace;
-  const int cout_all = cout, cw_max = cout < 128 ? cout : 128;
+  const int cout_all = cout;
   const int nb = (n_rows + PL_BLK - 1) / PL_BLK;
-  char *wsp = (char *)workspace + wg_align((size_t)nchunks * kvol * cin * cw_max * sizeof(float));
-  int32_t *tbl_t = (int32_t *)wsp; wsp += wg_align((size_t)kvol * n_rows * 4);   // pin[k][j]
-  int32_t *o_t = (int32_t *)wsp; wsp += wg_align((size_t)kvol * n_rows * 4);     // pout[k][j]
-  int32_t *bcount = (int32_t *)wsp; wsp += wg_align((size_t)kvol * nb * 4);
-  int32_t *pair_cnt = (int32_t *)wsp;
-  hipLaunchKernelGGL(k_pairs_count, dim3(nb, kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, nb, bcount);
-  hipLaunchKernelGGL(k_pairs_scan, dim3(kvol), dim3(256), 0, stream, bcount, nb, pair_cnt);
-  hipLaunchKernelGGL(k_pairs_emit, dim3(nb, kvol), dim3(256), 0, stream, tbl, row_order, n_rows, n_rows_dev, kvol, nb, (const int32_t *)bcount, tbl_t, o_t);
+  const char *wsp = (const char *)pairs;
+  const int32_t *tbl_t = (const int32_t *)wsp; wsp += wg_align((size_t)kvol * n_rows * 4);   // pin[k][j]
+  const int32_t *o_t = (const int32_t *)wsp; wsp += wg_align((size_t)kvol * n_rows * 4);     // pout[k][j]
+  wsp += wg_align((size_t)kvol * nb * 4);
+  const int32_t *pair_cnt = (const int32_t *)wsp;
   const dim3 grid((unsigned)(nchunks * wg_ci_groups(cin)), (unsigned)kvol);
   const dim3 grid_lds((unsigned)(nchunks * ((cin + 127) / 128)), (unsigned)kvol);  // k_spconv_wgrad_lds: tiles of 128 input channels
   const int products_all = products;

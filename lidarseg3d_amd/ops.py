@@ -686,11 +686,23 @@ def _tile_ws(nbytes, like):
 _WGRAD_PLANES = _os.environ.get("LS3D_WGRAD_PLANES", "1") != "0"
 
 
-def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None):
+def spconv_pairs(tbl, order=None):
+    """compacted (input row, output row) lists per kernel offset of one (table, row order), for spconv_wgrad(pairs=...): built once for
+    all the layers that share the table (ls3d_spconv_pairs)"""
+    n, kvol = tbl.shape
+    L = _L()
+    pairs = torch.empty((int(L.ls3d_spconv_pairs_bytes(kvol, n)),), dtype=torch.uint8, device=tbl.device)
+    check(L.ls3d_spconv_pairs(_ptr(tbl), _ptr(order), n, None, kvol, _ptr(pairs), ctypes.c_size_t(pairs.numel()), _stream(tbl)),
+          "ls3d_spconv_pairs")
+    return pairs
+
+
+def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None, pairs=None):
     """grad_w[kvol, cin, cout] of a sparse convolution: x = the forward input features (rows indexed by tbl), grad_out on the
     forward output rows, tbl/order = the table and row order of the forward launch.  products: 0 = exact-f32 MFMA kernel, 6 / 8 = the exact
     3-plane bf16 split (f32-grade; the library uses it for layers with >= 8 output blocks of 32 x 32 and the exact-f32 kernel below that);
-    None = ops.set_precision's product count (0 in "f32" / "bf16x3"; LS3D_WGRAD_PLANES=0 forces 0)."""
+    None = ops.set_precision's product count (0 in "f32" / "bf16x3"; LS3D_WGRAD_PLANES=0 forces 0).  pairs = spconv_pairs(tbl, order)
+    when several layers share the table (same result, the lists are not rebuilt)."""
     n, kvol = tbl.shape
     gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
     L = _L()
@@ -698,6 +710,11 @@ def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None):
     if products is None:
         products = tile_products() if _WGRAD_PLANES else 0
         products = 0 if products == 1 else products  # no plain-bf16 weight gradient: exact f32
+    if pairs is not None:
+        check(L.ls3d_spconv_wgrad_on_pairs(_ptr(x), x.shape[1], _ptr(grad_out), grad_out.shape[1], _ptr(pairs), kvol, cin, cout, n,
+                                           int(products), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(gw), _stream(x)),
+              "ls3d_spconv_wgrad_on_pairs")
+        return gw
     check(L.ls3d_spconv_wgrad(_ptr(x), x.shape[1], _ptr(grad_out), grad_out.shape[1], _ptr(tbl), _ptr(order), kvol, cin, cout, n, None,
                               int(products), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(gw), _stream(x)), "ls3d_spconv_wgrad")
     return gw

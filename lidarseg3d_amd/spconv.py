@@ -26,6 +26,8 @@ def _triple(v):
 # instead of 124 / 87 (~4 offsets per tile instead of ~27), but their two extra 4-pass sorts sit on the geometry stream in front of
 # the level-2 plan and the frame does not get shorter (LS3D_ORDER_MIN_CC=0: 6.08 vs 6.08 ms of convolutions) - left off.
 ORDER_MIN_CC = int(os.environ.get("LS3D_ORDER_MIN_CC", "4096"))
+# weight gradients of the layers that share a table run on one set of pair lists (LS3D_CACHE_PAIRS=0: each layer builds its own)
+CACHE_PAIRS = os.environ.get("LS3D_CACHE_PAIRS", "1") != "0"
 
 
 class SparseConvTensor(object):
@@ -67,7 +69,7 @@ class SparseModule(nn.Module):
 
 
 class _Rulebook(object):
-    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index", "_orders", "_plans", "batch_size",
+    __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index", "_orders", "_plans", "_pairs", "batch_size",
                  "n_in_dev", "n_out_dev", "overflow_dev")
 
     def rows_dev(self, inverse):
@@ -93,6 +95,16 @@ class _Rulebook(object):
             self._orders[inverse] = ops.rulebook_order(self.tbl_inv if inverse else self.tbl,
                                                        self.in_indices if inverse else self.out_indices, n_dev=self.rows_dev(inverse))
         return self._orders[inverse]
+
+    def pairs(self, inverse, ordered):
+        """compacted pair lists of the (inverse) table for the weight gradients (ops.spconv_pairs), built once per rulebook: every
+        layer of an indice_key shares them.  Dropped with the rulebook, so a training step holds them only until its backward ends."""
+        if getattr(self, "_pairs", None) is None:
+            self._pairs = {}
+        key = (inverse, ordered)
+        if key not in self._pairs:
+            self._pairs[key] = ops.spconv_pairs(self.tbl_inv if inverse else self.tbl, self.order(inverse) if ordered else None)
+        return self._pairs[key]
 
 
 class _SparseConvFn(torch.autograd.Function):
@@ -147,7 +159,8 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             tbl = rb.tbl_inv if inverse else rb.tbl
             order = rb.order(inverse) if cin * cout >= ORDER_MIN_CC else None
-            gw = ops.spconv_wgrad(feats.detach().contiguous(), gout, tbl, order, cin, cout).reshape(weight.shape)
+            pairs = rb.pairs(inverse, order is not None) if CACHE_PAIRS else None
+            gw = ops.spconv_wgrad(feats.detach().contiguous(), gout, tbl, order, cin, cout, pairs=pairs).reshape(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(0)
         return gin, gw, gb, None, None, None
@@ -208,7 +221,7 @@ class SparseConvolution(PackedModule, SparseModule):
             return x.find_indice_pair(self.indice_key)
         else:
             rb = _Rulebook()
-            rb._orders = rb._plans = None
+            rb._orders = rb._plans = rb._pairs = None
             rb.batch_size = x.batch_size
             rb.n_in_dev = rb.n_out_dev = rb.overflow_dev = None
             rb.in_indices, rb.in_shape = x.indices, list(x.spatial_shape)
@@ -259,7 +272,7 @@ class SparseConvolution(PackedModule, SparseModule):
 
 def subm_rulebook(indices, spatial_shape, kernel_size, batch_size=None, n_dev=None):
     rb = _Rulebook()
-    rb._orders = rb._plans = None
+    rb._orders = rb._plans = rb._pairs = None
     rb.batch_size = batch_size
     rb.kind = "subm"
     rb.n_in_dev = rb.n_out_dev = n_dev
@@ -321,7 +334,7 @@ def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, cap
         # the caller checks the overflow flags once per frame (UNetSCN3D.geometry_record)
         for c, icoords, ishape, oc, cnt, nbr_out, nbr_inv, oshape, n_in_dev in pend:
             rb = _Rulebook()
-            rb._orders = rb._plans = None
+            rb._orders = rb._plans = rb._pairs = None
             rb.batch_size = x.batch_size
             rb.kind, rb.in_indices, rb.in_shape = "conv", icoords, list(ishape)
             rb.out_indices, rb.out_shape = oc, oshape
@@ -335,7 +348,7 @@ def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, cap
     for (c, icoords, ishape, oc, cnt, nbr_out, nbr_inv, oshape), (n_out, overflow) in zip(pend, counts):
         assert not overflow
         rb = _Rulebook()
-        rb._orders = rb._plans = None
+        rb._orders = rb._plans = rb._pairs = None
         rb.batch_size = x.batch_size
         rb.n_in_dev = rb.n_out_dev = rb.overflow_dev = None
         rb.kind, rb.in_indices, rb.in_shape = "conv", (icoords if n_in == icoords.shape[0] else icoords[:n_in]), list(ishape)

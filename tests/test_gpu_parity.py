@@ -763,6 +763,7 @@ def test_wgrad_on_bf16_planes_is_f32_grade_gpu(cin, cout, products):
     got32 = ops.spconv_wgrad(X, G, T, None, cin, cout, products=0).double()
     gotp = ops.spconv_wgrad(X, G, T, None, cin, cout, products=products)
     assert torch.equal(gotp, ops.spconv_wgrad(X, G, T, None, cin, cout, products=products))
+    assert torch.equal(gotp, ops.spconv_wgrad(X, G, T, None, cin, cout, products=products, pairs=ops.spconv_pairs(T)))  # shared pair lists
     e32 = float((got32 - want).pow(2).mean().sqrt()) / scale
     ep = float((gotp.double() - want).pow(2).mean().sqrt()) / scale
     m32, mp = float((got32 - want).abs().max()) / scale, float((gotp.double() - want).abs().max()) / scale

@@ -536,6 +536,9 @@ def test_wgrad_on_bf16_planes_is_f32_grade(cin, cout, products):
     for name, pr, od in (("f32", 0, None), ("planes", products, None), ("planes_ordered", products, order)):
         got = ops.spconv_wgrad(tx, tg, tt, od, cin, cout, products=pr).numpy()
         err[name] = float((np.abs(got - want) / np.maximum(mag, 1e-30)).max())
+        # the two-step form (pair lists built once, shared by the layers of a table) is the same computation
+        shared = ops.spconv_wgrad(tx, tg, tt, od, cin, cout, products=pr, pairs=ops.spconv_pairs(tt, od)).numpy()
+        assert np.array_equal(shared, got), name
     assert err["planes"] <= 4 * err["f32"] + 2.0 ** -22 and err["planes_ordered"] <= 4 * err["f32"] + 2.0 ** -22, err
 
 
