@@ -283,42 +283,43 @@ __global__ __launch_bounds__(256, 2) void k_spconv_wgrad_lds(const float *__rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = acs[t][r] = 0.0f;
   // Row pipeline.  The 16 row indices of a group come with ONE unconditional vector load each (lane l holds row l & 15; rows past the end
-  // re-read row 0 and are masked) and are handed out with v_readlane - written as scalar loads under `r < N` conditions hipcc waited for
-  // each one before issuing the next: ~3 us per group, 8x the group's MFMA time.  The row loads are branch-free for the same reason
-  // (absent rows / channels past the end read a valid address and are zeroed afterwards).  Indices run three groups ahead of the MFMAs,
-  // rows two (two register sets in rotation): index latency, row latency and the MFMAs of a group overlap.
+  // re-read entry 0, a valid pair) and are handed out with v_readlane; every row load is unconditional too.  Nothing in the loop
+  // consumes a loaded value before the step that needs it: validity is a wave-uniform bit mask computed from the group number alone, rows
+  // past the end are zeroed at split time (only the last group of a list has any), channels past cin / cout are loaded from a clamped
+  // column and never stored.  (Selecting on the loaded values right behind the loads made hipcc wait for all 16 of them in place -
+  // vmcnt(0) per group, the whole memory latency exposed: 22 % MFMA busy.)  Indices run three groups ahead of the MFMAs in two register
+  // sets, rows two groups ahead in two more; the index load of a step is issued BEFORE its row loads, so that waiting for it (in the next
+  // step) leaves those row loads in flight (vmcnt counts in order).
   float ra0[8], rb0[8], ra1[8], rb1[8];
-  bool any0 = false, any1 = false, anyp = false;
-  int tkp = -1, op = 0;
-#define WGL_IDX(g_)                                                                              \
+  unsigned m0 = 0, m1 = 0, mP = 0, mQ = 0;  // valid rows (bit r = row r of the group) of the two row sets and the two index sets
+  int tkP = 0, opP = 0, tkQ = 0, opQ = 0;
+#define WGL_IDX(TK, OP, MK, g_)                                                                  \
   {                                                                                              \
     const int r16_ = (g_) * WGL_ROWS + (lane & 15);                                              \
     const bool v16_ = (g_) < g1 && r16_ < N;                                                     \
-    tkp = tk[v16_ ? r16_ : 0];                                                                   \
-    op = o_t[v16_ ? r16_ : 0];                                                                   \
-    if (!v16_) tkp = -1;                                                                         \
+    TK = tk[v16_ ? r16_ : 0];                                                                    \
+    OP = o_t[v16_ ? r16_ : 0];                                                                   \
+    MK = (unsigned)__ballot(v16_) & 0xFFFFu;                                                     \
   }
-#define WGL_ROWS_LOAD(RA, RB, ANY)                                                               \
+#define WGL_ROWS_LOAD(RA, RB, TK, OP)                                                            \
   {                                                                                              \
-    ANY = __any(tkp >= 0);                                                                       \
-    if (ANY) {                                                                                   \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
-        const int idx_ = __builtin_amdgcn_readlane(tkp, rg * 8 + j);                             \
-        const int o_ = __builtin_amdgcn_readlane(op, rg * 8 + j);                                \
-        const float *arow_ = in + (size_t)(idx_ >= 0 ? idx_ : 0) * in_ld;                        \
-        const float *brow_ = gout + (size_t)o_ * go_ld;                                          \
-        const float av_ = arow_[ca], bv_ = brow_[cbc];                                           \
-        RA[j] = (idx_ >= 0 && a_in) ? av_ : 0.0f;                                                \
-        RB[j] = (idx_ >= 0 && b_in) ? bv_ : 0.0f;                                                \
-      }                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                              \
+      const int idx_ = __builtin_amdgcn_readlane(TK, rg * 8 + j);                                \
+      const int o_ = __builtin_amdgcn_readlane(OP, rg * 8 + j);                                  \
+      RA[j] = in[(size_t)idx_ * in_ld + ca];                                                     \
+      RB[j] = gout[(size_t)o_ * go_ld + cbc];                                                    \
     }                                                                                            \
   }
-  // one group: split this set's rows into LDS, refill the set with the rows of the group whose indices are pending, fetch the
-  // indices of group gi_, multiply
-#define WGL_STEP(RA, RB, ANY, gi_)                                                               \
+  // one group: split this set's rows into LDS, fetch the indices of group gi_ into the free index set, refill the row set with the rows
+  // of the group whose indices are pending in the other one, multiply
+#define WGL_STEP(RA, RB, MS, TKU, OPU, MKU, TKL, OPL, MKL, gi_)                                  \
   {                                                                                              \
-    const bool any = ANY;                                                                        \
-    if (any) {                                                                                   \
+    const unsigned ms_ = MS;                                                                     \
+    if (ms_) {                                                                                   \
+      if (ms_ != 0xFFFFu) {                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                            \
+          if (!((ms_ >> (rg * 8 + j)) & 1u)) RA[j] = RB[j] = 0.0f;                               \
+      }                                                                                          \
       uint4 h, m, l;                                                                             \
       if (a_live) {                                                                              \
         ls3d_split_pair3_rne(RA[0], RA[1], h.x, m.x, l.x);                                       \
@@ -335,23 +336,35 @@ __global__ __launch_bounds__(256, 2) void k_spconv_wgrad_lds(const float *__rest
         sB[buf][0][rg][c] = h; sB[buf][1][rg][c] = m; sB[buf][2][rg][c] = l;                     \
       }                                                                                          \
     }                                                                                            \
-    WGL_ROWS_LOAD(RA, RB, ANY)                                                                   \
-    WGL_IDX(gi_)                                                                                 \
-    if (any) {                                                                                   \
+    WGL_IDX(TKL, OPL, MKL, gi_)                                                                  \
+    LS3D_SCHED_FENCE(); /* index loads stay in front of the row loads */                         \
+    WGL_ROWS_LOAD(RA, RB, TKU, OPU)                                                              \
+    LS3D_SCHED_FENCE();                                                                          \
+    MS = MKU;                                                                                    \
+    if (ms_) {                                                                                   \
       __syncthreads();                                                                           \
       wgl_multiply<NP>(sA[buf], sB[buf], acc, acs, wave, i, half, nblk, NB);                     \
       buf ^= 1;                                                                                  \
     }                                                                                            \
   }
   int buf = 0;
-  WGL_IDX(g0)
-  WGL_ROWS_LOAD(ra0, rb0, any0)
-  WGL_IDX(g0 + 1)
-  WGL_ROWS_LOAD(ra1, rb1, any1)
-  WGL_IDX(g0 + 2)
-  for (int g = g0; g < g1; g += 2) {
-    WGL_STEP(ra0, rb0, any0, g + 3)
-    WGL_STEP(ra1, rb1, any1, g + 4)
+  if (g0 < g1) {  // (an empty chunk has nothing to read: entry 0 of an empty list is not a pair)
+    // (the prologue leaves the loads in the order a loop step does - indices of g0 + 2, then the rows of g0 + 1 - so that the wait counts
+    // hipcc derives for the loop head are the steady-state ones on both ways in)
+    WGL_IDX(tkP, opP, mP, g0)
+    WGL_ROWS_LOAD(ra0, rb0, tkP, opP)
+    m0 = mP;
+    WGL_IDX(tkQ, opQ, mQ, g0 + 1)
+    LS3D_SCHED_FENCE();
+    WGL_IDX(tkP, opP, mP, g0 + 2)
+    LS3D_SCHED_FENCE();
+    WGL_ROWS_LOAD(ra1, rb1, tkQ, opQ)
+    LS3D_SCHED_FENCE();
+    m1 = mQ;
+    for (int g = g0; g < g1; g += 2) {
+      WGL_STEP(ra0, rb0, m0, tkP, opP, mP, tkQ, opQ, mQ, g + 3)
+      WGL_STEP(ra1, rb1, m1, tkQ, opQ, mQ, tkP, opP, mP, g + 4)
+    }
   }
 #undef WGL_STEP
 #undef WGL_ROWS_LOAD
