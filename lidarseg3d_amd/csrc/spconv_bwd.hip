@@ -129,53 +129,67 @@ __global__ __launch_bounds__(256) void k_spconv_wgrad(const float *__restrict__ 
   for (int n = 0; n < COB; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-  // two-stage software pipeline over groups of WG_UNROLL row pairs: the operands of group g + 1 are loaded before the MFMAs
-  // of group g are issued, the (contiguous) indices of group g + 2 before that
-  int o_n[WG_UNROLL], idx_n[WG_UNROLL];
-  float a_c[WG_UNROLL], b_c[WG_UNROLL][COB];
-  unsigned any_c = 0u;
-#define WG_LOAD_IDX(p_)                                                                       \
+  // Software pipeline over groups of WG_UNROLL row pairs, written so that hipcc never waits for a load before the step that consumes it
+  // (the same rules as in k_spconv_wgrad_lds below): every load is unconditional - rows past the end re-read entry 0 of the list (a valid
+  // pair), channels past cin / cout a clamped column whose products are never stored - validity is a function of the position alone and is
+  // applied when a set is consumed (only the last group of a list has invalid rows); indices run three groups ahead of the MFMAs in two
+  // register sets, operands two groups ahead in two more, the index loads of a step in front of its operand loads (vmcnt counts in
+  // order: waiting for the indices leaves the operands in flight); the MFMAs are unconditional, so the accumulators never move.
+  const int cic = ci < cin ? ci : cin - 1;
+  int colc[COB];
+#pragma unroll
+  for (int n = 0; n < COB; ++n) colc[n] = n * 32 + i < cout ? n * 32 + i : cout - 1;
+  int oP[WG_UNROLL], iP[WG_UNROLL], oQ[WG_UNROLL], iQ[WG_UNROLL];
+  float a0[WG_UNROLL], b0[WG_UNROLL][COB], a1[WG_UNROLL], b1[WG_UNROLL][COB];
+#define WG_LOAD_IDX(IX, OX, p_)                                                               \
   _Pragma("unroll") for (int u = 0; u < WG_UNROLL; ++u) {                                     \
     const int r_ = 2 * ((p_) + u) + half;                                                     \
     const bool ok_ = (p_) + u < p1 && r_ < N;                                                 \
-    o_n[u] = ok_ ? o_t[r_] : -1;                                                              \
-    idx_n[u] = ok_ ? tk[r_] : -1;                                                             \
+    OX[u] = o_t[ok_ ? r_ : 0];                                                                \
+    IX[u] = tk[ok_ ? r_ : 0];                                                                 \
   }
-#define WG_LOAD_OPS()                                                                         \
-  any_c = 0u;                                                                                 \
+#define WG_LOAD_OPS(A, B, IX, OX)                                                             \
   _Pragma("unroll") for (int u = 0; u < WG_UNROLL; ++u) {                                     \
-    const bool on_ = idx_n[u] >= 0;                                                           \
-    if (__any(on_)) any_c |= 1u << u;                                                         \
-    a_c[u] = (on_ && ci < cin) ? in[(size_t)idx_n[u] * in_ld + ci] : 0.0f;                    \
-    _Pragma("unroll") for (int n = 0; n < COB; ++n)                                           \
-        b_c[u][n] = (on_ && n * 32 + i < cout) ? gout[(size_t)o_n[u] * go_ld + n * 32 + i] : 0.0f; \
+    A[u] = in[(size_t)IX[u] * in_ld + cic];                                                   \
+    _Pragma("unroll") for (int n = 0; n < COB; ++n) B[u][n] = gout[(size_t)OX[u] * go_ld + colc[n]]; \
+  }
+  // one group at position p_: take the set's operands (zero the rows past the end), fetch the indices of the group three ahead into the free
+  // index set, refill the operand set through the other index set, multiply
+#define WG_STEP(A, B, IXU, OXU, IXL, OXL, p_)                                                 \
+  {                                                                                           \
+    float a[WG_UNROLL], bb[WG_UNROLL][COB];                                                   \
+    const bool full_ = (p_) + WG_UNROLL <= p1 && 2 * ((p_) + WG_UNROLL) <= N;                 \
+    _Pragma("unroll") for (int u = 0; u < WG_UNROLL; ++u) {                                   \
+      const bool ok_ = full_ || ((p_) + u < p1 && 2 * ((p_) + u) + half < N);                 \
+      a[u] = ok_ ? A[u] : 0.0f;                                                               \
+      _Pragma("unroll") for (int n = 0; n < COB; ++n) bb[u][n] = ok_ ? B[u][n] : 0.0f;        \
+    }                                                                                         \
+    LS3D_SCHED_FENCE();                                                                       \
+    WG_LOAD_IDX(IXL, OXL, (p_) + 3 * pstep)                                                   \
+    LS3D_SCHED_FENCE();                                                                       \
+    WG_LOAD_OPS(A, B, IXU, OXU)                                                               \
+    LS3D_SCHED_FENCE();                                                                       \
+    _Pragma("unroll") for (int u = 0; u < WG_UNROLL; ++u)                                     \
+      _Pragma("unroll") for (int n = 0; n < COB; ++n)                                         \
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb[u][n], acc[n], 0, 0, 0);     \
   }
   const int pstep = RG * WG_UNROLL;
   int p = p0 + rg * WG_UNROLL;
-  WG_LOAD_IDX(p)
-  WG_LOAD_OPS()
-  if (p + pstep < p1) { WG_LOAD_IDX(p + pstep) }
-  for (; p < p1; p += pstep) {
-    float a[WG_UNROLL], bb[WG_UNROLL][COB];
-    const unsigned any = any_c;
-#pragma unroll
-    for (int u = 0; u < WG_UNROLL; ++u) {
-      a[u] = a_c[u];
-#pragma unroll
-      for (int n = 0; n < COB; ++n) bb[u][n] = b_c[u][n];
-    }
-    if (p + pstep < p1) {
-      WG_LOAD_OPS()                                                // operands of the next group (indices already here)
-      if (p + 2 * pstep < p1) { WG_LOAD_IDX(p + 2 * pstep) }       // indices of the group after it
-    }
-#pragma unroll
-    for (int u = 0; u < WG_UNROLL; ++u) {
-      if ((any >> u) & 1u) {
-#pragma unroll
-        for (int n = 0; n < COB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bb[u][n], acc[n], 0, 0, 0);
-      }
+  if (p0 < p1) {  // (entry 0 of an empty list is not a pair: nothing is read then)
+    WG_LOAD_IDX(iP, oP, p)
+    WG_LOAD_OPS(a0, b0, iP, oP)
+    WG_LOAD_IDX(iQ, oQ, p + pstep)
+    LS3D_SCHED_FENCE();
+    WG_LOAD_IDX(iP, oP, p + 2 * pstep)
+    LS3D_SCHED_FENCE();
+    WG_LOAD_OPS(a1, b1, iQ, oQ)
+    LS3D_SCHED_FENCE();
+    for (; p < p1; p += 2 * pstep) {
+      WG_STEP(a0, b0, iP, oP, iQ, oQ, p)
+      WG_STEP(a1, b1, iQ, oQ, iP, oP, p + pstep)
     }
   }
+#undef WG_STEP
 #undef WG_LOAD_IDX
 #undef WG_LOAD_OPS
   // ---- the row groups 1..RG-1 of a cin block hand their tiles to row group 0 one after the other (fixed order; at most two
