@@ -406,6 +406,26 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *partial, int 
     gw[(t / cw) * cout + col0 + (t % cw)] = s;
   }
 }
+// the same for many chunks of a small gradient (a Linear layer: <= 1024 chunks of <= 256 x 128 sums): a workgroup owns 32 elements, its 8
+// thread groups each add every 8th chunk in order, then the 8 sums are added in order - a fixed summation tree with 8 x the threads
+__global__ __launch_bounds__(256) void k_wgrad_reduce_split(const float *partial, int nchunks, long long elems, int cw, int cout, int col0, float *gw) {
+  __shared__ float red[8][32];
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long long t = (long long)blockIdx.x * 32 + lane;
+  float s = 0.0f;
+  if (t < elems) {
+#pragma unroll 8
+    for (int c = grp; c < nchunks; c += 8) s += partial[(size_t)c * elems + t];
+  }
+  red[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && t < elems) {
+    float v = red[0][lane];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) v += red[g][lane];
+    gw[(t / cw) * cout + col0 + (t % cw)] = v;
+  }
+}
 
 static inline int wg_ci_groups(int cin) {
   const int ci_blocks = (cin + 31) / 32, ciw = ci_blocks >= 4 ? 4 : ci_blocks >= 2 ? 2 : 1;
@@ -413,13 +433,17 @@ static inline int wg_ci_groups(int cin) {
 }
 
 static inline int wg_chunks(int n_rows, int kvol, int cin) {
-  // enough workgroups for 256 CUs x ~8, at least ~256 row pairs per chunk
+  // enough workgroups for 256 CUs x ~8, at least ~256 row pairs per chunk; the chunks' partial sums (kvol x cin x <= 128 floats each,
+  // written once and read once by the reduction) stay under ~256 MB.  Few offsets (a Linear layer's weight gradient is one offset
+  // over 10^5..10^6 rows) need many chunks: a fixed cap of 96 left 160 CUs idle there.
   const long long per = (long long)kvol * wg_ci_groups(cin);
   long long want = (2048 + per - 1) / per;
   long long cap = ((long long)n_rows / 2 + 255) / 256;
   if (want > cap) want = cap;
+  long long cap_bytes = (256ll << 20) / ((long long)kvol * cin * 128 * 4);
+  if (cap_bytes > 1024) cap_bytes = 1024;
+  if (want > cap_bytes) want = cap_bytes;
   if (want < 1) want = 1;
-  if (want > 96) want = 96;
   return (int)want;
 }
 
@@ -534,7 +558,11 @@ static int wg_on_pairs(const float *in, int in_ld, const float *grad_out, int go
                        cin, cout, n_rows, (const int32_t *)pair_cnt, nchunks, partial);
   }
 #undef LS3D_WG
-  hipLaunchKernelGGL(k_wgrad_reduce, ls3d_grid(elems), dim3(256), 0, stream, (const float *)partial, nchunks, elems, cout, cout_all, col0, grad_w);
+  if (nchunks > 128)
+    hipLaunchKernelGGL(k_wgrad_reduce_split, dim3((unsigned)((elems + 31) / 32)), dim3(256), 0, stream, (const float *)partial, nchunks, elems, cout,
+                       cout_all, col0, grad_w);
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce, ls3d_grid(elems), dim3(256), 0, stream, (const float *)partial, nchunks, elems, cout, cout_all, col0, grad_w);
   }
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;

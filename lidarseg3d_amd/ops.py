@@ -735,19 +735,22 @@ def linear_wgrad(x, gy, products=None):
     if products is None:
         products = 6 if cin >= 128 else 0
     key = (x.device, n)
-    tbl = _ARANGE.get(key)
-    if tbl is None:
+    ident = _ARANGE.get(key)
+    if ident is None:
         if len(_ARANGE) > 8:
             _ARANGE.clear()
-        tbl = _ARANGE[key] = torch.arange(n, dtype=_i32, device=x.device).unsqueeze(1).contiguous()
+        tbl = torch.arange(n, dtype=_i32, device=x.device).unsqueeze(1).contiguous()
+        ident = _ARANGE[key] = (tbl, spconv_pairs(tbl))  # the identity table and its pair lists, built once per row count
+    pairs = ident[1]
     L = _L()
     gw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
     for c0 in range(0, cout, 128):
         c1 = min(c0 + 128, cout)
         part = torch.empty((1, cin, c1 - c0), dtype=torch.float32, device=x.device)
         ws = _ws(L.ls3d_spconv_wgrad_workspace_bytes(1, cin, c1 - c0, n), x)
-        check(L.ls3d_spconv_wgrad(_ptr(x), x.shape[1], ctypes.c_void_p(gy.data_ptr() + 4 * c0), gy.shape[1], _ptr(tbl), None, 1, cin, c1 - c0, n, None,
-                                  int(products), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(part), _stream(x)), "ls3d_spconv_wgrad")
+        check(L.ls3d_spconv_wgrad_on_pairs(_ptr(x), x.shape[1], ctypes.c_void_p(gy.data_ptr() + 4 * c0), gy.shape[1], _ptr(pairs), 1, cin, c1 - c0, n,
+                                           int(products), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(part), _stream(x)),
+              "ls3d_spconv_wgrad_on_pairs")
         gw[c0:c1] = part[0].t()
     return gw
 
