@@ -723,6 +723,18 @@ def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None, pairs=None):
 _ARANGE = {}
 
 
+def _identity(device, n):
+    """(identity table [n, 1], its pair lists), built once per row count"""
+    key = (device, n)
+    ident = _ARANGE.get(key)
+    if ident is None:
+        if len(_ARANGE) > 8:
+            _ARANGE.clear()
+        tbl = torch.arange(n, dtype=_i32, device=device).unsqueeze(1).contiguous()
+        ident = _ARANGE[key] = (tbl, spconv_pairs(tbl))
+    return ident
+
+
 def linear_wgrad(x, gy, products=None):
     """grad_W [cout, cin] = gy^T x of a Linear layer over many rows (x [n, cin], gy [n, cout], both row-major): the tall-skinny GEMM
     (n = 10^5..10^6 rows reduced into a <= 256 x 256 matrix) that hipBLASLt serves with 32 x 32 macro tiles at ~10 TFLOP/s - here it is
@@ -734,14 +746,7 @@ def linear_wgrad(x, gy, products=None):
     cout = gy.shape[1]
     if products is None:
         products = 6 if cin >= 128 else 0
-    key = (x.device, n)
-    ident = _ARANGE.get(key)
-    if ident is None:
-        if len(_ARANGE) > 8:
-            _ARANGE.clear()
-        tbl = torch.arange(n, dtype=_i32, device=x.device).unsqueeze(1).contiguous()
-        ident = _ARANGE[key] = (tbl, spconv_pairs(tbl))  # the identity table and its pair lists, built once per row count
-    pairs = ident[1]
+    pairs = _identity(x.device, n)[1]
     L = _L()
     gw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
     for c0 in range(0, cout, 128):

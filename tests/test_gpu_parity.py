@@ -771,6 +771,20 @@ def test_wgrad_on_bf16_planes_is_f32_grade_gpu(cin, cout, products):
     assert ep <= 1.05 * e32 + 1e-9 and mp <= 1.5 * m32 + 1e-8, (ep, e32, mp, m32)
 
 
+@pytest.mark.parametrize("cin,cout", [(96, 96), (192, 96), (64, 192)])
+def test_linear_weight_gradient_gpu(cin, cout):
+    """ops.linear_wgrad on 360k rows (one kernel offset over many row chunks: the chunk count is bounded by the partial
+    sums' bytes, the reduction over > 128 chunks is the split one) against float64; bitwise reproducible"""
+    torch.manual_seed(cin + cout)
+    n = 360000
+    x = torch.randn(n, cin, device=DEV).relu_()
+    gy = torch.randn(n, cout, device=DEV) * 0.1
+    want = gy.double().t() @ x.double()
+    got = ops.linear_wgrad(x, gy)
+    assert torch.equal(got, ops.linear_wgrad(x, gy))
+    assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (128, 128), (96, 32)])
 def test_sparse_conv_backward_gpu(cin, cout):
     """dgrad (gather-GEMM on the transposed tables) and wgrad (ls3d_spconv_wgrad) of SubM / strided / inverse convolutions on
