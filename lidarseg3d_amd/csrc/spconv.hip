@@ -291,9 +291,17 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather
 #pragma unroll
       for (int r = 0; r < 16; ++r) acs[n][r] = 0.0f;
     if (rem) {
-      int k_cur = __ffsll((long long)rem) - 1;
-      rem &= rem - 1;
-      int k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
+      // active offsets are taken off `rem` lowest first; the neighbour index of an offset is loaded TWO offsets before its rows are
+      // (k_nn / idx_nn, an unconditional load from a clamped address whose validity is applied when it moves up): loaded one offset
+      // ahead and under its validity condition it was waited for in place
+#define LS3D_LOAD_IDX_RAW(k) (SPARSE ? tbl[(size_t)(row >= 0 ? row : 0) * kvol + ((k) >= 0 ? (k) : 0)] : row)
+#define LS3D_POP_OFFSET(k)                       \
+  {                                              \
+    k = rem ? __ffsll((long long)rem) - 1 : -1;  \
+    rem &= rem - 1;                              \
+  }
+      int k_cur, k_nxt, k_nn;
+      LS3D_POP_OFFSET(k_cur) LS3D_POP_OFFSET(k_nxt) LS3D_POP_OFFSET(k_nn)
 #define LS3D_LOAD_IDX(k) ((row >= 0) ? (SPARSE ? tbl[(size_t)row * kvol + (k)] : row) : -1)
 #define LS3D_LOAD_A(dst, idx, c0_)                                                              \
   do {                                                                                          \
@@ -327,6 +335,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather
   } while (0)
       int idx_cur = LS3D_LOAD_IDX(k_cur);
       int idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
+      int idx_nn = LS3D_LOAD_IDX_RAW(k_nn);
       float4 a_cur[4], a_nxt[4];
       float4 breg0, breg1, breg2, breg3, breg4, breg5;
       static_assert(BPT <= 6, "weight chunk too large for the staging registers");
@@ -407,13 +416,15 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather
         for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
         if (nk != k_cur) {
           k_cur = nk; idx_cur = idx_nxt;
-          rem &= rem - 1;
-          k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
-          idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
+          k_nxt = k_nn; idx_nxt = (k_nn >= 0 && row >= 0) ? idx_nn : -1;
+          LS3D_POP_OFFSET(k_nn)
+          idx_nn = LS3D_LOAD_IDX_RAW(k_nn);
         }
         c0 = nc0;
       }
     }
+#undef LS3D_POP_OFFSET
+#undef LS3D_LOAD_IDX_RAW
 #undef LS3D_LOAD_IDX
 #undef LS3D_LOAD_A
 #undef LS3D_LOAD_B
