@@ -303,46 +303,50 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather
       int k_cur, k_nxt, k_nn;
       LS3D_POP_OFFSET(k_cur) LS3D_POP_OFFSET(k_nxt) LS3D_POP_OFFSET(k_nn)
 #define LS3D_LOAD_IDX(k) ((row >= 0) ? (SPARSE ? tbl[(size_t)row * kvol + (k)] : row) : -1)
-#define LS3D_LOAD_A(dst, idx, c0_)                                                              \
+// the 16 floats of a row are loaded UNCONDITIONALLY: an absent neighbour reads 64 valid bytes of the packed weights instead and is zeroed when
+// the registers move up (`valid`: at the end of a chunk, behind the wait that the weights need anyway).  Loads under a per-lane condition are loads hipcc cannot count on: it then waited for them in
+// place - `s_waitcnt vmcnt(1)` right behind the four row loads, in front of the weight loads - and the gather latency of every chunk
+// was exposed.
+#define LS3D_LOAD_A(dst, valid, idx, c0_)                                                       \
   do {                                                                                          \
-    if ((idx) >= 0) {                                                                           \
-      const float4 *p_ = (const float4 *)(in + (size_t)(idx)*in_ld + (c0_) + kk * 16);          \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) dst[q] = p_[q];                             \
-    } else {                                                                                    \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);   \
-    }                                                                                           \
+    valid = (idx) >= 0;                                                                         \
+    const float4 *p_ = valid ? (const float4 *)(in + (size_t)(idx)*in_ld + (c0_) + kk * 16) : (const float4 *)wbase; \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) dst[q] = p_[q];                               \
   } while (0)
-#define LS3D_B_ONE(j, reg, OP)                                                                  \
+#define LS3D_B_ONE(j, reg, OP, UNCOND)                                                                \
   if constexpr (BPT > (j)) {                                                                    \
     const int i_ = tid + (j)*256;                                                               \
-    if (BV % 256 == 0 || i_ < BV) { OP(reg, i_); }                                              \
+    if (UNCOND || BV % 256 == 0 || i_ < BV) { OP(reg, i_); }                                    \
   }
-#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)(i_)*4)
+#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)((BV % 256 == 0 || (i_) < BV) ? (i_) : BV - 1) * 4) /* unconditional, clamped */
 #define LS3D_B_ST(reg, i_) *(float4 *)(dst_ + (i_)*4) = reg
 #define LS3D_LOAD_B(k, c0_)                                                                     \
   do {                                                                                          \
     const float *wk_ = wbase + ((size_t)(k) * nslab * (cin / KC) + (c0_) / KC) * CHF;           \
-    LS3D_B_ONE(0, breg0, LS3D_B_LD) LS3D_B_ONE(1, breg1, LS3D_B_LD)                             \
-    LS3D_B_ONE(2, breg2, LS3D_B_LD) LS3D_B_ONE(3, breg3, LS3D_B_LD)                             \
-    LS3D_B_ONE(4, breg4, LS3D_B_LD) LS3D_B_ONE(5, breg5, LS3D_B_LD)                             \
+    LS3D_B_ONE(0, breg0, LS3D_B_LD, true) LS3D_B_ONE(1, breg1, LS3D_B_LD, true)                             \
+    LS3D_B_ONE(2, breg2, LS3D_B_LD, true) LS3D_B_ONE(3, breg3, LS3D_B_LD, true)                             \
+    LS3D_B_ONE(4, breg4, LS3D_B_LD, true) LS3D_B_ONE(5, breg5, LS3D_B_LD, true)                             \
   } while (0)
 #define LS3D_STORE_B(dst)                                                                       \
   do {                                                                                          \
     float *dst_ = (dst);                                                                        \
-    LS3D_B_ONE(0, breg0, LS3D_B_ST) LS3D_B_ONE(1, breg1, LS3D_B_ST)                             \
-    LS3D_B_ONE(2, breg2, LS3D_B_ST) LS3D_B_ONE(3, breg3, LS3D_B_ST)                             \
-    LS3D_B_ONE(4, breg4, LS3D_B_ST) LS3D_B_ONE(5, breg5, LS3D_B_ST)                             \
+    LS3D_B_ONE(0, breg0, LS3D_B_ST, false) LS3D_B_ONE(1, breg1, LS3D_B_ST, false)                             \
+    LS3D_B_ONE(2, breg2, LS3D_B_ST, false) LS3D_B_ONE(3, breg3, LS3D_B_ST, false)                             \
+    LS3D_B_ONE(4, breg4, LS3D_B_ST, false) LS3D_B_ONE(5, breg5, LS3D_B_ST, false)                             \
   } while (0)
       int idx_cur = LS3D_LOAD_IDX(k_cur);
       int idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
       int idx_nn = LS3D_LOAD_IDX_RAW(k_nn);
       float4 a_cur[4], a_nxt[4];
+      bool va_cur = false, va_nxt = false;  // the row loaded into a_cur / a_nxt exists
       float4 breg0, breg1, breg2, breg3, breg4, breg5;
       static_assert(BPT <= 6, "weight chunk too large for the staging registers");
       int c0 = 0, buf = 0;
-      LS3D_LOAD_A(a_cur, idx_cur, 0);
+      LS3D_LOAD_A(a_cur, va_cur, idx_cur, 0);
       LS3D_LOAD_B(k_cur, 0);
       LS3D_STORE_B(Bs[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_cur[q] = va_cur ? a_cur[q] : make_float4(0.f, 0.f, 0.f, 0.f);  // (nothing in flight at the loop head)
       __syncthreads();
       for (;;) {
         int nk = k_cur, nc0 = c0 + KC, nidx = idx_cur;
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather
           has_next = nk >= 0;
         }
         if (has_next) {
-          LS3D_LOAD_A(a_nxt, nidx, nc0);
+          LS3D_LOAD_A(a_nxt, va_nxt, nidx, nc0);
           LS3D_LOAD_B(nk, nc0);
         }
         if ((wmask >> k_cur) & 1ull) {
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather
         __syncthreads();
         buf ^= 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+        for (int q = 0; q < 4; ++q) a_cur[q] = va_nxt ? a_nxt[q] : make_float4(0.f, 0.f, 0.f, 0.f);  // (behind the wait for this chunk's loads)
         if (nk != k_cur) {
           k_cur = nk; idx_cur = idx_nxt;
           k_nxt = k_nn; idx_nxt = (k_nn >= 0 && row >= 0) ? idx_nn : -1;
