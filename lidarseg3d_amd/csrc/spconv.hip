@@ -110,49 +110,62 @@ __global__ __launch_bounds__(256, (NT == 1 && WC == 1) ? 5 : (NT == 2 && WC == 1
     if (rem) {
       // ---- software pipeline over the chunks (k, c0): while chunk i feeds the MFMAs, the gathered A rows and
       //      the weight chunk of i+1 are already in flight (registers / the other LDS buffer).
-      int k_cur = __ffsll((long long)rem) - 1;
-      rem &= rem - 1;
-      int k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
+      //      Every load in the loop is unconditional (k_gather_gemm_bf16x3 below has the why): the neighbour index comes two offsets
+      //      ahead from a clamped address, an absent neighbour's row reads valid bytes of the weights and is zeroed when the registers
+      //      move up, the weight loads are clamped.
+#define LS3D_POP_OFFSET(k)                       \
+  {                                              \
+    k = rem ? __ffsll((long long)rem) - 1 : -1;  \
+    rem &= rem - 1;                              \
+  }
+      int k_cur, k_nxt, k_nn;
+      LS3D_POP_OFFSET(k_cur) LS3D_POP_OFFSET(k_nxt) LS3D_POP_OFFSET(k_nn)
 #define LS3D_LOAD_IDX(k) ((row >= 0) ? (SPARSE ? tbl[(size_t)row * kvol + (k)] : row) : -1)
-#define LS3D_LOAD_A(dst, idx, c0_)                                                              \
+#define LS3D_LOAD_IDX_RAW(k) (SPARSE ? tbl[(size_t)(row >= 0 ? row : 0) * kvol + ((k) >= 0 ? (k) : 0)] : row)
+#define LS3D_LOAD_A(dst, valid, idx, c0_)                                                       \
   do {                                                                                          \
-    if ((idx) >= 0) {                                                                           \
-      const float4 *p_ = (const float4 *)(in + (size_t)(idx)*in_ld + (c0_) + kk * SPL);         \
-      _Pragma("unroll") for (int q = 0; q < SPL / 4; ++q) dst[q] = p_[q];                       \
-    } else {                                                                                    \
-      _Pragma("unroll") for (int q = 0; q < SPL / 4; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f); \
-    }                                                                                           \
+    valid = (idx) >= 0;                                                                         \
+    const float4 *p_ = valid ? (const float4 *)(in + (size_t)(idx)*in_ld + (c0_) + kk * SPL) : (const float4 *)wbase; \
+    _Pragma("unroll") for (int q = 0; q < SPL / 4; ++q) dst[q] = p_[q];                         \
   } while (0)
 // weight staging registers are named scalars (not an array): an array indexed inside the pipelined loop is not
 // promoted to registers by hipcc and ends up in scratch.  Float4 i_ of the chunk = piece (i_/PV), offset (i_%PV).
-#define LS3D_B_ONE(j, reg, OP)                                                                  \
+#define LS3D_B_ONE(j, reg, OP, UNCOND)                                                          \
   if constexpr (BPT > (j)) {                                                                    \
     const int i_ = tid + (j)*256;                                                               \
-    if (BV % 256 == 0 || i_ < BV) { OP(reg, i_); }                                              \
+    if (UNCOND || BV % 256 == 0 || i_ < BV) { OP(reg, i_); }                                    \
   }
-#define LS3D_B_LD(reg, i_) reg = *(const float4 *)(wk_ + (size_t)((i_) / PV) * cin * WSLAB + (size_t)((i_) % PV) * 4)
+#define LS3D_B_LD(reg, i_)                                                                      \
+  {                                                                                             \
+    const int ic_ = (BV % 256 == 0 || (i_) < BV) ? (i_) : BV - 1; /* unconditional, clamped */  \
+    reg = *(const float4 *)(wk_ + (size_t)(ic_ / PV) * cin * WSLAB + (size_t)(ic_ % PV) * 4);   \
+  }
 #define LS3D_B_ST(reg, i_) *(float4 *)(dst_ + (i_)*4) = reg
 #define LS3D_LOAD_B(k, c0_)                                                                     \
   do {                                                                                          \
     const float *wk_ = wbase + ((size_t)(k)*cin * nwslab + (c0_)) * WSLAB;                      \
-    LS3D_B_ONE(0, breg0, LS3D_B_LD) LS3D_B_ONE(1, breg1, LS3D_B_LD)                             \
-    LS3D_B_ONE(2, breg2, LS3D_B_LD) LS3D_B_ONE(3, breg3, LS3D_B_LD)                             \
+    LS3D_B_ONE(0, breg0, LS3D_B_LD, true) LS3D_B_ONE(1, breg1, LS3D_B_LD, true)                 \
+    LS3D_B_ONE(2, breg2, LS3D_B_LD, true) LS3D_B_ONE(3, breg3, LS3D_B_LD, true)                 \
   } while (0)
 #define LS3D_STORE_B(dst)                                                                       \
   do {                                                                                          \
     float *dst_ = (dst);                                                                        \
-    LS3D_B_ONE(0, breg0, LS3D_B_ST) LS3D_B_ONE(1, breg1, LS3D_B_ST)                             \
-    LS3D_B_ONE(2, breg2, LS3D_B_ST) LS3D_B_ONE(3, breg3, LS3D_B_ST)                             \
+    LS3D_B_ONE(0, breg0, LS3D_B_ST, false) LS3D_B_ONE(1, breg1, LS3D_B_ST, false)               \
+    LS3D_B_ONE(2, breg2, LS3D_B_ST, false) LS3D_B_ONE(3, breg3, LS3D_B_ST, false)               \
   } while (0)
       int idx_cur = LS3D_LOAD_IDX(k_cur);
       int idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
+      int idx_nn = LS3D_LOAD_IDX_RAW(k_nn);
       float4 a_cur[SPL / 4], a_nxt[SPL / 4];
+      bool va_cur = false, va_nxt = false;  // the row loaded into a_cur / a_nxt exists
       float4 breg0, breg1, breg2, breg3;
       static_assert(BPT <= 4, "weight chunk too large for the staging registers");
       int c0 = 0, buf = 0;
-      LS3D_LOAD_A(a_cur, idx_cur, 0);
+      LS3D_LOAD_A(a_cur, va_cur, idx_cur, 0);
       LS3D_LOAD_B(k_cur, 0);
       LS3D_STORE_B(Bs[0]);
+#pragma unroll
+      for (int q = 0; q < SPL / 4; ++q) a_cur[q] = va_cur ? a_cur[q] : make_float4(0.f, 0.f, 0.f, 0.f);  // (nothing in flight at the loop head)
       __syncthreads();
       for (;;) {
         int nk = k_cur, nc0 = c0 + KC, nidx = idx_cur;
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(256, (NT == 1 && WC == 1) ? 5 : (NT == 2 && WC == 1
           has_next = nk >= 0;
         }
         if (has_next) {
-          LS3D_LOAD_A(a_nxt, nidx, nc0);
+          LS3D_LOAD_A(a_nxt, va_nxt, nidx, nc0);
           LS3D_LOAD_B(nk, nc0);
         }
         if ((wmask >> k_cur) & 1ull) {
@@ -189,16 +202,18 @@ __global__ __launch_bounds__(256, (NT == 1 && WC == 1) ? 5 : (NT == 2 && WC == 1
         __syncthreads();
         buf ^= 1;
 #pragma unroll
-        for (int q = 0; q < SPL / 4; ++q) a_cur[q] = a_nxt[q];
+        for (int q = 0; q < SPL / 4; ++q) a_cur[q] = va_nxt ? a_nxt[q] : make_float4(0.f, 0.f, 0.f, 0.f);  // (behind the wait for this chunk's loads)
         if (nk != k_cur) {
           k_cur = nk; idx_cur = idx_nxt;
-          rem &= rem - 1;
-          k_nxt = rem ? __ffsll((long long)rem) - 1 : -1;
-          idx_nxt = k_nxt >= 0 ? LS3D_LOAD_IDX(k_nxt) : -1;
+          k_nxt = k_nn; idx_nxt = (k_nn >= 0 && row >= 0) ? idx_nn : -1;
+          LS3D_POP_OFFSET(k_nn)
+          idx_nn = LS3D_LOAD_IDX_RAW(k_nn);
         }
         c0 = nc0;
       }
     }
+#undef LS3D_POP_OFFSET
+#undef LS3D_LOAD_IDX_RAW
 #undef LS3D_LOAD_IDX
 #undef LS3D_LOAD_A
 #undef LS3D_LOAD_B
