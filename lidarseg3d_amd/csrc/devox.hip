@@ -412,10 +412,20 @@ __global__ __launch_bounds__(256) void k_devox_hard(const float *points, int pt_
     const int v0 = vx_off[frame], m = vx_off[frame + 1] - v0;
     Top3 t;
     top3_init(t);
-    for (int k = threadIdx.x; k < m; k += 256) {
-      const float *c = centers + 4 * (size_t)(v0 + k);
-      const float dx = ux - c[1], dy = uy - c[2], dz = uz - c[3];
-      top3_push_lex(t, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), k);
+    // 4 centres per trip, their 16-byte loads issued together from clamped addresses (one centre per trip was a load -> wait -> compare
+    // chain of m / 256 round trips to L2 per thread); the result does not depend on the order of the pushes
+    const float4 *cen = (const float4 *)centers + v0;
+    for (int k = threadIdx.x; k < m; k += 1024) {
+      float4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = cen[min(k + u * 256, m - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k + u * 256 < m) {
+          const float dx = ux - q[u].y, dy = uy - q[u].z, dz = uz - q[u].w;
+          top3_push_lex(t, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), k + u * 256);
+        }
+      }
     }
     // wave merge (butterfly): after each step every lane holds the top-3 of a growing group
 #pragma unroll
