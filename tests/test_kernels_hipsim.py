@@ -1471,3 +1471,36 @@ def test_layer_norm_forward_backward_vs_torch(n, c):
     xs2, gs2, bs2 = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
     ops._LayerNormFn.apply(xs2, gs2, bs2, 1e-5).backward(dy)
     assert torch.equal(xs2.grad, xs.grad) and torch.equal(gs2.grad, gs.grad) and torch.equal(bs2.grad, bs.grad)
+
+
+def test_pair_list_entry_points_argument_and_workspace_errors():
+    """ls3d_spconv_pairs / ls3d_spconv_wgrad_on_pairs: status codes instead of faults (include/ls3d.h: LS3D_ERR_ARG -1, LS3D_ERR_WORKSPACE -4),
+    empty tables are fine, and the two-step form equals the one-call form on a table with an empty offset and a ragged tail"""
+    import ctypes
+    L = ops._L()
+    rng = np.random.default_rng(5)
+    n_in, n_out, kvol, cin, cout = 70, 53, 4, 32, 32
+    tbl = torch.from_numpy(rng.integers(-1, n_in, size=(n_out, kvol)).astype(np.int32))
+    tbl[:, 2] = -1  # an offset without pairs
+    x, go = torch.from_numpy(rng.normal(size=(n_in, cin)).astype(np.float32)), torch.from_numpy(rng.normal(size=(n_out, cout)).astype(np.float32))
+    nbytes = int(L.ls3d_spconv_pairs_bytes(kvol, n_out))
+    pairs = torch.empty(nbytes, dtype=torch.uint8)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert L.ls3d_spconv_pairs(p(tbl), None, n_out, None, kvol, p(pairs), ctypes.c_size_t(nbytes - 1), None) == -4
+    assert L.ls3d_spconv_pairs(p(tbl), None, n_out, None, kvol, ctypes.c_void_p(pairs.data_ptr() + 4), ctypes.c_size_t(nbytes), None) == -4  # 16-byte alignment
+    assert L.ls3d_spconv_pairs(None, None, n_out, None, kvol, p(pairs), ctypes.c_size_t(nbytes), None) == -1
+    assert L.ls3d_spconv_pairs(p(tbl), None, 0, None, kvol, None, ctypes.c_size_t(0), None) == 0  # empty table: nothing to build
+    assert L.ls3d_spconv_pairs(p(tbl), None, n_out, None, kvol, p(pairs), ctypes.c_size_t(nbytes), None) == 0
+    ws_bytes = int(L.ls3d_spconv_wgrad_workspace_bytes(kvol, cin, cout, n_out))
+    ws, gw = torch.empty(ws_bytes, dtype=torch.uint8), torch.empty(kvol, cin, cout)
+    args = lambda w, nb, prod=0: (p(x), cin, p(go), cout, p(pairs), kvol, cin, cout, n_out, prod, p(w), ctypes.c_size_t(nb), p(gw), None)
+    assert L.ls3d_spconv_wgrad_on_pairs(*args(ws, 16)) == -4
+    assert L.ls3d_spconv_wgrad_on_pairs(*args(ws, ws_bytes, prod=3)) == -1  # products: 0 | 6 | 8
+    assert L.ls3d_spconv_wgrad_on_pairs(*args(ws, ws_bytes)) == 0
+    assert torch.equal(gw, ops.spconv_wgrad(x, go, tbl, None, cin, cout, products=0))
+    assert float(gw[2].abs().max()) == 0.0
+    want = torch.zeros(kvol, cin, cout, dtype=torch.float64)
+    for k in range(kvol):
+        o = torch.nonzero(tbl[:, k] >= 0)[:, 0]
+        want[k] = x[tbl[o, k].long()].double().t() @ go[o].double()
+    assert float((gw.double() - want).abs().max()) < 1e-4
