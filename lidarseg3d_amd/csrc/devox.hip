@@ -393,17 +393,57 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
   }
 }
 
-// one workgroup per deferred point: exact scan of every voxel centre of the point's frame, block-wide top-3 merge
-// in lexicographic (distance, index) order, then the interpolated row.
+// block-wide merge of the threads' top-3 sets in lexicographic (distance, index) order: wave butterfly, then thread 0 over the 4 waves'
+// sets; every thread returns with the workgroup's set.  Untouched slots are (+inf, 0): they never displace a real candidate, and the real
+// candidates of different threads are distinct.
+__device__ __forceinline__ void dh_block_top3(Top3 &t, float *s_d, int *s_i, float *s_fd, int *s_fi) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float e0 = __shfl_xor(t.d0, off), e1 = __shfl_xor(t.d1, off), e2 = __shfl_xor(t.d2, off);
+    const int j0 = __shfl_xor(t.i0, off), j1 = __shfl_xor(t.i1, off), j2 = __shfl_xor(t.i2, off);
+    if (e0 < __int_as_float(0x7f800000)) top3_push_lex(t, e0, j0);
+    if (e1 < __int_as_float(0x7f800000)) top3_push_lex(t, e1, j1);
+    if (e2 < __int_as_float(0x7f800000)) top3_push_lex(t, e2, j2);
+  }
+  __syncthreads();  // earlier readers of s_* are done
+  if (lane == 0) {
+    s_d[wave * 3 + 0] = t.d0; s_d[wave * 3 + 1] = t.d1; s_d[wave * 3 + 2] = t.d2;
+    s_i[wave * 3 + 0] = t.i0; s_i[wave * 3 + 1] = t.i1; s_i[wave * 3 + 2] = t.i2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Top3 b;
+    top3_init(b);
+    for (int q = 0; q < 12; ++q)
+      if (s_d[q] < __int_as_float(0x7f800000)) top3_push_lex(b, s_d[q], s_i[q]);
+    s_fd[0] = b.d0; s_fd[1] = b.d1; s_fd[2] = b.d2;
+    s_fi[0] = b.i0; s_fi[1] = b.i1; s_fi[2] = b.i2;
+  }
+  __syncthreads();
+  t.d0 = s_fd[0]; t.d1 = s_fd[1]; t.d2 = s_fd[2];
+  t.i0 = s_fi[0]; t.i1 = s_fi[1]; t.i2 = s_fi[2];
+}
+
+// One workgroup per deferred point (the ~2 % of a frame whose neighbours are metres away: isolated returns, points outside the voxel
+// range): exact top-3 in lexicographic (distance, index) order, then the interpolated row.  Scanning every voxel centre of the frame
+// for each of them cost more than the other 98 % of the points (2.4k points x 65.9k centres = 2.4 GB of L2 reads per frame), so the
+// workgroup prunes with the coarse grid the shell search uses: (1) an upper bound on the 3rd-nearest distance from 1024 centres taken
+// evenly from the cell-sorted list, (2) the threads walk the occupancy bitmap, and only cells whose box is not farther than the bound
+// (nor than the thread's own 3rd best; the margin of the shell search) have their centres compared - with the same f32 expression and
+// the same frame-local indices as everywhere else, so the result is the brute-force one.  Frames with few centres are scanned whole.
+#define DH_SCAN_ALL 2048
 __global__ __launch_bounds__(256) void k_devox_hard(const float *points, int pt_stride, const int32_t *hard_list, const int32_t *hard_count,
-                                                   const float *centers, const int32_t *vx_off, const float *feat, int feat_ld, int C,
-                                                   float *out, int out_ld, int32_t *idx_out, float *w_out) {
+                                                   const float *centers, const int32_t *vx_off, CGeom g, const int32_t *start,
+                                                   const float4 *sorted, const uint32_t *occ, const float *feat, int feat_ld, int C, float *out,
+                                                   int out_ld, int32_t *idx_out, float *w_out) {
   __shared__ float s_d[4 * 3];
   __shared__ int s_i[4 * 3];
+  __shared__ float s_fd[3];
+  __shared__ int s_fi[3];
   __shared__ float s_w3[3];
-  __shared__ int s_i3[3];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int count = *hard_count;
+  const int ncf = g.dim[0] * g.dim[1] * g.dim[2];
   for (int h = blockIdx.x; h < count; h += gridDim.x) {
     const int i = hard_list[h];
     const float *u = points + (size_t)i * pt_stride;
@@ -412,55 +452,88 @@ __global__ __launch_bounds__(256) void k_devox_hard(const float *points, int pt_
     const int v0 = vx_off[frame], m = vx_off[frame + 1] - v0;
     Top3 t;
     top3_init(t);
-    // 4 centres per trip, their 16-byte loads issued together from clamped addresses (one centre per trip was a load -> wait -> compare
-    // chain of m / 256 round trips to L2 per thread); the result does not depend on the order of the pushes
-    const float4 *cen = (const float4 *)centers + v0;
-    for (int k = threadIdx.x; k < m; k += 1024) {
-      float4 q[4];
+    if (m < DH_SCAN_ALL) {
+      // 4 centres per trip, their 16-byte loads issued together from clamped addresses; the result does not depend on the order of the pushes
+      const float4 *cen = (const float4 *)centers + v0;
+      for (int k = threadIdx.x; k < m; k += 1024) {
+        float4 q[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) q[u] = cen[min(k + u * 256, m - 1)];
+        for (int e = 0; e < 4; ++e) q[e] = cen[min(k + e * 256, m - 1)];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (k + u * 256 < m) {
-          const float dx = ux - q[u].y, dy = uy - q[u].z, dz = uz - q[u].w;
-          top3_push_lex(t, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), k + u * 256);
+        for (int e = 0; e < 4; ++e) {
+          if (k + e * 256 < m) {
+            const float dx = ux - q[e].y, dy = uy - q[e].z, dz = uz - q[e].w;
+            top3_push_lex(t, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), k + e * 256);
+          }
+        }
+      }
+    } else {
+      const int32_t *fstart = start + (size_t)frame * ncf;
+      const int s_lo = fstart[0];
+      // (1) any three centres bound the 3rd-nearest distance from above: 4 per thread, evenly spread over the cell-sorted list
+      {
+        float4 q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = sorted[s_lo + (int)(((long long)(threadIdx.x * 4 + e) * m) >> 10)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dx = ux - q[e].x, dy = uy - q[e].y, dz = uz - q[e].z;
+          top3_push_lex(t, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q[e].w));
+        }
+      }
+      dh_block_top3(t, s_d, s_i, s_fd, s_fi);
+      const float bound = t.d2;
+      top3_init(t);  // the sampled centres are met again in their cells
+      // (2) occupied cells whose box can hold a centre at most `bound` away
+      float cs[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) cs[a] = g.vs[a] * (float)g.cg[a];
+      const uint32_t *focc = occ + (size_t)frame * g.wpf;
+      const int plane = g.dim[0] * g.dim[1];
+      for (int w = threadIdx.x; w < g.wpf; w += 256) {
+        uint32_t bits = focc[w];
+        while (bits) {
+          const int cell = (w << 5) + __ffs((int)bits) - 1;
+          bits &= bits - 1;
+          const int z = cell / plane, rem = cell - z * plane, y = rem / g.dim[0], x = rem - y * g.dim[0];
+          // (the last coarse cell of an axis may hold more fine cells: its true upper face)
+          const float bx0 = g.lo[0] + cs[0] * (float)x, bx1 = (x == g.dim[0] - 1) ? g.lo[0] + g.vs[0] * (float)g.grid[0] : bx0 + cs[0];
+          const float by0 = g.lo[1] + cs[1] * (float)y, by1 = (y == g.dim[1] - 1) ? g.lo[1] + g.vs[1] * (float)g.grid[1] : by0 + cs[1];
+          const float bz0 = g.lo[2] + cs[2] * (float)z, bz1 = (z == g.dim[2] - 1) ? g.lo[2] + g.vs[2] * (float)g.grid[2] : bz0 + cs[2];
+          const float ex = fmaxf(fmaxf(bx0 - ux, ux - bx1), 0.0f), ey = fmaxf(fmaxf(by0 - uy, uy - by1), 0.0f),
+                      ez = fmaxf(fmaxf(bz0 - uz, uz - bz1), 0.0f);
+          // strictly farther than the bound (with the rounding margin of the shell search): equal-distance candidates are never lost
+          if ((ex * ex + ey * ey + ez * ez) * 0.9999f > fminf(bound, t.d2)) continue;
+          const int c0 = fstart[cell], c1 = fstart[cell + 1];
+          for (int j = c0; j < c1; j += 4) {
+            float4 q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = sorted[min(j + e, c1 - 1)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (j + e < c1) {
+                const float dx = ux - q[e].x, dy = uy - q[e].y, dz = uz - q[e].z;
+                top3_push_lex(t, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q[e].w));
+              }
+            }
+          }
         }
       }
     }
-    // wave merge (butterfly): after each step every lane holds the top-3 of a growing group
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float e0 = __shfl_xor(t.d0, off), e1 = __shfl_xor(t.d1, off), e2 = __shfl_xor(t.d2, off);
-      const int j0 = __shfl_xor(t.i0, off), j1 = __shfl_xor(t.i1, off), j2 = __shfl_xor(t.i2, off);
-      // untouched slots are (+inf, 0): they never displace a real candidate, and real candidates of both halves are distinct
-      if (e0 < __int_as_float(0x7f800000)) top3_push_lex(t, e0, j0);
-      if (e1 < __int_as_float(0x7f800000)) top3_push_lex(t, e1, j1);
-      if (e2 < __int_as_float(0x7f800000)) top3_push_lex(t, e2, j2);
-    }
-    __syncthreads();  // previous iteration's readers of s_* are done
-    if (lane == 0) {
-      s_d[wave * 3 + 0] = t.d0; s_d[wave * 3 + 1] = t.d1; s_d[wave * 3 + 2] = t.d2;
-      s_i[wave * 3 + 0] = t.i0; s_i[wave * 3 + 1] = t.i1; s_i[wave * 3 + 2] = t.i2;
-    }
-    __syncthreads();
+    dh_block_top3(t, s_d, s_i, s_fd, s_fi);
     if (threadIdx.x == 0) {
-      Top3 b;
-      top3_init(b);
-      for (int q = 0; q < 12; ++q)
-        if (s_d[q] < __int_as_float(0x7f800000)) top3_push_lex(b, s_d[q], s_i[q]);
-      const float r0 = __fdiv_rn(1.0f, sqrtf(b.d0) + 1e-8f), r1 = __fdiv_rn(1.0f, sqrtf(b.d1) + 1e-8f), r2 = __fdiv_rn(1.0f, sqrtf(b.d2) + 1e-8f);
+      const float r0 = __fdiv_rn(1.0f, sqrtf(t.d0) + 1e-8f), r1 = __fdiv_rn(1.0f, sqrtf(t.d1) + 1e-8f), r2 = __fdiv_rn(1.0f, sqrtf(t.d2) + 1e-8f);
       const float norm = (r0 + r1) + r2;
       s_w3[0] = __fdiv_rn(r0, norm); s_w3[1] = __fdiv_rn(r1, norm); s_w3[2] = __fdiv_rn(r2, norm);
-      s_i3[0] = b.i0; s_i3[1] = b.i1; s_i3[2] = b.i2;
-      if (idx_out) { idx_out[(size_t)i * 3] = b.i0; idx_out[(size_t)i * 3 + 1] = b.i1; idx_out[(size_t)i * 3 + 2] = b.i2; }
+      if (idx_out) { idx_out[(size_t)i * 3] = t.i0; idx_out[(size_t)i * 3 + 1] = t.i1; idx_out[(size_t)i * 3 + 2] = t.i2; }
       if (w_out) { w_out[(size_t)i * 3] = s_w3[0]; w_out[(size_t)i * 3 + 1] = s_w3[1]; w_out[(size_t)i * 3 + 2] = s_w3[2]; }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < (feat ? C : 0); c += 256) {
       float o = 0.0f;
       if (m > 0) {
-        const float a = feat[(size_t)(v0 + s_i3[0]) * feat_ld + c], b2 = feat[(size_t)(v0 + s_i3[1]) * feat_ld + c],
-                    c2 = feat[(size_t)(v0 + s_i3[2]) * feat_ld + c];
+        const float a = feat[(size_t)(v0 + t.i0) * feat_ld + c], b2 = feat[(size_t)(v0 + t.i1) * feat_ld + c],
+                    c2 = feat[(size_t)(v0 + t.i2) * feat_ld + c];
         o = fmaf(s_w3[2], c2, fmaf(s_w3[1], b2, s_w3[0] * a));
       }
       out[(size_t)i * out_ld + c] = o;
@@ -544,7 +617,8 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
                      (const int32_t *)perm, g, (const int32_t *)start, (const float4 *)sorted, (const uint32_t *)occ, vx_off, feat, feat_ld, c, out, out_ld, idx_out, w_out,
                      hard_list, hard_count);
   hipLaunchKernelGGL(k_devox_hard, dim3(n_points < 2048 ? (n_points > 0 ? n_points : 1) : 2048), dim3(256), 0, stream, points, pt_stride,
-                     (const int32_t *)hard_list, (const int32_t *)hard_count, centers, vx_off, feat, feat_ld, c, out, out_ld, idx_out, w_out);
+                     (const int32_t *)hard_list, (const int32_t *)hard_count, centers, vx_off, g, (const int32_t *)start, (const float4 *)sorted,
+                     (const uint32_t *)occ, feat, feat_ld, c, out, out_ld, idx_out, w_out);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

@@ -1504,3 +1504,32 @@ def test_pair_list_entry_points_argument_and_workspace_errors():
         o = torch.nonzero(tbl[:, k] >= 0)[:, 0]
         want[k] = x[tbl[o, k].long()].double().t() @ go[o].double()
     assert float((gw.double() - want).abs().max()) < 1e-4
+
+
+def test_deferred_points_pruned_scan_equals_brute_force():
+    """k_devox_hard (points the shell search defers: neighbours metres away) prunes with the coarse grid - an upper bound from a sample of
+    the centres, then only the cells whose box is within it.  Hundreds of such points per frame - far outside the range on every side,
+    inside it but in empty space, exactly on lattice positions (equal distances: the smallest index must win) - against the brute-force
+    kernel, bit for bit (indices, weights, rows)"""
+    g = golden("head_mseg3d_nusc.npz")
+    coords, ctr, feat = torch.from_numpy(g["coords"]), torch.from_numpy(g["conv_point_coords"]), torch.from_numpy(g["conv_point_features"])
+    cfg = synth.NUSC
+    lo, hi = np.float32(cfg["pc_range"][:3]), np.float32(cfg["pc_range"][3:])
+    rng = np.random.default_rng(12)
+    far = []
+    for b in (0, 1):
+        p = rng.uniform(lo - 60.0, hi + 60.0, size=(150, 3)).astype(np.float32)          # all around, mostly outside
+        q = rng.uniform(lo, hi, size=(100, 3)).astype(np.float32); q[:, 2] = hi[2] - 0.05    # inside the range, above everything
+        c = ctr[ctr[:, 0] == b][:: max(1, int((ctr[:, 0] == b).sum()) // 40), 1:4].numpy().copy()
+        c[:, 0] += np.float32(40.0)                                                           # lattice-aligned offsets: ties between centres
+        far.append(np.concatenate([np.full((len(p) + len(q) + len(c), 1), b, np.float32), np.concatenate([p, q, c])], 1))
+    pts = torch.from_numpy(np.concatenate(far)).contiguous()
+    pt_off, vx_off = ops.frame_offsets(pts[:, 0], 2), ops.frame_offsets(ctr[:, 0], 2)
+    assert int((vx_off[1:] - vx_off[:-1]).min()) >= 2048  # the pruned path, not the scan of small frames
+    a, ia = ops.devoxelize_grid(pts, pt_off, coords, ctr, vx_off, 2, cfg["voxel_size"], cfg["pc_range"], feat, return_idx=True)
+    b, ib = ops.devoxelize(pts, pt_off, ctr, vx_off, 2, pts.shape[0], feat, return_idx=True)
+    assert torch.equal(ia, ib) and torch.equal(a, b)
+    idx, w = ops.devoxelize_grid(pts, pt_off, coords, ctr, vx_off, 2, cfg["voxel_size"], cfg["pc_range"], None)
+    assert torch.equal(idx, ia)
+    want, widx = orc.three_interpolate_wrap(pts, ctr, feat, 2, return_idx=True)
+    assert np.array_equal(ia.numpy(), np.concatenate(widx))
