@@ -583,31 +583,30 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   cg_setup(grid_xyz, g);
   const long long ncell = (long long)batch * g.dim[0] * g.dim[1] * g.dim[2];
   if (ncell + 1 > 0x7FFFFFFFLL) return LS3D_ERR_UNSUPPORTED;
+  // everything that starts at zero lies in front, one block = one memset: cell counts / cursors of the centres and of the query points, the occupancy
+  // bitmaps, the deferred-point counter (six fills per frame before)
   char *base = (char *)workspace;
-  int32_t *cell_of = (int32_t *)base; base += dv_align((size_t)n_voxels * 4);
+  char *const zero_begin = base;
   int32_t *cnt = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
-  int32_t *start = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
   int32_t *cursor = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  int32_t *pcnt = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  int32_t *pcursor = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
+  uint32_t *occ = (uint32_t *)base; base += dv_align((size_t)batch * g.wpf * 4);
+  int32_t *hard_count = (int32_t *)base; base += 256;
+  char *const zero_end = base;
+  int32_t *cell_of = (int32_t *)base; base += dv_align((size_t)n_voxels * 4);
+  int32_t *start = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
   int32_t *scan_tmp = (int32_t *)base; base += dv_align(ls3d_scan_tmp_ints(ncell + 1) * 4);
   float4 *sorted = (float4 *)base; base += dv_align((size_t)n_voxels * 16);
-  uint32_t *occ = (uint32_t *)base; base += dv_align((size_t)batch * g.wpf * 4);
   int32_t *pcell = (int32_t *)base; base += dv_align((size_t)n_points * 4);
   int32_t *perm = (int32_t *)base; base += dv_align((size_t)n_points * 4);
-  int32_t *pcnt = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
   int32_t *pstart = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
-  int32_t *pcursor = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
-  int32_t *hard_list = (int32_t *)base; base += dv_align((size_t)n_points * 4);
-  int32_t *hard_count = (int32_t *)base;
-  hipMemsetAsync(hard_count, 0, 4, stream);
-  hipMemsetAsync(pcnt, 0, (size_t)(ncell + 1) * 4, stream);
-  hipMemsetAsync(pcursor, 0, (size_t)(ncell + 1) * 4, stream);
+  int32_t *hard_list = (int32_t *)base;
+  hipMemsetAsync(zero_begin, 0, (size_t)(zero_end - zero_begin), stream);
   hipLaunchKernelGGL(k_pt_count, ls3d_grid(n_points), dim3(256), 0, stream, points, pt_stride, n_points, g, pcell, pcnt);
   int rcp = ls3d_exclusive_scan_i32(pcnt, pstart, (int)(ncell + 1), scan_tmp, nullptr, stream);
   if (rcp != LS3D_OK) return rcp;
   hipLaunchKernelGGL(k_pt_fill, ls3d_grid(n_points), dim3(256), 0, stream, n_points, (const int32_t *)pcell, (const int32_t *)pstart, pcursor, perm);
-  hipMemsetAsync(cnt, 0, (size_t)(ncell + 1) * 4, stream);
-  hipMemsetAsync(cursor, 0, (size_t)(ncell + 1) * 4, stream);
-  hipMemsetAsync(occ, 0, (size_t)batch * g.wpf * 4, stream);
   hipLaunchKernelGGL(k_cg_count, ls3d_grid(n_voxels), dim3(256), 0, stream, coords, n_voxels, n_voxels_dev, g, cell_of, cnt, occ);
   int rc = ls3d_exclusive_scan_i32(cnt, start, (int)(ncell + 1), scan_tmp, nullptr, stream);
   if (rc != LS3D_OK) return rc;
