@@ -507,6 +507,19 @@ typedef struct {
 int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
                       const ls3d_sffm_t *model_host, float *out, int out_ld, ls3d_stream_t stream);
 
+/* The class-embedding ("memory") side of the same decoder for all layers in one launch (context_module.py:147-171, :211-250, :320-338): per
+ * frame the L <= 64 memory tokens [L][96] go through num_layers x { self-attention (4 heads) + residual + norm1 } and every layer's cross-attention
+ * k_proj / v_proj (Conv1d, k = 1) is written as kv[2 l + {0: k, 1: v}][batch][96][L] - the `kv` input of ls3d_sffm_decoder.  Weights are the
+ * modules' own matrices TRANSPOSED to [in][out] row-major f32 (in_proj_weight^T [96][288], out_proj.weight^T, k_proj / v_proj weight^T [96][96]).
+ * Plain f32 fma contractions in ascending k.  mem_out (optional): the memory after the last layer, [batch * L][96].  Other shapes
+ * (embed != 96, heads != 4, L > 64, > 8 layers): LS3D_ERR_UNSUPPORTED, the caller composes it from ls3d_gather_gemm / ls3d_mha_core. */
+typedef struct {
+  const float *wqkv_t, *bqkv, *wo_t, *bo, *n1_gamma, *n1_beta, *wk_t, *bk, *wv_t, *bv;
+  float n1_eps;
+} ls3d_sffm_memory_layer_t;
+int ls3d_sffm_memory(const float *mem, int batch, int L, int embed, int heads, int num_layers, const ls3d_sffm_memory_layer_t *layers_host,
+                     float *kv, float *mem_out, ls3d_stream_t stream);
+
 /* SparsePointCorssAttention core (context_module.py:339-372): q[n,embed] (already projected), per-frame
  * k,v[batch, heads, embed/heads, L] (Conv1d outputs reshaped as the reference does), softmax(q.k*scale) v
  * -> out[n, embed].  frame of point p = (int)points[p*pt_stride]. */

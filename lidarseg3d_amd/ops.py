@@ -1061,6 +1061,37 @@ def sffm_decoder(x, points, kv, L, batch, model):
     return out
 
 
+class SffmMemoryModel(object):
+    """device weights (transposed to [in][out]) + the host-side layer descriptors of ls3d_sffm_memory.  `layers`: dicts with wqkv_t, bqkv, wo_t,
+    bo, n1 = (gamma, beta, eps), wk_t, bk, wv_t, bv"""
+
+    def __init__(self, layers, embed, heads):
+        from ._lib import SffmMemoryLayer
+        self.embed, self.heads, self.keep = int(embed), int(heads), []
+        arr = (SffmMemoryLayer * max(len(layers), 1))()
+        for i, l in enumerate(layers):
+            t = dict(wqkv_t=l["wqkv_t"], bqkv=l["bqkv"], wo_t=l["wo_t"], bo=l["bo"], n1_gamma=l["n1"][0], n1_beta=l["n1"][1], wk_t=l["wk_t"], bk=l["bk"],
+                     wv_t=l["wv_t"], bv=l["bv"])
+            self.keep.extend(t.values())
+            for k, v in t.items():
+                _ptr(v)  # device / contiguity check
+                setattr(arr[i], k, v.data_ptr())
+            arr[i].n1_eps = float(l["n1"][2])
+        self.layers, self.num_layers = arr, len(layers)
+
+
+def sffm_memory(mem, batch, L, model, return_memory=False):
+    """class-embedding side of the SF-Phase decoder for all layers in one launch (ls3d_sffm_memory): mem [batch * L, 96] -> kv
+    [2 * layers, batch, 96, L] for sffm_decoder (and the memory after the last layer); None when the shape is not supported"""
+    kv = torch.empty((2 * model.num_layers, batch, model.embed, L), dtype=torch.float32, device=mem.device)
+    out = torch.empty_like(mem) if return_memory else None
+    rc = _L().ls3d_sffm_memory(_ptr(mem), int(batch), int(L), model.embed, model.heads, model.num_layers, model.layers, _ptr(kv), _ptr(out), _stream(mem))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "ls3d_sffm_memory")
+    return (kv, out) if return_memory else kv
+
+
 def cross_attn(q, k, v, batch, heads, points):
     n, e = q.shape
     L = k.numel() // (batch * e)

@@ -243,12 +243,21 @@ class TransformerDecoder(nn.Module):
 
 import os as _os
 _FUSED_SFFM = _os.environ.get("LS3D_FUSED_SFFM", "1") != "0"
+# the class-embedding side of all decoder layers in one launch (ls3d_sffm_memory) instead of ~40 small ones.  Built after round 3's GPU budget was
+# spent: equal to the layer-by-layer form to 1e-6 on tests/hipsim, NOT yet run on the device -> off until it is (LS3D_FUSED_SFFM_MEMORY=1).
+_FUSED_SFFM_MEMORY = _os.environ.get("LS3D_FUSED_SFFM_MEMORY", "0") != "0"
 
 
 def set_fused_sffm(on):
     """A/B switch: the point side of the SF-Phase decoder as one kernel (default) or layer by layer"""
     global _FUSED_SFFM
     _FUSED_SFFM = bool(on)
+
+
+def set_fused_sffm_memory(on):
+    """A/B switch: the class-embedding side of all decoder layers in one launch (ls3d_sffm_memory) or layer by layer (default until timed)"""
+    global _FUSED_SFFM_MEMORY
+    _FUSED_SFFM_MEMORY = bool(on)
 
 
 class SemanticFeatureFusionModule(PackedModule):
@@ -295,6 +304,17 @@ class SemanticFeatureFusionModule(PackedModule):
                                w1a=pack_linear(w1[:E])[0], w1b=pack_linear(w1[E:])[0], b1=t(l.linear1.bias),
                                w2a=pack_linear(w2[:, :E])[0], w2b=pack_linear(w2[:, E:])[0], b2=t(l.linear2.bias), n2=lp["n2"], n3=lp["n3"]))
             p["fused"] = ops.SffmModel(p["point"][0], t(self.input_proj_point.bias), fl, p["norm_tgt"], d_in, E, self.nhead, ffn)
+        if E == 96 and self.nhead == 4 and len(self.decoder.layers) <= 8:
+            # the class-embedding side of all layers in one launch (ls3d_sffm_memory): the modules' matrices transposed to [in][out]
+            t = lambda w: w.detach().float().contiguous()
+            tt = lambda w: w.detach().float().reshape(w.shape[0], -1).t().contiguous()
+            ml = []
+            for l, lp in zip(self.decoder.layers, p["layers"]):
+                ca = l.crossocr_attn
+                ml.append(dict(wqkv_t=tt(l.self_attn.in_proj_weight), bqkv=t(l.self_attn.in_proj_bias), wo_t=tt(l.self_attn.out_proj.weight),
+                               bo=t(l.self_attn.out_proj.bias), n1=lp["n1"], wk_t=tt(ca.k_proj.weight), bk=t(ca.k_proj.bias), wv_t=tt(ca.v_proj.weight),
+                               bv=t(ca.v_proj.bias)))
+            p["memory"] = ops.SffmMemoryModel(ml, E, self.nhead)
         return p
 
     def forward(self, input_point_features, input_sem_embeddings1, input_sem_embeddings2, batch_idx, batch_size,
@@ -322,13 +342,15 @@ class SemanticFeatureFusionModule(PackedModule):
         if _FUSED_SFFM and "fused" in pk and not return_context and L <= 64:
             # the class-embedding side of every layer first (2*cls rows per frame; it never sees the points), then ONE kernel for
             # the point side of the whole decoder (ls3d_sffm_decoder)
-            kvs, mf = [], mem
-            for lp in pk["layers"]:
-                att = ops.mha_core(_lin(mf, lp["sa_qkv"]), B, L, E, H)
-                mf = _lin(att, lp["sa_out"], res=mf, ln=lp["n1"])
-                kvs.append(_lin(mf, lp["k"]).view(B, L, E).permute(0, 2, 1))
-                kvs.append(_lin(mf, lp["v"]).view(B, L, E).permute(0, 2, 1))
-            kv = torch.stack(kvs).contiguous()  # [layers * 2, B, E, L]
+            kv = ops.sffm_memory(mem, B, L, pk["memory"]) if (_FUSED_SFFM_MEMORY and "memory" in pk) else None
+            if kv is None:
+                kvs, mf = [], mem
+                for lp in pk["layers"]:
+                    att = ops.mha_core(_lin(mf, lp["sa_qkv"]), B, L, E, H)
+                    mf = _lin(att, lp["sa_out"], res=mf, ln=lp["n1"])
+                    kvs.append(_lin(mf, lp["k"]).view(B, L, E).permute(0, 2, 1))
+                    kvs.append(_lin(mf, lp["v"]).view(B, L, E).permute(0, 2, 1))
+                kv = torch.stack(kvs).contiguous()  # [layers * 2, B, E, L]
             x = input_point_features if input_point_features.is_contiguous() else input_point_features.contiguous()
             tgt = ops.sffm_decoder(x, points, kv, L, B, pk["fused"])
             if tgt is not None:

@@ -1533,3 +1533,47 @@ def test_deferred_points_pruned_scan_equals_brute_force():
     assert torch.equal(idx, ia)
     want, widx = orc.three_interpolate_wrap(pts, ctr, feat, 2, return_idx=True)
     assert np.array_equal(ia.numpy(), np.concatenate(widx))
+
+
+@pytest.mark.parametrize("cls,layers", [(17, 3), (23, 6), (32, 1)])
+def test_sffm_memory_side_in_one_launch_equals_layer_by_layer(cls, layers):
+    """ls3d_sffm_memory (self-attention + norm1 of the class embeddings and every layer's k / v projection, one workgroup per frame)
+    against the layer-by-layer composition on the GEMM / attention-core kernels: the kv tensor itself, then the whole SF-Phase output and
+    the oracle's SFFM.  L = 2 * cls tokens: 34 (nuScenes), 46 (Waymo), 64 (the kernel's limit)"""
+    torch.manual_seed(cls + layers)
+    m = point_heads.SemanticFeatureFusionModule(64, 48, 64, d_model=96, nhead=4, num_decoder_layers=layers, dim_feedforward=192).eval()
+    with torch.no_grad():
+        for l in m.decoder.layers:  # non-trivial LayerNorm parameters and biases
+            l.norm1.weight.uniform_(0.5, 1.5); l.norm1.bias.normal_(0, 0.2)
+            l.self_attn.in_proj_bias.normal_(0, 0.2); l.crossocr_attn.k_proj.bias.normal_(0, 0.2)
+    n0, n1, B, L, E = 150, 61, 2, 2 * cls, 96
+    x = torch.randn(n0 + n1, 64)
+    e1, e2 = torch.randn(B, 48, cls, 1), torch.randn(B, 64, cls, 1)
+    bidx = torch.cat([torch.zeros(n0), torch.ones(n1)])
+    pts = torch.cat([bidx[:, None], torch.randn(n0 + n1, 3)], 1).contiguous()
+    pk = m.packed()
+    assert "memory" in pk
+    mem = torch.randn(B * L, E)
+    kv, mem_out = ops.sffm_memory(mem, B, L, pk["memory"], return_memory=True)
+    kvs, mf = [], mem
+    for lp in pk["layers"]:
+        att = ops.mha_core(point_heads._lin(mf, lp["sa_qkv"]), B, L, E, 4)
+        mf = point_heads._lin(att, lp["sa_out"], res=mf, ln=lp["n1"])
+        kvs.append(point_heads._lin(mf, lp["k"]).view(B, L, E).permute(0, 2, 1))
+        kvs.append(point_heads._lin(mf, lp["v"]).view(B, L, E).permute(0, 2, 1))
+    want_kv = torch.stack(kvs).contiguous()
+    assert kv.shape == want_kv.shape
+    np.testing.assert_allclose(kv.numpy(), want_kv.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(mem_out.numpy(), mf.numpy(), rtol=0, atol=2e-5)
+    try:
+        with torch.no_grad():
+            ref = m(x, e1, e2, bidx, B, points=pts)
+            point_heads.set_fused_sffm_memory(True)
+            got = m(x, e1, e2, bidx, B, points=pts)
+    finally:
+        point_heads.set_fused_sffm_memory(False)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    np.testing.assert_allclose(got.numpy(), orc.sffm(sd, "", x, e1, e2, bidx, B, 4).numpy(), rtol=0, atol=5e-5)
+    # other shapes are declined, not faulted
+    assert ops._L().ls3d_sffm_memory(ops._ptr(mem), B, 65, E, 4, 0, None, ops._ptr(kv), None, None) == -3
