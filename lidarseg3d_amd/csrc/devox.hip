@@ -490,20 +490,47 @@ __global__ __launch_bounds__(256) void k_devox_hard(const float *points, int pt_
       for (int a = 0; a < 3; ++a) cs[a] = g.vs[a] * (float)g.cg[a];
       const uint32_t *focc = occ + (size_t)frame * g.wpf;
       const int plane = g.dim[0] * g.dim[1];
+      const float xhi = g.lo[0] + g.vs[0] * (float)g.grid[0], yhi = g.lo[1] + g.vs[1] * (float)g.grid[1], zhi = g.lo[2] + g.vs[2] * (float)g.grid[2];
       for (int w = threadIdx.x; w < g.wpf; w += 256) {
         uint32_t bits = focc[w];
-        while (bits) {
-          const int cell = (w << 5) + __ffs((int)bits) - 1;
-          bits &= bits - 1;
-          const int z = cell / plane, rem = cell - z * plane, y = rem / g.dim[0], x = rem - y * g.dim[0];
+        if (!bits) continue;
+        // the word's first cell (one pair of divisions per word, not per cell); its 32 cells run along x and usually stay in one row
+        const int base = w << 5;
+        int z = base / plane, rem = base - z * plane, y = rem / g.dim[0];
+        const int x0 = rem - y * g.dim[0];
+        const bool one_row = x0 + 31 < g.dim[0];
+        float eyz = 0.0f;  // squared distance to the row's y / z slab
+        if (one_row) {
           // (the last coarse cell of an axis may hold more fine cells: its true upper face)
-          const float bx0 = g.lo[0] + cs[0] * (float)x, bx1 = (x == g.dim[0] - 1) ? g.lo[0] + g.vs[0] * (float)g.grid[0] : bx0 + cs[0];
-          const float by0 = g.lo[1] + cs[1] * (float)y, by1 = (y == g.dim[1] - 1) ? g.lo[1] + g.vs[1] * (float)g.grid[1] : by0 + cs[1];
-          const float bz0 = g.lo[2] + cs[2] * (float)z, bz1 = (z == g.dim[2] - 1) ? g.lo[2] + g.vs[2] * (float)g.grid[2] : bz0 + cs[2];
-          const float ex = fmaxf(fmaxf(bx0 - ux, ux - bx1), 0.0f), ey = fmaxf(fmaxf(by0 - uy, uy - by1), 0.0f),
-                      ez = fmaxf(fmaxf(bz0 - uz, uz - bz1), 0.0f);
+          const float by0 = g.lo[1] + cs[1] * (float)y, by1 = (y == g.dim[1] - 1) ? yhi : by0 + cs[1];
+          const float bz0 = g.lo[2] + cs[2] * (float)z, bz1 = (z == g.dim[2] - 1) ? zhi : bz0 + cs[2];
+          const float ey = fmaxf(fmaxf(by0 - uy, uy - by1), 0.0f), ez = fmaxf(fmaxf(bz0 - uz, uz - bz1), 0.0f);
+          eyz = ey * ey + ez * ez;
+          // the whole word at once: the box of its 32 cells
+          const float wx0 = g.lo[0] + cs[0] * (float)x0, wx1 = (x0 + 31 == g.dim[0] - 1) ? xhi : g.lo[0] + cs[0] * (float)(x0 + 32);
+          const float ewx = fmaxf(fmaxf(wx0 - ux, ux - wx1), 0.0f);
+          if ((ewx * ewx + eyz) * 0.9999f > fminf(bound, t.d2)) continue;
+        }
+        while (bits) {
+          const int bit = __ffs((int)bits) - 1;
+          bits &= bits - 1;
+          int x = x0 + bit, yy = y, zz = z;
+          float e2 = eyz;
+          if (!one_row) {  // the word wraps into the next row(s)
+            while (x >= g.dim[0]) {
+              x -= g.dim[0];
+              if (++yy == g.dim[1]) { yy = 0; ++zz; }
+            }
+            const float by0 = g.lo[1] + cs[1] * (float)yy, by1 = (yy == g.dim[1] - 1) ? yhi : by0 + cs[1];
+            const float bz0 = g.lo[2] + cs[2] * (float)zz, bz1 = (zz == g.dim[2] - 1) ? zhi : bz0 + cs[2];
+            const float ey = fmaxf(fmaxf(by0 - uy, uy - by1), 0.0f), ez = fmaxf(fmaxf(bz0 - uz, uz - bz1), 0.0f);
+            e2 = ey * ey + ez * ez;
+          }
+          const float bx0 = g.lo[0] + cs[0] * (float)x, bx1 = (x == g.dim[0] - 1) ? xhi : bx0 + cs[0];
+          const float ex = fmaxf(fmaxf(bx0 - ux, ux - bx1), 0.0f);
           // strictly farther than the bound (with the rounding margin of the shell search): equal-distance candidates are never lost
-          if ((ex * ex + ey * ey + ez * ez) * 0.9999f > fminf(bound, t.d2)) continue;
+          if ((ex * ex + e2) * 0.9999f > fminf(bound, t.d2)) continue;
+          const int cell = base + bit;
           const int c0 = fstart[cell], c1 = fstart[cell + 1];
           for (int j = c0; j < c1; j += 4) {
             float4 q[4];

@@ -1577,3 +1577,34 @@ def test_sffm_memory_side_in_one_launch_equals_layer_by_layer(cls, layers):
     np.testing.assert_allclose(got.numpy(), orc.sffm(sd, "", x, e1, e2, bidx, B, 4).numpy(), rtol=0, atol=5e-5)
     # other shapes are declined, not faulted
     assert ops._L().ls3d_sffm_memory(ops._ptr(mem), B, 65, E, 4, 0, None, ops._ptr(kv), None, None) == -3
+
+
+def test_deferred_points_on_a_grid_whose_rows_are_not_whole_bitmap_words():
+    """the same pruned scan when the coarse grid is 25 x 19 x 5 cells: occupancy words straddle rows and planes (the NUSC grid has 128 cells per
+    row = 4 whole words), the last coarse cell of every axis holds more fine cells than the others"""
+    rng = np.random.default_rng(3)
+    vs, rng_lo = [0.1, 0.1, 0.2], [-10.0, -7.9, -3.0]
+    grid = [203, 157, 21]  # fine cells x, y, z: 25 x 19 x 5 coarse cells of 8 x 8 x 4, with remainders on every axis
+    pc_range = rng_lo + [rng_lo[a] + vs[a] * grid[a] for a in range(3)]
+    per = 3000
+    coords = []
+    for b in (0, 1):
+        c = np.unique(np.stack([rng.integers(0, grid[2], per), rng.integers(0, grid[1], per), rng.integers(0, grid[0], per)], 1), axis=0)
+        coords.append(np.concatenate([np.full((len(c), 1), b), c], 1))
+    coords = torch.from_numpy(np.concatenate(coords).astype(np.int32))
+    ctr = ops.voxel_centers(coords, vs, pc_range)
+    feat = torch.from_numpy(rng.normal(size=(coords.shape[0], 8)).astype(np.float32))
+    lo, hi = np.float32(pc_range[:3]), np.float32(pc_range[3:])
+    pts = []
+    for b in (0, 1):
+        p = rng.uniform(lo - 25.0, hi + 25.0, size=(200, 3)).astype(np.float32)
+        q = rng.uniform(lo, hi, size=(100, 3)).astype(np.float32)
+        pts.append(np.concatenate([np.full((300, 1), b, np.float32), np.concatenate([p, q])], 1))
+    pts = torch.from_numpy(np.concatenate(pts)).contiguous()
+    pt_off, vx_off = ops.frame_offsets(pts[:, 0], 2), ops.frame_offsets(ctr[:, 0], 2)
+    assert int((vx_off[1:] - vx_off[:-1]).min()) >= 2048
+    a, ia = ops.devoxelize_grid(pts, pt_off, coords, ctr, vx_off, 2, vs, pc_range, feat, return_idx=True)
+    b, ib = ops.devoxelize(pts, pt_off, ctr, vx_off, 2, pts.shape[0], feat, return_idx=True)
+    assert torch.equal(ia, ib) and torch.equal(a, b)
+    want, widx = orc.three_interpolate_wrap(pts, ctr, feat, 2, return_idx=True)
+    assert np.array_equal(ia.numpy(), np.concatenate(widx))
