@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void k_devoxelize(const float *points, int pt_
 // and ordered lexicographically by (distance, index), which yields exactly the brute-force result
 // (strict '<' in ascending index order == smallest index among equal distances).  Points far outside the
 // range simply walk more shells: always exact, no fallback path.
-#define CG_RMAX 3
+#define CG_RMAX 3   // shells searched by k_devox_grid; beyond: k_devox_hard
+#define CG_RLANE 1  // shells a lane walks alone for its own point; CG_RLANE + 1 .. CG_RMAX by the wave, one point at a time
 
 struct CGeom {
   float vs[3], lo[3];
@@ -271,26 +272,54 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
   const int32_t *fstart = start + (size_t)frame * ncf;
   Top3 t;
   top3_init(t);
+  float ux = 0.0f, uy = 0.0f, uz = 0.0f, gap[3] = {0.0f, 0.0f, 0.0f}, cs[3];
+  int cc[3] = {0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) cs[a] = g.vs[a] * (float)g.cg[a];
+  const float xhi = g.lo[0] + g.vs[0] * (float)g.grid[0], yhi = g.lo[1] + g.vs[1] * (float)g.grid[1], zhi = g.lo[2] + g.vs[2] * (float)g.grid[2];
+  // one coarse cell against the point (px, py, pz): skipped when its box is strictly farther than `best` (with a rounding margin, so
+  // equal-distance candidates with a lower index are never lost), else its centres are compared - 4 per trip, loads issued together
+  auto scan_cell = [&](int cell, int cxi, int y, int z, float px, float py, float pz, float best, Top3 &tt) {
+    const float bx0 = g.lo[0] + cs[0] * (float)cxi, bx1 = (cxi == g.dim[0] - 1) ? xhi : bx0 + cs[0];
+    const float by0 = g.lo[1] + cs[1] * (float)y, by1 = (y == g.dim[1] - 1) ? yhi : by0 + cs[1];
+    const float bz0 = g.lo[2] + cs[2] * (float)z, bz1 = (z == g.dim[2] - 1) ? zhi : bz0 + cs[2];
+    const float ex = fmaxf(fmaxf(bx0 - px, px - bx1), 0.0f), ey = fmaxf(fmaxf(by0 - py, py - by1), 0.0f), ez = fmaxf(fmaxf(bz0 - pz, pz - bz1), 0.0f);
+    if ((ex * ex + ey * ey + ez * ez) * 0.9999f > best) return;
+    const int s0 = fstart[cell], s1 = fstart[cell + 1];
+    for (int j = s0; j < s1; j += 4) {
+      float4 q[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] = sorted[min(j + e, s1 - 1)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (j + e < s1) {
+          const float dx = px - q[e].x, dy = py - q[e].y, dz = pz - q[e].z;
+          top3_push_lex(tt, fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(q[e].w));
+        }
+      }
+    }
+  };
+  // after shell r every unvisited centre is at least lb away; the search is over when the 3rd best is strictly below (or the grid is covered)
+  auto shell_done = [&](int r, const int *c3, const float *gp, float d2) {
+    const float lb = fminf(gp[0] + (float)r * cs[0], fminf(gp[1] + (float)r * cs[1], gp[2] + (float)r * cs[2]));
+    if (d2 < lb * lb * 0.99999f) return true;
+    return c3[0] - r <= 0 && c3[1] - r <= 0 && c3[2] - r <= 0 && c3[0] + r >= g.dim[0] - 1 && c3[1] + r >= g.dim[1] - 1 && c3[2] + r >= g.dim[2] - 1;
+  };
+  bool resolved = !active;
   if (active) {
     const float *u = points + (size_t)i * pt_stride;
-    const float ux = u[1], uy = u[2], uz = u[3];
+    ux = u[1]; uy = u[2]; uz = u[3];
     const float pu[3] = {ux, uy, uz};
-    float gap[3], cs[3];
-    int cc[3];
     cg_point_cell(g, pu, cc);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      cs[a] = g.vs[a] * (float)g.cg[a];
       const float clo = g.lo[a] + cs[a] * (float)cc[a];
       // the last coarse cell of an axis may hold more fine cells: use its true upper face
       const float chi = (cc[a] == g.dim[a] - 1) ? g.lo[a] + g.vs[a] * (float)g.grid[a] : clo + cs[a];
       gap[a] = fmaxf(fminf(pu[a] - clo, chi - pu[a]), 0.0f);
     }
-    // Shells up to CG_RMAX resolve all but the ~1 % of points whose neighbours are metres away (isolated returns,
-    // points outside the voxel range); those are handed to k_devox_hard, where a whole workgroup scans the frame
-    // for ONE point — a lane walking thousands of cells alone would stall its wave for milliseconds.
-    bool resolved = false;
-    for (int r = 0; r <= CG_RMAX; ++r) {
+    // ---- shells 0 .. CG_RLANE, every lane for its own point: 98 % of the points of a LiDAR frame end here (~5 occupied cells, ~60 centres)
+    for (int r = 0; r <= CG_RLANE; ++r) {
       const int z0 = max(cc[2] - r, 0), z1 = min(cc[2] + r, g.dim[2] - 1);
       const int y0 = max(cc[1] - r, 0), y1 = min(cc[1] + r, g.dim[1] - 1);
       const int x0 = max(cc[0] - r, 0), x1 = min(cc[0] + r, g.dim[0] - 1);
@@ -317,45 +346,63 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
             while (m) {
               const int cell = wlo + __ffs((int)m) - 1;
               m &= m - 1;
-              {
-                // prune: a cell whose box is farther than the current 3rd best cannot contribute (strictly farther,
-                // with a rounding margin, so equal-distance candidates with a lower index are never lost)
-                const int cxi = cell - rowbase;
-                const float bx0 = g.lo[0] + cs[0] * (float)cxi, bx1 = (cxi == g.dim[0] - 1) ? g.lo[0] + g.vs[0] * (float)g.grid[0] : bx0 + cs[0];
-                const float by0 = g.lo[1] + cs[1] * (float)y, by1 = (y == g.dim[1] - 1) ? g.lo[1] + g.vs[1] * (float)g.grid[1] : by0 + cs[1];
-                const float bz0 = g.lo[2] + cs[2] * (float)z, bz1 = (z == g.dim[2] - 1) ? g.lo[2] + g.vs[2] * (float)g.grid[2] : bz0 + cs[2];
-                const float ex = fmaxf(fmaxf(bx0 - ux, ux - bx1), 0.0f), ey = fmaxf(fmaxf(by0 - uy, uy - by1), 0.0f),
-                            ez = fmaxf(fmaxf(bz0 - uz, uz - bz1), 0.0f);
-                if ((ex * ex + ey * ey + ez * ez) * 0.9999f > t.d2) continue;
-              }
-              const int s0 = fstart[cell], s1 = fstart[cell + 1];
-              // 4 candidates per trip, loads issued together: the scan is latency-, not ALU-bound
-              for (int j = s0; j < s1; j += 4) {
-                float4 q[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) q[u] = sorted[min(j + u, s1 - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  if (j + u < s1) {
-                    const float dx = ux - q[u].x, dy = uy - q[u].y, dz = uz - q[u].z;
-                    const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    top3_push_lex(t, d, __float_as_int(q[u].w));
-                  }
-                }
-              }
+              scan_cell(cell, cell - rowbase, y, z, ux, uy, uz, t.d2, t);
             }
           }
         }
       }
-      // lower bound on the distance to anything outside the visited box
-      const float lb = fminf(gap[0] + (float)r * cs[0], fminf(gap[1] + (float)r * cs[1], gap[2] + (float)r * cs[2]));
-      if (t.d2 < lb * lb * 0.99999f) { resolved = true; break; }
-      if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1) { resolved = true; break; }
+      if (shell_done(r, cc, gap, t.d2)) { resolved = true; break; }
     }
-    if (!resolved) {
-      hard_list[atomicAdd(hard_count, 1)] = i;
-      s_pt[threadIdx.x] = -1;  // no output from this kernel for the point
+  }
+  // ---- shells CG_RLANE + 1 .. CG_RMAX, the WAVE for one point at a time.  A wave runs as long as its slowest lane, and 3 of 4 waves hold
+  // at least one of the ~2 % of points whose third neighbour lies beyond shell 1: alone, such a lane walks 98 (then 218) more cells with a
+  // dependent L2 round trip per occupied one while 63 lanes wait.  Here the 64 lanes share the shell's cells, then merge their top-3 sets
+  // (distance, index order: the result does not depend on who compared what).
+  {
+    const int lane = threadIdx.x & 63;
+    unsigned long long pend = __ballot(!resolved);
+    while (pend) {
+      const int src = __ffsll((long long)pend) - 1;
+      pend &= pend - 1;
+      const float px = __shfl(ux, src), py = __shfl(uy, src), pz = __shfl(uz, src);
+      const int c3[3] = {__shfl(cc[0], src), __shfl(cc[1], src), __shfl(cc[2], src)};
+      const float gp[3] = {__shfl(gap[0], src), __shfl(gap[1], src), __shfl(gap[2], src)};
+      Top3 tw;  // the point's set so far on its own lane, empty elsewhere
+      top3_init(tw);
+      if (lane == src) tw = t;
+      bool done = false;
+      for (int r = CG_RLANE + 1; r <= CG_RMAX && !done; ++r) {
+        const float best = __shfl(tw.d2, src);  // (every lane holds the merged set after a shell; before the first one only `src` does)
+        const int w = 2 * r + 1, ncell = w * w * w;
+        for (int n = lane; n < ncell; n += 64) {
+          const int dz = n / (w * w) - r, rem = n % (w * w), dy = rem / w - r, dx = rem % w - r;
+          if (max(max(abs(dx), abs(dy)), abs(dz)) != r) continue;  // the shell only
+          const int x = c3[0] + dx, y = c3[1] + dy, z = c3[2] + dz;
+          if (x < 0 || y < 0 || z < 0 || x >= g.dim[0] || y >= g.dim[1] || z >= g.dim[2]) continue;
+          const int cell = (z * g.dim[1] + y) * g.dim[0] + x;
+          if (!((s_occ[cell >> 5] >> (cell & 31)) & 1u)) continue;
+          scan_cell(cell, x, y, z, px, py, pz, fminf(best, tw.d2), tw);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {  // butterfly: afterwards every lane holds the wave's set
+          const float e0 = __shfl_xor(tw.d0, off), e1 = __shfl_xor(tw.d1, off), e2 = __shfl_xor(tw.d2, off);
+          const int j0 = __shfl_xor(tw.i0, off), j1 = __shfl_xor(tw.i1, off), j2 = __shfl_xor(tw.i2, off);
+          if (e0 < __int_as_float(0x7f800000)) top3_push_lex(tw, e0, j0);
+          if (e1 < __int_as_float(0x7f800000)) top3_push_lex(tw, e1, j1);
+          if (e2 < __int_as_float(0x7f800000)) top3_push_lex(tw, e2, j2);
+        }
+        done = shell_done(r, c3, gp, tw.d2);
+        if (lane == src) t = tw;
+        else top3_init(tw);  // one copy of the merged set only: the next merge must not meet an entry twice
+      }
+      if (lane == src) resolved = done;
     }
+  }
+  if (active && !resolved) {
+    // beyond CG_RMAX (the ~2 % of a frame whose neighbours are metres away: isolated returns, points outside the voxel range): k_devox_hard,
+    // a workgroup per point
+    hard_list[atomicAdd(hard_count, 1)] = i;
+    s_pt[threadIdx.x] = -1;  // no output from this kernel for the point
   }
   const float r0 = __fdiv_rn(1.0f, sqrtf(t.d0) + 1e-8f), r1 = __fdiv_rn(1.0f, sqrtf(t.d1) + 1e-8f), r2 = __fdiv_rn(1.0f, sqrtf(t.d2) + 1e-8f);
   const float norm = (r0 + r1) + r2;
