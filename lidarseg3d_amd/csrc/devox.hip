@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
   // (distance, index order: the result does not depend on who compared what).
   {
     const int lane = threadIdx.x & 63;
-    unsigned long long pend = __ballot(!resolved);
+    // (a point without three candidates in its 27 cells is metres from everything - typically a return outside the voxel range, and such
+    // points come in whole waves: they go straight to k_devox_hard instead of queueing up here)
+    unsigned long long pend = __ballot(!resolved && t.d2 < __int_as_float(0x7f800000));
     while (pend) {
       const int src = __ffsll((long long)pend) - 1;
       pend &= pend - 1;
