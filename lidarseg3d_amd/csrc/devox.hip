@@ -172,8 +172,7 @@ __global__ __launch_bounds__(256) void k_devoxelize(const float *points, int pt_
 // and ordered lexicographically by (distance, index), which yields exactly the brute-force result
 // (strict '<' in ascending index order == smallest index among equal distances).  Points far outside the
 // range simply walk more shells: always exact, no fallback path.
-#define CG_RMAX 3   // shells searched by k_devox_grid; beyond: k_devox_hard
-#define CG_RLANE 1  // shells a lane walks alone for its own point; CG_RLANE + 1 .. CG_RMAX by the wave, one point at a time
+#define CG_RMAX 3   // shells a lane walks for its own point in k_devox_grid; beyond: k_devox_hard
 
 struct CGeom {
   float vs[3], lo[3];
@@ -318,8 +317,10 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
       const float chi = (cc[a] == g.dim[a] - 1) ? g.lo[a] + g.vs[a] * (float)g.grid[a] : clo + cs[a];
       gap[a] = fmaxf(fminf(pu[a] - clo, chi - pu[a]), 0.0f);
     }
-    // ---- shells 0 .. CG_RLANE, every lane for its own point: 98 % of the points of a LiDAR frame end here (~5 occupied cells, ~60 centres)
-    for (int r = 0; r <= CG_RLANE; ++r) {
+    // ---- shells 0 .. CG_RMAX, every lane for its own point: 98 % of the points of a LiDAR frame end in shells 0 - 1 (~5 occupied cells,
+    //      ~60 centres).  (Round 3 shared shells 2 - 3 between the 64 lanes of the wave, one unresolved point at a time with a butterfly
+    //      merge of the top-3 sets: bit-identical, but 356 us instead of 170 us per 120k-point frame on the device - removed.)
+    for (int r = 0; r <= CG_RMAX; ++r) {
       const int z0 = max(cc[2] - r, 0), z1 = min(cc[2] + r, g.dim[2] - 1);
       const int y0 = max(cc[1] - r, 0), y1 = min(cc[1] + r, g.dim[1] - 1);
       const int x0 = max(cc[0] - r, 0), x1 = min(cc[0] + r, g.dim[0] - 1);
@@ -352,52 +353,6 @@ __global__ __launch_bounds__(256) void k_devox_grid(const float *points, int pt_
         }
       }
       if (shell_done(r, cc, gap, t.d2)) { resolved = true; break; }
-    }
-  }
-  // ---- shells CG_RLANE + 1 .. CG_RMAX, the WAVE for one point at a time.  A wave runs as long as its slowest lane, and 3 of 4 waves hold
-  // at least one of the ~2 % of points whose third neighbour lies beyond shell 1: alone, such a lane walks 98 (then 218) more cells with a
-  // dependent L2 round trip per occupied one while 63 lanes wait.  Here the 64 lanes share the shell's cells, then merge their top-3 sets
-  // (distance, index order: the result does not depend on who compared what).
-  {
-    const int lane = threadIdx.x & 63;
-    // (a point without three candidates in its 27 cells is metres from everything - typically a return outside the voxel range, and such
-    // points come in whole waves: they go straight to k_devox_hard instead of queueing up here)
-    unsigned long long pend = __ballot(!resolved && t.d2 < __int_as_float(0x7f800000));
-    while (pend) {
-      const int src = __ffsll((long long)pend) - 1;
-      pend &= pend - 1;
-      const float px = __shfl(ux, src), py = __shfl(uy, src), pz = __shfl(uz, src);
-      const int c3[3] = {__shfl(cc[0], src), __shfl(cc[1], src), __shfl(cc[2], src)};
-      const float gp[3] = {__shfl(gap[0], src), __shfl(gap[1], src), __shfl(gap[2], src)};
-      Top3 tw;  // the point's set so far on its own lane, empty elsewhere
-      top3_init(tw);
-      if (lane == src) tw = t;
-      bool done = false;
-      for (int r = CG_RLANE + 1; r <= CG_RMAX && !done; ++r) {
-        const float best = __shfl(tw.d2, src);  // (every lane holds the merged set after a shell; before the first one only `src` does)
-        const int w = 2 * r + 1, ncell = w * w * w;
-        for (int n = lane; n < ncell; n += 64) {
-          const int dz = n / (w * w) - r, rem = n % (w * w), dy = rem / w - r, dx = rem % w - r;
-          if (max(max(abs(dx), abs(dy)), abs(dz)) != r) continue;  // the shell only
-          const int x = c3[0] + dx, y = c3[1] + dy, z = c3[2] + dz;
-          if (x < 0 || y < 0 || z < 0 || x >= g.dim[0] || y >= g.dim[1] || z >= g.dim[2]) continue;
-          const int cell = (z * g.dim[1] + y) * g.dim[0] + x;
-          if (!((s_occ[cell >> 5] >> (cell & 31)) & 1u)) continue;
-          scan_cell(cell, x, y, z, px, py, pz, fminf(best, tw.d2), tw);
-        }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {  // butterfly: afterwards every lane holds the wave's set
-          const float e0 = __shfl_xor(tw.d0, off), e1 = __shfl_xor(tw.d1, off), e2 = __shfl_xor(tw.d2, off);
-          const int j0 = __shfl_xor(tw.i0, off), j1 = __shfl_xor(tw.i1, off), j2 = __shfl_xor(tw.i2, off);
-          if (e0 < __int_as_float(0x7f800000)) top3_push_lex(tw, e0, j0);
-          if (e1 < __int_as_float(0x7f800000)) top3_push_lex(tw, e1, j1);
-          if (e2 < __int_as_float(0x7f800000)) top3_push_lex(tw, e2, j2);
-        }
-        done = shell_done(r, c3, gp, tw.d2);
-        if (lane == src) t = tw;
-        else top3_init(tw);  // one copy of the merged set only: the next merge must not meet an entry twice
-      }
-      if (lane == src) resolved = done;
     }
   }
   if (active && !resolved) {
