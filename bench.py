@@ -19,11 +19,22 @@ end-to-end logit error against a float64 evaluation is BELOW the exact-f32 MFMA 
 measured (tests/test_gpu_parity.py::test_sdseg3d_every_arithmetic_vs_float64_..., profiles/round2_accuracy_*.json, DESIGN.md 4.1) —
 and the 8-product variant (`f32_grade_8_product_mode`) and the exact-f32 path (`exact_f32_mode`) are timed beside it.
 
+`--gpus N` without a torch.distributed.run environment checks that the box has N GPUs (exit code 2 otherwise) and re-executes itself
+under `python -m torch.distributed.run --nproc-per-node N` (the reference launches its test the same way: tools/dist_test.py:99-104,
+docs/semanticNusc.md:72); inside such an environment WORLD_SIZE must equal N.  The record carries what RCCL saw (`rccl_world_size`,
+`ranks`: per-rank device and frames/s).
+
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     — the sparse-conv stack (37 launches, contiguous on the main stream, bracketed by two HIP-event pairs per frame: level 1 | the rest):
                  algorithmic pair-model bytes sum_l P_l*(Cin+Cout)*4 (SURVEY.md §8d) over its measured duration;
+  stage_rooflines — every other stage SURVEY.md §8(d) lists (voxelize, reader, rulebooks + plans, devoxelization, head; MSeg3D: grid gather, SFAM,
+                 SF-Phase decoder) with its algorithmic bytes / flops, duration and fraction of its bound;
+  batched      — frames/s with 1 / 2 / 4 / 8 frames collated into one forward, in the arithmetic of `value`;
   cpu_baseline — the CPU oracle (oracle/ref.py, kind "port") timed on the host cores on a bounded sample;
   stages_ms    — per-stage HIP-event breakdown of a frame; latency — median / p95 of the per-step wall time.
+
+Test hook (tests/test_host_logic.py, never set by the product): LS3D_BENCH_HIPSIM=1 runs the same code path on CPU tensors with the kernels of
+tests/hipsim and the gloo backend, so that the N > 1 bookkeeping is exercised where there is no GPU.
 """
 import argparse
 import json
@@ -42,7 +53,9 @@ if ROOT not in sys.path:
 F32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
-PMC_RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_pmc.json")  # tools/collect_profiles.sh -> profiles/summarize_pmc.py
+import glob as _glob
+# the newest counter record: tools/collect_profiles.sh -> profiles/summarize_pmc.py -> profiles/round<N>_pmc.json
+PMC_RECORD = (sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round*_pmc.json"))) or [""])[-1]
 PLANE_PRODUCTS = {"bf16x6": 6, "bf16x8": 8, "bf16x3": 3}
 
 DTYPES = {
@@ -59,7 +72,8 @@ DTYPES = {
 def build_model(dev, seed=5, kind="sdseg3d"):
     import lidarseg3d_amd as L
     from lidarseg3d_amd import models_cfg, synth
-    cfg = models_cfg.mseg3d() if kind == "mseg3d" else models_cfg.sdseg3d()
+    kw = dict(pc_range=(-6.4, -6.4, -5.0, 6.4, 6.4, 3.0)) if SIM else {}  # test hook: a 128 x 128 x 40 grid keeps the host emulation in seconds
+    cfg = models_cfg.mseg3d(**kw) if kind == "mseg3d" else models_cfg.sdseg3d(**kw)
     model = L.build_detector(cfg, train_cfg=None, test_cfg={}).eval()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, seed).items()}
@@ -92,7 +106,7 @@ class ConvCensus:
             torch.cuda.synchronize()
         finally:
             ops.gather_gemm, ops.tile_conv = g, t
-        pairs, uniq, rows, algo, flops, bmin = {}, {}, {}, 0.0, 0.0, 0.0
+        pairs, uniq, rows, kv, algo, flops, bmin = {}, {}, {}, {}, 0.0, 0.0, 0.0
         for tbl, cin, cout, _, n_dev in self.meta:
             key = (tbl.data_ptr(), tbl.shape[0])
             if key not in pairs:
@@ -101,11 +115,23 @@ class ConvCensus:
                 pairs[key] = int((tbl >= 0).sum().item())
                 uniq[key] = int(torch.unique(tbl[tbl >= 0]).numel())
                 rows[key] = tbl.shape[0]
+                kv[key] = int(tbl.shape[1])
             algo += pairs[key] * (cin + cout) * 4.0
             flops += 2.0 * pairs[key] * cin * cout
             # B_min: what a launch cannot avoid moving: every referenced input row once, every output row once, the weights once
             bmin += (uniq[key] * cin + rows[key] * cout + tbl.shape[1] * cin * cout) * 4.0
-        return dict(launches=len(self.meta), tile_launches=sum(1 for m in self.meta if m[3] == "tile"), algo_bytes=algo, flops=flops, b_min_bytes=bmin)
+        first = self.meta[0] if self.meta else None
+        n_in = (int(first[4].item()) if first[4] is not None else first[0].shape[0]) if first else 0
+        return dict(launches=len(self.meta), tile_launches=sum(1 for m in self.meta if m[3] == "tile"), algo_bytes=algo, flops=flops, b_min_bytes=bmin,
+                    input_voxels=n_in, tables=sorted(set((rows[k], kv[k]) for k in rows), reverse=True))
+
+
+SIM = os.environ.get("LS3D_BENCH_HIPSIM") == "1"  # test hook, see the module docstring
+
+
+def _sync():
+    if not SIM:
+        torch.cuda.synchronize()
 
 
 def timed_steps(step, steps, warmup, dist=None, dev=None):
@@ -113,31 +139,37 @@ def timed_steps(step, steps, warmup, dist=None, dev=None):
     with torch.no_grad():
         for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
+        _sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-        t0 = time.perf_counter()
-        marks[0].record()
+        _sync()
+        marks = [] if SIM else [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ticks = [time.perf_counter()]
+        t0 = ticks[0]
+        if marks:
+            marks[0].record()
         for i in range(steps):
             step()
-            marks[i + 1].record()
-        torch.cuda.synchronize()
+            if marks:
+                marks[i + 1].record()
+            else:
+                ticks.append(time.perf_counter())
+        _sync()
         elapsed = time.perf_counter() - t0
+    local = elapsed
     if dist is not None:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps)) if marks else sorted(1e3 * (b - a) for a, b in zip(ticks[:-1], ticks[1:]))
     return elapsed, dict(median_ms=statistics.median(per), p95_ms=per[min(len(per) - 1, int(round(0.95 * (len(per) - 1))))], min_ms=per[0],
-                         max_ms=per[-1])
+                         max_ms=per[-1], local_elapsed_s=local)
 
 
 def cpu_baseline_worker(n_points, seed, threads, repeats, dump=None):
-    """runs in a child process: the CPU oracle's full SDSeg3D forward on one frame, timed `repeats` times; `dump`: .npy path that
-    receives the logits of the last run (the parity check of the frame the GPU legs time)"""
+    """runs in a child process: the CPU oracle's full SDSeg3D forward on one frame, one untimed warm-up run of the same frame, then timed
+    `repeats` times; `dump`: .npy path that receives the logits of the last run (the parity check of the frame the GPU legs time)"""
     from lidarseg3d_amd import synth
     from oracle import ref as orc
     torch.set_num_threads(threads)
@@ -148,7 +180,7 @@ def cpu_baseline_worker(n_points, seed, threads, repeats, dump=None):
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = {k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, 5).items()}
     frame = synth.lidar_frame(n_points, seed=seed, **synth.NUSC)
-    orc.sdseg3d_forward(sd, [synth.lidar_frame(2000, seed=1, **synth.NUSC)], synth.NUSC["voxel_size"], synth.NUSC["pc_range"])  # warm-up
+    orc.sdseg3d_forward(sd, [synth.lidar_frame(min(n_points, 4000), seed=1, **synth.NUSC)], synth.NUSC["voxel_size"], synth.NUSC["pc_range"])  # warm-up
     ts = []
     for _ in range(repeats):
         t0 = time.time()
@@ -182,25 +214,39 @@ def parity_vs_cpu(gpu_logits, cpu_logits, num_class=17):
                 within_1e3_at_scale_10=bool(10.0 * float(d.max()) / scale <= 1e-3))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(n_points, seed, gpu_logits=None):
-    """the CPU oracle (oracle/ref.py, a port: the reference has no CPU forward), rank 0 / N=1 only, bounded: median of 3 warmed
-    runs of ONE full-size frame on min(cores, 32) threads (torch-CPU index_add_/mm of the restatement stops scaling there: on a
-    256-thread host the uncapped run is >10x slower), plus a 1-thread figure on a 1/8-size frame"""
+    """the CPU oracle (oracle/ref.py, a port: the reference has no CPU forward), rank 0 / N=1 only, on a BOUNDED sample of the workload
+    (all host threads AND one thread, median of 5 after a warm-up, CPU model stated):
+      * `value`: median of 5 warmed runs of the FULL frame on min(cores, 32) threads - where the restatement's torch-CPU index_add_ / mm stop
+        scaling (on a 256-thread host the uncapped run is > 10x slower) - and the run whose logits are compared with the GPU's;
+      * `all_threads`: os.cpu_count() threads, median of 5 warmed runs of a 1/8-size frame, scaled linearly in the point count;
+      * `single_thread`: 1 thread, median of 5 warmed runs of a 1/8-size frame, scaled likewise."""
     cores = os.cpu_count() or 1
     threads = min(cores, 32)
     dump = None
     if gpu_logits is not None and gpu_logits.shape[0] == n_points:
         import tempfile
         dump = os.path.join(tempfile.gettempdir(), "ls3d_cpu_logits_%d.npy" % os.getpid())
+    med = lambda v: statistics.median(v)
     try:
-        ts = _cpu_run(n_points, seed, threads, 3, 300, dump)
-        med = statistics.median(ts)
-        out = dict(value=1.0 / med, unit="frames/s", cores=threads, kind="port",
-                   sample="median of 3 warmed runs of 1 frame of %d points (%s s), full SDSeg3D forward incl. CPU voxelization, %d of %d host "
+        ts = _cpu_run(n_points, seed, threads, 5, 400, dump)
+        out = dict(value=1.0 / med(ts), unit="frames/s", cores=threads, kind="port", cpu_model=cpu_model(), host_threads=cores,
+                   sample="median of 5 warmed runs of 1 frame of %d points (%s s), full SDSeg3D forward incl. CPU voxelization, %d of %d host "
                           "threads; oracle/ref.py (torch-CPU gather-mm-scatter spconv restatement, OpenMP C exact 3-NN)"
                           % (n_points, "/".join("%.1f" % t for t in ts), threads, cores))
     except Exception as e:  # never let the baseline take the bench down
-        return dict(value=None, unit="frames/s", cores=threads, kind="port", sample="failed: %r" % (e,))
+        return dict(value=None, unit="frames/s", cores=threads, kind="port", cpu_model=cpu_model(), sample="failed: %r" % (e,))
     if dump is not None:
         try:
             out["parity"] = parity_vs_cpu(gpu_logits, np.load(dump))
@@ -209,13 +255,17 @@ def cpu_baseline(n_points, seed, gpu_logits=None):
         finally:
             if os.path.exists(dump):
                 os.remove(dump)
-    try:
-        small = max(n_points // 8, 1000)
-        t1 = _cpu_run(small, seed, 1, 1, 200)[0]
-        out["single_thread"] = dict(seconds=t1, points=small, frames_per_s_scaled_to_full_frame=1.0 / (t1 * n_points / small),
-                                    note="1 thread, 1/8-size frame, scaled linearly in the point count")
-    except Exception as e:
-        out["single_thread"] = dict(error=repr(e))
+    for key, thr, div in (("all_threads", cores, 8), ("single_thread", 1, 8)):
+        if key == "all_threads" and cores == threads:
+            out[key] = dict(threads=cores, frames_per_s=out["value"], note="the host has no more than %d threads: same run as `value`" % threads)
+            continue
+        try:
+            small = max(n_points // div, 1000)
+            t = _cpu_run(small, seed, thr, 5, 150)
+            out[key] = dict(threads=thr, points=small, seconds=t, median_s=med(t), frames_per_s_scaled_to_full_frame=1.0 / (med(t) * n_points / small),
+                            note="median of 5 warmed runs of a 1/%d-size frame, scaled linearly in the point count" % div)
+        except Exception as e:
+            out[key] = dict(threads=thr, error=repr(e))
     return out
 
 
@@ -250,6 +300,169 @@ def stage_breakdown(model, pts, B, frames=5):
     return {k: statistics.median(v) for k, v in acc.items()}
 
 
+class OpTimer(object):
+    """HIP-event pairs around selected host-level calls of ONE eager frame that runs on a single stream (LS3D_OVERLAP=0: geometry inline): the
+    per-stage durations behind `stage_rooflines`.  Each pair costs a few microseconds of idle GPU, so this leg only feeds the breakdown."""
+
+    def __init__(self):
+        self.ev, self.undo = {}, []
+
+    def wrap(self, label, owner, name, when=None):
+        fn = getattr(owner, name)
+
+        def timed(*a, **kw):
+            if when is not None and not when(*a, **kw):
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                return fn(*a, **kw)
+            finally:
+                e1.record()
+                self.ev.setdefault(label, []).append((e0, e1))
+        setattr(owner, name, timed)
+        self.undo.append((owner, name, fn))
+
+    def module(self, label, mod):
+        h0 = mod.register_forward_pre_hook(lambda m, a: self._open(label))
+        h1 = mod.register_forward_hook(lambda m, a, o: self._close(label))
+        self.undo.append((h0, None, None))
+        self.undo.append((h1, None, None))
+
+    def _open(self, label):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev.setdefault(label, []).append([e, None])
+
+    def _close(self, label):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev[label][-1][1] = e
+
+    def restore(self):
+        for owner, name, fn in reversed(self.undo):
+            if name is None:
+                owner.remove()
+            else:
+                setattr(owner, name, fn)
+        self.undo = []
+
+    def ms(self):
+        return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.ev.items()}
+
+    def clear(self):
+        self.ev = {}
+
+
+def stage_rooflines(model, example, kind, census, frames=5):
+    """SURVEY.md 8(d) "roofline bound per stage": duration (median over a few eager single-stream frames, HIP events around the stage's calls),
+    algorithmic bytes or flops from 8(d)'s formulas, and the fraction of the bound's peak.  The sparse-conv stack has its own object (`roofline`)."""
+    from lidarseg3d_amd import ops, spconv
+    pts = example["points"]
+    N, cp = int(pts.shape[0]), int(pts.shape[1]) - 1
+    tm = OpTimer()
+    prev = os.environ.get("LS3D_OVERLAP")
+    os.environ["LS3D_OVERLAP"] = "0"
+    shapes = {}
+
+    def note(label, fn):  # remembers an argument-derived size of the last call
+        def inner(*a, **kw):
+            shapes[label] = fn(*a, **kw)
+            return True
+        return inner
+    try:
+        tm.wrap("voxelize", ops, "voxelize_hard")
+        tm.module("reader", model.reader)
+        tm.wrap("rulebooks", spconv, "subm_rulebook")
+        tm.wrap("rulebooks", spconv, "prebuild_conv_rulebooks")
+        tm.wrap("plans+orders", spconv, "prebuild_orders")
+        tm.wrap("devox_search", ops, "devoxelize_grid")
+        tm.wrap("interpolate", ops, "interpolate_rows", note("interp_c", lambda feat, *a, **kw: int(feat.shape[1])))
+        tm.wrap("head_mlp", ops, "gather_gemm", lambda x, w, tbl=None, **kw: tbl is None and x.shape[0] >= N)
+        if kind == "mseg3d":
+            tm.wrap("grid_gather", ops, "grid_gather", note("img_c", lambda img, *a, **kw: int(img.shape[2])))
+            tm.wrap("sfam", ops, "sfam")
+            tm.wrap("sffm_decoder", ops, "sffm_decoder", note("sffm", lambda x, points, kv, L, batch, m: (int(x.shape[1]), int(L), m)))
+            tm.wrap("sffm_memory_side", ops, "cross_attn")
+        per = []
+        with torch.no_grad():
+            model(dict(example), return_loss=False)
+            for _ in range(frames):
+                tm.clear()
+                model(dict(example), return_loss=False)
+                torch.cuda.synchronize()
+                per.append(tm.ms())
+    finally:
+        tm.restore()
+        if prev is None:
+            os.environ.pop("LS3D_OVERLAP", None)
+        else:
+            os.environ["LS3D_OVERLAP"] = prev
+    ms = {k: statistics.median(d.get(k, 0.0) for d in per) for k in per[0]}
+    V = census.get("input_voxels", 0)
+    tables = census.get("tables", [])
+    out = {}
+
+    def hbm(label, nbytes, formula):
+        if label in ms and ms[label] > 0:
+            gbs = nbytes / (ms[label] * 1e-3) / 1e9
+            out[label] = dict(bound="hbm", ms=ms[label], algorithmic_bytes=nbytes, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                              formula=formula)
+
+    def mfma(label, flops, peak, dtype, formula, products=1):
+        if label in ms and ms[label] > 0:
+            tf = flops / (ms[label] * 1e-3) / 1e12
+            out[label] = dict(bound="mfma", ms=ms[label], algorithmic_flops=flops, achieved=products * tf, useful_f32_equivalent_tflops=tf, peak=peak,
+                              unit="TFLOP/s", dtype=dtype, frac=products * tf / peak, formula=formula)
+    hbm("voxelize", N * (1 + cp) * 4.0 + V * (5 * cp + 5) * 4.0 + 2.0 * N * 16, "N*(1+Cp)*4 read + V*(5*Cp+5)*4 written + hash 2N*16 (DESIGN.md 4)")
+    c_vfe = int(model.backbone.conv_input[0].in_channels)
+    if kind == "sdseg3d":
+        f_tok = 2.0 * (2 * cp + 8) * 64 + 3.0 * (8 * 64 * 64 + 4 * 5 * 64 + 4 * 64 * 128)
+        np_ = PLANE_PRODUCTS.get(ops.get_precision())
+        mfma("reader", V * 5.0 * f_tok, BF16_MFMA_PEAK_TFLOPS if np_ else F32_MFMA_PEAK_TFLOPS, "bf16 planes" if np_ else "f32",
+             "TransVFE, SURVEY.md 8(d): V*5*(2*(2Cp+8)*64 + 3*(8*64*64 + 4*5*64 + 4*64*128)) over ALL 5 slots (the kernel computes a voxel's identical "
+             "padding tokens once: fewer executed flops, same algorithmic ones)", products=np_ or 1)
+    else:
+        hbm("reader", V * 5.0 * cp * 4 + V * 4.0 + V * c_vfe * 4.0, "ImprovedMeanVFE: V*5*Cp*4 + V*4 read + V*C_vfe*4 written")
+    hbm("rulebooks", sum(r * k * 4.0 for r, k in tables) + sum(r * 16.0 * 2 for r, k in tables if k == 27),
+        "sum over the 8 rulebooks of rows*kvol*4 (SURVEY.md 8(d): V*27*4 per table) + hash 2V*16 per SubM index")
+    hbm("plans+orders", sum(r * k * 4.0 + r * k * 2.0 + r * 8.0 for r, k in tables if k == 27),
+        "per tile plan: table read rows*27*4 + 16-bit local table written rows*27*2 + keys / order rows*8")
+    hbm("devox_search", N * 16.0 + V * 16.0 + N * 24.0, "SURVEY.md 8(d) windowed search: N*12(+4 batch) + V*12(+4) read + N*(12+12) idx / weights written")
+    ic = shapes.get("interp_c", 32)
+    hbm("interpolate", 3.0 * N * ic * 4 + N * ic * 4.0 + N * 24.0, "3*N*C*4 gathered + N*C*4 written + N*24 idx / weights")
+    if kind == "mseg3d":
+        c_img = shapes.get("img_c", 48)
+        hbm("grid_gather", 0.75 * N * 4 * c_img * 4.0 + N * c_img * 4.0, "SURVEY.md 8(d): Nv*4 taps*48*4 + N*48*4 (Nv = 0.75 N valid points)")
+        hbm("sfam", V * (32 + 17) * 4.0 * 2, "softmax over voxels: V*(C + cls)*4, two passes")
+        if "sffm" in shapes:
+            d_in, L, m = shapes["sffm"]
+            d, ffn, layers = int(m.c.d_model), int(m.c.ffn), int(m.c.num_layers)
+            flops = N * (2.0 * d_in * d + layers * (2.0 * d * d * 2 + 2.0 * 2 * d * L + 2.0 * 2 * d * ffn))
+            mfma("sffm_decoder", flops, F32_MFMA_PEAK_TFLOPS, "f32",
+                 "SURVEY.md 8(d) SFFM: N*(2*d_in*d + layers*(2*d*d*2 + 2*2*d*L + 2*2*d*ffn)), d=%d, L=%d tokens, ffn=%d, %d layers" % (d, L, ffn, layers))
+    out["_unattributed_ms"] = {k: v for k, v in ms.items() if k not in out}
+    return out
+
+
+def relaunch_under_launcher(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed.run environment: fail loudly when the box does not have N GPUs, else
+    re-execute this command as one rank per GPU (tools/dist_test.py:99-104 of the reference runs under torch.distributed.launch the same way)"""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not SIM and have < args.gpus:
+        print("bench.py --gpus %d: this box has %d GPU(s); refusing to report a %d-GPU figure from fewer devices" % (args.gpus, have, args.gpus),
+              file=sys.stderr)
+        raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,7 +473,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=list(DTYPES), default="bf16x6",
                     help="arithmetic of the sparse convolutions (see the module docstring); f32 = exact-f32 MFMA everywhere")
-    ap.add_argument("--no-extra-modes", action="store_true", help="skip the extra legs (exact f32, bf16x3, two streams, MSeg3D)")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the extra legs (exact f32, bf16x3, two streams, batched, MSeg3D)")
     ap.add_argument("--no-fast-mode", action="store_true", help=argparse.SUPPRESS)  # round-1 spelling of --no-extra-modes
     ap.add_argument("--streams", type=int, default=1,
                     help="throughput mode: a step = this many frames, each a batch of one on its own HIP stream; SDSeg3D only")
@@ -278,19 +491,40 @@ def main():
         cpu_baseline_worker(*[int(v) for v in w[:4]], dump=(w[4] if len(w) > 4 else None))
         return
     extra_modes = not (args.no_extra_modes or args.no_fast_mode)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        relaunch_under_launcher(args, sys.argv[1:])
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    from lidarseg3d_amd import sharding
+    rank, local_rank, world = sharding.env_rank_world()
+    if world != args.gpus:
+        print("bench.py --gpus %d inside a launcher environment with WORLD_SIZE=%d: the record would not be a %d-GPU figure" % (args.gpus, world, args.gpus),
+              file=sys.stderr)
+        raise SystemExit(2)
+    if SIM:  # test hook: the kernels of tests/hipsim on CPU tensors, gloo instead of RCCL
+        sys.path.insert(0, os.path.join(ROOT, "tests", "hipsim"))
+        import build_sim
+        from lidarseg3d_amd import _lib as l3lib, ops as l3ops
+        l3lib.use_library_for_testing(build_sim.build())
+        l3ops.set_sim(True)
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        if torch.cuda.device_count() <= local_rank:
+            print("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()), file=sys.stderr)
+            raise SystemExit(2)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("LS3D_BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://")
+        dist.init_process_group("gloo" if SIM else "nccl", init_method="env://")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
 
     from lidarseg3d_amd import detectors, ops, scn_unet, synth
     ops.set_precision(args.precision)
@@ -298,21 +532,26 @@ def main():
     model, sd = build_model(dev, kind=args.model)
     B = max(1, args.frames_per_step)
     S = max(1, args.streams)
-    TP = 2 if (args.model == "sdseg3d" and B == 1 and S == 1 and world == 1 and extra_modes) else 0
+    single = world == 1 and dist is None
+    TP = 2 if (args.model == "sdseg3d" and B == 1 and S == 1 and single and extra_modes and not SIM) else 0
+    # frames shard across the ranks as independent units (sharding.shard_frames): rank r of N times frames r*B .. r*B + B - 1 of the N*B
+    my_frames = sharding.shard_frames(world * B, rank, world)
 
-    def make_inputs(kind, n_streams):
-        frames = [synth.lidar_frame(args.points, seed=100 + rank * B + b, **synth.NUSC) for b in range(B)]
-        pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1)
-                                               for b, f in enumerate(frames)])).to(dev)
+    def frames_to_points(frames):
+        return torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])).to(dev)
+
+    def make_inputs(kind, n_streams, frame_ids=None, seed0=100):
+        ids = my_frames if frame_ids is None else frame_ids
+        pts = frames_to_points([synth.lidar_frame(args.points, seed=seed0 + i, **synth.NUSC) for i in ids])
         extra = {}
         if kind == "mseg3d":  # HRNet-w18 feature maps of 6 cameras at 1/4 resolution + camera class embeddings (inputs of the path)
-            img, emb, cuv = synth.camera_inputs(args.points * B, seed=100 + rank, ncam=6, c_img=48, h=160, w=240, batch=B)
+            img, emb, cuv = synth.camera_inputs(args.points * len(ids), seed=seed0 + ids[0], ncam=6, c_img=48, h=160, w=240, batch=len(ids))
             extra = dict(points_cuv=torch.from_numpy(cuv).to(dev), image_features=torch.from_numpy(img).to(dev),
                          camera_semantic_embeddings=torch.from_numpy(emb).to(dev))
         spts, streams = [], []
         if n_streams > 1:
-            sframes = [synth.lidar_frame(args.points, seed=100 + rank * n_streams + i, **synth.NUSC) for i in range(n_streams)]
-            spts = [torch.from_numpy(np.concatenate([np.zeros((f.shape[0], 1), np.float32), f], 1)).to(dev) for f in sframes]
+            sframes = [synth.lidar_frame(args.points, seed=seed0 + rank * n_streams + i, **synth.NUSC) for i in range(n_streams)]
+            spts = [frames_to_points([f]) for f in sframes]
             streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
         return pts, extra, spts, streams
 
@@ -320,9 +559,9 @@ def main():
     if S > 1:
         assert args.model == "sdseg3d" and B == 1, "--streams: SDSeg3D, one frame per stream"
 
-    def make_step(m, pts_, extra_, n_streams):
+    def make_step(m, pts_, extra_, n_streams, nb=B):
         if n_streams == 1:
-            return lambda: m(dict(points=pts_, batch_size=B, **extra_), return_loss=False)[0]["pred_point_sem_labels"]
+            return lambda: m(dict(points=pts_, batch_size=nb, **extra_), return_loss=False)[0]["pred_point_sem_labels"]
 
         def step_n():
             cur = torch.cuda.current_stream(dev)
@@ -340,19 +579,20 @@ def main():
         """one leg: W untimed + K timed steps; with one stream also the conv-stack event brackets of the timed steps"""
         ops.set_precision(prec)
         st = make_step(model, pts, extra, n_streams)
-        census = ConvCensus(ops).run(make_step(model, pts, extra, 1)) if n_streams == 1 else None
+        census = ConvCensus(ops).run(make_step(model, pts, extra, 1)) if (n_streams == 1 and not SIM) else None
         events = []
-        scn_unet.UNetSCN3D.conv_stack_events = events if n_streams == 1 else None
+        scn_unet.UNetSCN3D.conv_stack_events = events if (n_streams == 1 and not SIM) else None
         try:
             with torch.no_grad():
                 for _ in range(warmup):
                     st()
-            torch.cuda.synchronize()
+            _sync()
             del events[:]  # the brackets of the warm-up steps
             elapsed, lat = timed_steps(st, steps, 0, dist if with_dist else None, dev)
         finally:
             scn_unet.UNetSCN3D.conv_stack_events = None
-        out = dict(precision=prec, frames_per_s=world * B * n_streams * steps / elapsed, ms_per_step=1e3 * elapsed / steps, latency=lat)
+        out = dict(precision=prec, frames_per_s=world * B * n_streams * steps / elapsed, ms_per_step=1e3 * elapsed / steps, latency=lat,
+                   local_frames_per_s=B * n_streams * steps / lat["local_elapsed_s"])
         if census is not None and events:
             per = max(len(events) // steps, 1)  # (start, end) pairs per frame: the stack is bracketed in contiguous pieces
             ms = [a.elapsed_time(b) for a, b in events]
@@ -369,7 +609,7 @@ def main():
     # from Python and its latency-bound geometry chain is host-bound; it stays in the record (`eager_mode`) and carries the HIP-event
     # brackets of the sparse-conv stack (timing events cannot be captured) - the graph replays exactly those launches
     graph_leg = None
-    if not args.no_graph and S == 1 and B == 1 and detectors.CAPACITY_MODE:
+    if not args.no_graph and S == 1 and B == 1 and detectors.CAPACITY_MODE and not SIM:
         try:
             from lidarseg3d_amd import graph as lgraph
             ops.set_precision(args.precision)
@@ -379,35 +619,69 @@ def main():
             elapsed, lat = timed_steps(gstep, args.steps, args.warmup, dist, dev)
             same = bool(torch.equal(fg.logits, ref_logits))
             graph_leg = dict(frames_per_s=world * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, latency=lat,
+                             local_frames_per_s=args.steps / lat["local_elapsed_s"],
                              logits_bit_identical_to_eager=same, fallbacks=fg.fallbacks, recaptures=fg.recaptures)
-            # the reference's `--speed_test` way of timing (tools/dist_test.py:189-230: host data in, synchronise, host results out):
-            # the frame starts in pinned host memory, crosses PCIe into the graph's input buffer, the labels come back to the host
-            hpts = pts.cpu().pin_memory()
-            hlab = torch.empty((pts.shape[0],), dtype=torch.int64).pin_memory()
+            if single:
+                # the reference's `--speed_test` way of timing (tools/dist_test.py:189-230: host data in, synchronise, host results out):
+                # the frame starts in pinned host memory, crosses PCIe into the graph's input buffer, the labels come back to the host
+                hpts = pts.cpu().pin_memory()
+                hlab = torch.empty((pts.shape[0],), dtype=torch.int64).pin_memory()
 
-            def pstep():
-                lab = fg(dict(points=hpts, batch_size=1, **extra), clone=False)[0]["pred_point_sem_labels"]
-                hlab.copy_(lab, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                return lab
-            el3, lat3 = timed_steps(pstep, max(args.steps // 2, 5), 2)
-            graph_leg["pcie_inclusive"] = dict(frames_per_s=max(args.steps // 2, 5) / el3, ms_per_step=1e3 * el3 / max(args.steps // 2, 5), latency=lat3,
-                                               bytes_in=int(hpts.numel() * 4), bytes_out=int(hlab.numel() * 8),
-                                               note="points from pinned host memory, labels back to pinned host memory, one synchronisation per frame")
+                def pstep():
+                    lab = fg(dict(points=hpts, batch_size=1, **extra), clone=False)[0]["pred_point_sem_labels"]
+                    hlab.copy_(lab, non_blocking=True)
+                    torch.cuda.current_stream().synchronize()
+                    return lab
+                el3, lat3 = timed_steps(pstep, max(args.steps // 2, 5), 2)
+                graph_leg["pcie_inclusive"] = dict(frames_per_s=max(args.steps // 2, 5) / el3, ms_per_step=1e3 * el3 / max(args.steps // 2, 5), latency=lat3,
+                                                   bytes_in=int(hpts.numel() * 4), bytes_out=int(hlab.numel() * 8),
+                                                   note="points from pinned host memory, labels back to pinned host memory, one synchronisation per frame")
             del fg
         except Exception as e:  # never let the graph path take the bench down: the eager leg is the value then
             graph_leg = dict(error=repr(e))
+    head = graph_leg if (graph_leg and "error" not in graph_leg) else main_leg
+    # what every rank measured, gathered over the process group: a record of N ranks can be checked rank by rank
+    mine = dict(rank=rank, local_rank=local_rank, device=str(dev), device_name=(torch.cuda.get_device_name(dev) if not SIM else "hipsim (test hook)"),
+                frame_seeds=[100 + i for i in my_frames], frames_per_s=head["local_frames_per_s"],
+                ms_per_step=1e3 * head["latency"]["local_elapsed_s"] / args.steps)
+    ranks = sharding.gather_frame_results(mine) if dist is not None else [mine]
     value_logits_cpu = ref_logits[:args.points].cpu() if (B == 1 and S == 1) else None  # frame 0 of rank 0 = the CPU baseline's frame
-    stages = stage_breakdown(model, pts, B) if (S == 1 and args.model == "sdseg3d") else None
+    stages = stage_breakdown(model, pts, B) if (S == 1 and args.model == "sdseg3d" and not SIM) else None
+    stage_roof = None
+    if S == 1 and B == 1 and single and not SIM:
+        try:
+            ops.set_precision(args.precision)
+            stage_roof = stage_rooflines(model, dict(points=pts, batch_size=1, **extra), args.model, main_leg.get("census") or {})
+        except Exception as e:
+            stage_roof = dict(error=repr(e))
 
     legs = {}
-    if extra_modes and world == 1 and S == 1 and B == 1:
+    if extra_modes and single and S == 1 and B == 1 and not SIM:
         for prec in [p for p in ("f32", "bf16x8", "bf16x6", "bf16x3") if p != args.precision]:
             leg = measure(prec, args.steps, max(2, args.warmup), 1, False)
             got = model.point_head.forward_ret_dict["out_logits"]
             leg["max_rel_logit_diff_vs_value_mode"] = float((got - ref_logits).abs().max() / ref_logits.abs().max())
             leg["argmax_agreement_vs_value_mode"] = float((got.argmax(1) == ref_logits.argmax(1)).float().mean())
             legs[prec] = leg
+    batched = None
+    if extra_modes and single and S == 1 and B == 1 and not SIM:
+        # "frames/s (B = 1 latency^-1 AND batched throughput)" in the arithmetic of `value`: fb frames collated into ONE forward
+        # (collate.py:141-150: batch index in column 0), eager submission in capacity mode (the host's ~3 ms of launches are amortised over fb
+        # frames; FrameGraph captures single frames).  The reference trains / tests with samples_per_gpu = 2 (semwaymo_..._e12.py:231).
+        batched = dict(precision=args.precision, execution="eager, capacity mode, one forward per step", legs=[])
+        try:
+            ops.set_precision(args.precision)
+            for fb in (1, 2, 4, 8):
+                pb, eb, _, _ = make_inputs(args.model, 1, frame_ids=list(range(fb)))
+                torch.cuda.reset_peak_memory_stats(dev)
+                nb = max(args.steps // fb, 3)
+                elb, latb = timed_steps(make_step(model, pb, eb, 1, nb=fb), nb, 2)
+                batched["legs"].append(dict(frames_per_step=fb, frames_per_s=fb * nb / elb, ms_per_step=1e3 * elb / nb, ms_per_frame=1e3 * elb / nb / fb,
+                                            steps=nb, peak_resident_GB=torch.cuda.max_memory_allocated(dev) / 1e9))
+                del pb, eb
+        except Exception as e:
+            batched["error"] = repr(e)
+        torch.cuda.empty_cache()
     throughput = None
     if TP:
         # two frames in flight per GPU, one HIP stream each: the host-side launch work of one frame (the start of a frame is
@@ -446,7 +720,7 @@ def main():
             except Exception as e:
                 throughput["graph_error"] = repr(e)
     mseg = None
-    if extra_modes and world == 1 and args.model == "sdseg3d" and S == 1 and B == 1:
+    if extra_modes and single and args.model == "sdseg3d" and S == 1 and B == 1 and not SIM:
         # BASELINE configs[2] in the same driver-timed run: MSeg3D = + 6-camera feature maps, GF-/SF-Phase head
         del model
         torch.cuda.empty_cache()
@@ -454,6 +728,7 @@ def main():
         m2, _ = build_model(dev, kind="mseg3d")
         p2, e2, _, _ = make_inputs("mseg3d", 1)
         n2 = max(args.steps // 2, 5)
+        census2 = ConvCensus(ops).run(make_step(m2, p2, e2, 1))
         el2, lat2 = timed_steps(make_step(m2, p2, e2, 1), n2, 3)
         mseg = dict(metric="frames/sec, MSeg3D forward (LiDAR + 6-cam HRNet-w18 features [1,6,48,160,240], GF+SF-Phase), 120k-pt frame",
                     precision=args.precision, value=n2 / el2, ms_per_step=1e3 * el2 / n2, latency=lat2, steps=n2, execution="eager")
@@ -468,6 +743,13 @@ def main():
                 del fg2
             except Exception as e:
                 mseg["graph_error"] = repr(e)
+        try:  # configs[2]'s own roofline objects: the fused SF-Phase decoder (MFMA-bound) first, then the other stages of the frame
+            sr2 = stage_rooflines(m2, dict(points=p2, batch_size=1, **e2), "mseg3d", census2)
+            if "sffm_decoder" in sr2:
+                mseg["roofline"] = dict(kernel="k_sffm_decoder (SF-Phase decoder, 6 layers in one launch)", **sr2["sffm_decoder"])
+            mseg["stage_rooflines"] = sr2
+        except Exception as e:
+            mseg["stage_rooflines"] = dict(error=repr(e))
         # BASELINE configs[4]: MSeg3D with bf16 convolutions and fp8 (e4m3) SF-Phase attention, batches sized into the 288 GB of HBM.
         # Narrower arithmetic than the reference's fp32 (tolerance vs the oracle: tests/test_gpu_parity.py::test_bf16_mode_tolerance_vs_oracle),
         # so it never feeds `value`; frames per step are collated into one forward (host-count path: FrameGraph is single-frame).
@@ -475,19 +757,27 @@ def main():
         try:
             ops.set_precision("bf16")
             ops.set_sffm_attention("fp8")
-            for fb in (1, 4, 8):
-                fr = [synth.lidar_frame(args.points, seed=300 + b, **synth.NUSC) for b in range(fb)]
-                pb = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(fr)])).to(dev)
-                img, emb, cuv = synth.camera_inputs(args.points * fb, seed=300, ncam=6, c_img=48, h=160, w=240, batch=fb)
-                exb = dict(points=pb, batch_size=fb, points_cuv=torch.from_numpy(cuv).to(dev), image_features=torch.from_numpy(img).to(dev),
-                           camera_semantic_embeddings=torch.from_numpy(emb).to(dev))
+            last = 0.0
+            for fb in (1, 4, 8, 16, 32):
+                pb, eb, _, _ = make_inputs("mseg3d", 1, frame_ids=list(range(fb)), seed0=300)
+                exb = dict(points=pb, batch_size=fb, **eb)
                 torch.cuda.reset_peak_memory_stats(dev)
                 stepb = lambda: m2(dict(exb), return_loss=False)[0]["pred_point_sem_labels"]
-                nb = max(args.steps // (2 * fb), 3)
-                elb, _ = timed_steps(stepb, nb, 2)
-                cfg4["legs"].append(dict(frames_per_step=fb, frames_per_s=fb * nb / elb, ms_per_step=1e3 * elb / nb,
+                nb = max(args.steps // (2 * fb), 2)
+                elb, _ = timed_steps(stepb, nb, 1 if fb > 8 else 2)
+                fps = fb * nb / elb
+                cfg4["legs"].append(dict(frames_per_step=fb, frames_per_s=fps, ms_per_step=1e3 * elb / nb,
                                          peak_resident_GB=torch.cuda.max_memory_allocated(dev) / 1e9))
-                del exb, pb
+                del exb, pb, eb
+                torch.cuda.empty_cache()
+                if fb >= 8 and fps < 1.02 * last:  # batch sizing: stop where another doubling buys < 2 %
+                    cfg4["saturated_at_frames_per_step"] = fb
+                    break
+                last = fps
+            peak = max(l["peak_resident_GB"] for l in cfg4["legs"])
+            per_frame = peak / cfg4["legs"][-1]["frames_per_step"]
+            cfg4["hbm_288GB_sizing"] = dict(resident_GB_per_frame=per_frame, frames_that_fit_in_250GB=int(250.0 / per_frame),
+                                            note="throughput saturates long before memory does: one frame keeps the 256 CUs busy for milliseconds")
         except Exception as e:
             cfg4["error"] = repr(e)
         finally:
@@ -502,11 +792,10 @@ def main():
         c = main_leg.get("census") or {}
         stack = main_leg.get("conv_stack_ms") or {}
         mean_ms = stack.get("mean", 0.0)
-        achieved = c["algo_bytes"] / (mean_ms * 1e-3) / 1e9 if mean_ms else 0.0
-        head = graph_leg if (graph_leg and "error" not in graph_leg) else main_leg
+        achieved = c["algo_bytes"] / (mean_ms * 1e-3) / 1e9 if (mean_ms and c) else 0.0
         out = {
             "metric": "frames/sec, SDSeg3D forward, 120k-pt nuScenes-style frame",
-            "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": dist.get_world_size() if dist is not None else 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead), "
@@ -515,9 +804,16 @@ def main():
                        "precision": args.precision, "frames_per_gpu_per_step": B * S, "streams": S,
                        "host_syncs_per_frame": ("0 blocking (capacity mode: device-side row counts; one wait for the frame's rulebook counts, "
                                                 "which are ready early in the frame)" if detectors.CAPACITY_MODE else "3 (host-side row counts)"),
-                       "parallelism": "frames sharded 1/GPU (dp%d)" % world},
-            "latency": head["latency"],
+                       "parallelism": "frames sharded 1/GPU (dp%d), no data-path collective" % world},
+            "latency": {k: v for k, v in head["latency"].items() if k != "local_elapsed_s"},
+            # the process group as the collective library saw it: world size from dist.get_world_size(), one entry per rank
+            "rccl_world_size": dist.get_world_size() if dist is not None else 1,
+            "collective_backend": (dist.get_backend() if dist is not None else None),
+            "rccl_version": (list(torch.cuda.nccl.version()) if (dist is not None and not SIM) else None),
+            "ranks": ranks,
         }
+        if SIM:
+            out["data"] = "synthetic (LS3D_BENCH_HIPSIM test hook: kernels emulated on the host - not a measurement)"
         out["config"]["execution"] = ("one hipGraph per frame (capacity mode: device-side row counts, both streams captured); the host copies the "
                                       "frame in, replays, waits for the frame and reads its overflow flags" if head is graph_leg
                                       else "eager: every launch submitted from Python")
@@ -560,13 +856,15 @@ def main():
                 r = j.get(args.precision)
                 if r:
                     out["roofline"]["traffic"] = r["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/round3_pmc.json: (2*FETCH_SIZE+WRITE_SIZE)*1024 per sparse-conv launch, corrected per MI355X_MICROARCH.md; kernels " + ", ".join(r.get("kernels", []))
+                    out["roofline"]["traffic_source"] = os.path.relpath(PMC_RECORD, ROOT) + ": (2*FETCH_SIZE+WRITE_SIZE)*1024 per sparse-conv launch, corrected per MI355X_MICROARCH.md; kernels " + ", ".join(r.get("kernels", []))
                     out["roofline"]["hbm_physical_GBps"] = r["traffic_bytes_per_launch"] * c["launches"] / (mean_ms * 1e-3) / 1e9 if mean_ms else None
                     if r.get("mfma_busy") is not None:
                         out["roofline"]["mfma"]["mfma_busy"] = r["mfma_busy"]
-                        out["roofline"]["mfma"]["mfma_busy_source"] = "profiles/round3_pmc_sq.md: SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, time-weighted over the stack's kernels"
+                        out["roofline"]["mfma"]["mfma_busy_source"] = os.path.relpath(PMC_RECORD, ROOT).replace(".json", "_sq.md") + ": SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, time-weighted over the stack's kernels"
         if stages is not None:
             out["stages_ms"] = stages
+        if stage_roof is not None:
+            out["stage_rooflines"] = stage_roof
         for prec, leg in legs.items():
             key = {"f32": "exact_f32_mode", "bf16x3": "fast_mode", "bf16x8": "f32_grade_8_product_mode", "bf16x6": "f32_grade_6_product_mode"}[prec]
             out[key] = dict(precision=DTYPES[prec], value=leg["frames_per_s"], ms_per_step=leg["ms_per_step"], latency=leg["latency"],
@@ -575,6 +873,8 @@ def main():
                             argmax_agreement_vs_value_mode=leg["argmax_agreement_vs_value_mode"])
             if prec == "f32" and leg.get("tflops"):
                 out[key]["mfma"] = dict(achieved_tflops=leg["tflops"], peak_tflops=F32_MFMA_PEAK_TFLOPS, frac=leg["tflops"] / F32_MFMA_PEAK_TFLOPS)
+        if batched is not None:
+            out["batched"] = batched
         if throughput is not None:
             out["throughput_mode"] = throughput
         if mseg is not None:
@@ -586,7 +886,7 @@ def main():
             out["config"]["workload"] = out["config"]["workload"].replace(
                 "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead)",
                 "nuScenes MSeg3D (ImprovedMeanVFE->UNetSCN3D->PointSegMSeg3DHead GF+SF-Phase, image_features [1,6,48,160,240])")
-        if world == 1 and not args.no_cpu_baseline and args.model == "sdseg3d":
+        if single and not args.no_cpu_baseline and args.model == "sdseg3d" and not SIM:
             out["cpu_baseline"] = cpu_baseline(args.cpu_points or args.points, 100, value_logits_cpu)
             if "parity" in out["cpu_baseline"]:  # GPU logits of the TIMED frame (value's arithmetic) vs the CPU oracle's
                 out["parity_vs_cpu"] = out["cpu_baseline"].pop("parity")

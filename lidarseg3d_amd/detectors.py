@@ -47,8 +47,9 @@ def _voxel_inputs(example, voxel_cfg, capacity=False):
         # no frame can reach the dataloader's per-frame cap (a frame has at most as many voxels as points): one batched launch
         # is bit-identical to voxelising frame by frame
         v, c, n, nv = ops.voxelize_hard(points, voxel_cfg["voxel_size"], voxel_cfg["range"], mp, int(mv) * batch_size, batched=True)
-        if capacity and off is None:
-            # capacity mode: all min(N, cap) rows stay, the count stays on the device
+        if capacity:
+            # capacity mode: all min(N, cap) rows stay, the count stays on the device (batches of more points than one frame's voxel cap paid
+            # one host read of the frame offsets above - before anything of the frame was submitted)
             example["num_voxels"] = ops.frame_offsets(c, batch_size, n_dev=nv).diff()
             return v, c, n, batch_size, np.asarray(grid), nv
         V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it

@@ -100,6 +100,10 @@ class FrameGraph(object):
             self.recaptures += 1
             self._capture()
             return out
-        if not clone:
-            return self.ret
-        return [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()} for r in self.ret]
+        # the captured dicts hold the FIRST frame's non-tensor fields: every replay hands out the current frame's `metadata` (the reference keys
+        # its saved predictions by output['metadata']['token'], tools/dist_test.py:212)
+        meta = example.get("metadata") or [None] * len(self.ret)
+        out = self.ret if not clone else [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()} for r in self.ret]
+        for i, r in enumerate(out):
+            r["metadata"] = meta[i] if i < len(meta) else None
+        return out

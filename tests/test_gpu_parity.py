@@ -389,7 +389,7 @@ def test_frame_graph_equals_eager_forward_120k(kind):
     try:
         def example(n, seed):
             f = synth.lidar_frame(n, seed=seed, **cfg)
-            ex = dict(points=cu(np.concatenate([np.zeros((n, 1), np.float32), f], 1)), batch_size=1)
+            ex = dict(points=cu(np.concatenate([np.zeros((n, 1), np.float32), f], 1)), batch_size=1, metadata=[dict(token="frame-%d" % seed)])
             if kind == "mseg3d":
                 img, emb, cuv = synth.camera_inputs(n, seed=seed, ncam=6, c_img=48, h=40, w=60, batch=1)
                 ex.update(points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
@@ -404,8 +404,11 @@ def test_frame_graph_equals_eager_forward_120k(kind):
         want = [eager(e) for e in (ex0, ex1, ex2)]
         fg = graph.FrameGraph(model, ex0)
         for e, (wl, wp) in ((ex0, want[0]), (ex1, want[1]), (ex0, want[0])):
-            ret = fg(e)
-            assert torch.equal(ret[0]["pred_point_sem_labels"], wp) and torch.equal(fg.logits, wl)
+            for clone in (True, False):
+                ret = fg(e, clone=clone)
+                assert torch.equal(ret[0]["pred_point_sem_labels"], wp) and torch.equal(fg.logits, wl)
+                # a replay hands out THIS frame's metadata, not the captured frame's (tools/dist_test.py:212 keys predictions by the token)
+                assert ret[0]["metadata"]["token"] == e["metadata"][0]["token"]
         assert fg.fallbacks == 0 and fg.recaptures == 0
         ret = fg(ex2)  # another point count: eager path
         assert fg.fallbacks == 1 and torch.equal(ret[0]["pred_point_sem_labels"], want[2][1])
@@ -497,6 +500,15 @@ def test_bench_under_rccl_process_group_one_rank():
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["scaling"] == "weak" and j["unit"] == "frames/s"
     assert j["value"] > 50 and abs(j["value"] * j["ms_per_step"] * 1e-3 - 1.0) < 1e-6  # frames/s x s/frame == 1 at one frame per step and rank
     assert j["roofline"]["bound"] in ("mfma", "hbm") and 0.0 < j["roofline"]["frac"] < 1.0
+    # what the process group saw, rank by rank: a SCALE record cannot silently be an N = 1 run
+    assert j["rccl_world_size"] == 1 and j["collective_backend"] == "nccl" and len(j["rccl_version"]) >= 2
+    assert [x["rank"] for x in j["ranks"]] == [0] and j["ranks"][0]["device"] == "cuda:0" and j["ranks"][0]["frames_per_s"] >= j["value"] * 0.999
+    if torch.cuda.device_count() < 2:
+        # `--gpus 2` on this box: exit code 2, no record (bench.py re-executes itself under torch.distributed.run only when the GPUs exist)
+        env2 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--no-cpu-baseline", "--no-extra-modes"],
+                            env=env2, capture_output=True, text=True, timeout=300, cwd=root)
+        assert r2.returncode == 2 and "GPU(s)" in r2.stderr and not r2.stdout.strip()
 
 
 def test_devoxelize_grid_equals_brute_force_120k():

@@ -1,6 +1,7 @@
 """CPU tests of the host-side mirror of the reference interface: registry / builder semantics, state_dict layout,
 config dict building, checkpoint loading, C-ABI surface, frame sharding (gloo, world_size 2)."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -181,6 +182,38 @@ def test_frame_sharding_two_process_gloo(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "OK 2" in out.stdout
+
+
+def _run_bench(args, env=None, timeout=900):
+    e = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_gpus_2_is_two_ranks_on_gloo_with_the_kernels_on_hipsim():
+    """`python bench.py --gpus 2` - the REAL bench.py, not a stand-in: it re-executes itself under torch.distributed.run, the two ranks
+    take their shares of the frames (sharding.shard_frames), barrier, time, MAX-reduce and gather; the record says what the process
+    group saw.  The LS3D_BENCH_HIPSIM hook puts the kernels on tests/hipsim and the group on gloo (there is no GPU here)."""
+    out = _run_bench(["--gpus", "2", "--points", "300", "--steps", "1", "--warmup", "0", "--precision", "f32", "--no-extra-modes", "--no-cpu-baseline"],
+                     env=dict(LS3D_BENCH_HIPSIM="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 2 and rec["rccl_world_size"] == 2 and rec["collective_backend"] == "gloo" and rec["scaling"] == "weak"
+    assert [r["rank"] for r in rec["ranks"]] == [0, 1] and [r["frame_seeds"] for r in rec["ranks"]] == [[100], [101]]
+    # whole-job value = frames of all ranks over the slowest rank's time: never above the sum of the per-rank rates
+    assert 0 < rec["value"] <= sum(r["frames_per_s"] for r in rec["ranks"]) * 1.0001
+    assert rec["value"] == pytest.approx(2 * 1e3 / rec["ms_per_step"], rel=1e-6)
+    assert "HIPSIM" in rec["data"]  # a record of this hook can never pass for a measurement
+
+
+def test_bench_refuses_to_report_more_gpus_than_it_runs_on():
+    """--gpus N on a box with fewer GPUs, or inside a launcher environment of another size, exits non-zero instead of printing an N = 1 record"""
+    out = _run_bench(["--gpus", "2", "--no-extra-modes", "--no-cpu-baseline"], timeout=300)
+    assert out.returncode == 2 and "GPU(s)" in out.stderr and not out.stdout.strip()
+    out = _run_bench(["--gpus", "1", "--no-extra-modes", "--no-cpu-baseline"], env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"), timeout=300)
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr and not out.stdout.strip()
 
 
 REF_CFGS = ["/root/reference/configs/semanticnusc/SDSeg3D/semnusc_transvfe_unetscn3d_batchloss_e48.py",
