@@ -94,7 +94,7 @@ size_t ls3d_dynamic_scatter_workspace_bytes(int n);
 /* DynamicScatter (det3d/ops/voxel/scatter_points.py:68-129 over dynamic_point_to_voxel_forward,
  * det3d/ops/voxel/src/voxelization.h:90-100): group points of equal coordinate (coors[n,coors_cols],
  * rows with -1 dropped), first-appearance voxel order, reduce ALL points of a voxel:
- * mode 0 = mean, 1 = max.  Outputs feats[n,n_feat] (first *num_voxels_dev rows valid), voxel_coors[n,coors_cols],
+ * mode 0 = mean, 1 = max, 2 = sum (point order; DynamicScatterWithDistance, scatter_points.py:132-213).  Outputs feats[n,n_feat] (first *num_voxels_dev rows valid), voxel_coors[n,coors_cols],
  * point2voxel[n] (may be NULL). */
 int ls3d_dynamic_scatter(const float *feats_in, int n, int n_feat, const int32_t *coors, int coors_cols,
                          const int32_t shape_zyx_host[3], int mode, void *workspace, size_t workspace_bytes,

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_seg_bounds(const uint32_t *skeys, int n
 }
 
 __global__ __launch_bounds__(256) void k_seg_mean_ordered(const float *src, int C, const int32_t *perm, const int32_t *start, const int32_t *end,
-                                                         int n_seg, const int32_t *n_seg_dev, float *out, int32_t *counts) {
+                                                         int n_seg, const int32_t *n_seg_dev, float *out, int32_t *counts, int divide) {
   const int S = ls3d_count(n_seg, n_seg_dev);
   const long long work = (long long)S * C;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
@@ -345,13 +345,14 @@ __global__ __launch_bounds__(256) void k_seg_mean_ordered(const float *src, int 
     const int a = start[sg], b = end[sg];
     float acc = 0.0f;
     for (int p = a; p < b; ++p) acc = __fadd_rn(acc, src[(size_t)perm[p] * C + c]);
-    out[t] = b > a ? __fdiv_rn(acc, (float)(b - a)) : 0.0f;
+    out[t] = b > a ? (divide ? __fdiv_rn(acc, (float)(b - a)) : acc) : 0.0f;  // divide == 0: the ordered SUM (ls3d_dynamic_scatter mode 2)
     if (c == 0 && counts) counts[sg] = b - a;
   }
 }
 
 // ids[n] (uint32, >= n_seg = not in any segment) -> out[n_seg, C] = ordered mean; counts (optional) [n_seg]
-static int seg_mean_ordered(const float *src, int n, int C, int n_seg, const int32_t *n_seg_dev, SegWs &w, float *out, int32_t *counts, hipStream_t stream) {
+static int seg_mean_ordered(const float *src, int n, int C, int n_seg, const int32_t *n_seg_dev, SegWs &w, float *out, int32_t *counts, hipStream_t stream,
+                            int divide = 1) {
   int bits = 1;
   while ((1u << bits) <= (unsigned)n_seg && bits < 31) ++bits;
   int rc = ls3d_radix_sort_pairs(w.keys, nullptr, n, nullptr, bits, w.skeys, w.perm, w.sort_ws, w.sort_bytes, stream);
@@ -360,7 +361,7 @@ static int seg_mean_ordered(const float *src, int n, int C, int n_seg, const int
   hipMemsetAsync(w.end, 0, (size_t)(n_seg + 1) * 4, stream);
   hipLaunchKernelGGL(k_seg_bounds, ls3d_grid(n), dim3(256), 0, stream, (const uint32_t *)w.skeys, n, n_seg, w.start, w.end);
   hipLaunchKernelGGL(k_seg_mean_ordered, ls3d_grid((long long)n_seg * C), dim3(256), 0, stream, src, C, (const int32_t *)w.perm,
-                     (const int32_t *)w.start, (const int32_t *)w.end, n_seg, n_seg_dev, out, counts);
+                     (const int32_t *)w.start, (const int32_t *)w.end, n_seg, n_seg_dev, out, counts, divide);
   return LS3D_OK;
 }
 
@@ -469,8 +470,10 @@ extern "C" int ls3d_dynamic_scatter(const float *feats_in, int n, int n_feat, co
                                     int32_t *num_voxels_dev, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!feats_in || !coors || !shape_zyx || !workspace || !feats_out || !voxel_coors || !num_voxels_dev) return LS3D_ERR_ARG;
-  if (n < 0 || n_feat < 1 || (coors_cols != 3 && coors_cols != 4) || (mode != 0 && mode != 1)) return LS3D_ERR_ARG;
+  if (n < 0 || n_feat < 1 || (coors_cols != 3 && coors_cols != 4) || (mode != 0 && mode != 1 && mode != 2)) return LS3D_ERR_ARG;
   if (n == 0) { hipMemsetAsync(num_voxels_dev, 0, 4, stream); return LS3D_OK; }
+  const int divide = mode == 2 ? 0 : 1;  // mode 2: the ordered sum of a voxel's points (DynamicScatterWithDistance's weighted average)
+  if (mode == 2) mode = 0;
   DsWs w = ds_ws_layout((char *)workspace, n);
   if (workspace_bytes < w.bytes) return LS3D_ERR_WORKSPACE;
   hipMemsetAsync(w.keys, 0xFF, (size_t)w.cap * 8, stream);
@@ -491,7 +494,7 @@ extern "C" int ls3d_dynamic_scatter(const float *feats_in, int n, int n_feat, co
   hipLaunchKernelGGL(k_ds_reduce, ls3d_grid((long long)n * n_feat), blk, 0, stream, feats_in, n, n_feat, (const int32_t *)w.slot_of_pt,
                      (const int32_t *)w.slot_vid, mode, feats_out, w.counts, point2voxel, mode == 0 ? w.seg.keys : nullptr);
   if (mode == 0) {  // ordered mean: rows beyond *num_voxels_dev stay zero (the memset above)
-    rc = seg_mean_ordered(feats_in, n, n_feat, n, num_voxels_dev, w.seg, feats_out, nullptr, stream);
+    rc = seg_mean_ordered(feats_in, n, n_feat, n, num_voxels_dev, w.seg, feats_out, nullptr, stream, divide);
     if (rc != LS3D_OK) return rc;
     LS3D_RETURN_IF_LAUNCH_FAILED();
     return LS3D_OK;

@@ -124,7 +124,7 @@ def dynamic_scatter(feats, coors, shape_zyx, mode="mean"):
     nv = torch.zeros((1,), dtype=_i32, device=dev)
     L = _L()
     ws = _ws(L.ls3d_dynamic_scatter_workspace_bytes(n), feats)
-    check(L.ls3d_dynamic_scatter(_ptr(feats), n, c, _ptr(coors), cols, _i3(shape_zyx), 0 if mode == "mean" else 1,
+    check(L.ls3d_dynamic_scatter(_ptr(feats), n, c, _ptr(coors), cols, _i3(shape_zyx), {"mean": 0, "max": 1, "sum": 2}[mode],
                                  _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(out), _ptr(vc), _ptr(p2v), _ptr(nv),
                                  _stream(feats)), "ls3d_dynamic_scatter")
     return out, vc, p2v, nv

@@ -64,6 +64,21 @@ import os as _os
 _N_SIDE = int(_os.environ.get("LS3D_GEOM_STREAMS", "2"))
 
 
+# The lateral SparseBasicBlock of a decoder level (conv_up_t<l>, scn_unet.py:163-165) reads the ENCODER output of its level only: it does not
+# depend on anything the deeper levels compute.  It runs on its own stream from the moment the encoder leaves the level, beside the
+# deeper levels - whose launches do not fill the chip (level 4 of a 120k-point frame: 215 tiles for 512 workgroup slots) and whose tails
+# leave CUs idle - and the decoder picks it up with one event.  Same kernels on the same inputs: bit-identical.  LS3D_LATERAL_STREAM=0: inline.
+_LATERAL = _os.environ.get("LS3D_LATERAL_STREAM", "1") != "0"
+_LATERAL_STREAMS = {}
+
+
+def _lateral_stream(dev):
+    st = _LATERAL_STREAMS.get(dev)
+    if st is None:
+        st = _LATERAL_STREAMS[dev] = torch.cuda.Stream(dev)
+    return st
+
+
 class _GeometryStream(object):
     """`with _GeometryStream(t):` runs the body on a per-device side stream that starts after the current stream's work so far;
     on exit the current stream waits for it.  hand_over() tells the caching allocator that tensors created inside are used
@@ -191,7 +206,31 @@ class UNetSCN3D(nn.Module):
         self.conv5 = spconv.SparseSequential(block(c1, c1, 3, norm_fn=norm_fn, padding=1, indice_key="subm1"))
         self.num_point_features = c1
 
-    def UR_block_forward(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv, cat=None, next_cat=None):
+    @staticmethod
+    def _lateral_block(x_lateral, conv_t, cat):
+        """conv_t's two convolutions; the second writes straight into the right half of the level's concat buffer"""
+        c = x_lateral.features.shape[1]
+        mid = conv_bn_act(conv_t.conv1, conv_t.bn1, x_lateral, relu=True)
+        rb = conv_t.conv2.rulebook(mid)
+        s, t = spconv.cached_bn_scale_shift(conv_t.conv2, conv_t.bn2)
+        conv_t.conv2.conv(mid, rb, scale=s, shift=t, relu=True, res_pre=x_lateral.features, out=cat[:, c:], out_ld=2 * c)
+
+    def _lateral_launch(self, x_lateral, conv_t, cat):
+        """-> event behind conv_t's block on the lateral stream (None: not launched, UR_block_forward runs it inline)"""
+        f = x_lateral.features
+        if not (_LATERAL and f.is_cuda and _os.environ.get("LS3D_OVERLAP", "1") != "0"):
+            return None
+        main, lat = torch.cuda.current_stream(f.device), _lateral_stream(f.device)
+        lat.wait_stream(main)
+        with torch.cuda.stream(lat):
+            self._lateral_block(x_lateral, conv_t, cat)
+            done = torch.cuda.Event()
+            done.record(lat)
+        f.record_stream(lat)
+        cat.record_stream(lat)
+        return done
+
+    def UR_block_forward(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv, cat=None, next_cat=None, lateral=None):
         """scn_unet.py:163-171 with the data movement fused away:
           * `cat` [V, 2C] is the concat buffer; its left half already holds x_bottom when the previous UR block's
             inverse conv wrote there (`next_cat`), otherwise it is copied in;
@@ -203,10 +242,10 @@ class UNetSCN3D(nn.Module):
         if cat is None:
             cat = torch.empty((n, 2 * c), dtype=torch.float32, device=x_lateral.features.device)
             cat[:, :c].copy_(x_bottom.features)
-        mid = conv_bn_act(conv_t.conv1, conv_t.bn1, x_lateral, relu=True)
-        rb = conv_t.conv2.rulebook(mid)
-        s, t = spconv.cached_bn_scale_shift(conv_t.conv2, conv_t.bn2)
-        conv_t.conv2.conv(mid, rb, scale=s, shift=t, relu=True, res_pre=x_lateral.features, out=cat[:, c:], out_ld=2 * c)
+        if lateral is None:
+            self._lateral_block(x_lateral, conv_t, cat)
+        elif lateral is not True:
+            torch.cuda.current_stream(cat.device).wait_event(lateral)  # the block ran beside the deeper levels (_lateral_launch)
         x = x_lateral._like(cat)
         x = conv_bn_act(conv_m[0], conv_m[1], x, relu=True, pair=cat)
         if next_cat is None:
@@ -272,6 +311,10 @@ class UNetSCN3D(nn.Module):
         # gets level k's convolutions (a millisecond of GPU work) before the host turns to level k+1's geometry (round-2 trace with
         # all geometry submitted first: 0.6 ms of idle main stream per frame, all of it host submission time).
         ev0, x_enc = None, x_conv1
+        infer = not (self.training or (torch.is_grad_enabled() and voxel_features.requires_grad))
+        cats, lats = [None, None, self._new_cat(x_conv1) if infer else None], [None, None, None]  # levels 3, 2, 1 (the order the decoder takes them)
+        if infer:
+            lats[2] = self._lateral_launch(x_conv1, self.conv_up_t1, cats[2])
         for lvl, (key, src, stage) in enumerate((("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4))):
             with _GeometryStream(x.indices, ready, join=False) as gs:
                 rb = x.find_indice_pair(src)
@@ -291,14 +334,15 @@ class UNetSCN3D(nn.Module):
                     spconv.prebuild_conv_rulebooks(x, rest, coords=rb2.out_indices, shape=rb2.out_shape)
             elif lvl == 1:
                 x_conv3 = x_enc
+            if infer and lvl < 2:  # the level's lateral block starts beside the deeper levels
+                cats[1 - lvl] = self._new_cat(x_enc)
+                lats[1 - lvl] = self._lateral_launch(x_enc, self.conv_up_t2 if lvl == 0 else self.conv_up_t3, cats[1 - lvl])
         x_conv4 = x_enc
         # the neighbour search of the devoxelization (points -> 3 nearest voxel centres + weights) is geometry as well: it runs on the
         # side stream beside the decoder; the point head only interpolates (point_heads._devoxelize)
         with _GeometryStream(x.indices, ready, join=False) as gs2:
             self._start_devox_search(batch_dict, x, gs2)
-        if self.conv_out is not None:
-            batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
-            batch_dict["encoded_spconv_tensor_stride"] = 8
+        conv_out_done = self._conv_out(batch_dict, x_conv4, beside=infer)
         if self.training or (torch.is_grad_enabled() and voxel_features.requires_grad):
             x_up4 = self.UR_block_forward_train(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4)
             x_up3 = self.UR_block_forward_train(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3)
@@ -306,15 +350,40 @@ class UNetSCN3D(nn.Module):
             x_up1 = self.UR_block_forward_train(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5)
             self._stack_event(ev0)
             return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
-        dev = voxel_features.device
-        cats = [torch.empty((t.features.shape[0], 2 * t.features.shape[1]), dtype=torch.float32, device=dev)
-                for t in (x_conv3, x_conv2, x_conv1)]
         x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4, next_cat=cats[0])
-        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1])
-        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2])
-        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2])
+        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1], lateral=lats[0])
+        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2], lateral=lats[1])
+        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2], lateral=lats[2])
         self._stack_event(ev0)
+        self._wait(x, conv_out_done)
         return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
+
+    def _conv_out(self, batch_dict, x_conv4, beside=True):
+        """`encoded_spconv_tensor` (scn_unet.py:218-222) feeds no segmentation head: the key stays in batch_dict, its (3,1,1) convolution
+        runs beside the decoder on the lateral stream.  -> event to wait for at the end of the forward (None: it ran inline)"""
+        if self.conv_out is None:
+            return None
+        f = x_conv4.features
+        if not (beside and _LATERAL and f.is_cuda and _os.environ.get("LS3D_OVERLAP", "1") != "0"):
+            batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
+            batch_dict["encoded_spconv_tensor_stride"] = 8
+            return None
+        main, lat = torch.cuda.current_stream(f.device), _lateral_stream(f.device)
+        lat.wait_stream(main)
+        with torch.cuda.stream(lat):
+            enc = self.conv_out(x_conv4)
+            done = torch.cuda.Event()
+            done.record(lat)
+        f.record_stream(lat)
+        enc.features.record_stream(main)
+        batch_dict["encoded_spconv_tensor"], batch_dict["encoded_spconv_tensor_stride"] = enc, 8
+        return done
+
+    @staticmethod
+    def _new_cat(x):
+        """concat buffer [rows, 2C] of a decoder level: left half <- the inverse convolution from below, right half <- the lateral block"""
+        n, c = x.features.shape
+        return torch.empty((n, 2 * c), dtype=torch.float32, device=x.features.device)
 
     # ---------------------------------------------------------------------------------------------- capacity mode (no host syncs)
     _caps = None  # {strided layer key: [capacity of its output sites, largest count seen]} - adapted from the frames seen so far
@@ -427,6 +496,8 @@ class UNetSCN3D(nn.Module):
         x_conv1 = self.conv1(x)
         ev1 = self._stack_event(ev0)
         ev0, x_enc = None, x_conv1
+        cats, lats = [None, None, self._new_cat(x_conv1)], [None, None, None]  # levels 3, 2, 1 (the order the decoder takes them)
+        lats[2] = self._lateral_launch(x_conv1, self.conv_up_t1, cats[2])
         for lvl, stage in enumerate((self.conv2, self.conv3, self.conv4)):
             self._wait(x, level_ready[lvl + 1])
             if lvl == 0:
@@ -436,19 +507,18 @@ class UNetSCN3D(nn.Module):
                 x_conv2 = x_enc
             elif lvl == 1:
                 x_conv3 = x_enc
+            if lvl < 2:  # the level's lateral block starts beside the deeper levels
+                cats[1 - lvl] = self._new_cat(x_enc)
+                lats[1 - lvl] = self._lateral_launch(x_enc, self.conv_up_t2 if lvl == 0 else self.conv_up_t3, cats[1 - lvl])
         x_conv4 = x_enc
         self._wait(x, counts_copied)  # joins stream 1 (matters for a captured frame: no unjoined work at the end of the capture)
-        if self.conv_out is not None:
-            batch_dict["encoded_spconv_tensor"] = self.conv_out(x_conv4)
-            batch_dict["encoded_spconv_tensor_stride"] = 8
-        dev = voxel_features.device
-        cats = [torch.empty((t.features.shape[0], 2 * t.features.shape[1]), dtype=torch.float32, device=dev)
-                for t in (x_conv3, x_conv2, x_conv1)]
+        conv_out_done = self._conv_out(batch_dict, x_conv4)
         x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4, next_cat=cats[0])
-        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1])
-        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2])
-        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2])
+        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1], lateral=lats[0])
+        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2], lateral=lats[1])
+        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2], lateral=lats[2])
         self._stack_event(ev0)
+        self._wait(x, conv_out_done)
         batch_dict["num_active_voxels_dev"] = x_up1.n_dev
         return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
 

@@ -441,3 +441,43 @@ def test_weight_gradient_row_pipelines_are_not_drained():
     for cob, floor in ((1, 12), (2, 16), (4, 24)):  # 4 x (1 + COB) operand loads of the other set
         exact = _inner_loop_waits(asm, "_Z14k_spconv_wgradILi%dE" % cob)
         assert exact and min(exact) >= floor, (cob, exact)
+
+
+def test_tile_kernel_offset_loop_waits_for_nothing_but_its_weight_dma():
+    """The pipelined offset loop of k_tile_conv (csrc/tileconv.hip, LP = 1) is written so that nothing between two step barriers waits for
+    global memory: the halo chunk is staged before the loop, the weights arrive by LDS-DMA one step ahead.  tests/hipsim turns the wait
+    and DMA helpers into no-ops, so the protocol is checked on what hipcc emits for gfx950: in every basic block of the kernel that issues
+    MFMAs there is no `s_waitcnt vmcnt` - except in the block with the step barrier, where `vmcnt(0)` (this wave's share of the next
+    step's weights has landed) comes BEFORE `s_barrier`, and the DMA of the step after next (`global_load_lds_dwordx4`) is issued behind it."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    from lidarseg3d_amd import build as B
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "tileconv.s")
+        subprocess.check_call([hipcc] + B.CFLAGS + ["-S", "--cuda-device-only", os.path.join(B.CSRC, "tileconv.hip"), "-o", out], cwd=tmp,
+                              stderr=subprocess.DEVNULL)
+        asm = open(out).read()
+    for nt, per_offset in ((4, 24), (2, 12)):
+        name = "_Z11k_tile_convILi%dELi6ELb0ELi1E" % nt
+        start = asm.index("\n" + name)
+        body = asm[start:asm.index("s_endpgm", start)]
+        parts = re.split(r"^(\.LBB\d+_\d+):.*$", body, flags=re.M)
+        with_barrier = mfmas = 0
+        for label, text in zip(parts[1::2], parts[2::2]):
+            ops = [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.strip().startswith((";", "."))]
+            n_mfma = sum("v_mfma" in o for o in ops)
+            if not n_mfma:
+                continue
+            mfmas += n_mfma
+            waits = [i for i, o in enumerate(ops) if o.startswith("s_waitcnt") and "vmcnt" in o]
+            bars = [i for i, o in enumerate(ops) if o.startswith("s_barrier")]
+            if not bars:
+                assert not waits, (name, label, [ops[i] for i in waits])  # MFMAs never wait for global memory
+                continue
+            with_barrier += 1
+            assert len(bars) == 1 and len(waits) == 1 and "vmcnt(0)" in ops[waits[0]] and waits[0] < bars[0], (name, label)
+            dma = [i for i, o in enumerate(ops) if o.startswith("global_load_lds_dwordx4")]
+            assert len(dma) == 3 and min(dma) > bars[0], (name, label, dma)  # three 1 KB blocks per wave and step, into the buffer just released
+            assert not any(o.startswith(("global_load_dword", "buffer_load", "flat_load")) for o in ops), (name, label)
+        assert with_barrier >= 1 and mfmas % per_offset == 0, (name, with_barrier, mfmas)

@@ -42,6 +42,12 @@ def test_voxelize_bit_exact_vs_reference(tag):
     assert np.array_equal(ops.voxelize_dynamic(pts, g["voxel_size"], g["pc_range"]).numpy(), g["cpp_dyn_coors"])
 
 
+def test_voxel_ops_modules_vs_reference_cpp():
+    """Voxelization (hard and max_num_points = -1), HardSimpleVFE, DynamicSimpleVFE, DynamicScatterWithDistance: tests/voxel_cases.py"""
+    from tests import voxel_cases
+    voxel_cases.run("cpu")
+
+
 def test_voxelize_empty_and_all_outside():
     cfg = synth.NUSC
     pts = torch.full((10, 5), 1000.0)
