@@ -493,6 +493,9 @@ typedef struct {
   const float *wq, *bq, *wo, *bo, *w1a, *w1b, *b1, *w2a, *w2b, *b2;
   const float *n2_gamma, *n2_beta, *n3_gamma, *n3_beta;
   float n2_eps, n3_eps;
+  /* gemm_products == 6: the six matrices again as three exact bf16 planes - ls3d_tile_conv_pack(plain [in][out], kvol 1, cin 96, cin_pad 96,
+   * cout 96) of each; NULL otherwise */
+  const void *wq_planes, *wo_planes, *w1a_planes, *w1b_planes, *w2a_planes, *w2b_planes;
 } ls3d_sffm_layer_t;
 typedef struct {
   const float *w_in, *b_in;
@@ -503,6 +506,10 @@ typedef struct {
   int32_t attention; /* arithmetic of the decoder's point -> class-embedding attention (QK^T and PV): 0 (default) exact f32 on
                       * v_mfma_f32_32x32x2_f32, 1 operands rounded to bf16 on v_mfma_f32_32x32x16_bf16, 3 operands rounded to OCP e4m3 on
                       * v_mfma_f32_32x32x16_fp8_fp8 - both with f32 accumulation and f32 softmax (BASELINE configs[4]); 2 the vector pipe (A/B) */
+  const void *w_in_planes; /* gemm_products == 6: the input projection as three bf16 planes (ls3d_tile_conv_pack, cin_pad = d_in) */
+  int32_t gemm_products;   /* arithmetic of the decoder's GEMMs: 0 exact f32 on v_mfma_f32_32x32x2_f32; 6 both operands split exactly into three
+                            * round-to-nearest bf16 planes, the six plane products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16, f32 accumulation,
+                            * head x head in its own accumulator (the f32-grade arithmetic of ls3d_tile_conv) */
 } ls3d_sffm_t;
 int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
                       const ls3d_sffm_t *model_host, float *out, int out_ld, ls3d_stream_t stream);

@@ -55,7 +55,8 @@ class TransVFE(ctypes.Structure):
 
 class SffmLayer(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in ("wq", "bq", "wo", "bo", "w1a", "w1b", "b1", "w2a", "w2b", "b2", "n2_gamma", "n2_beta", "n3_gamma",
-                                                "n3_beta")] + [("n2_eps", ctypes.c_float), ("n3_eps", ctypes.c_float)]
+                                                "n3_beta")] + [("n2_eps", ctypes.c_float), ("n3_eps", ctypes.c_float)] + \
+        [(k, ctypes.c_void_p) for k in ("wq_planes", "wo_planes", "w1a_planes", "w1b_planes", "w2a_planes", "w2b_planes")]
 
 
 class SffmMemoryLayer(ctypes.Structure):
@@ -65,7 +66,8 @@ class SffmMemoryLayer(ctypes.Structure):
 class Sffm(ctypes.Structure):
     _fields_ = [("w_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p), ("layers", ctypes.POINTER(SffmLayer)), ("num_layers", ctypes.c_int32),
                 ("d_in", ctypes.c_int32), ("d_model", ctypes.c_int32), ("heads", ctypes.c_int32), ("ffn", ctypes.c_int32),
-                ("norm_gamma", ctypes.c_void_p), ("norm_beta", ctypes.c_void_p), ("norm_eps", ctypes.c_float), ("attention", ctypes.c_int32)]
+                ("norm_gamma", ctypes.c_void_p), ("norm_beta", ctypes.c_void_p), ("norm_eps", ctypes.c_float), ("attention", ctypes.c_int32),
+                ("w_in_planes", ctypes.c_void_p), ("gemm_products", ctypes.c_int32)]
 
 
 class LibraryMissing(RuntimeError):

@@ -10,7 +10,7 @@
 // (2.0 ms GEMMs + 0.6 ms attention for 120k points).  Here a wave keeps its 32 points in LDS from the projected input to the
 // final LayerNorm: a point is read once (d_in floats) and written once (96 floats); only the weights stream (L2 -> LDS,
 // 221 KB per layer and 128-point tile).
-//   * GEMMs: v_mfma_f32_32x32x2_f32 (exact f32), all of shape [32 x K] x [K x 96], K in {d_in, 96}: three accumulators per wave,
+//   * GEMMs: v_mfma_f32_32x32x2_f32 (exact f32; gemm_products = 6: the exact 3-plane bf16 split, sf_gemm_planes), all of shape [32 x K] x [K x 96], K in {d_in, 96}: three accumulators per wave,
 //     A fragments from the wave's LDS tile (row stride 100 floats), B = 32 x 96 weight chunks in the packed layout of
 //     ls3d_gather_gemm_pack(nt = 3), double buffered in LDS, staged by the 4 waves together.  The FFN (96 -> 192 -> 96) runs as two
 //     96-wide halves accumulated into the same three accumulators, so the hidden tile is 96 wide too.
@@ -20,6 +20,7 @@
 //   * LayerNorm: two lanes per row, statistics by one shuffle.
 // LDS: 4 x 2 x 32 x 100 floats + 2 x 12 KB weight chunks + 26 KB K/V = 152 KB -> one workgroup per CU.
 #include "common.h"
+#include "gemm_common.h"
 
 typedef float sf_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 sf_bf16x8 __attribute__((ext_vector_type(8)));
@@ -40,11 +41,13 @@ constexpr int SF_KV = 2 * SF_E * SF_LMAX;    // K and V of one frame and layer, 
 struct SfLayer {
   const float *wq, *bq, *wo, *bo, *w1a, *w1b, *b1, *w2a, *w2b, *b2, *n2g, *n2b, *n3g, *n3b;
   float n2eps, n3eps;
+  const uint4 *pwq, *pwo, *pw1a, *pw1b, *pw2a, *pw2b;  // the same matrices as three bf16 planes (ls3d_tile_conv_pack, kvol = 1), GP = 6
 };
 struct SfParams {
   const float *win, *bin, *ng, *nb;
   float neps;
   int num_layers, d_in;
+  const uint4 *pwin;
   SfLayer layer[SF_MAX_LAYERS];
 };
 
@@ -93,6 +96,91 @@ __device__ __forceinline__ void sf_gemm(const float *A, int lda, int K, const fl
       buf ^= 1;
     }
   }
+}
+
+// The same product on the exact 3-plane bf16 split of both operands (the arithmetic of k_tile_conv and of the reader's GEMMs):
+// Wq = the matrix packed by ls3d_tile_conv_pack(kvol = 1, cout = 96): per 16-channel chunk [column block 4][plane 3][kk 2][col 32] x 8 bf16 =
+// 12 KB, of which the first three column blocks (9 KB) are staged; the A fragment (8 contiguous floats per lane and chunk) is split in
+// registers (round-to-nearest planes); six v_mfma_f32_32x32x16_bf16 per column block and chunk, head x head in its own accumulator:
+// 18 MFMAs of 32 cycles per 16 channels instead of 24 of 64.  Chunks of 16 channels so that two weight buffers fit where the f32 path keeps
+// its two 32-channel chunks (LDS stays at 152 KB).
+constexpr int SF_PCHUNK = 576;   // uint4 staged per chunk (3 column blocks x 3 planes x 64)
+constexpr int SF_PSTRIDE = 768;  // uint4 per chunk in the packed matrix (4 column blocks: 96 columns are padded to 128)
+// one staged chunk in flight: 9 KB = 576 x 16 bytes over 256 threads (the third unit only for the first 64; an unconditional load from a
+// clamped address otherwise, so that hipcc can count on it)
+struct SfPre { uint4 a, b, c; };
+__device__ __forceinline__ SfPre sf_fetch(const uint4 *__restrict__ chunk) {
+  const int tid = threadIdx.x;
+  SfPre p;
+  p.a = chunk[tid]; p.b = chunk[tid + 256]; p.c = chunk[tid < SF_PCHUNK - 512 ? tid + 512 : tid];
+  return p;
+}
+__device__ __forceinline__ void sf_stash(uint4 *dst, const SfPre &p) {
+  const int tid = threadIdx.x;
+  dst[tid] = p.a; dst[tid + 256] = p.b;
+  if (tid < SF_PCHUNK - 512) dst[tid + 512] = p.c;
+}
+// `pre` comes in holding chunk 0 of THIS matrix (fetched while the previous GEMM / attention / LayerNorm ran: the weights do not depend on the
+// data) and goes out holding chunk 0 of `next`; inside, chunk c + 2 is fetched while chunk c multiplies: a chunk's MFMAs (18 x 32 cycles) are
+// shorter than an L2 round trip, one chunk ahead left every barrier waiting for memory (measured: slower than the f32 form).
+__device__ __forceinline__ void sf_gemm_planes(const float *A, int lda, int K, const uint4 *__restrict__ Wq, const uint4 *__restrict__ next, float *Bs,
+                                               sf_f32x16 (&acc)[3], bool zero, SfPre &pre) {
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 31, kk = lane >> 5;
+  const int nkc = K / 16;
+  uint4 *Bq = (uint4 *)Bs;
+  if (!next) next = Wq;
+  __syncthreads();  // previous users of Bs are done
+  sf_stash(Bq, pre);
+  SfPre p1 = sf_fetch(nkc > 1 ? Wq + SF_PSTRIDE : next);
+  __syncthreads();
+  sf_f32x16 acs[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acs[n][r] = 0.0f;
+      if (zero) acc[n][r] = 0.0f;
+    }
+  int buf = 0;
+  for (int c = 0; c < nkc; ++c) {
+    SfPre p2 = p1;
+    if (c + 2 <= nkc) p2 = sf_fetch(c + 2 < nkc ? Wq + (size_t)(c + 2) * SF_PSTRIDE : next);
+    {
+      const float4 *ap = (const float4 *)(A + col * lda + c * 16 + kk * 8);
+      const float4 a0 = ap[0], a1 = ap[1];
+      uint4 ah, am, al;
+      ls3d_split_pair3_rne(a0.x, a0.y, ah.x, am.x, al.x);
+      ls3d_split_pair3_rne(a0.z, a0.w, ah.y, am.y, al.y);
+      ls3d_split_pair3_rne(a1.x, a1.y, ah.z, am.z, al.z);
+      ls3d_split_pair3_rne(a1.z, a1.w, ah.w, am.w, al.w);
+      const sf_bf16x8 Ah = __builtin_bit_cast(sf_bf16x8, ah), Am = __builtin_bit_cast(sf_bf16x8, am), Al = __builtin_bit_cast(sf_bf16x8, al);
+      const uint4 *bs = Bq + buf * SF_PCHUNK + lane;
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const sf_bf16x8 Bh = __builtin_bit_cast(sf_bf16x8, bs[(n * 3 + 0) * 64]);
+        const sf_bf16x8 Bm = __builtin_bit_cast(sf_bf16x8, bs[(n * 3 + 1) * 64]);
+        const sf_bf16x8 Bl = __builtin_bit_cast(sf_bf16x8, bs[(n * 3 + 2) * 64]);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acs[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acs[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acs[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acs[n], 0, 0, 0);
+        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acs[n], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nkc) {
+      sf_stash(Bq + (buf ^ 1) * SF_PCHUNK, p1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    p1 = p2;
+  }
+  pre = p1;  // chunk 0 of `next`
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] += acs[n][r];
 }
 
 // accumulator fragment (register r of lane (col, kk)) -> tile row:  row = (r & 3) + 8 * (r >> 2) + 4 * kk; column = 32 n + col
@@ -357,7 +445,8 @@ __device__ __forceinline__ void sf_attention_mfma(float *T, const float *kvs, in
   }
 }
 
-// one workgroup = 128 consecutive points (4 waves x 32)
+// one workgroup = 128 consecutive points (4 waves x 32).  GP = 0: the GEMMs on exact-f32 MFMA; GP = 6: on the 3-plane bf16 split (six products)
+template <int GP>
 __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict__ x, int x_ld, int n, const float *__restrict__ points,
                                                          int pt_stride, const float *__restrict__ kv, int L, int batch, SfParams prm,
                                                          float *__restrict__ out, int out_ld, int att_mode) {
@@ -385,15 +474,22 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
     __syncthreads();
     const int fs = s_frame[0];  // the frame whose K / V are staged (the tile's first point)
     sf_f32x16 acc[3];
+    SfPre pre;
+    if constexpr (GP == 6) pre = sf_fetch(prm.pwin);  // chunk 0 of the first matrix: in flight while the tile's rows land
+#define SF_GEMM(A_, K_, Wf_, Wp_, Wnext_, acc_, zero_)                                        \
+  do {                                                                                        \
+    if constexpr (GP == 6) sf_gemm_planes(A_, SF_XS, K_, Wp_, Wnext_, Bs, acc_, zero_, pre);   \
+    else sf_gemm(A_, SF_XS, K_, Wf_, Bs, acc_, zero_);                                        \
+  } while (0)
     // ---- input projection -> X
-    sf_gemm(T, SF_XS, prm.d_in, prm.win, Bs, acc, true);
+    SF_GEMM(T, prm.d_in, prm.win, prm.pwin, (prm.num_layers ? prm.layer[0].pwq : nullptr), acc, true);
     SF_FOR_ACC(nn, r, row) X[row * SF_XS + nn * 32 + col] = acc[nn][r] + prm.bin[nn * 32 + col];
     SF_WAVE_SYNC();
     for (int l = 0; l < prm.num_layers; ++l) {
       const SfLayer &Ly = prm.layer[l];
       const float *kg = kv + (size_t)l * kv_layer, *vg = kg + (size_t)batch * SF_E * L;
       // ---- q projection -> T
-      sf_gemm(X, SF_XS, SF_E, Ly.wq, Bs, acc, true);
+      SF_GEMM(X, SF_E, Ly.wq, Ly.pwq, Ly.pwo, acc, true);
       SF_FOR_ACC(nn, r, row) T[row * SF_XS + nn * 32 + col] = acc[nn][r] + Ly.bq[nn * 32 + col];
       // ---- K / V of the layer and the tile's first frame, transposed: source [h][d][l] -> LDS [h][l][d]
       __syncthreads();  // every wave is past the previous layer's attention (KVs) and has written its q
@@ -430,22 +526,22 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
       }
       SF_WAVE_SYNC();
       // ---- out projection + residual -> X, LayerNorm (norm2)
-      sf_gemm(T, SF_XS, SF_E, Ly.wo, Bs, acc, true);
+      SF_GEMM(T, SF_E, Ly.wo, Ly.pwo, Ly.pw1a, acc, true);
       SF_FOR_ACC(nn, r, row) X[row * SF_XS + nn * 32 + col] += acc[nn][r] + Ly.bo[nn * 32 + col];
       SF_WAVE_SYNC();
       sf_layernorm(X, Ly.n2g, Ly.n2b, Ly.n2eps);
       SF_WAVE_SYNC();
       // ---- FFN in two 96-wide halves of the hidden layer: T = relu(X W1[:, half] + b1[half]); acc += T W2[half, :]
       sf_f32x16 acf[3];
-      sf_gemm(X, SF_XS, SF_E, Ly.w1a, Bs, acc, true);
+      SF_GEMM(X, SF_E, Ly.w1a, Ly.pw1a, Ly.pw2a, acc, true);
       SF_FOR_ACC(nn, r, row) T[row * SF_XS + nn * 32 + col] = fmaxf(acc[nn][r] + Ly.b1[nn * 32 + col], 0.0f);
       SF_WAVE_SYNC();
-      sf_gemm(T, SF_XS, SF_E, Ly.w2a, Bs, acf, true);
-      sf_gemm(X, SF_XS, SF_E, Ly.w1b, Bs, acc, true);
+      SF_GEMM(T, SF_E, Ly.w2a, Ly.pw2a, Ly.pw1b, acf, true);
+      SF_GEMM(X, SF_E, Ly.w1b, Ly.pw1b, Ly.pw2b, acc, true);
       SF_WAVE_SYNC();  // the first half's A fragments have been read by this wave's MFMAs (same wave: program order) - keep T writes behind
       SF_FOR_ACC(nn, r, row) T[row * SF_XS + nn * 32 + col] = fmaxf(acc[nn][r] + Ly.b1[SF_E + nn * 32 + col], 0.0f);
       SF_WAVE_SYNC();
-      sf_gemm(T, SF_XS, SF_E, Ly.w2b, Bs, acf, false);
+      SF_GEMM(T, SF_E, Ly.w2b, Ly.pw2b, (l + 1 < prm.num_layers ? prm.layer[l + 1].pwq : prm.pwin), acf, false);
       SF_FOR_ACC(nn, r, row) X[row * SF_XS + nn * 32 + col] += acf[nn][r] + Ly.b2[nn * 32 + col];
       SF_WAVE_SYNC();
       sf_layernorm(X, Ly.n3g, Ly.n3b, Ly.n3eps);
@@ -460,6 +556,7 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
       const int p = p0 + wave * 32 + row;
       if (p < n) *(float4 *)(out + (size_t)p * out_ld + c4 * 4) = *(const float4 *)(X + row * SF_XS + c4 * 4);
     }
+#undef SF_GEMM
   }
 }
 
@@ -476,21 +573,34 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
   SfParams prm;
   prm.win = m->w_in; prm.bin = m->b_in; prm.ng = m->norm_gamma; prm.nb = m->norm_beta; prm.neps = m->norm_eps;
   prm.num_layers = m->num_layers; prm.d_in = m->d_in;
+  const bool planes = m->gemm_products == 6;
+  if (m->gemm_products != 0 && !planes) return LS3D_ERR_ARG;
+  prm.pwin = (const uint4 *)m->w_in_planes;
+  if (planes && (!m->w_in_planes || (m->d_in % 16))) return LS3D_ERR_ARG;
   for (int l = 0; l < m->num_layers; ++l) {
     const ls3d_sffm_layer_t &s = m->layers[l];
     if (!s.wq || !s.bq || !s.wo || !s.bo || !s.w1a || !s.w1b || !s.b1 || !s.w2a || !s.w2b || !s.b2 || !s.n2_gamma || !s.n2_beta || !s.n3_gamma || !s.n3_beta)
       return LS3D_ERR_ARG;
-    prm.layer[l] = SfLayer{s.wq, s.bq, s.wo, s.bo, s.w1a, s.w1b, s.b1, s.w2a, s.w2b, s.b2, s.n2_gamma, s.n2_beta, s.n3_gamma, s.n3_beta, s.n2_eps, s.n3_eps};
+    if (planes && (!s.wq_planes || !s.wo_planes || !s.w1a_planes || !s.w1b_planes || !s.w2a_planes || !s.w2b_planes)) return LS3D_ERR_ARG;
+    prm.layer[l] = SfLayer{s.wq, s.bq, s.wo, s.bo, s.w1a, s.w1b, s.b1, s.w2a, s.w2b, s.b2, s.n2_gamma, s.n2_beta, s.n3_gamma, s.n3_beta, s.n2_eps, s.n3_eps,
+                           (const uint4 *)s.wq_planes, (const uint4 *)s.wo_planes, (const uint4 *)s.w1a_planes, (const uint4 *)s.w1b_planes,
+                           (const uint4 *)s.w2a_planes, (const uint4 *)s.w2b_planes};
   }
   const int lds = (4 * SF_WAVE_FLOATS + 2 * SF_BCHUNK + SF_KV) * (int)sizeof(float) + (128 + 8) * (int)sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_sffm_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_sffm_decoder<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_decoder<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
   long long blocks = ((long long)n + 127) / 128;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(k_sffm_decoder, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, (m->attention >= 0 && m->attention <= 3) ? m->attention : 0);
+  const int att = (m->attention >= 0 && m->attention <= 3) ? m->attention : 0;
+  if (planes)
+    hipLaunchKernelGGL(k_sffm_decoder<6>, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, att);
+  else
+    hipLaunchKernelGGL(k_sffm_decoder<0>, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, att);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

@@ -188,6 +188,9 @@ class SegMSeg3DNet(SingleStageDetector):
         data["voxel_coords_ready"] = _coords_ready(coords)
         if n_dev is None:
             raise ops.CapacityModeUnsupported("frame-by-frame voxelization")
+        cam = getattr(self.point_head, "camera_branch", None)
+        if cam is not None:  # depends on the frame's inputs only: beside the reader and the backbone
+            data["camera_branch"] = cam(example["image_features"], example["points_cuv"], data["points"])
         data["num_active_voxels_dev"] = n_dev
         data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"], n_dev=n_dev)
         data = self.backbone(data)
@@ -234,6 +237,9 @@ class SegMSeg3DNet(SingleStageDetector):
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
                     points=example["points"][:, 0:4].contiguous())
         data["voxel_coords_ready"] = _coords_ready(coords)
+        cam = getattr(self.point_head, "camera_branch", None)
+        if cam is not None and not return_loss and not self.training:
+            data["camera_branch"] = cam(image_features, example["points_cuv"], data["points"])
         data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
         data = self.backbone(data)
         data.update(points_cuv=example["points_cuv"], image_features=image_features,

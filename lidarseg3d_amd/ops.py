@@ -1031,14 +1031,22 @@ class SffmModel(object):
             for k, v in t.items():
                 setattr(arr[i], k, v.data_ptr())
             arr[i].n2_eps, arr[i].n3_eps = float(l["n2"][2]), float(l["n3"][2])
+            # the same matrices as three exact bf16 planes (ls3d_tile_conv_pack): the decoder's GEMMs in the 3-plane modes
+            for k in ("wq", "wo", "w1a", "w1b", "w2a", "w2b"):
+                t = l[k].for_tile()
+                self.keep.append(t)
+                setattr(arr[i], k + "_planes", t.data_ptr())
         self.layers = arr
         self.keep.extend([norm[0], norm[1]] if norm is not None else [])
+        w_in_planes = w_in.for_tile()
+        self.keep.append(w_in_planes)
         self.c = Sffm(self.keep[0].data_ptr(), b_in.data_ptr(), arr, len(layers), int(d_in), int(d_model), int(heads), int(ffn),
                       norm[0].data_ptr() if norm is not None else None, norm[1].data_ptr() if norm is not None else None,
-                      float(norm[2]) if norm is not None else 0.0, 0)
+                      float(norm[2]) if norm is not None else 0.0, 0, w_in_planes.data_ptr(), 0)
 
 
 _SFFM_ATTENTION = 0
+_SFFM_PLANES = _os.environ.get("LS3D_SFFM_PLANES", "1") != "0"  # A/B: the decoder's GEMMs on the 3-plane bf16 split in the 3-plane precisions
 
 
 def set_sffm_attention(mode):
@@ -1053,6 +1061,7 @@ def sffm_decoder(x, points, kv, L, batch, model):
     n = x.shape[0]
     out = torch.empty((n, model.c.d_model), dtype=torch.float32, device=x.device)
     model.c.attention = _SFFM_ATTENTION
+    model.c.gemm_products = 6 if (_PRECISION in (BF16X6, BF16X8, BF16) and _SFFM_PLANES) else 0  # the 3-plane modes: f32-grade, like the convolutions'
     rc = _L().ls3d_sffm_decoder(_ptr(x), x.shape[1], n, _ptr(points), points.shape[1] if points.dim() == 2 else 1, _ptr(kv), int(L), int(batch),
                                 ctypes.byref(model.c), _ptr(out), out.shape[1], _stream(x))
     if rc == _lib.ERR_UNSUPPORTED:

@@ -242,10 +242,13 @@ class TransformerDecoder(nn.Module):
 
 
 import os as _os
+_HEAD_STREAMS = {}
+_HEAD_OVERLAP = _os.environ.get("LS3D_HEAD_OVERLAP", "1") != "0"  # MSeg3D head: camera branch / class-embedding side on their own streams
+_EVAL_MIMIC = _os.environ.get("LS3D_EVAL_MIMIC", "0") != "0"
 _FUSED_SFFM = _os.environ.get("LS3D_FUSED_SFFM", "1") != "0"
-# the class-embedding side of all decoder layers in one launch (ls3d_sffm_memory) instead of ~40 small ones.  Built after round 3's GPU budget was
-# spent: equal to the layer-by-layer form to 1e-6 on tests/hipsim, NOT yet run on the device -> off until it is (LS3D_FUSED_SFFM_MEMORY=1).
-_FUSED_SFFM_MEMORY = _os.environ.get("LS3D_FUSED_SFFM_MEMORY", "0") != "0"
+# the class-embedding side of all decoder layers in one launch (ls3d_sffm_memory) instead of ~40 small ones: 0.21 ms instead of 0.37 ms per frame
+# on the device since round 4 (round 3's first version was slower than the launches: 0.66 ms); LS3D_FUSED_SFFM_MEMORY=0: layer by layer
+_FUSED_SFFM_MEMORY = _os.environ.get("LS3D_FUSED_SFFM_MEMORY", "1") != "0"
 
 
 def set_fused_sffm(on):
@@ -317,10 +320,47 @@ class SemanticFeatureFusionModule(PackedModule):
             p["memory"] = ops.SffmMemoryModel(ml, E, self.nhead)
         return p
 
+    def _memory_tokens(self, input_sem_embeddings1, input_sem_embeddings2, pk):
+        """-> mem [B * L, E]: rows ordered (frame, token), tokens 0..cls-1 camera, cls..2cls-1 LiDAR (context_module.py:105-108)"""
+        E = self.d_model
+        e1 = input_sem_embeddings1.squeeze(-1).permute(0, 2, 1).contiguous()  # [B,cls,C1]
+        e2 = input_sem_embeddings2.squeeze(-1).permute(0, 2, 1).contiguous()
+        B, cls = e1.shape[0], e1.shape[1]
+        L = 2 * cls
+        mem = torch.empty((B, L, E), dtype=torch.float32, device=e1.device)
+        mem[:, :cls] = _lin(e1.reshape(B * cls, -1), pk["emb1"]).view(B, cls, E)
+        mem[:, cls:] = _lin(e2.reshape(B * cls, -1), pk["emb2"]).view(B, cls, E)
+        return mem.view(B * L, E), L
+
+    def _memory_kv(self, mem, B, L, pk):
+        """the class-embedding side of every decoder layer: kv [layers * 2, B, E, L] (k / v of each layer's cross attention), the `kv`
+        input of ls3d_sffm_decoder.  It never sees the points."""
+        E, H = self.d_model, self.nhead
+        kv = ops.sffm_memory(mem, B, L, pk["memory"]) if (_FUSED_SFFM_MEMORY and "memory" in pk) else None
+        if kv is None:
+            kvs, mf = [], mem
+            for lp in pk["layers"]:
+                att = ops.mha_core(_lin(mf, lp["sa_qkv"]), B, L, E, H)
+                mf = _lin(att, lp["sa_out"], res=mf, ln=lp["n1"])
+                kvs.append(_lin(mf, lp["k"]).view(B, L, E).permute(0, 2, 1))
+                kvs.append(_lin(mf, lp["v"]).view(B, L, E).permute(0, 2, 1))
+            kv = torch.stack(kvs).contiguous()
+        return kv
+
+    def memory_side(self, input_sem_embeddings1, input_sem_embeddings2):
+        """inference helper of PointSegMSeg3DHead: the whole class-embedding side (token projections + every layer's self-attention and k / v
+        projections) for forward(..., memory_kv=...), or None when the fused decoder does not apply.  The caller may run it on a stream of
+        its own: nothing here depends on the points."""
+        pk = self.packed()
+        mem, L = self._memory_tokens(input_sem_embeddings1, input_sem_embeddings2, pk)
+        if not (_FUSED_SFFM and "fused" in pk and L <= 64):
+            return None
+        return self._memory_kv(mem, input_sem_embeddings1.shape[0], L, pk)
+
     def forward(self, input_point_features, input_sem_embeddings1, input_sem_embeddings2, batch_idx, batch_size,
-                return_context=False, points=None):
+                return_context=False, points=None, memory_kv=None):
         """embeddings [B, C, num_cls, 1]; `points` (rows with the batch index in column 0) may be passed to avoid
-        rebuilding it from batch_idx."""
+        rebuilding it from batch_idx; memory_kv: the result of memory_side() on the same embeddings."""
         if torch.is_grad_enabled() and (self.training or input_point_features.requires_grad):
             return self._forward_train(input_point_features, input_sem_embeddings1, input_sem_embeddings2, batch_idx,
                                        batch_size, return_context)
@@ -330,31 +370,20 @@ class SemanticFeatureFusionModule(PackedModule):
         if points is None:
             points = batch_idx.float().unsqueeze(1).contiguous()
         B = batch_size
-        # memory rows ordered (frame, token): tokens 0..cls-1 camera, cls..2cls-1 LiDAR  (context_module.py:105-108)
-        e1 = input_sem_embeddings1.squeeze(-1).permute(0, 2, 1).contiguous()  # [B,cls,C1]
-        e2 = input_sem_embeddings2.squeeze(-1).permute(0, 2, 1).contiguous()
-        cls = e1.shape[1]
-        L = 2 * cls
-        mem = torch.empty((B, L, E), dtype=torch.float32, device=e1.device)
-        mem[:, :cls] = _lin(e1.reshape(B * cls, -1), pk["emb1"]).view(B, cls, E)
-        mem[:, cls:] = _lin(e2.reshape(B * cls, -1), pk["emb2"]).view(B, cls, E)
-        mem = mem.view(B * L, E)
+        if memory_kv is not None and not return_context:
+            mem, L = None, memory_kv.shape[3]
+        else:
+            mem, L = self._memory_tokens(input_sem_embeddings1, input_sem_embeddings2, pk)
         if _FUSED_SFFM and "fused" in pk and not return_context and L <= 64:
             # the class-embedding side of every layer first (2*cls rows per frame; it never sees the points), then ONE kernel for
             # the point side of the whole decoder (ls3d_sffm_decoder)
-            kv = ops.sffm_memory(mem, B, L, pk["memory"]) if (_FUSED_SFFM_MEMORY and "memory" in pk) else None
-            if kv is None:
-                kvs, mf = [], mem
-                for lp in pk["layers"]:
-                    att = ops.mha_core(_lin(mf, lp["sa_qkv"]), B, L, E, H)
-                    mf = _lin(att, lp["sa_out"], res=mf, ln=lp["n1"])
-                    kvs.append(_lin(mf, lp["k"]).view(B, L, E).permute(0, 2, 1))
-                    kvs.append(_lin(mf, lp["v"]).view(B, L, E).permute(0, 2, 1))
-                kv = torch.stack(kvs).contiguous()  # [layers * 2, B, E, L]
+            kv = memory_kv if memory_kv is not None else self._memory_kv(mem, B, L, pk)
             x = input_point_features if input_point_features.is_contiguous() else input_point_features.contiguous()
             tgt = ops.sffm_decoder(x, points, kv, L, B, pk["fused"])
             if tgt is not None:
                 return tgt
+        if mem is None:  # the fused decoder declined this shape: the layer-by-layer form starts from the tokens
+            mem, L = self._memory_tokens(input_sem_embeddings1, input_sem_embeddings2, pk)
         tgt = _lin(input_point_features, pk["point"])
         for lp in pk["layers"]:
             att = ops.mha_core(_lin(mem, lp["sa_qkv"]), B, L, E, H)
@@ -491,6 +520,40 @@ class PointSegMSeg3DHead(PackedModule):
                     mimic=_pack_mlp(self.lidar_camera_mimic_layer),
                     out=pack_linear(self.out_cls_layers.weight, self.out_cls_layers.bias))
 
+    @staticmethod
+    def _beside(fn, index, inputs=()):
+        """run fn() on head stream `index` behind the current stream's work so far -> (result, event), or (fn(), None) on the current stream
+        when streams are off (CPU tensors under tests/hipsim, LS3D_OVERLAP=0)"""
+        t = inputs[0] if inputs else None
+        if t is None or not t.is_cuda or _os.environ.get("LS3D_OVERLAP", "1") == "0" or not _HEAD_OVERLAP:
+            return fn(), None
+        main = torch.cuda.current_stream(t.device)
+        st = _HEAD_STREAMS.get((t.device, index))
+        if st is None:
+            st = _HEAD_STREAMS[(t.device, index)] = torch.cuda.Stream(t.device)
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            out = fn()
+            ev = torch.cuda.Event()
+            ev.record(st)
+        for x in inputs:
+            x.record_stream(st)
+        for x in (out if isinstance(out, (tuple, list)) else (out,)):
+            if torch.is_tensor(x):
+                x.record_stream(main)
+        return out, ev
+
+    def camera_branch(self, image_features, points_cuv, points):
+        """GF-Phase's camera side - NCHW -> NHWC of the camera maps, the bilinear gather of every point's pixel, gffm_camera (:281-300) -
+        depends on the frame's INPUTS only: the detector launches it at the start of the frame, beside the reader and the backbone.
+        -> dict for batch_dict["camera_branch"] (None: the head computes it in place)"""
+        if self.training or not points_cuv.is_cuda or not _HEAD_OVERLAP:
+            return None
+        pk = self.packed()
+        cuv, img = points_cuv.contiguous(), image_features.contiguous()
+        pc, ev = self._beside(lambda: _run_mlp(ops.grid_gather(img, cuv, points), pk["camera"]), 0, (img, cuv, points))
+        return None if ev is None else dict(pc=pc, event=ev, cuv=points_cuv)
+
     def get_points_image_feature(self, input_img_feature, points_cuv, batch_idx):
         """point_seg_mseg3d_head.py:200-236 (rows with valid != 1 come back as zeros)"""
         pts = batch_idx.float().unsqueeze(1).contiguous()
@@ -543,20 +606,38 @@ class PointSegMSeg3DHead(PackedModule):
         self.forward_ret_dict["voxel_logits"] = voxel_logits
         centers = batch_dict["conv_point_coords"]
         points = batch_dict["points"].contiguous()
+        ds = batch_dict.get("devox_search")
+        early = ds is not None and ds["centers"] is centers and ds["points"] is points  # the voxels' frame offsets exist before the interpolation
+        memory_kv = mem_done = None
+        if early:
+            # SF-Phase's class-embedding side first (:348-365): the LiDAR embeddings need the voxel logits only, and the six layers of token
+            # self-attention + k / v projections (~40 small launches) never see the points - they run on a stream of their own beside the
+            # GF-Phase below; the decoder waits for one event
+            lemb = ops.sfam(vf, voxel_logits, ds["vx_off"], B, vf.shape[0]).permute(0, 2, 1).contiguous().unsqueeze(3)
+            memory_kv, mem_done = self._beside(lambda: self.sffm.memory_side(batch_dict["camera_semantic_embeddings"], lemb), 1,
+                                               (lemb, batch_dict["camera_semantic_embeddings"]))
         pl0, vx_off = _devoxelize(batch_dict, points, centers, vf, B)
         # GF-Phase (:272-342).  The reference runs the camera / mimic branches on the valid subset and scatters
         # back; here they run on all rows and complete_concat selects per row (eval BatchNorm is row-wise).
         pl = _run_mlp(pl0, pk["lidar"])
         cuv = batch_dict["points_cuv"].contiguous()
-        pc = _run_mlp(ops.grid_gather(batch_dict["image_features"].contiguous(), cuv, points), pk["camera"])
-        # The mimic (pseudo-camera) branch only feeds the training loss: the reference evaluates it on the valid
-        # points and zero-pads the others (:305,:320-334), so points without a camera hit get ZERO camera
-        # features at inference.  It is still evaluated here, as the reference's forward does.
-        self.forward_ret_dict["point_features_pcamera"] = _run_mlp(pl, pk["mimic"])
+        cb = batch_dict.get("camera_branch")
+        if cb is not None and cb["cuv"] is batch_dict["points_cuv"]:  # launched at the start of the frame (camera_branch)
+            torch.cuda.current_stream(vf.device).wait_event(cb["event"])
+            pc = cb["pc"]
+        else:
+            pc = _run_mlp(ops.grid_gather(batch_dict["image_features"].contiguous(), cuv, points), pk["camera"])
+        # The mimic (pseudo-camera) branch only feeds the training loss: the reference evaluates it on the valid points and zero-pads the
+        # others (:305,:320-334), so points without a camera hit get ZERO camera features at inference.  Its three layers are not evaluated
+        # at inference (nothing reads forward_ret_dict["point_features_pcamera"] outside get_loss; LS3D_EVAL_MIMIC=1 restores them).
+        if _EVAL_MIMIC:
+            self.forward_ret_dict["point_features_pcamera"] = _run_mlp(pl, pk["mimic"])
         fused = _run_mlp(ops.complete_concat(pl, pc, None, cuv), pk["lc"])
-        # SF-Phase (:348-365)
-        lemb = ops.sfam(vf, voxel_logits, vx_off, B, vf.shape[0]).permute(0, 2, 1).contiguous().unsqueeze(3)
-        sem = self.sffm(fused, batch_dict["camera_semantic_embeddings"], lemb, points[:, 0], B, points=points)
+        if not early:
+            lemb = ops.sfam(vf, voxel_logits, vx_off, B, vf.shape[0]).permute(0, 2, 1).contiguous().unsqueeze(3)
+        if mem_done is not None:
+            torch.cuda.current_stream(vf.device).wait_event(mem_done)
+        sem = self.sffm(fused, batch_dict["camera_semantic_embeddings"], lemb, points[:, 0], B, points=points, memory_kv=memory_kv)
         out = _lin(sem, pk["out"])
         batch_dict["out_logits"] = out
         self.forward_ret_dict["out_logits"] = out

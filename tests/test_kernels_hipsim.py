@@ -1328,6 +1328,14 @@ def test_fused_sffm_decoder_equals_layer_by_layer_and_oracle():
         ops.sffm_decoder = orig
     assert len(calls) == 1
     np.testing.assert_allclose(fused.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    try:  # the fused kernel's GEMMs on the exact 3-plane bf16 split (gemm_products = 6: what the 3-plane precisions select)
+        ops.set_precision("bf16x6")
+        with torch.no_grad():
+            planes = m(x, e1, e2, bidx, 2, points=pts)
+    finally:
+        ops.set_precision("f32")
+    assert not torch.equal(planes, fused)  # another arithmetic ran ...
+    np.testing.assert_allclose(planes.numpy(), ref.numpy(), rtol=0, atol=2e-5)  # ... and it is f32-grade (LayerNorm'd outputs: unit scale)
     try:  # the other attention arithmetics of the fused kernel
         with torch.no_grad():
             ops.set_sffm_attention("valu")
