@@ -494,7 +494,8 @@ typedef struct {
   const float *n2_gamma, *n2_beta, *n3_gamma, *n3_beta;
   float n2_eps, n3_eps;
   /* gemm_products == 6: the six matrices again as three exact bf16 planes - ls3d_tile_conv_pack(plain [in][out], kvol 1, cin 96, cin_pad 96,
-   * cout 96) of each; NULL otherwise */
+   * cout 96) of each with the INPUT channels of every 16-block reordered for the transposed product: packed row 16 c + 8 kk + q = plain row
+   * 16 c + 8 (q / 4) + 4 kk + q % 4 (csrc/sffm.hip, k_sffm_decoder_rt); NULL otherwise */
   const void *wq_planes, *wo_planes, *w1a_planes, *w1b_planes, *w2a_planes, *w2b_planes;
 } ls3d_sffm_layer_t;
 typedef struct {
@@ -507,9 +508,12 @@ typedef struct {
                       * v_mfma_f32_32x32x2_f32, 1 operands rounded to bf16 on v_mfma_f32_32x32x16_bf16, 3 operands rounded to OCP e4m3 on
                       * v_mfma_f32_32x32x16_fp8_fp8 - both with f32 accumulation and f32 softmax (BASELINE configs[4]); 2 the vector pipe (A/B) */
   const void *w_in_planes; /* gemm_products == 6: the input projection as three bf16 planes (ls3d_tile_conv_pack, cin_pad = d_in) */
+  const int32_t *pt_off;   /* gemm_products == 6: DEVICE int32 [batch + 1], first row of every frame in the frame-sorted x (ls3d_frame_offsets):
+                            * the register-resident kernel cuts its 128-point tiles per frame */
   int32_t gemm_products;   /* arithmetic of the decoder's GEMMs: 0 exact f32 on v_mfma_f32_32x32x2_f32; 6 both operands split exactly into three
                             * round-to-nearest bf16 planes, the six plane products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16, f32 accumulation,
-                            * head x head in its own accumulator (the f32-grade arithmetic of ls3d_tile_conv) */
+                            * head x head in its own accumulator (the f32-grade arithmetic of ls3d_tile_conv) - the decoder then runs
+                            * transposed with its activations in registers (needs pt_off, attention == 0, L <= 64) */
 } ls3d_sffm_t;
 int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
                       const ls3d_sffm_t *model_host, float *out, int out_ld, ls3d_stream_t stream);

@@ -67,7 +67,7 @@ class Sffm(ctypes.Structure):
     _fields_ = [("w_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p), ("layers", ctypes.POINTER(SffmLayer)), ("num_layers", ctypes.c_int32),
                 ("d_in", ctypes.c_int32), ("d_model", ctypes.c_int32), ("heads", ctypes.c_int32), ("ffn", ctypes.c_int32),
                 ("norm_gamma", ctypes.c_void_p), ("norm_beta", ctypes.c_void_p), ("norm_eps", ctypes.c_float), ("attention", ctypes.c_int32),
-                ("w_in_planes", ctypes.c_void_p), ("gemm_products", ctypes.c_int32)]
+                ("w_in_planes", ctypes.c_void_p), ("pt_off", ctypes.c_void_p), ("gemm_products", ctypes.c_int32)]
 
 
 class LibraryMissing(RuntimeError):

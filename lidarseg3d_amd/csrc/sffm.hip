@@ -120,69 +120,6 @@ __device__ __forceinline__ void sf_stash(uint4 *dst, const SfPre &p) {
   dst[tid] = p.a; dst[tid + 256] = p.b;
   if (tid < SF_PCHUNK - 512) dst[tid + 512] = p.c;
 }
-// `pre` comes in holding chunk 0 of THIS matrix (fetched while the previous GEMM / attention / LayerNorm ran: the weights do not depend on the
-// data) and goes out holding chunk 0 of `next`; inside, chunk c + 2 is fetched while chunk c multiplies: a chunk's MFMAs (18 x 32 cycles) are
-// shorter than an L2 round trip, one chunk ahead left every barrier waiting for memory (measured: slower than the f32 form).
-__device__ __forceinline__ void sf_gemm_planes(const float *A, int lda, int K, const uint4 *__restrict__ Wq, const uint4 *__restrict__ next, float *Bs,
-                                               sf_f32x16 (&acc)[3], bool zero, SfPre &pre) {
-  const int lane = threadIdx.x & 63;
-  const int col = lane & 31, kk = lane >> 5;
-  const int nkc = K / 16;
-  uint4 *Bq = (uint4 *)Bs;
-  if (!next) next = Wq;
-  __syncthreads();  // previous users of Bs are done
-  sf_stash(Bq, pre);
-  SfPre p1 = sf_fetch(nkc > 1 ? Wq + SF_PSTRIDE : next);
-  __syncthreads();
-  sf_f32x16 acs[3];
-#pragma unroll
-  for (int n = 0; n < 3; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acs[n][r] = 0.0f;
-      if (zero) acc[n][r] = 0.0f;
-    }
-  int buf = 0;
-  for (int c = 0; c < nkc; ++c) {
-    SfPre p2 = p1;
-    if (c + 2 <= nkc) p2 = sf_fetch(c + 2 < nkc ? Wq + (size_t)(c + 2) * SF_PSTRIDE : next);
-    {
-      const float4 *ap = (const float4 *)(A + col * lda + c * 16 + kk * 8);
-      const float4 a0 = ap[0], a1 = ap[1];
-      uint4 ah, am, al;
-      ls3d_split_pair3_rne(a0.x, a0.y, ah.x, am.x, al.x);
-      ls3d_split_pair3_rne(a0.z, a0.w, ah.y, am.y, al.y);
-      ls3d_split_pair3_rne(a1.x, a1.y, ah.z, am.z, al.z);
-      ls3d_split_pair3_rne(a1.z, a1.w, ah.w, am.w, al.w);
-      const sf_bf16x8 Ah = __builtin_bit_cast(sf_bf16x8, ah), Am = __builtin_bit_cast(sf_bf16x8, am), Al = __builtin_bit_cast(sf_bf16x8, al);
-      const uint4 *bs = Bq + buf * SF_PCHUNK + lane;
-#pragma unroll
-      for (int n = 0; n < 3; ++n) {
-        const sf_bf16x8 Bh = __builtin_bit_cast(sf_bf16x8, bs[(n * 3 + 0) * 64]);
-        const sf_bf16x8 Bm = __builtin_bit_cast(sf_bf16x8, bs[(n * 3 + 1) * 64]);
-        const sf_bf16x8 Bl = __builtin_bit_cast(sf_bf16x8, bs[(n * 3 + 2) * 64]);
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[n], 0, 0, 0);
-        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acs[n], 0, 0, 0);
-        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acs[n], 0, 0, 0);
-        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acs[n], 0, 0, 0);
-        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acs[n], 0, 0, 0);
-        acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acs[n], 0, 0, 0);
-      }
-    }
-    if (c + 1 < nkc) {
-      sf_stash(Bq + (buf ^ 1) * SF_PCHUNK, p1);
-      __syncthreads();
-      buf ^= 1;
-    }
-    p1 = p2;
-  }
-  pre = p1;  // chunk 0 of `next`
-#pragma unroll
-  for (int n = 0; n < 3; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] += acs[n][r];
-}
-
 // accumulator fragment (register r of lane (col, kk)) -> tile row:  row = (r & 3) + 8 * (r >> 2) + 4 * kk; column = 32 n + col
 #define SF_FOR_ACC(n, r, row) \
   _Pragma("unroll") for (int n = 0; n < 3; ++n) _Pragma("unroll") for (int r = 0, row = 4 * kk; r < 16; ++r, row = (r & 3) + 8 * (r >> 2) + 4 * kk)
@@ -445,8 +382,7 @@ __device__ __forceinline__ void sf_attention_mfma(float *T, const float *kvs, in
   }
 }
 
-// one workgroup = 128 consecutive points (4 waves x 32).  GP = 0: the GEMMs on exact-f32 MFMA; GP = 6: on the 3-plane bf16 split (six products)
-template <int GP>
+// one workgroup = 128 consecutive points (4 waves x 32); GEMMs on exact-f32 MFMA (gemm_products = 0)
 __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict__ x, int x_ld, int n, const float *__restrict__ points,
                                                          int pt_stride, const float *__restrict__ kv, int L, int batch, SfParams prm,
                                                          float *__restrict__ out, int out_ld, int att_mode) {
@@ -474,13 +410,7 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
     __syncthreads();
     const int fs = s_frame[0];  // the frame whose K / V are staged (the tile's first point)
     sf_f32x16 acc[3];
-    SfPre pre;
-    if constexpr (GP == 6) pre = sf_fetch(prm.pwin);  // chunk 0 of the first matrix: in flight while the tile's rows land
-#define SF_GEMM(A_, K_, Wf_, Wp_, Wnext_, acc_, zero_)                                        \
-  do {                                                                                        \
-    if constexpr (GP == 6) sf_gemm_planes(A_, SF_XS, K_, Wp_, Wnext_, Bs, acc_, zero_, pre);   \
-    else sf_gemm(A_, SF_XS, K_, Wf_, Bs, acc_, zero_);                                        \
-  } while (0)
+#define SF_GEMM(A_, K_, Wf_, Wp_, Wnext_, acc_, zero_) sf_gemm(A_, SF_XS, K_, Wf_, Bs, acc_, zero_)
     // ---- input projection -> X
     SF_GEMM(T, prm.d_in, prm.win, prm.pwin, (prm.num_layers ? prm.layer[0].pwq : nullptr), acc, true);
     SF_FOR_ACC(nn, r, row) X[row * SF_XS + nn * 32 + col] = acc[nn][r] + prm.bin[nn * 32 + col];
@@ -560,6 +490,316 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The register-resident form (gemm_products = 6): the decoder TRANSPOSED, activations never leave the registers.
+//
+// k_sffm_decoder above keeps a wave's 32 points as [32][96] tiles in LDS: every GEMM reads its A fragments from LDS and writes its
+// result back through 48 ds_write_b32 per lane, 152 KB of LDS allow one workgroup per CU (one wave per SIMD: every LDS round trip, every
+// barrier is exposed) - with the GEMMs on the 3-plane bf16 split the kernel ran no faster than in exact f32: its matrix work is a third
+// of its time (round-4 ablations: attention 0.45, FFN 0.62, LayerNorms 0.08 of 1.51 ms per 120k-point frame).
+// Here the products are computed transposed, Y^T[channel][point] = W^T X^T:
+//   * the weights are the MFMA's A operand (rows = output channels), the activations its B operand (columns = the wave's 32 points).  The
+//     C layout of v_mfma_f32_32x32x16_bf16 gives lane (point, kk) the channels 32 n + 8 i + 4 kk + j (n: 32-channel block, register
+//     r = 4 i + j) of ITS point - and the B operand of the next product wants, from lane (point, kk), eight K-values per step.  The K index of
+//     an MFMA is a free permutation as long as both operands agree: step (n, u) takes registers 8 u .. 8 u + 7 of block n, i.e. channels
+//     32 n + 8 (2 u + q / 4) + 4 kk + q % 4, and the weights are packed in that channel order (ops.SffmModel permutes the rows of the plain
+//     matrix before ls3d_tile_conv_pack).  A GEMM's output registers ARE the next GEMM's input registers;
+//   * bias, residual, ReLU are register arithmetic; LayerNorm is a reduction over a lane's 48 registers plus one shuffle with lane ^ 32;
+//   * attention: S^T = K_h q^T with the head's 24 q-values of a point taken straight from the registers (12 per lane: groups 3 h .. 3 h + 2 of
+//     eight channels), all L <= 64 class embeddings as two 32-token row blocks on the matrix pipe, softmax over a lane's score registers + one
+//     shuffle, O^T = V_h^T P with the probabilities as B operand; the output registers are the out-projection's input registers;
+//   * LDS holds only what the four waves share: the weight stream (two 9 KB chunks), K / V of the frame and layer, the layer's bias / LayerNorm
+//     vectors: 73 KB -> two workgroups per CU (<= 256 VGPRs), two waves per SIMD to hide each other's waits.
+// A workgroup's 128 points belong to ONE frame (tiles are cut per frame from pt_off), so K / V are staged once for all four waves and no wave
+// straddles a frame.
+constexpr int RT_LMAX = 64;
+#ifndef RT_WGS_PER_CU
+#define RT_WGS_PER_CU 1
+#endif
+constexpr int RT_KV = 2 * SF_E * RT_LMAX;   // floats: [k | v][head][token][24]
+constexpr int RT_VEC = 10 * SF_E;           // floats per layer: bq bo b1[192] b2 n2g n2b n3g n3b (+ 96 spare)
+constexpr int RT_LDS_BYTES = 2 * SF_PCHUNK * 16 + RT_KV * 4 + 2 * RT_VEC * 4 + 3 * SF_E * 4;
+
+// four consecutive channels 32 n + 8 i + 4 kk .. + 3 of a per-channel vector in LDS (one broadcast ds_read_b128 per lane half)
+#define RT_VEC4(vec_, n_, i_) (*(const float4 *)((vec_) + 32 * (n_) + 8 * (i_) + 4 * kk))
+#define RT_FOR(n, i) _Pragma("unroll") for (int n = 0; n < 3; ++n) _Pragma("unroll") for (int i = 0; i < 4; ++i)
+
+// out[m] (+)= W^T[32 m ..][K] in[K][point]:  in = NB blocks of 32 channels in the C layout, weights staged chunk by chunk (16 channels) as in
+// sf_gemm_planes of round 4's first attempt: chunk c + 2 in flight while chunk c multiplies, `pre` = chunk 0 of this matrix on entry and of
+// `next` on exit.  Six plane products per f32 product, head x head alone in `out`, the five small ones in a second accumulator.
+template <int NB>
+__device__ __forceinline__ void rt_gemm(const sf_f32x16 (&in)[3], const uint4 *__restrict__ Wq, const uint4 *__restrict__ next, uint4 *Bq,
+                                        sf_f32x16 (&out)[3], bool zero, SfPre &pre) {
+  constexpr int NKC = 2 * NB;
+  const int lane = threadIdx.x & 63;
+  if (!next) next = Wq;
+  __syncthreads();  // previous users of the weight buffers are done
+  sf_stash(Bq, pre);
+  SfPre p1 = sf_fetch(NKC > 1 ? Wq + SF_PSTRIDE : next);
+  __syncthreads();
+  sf_f32x16 acs[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acs[m][r] = 0.0f;
+      if (zero) out[m][r] = 0.0f;
+    }
+#pragma unroll
+  for (int c = 0; c < NKC; ++c) {
+    SfPre p2 = p1;
+    if (c + 2 <= NKC) p2 = sf_fetch(c + 2 < NKC ? Wq + (size_t)(c + 2) * SF_PSTRIDE : next);
+    {
+      constexpr int dummy = 0; (void)dummy;
+      const int n = c >> 1, u = c & 1;
+      uint4 xh, xm, xl;
+      ls3d_split_pair3_rne(in[n][8 * u + 0], in[n][8 * u + 1], xh.x, xm.x, xl.x);
+      ls3d_split_pair3_rne(in[n][8 * u + 2], in[n][8 * u + 3], xh.y, xm.y, xl.y);
+      ls3d_split_pair3_rne(in[n][8 * u + 4], in[n][8 * u + 5], xh.z, xm.z, xl.z);
+      ls3d_split_pair3_rne(in[n][8 * u + 6], in[n][8 * u + 7], xh.w, xm.w, xl.w);
+      const sf_bf16x8 Xh = __builtin_bit_cast(sf_bf16x8, xh), Xm = __builtin_bit_cast(sf_bf16x8, xm), Xl = __builtin_bit_cast(sf_bf16x8, xl);
+      const uint4 *bs = Bq + (c & 1) * SF_PCHUNK + lane;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const sf_bf16x8 Wh = __builtin_bit_cast(sf_bf16x8, bs[(m * 3 + 0) * 64]);
+        const sf_bf16x8 Wm = __builtin_bit_cast(sf_bf16x8, bs[(m * 3 + 1) * 64]);
+        const sf_bf16x8 Wl = __builtin_bit_cast(sf_bf16x8, bs[(m * 3 + 2) * 64]);
+        out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Xh, out[m], 0, 0, 0);
+        acs[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wl, Xh, acs[m], 0, 0, 0);
+        acs[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Xl, acs[m], 0, 0, 0);
+        acs[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wm, Xm, acs[m], 0, 0, 0);
+        acs[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wm, Xh, acs[m], 0, 0, 0);
+        acs[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Xm, acs[m], 0, 0, 0);
+      }
+    }
+    if (c + 1 < NKC) {
+      sf_stash(Bq + ((c + 1) & 1) * SF_PCHUNK, p1);
+      __syncthreads();
+    }
+    p1 = p2;
+  }
+  pre = p1;  // chunk 0 of `next`
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[m][r] += acs[m][r];
+}
+
+// x = LayerNorm(x) over the 96 channels of a point: 48 registers here, 48 in lane ^ 32
+__device__ __forceinline__ void rt_layernorm(sf_f32x16 (&x)[3], const float *g, const float *b, float eps, int kk) {
+  float s = 0.0f;
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += x[n][r];
+  s += __shfl_xor(s, 32);
+  const float mean = s / (float)SF_E;
+  float q2 = 0.0f;
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[n][r] -= mean; q2 = fmaf(x[n][r], x[n][r], q2); }
+  q2 += __shfl_xor(q2, 32);
+  const float rstd = 1.0f / sqrtf(q2 / (float)SF_E + eps);
+  RT_FOR(n, i) {
+    const float4 gg = RT_VEC4(g, n, i), bb = RT_VEC4(b, n, i);
+    x[n][4 * i + 0] = x[n][4 * i + 0] * rstd * gg.x + bb.x;
+    x[n][4 * i + 1] = x[n][4 * i + 1] * rstd * gg.y + bb.y;
+    x[n][4 * i + 2] = x[n][4 * i + 2] * rstd * gg.z + bb.z;
+    x[n][4 * i + 3] = x[n][4 * i + 3] * rstd * gg.w + bb.w;
+  }
+}
+
+// attention of the wave's 32 points over the frame's L <= 64 class embeddings, one head: q = t's registers of groups 3 h .. 3 h + 2 (overwritten
+// by the head's output).  kvs: [k | v][head][token][24] f32 in LDS.  Exact f32 products (v_mfma_f32_32x32x2_f32), f32 softmax.
+template <int H>
+__device__ __forceinline__ void rt_attention_head(sf_f32x16 (&t)[3], const float *kvs, int L) {
+  const int lane = threadIdx.x & 63, col = lane & 31, kk = lane >> 5;
+  const float scale = 1.0f / sqrtf((float)SF_HD);
+  const bool two = L > 32;
+  const float *Kh = kvs + H * L * SF_HD, *Vh = kvs + SF_E * L + H * L * SF_HD;
+  const int tok0 = col < L ? col : 0, tok1 = (32 + col) < L ? 32 + col : 0;  // this lane's key rows of the two A operands (rows >= L are masked below)
+  sf_f32x16 s0, s1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s0[r] = 0.0f; s1[r] = 0.0f; }
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    constexpr int dummy = 0; (void)dummy;
+    const int G = 3 * H + g, n = G >> 2, i = G & 3;
+    const float4 k0 = *(const float4 *)(Kh + tok0 * SF_HD + 8 * g + 4 * kk);
+    const float kv0[4] = {k0.x, k0.y, k0.z, k0.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv0[j], t[n][4 * i + j], s0, 0, 0, 0);
+    if (two) {
+      const float4 k1 = *(const float4 *)(Kh + tok1 * SF_HD + 8 * g + 4 * kk);
+      const float kv1[4] = {k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv1[j], t[n][4 * i + j], s1, 0, 0, 0);
+    }
+  }
+  float m = -3.0e38f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int token = (r & 3) + 8 * (r >> 2) + 4 * kk;
+    s0[r] = token < L ? s0[r] * scale : -3.0e38f;
+    s1[r] = (two && token + 32 < L) ? s1[r] * scale : -3.0e38f;
+    m = fmaxf(m, fmaxf(s0[r], s1[r]));
+  }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float den = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int token = (r & 3) + 8 * (r >> 2) + 4 * kk;
+    s0[r] = token < L ? expf(s0[r] - m) : 0.0f;
+    s1[r] = (two && token + 32 < L) ? expf(s1[r] - m) : 0.0f;
+    den += s0[r] + s1[r];
+  }
+  den += __shfl_xor(den, 32);
+  // O^T[d][point] = sum_token V_h[token][d] P[token][point]: A = V_h^T (row d: this lane's half of the step's two tokens), B = the probabilities
+  sf_f32x16 oc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oc[r] = 0.0f;
+  const int dv = col < SF_HD ? col : 0;  // rows >= 24 of the output are discarded
+#pragma unroll
+  for (int s2 = 0; s2 < 16; ++s2) {
+    const int token = (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
+    const float va = token < L ? Vh[token * SF_HD + dv] : 0.0f;
+    oc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s0[s2], oc, 0, 0, 0);
+  }
+  if (two) {
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int token = 32 + (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
+      const float va = token < L ? Vh[token * SF_HD + dv] : 0.0f;
+      oc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s1[s2], oc, 0, 0, 0);
+    }
+  }
+  const float inv = 1.0f / den;
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {  // output row d = (r & 3) + 8 (r >> 2) + 4 kk of the head = channel 24 h + d: group 3 h + (r >> 2), j = r & 3
+    constexpr int dummy = 0; (void)dummy;
+    const int G = 3 * H + (r >> 2), n = G >> 2, i = G & 3;
+    t[n][4 * i + (r & 3)] = oc[r] * inv;
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, RT_WGS_PER_CU) void k_sffm_decoder_rt(const float *__restrict__ x, int x_ld, int n, const int32_t *__restrict__ pt_off,
+                                                            const float *__restrict__ kv, int L, int batch, SfParams prm,
+                                                            float *__restrict__ out, int out_ld) {
+  HIP_DYNAMIC_SHARED(float, smem)
+  uint4 *Bq = (uint4 *)smem;                                   // [2][SF_PCHUNK] weight chunks
+  float *KVs = smem + 2 * SF_PCHUNK * 4;                       // [k | v][head][token][24]
+  float *VEC = KVs + RT_KV;                                    // [2][RT_VEC] the layer's per-channel vectors (double buffered over the layers)
+  float *GV = VEC + 2 * RT_VEC;                                // bin | ng | nb
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kk = lane >> 5;
+  // ---- this workgroup's tile: 128 consecutive points of ONE frame
+  int f = 0, tile = (int)blockIdx.x, lo = 0, hi = 0;
+  for (;; ++f) {
+    if (f >= batch) return;  // beyond the tiles of the batch (the grid covers the worst case: ceil(n / 128) + batch)
+    lo = pt_off[f]; hi = pt_off[f + 1];
+    const int nt = (hi - lo + 127) >> 7;
+    if (tile < nt) break;
+    tile -= nt;
+  }
+  const int p = lo + tile * 128 + wave * 32 + col;  // this lane's point (both halves kk of a column hold the same point)
+  const bool live = p < hi;
+  const size_t kv_layer = (size_t)2 * batch * SF_E * L;
+  for (int i = tid; i < SF_E; i += 256) {
+    GV[i] = prm.bin[i];
+    GV[SF_E + i] = prm.ng ? prm.ng[i] : 1.0f;
+    GV[2 * SF_E + i] = prm.nb ? prm.nb[i] : 0.0f;
+  }
+  SfPre pre = sf_fetch(prm.pwin);
+  // ---- the point's input row -> registers in the C layout (channels 32 n + 8 i + 4 kk + j)
+  sf_f32x16 xin[3], xs[3], t[3], acc[3];
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xin[nb][r] = 0.0f;
+  {
+    const float *row = x + (size_t)(live ? p : lo) * x_ld;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = *(const float4 *)(row + 32 * nb + 8 * i + 4 * kk);
+        xin[nb][4 * i + 0] = v.x; xin[nb][4 * i + 1] = v.y; xin[nb][4 * i + 2] = v.z; xin[nb][4 * i + 3] = v.w;
+      }
+  }
+  // ---- input projection -> xs
+  rt_gemm<NB>(xin, prm.pwin, prm.num_layers ? prm.layer[0].pwq : nullptr, Bq, xs, true, pre);
+  RT_FOR(nn, i) {
+    const float4 b4 = RT_VEC4(GV, nn, i);
+    xs[nn][4 * i + 0] += b4.x; xs[nn][4 * i + 1] += b4.y; xs[nn][4 * i + 2] += b4.z; xs[nn][4 * i + 3] += b4.w;
+  }
+  for (int l = 0; l < prm.num_layers; ++l) {
+    const SfLayer &Ly = prm.layer[l];
+    float *V = VEC + (l & 1) * RT_VEC;
+    // ---- what the four waves share in this layer: the per-channel vectors and K / V of the frame, transposed: source [h][d][l] -> LDS
+    //      [h][l][d].  No barrier of its own: every wave is past the previous layer's attention and LayerNorms of layer l - 2 (the GEMMs in
+    //      between synchronise the workgroup), and the q-projection's first barrier orders these writes against their readers.
+    for (int i = tid; i < SF_E; i += 256) {
+      V[i] = Ly.bq[i]; V[SF_E + i] = Ly.bo[i]; V[2 * SF_E + i] = Ly.b1[i]; V[3 * SF_E + i] = Ly.b1[SF_E + i]; V[4 * SF_E + i] = Ly.b2[i];
+      V[5 * SF_E + i] = Ly.n2g[i]; V[6 * SF_E + i] = Ly.n2b[i]; V[7 * SF_E + i] = Ly.n3g[i]; V[8 * SF_E + i] = Ly.n3b[i];
+    }
+    {
+      const float *kg = kv + (size_t)l * kv_layer + (size_t)f * SF_E * L, *vg = kg + (size_t)batch * SF_E * L;
+      for (int i = tid; i < SF_E * L; i += 256) {
+        const int ll = i % L, hd = i / L, h = hd / SF_HD, d = hd - h * SF_HD;
+        const int o = (h * L + ll) * SF_HD + d;
+        KVs[o] = kg[i];
+        KVs[SF_E * L + o] = vg[i];
+      }
+    }
+    // ---- q projection -> t
+    rt_gemm<3>(xs, Ly.pwq, Ly.pwo, Bq, t, true, pre);
+    RT_FOR(nn, i) {
+      const float4 b4 = RT_VEC4(V, nn, i);
+      t[nn][4 * i + 0] += b4.x; t[nn][4 * i + 1] += b4.y; t[nn][4 * i + 2] += b4.z; t[nn][4 * i + 3] += b4.w;
+    }
+    rt_attention_head<0>(t, KVs, L);
+    rt_attention_head<1>(t, KVs, L);
+    rt_attention_head<2>(t, KVs, L);
+    rt_attention_head<3>(t, KVs, L);
+    // ---- out projection + residual, LayerNorm (norm2)
+    rt_gemm<3>(t, Ly.pwo, Ly.pw1a, Bq, acc, true, pre);
+    RT_FOR(nn, i) {
+      const float4 b4 = RT_VEC4(V + SF_E, nn, i);
+      xs[nn][4 * i + 0] += acc[nn][4 * i + 0] + b4.x; xs[nn][4 * i + 1] += acc[nn][4 * i + 1] + b4.y;
+      xs[nn][4 * i + 2] += acc[nn][4 * i + 2] + b4.z; xs[nn][4 * i + 3] += acc[nn][4 * i + 3] + b4.w;
+    }
+    rt_layernorm(xs, V + 5 * SF_E, V + 6 * SF_E, Ly.n2eps, kk);
+    // ---- FFN in two 96-wide halves of the hidden layer: t = relu(W1[half]^T x + b1[half]); acc += W2[half]^T t
+    rt_gemm<3>(xs, Ly.pw1a, Ly.pw2a, Bq, t, true, pre);
+    RT_FOR(nn, i) {
+      const float4 b4 = RT_VEC4(V + 2 * SF_E, nn, i);
+      t[nn][4 * i + 0] = fmaxf(t[nn][4 * i + 0] + b4.x, 0.0f); t[nn][4 * i + 1] = fmaxf(t[nn][4 * i + 1] + b4.y, 0.0f);
+      t[nn][4 * i + 2] = fmaxf(t[nn][4 * i + 2] + b4.z, 0.0f); t[nn][4 * i + 3] = fmaxf(t[nn][4 * i + 3] + b4.w, 0.0f);
+    }
+    rt_gemm<3>(t, Ly.pw2a, Ly.pw1b, Bq, acc, true, pre);
+    rt_gemm<3>(xs, Ly.pw1b, Ly.pw2b, Bq, t, true, pre);
+    RT_FOR(nn, i) {
+      const float4 b4 = RT_VEC4(V + 3 * SF_E, nn, i);
+      t[nn][4 * i + 0] = fmaxf(t[nn][4 * i + 0] + b4.x, 0.0f); t[nn][4 * i + 1] = fmaxf(t[nn][4 * i + 1] + b4.y, 0.0f);
+      t[nn][4 * i + 2] = fmaxf(t[nn][4 * i + 2] + b4.z, 0.0f); t[nn][4 * i + 3] = fmaxf(t[nn][4 * i + 3] + b4.w, 0.0f);
+    }
+    rt_gemm<3>(t, Ly.pw2b, (l + 1 < prm.num_layers ? prm.layer[l + 1].pwq : nullptr), Bq, acc, false, pre);
+    RT_FOR(nn, i) {
+      const float4 b4 = RT_VEC4(V + 4 * SF_E, nn, i);
+      xs[nn][4 * i + 0] += acc[nn][4 * i + 0] + b4.x; xs[nn][4 * i + 1] += acc[nn][4 * i + 1] + b4.y;
+      xs[nn][4 * i + 2] += acc[nn][4 * i + 2] + b4.z; xs[nn][4 * i + 3] += acc[nn][4 * i + 3] + b4.w;
+    }
+    rt_layernorm(xs, V + 7 * SF_E, V + 8 * SF_E, Ly.n3eps, kk);
+  }
+  if (prm.ng) rt_layernorm(xs, GV + SF_E, GV + 2 * SF_E, prm.neps, kk);
+  if (live) {
+    float *row = out + (size_t)p * out_ld;
+    RT_FOR(nn, i) *(float4 *)(row + 32 * nn + 8 * i + 4 * kk) = make_float4(xs[nn][4 * i + 0], xs[nn][4 * i + 1], xs[nn][4 * i + 2], xs[nn][4 * i + 3]);
+  }
+}
+
 extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int pt_stride, const float *kv, int L, int batch,
                                  const ls3d_sffm_t *m, float *out, int out_ld, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -576,7 +816,8 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
   const bool planes = m->gemm_products == 6;
   if (m->gemm_products != 0 && !planes) return LS3D_ERR_ARG;
   prm.pwin = (const uint4 *)m->w_in_planes;
-  if (planes && (!m->w_in_planes || (m->d_in % 16))) return LS3D_ERR_ARG;
+  if (planes && (!m->w_in_planes || !m->pt_off || (m->d_in % 32))) return LS3D_ERR_ARG;
+  if (planes && (m->attention != 0 || L > RT_LMAX)) return LS3D_ERR_UNSUPPORTED;  // the reduced-precision attentions live in the LDS-tile kernel
   for (int l = 0; l < m->num_layers; ++l) {
     const ls3d_sffm_layer_t &s = m->layers[l];
     if (!s.wq || !s.bq || !s.wo || !s.bo || !s.w1a || !s.w1b || !s.b1 || !s.w2a || !s.w2b || !s.b2 || !s.n2_gamma || !s.n2_beta || !s.n3_gamma || !s.n3_beta)
@@ -589,18 +830,25 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
   const int lds = (4 * SF_WAVE_FLOATS + 2 * SF_BCHUNK + SF_KV) * (int)sizeof(float) + (128 + 8) * (int)sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_sffm_decoder<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_sffm_decoder<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void *)k_sffm_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess)
       return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
   long long blocks = ((long long)n + 127) / 128;
   if (blocks > 65536) blocks = 65536;
   const int att = (m->attention >= 0 && m->attention <= 3) ? m->attention : 0;
-  if (planes)
-    hipLaunchKernelGGL(k_sffm_decoder<6>, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, att);
-  else
-    hipLaunchKernelGGL(k_sffm_decoder<0>, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, att);
+  if (planes) {  // the register-resident form: tiles cut per frame
+    const unsigned grid = (unsigned)(((long long)n + 127) / 128 + batch);
+    const int32_t *po = (const int32_t *)m->pt_off;
+#define RT_LAUNCH(NB_) hipLaunchKernelGGL((k_sffm_decoder_rt<NB_>), dim3(grid), dim3(256), RT_LDS_BYTES, stream, x, x_ld, n, po, kv, L, batch, prm, out, out_ld)
+    if (m->d_in == 32) RT_LAUNCH(1); else if (m->d_in == 64) RT_LAUNCH(2); else RT_LAUNCH(3);
+#undef RT_LAUNCH
+  } else {
+    hipLaunchKernelGGL(k_sffm_decoder, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, att);
+  }
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

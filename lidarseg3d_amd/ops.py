@@ -1031,18 +1031,32 @@ class SffmModel(object):
             for k, v in t.items():
                 setattr(arr[i], k, v.data_ptr())
             arr[i].n2_eps, arr[i].n3_eps = float(l["n2"][2]), float(l["n3"][2])
-            # the same matrices as three exact bf16 planes (ls3d_tile_conv_pack): the decoder's GEMMs in the 3-plane modes
+            # the same matrices as three exact bf16 planes for the register-resident (transposed) form of the decoder: input channels of every
+            # 16-block in the order the MFMA's C layout hands them on (include/ls3d.h: ls3d_sffm_layer_t)
             for k in ("wq", "wo", "w1a", "w1b", "w2a", "w2b"):
-                t = l[k].for_tile()
+                t = self._transposed_planes(l[k])
                 self.keep.append(t)
                 setattr(arr[i], k + "_planes", t.data_ptr())
         self.layers = arr
         self.keep.extend([norm[0], norm[1]] if norm is not None else [])
-        w_in_planes = w_in.for_tile()
+        w_in_planes = self._transposed_planes(w_in)
         self.keep.append(w_in_planes)
         self.c = Sffm(self.keep[0].data_ptr(), b_in.data_ptr(), arr, len(layers), int(d_in), int(d_model), int(heads), int(ffn),
                       norm[0].data_ptr() if norm is not None else None, norm[1].data_ptr() if norm is not None else None,
-                      float(norm[2]) if norm is not None else 0.0, 0, w_in_planes.data_ptr(), 0)
+                      float(norm[2]) if norm is not None else 0.0, 0, w_in_planes.data_ptr(), None, 0)
+
+    @staticmethod
+    def _transposed_planes(pw):
+        """PackedWeight of a Linear ([in][out] plain) -> ls3d_tile_conv_pack of the matrix with packed input row 16 c + 8 kk + q taken from
+        plain row 16 c + 8 (q // 4) + 4 kk + q % 4"""
+        cin = pw.cin
+        k = torch.arange(cin, device=pw.plain.device)
+        c, kk, q = k // 16, (k % 16) // 8, k % 8
+        src = 16 * c + 8 * (q // 4) + 4 * kk + q % 4
+        plain = pw.plain.reshape(-1, pw.plain.shape[-1])
+        if plain.shape[0] < cin:  # rows beyond the module's input width are zero padding
+            plain = torch.cat([plain, plain.new_zeros((cin - plain.shape[0], plain.shape[1]))])
+        return tile_conv_pack(plain[src].contiguous(), 1, cin, cin, pw.cout)
 
 
 _SFFM_ATTENTION = 0
@@ -1056,12 +1070,19 @@ def set_sffm_attention(mode):
     _SFFM_ATTENTION = {"f32": 0, "bf16": 1, "valu": 2, "fp8": 3}[mode]
 
 
-def sffm_decoder(x, points, kv, L, batch, model):
-    """fused point side of the SF-Phase decoder (ls3d_sffm_decoder); returns None when the shape is not supported"""
+def sffm_decoder(x, points, kv, L, batch, model, pt_off=None):
+    """fused point side of the SF-Phase decoder (ls3d_sffm_decoder); returns None when the shape is not supported.  In the 3-plane precisions
+    (and with exact-f32 attention, L <= 64) the register-resident form runs: GEMMs on the 3-plane bf16 split, f32-grade like the convolutions'
+    (pt_off: the frames' first rows, computed here when the caller has none)"""
     n = x.shape[0]
     out = torch.empty((n, model.c.d_model), dtype=torch.float32, device=x.device)
     model.c.attention = _SFFM_ATTENTION
-    model.c.gemm_products = 6 if (_PRECISION in (BF16X6, BF16X8, BF16) and _SFFM_PLANES) else 0  # the 3-plane modes: f32-grade, like the convolutions'
+    planes = _PRECISION in (BF16X6, BF16X8, BF16) and _SFFM_PLANES and _SFFM_ATTENTION == 0 and L <= 64
+    model.c.gemm_products = 6 if planes else 0
+    if planes:
+        if pt_off is None:
+            pt_off = frame_offsets(points if points.dim() == 2 else points.unsqueeze(1).contiguous(), batch)
+        model.c.pt_off = pt_off.data_ptr()
     rc = _L().ls3d_sffm_decoder(_ptr(x), x.shape[1], n, _ptr(points), points.shape[1] if points.dim() == 2 else 1, _ptr(kv), int(L), int(batch),
                                 ctypes.byref(model.c), _ptr(out), out.shape[1], _stream(x))
     if rc == _lib.ERR_UNSUPPORTED:
