@@ -572,6 +572,23 @@ int ls3d_seg_loss_forward(const float *logits, int ld, const int32_t *labels, in
 int ls3d_seg_loss_backward(const int32_t *labels, int n_points, int num_classes, int ignore_index, const void *workspace, size_t workspace_bytes,
                            const float *grad_ce, const float *grad_lovasz, float *grad_logits, int ld, ls3d_stream_t stream);
 
+/* BatchNorm1d over [n, c] rows in training mode (batch statistics) with the ReLU / residual add that follow it in the UNet fused in
+ * (det3d/models/backbones/scn_unet.py:11-69; nn.BatchNorm1d semantics: biased variance for the normalisation), c % 4 == 0, c <= 256, 256 % (c / 4) == 0:
+ *   ls3d_batch_norm_stats         : mean_m2[2 c] = per-column mean and sum of squared deviations of the n rows (one pass over x, per-block partials
+ *                                   merged with Chan's update in block order: deterministic, no cancellation); workspace = ls3d_batch_norm_workspace_bytes;
+ *   ls3d_batch_norm_apply         : y = [relu]((x - mean) * rstd * gamma + beta [+ res]);
+ *   ls3d_batch_norm_backward_sums : sums[2 c] = column sums of g and of g * xhat, g = dy * [y > 0] (y_or_null = NULL: g = dy) - exposed so that a
+ *                                   data-parallel step can all-reduce them (lidarseg3d_amd/syncbn.py);
+ *   ls3d_batch_norm_backward_apply: dx = gamma rstd (g - sums[0..c) * inv_count - xhat * sums[c..2c) * inv_count), dres = g (dres may be NULL). */
+size_t ls3d_batch_norm_workspace_bytes(int n, int c);
+int ls3d_batch_norm_stats(const float *x, int ld, int n, int c, void *workspace, size_t workspace_bytes, float *mean_m2, ls3d_stream_t stream);
+int ls3d_batch_norm_apply(const float *x, int ld, int n, int c, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                          const float *res, int res_ld, int relu, float *y, int y_ld, ls3d_stream_t stream);
+int ls3d_batch_norm_backward_sums(const float *x, int ld, const float *dy, const float *y_or_null, int n, int c, const float *mean, const float *rstd,
+                                  void *workspace, size_t workspace_bytes, float *sums, ls3d_stream_t stream);
+int ls3d_batch_norm_backward_apply(const float *x, int ld, const float *dy, const float *y_or_null, int n, int c, const float *mean, const float *rstd,
+                                   const float *gamma, const float *sums, float inv_count, float *dx, float *dres, ls3d_stream_t stream);
+
 /* Row LayerNorm over [n, c] (rows contiguous, c % 4 == 0, c <= 256), forward and backward, for the training step: the LayerNorms of the
  * reader (voxel_encoder.py:149-163) and of the SF-Phase decoder (context_module.py:319-376) over 10^5 - 10^6 token rows.
  *   forward : y = (x - mean) * rstd * gamma + beta per row, biased variance + eps as torch.nn.LayerNorm; stats[n][2] = (mean, rstd) for

@@ -206,3 +206,228 @@ extern "C" int ls3d_layer_norm_backward(const float *x, const float *dy, const f
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// BatchNorm1d over [n, c] rows in TRAINING mode (batch statistics), forward and backward, with the ReLU and the residual add that follow it
+// in the UNet fused in (det3d/models/backbones/scn_unet.py:11-69: SubMConv3d -> BatchNorm1d(eps 1e-3, momentum 0.01) -> ReLU, and the
+// SparseBasicBlock's relu(bn2(conv2(.)) + identity)); the point heads' Linear -> BatchNorm1d -> ReLU chains use the same entry points.
+// torch runs this as collect_statistics + transform (+ add + relu) forward and backward_reduce + backward_elemt (+ relu / add backward):
+// 13 ms of BatchNorm kernels and ~6 ms of elementwise kernels per 2 x 180k-point Waymo step.  Here:
+//   statistics: one pass over x.  A workgroup owns BN_ROWS consecutive rows: column sums -> the block's mean, then the centred second moment
+//     around it from a second walk over the same rows (they are in L2: one HBM read), and the partials (mean_b, M2_b) of the row blocks are
+//     merged per column with the pairwise update of Chan et al. in block order: deterministic, no E[x^2] - mean^2 cancellation;
+//   apply:      y = [relu]((x - mean) * rstd * gamma + beta [+ res]);
+//   backward:   g = dy * [y > 0]; column sums of g and g * xhat per row block -> fixed-order reduction; dx = gamma rstd (g - sum g / N - xhat
+//     sum(g xhat) / N), dres = g.  The two sums are exposed between the launches so that a data-parallel step can all-reduce them
+//     (count-weighted SyncBN, lidarseg3d_amd/syncbn.py).
+constexpr int BN_ROWS = 512;  // rows per workgroup of the reductions
+
+// thread (rg, cg): column group cg (4 channels), rows rg, rg + RP, ... of the block; c4 = c / 4 <= 64 column groups, RP = 256 / c4 row lanes
+__global__ __launch_bounds__(256) void k_bn_stats_part(const float *__restrict__ x, int ld, int n, int c, float *__restrict__ part) {
+  __shared__ float4 s_red[256];
+  __shared__ float4 s_mean[64];
+  const int c4 = c >> 2, RP = 256 / c4, tid = threadIdx.x;
+  const int cg = tid % c4, rg = tid / c4;
+  const int r0 = blockIdx.x * BN_ROWS, r1 = min(n, r0 + BN_ROWS);
+  const bool on = rg < RP;
+  // (four rows per trip, their loads issued together from clamped addresses: a lane walking its rows with one load in flight is bound by
+  // the memory latency, not the bandwidth - round 3's BatchNorm attempt lost to torch for that reason)
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on)
+    for (int r = r0 + rg; r < r1; r += 4 * RP) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(x + (size_t)min(r + u * RP, r1 - 1) * ld + cg * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + u * RP < r1) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+  s_red[tid] = s;
+  __syncthreads();
+  if (tid < c4) {
+    float4 t = s_red[tid];
+    for (int g = 1; g < RP; ++g) { const float4 u = s_red[g * c4 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    const float inv = 1.0f / (float)(r1 - r0);
+    s_mean[tid] = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+  }
+  __syncthreads();
+  const float4 mu = s_mean[cg];
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on)
+    for (int r = r0 + rg; r < r1; r += 4 * RP) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(x + (size_t)min(r + u * RP, r1 - 1) * ld + cg * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + u * RP < r1) {
+          const float dx = v[u].x - mu.x, dy = v[u].y - mu.y, dz = v[u].z - mu.z, dw = v[u].w - mu.w;
+          q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+        }
+    }
+  s_red[tid] = q;
+  __syncthreads();
+  if (tid < c4) {
+    float4 t = s_red[tid];
+    for (int g = 1; g < RP; ++g) { const float4 u = s_red[g * c4 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *(float4 *)(part + ((size_t)blockIdx.x * 2 + 0) * c + tid * 4) = mu;
+    *(float4 *)(part + ((size_t)blockIdx.x * 2 + 1) * c + tid * 4) = t;
+  }
+}
+
+// (mean_b, M2_b, n_b) of the row blocks -> mean[c], M2[c] of all n rows: Chan's pairwise update, blocks in order, one thread per column
+__global__ __launch_bounds__(256) void k_bn_stats_merge(const float *__restrict__ part, int nblocks, int n, int c, float *__restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  double mean = 0.0, m2 = 0.0, cnt = 0.0;  // (c threads x nblocks steps: double costs nothing here and keeps the merge out of the error budget)
+  for (int b = 0; b < nblocks; ++b) {
+    const double nb = (double)min(BN_ROWS, n - b * BN_ROWS);
+    const double mb = part[((size_t)b * 2 + 0) * c + col], qb = part[((size_t)b * 2 + 1) * c + col];
+    const double tot = cnt + nb, d = mb - mean;
+    mean += d * (nb / tot);
+    m2 += qb + d * d * (cnt * nb / tot);
+    cnt = tot;
+  }
+  out[col] = (float)mean;
+  out[c + col] = (float)m2;
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int ld, int n, int c, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                  const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ res, int res_ld, int relu,
+                                                  float *__restrict__ y, int y_ld) {
+  const int c4 = c >> 2;
+  const long long work = (long long)n * c4;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(t / c4), cg = (int)(t % c4);
+    const float4 v = *(const float4 *)(x + (size_t)r * ld + cg * 4), mu = *(const float4 *)(mean + cg * 4), rs = *(const float4 *)(rstd + cg * 4);
+    const float4 g = *(const float4 *)(gamma + cg * 4), b = *(const float4 *)(beta + cg * 4);
+    float4 o;
+    o.x = (v.x - mu.x) * rs.x * g.x + b.x; o.y = (v.y - mu.y) * rs.y * g.y + b.y;
+    o.z = (v.z - mu.z) * rs.z * g.z + b.z; o.w = (v.w - mu.w) * rs.w * g.w + b.w;
+    if (res) {
+      const float4 q = *(const float4 *)(res + (size_t)r * res_ld + cg * 4);
+      o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+    }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *(float4 *)(y + (size_t)r * y_ld + cg * 4) = o;
+  }
+}
+
+// per row block: column sums of g = dy * [y > 0] and of g * xhat -> part[block][2][c]
+__global__ __launch_bounds__(256) void k_bn_bwd_part(const float *__restrict__ x, int ld, const float *__restrict__ dy, const float *__restrict__ y, int n, int c,
+                                                     const float *__restrict__ mean, const float *__restrict__ rstd, float *__restrict__ part) {
+  __shared__ float4 s_red[2][256];
+  const int c4 = c >> 2, RP = 256 / c4, tid = threadIdx.x;
+  const int cg = tid % c4, rg = tid / c4;
+  const int r0 = blockIdx.x * BN_ROWS, r1 = min(n, r0 + BN_ROWS);
+  float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rg < RP) {
+    const float4 mu = *(const float4 *)(mean + cg * 4), rs = *(const float4 *)(rstd + cg * 4);
+    for (int r = r0 + rg; r < r1; r += 2 * RP) {
+      float4 v[2], gg[2], oo[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const size_t rr = (size_t)min(r + u * RP, r1 - 1);
+        v[u] = *(const float4 *)(x + rr * ld + cg * 4);
+        gg[u] = *(const float4 *)(dy + rr * c + cg * 4);
+        oo[u] = y ? *(const float4 *)(y + rr * c + cg * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (r + u * RP < r1) {
+          float4 g = gg[u];
+          g.x = oo[u].x > 0.f ? g.x : 0.f; g.y = oo[u].y > 0.f ? g.y : 0.f; g.z = oo[u].z > 0.f ? g.z : 0.f; g.w = oo[u].w > 0.f ? g.w : 0.f;
+          sg.x += g.x; sg.y += g.y; sg.z += g.z; sg.w += g.w;
+          sx.x = fmaf(g.x, (v[u].x - mu.x) * rs.x, sx.x); sx.y = fmaf(g.y, (v[u].y - mu.y) * rs.y, sx.y);
+          sx.z = fmaf(g.z, (v[u].z - mu.z) * rs.z, sx.z); sx.w = fmaf(g.w, (v[u].w - mu.w) * rs.w, sx.w);
+        }
+    }
+  }
+  s_red[0][tid] = sg;
+  s_red[1][tid] = sx;
+  __syncthreads();
+  if (tid < 2 * c4) {
+    const int which = tid / c4, k = tid % c4;
+    float4 t = s_red[which][k];
+    for (int g = 1; g < RP; ++g) { const float4 u = s_red[which][g * c4 + k]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *(float4 *)(part + ((size_t)blockIdx.x * 2 + which) * c + k * 4) = t;
+  }
+}
+
+// sums[2 c] = (sum g, sum g xhat) over all rows, ALREADY divided by nothing: dx = gamma rstd (g - sums[0] / N - xhat sums[1] / N); dres = g
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, int ld, const float *__restrict__ dy, const float *__restrict__ y, int n, int c,
+                                                      const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                      const float *__restrict__ sums, float inv_count, float *__restrict__ dx, float *__restrict__ dres) {
+  const int c4 = c >> 2;
+  const long long work = (long long)n * c4;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(t / c4), cg = (int)(t % c4);
+    const float4 v = *(const float4 *)(x + (size_t)r * ld + cg * 4), mu = *(const float4 *)(mean + cg * 4), rs = *(const float4 *)(rstd + cg * 4);
+    const float4 gm = *(const float4 *)(gamma + cg * 4), s1 = *(const float4 *)(sums + cg * 4), s2 = *(const float4 *)(sums + c + cg * 4);
+    float4 g = *(const float4 *)(dy + (size_t)r * c + cg * 4);
+    if (y) {
+      const float4 o = *(const float4 *)(y + (size_t)r * c + cg * 4);
+      g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    }
+    if (dres) *(float4 *)(dres + (size_t)r * c + cg * 4) = g;
+    float4 o;
+    o.x = gm.x * rs.x * (g.x - s1.x * inv_count - (v.x - mu.x) * rs.x * (s2.x * inv_count));
+    o.y = gm.y * rs.y * (g.y - s1.y * inv_count - (v.y - mu.y) * rs.y * (s2.y * inv_count));
+    o.z = gm.z * rs.z * (g.z - s1.z * inv_count - (v.z - mu.z) * rs.z * (s2.z * inv_count));
+    o.w = gm.w * rs.w * (g.w - s1.w * inv_count - (v.w - mu.w) * rs.w * (s2.w * inv_count));
+    *(float4 *)(dx + (size_t)r * c + cg * 4) = o;
+  }
+}
+
+static inline int bn_blocks(int n) { return n > 0 ? (n + BN_ROWS - 1) / BN_ROWS : 1; }
+static inline bool bn_shape_ok(int c) { return c >= 4 && !(c & 3) && c <= 256 && (256 % (c >> 2)) == 0; }
+
+extern "C" size_t ls3d_batch_norm_workspace_bytes(int n, int c) { return (size_t)bn_blocks(n) * 2 * (c > 0 ? c : 1) * sizeof(float) + 256; }
+
+extern "C" int ls3d_batch_norm_stats(const float *x, int ld, int n, int c, void *workspace, size_t workspace_bytes, float *mean_m2, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!mean_m2 || n < 0 || c < 4 || (c & 3)) return LS3D_ERR_ARG;
+  if (!bn_shape_ok(c)) return LS3D_ERR_UNSUPPORTED;
+  if (n == 0) return hipMemsetAsync(mean_m2, 0, 2 * c * sizeof(float), stream) == hipSuccess ? LS3D_OK : LS3D_ERR_LAUNCH;
+  if (!x || !workspace || ld < c || (ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)workspace & 15)) return LS3D_ERR_ARG;
+  if (workspace_bytes < ls3d_batch_norm_workspace_bytes(n, c)) return LS3D_ERR_WORKSPACE;
+  const int nb = bn_blocks(n);
+  hipLaunchKernelGGL(k_bn_stats_part, dim3(nb), dim3(256), 0, stream, x, ld, n, c, (float *)workspace);
+  hipLaunchKernelGGL(k_bn_stats_merge, dim3((c + 255) / 256), dim3(256), 0, stream, (const float *)workspace, nb, n, c, mean_m2);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_batch_norm_apply(const float *x, int ld, int n, int c, const float *mean, const float *rstd, const float *gamma, const float *beta,
+                                     const float *res, int res_ld, int relu, float *y, int y_ld, ls3d_stream_t stream_) {
+  if (n == 0 && bn_shape_ok(c)) return LS3D_OK;
+  if (!x || !mean || !rstd || !gamma || !beta || !y || n < 0 || !bn_shape_ok(c) || ld < c || (ld & 3) || y_ld < c || (y_ld & 3) || (res && (res_ld < c || (res_ld & 3))))
+    return LS3D_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_apply, ls3d_grid((long long)n * (c >> 2)), dim3(256), 0, (hipStream_t)stream_, x, ld, n, c, mean, rstd, gamma, beta, res, res_ld, relu, y, y_ld);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_batch_norm_backward_sums(const float *x, int ld, const float *dy, const float *y_or_null, int n, int c, const float *mean, const float *rstd,
+                                             void *workspace, size_t workspace_bytes, float *sums, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!sums || n < 0 || !bn_shape_ok(c)) return LS3D_ERR_ARG;
+  if (n == 0) return hipMemsetAsync(sums, 0, 2 * c * sizeof(float), stream) == hipSuccess ? LS3D_OK : LS3D_ERR_LAUNCH;
+  if (!x || !dy || !mean || !rstd || !workspace || ld < c || (ld & 3)) return LS3D_ERR_ARG;
+  if (workspace_bytes < ls3d_batch_norm_workspace_bytes(n, c)) return LS3D_ERR_WORKSPACE;
+  const int nb = bn_blocks(n);
+  hipLaunchKernelGGL(k_bn_bwd_part, dim3(nb), dim3(256), 0, stream, x, ld, dy, y_or_null, n, c, mean, rstd, (float *)workspace);
+  hipLaunchKernelGGL(k_ln_bwd_reduce, dim3((2 * c + 31) / 32), dim3(256), 0, stream, (const float *)workspace, nb, c, sums, sums + c);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_batch_norm_backward_apply(const float *x, int ld, const float *dy, const float *y_or_null, int n, int c, const float *mean, const float *rstd,
+                                              const float *gamma, const float *sums, float inv_count, float *dx, float *dres, ls3d_stream_t stream_) {
+  if (n == 0 && bn_shape_ok(c)) return LS3D_OK;
+  if (!x || !dy || !mean || !rstd || !gamma || !sums || !dx || n < 0 || !bn_shape_ok(c) || ld < c || (ld & 3)) return LS3D_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_bwd_apply, ls3d_grid((long long)n * (c >> 2)), dim3(256), 0, (hipStream_t)stream_, x, ld, dy, y_or_null, n, c, mean, rstd, gamma, sums,
+                     inv_count, dx, dres);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

@@ -815,6 +815,17 @@ class fast_linear_backward(object):
                         print("fast_linear_backward: not taken:", key, file=_sys.stderr)
                 return orig(input, weight, bias)
             torch.nn.functional.linear = linear
+            orig_bn = self.orig_bn = torch.nn.BatchNorm1d.forward
+
+            def bn_forward(mod, input):
+                # BatchNorm1d over [rows, c] in training mode: statistics, normalisation and their backward on csrc/norm.hip (the sites with a
+                # ReLU / residual behind the BatchNorm call ops.batch_norm_train themselves: spconv.SparseSequential, scn_unet.SparseBasicBlock)
+                if mod.training and input.dim() == 2 and input.is_cuda and input.shape[0] >= 4096 and torch.is_grad_enabled():
+                    y = batch_norm_train(mod, input)
+                    if y is not None:
+                        return y
+                return orig_bn(mod, input)
+            torch.nn.BatchNorm1d.forward = bn_forward
             orig_ln = self.orig_ln = torch.nn.functional.layer_norm
 
             def layer_norm(input, normalized_shape, weight=None, bias=None, eps=1e-5):
@@ -835,6 +846,7 @@ class fast_linear_backward(object):
         if self.on:
             torch.nn.functional.linear = _ORIG_LINEAR
             torch.nn.functional.layer_norm = self.orig_ln
+            torch.nn.BatchNorm1d.forward = self.orig_bn
             _ORIG_LINEAR = None
         return False
 
@@ -1212,3 +1224,108 @@ class _LayerNormFn(torch.autograd.Function):
         x, weight, stats = ctx.saved_tensors
         dx, dg, db = layer_norm_backward(x, gy.contiguous(), weight.detach().contiguous(), stats)
         return dx, dg, db, None
+
+
+# ---------------------------------------------------------------------------------------------- BatchNorm1d, training mode
+def batch_norm_supported(x):
+    """shapes ls3d_batch_norm_* take: [n, c] f32 rows on the device, c % 4 == 0, c <= 256, 256 % (c / 4) == 0"""
+    return (x.dim() == 2 and x.dtype == torch.float32 and (x.is_cuda or _SIM) and x.shape[1] % 4 == 0 and 4 <= x.shape[1] <= 256
+            and 256 % (x.shape[1] // 4) == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def batch_norm_stats(x):
+    """-> [2 c]: per-column mean and sum of squared deviations over the rows of x (ls3d_batch_norm_stats)"""
+    n, c = x.shape
+    out = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    ws = _ws(_L().ls3d_batch_norm_workspace_bytes(n, c), x)
+    check(_L().ls3d_batch_norm_stats(_vp_any(x), x.stride(0), n, c, _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(out), _stream(x)), "ls3d_batch_norm_stats")
+    return out
+
+
+def batch_norm_apply(x, mean, rstd, gamma, beta, res=None, relu=False):
+    n, c = x.shape
+    y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    check(_L().ls3d_batch_norm_apply(_vp_any(x), x.stride(0), n, c, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _vp_any(res) if res is not None else None,
+                                     res.stride(0) if res is not None else 0, 1 if relu else 0, _ptr(y), c, _stream(x)), "ls3d_batch_norm_apply")
+    return y
+
+
+def batch_norm_backward_sums(x, dy, y, mean, rstd):
+    n, c = x.shape
+    sums = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    ws = _ws(_L().ls3d_batch_norm_workspace_bytes(n, c), x)
+    check(_L().ls3d_batch_norm_backward_sums(_vp_any(x), x.stride(0), _ptr(dy), _vp(y), n, c, _ptr(mean), _ptr(rstd), _ptr(ws), ctypes.c_size_t(ws.numel()),
+                                             _ptr(sums), _stream(x)), "ls3d_batch_norm_backward_sums")
+    return sums
+
+
+def batch_norm_backward_apply(x, dy, y, mean, rstd, gamma, sums, count, want_dres):
+    n, c = x.shape
+    dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    dres = torch.empty((n, c), dtype=torch.float32, device=x.device) if want_dres else None
+    check(_L().ls3d_batch_norm_backward_apply(_vp_any(x), x.stride(0), _ptr(dy), _vp(y), n, c, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(sums),
+                                              ctypes.c_float(1.0 / max(float(count), 1.0)), _ptr(dx), _vp(dres), _stream(x)), "ls3d_batch_norm_backward_apply")
+    return dx, dres
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    """[relu](BatchNorm1d(x) [+ res]) with batch statistics on ls3d_batch_norm_* (csrc/norm.hip).  `merge`: None, or a callable
+    (mean_m2 [2 c], n) -> (mean [c], var [c], count) that combines the ranks' statistics (syncbn.py) - its partner `reduce` all-reduces the
+    backward's two column sums.  Returns y and the statistics the module's running averages are updated with."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, eps, relu, merge, reduce):
+        n, c = x.shape
+        st = batch_norm_stats(x)
+        if merge is None:
+            mean, var, count = st[:c], st[c:] / max(n, 1), float(n)
+        else:
+            mean, var, count = merge(st, n)
+        mean, var = mean.contiguous(), var.contiguous()
+        rstd = (1.0 / torch.sqrt(var.double() + eps)).float()
+        y = batch_norm_apply(x, mean, rstd, weight.detach().contiguous(), bias.detach().contiguous(), res, relu)
+        ctx.save_for_backward(x, y if relu else None, mean, rstd, weight)
+        ctx.count, ctx.reduce, ctx.has_res = count, reduce, res is not None and res.requires_grad
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        x, y, mean, rstd, weight = ctx.saved_tensors
+        c = x.shape[1]
+        gy = gy.contiguous()
+        sums = batch_norm_backward_sums(x, gy, y, mean, rstd)
+        gb, gw = sums[:c].clone(), sums[c:].clone()  # local sums: the parameter gradients (DDP averages them over the ranks)
+        if ctx.reduce is not None:
+            sums = ctx.reduce(sums)
+        dx, dres = batch_norm_backward_apply(x, gy, y, mean, rstd, weight.detach().contiguous(), sums, ctx.count, ctx.has_res)
+        return dx, gw, gb, dres, None, None, None, None
+
+
+_BN_KERNELS = _os.environ.get("LS3D_BN_KERNELS", "1") != "0"
+_TORCH_RELU = torch.relu
+
+
+def batch_norm_train(bn, x, res=None, relu=False):
+    """bn (nn.BatchNorm1d in training mode, or its count-weighted SyncBN variant) applied to the rows x with batch statistics, fused with the residual
+    add and the ReLU that follow it; updates the running statistics as nn.BatchNorm1d does.  -> y, or None when the shape / module is not covered
+    (the caller composes it from the torch modules)"""
+    if not (_BN_KERNELS and bn.training and bn.affine and batch_norm_supported(x) and (res is None or batch_norm_supported(res)) and x.shape[0] > 1):
+        return None
+    merge = reduce = None
+    state = {"count": float(x.shape[0])}
+    sync = getattr(bn, "_ls3d_sync", None)
+    if sync is not None:
+        merge, reduce = sync(state)  # (None, None) without an active process group
+    fuse_relu = relu and torch.relu is _TORCH_RELU  # an instrumented torch.relu (tests pin / count ReLU gates by patching it) still sees the ReLU
+    y, mean, var = _BatchNormTrainFn.apply(x, bn.weight, bn.bias, res, bn.eps, fuse_relu, merge, reduce)
+    if relu and not fuse_relu:
+        y = torch.relu(y)
+    if bn.track_running_stats:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            n = state["count"]
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1.0, 1.0)), alpha=m)  # unbiased, as nn.BatchNorm does
+    return y

@@ -49,9 +49,11 @@ class SparseBasicBlock(spconv.SparseModule):
         identity = x.features if self.downsample is None else self.downsample(x)
         if self.training or (torch.is_grad_enabled() and x.features.requires_grad):  # scn_unet.py:51-69 as written, differentiable
             out = self.conv1(x)
-            out.features = torch.relu(self.bn1(out.features))
+            y = ops.batch_norm_train(self.bn1, out.features, relu=True)  # BatchNorm + ReLU (+ residual) fused, forward and backward (csrc/norm.hip)
+            out.features = y if y is not None else torch.relu(self.bn1(out.features))
             out = self.conv2(out)
-            out.features = torch.relu(self.bn2(out.features) + identity)
+            y = ops.batch_norm_train(self.bn2, out.features, res=identity, relu=True)
+            out.features = y if y is not None else torch.relu(self.bn2(out.features) + identity)
             return out
         out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
         return conv_bn_act(self.conv2, self.bn2, out, relu=True, res_pre=identity)

@@ -409,6 +409,11 @@ class SparseSequential(SparseModule):
                 relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
                 x = conv_bn_act(m, mods[i + 1], x, relu=relu)
                 i += 3 if relu else 2
+            elif isinstance(m, nn.BatchNorm1d) and m.training and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and x.indices.shape[0] != 0:
+                # training: BatchNorm (batch statistics) + ReLU as one pair of kernels forward and backward (csrc/norm.hip)
+                y = ops.batch_norm_train(m, x.features, relu=True) if (x.features.is_cuda or ops.sim_mode()) else None
+                x.features = y if y is not None else mods[i + 1](m(x.features))
+                i += 2
             elif isinstance(m, SparseModule):
                 x = m(x)
                 i += 1

@@ -60,7 +60,38 @@ class CountSyncBatchNorm1d(nn.BatchNorm1d):
         super().__init__(*a, **k)
         self.process_group = process_group
 
+    def _ls3d_sync(self, state):
+        """protocol of ops.batch_norm_train (the HIP BatchNorm kernels): -> (merge, reduce) closures that combine the ranks' statistics / the
+        backward's column sums, (None, None) without an active group.  merge stores the total row count in state["count"]."""
+        group = self.process_group
+        if not _active(group):
+            return None, None
+
+        def merge(mean_m2, n):
+            c = mean_m2.numel() // 2
+            local = torch.cat([mean_m2, mean_m2.new_tensor([float(n)])])
+            parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
+            dist.all_gather(parts, local, group=group)
+            allp = torch.stack(parts)
+            cnt = allp[:, -1:]
+            tot = cnt.sum().clamp_min(1.0)
+            mean = (allp[:, :c] * cnt).sum(0) / tot
+            var = (allp[:, c:2 * c] + cnt * (allp[:, :c] - mean) ** 2).sum(0) / tot
+            state["count"] = float(tot)
+            return mean, var, float(tot)
+
+        def reduce(sums):
+            sums = sums.clone()
+            dist.all_reduce(sums, group=group)
+            return sums
+        return merge, reduce
+
     def forward(self, x):
+        if self.training and x.dim() == 2 and torch.is_grad_enabled():
+            from . import ops
+            y = ops.batch_norm_train(self, x) if (x.is_cuda or ops.sim_mode()) else None  # statistics / normalisation / backward on csrc/norm.hip, the same two collectives
+            if y is not None:
+                return y
         if not (self.training and _active(self.process_group)):
             return super().forward(x)
         y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps, self.process_group)

@@ -1271,6 +1271,47 @@ def test_waymo_mseg3d_two_frame_training_step_ddp_syncbn_gpu(prec):
         assert rec[k]["product_free"] <= 1e-2, (k, rec[k])
 
 
+@pytest.mark.parametrize("n,c", [(241737, 128), (241737, 64), (360000, 64), (100001, 32), (33333, 16)])
+def test_batch_norm_train_kernels_gpu(n, c):
+    """ls3d_batch_norm_* at the sizes of the Waymo step (rows = active voxels / points of 2 x 180k-point frames) against float64 nn.BatchNorm1d + residual +
+    ReLU: not further from float64 than torch's own f32 kernels (1.5x; 3x for the two column sums), bit-reproducible, running statistics equal"""
+    torch.manual_seed(c)
+    x = (torch.randn(n, c, device=DEV) * 3 + 2).requires_grad_(True)
+    r = torch.randn(n, c, device=DEV).requires_grad_(True)
+    g = torch.randn(n, c, device=DEV)
+    mods = {}
+    for key, dt in (("f64", torch.float64), ("f32", torch.float32), ("hip", torch.float32)):
+        m = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(DEV).to(dt).train()
+        with torch.no_grad():
+            m.weight.copy_(torch.linspace(0.5, 1.5, c)); m.bias.copy_(torch.linspace(-1, 1, c))
+        mods[key] = m
+    outs = {}
+    for key, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        xx, rr = x.detach().to(dt).requires_grad_(True), r.detach().to(dt).requires_grad_(True)
+        y = torch.relu(mods[key](xx) + rr)
+        y.backward(g.to(dt))
+        outs[key] = (y.detach(), xx.grad, rr.grad, mods[key].weight.grad, mods[key].bias.grad)
+    y = ops.batch_norm_train(mods["hip"], x, res=r, relu=True)
+    y.backward(g)
+    outs["hip"] = (y.detach(), x.grad, r.grad, mods["hip"].weight.grad, mods["hip"].bias.grad)
+    x.grad = r.grad = None
+    mods["hip"].zero_grad(set_to_none=True)
+    y2 = ops.batch_norm_train(mods["hip"], x, res=r, relu=True)
+    y2.backward(g)
+    assert torch.equal(y2, y) and torch.equal(x.grad, outs["hip"][1]) and torch.equal(mods["hip"].weight.grad, outs["hip"][3])
+    rel = lambda a, b: float((a.double() - b).norm() / (b.norm() + 1e-300))
+    for i, what in enumerate(("y", "dx", "dres", "dgamma", "dbeta")):
+        e_hip, e_f32 = rel(outs["hip"][i], outs["f64"][i]), rel(outs["f32"][i], outs["f64"][i])
+        # (6e-8 = half an f32 ulp: both are at the rounding floor; the column sums over 10^5 rows - dgamma, dbeta - are fixed-order f32 sums
+        # of per-block partials: within 3x of torch's, i.e. 2.5e-7 relative measured)
+        assert e_hip <= (3.0 if what in ("dgamma", "dbeta") else 1.5) * e_f32 + 6e-8, (what, e_hip, e_f32)
+    # ("hip" has been updated twice by now: the running statistics are compared on a fresh module)
+    m1 = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(DEV).train()
+    ops.batch_norm_train(m1, x.detach())
+    np.testing.assert_allclose(m1.running_mean.cpu().numpy(), mods["f32"].running_mean.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(m1.running_var.cpu().numpy(), mods["f32"].running_var.cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
 def test_waymo_mseg3d_training_step_at_full_size_properties():
     """BASELINE configs[3] at the size it names - Waymo geometry, 23 classes, 5 cameras at 160 x 240, 2 frames x 180 000 points per GPU
     (semwaymo_avgvfe_unetscn3d_hrnetw18_lr1en2_e12.py:59-60,231), SegMSeg3DNet.train(), return_loss=True, bf16x6 - as properties the size

@@ -48,6 +48,41 @@ def test_voxel_ops_modules_vs_reference_cpp():
     voxel_cases.run("cpu")
 
 
+@pytest.mark.parametrize("n,c,relu,res", [(1500, 64, True, True), (777, 16, True, False), (2100, 128, False, False), (5, 32, True, True), (1030, 32, False, True)])
+def test_batch_norm_train_kernels_vs_torch(n, c, relu, res):
+    """ls3d_batch_norm_* (training-mode BatchNorm1d with the ReLU / residual add fused in, csrc/norm.hip) against nn.BatchNorm1d + add + relu under
+    torch autograd: output, dx, dres, dgamma, dbeta and the running statistics; row counts that are no multiple of the 512-row blocks"""
+    torch.manual_seed(n + c)
+    x = (torch.randn(n, c) * 2 + 1.5).requires_grad_(True)
+    r = torch.randn(n, c).requires_grad_(True) if res else None
+    bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).train()
+    ref.load_state_dict(bn.state_dict())
+    y = ops.batch_norm_train(bn, x, res=r, relu=relu)
+    assert y is not None
+    x2 = x.detach().clone().requires_grad_(True)
+    r2 = r.detach().clone().requires_grad_(True) if res else None
+    z = ref(x2)
+    z = z + r2 if res else z
+    z = torch.relu(z) if relu else z
+    g = torch.randn(n, c)
+    y.backward(g)
+    z.backward(g)
+    np.testing.assert_allclose(y.detach().numpy(), z.detach().numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(x.grad.numpy(), x2.grad.numpy(), rtol=0, atol=2e-6)
+    if res:
+        assert torch.equal(r.grad, r2.grad)
+    for a, b in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) * max(1.0, n ** 0.5 / 8)
+    np.testing.assert_allclose(bn.running_mean.numpy(), ref.running_mean.numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(bn.running_var.numpy(), ref.running_var.numpy(), rtol=1e-6, atol=1e-7)
+    assert int(bn.num_batches_tracked) == 1
+    assert ops.batch_norm_train(bn.eval(), x.detach()) is None  # eval mode: the caller's folded epilogue / torch path
+    assert ops.batch_norm_train(torch.nn.BatchNorm1d(13).train(), torch.randn(40, 13)) is None  # 13 channels: not covered, torch composes it
+
+
 def test_voxelize_empty_and_all_outside():
     cfg = synth.NUSC
     pts = torch.full((10, 5), 1000.0)
