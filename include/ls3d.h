@@ -279,7 +279,8 @@ int ls3d_gather_gemm_pack(const float *w_plain, int kvol, int cin_src, int cin_p
  * row_order (optional, int32[n_rows]): tile slot i processes output row row_order[i] (see ls3d_rulebook_masks).
  * flags (per call; results are identical for every value): bits 0-1 = workgroup -> (tile, column slab) mapping, 0 (default): the
  * slabs of a tile run on one XCD, tiles interleaved over the 8 XCDs; bit 0: each XCD takes a contiguous range of tiles; bit 1:
- * slab-major dispatch (every slab re-gathers its rows from HBM).
+ * slab-major dispatch (every slab re-gathers its rows from HBM); bit 2: sparse BF16X6 layers on the one-stage pipeline of round 3 instead of
+ * the one that gathers two stages ahead (k_gather_gemm_x6, csrc/spconv.hip; kvol <= 27).
  * One kernel serves SubMConv3d (tbl = subm nbr), SparseConv3d (tbl = nbr_out), SparseInverseConv3d
  * (tbl = nbr_inv) and every nn.Linear on the path. */
 int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32_t *row_order, int kvol, const float *w, int nt, int wc,

@@ -461,6 +461,182 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same 6-product operator for the sparse layers (strided / inverse convolutions of the 3-plane modes), pipelined TWO stages deep.
+// k_gather_gemm_bf16x3 issues the gathered rows and the weight chunk of stage i + 1 at the top of stage i and needs both at its end:
+// a stage's MFMAs (12 - 24 x 32 cycles) are a fraction of an L2 gather round trip, so every stage of the seven layers waited
+// for memory (tools/asm_waits.py: vmcnt(0) in front of every step barrier; conv2.0 of the 120k frame: 27 stages x 2.2 us per tile).
+// Here the gathered rows of stage i + 2 are issued while stage i multiplies (three row sets in registers); the weight chunk of stage i + 1 -
+// a contiguous L2-resident read - is issued in FRONT of them and goes to the other LDS buffer behind stage i.  The neighbour indices of the tile (27 x 128 ints) are read once into LDS - the prologue needs them
+// all for the offset masks anyway - so a stage's row addresses cost one LDS read instead of an index load two offsets ahead.
+// Same arithmetic, same summation order as k_gather_gemm_bf16x3<NT, true, 3>: bit-identical results.
+template <int NT>
+__global__ __launch_bounds__(256, (NT == 1 ? 4 : NT == 2 ? 3 : 2)) void k_gather_gemm_x6(const float *__restrict__ in, int in_ld, const int32_t *__restrict__ tbl,
+                                                           const int32_t *__restrict__ order, int kvol, const float *__restrict__ w,
+                                                           int cin, int w_ld, int cout, int n_rows, const int32_t *n_rows_dev, EpiDev e,
+                                                           float *__restrict__ out, int out_ld, int xcd_map) {
+  constexpr int KC = 32, TR = 128, SLAB = NT * 32, PL = 3;
+  constexpr int BV = NT * 2 * PL * 64;   // 16-byte units in one weight chunk: [n][t][plane][kk][col] x (8 bf16)
+  constexpr int BPT = (BV + 255) / 256;  // units staged per thread
+  constexpr int CHF = BV * 4;            // floats per chunk
+  __shared__ __attribute__((aligned(16))) float Bs[2][CHF];
+  __shared__ int s_idx[27][TR];          // neighbour row of (kernel offset, tile slot), -1 = none (kvol <= 27: 3 x 3 x 3 kernels)
+  __shared__ unsigned long long s_kmask;
+  __shared__ int s_rows[TR];
+  __shared__ float s_stat[2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kk = lane >> 5;
+  const int N = ls3d_count(n_rows, n_rows_dev);
+  const int ntiles = (N + TR - 1) / TR;
+  const int nslab = w_ld / SLAB;
+  const int nchunk = cin / KC;
+  const int tiles_per_xcd = (ntiles + 7) / 8;
+  for (int b = blockIdx.x; b < tiles_per_xcd * 8 * nslab; b += gridDim.x) {
+    int tile, slab;
+    if (xcd_map & 2) {
+      tile = b % (tiles_per_xcd * 8); slab = b / (tiles_per_xcd * 8);
+    } else {
+      const int xcd = b & 7, j = b >> 3;
+      slab = j % nslab;
+      tile = (xcd_map & 1) ? xcd * tiles_per_xcd + j / nslab : (j / nslab) * 8 + xcd;
+    }
+    if (tile >= ntiles) continue;
+    const int n0 = slab * SLAB;
+    const float *wbase = w + (size_t)slab * nchunk * CHF;  // packed: [kvol][slab][cin/32][chunk]
+    __syncthreads();  // the previous tile's epilogue is done with s_rows / Bs
+    if (tid == 0) s_kmask = 0ull;
+    if (tid < TR) {
+      const int r = tile * TR + tid;
+      s_rows[tid] = r < N ? (order ? order[r] : r) : -1;
+    }
+    __syncthreads();
+    {  // the tile's table rows -> LDS: two threads per slot, every other offset each
+      const int slot = tid & (TR - 1), part = tid >> 7;
+      const int row = s_rows[slot];
+      const int32_t *trow = tbl + (size_t)(row >= 0 ? row : 0) * kvol;
+      for (int k = part; k < kvol; k += 2) s_idx[k][slot] = row >= 0 ? trow[k] : -1;
+    }
+    __syncthreads();
+    unsigned long long wmask = 0ull;
+    for (int k = 0; k < kvol; ++k)
+      if (__any(s_idx[k][wave * 32 + col] >= 0)) wmask |= 1ull << k;
+    if (lane == 0 && wmask) atomicOr(&s_kmask, wmask);
+    __syncthreads();
+    unsigned long long rem = s_kmask;
+    f32x16 acc[NT], acs[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[n][r] = 0.0f; acs[n][r] = 0.0f; }
+    if (rem) {
+      // stage = (kernel offset k, 32-channel chunk c0); k = -1: past the end.  The sequence is the same for the four waves (the weights are shared).
+      int k0, c00 = 0, k1, c01, k2, c02;
+#define GX_POP(k_) { k_ = rem ? __ffsll((long long)rem) - 1 : -1; rem &= rem - 1; }
+#define GX_NEXT(kn_, cn_, k_, c_) { kn_ = k_; cn_ = c_ + KC; if (cn_ >= cin) { cn_ = 0; GX_POP(kn_) } }
+      // rows of stage (k_, c_): unconditional loads; an absent neighbour (or a stage past the end) reads valid bytes of the weights and is
+      // zeroed when the registers are split
+#define GX_LOAD_A(dst_, ok_, k_, c_)                                                              \
+  {                                                                                               \
+    const int idx_ = (k_) >= 0 ? s_idx[(k_)][wave * 32 + col] : -1;                               \
+    ok_ = idx_ >= 0;                                                                              \
+    const float4 *p_ = ok_ ? (const float4 *)(in + (size_t)idx_ * in_ld + (c_) + kk * 16) : (const float4 *)wbase; \
+    dst_##_0 = p_[0]; dst_##_1 = p_[1]; dst_##_2 = p_[2]; dst_##_3 = p_[3];                       \
+  }
+// (weight staging registers are named members, not an array: an array inside the pipelined loop ends up in scratch)
+#define GX_B_ONE(j_, OP_) if constexpr (BPT > (j_)) { const int i_ = tid + (j_) * 256; OP_ }
+#define GX_LOAD_B(dst_, k_, c_)                                                                   \
+  {                                                                                               \
+    const float *wk_ = wbase + ((size_t)((k_) >= 0 ? (k_) : 0) * nslab * nchunk + (c_) / KC) * CHF; \
+    GX_B_ONE(0, dst_##_0 = *(const float4 *)(wk_ + (size_t)((BV % 256 == 0 || i_ < BV) ? i_ : BV - 1) * 4);) \
+    GX_B_ONE(1, dst_##_1 = *(const float4 *)(wk_ + (size_t)((BV % 256 == 0 || i_ < BV) ? i_ : BV - 1) * 4);) \
+    GX_B_ONE(2, dst_##_2 = *(const float4 *)(wk_ + (size_t)((BV % 256 == 0 || i_ < BV) ? i_ : BV - 1) * 4);) \
+    GX_B_ONE(3, dst_##_3 = *(const float4 *)(wk_ + (size_t)((BV % 256 == 0 || i_ < BV) ? i_ : BV - 1) * 4);) \
+    GX_B_ONE(4, dst_##_4 = *(const float4 *)(wk_ + (size_t)((BV % 256 == 0 || i_ < BV) ? i_ : BV - 1) * 4);) \
+    GX_B_ONE(5, dst_##_5 = *(const float4 *)(wk_ + (size_t)((BV % 256 == 0 || i_ < BV) ? i_ : BV - 1) * 4);) \
+  }
+#define GX_STORE_B(buf_, src_)                                                                    \
+  {                                                                                               \
+    GX_B_ONE(0, if (BV % 256 == 0 || i_ < BV) *(float4 *)(Bs[buf_] + i_ * 4) = src_##_0;)          \
+    GX_B_ONE(1, if (BV % 256 == 0 || i_ < BV) *(float4 *)(Bs[buf_] + i_ * 4) = src_##_1;)          \
+    GX_B_ONE(2, if (BV % 256 == 0 || i_ < BV) *(float4 *)(Bs[buf_] + i_ * 4) = src_##_2;)          \
+    GX_B_ONE(3, if (BV % 256 == 0 || i_ < BV) *(float4 *)(Bs[buf_] + i_ * 4) = src_##_3;)          \
+    GX_B_ONE(4, if (BV % 256 == 0 || i_ < BV) *(float4 *)(Bs[buf_] + i_ * 4) = src_##_4;)          \
+    GX_B_ONE(5, if (BV % 256 == 0 || i_ < BV) *(float4 *)(Bs[buf_] + i_ * 4) = src_##_5;)          \
+  }
+      GX_POP(k0)
+      GX_NEXT(k1, c01, k0, c00)
+      float4 a0_0, a0_1, a0_2, a0_3, a1_0, a1_1, a1_2, a1_3, a2_0, a2_1, a2_2, a2_3;  // three row sets (named: arrays / structs land in scratch here)
+      bool ok0, ok1, ok2;
+      float4 b1_0, b1_1, b1_2, b1_3, b1_4, b1_5;  // the next stage's weight chunk (named registers)
+      static_assert(BPT <= 6, "weight chunk too large for the staging registers");
+      GX_LOAD_A(a0, ok0, k0, c00)
+      GX_LOAD_B(b1, k0, c00)
+      GX_STORE_B(0, b1)
+      GX_LOAD_A(a1, ok1, k1, c01)
+      __syncthreads();
+      int buf = 0;
+      for (;;) {
+        GX_NEXT(k2, c02, k1, c01)
+        if (k1 < 0) { k2 = -1; c02 = 0; }
+        // the weight chunk of stage i + 1 first (contiguous, L2-resident: one stage of flight is enough and it is waited for at the end of this
+        // stage), the gathered rows of stage i + 2 behind it (they stay in flight across that wait: vmcnt counts in order)
+        GX_LOAD_B(b1, k1, c01)
+        GX_LOAD_A(a2, ok2, k2, c02)
+        if ((wmask >> k0) & 1ull) {
+          const uint4 *bs = (const uint4 *)Bs[buf] + kk * 32 + col;  // unit index (((n*2+t)*PL+plane)*2+kk)*32+col
+          uint4 x0[3], x1[3];  // [plane]: head / middle / tail, round-to-nearest planes
+          const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 r0 = ok0 ? a0_0 : z, r1 = ok0 ? a0_1 : z, r2 = ok0 ? a0_2 : z, r3 = ok0 ? a0_3 : z;
+          ls3d_split_pair3_rne(r0.x, r0.y, x0[0].x, x0[1].x, x0[2].x);
+          ls3d_split_pair3_rne(r0.z, r0.w, x0[0].y, x0[1].y, x0[2].y);
+          ls3d_split_pair3_rne(r1.x, r1.y, x0[0].z, x0[1].z, x0[2].z);
+          ls3d_split_pair3_rne(r1.z, r1.w, x0[0].w, x0[1].w, x0[2].w);
+          ls3d_split_pair3_rne(r2.x, r2.y, x1[0].x, x1[1].x, x1[2].x);
+          ls3d_split_pair3_rne(r2.z, r2.w, x1[0].y, x1[1].y, x1[2].y);
+          ls3d_split_pair3_rne(r3.x, r3.y, x1[0].z, x1[1].z, x1[2].z);
+          ls3d_split_pair3_rne(r3.z, r3.w, x1[0].w, x1[1].w, x1[2].w);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, t ? x1[0] : x0[0]), am = __builtin_bit_cast(bf16x8, t ? x1[1] : x0[1]);
+              const bf16x8 al = __builtin_bit_cast(bf16x8, t ? x1[2] : x0[2]);
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, bs[((n * 2 + t) * 3 + 0) * 64]);
+              const bf16x8 bm = __builtin_bit_cast(bf16x8, bs[((n * 2 + t) * 3 + 1) * 64]);
+              const bf16x8 bl = __builtin_bit_cast(bf16x8, bs[((n * 2 + t) * 3 + 2) * 64]);
+              // the six products of weight >= 2^-16, smallest first (the order of k_gather_gemm_bf16x3)
+              acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acs[n], 0, 0, 0);
+              acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acs[n], 0, 0, 0);
+              acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acs[n], 0, 0, 0);
+              acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acs[n], 0, 0, 0);
+              acs[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acs[n], 0, 0, 0);
+              acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+            }
+          }
+        }
+        if (k1 < 0) break;
+        GX_STORE_B(buf ^ 1, b1)
+        __syncthreads();
+        buf ^= 1;
+        a0_0 = a1_0; a0_1 = a1_1; a0_2 = a1_2; a0_3 = a1_3; ok0 = ok1;
+        a1_0 = a2_0; a1_1 = a2_1; a1_2 = a2_2; a1_3 = a2_3; ok1 = ok2;
+        k0 = k1; c00 = c01; k1 = k2; c01 = c02;
+      }
+#undef GX_POP
+#undef GX_NEXT
+#undef GX_LOAD_A
+#undef GX_LOAD_B
+#undef GX_STORE_B
+#undef GX_B_ONE
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] += acs[n][r];
+    gg_epilogue<NT, 1, TR, 64>(acc, &Bs[0][0], s_rows, s_stat, wave, 0, kk, col, n0, cout, e, out, out_ld);
+  }
+}
+
 // plain [kvol][cin_src][cout] -> split-bf16 packed [kvol][slab][cin_pad/32][n][t][hi/lo][kk][col] x 8 bf16
 __global__ __launch_bounds__(256) void k_gg_pack_bf16x3(const float *src, int kvol, int cin_src, int cin_pad, int cout, int nt, int pl, uint4 *dst) {
   const int slab = nt * 32, nslab = ((cout + 31) / 32) / nt, nchunk = cin_pad / 32;
@@ -617,6 +793,15 @@ extern "C" int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, 
         case 3: LS3D_GG3(3, 2); break;
         default: LS3D_GG3(4, 2);
       }
+    } else if (tbl && kvol <= 27 && nt != 3 && !(flags & 4)) {
+      // sparse layers of the 3-plane modes: the two-stages-deep pipeline (flags bit 2: the one-stage kernel, for A/B runs; bit-identical)
+#define LS3D_GX6(NT_) hipLaunchKernelGGL((k_gather_gemm_x6<NT_>), grid, dim3(256), 0, stream, in, in_ld, tbl, row_order, kvol, w, cin, w_ld, cout, n_rows, n_rows_dev, e, out, out_ld, xcd_map)
+      switch (nt) {
+        case 1: LS3D_GX6(1); break;
+        case 2: LS3D_GX6(2); break;
+        default: LS3D_GX6(4);
+      }
+#undef LS3D_GX6
     } else {
       switch (nt) {
         case 1: LS3D_GG3(1, 3); break;

@@ -60,17 +60,28 @@ constexpr int TV_BCHUNK = 32 * 64;       // floats in one staged weight chunk
 // lane) is split in registers, 6 / 8 v_mfma_f32_32x32x16_bf16 per (column block, K step) with head x head in its own accumulator:
 // 24 / 32 MFMAs of 32 cycles per chunk instead of 32 of 64.
 constexpr int TV_PCHUNK = 768;  // uint4 per plane-packed chunk
+// one 12 KB plane-packed weight chunk in flight (3 x 16 bytes per thread).  MODE 6 / 8: a chunk's MFMAs (24 / 32 x 32 cycles) are shorter than
+// an L2 round trip, so chunk c + 2 is fetched while chunk c multiplies, and the first chunk of the NEXT matrix while this GEMM's last chunk
+// and the attention / LayerNorm behind it run (`pre`: in = chunk 0 of this matrix, out = chunk 0 of `next`; the weights do not depend on the data).
+struct TvPre { uint4 a, b, c; };
+__device__ __forceinline__ TvPre tv_fetch(const uint4 *__restrict__ chunk) {
+  const int tid = threadIdx.x;
+  TvPre p;
+  p.a = chunk[tid]; p.b = chunk[tid + 256]; p.c = chunk[tid + 512];
+  return p;
+}
 template <int MODE, typename Epi>
-__device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, const float *__restrict__ Wp, float *Bs, Epi epi) {
+__device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, const float *__restrict__ Wp, float *Bs, Epi epi, TvPre &pre,
+                                        const float *__restrict__ next) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int col = lane & 31, kk = lane >> 5;
   const int nslab = N / 64, nkc = K / 32, nchunks = nslab * nkc;
   if constexpr (MODE >= 6) {
-    const uint4 *Wq = (const uint4 *)Wp;
+    const uint4 *Wq = (const uint4 *)Wp, *Wn = next ? (const uint4 *)next : (const uint4 *)Wp;
     uint4 *Bq = (uint4 *)Bs;
-    uint4 r0 = Wq[tid], r1 = Wq[tid + 256], r2 = Wq[tid + 512];
     __syncthreads();  // previous users of Bs are done
-    Bq[tid] = r0; Bq[tid + 256] = r1; Bq[tid + 512] = r2;
+    Bq[tid] = pre.a; Bq[tid + 256] = pre.b; Bq[tid + 512] = pre.c;
+    TvPre p1 = tv_fetch(nchunks > 1 ? Wq + TV_PCHUNK : Wn);
     __syncthreads();
     tv_f32x16 acc0, acc1, acs0, acs1;
     int buf = 0;
@@ -80,10 +91,8 @@ __device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; acs0[r] = 0.0f; acs1[r] = 0.0f; }
       }
-      if (c + 1 < nchunks) {
-        const uint4 *src = Wq + (size_t)(c + 1) * TV_PCHUNK;
-        r0 = src[tid]; r1 = src[tid + 256]; r2 = src[tid + 512];
-      }
+      TvPre p2 = p1;
+      if (c + 2 <= nchunks) p2 = tv_fetch(c + 2 < nchunks ? Wq + (size_t)(c + 2) * TV_PCHUNK : Wn);
       {
         const float4 *ap = (const float4 *)(A + col * lda + kc * 32 + kk * 16);
         const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
@@ -127,11 +136,13 @@ __device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, c
       }
       if (c + 1 < nchunks) {
         uint4 *dst = Bq + (buf ^ 1) * TV_PCHUNK;
-        dst[tid] = r0; dst[tid + 256] = r1; dst[tid + 512] = r2;
+        dst[tid] = p1.a; dst[tid + 256] = p1.b; dst[tid + 512] = p1.c;
         __syncthreads();
         buf ^= 1;
       }
+      p1 = p2;
     }
+    pre = p1;  // chunk 0 of `next`
     return;
   }
   if constexpr (MODE == 1) {
@@ -307,6 +318,8 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       }
     }
     TV_WAVE_SYNC();
+    TvPre pre;  // the weight chunk in flight across the GEMMs of the tile (plane modes)
+    if constexpr (MODE >= 6) pre = tv_fetch((const uint4 *)prm.we);
     // ---- embedding (+ norm1 of layer 0)
     tv_gemm<MODE>(T, TV_TS, TV_KT, TV_E, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
       const float b0 = prm.be[col], b1 = prm.be[32 + col];
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
         X[row * TV_XS + col] = a0[r] + b0;
         X[row * TV_XS + 32 + col] = a1[r] + b1;
       }
-    });
+    }, pre, (prm.num_layers > 0 ? prm.layer[0].wqkv : nullptr));
     TV_WAVE_SYNC();
     if (prm.num_layers > 0) tv_layernorm(X, prm.layer[0].n1g, prm.layer[0].n1b, prm.layer[0].n1eps);
     TV_WAVE_SYNC();
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
           T[row * TV_TS + slab * 64 + col] = a0[r] + b0;
           T[row * TV_TS + slab * 64 + 32 + col] = a1[r] + b1;
         }
-      });
+      }, pre, L.wo);
       TV_WAVE_SYNC();
       // ---- attention inside each voxel: one lane per (voxel g, head h, query token t); output over the query's slice
       {
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
           X[row * TV_XS + 32 + col] = a1[r] + b1 + X[row * TV_XS + 32 + col];
         }
-      });
+      }, pre, L.w1);
       TV_WAVE_SYNC();
       tv_layernorm(X, L.n2g, L.n2b, L.n2eps);
       TV_WAVE_SYNC();
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
           T[row * TV_TS + slab * 64 + col] = fmaxf(a0[r] + b0, 0.0f);
           T[row * TV_TS + slab * 64 + 32 + col] = fmaxf(a1[r] + b1, 0.0f);
         }
-      });
+      }, pre, L.w2);
       TV_WAVE_SYNC();
       // ---- FF2 + residual -> X, then norm1 of the next layer
       tv_gemm<MODE>(T, TV_TS, TV_FF, TV_E, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
@@ -398,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
           X[row * TV_XS + 32 + col] = a1[r] + b1 + X[row * TV_XS + 32 + col];
         }
-      });
+      }, pre, (l + 1 < prm.num_layers ? prm.layer[l + 1].wqkv : nullptr));
       TV_WAVE_SYNC();
       if (l + 1 < prm.num_layers) {
         tv_layernorm(X, prm.layer[l + 1].n1g, prm.layer[l + 1].n1b, prm.layer[l + 1].n1eps);

@@ -462,7 +462,8 @@ def rulebook_orders(tbls, n_devs=None):
 
 _TRANSVFE_DIRECT = _os.environ.get("LS3D_TRANSVFE_DIRECT", "0") != "0"
 _TRANSVFE_DEDUP = _os.environ.get("LS3D_TRANSVFE_DEDUP", "1") != "0"  # identical padding tokens of a voxel computed once (ls3d_transvfe)
-_GEMM_FLAGS = int(_os.environ.get("LS3D_XCD_MAP", "0")) & 3  # per-call flags of ls3d_gather_gemm (workgroup -> tile mapping, A/B)
+# per-call flags of ls3d_gather_gemm (include/ls3d.h): bits 0-1 workgroup -> tile mapping, bit 2 the one-stage pipeline of the sparse 6-product kernel (A/B)
+_GEMM_FLAGS = (int(_os.environ.get("LS3D_XCD_MAP", "0")) & 3) | (int(_os.environ.get("LS3D_GEMM_FLAGS", "0"), 0) & 4)
 
 
 def set_transvfe_direct(on):
@@ -479,9 +480,10 @@ def set_transvfe_dedup(on):
 
 
 def set_gemm_flags(flags):
-    """per-call flags of ls3d_gather_gemm (include/ls3d.h): workgroup -> (tile, slab) mapping for A/B runs; results identical"""
+    """per-call flags of ls3d_gather_gemm (include/ls3d.h): workgroup -> (tile, slab) mapping (bits 0-1), one-stage pipeline of the sparse
+    6-product kernel (bit 2) for A/B runs; results identical"""
     global _GEMM_FLAGS
-    _GEMM_FLAGS = int(flags) & 3
+    _GEMM_FLAGS = int(flags) & 7
 
 
 def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None,

@@ -42,6 +42,39 @@ def test_voxelize_bit_exact_vs_reference(tag):
     assert np.array_equal(ops.voxelize_dynamic(pts, g["voxel_size"], g["pc_range"]).numpy(), g["cpp_dyn_coors"])
 
 
+@pytest.mark.parametrize("n_in,n_out,cin,cout,dens", [(500, 700, 32, 64, 0.06), (300, 333, 64, 32, 0.12), (400, 260, 128, 128, 0.35), (600, 601, 64, 128, 0.2)])
+def test_sparse_six_product_gather_pipelines_are_bit_identical(n_in, n_out, cin, cout, dens):
+    """k_gather_gemm_x6 (strided / inverse layers of the 3-plane modes: rows gathered two stages ahead, neighbour indices of the tile in LDS)
+    against the one-stage kernel it replaces (flags bit 2 of ls3d_gather_gemm): the same products in the same order - bit-identical, with
+    the fused epilogue, mask-sorted rows and tables as sparse as a stride-2 layer's (1.6 pairs per row)"""
+    from lidarseg3d_amd.packing import PackedWeight
+    rng = np.random.default_rng(n_in + cout)
+    tbl = rng.integers(0, n_in, size=(n_out, 27)).astype(np.int32)
+    tbl[rng.uniform(size=tbl.shape) > dens] = -1
+    tbl[5] = -1  # a row without neighbours
+    x = torch.from_numpy(rng.normal(size=(n_in, cin)).astype(np.float32))
+    w = torch.from_numpy((rng.normal(size=(27, cin, cout)) * 0.1).astype(np.float32))
+    pw, t = PackedWeight(w, 27, cin, cin, cout), torch.from_numpy(tbl)
+    sc, sh = torch.rand(cout) + 0.5, torch.randn(cout)
+    outs = {}
+    try:
+        ops.set_precision("bf16x6")
+        for order in (ops.rulebook_order(t), None):
+            for fl in (0, 4):
+                ops.set_gemm_flags(fl)
+                outs[fl] = ops.gather_gemm(x, pw, tbl=t, order=order, cout=cout, scale=sc, shift=sh, relu=True)
+            assert torch.equal(outs[0], outs[4])
+    finally:
+        ops.set_gemm_flags(0)
+        ops.set_precision("f32")
+    ref = torch.zeros(n_out, cout, dtype=torch.float64)
+    for k in range(27):
+        o = np.nonzero(tbl[:, k] >= 0)[0]
+        ref[o] += x[tbl[o, k]].double() @ w[k].double()
+    ref = torch.relu(ref * sc.double() + sh.double())
+    assert float((outs[0].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
 def test_voxel_ops_modules_vs_reference_cpp():
     """Voxelization (hard and max_num_points = -1), HardSimpleVFE, DynamicSimpleVFE, DynamicScatterWithDistance: tests/voxel_cases.py"""
     from tests import voxel_cases

@@ -10,7 +10,8 @@ import json,sys
 try:
     j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r=j.get("roofline",{}).get("sparse_conv_ms_per_frame",{})
-    print("%-22s value %.1f f/s  graph %.3f ms  eager %.3f ms  stack %.3f ms  bit-identical %s" % (sys.argv[2], j["value"], j["ms_per_step"], j.get("eager_mode",{}).get("ms_per_step",0), r.get("mean",0), j.get("graph_mode",{}).get("logits_bit_identical_to_eager")))
+    sr=j.get("stage_rooflines",{})
+    print("%-22s value %.1f f/s  graph %.3f ms  eager %.3f ms  stack %.3f ms  reader %.3f  decoder %.3f  bit-identical %s" % (sys.argv[2], j["value"], j["ms_per_step"], j.get("eager_mode",{}).get("ms_per_step",0), r.get("mean",0), sr.get("reader",{}).get("ms",0), sr.get("sffm_decoder",{}).get("ms",0), j.get("graph_mode",{}).get("logits_bit_identical_to_eager")))
 except Exception as e:
     print(sys.argv[2], "failed", e)
 PY
