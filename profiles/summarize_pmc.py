@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Turn the rocprofv3 counter passes of tests/run_gpu_checks.sh (PMC=1) into profiles/round<N>_pmc.{md,json} and round<N>_pmc_sq.md.
 
-  python profiles/summarize_pmc.py gpurun_out [N=3] [commit]
+  python profiles/summarize_pmc.py gpurun_out [N=4] [commit]
 
 HBM-side bytes per kernel = 2 x FETCH_SIZE + WRITE_SIZE (KiB), the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md
 (FETCH_SIZE reports half of the bytes of wide coalesced reads); the counters sit on the L2 -> fabric side, Infinity-Cache hits are
-included: an upper bound of DRAM traffic.  Sparse-conv kernels = k_tile_conv<*>, k_gather_gemm<*, true> and k_gather_gemm_bf16x3<*, true, *> (the table-driven
+included: an upper bound of DRAM traffic.  Sparse-conv kernels = k_tile_conv<*>, k_gather_gemm_x6<*>, k_gather_gemm<*, true> and k_gather_gemm_bf16x3<*, true, *> (the table-driven
 launches); bytes per launch = their summed bytes / their launch count, per precision mode of `bench.py --precision P`."""
 import json
 import os
@@ -13,7 +13,7 @@ import sys
 
 import pandas as pd
 
-SPARSE = r"k_tile_conv<|k_gather_gemm(_bf16x3)?<.*true"
+SPARSE = r"k_tile_conv<|k_gather_gemm_x6<|k_gather_gemm(_bf16x3)?<.*true"
 
 
 def load(d, sub, counter):
@@ -23,7 +23,7 @@ def load(d, sub, counter):
     return df
 
 
-def main(d, rnd="3", commit=""):
+def main(d, rnd="4", commit=""):
     here = os.environ.get("LS3D_PROFILE_OUT") or os.path.dirname(os.path.abspath(__file__))  # on the GPU box: a directory under gpurun_out/
     os.makedirs(here, exist_ok=True)
     out, lines = {}, ["# HBM-side traffic of the sparse-conv launches (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes)", "",
@@ -54,7 +54,7 @@ def main(d, rnd="3", commit=""):
           "SIMD cycles available = kernel time x clock (GRBM_GUI_ACTIVE / 8 XCDs / time) x 1024 SIMDs.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count",
           "quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts cycles (MI355X_MICROARCH.md).", "",
           "| precision | kernel | launches | total ms | clock GHz | MFMA busy / SIMD cycles | waves/SIMD resident | WAIT_ANY | WAIT_INST_ANY | ACTIVE |", "|---|---|---|---|---|---|---|---|---|---|"]
-    for prec in ("bf16x6", "bf16x8", "f32"):
+    for prec in ("bf16x6", "bf16x8", "f32", "mseg3d"):  # "mseg3d": the SQ pass of `bench.py --model mseg3d` (k_sffm_decoder_rt, k_sffm_memory)
         try:
             sub = "pmc_SQ_" + prec
             df = pd.read_csv(os.path.join(d, sub, "bench_counter_collection.csv"))
@@ -88,4 +88,4 @@ def main(d, rnd="3", commit=""):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "3", sys.argv[3] if len(sys.argv) > 3 else "")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "4", sys.argv[3] if len(sys.argv) > 3 else "")
