@@ -523,7 +523,7 @@ int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *points, int 
  * frame the L <= 64 memory tokens [L][96] go through num_layers x { self-attention (4 heads) + residual + norm1 } and every layer's cross-attention
  * k_proj / v_proj (Conv1d, k = 1) is written as kv[2 l + {0: k, 1: v}][batch][96][L] - the `kv` input of ls3d_sffm_decoder.  Weights are the
  * modules' own matrices TRANSPOSED to [in][out] row-major f32 (in_proj_weight^T [96][288], out_proj.weight^T, k_proj / v_proj weight^T [96][96]).
- * Plain f32 fma contractions in ascending k.  mem_out (optional): the memory after the last layer, [batch * L][96].  Other shapes
+ * GEMMs on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), one 16-wave workgroup per frame.  mem_out (optional): the memory after the last layer, [batch * L][96].  Other shapes
  * (embed != 96, heads != 4, L > 64, > 8 layers): LS3D_ERR_UNSUPPORTED, the caller composes it from ls3d_gather_gemm / ls3d_mha_core. */
 typedef struct {
   const float *wqkv_t, *bqkv, *wo_t, *bo, *n1_gamma, *n1_beta, *wk_t, *bk, *wv_t, *bv;
