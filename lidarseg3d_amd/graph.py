@@ -15,7 +15,9 @@ Correctness contract: a replay runs exactly the launches of the eager capacity-m
 strided rulebooks are the ones learned from the warm-up frames (1.3x the largest count seen); every replay copies the frame's counts and
 overflow flags to pinned host memory, and __call__ checks them after the frame: an overflowing frame is computed again by the eager
 path (host-side counts, always correct) and the graph is captured again with the new capacities.  Inputs of another shape than the
-captured one go to the eager path as well (a graph is a fixed-shape object: one FrameGraph per point-count bucket).
+captured one go to the eager path as well (a graph is a fixed-shape object: one FrameGraph per point-count bucket).  A batch of several
+frames (round 4) is captured up to the labels of all points; the split into per-frame results - boolean masks, i.e. host synchronisations - runs
+after the replay.
 
 Several frames in flight: one FrameGraph per frame slot, each captured on its OWN stream (`stream=`: the arrival counters of the tile
 kernel's channel split are per stream, the pinned count buffer is per capture), then per slot `with torch.cuda.stream(s): fg.launch(ex)`
@@ -29,12 +31,17 @@ class FrameGraph(object):
     def __init__(self, model, example, warmup=3, stream=None):
         if model.training:
             raise ValueError("FrameGraph is an inference path: model.eval() first")
-        if int(example.get("batch_size", 1)) != 1:
-            raise ValueError("FrameGraph captures single-frame batches (predict() splits larger batches with synchronising boolean masks)")
+        if (getattr(model, "test_cfg", None) or {}).get("tta_flag", False) and int(example.get("batch_size", 1)) != 1:
+            raise ValueError("FrameGraph does not capture test-time-augmentation batches (their merge is per group of frames)")
         if not detectors.CAPACITY_MODE:
             raise ValueError("FrameGraph needs capacity mode (LS3D_CAPACITY_MODE=0 is set)")
         self.model, self.warmup, self.stream = model, int(warmup), stream
+        self.batch_size = int(example.get("batch_size", 1))
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example.items()}
+        if self.batch_size > 1:
+            # predict() splits a batch into frames with boolean masks (a host synchronisation each): the captured forward ends at the labels
+            # of all points, _after_replay() splits them by the batch column of the replayed example
+            self.static["_unsplit_predict"] = True
         self.shapes = {k: (tuple(v.shape), v.dtype) for k, v in example.items() if torch.is_tensor(v)}
         self.graph, self.ret, self.record, self.recaptures, self.fallbacks = None, None, None, 0, 0
         self._capture()
@@ -63,7 +70,7 @@ class FrameGraph(object):
 
     def matches(self, example):
         return all(k in example and torch.is_tensor(example[k]) and tuple(example[k].shape) == s and example[k].dtype == d
-                   for k, (s, d) in self.shapes.items()) and int(example.get("batch_size", 1)) == 1
+                   for k, (s, d) in self.shapes.items()) and int(example.get("batch_size", 1)) == self.batch_size
 
     def launch(self, example):
         """copy the inputs and replay on the CURRENT stream, without waiting (the example must match the captured shapes); finish() next"""
@@ -102,8 +109,23 @@ class FrameGraph(object):
             return out
         # the captured dicts hold the FIRST frame's non-tensor fields: every replay hands out the current frame's `metadata` (the reference keys
         # its saved predictions by output['metadata']['token'], tools/dist_test.py:212)
+        if self.batch_size > 1:
+            return self._split_frames(example)
         meta = example.get("metadata") or [None] * len(self.ret)
         out = self.ret if not clone else [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()} for r in self.ret]
         for i, r in enumerate(out):
             r["metadata"] = meta[i] if i < len(meta) else None
+        return out
+
+    def _split_frames(self, example):
+        """the list predict() returns for a batch (point_seg_batchloss_head.py:255-270): labels of frame i = the rows with batch index i"""
+        labels, b = self.ret[0]["pred_point_sem_labels"], example["points"][:, 0]
+        meta = example.get("metadata") or [None] * self.batch_size
+        out = []
+        for i in range(self.batch_size):
+            m = b == i
+            r = dict(metadata=meta[i] if i < len(meta) else None, pred_point_sem_labels=labels[m])
+            if "point_sem_labels" in example:
+                r["point_sem_labels"] = example["point_sem_labels"][m]
+            out.append(r)
         return out

@@ -112,6 +112,8 @@ def _predict(head, example, test_cfg):
             ret_list.append(ret)
         return ret_list
     labels = torch.argmax(logits, dim=1)
+    if example.get("_unsplit_predict"):  # graph.FrameGraph with several frames: the split by frame (host-synchronising masks) follows the replay
+        return [dict(metadata=None, pred_point_sem_labels=labels)]
     if batch_size == 1:  # one frame: no masking (boolean-mask indexing would force a host sync)
         ret = dict(metadata=meta[0], pred_point_sem_labels=labels)
         if "point_sem_labels" in example:

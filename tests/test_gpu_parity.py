@@ -470,6 +470,45 @@ def test_frame_graph_equals_eager_forward_120k(kind):
         ops.set_precision("f32")
 
 
+@pytest.mark.parametrize("kind", ["sdseg3d", "mseg3d"])
+def test_frame_graph_of_a_batch_of_frames_equals_eager_forward(kind):
+    """graph.FrameGraph over a collated batch (round 4; the reference tests with samples_per_gpu frames per forward, tools/dist_test.py:99-171): the
+    captured forward ends at the labels of all points, the per-frame split of predict() (boolean masks) runs after the replay.  Bit-identical
+    to the eager forward, also for a batch of the same total shape whose frames have OTHER sizes (the split follows the replayed example)"""
+    from lidarseg3d_amd import graph
+    cfg = synth.NUSC
+    model, _ = _model(getattr(models_cfg, kind)())
+    ops.set_precision("bf16x6")
+    try:
+        def example(sizes, seed):
+            rows = [np.concatenate([np.full((n, 1), i, np.float32), synth.lidar_frame(n, seed=seed + i, **cfg)], 1) for i, n in enumerate(sizes)]
+            ex = dict(points=cu(np.concatenate(rows, 0)), batch_size=len(sizes), metadata=[dict(token="f%d-%d" % (seed, i)) for i in range(len(sizes))])
+            if kind == "mseg3d":
+                img, emb, cuv = synth.camera_inputs(sum(sizes), seed=seed, ncam=6, c_img=48, h=40, w=60, batch=len(sizes))
+                ex.update(points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
+            return ex
+
+        def eager(ex):
+            with torch.no_grad():
+                ret = model(dict(ex), return_loss=False)
+            return model.point_head.forward_ret_dict["out_logits"].clone(), [r["pred_point_sem_labels"].clone() for r in ret]
+
+        exs = [example((60000, 45000), 21), example((45000, 60000), 31), example((60000, 45000), 41)]
+        want = [eager(e) for e in exs]
+        fg = graph.FrameGraph(model, exs[0])
+        for e, (wl, wp) in zip(exs + exs[:1], want + want[:1]):
+            ret = fg(e)
+            assert len(ret) == 2 and torch.equal(fg.logits, wl)
+            for i in range(2):
+                assert torch.equal(ret[i]["pred_point_sem_labels"], wp[i]) and ret[i]["metadata"]["token"] == e["metadata"][i]["token"]
+        assert fg.fallbacks == 0 and fg.recaptures == 0
+        one = example((105000,), 51)  # the same number of rows in ONE frame: another batch size, eager path
+        ret = fg(one)
+        assert fg.fallbacks == 1 and len(ret) == 1
+    finally:
+        ops.set_precision("f32")
+
+
 @pytest.mark.parametrize("n", [30000, 120000])
 def test_bf16_mode_tolerance_vs_oracle(n):
     """BASELINE configs[4]'s arithmetic (at 30k points and at the 120k points the configuration names): ops.set_precision("bf16") - SubM layers with plain bf16 operands (one MFMA per product, f32
