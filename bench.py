@@ -464,9 +464,20 @@ def stage_rooflines(model, example, kind, census, frames=5):
         if "sffm" in shapes:
             d_in, L, m = shapes["sffm"]
             d, ffn, layers = int(m.c.d_model), int(m.c.ffn), int(m.c.num_layers)
-            flops = N * (2.0 * d_in * d + layers * (2.0 * d * d * 2 + 2.0 * 2 * d * L + 2.0 * 2 * d * ffn))
-            mfma("sffm_decoder", flops, F32_MFMA_PEAK_TFLOPS, "f32",
-                 "SURVEY.md 8(d) SFFM: N*(2*d_in*d + layers*(2*d*d*2 + 2*2*d*L + 2*2*d*ffn)), d=%d, L=%d tokens, ffn=%d, %d layers" % (d, L, ffn, layers))
+            f_gemm = N * (2.0 * d_in * d + layers * (2.0 * d * d * 2 + 2.0 * 2 * d * ffn))
+            f_attn = N * layers * (2.0 * 2 * d * L)
+            formula = "SURVEY.md 8(d) SFFM: N*(2*d_in*d + layers*(2*d*d*2 + 2*2*d*L + 2*2*d*ffn)), d=%d, L=%d tokens, ffn=%d, %d layers" % (d, L, ffn, layers)
+            planes = (ops.get_precision() in ("bf16x6", "bf16x8", "bf16") and getattr(ops, "_SFFM_PLANES", False) and getattr(ops, "_SFFM_ATTENTION", 0) == 0 and L <= 64)
+            if planes and "sffm_decoder" in ms and ms["sffm_decoder"] > 0:
+                # k_sffm_decoder_rt: the GEMMs as 6 bf16 plane products per f32 product, the attention products on the exact-f32 MFMA
+                t = ms["sffm_decoder"] * 1e-3
+                out["sffm_decoder"] = dict(bound="mfma", ms=ms["sffm_decoder"], algorithmic_flops=f_gemm + f_attn, achieved=6 * f_gemm / t / 1e12,
+                                           useful_f32_equivalent_tflops=(f_gemm + f_attn) / t / 1e12, peak=BF16_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                           dtype="bf16 planes (GEMMs: 6 products per f32 product); attention QK^T / PV on the f32 MFMA beside it",
+                                           frac=6 * f_gemm / t / 1e12 / BF16_MFMA_PEAK_TFLOPS, attention_f32_tflops=f_attn / t / 1e12, formula=formula,
+                                           kernel="k_sffm_decoder_rt")
+            else:
+                mfma("sffm_decoder", f_gemm + f_attn, F32_MFMA_PEAK_TFLOPS, "f32", formula)
     out["_unattributed_ms"] = {k: v for k, v in ms.items() if k not in out}
     return out
 
@@ -790,10 +801,37 @@ def main():
                 del fg2
             except Exception as e:
                 mseg["graph_error"] = repr(e)
+            try:
+                # two frames in flight, one hipGraph per slot on its own stream: the decoder at the end of one frame (one 4-wave workgroup per CU,
+                # a third of the matrix pipe) runs beside the convolution stack of the other
+                sts = [torch.cuda.Stream(dev) for _ in range(2)]
+                exs2 = []
+                for k in range(2):
+                    pk_, ek_, _, _ = make_inputs("mseg3d", 1, frame_ids=[k], seed0=300)
+                    exs2.append(dict(points=pk_, batch_size=1, **ek_))
+                fgs2 = [lgraph.FrameGraph(m2, ex, stream=st) for ex, st in zip(exs2, sts)]
+
+                def step_g2():
+                    cur = torch.cuda.current_stream(dev)
+                    for st, fg, ex in zip(sts, fgs2, exs2):
+                        st.wait_stream(cur)
+                        with torch.cuda.stream(st):
+                            fg.launch(ex)
+                    labels = None
+                    for fg, ex in zip(fgs2, exs2):
+                        labels = fg.finish(ex, clone=False)[0]["pred_point_sem_labels"]
+                    return labels
+                el2t, _ = timed_steps(step_g2, n2, 2)
+                mseg["two_graphs_in_flight"] = dict(frames_per_s=2 * n2 / el2t, ms_per_step_of_2_frames=1e3 * el2t / n2,
+                                                    fallbacks=sum(fg.fallbacks for fg in fgs2))
+                del fgs2, exs2
+            except Exception as e:
+                mseg["two_graphs_in_flight"] = dict(error=repr(e))
         try:  # configs[2]'s own roofline objects: the fused SF-Phase decoder (MFMA-bound) first, then the other stages of the frame
             sr2 = stage_rooflines(m2, dict(points=p2, batch_size=1, **e2), "mseg3d", census2)
             if "sffm_decoder" in sr2:
-                mseg["roofline"] = dict(kernel="k_sffm_decoder (SF-Phase decoder, 6 layers in one launch)", **sr2["sffm_decoder"])
+                mseg["roofline"] = dict(dict(kernel="k_sffm_decoder"), **sr2["sffm_decoder"])
+                mseg["roofline"]["kernel"] += " (SF-Phase decoder, 6 layers in one launch)"
             mseg["stage_rooflines"] = sr2
         except Exception as e:
             mseg["stage_rooflines"] = dict(error=repr(e))
