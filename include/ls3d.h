@@ -231,6 +231,14 @@ int ls3d_rulebook_masks(const int32_t *tbl, int n, const int32_t *n_dev, int kvo
  * out[i] = perm[i] - seg_offsets[s] for i in [seg_offsets[s], seg_offsets[s+1]) (seg_offsets: nseg + 1 host ints). */
 int ls3d_rulebook_sort_keys(const int32_t *tbl, int n, const int32_t *n_dev, int kvol, int segment, int descending, int32_t *keys,
                             ls3d_stream_t stream);
+/* Sort keys for the rows of the TRANSPOSED table of a strided convolution (nbr_inv of ls3d_rulebook_conv: SparseInverseConv3d, dgrad of
+ * SparseConv3d) from the input coordinates alone: a row's offset mask is a function of the residues (c + pad) mod stride, so
+ * keys[r] = (segment << class_bits) | class(r), class < stride_z * stride_y * stride_x ordered densest first, and rows beyond *n_dev get
+ * the spare class 2^class_bits - 1.  One radix pass over class_bits + segment bits replaces the four passes of the 27-bit mask keys; use
+ * with ls3d_radix_sort + ls3d_segment_local_index32 exactly like ls3d_rulebook_sort_keys.  stride > 8 or more classes than
+ * 2^class_bits - 1: LS3D_ERR_UNSUPPORTED (sort by ls3d_rulebook_sort_keys instead). */
+int ls3d_rulebook_parity_keys(const int32_t *coords_in, int n, const int32_t *n_dev, const int32_t ksize_host[3], const int32_t stride_host[3],
+                              const int32_t pad_host[3], int segment, int class_bits, int32_t *keys, ls3d_stream_t stream);
 int ls3d_segment_local_index(const int64_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream);
 int ls3d_segment_local_index32(const int32_t *perm, int n, const int32_t *seg_offsets_host, int nseg, int32_t *out, ls3d_stream_t stream);
 

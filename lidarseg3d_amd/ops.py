@@ -401,7 +401,9 @@ def choose_geometry(cout, n_rows, target_blocks=None):
         # measured on MI355X (120k-pt frame): the f32 path is matrix-pipe bound and wants many small workgroups
         # (60.5 fps at >=1500 vs 53 at 256); the split-bf16 path is bound by re-gathering the input rows once per
         # column slab and wants few, wide workgroups (84.6 fps at 128-384 vs 67.5 at 1500)
-        target_blocks = _TARGET_BLOCKS or (192 if _PRECISION in (BF16X3, BF16) else 512 if _PRECISION == BF16X6 else 2000)
+        # bf16x6 (round 4, profiles/round4_ab_gather_knobs.txt): 256 instead of 512 puts conv4.0 / conv_out on two column blocks per wave (half the
+        # re-gathers): slower alone (142 -> 166 us), faster inside the frame (stack 5.80 -> 5.75 ms, 147.3 -> 148.4 frames/s)
+        target_blocks = _TARGET_BLOCKS or (192 if _PRECISION in (BF16X3, BF16) else 256 if _PRECISION == BF16X6 else 2000)
     total = (cout + 31) // 32
     cands = []
     # measured on MI355X (profiles/): sharing gathered rows between waves (wc > 1) is slower than re-gathering them
@@ -457,6 +459,42 @@ def rulebook_orders(tbls, n_devs=None):
               "ls3d_segment_local_index32")
         for s, i in enumerate(grp):
             out[i] = local[offs[s]:offs[s + 1]]
+    return out
+
+
+_PARITY_ORDER = _os.environ.get("LS3D_PARITY_ORDER", "1") != "0"  # A/B: transposed strided tables ordered by coordinate residue class (one radix pass)
+
+
+def rulebook_parity_orders(coords, geoms, n_devs=None):
+    """processing orders of the TRANSPOSED tables of strided convolutions (SparseInverseConv3d / dgrad of SparseConv3d) from the input
+    coordinates alone (include/ls3d.h: ls3d_rulebook_parity_keys): coords[i] [n_i, 4] int32 input sites, geoms[i] = (ksize, stride, padding)
+    triples.  One batched sort with ONE radix pass.  -> list of int32 orders, None where the geometry is not supported (the caller sorts
+    those tables by their masks: rulebook_orders) or row order is disabled."""
+    out = [None] * len(coords)
+    if _ROW_ORDER == "none" or not _PARITY_ORDER:
+        return out
+    L = _L()
+    sel = [i for i, c in enumerate(coords) if c.shape[0] > 0 and all(1 <= int(v) <= 8 for v in geoms[i][1])
+           and int(geoms[i][1][0]) * int(geoms[i][1][1]) * int(geoms[i][1][2]) < 15]
+    for lo in range(0, len(sel), 16):
+        grp = sel[lo:lo + 16]
+        offs = [0]
+        for i in grp:
+            offs.append(offs[-1] + coords[i].shape[0])
+        dev = coords[grp[0]].device
+        keys = torch.empty((offs[-1],), dtype=_i32, device=dev)
+        for s_, i in enumerate(grp):
+            c = coords[i]
+            assert c.dtype == _i32 and c.is_contiguous() and c.shape[1] == 4
+            k3, s3, p3 = ((ctypes.c_int32 * 3)(*[int(v) for v in g]) for g in geoms[i])
+            check(L.ls3d_rulebook_parity_keys(_ptr(c), c.shape[0], _ndev(n_devs[i]) if n_devs is not None else None, k3, s3, p3, s_, 4,
+                                              ctypes.c_void_p(keys.data_ptr() + 4 * offs[s_]), _stream(c)), "ls3d_rulebook_parity_keys")
+        perm = radix_argsort(keys, 4 + max(len(grp) - 1, 1).bit_length())
+        local = torch.empty((offs[-1],), dtype=_i32, device=dev)
+        check(L.ls3d_segment_local_index32(_ptr(perm), offs[-1], (ctypes.c_int32 * len(offs))(*offs), len(grp), _ptr(local), _stream(perm)),
+              "ls3d_segment_local_index32")
+        for s_, i in enumerate(grp):
+            out[i] = local[offs[s_]:offs[s_ + 1]]
     return out
 
 

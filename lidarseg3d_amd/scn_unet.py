@@ -70,6 +70,7 @@ _N_SIDE = int(_os.environ.get("LS3D_GEOM_STREAMS", "2"))
 # depend on anything the deeper levels compute.  It runs on its own stream from the moment the encoder leaves the level, beside the
 # deeper levels - whose launches do not fill the chip (level 4 of a 120k-point frame: 215 tiles for 512 workgroup slots) and whose tails
 # leave CUs idle - and the decoder picks it up with one event.  Same kernels on the same inputs: bit-identical.  LS3D_LATERAL_STREAM=0: inline.
+_EARLY_ORDER = _os.environ.get("LS3D_EARLY_ORDER", "1") != "0"  # capacity mode: the first strided layer's row order from its own early sort
 _LATERAL = _os.environ.get("LS3D_LATERAL_STREAM", "1") != "0"
 _LATERAL_STREAMS = {}
 
@@ -480,6 +481,17 @@ class UNetSCN3D(nn.Module):
             spconv.prebuild_orders(x, list(self.conv_input.modules()) + list(self.conv1.modules()))
             gs.hand_over(x.indice_dict.values())
             level_ready.append(gs.finish_event())
+        conv2_order = None
+        if _EARLY_ORDER:
+            # The first strided layer (32 -> 64 on 142k output rows with 1.6 neighbours each) is too small for ORDER_MIN_CC, and unsorted it walks
+            # ~25 of the 27 offsets per 128-row tile (114 us; sorted: 4.6 offsets, 51 us - profiles/round4_ab_gather_knobs.txt).  In the frame's one
+            # batched sort its order arrived too late (the layer is the first consumer: `value` 147 -> 142); built HERE - behind the level-1
+            # geometry on its stream, from the first strided rulebook alone - it is ready ~0.3 ms before the layer runs.
+            with _GeometryStream(x.indices, ready, join=False, index=0, after=rb_events[:1]) as gs:
+                rb2 = x.find_indice_pair(self.conv2[0][0].indice_key)
+                rb2.order(False)
+                gs.hand_over([rb2])
+                conv2_order = gs.finish_event()
         for lvl, (key, src, stage) in enumerate((("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4))):
             # the last level's block also builds what is left - the decoder's row orders (the inverse tables of EVERY strided rulebook,
             # conv_out's included) - so it waits for the whole chain
@@ -503,6 +515,7 @@ class UNetSCN3D(nn.Module):
         for lvl, stage in enumerate((self.conv2, self.conv3, self.conv4)):
             self._wait(x, level_ready[lvl + 1])
             if lvl == 0:
+                self._wait(x, conv2_order)
                 ev0 = self._stack_event() if ev1 is not None else None
             x_enc = stage(x_enc)
             if lvl == 0:

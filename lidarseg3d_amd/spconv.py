@@ -70,7 +70,7 @@ class SparseModule(nn.Module):
 
 class _Rulebook(object):
     __slots__ = ("kind", "tbl", "tbl_inv", "in_indices", "in_shape", "out_indices", "out_shape", "index", "_orders", "_plans", "_pairs", "batch_size",
-                 "n_in_dev", "n_out_dev", "overflow_dev")
+                 "n_in_dev", "n_out_dev", "overflow_dev", "conv_geom")
 
     def rows_dev(self, inverse):
         """device count of the rows of the (inverse) table = the output rows of a launch on it (None: the table has no spare rows)"""
@@ -87,14 +87,33 @@ class _Rulebook(object):
                                                  n_dev=self.rows_dev(inverse))
         return self._plans[inverse]
 
+    def parity_geom(self, inverse):
+        """(ksize, stride, padding) when the rows of the (inverse) table can be ordered by the residue class of their coordinates instead of
+        their 27-bit masks (ops.rulebook_parity_orders: the transposed table of a strided convolution), else None"""
+        g = getattr(self, "conv_geom", None)
+        return g if (inverse and self.kind == "conv" and g is not None and ops._PARITY_ORDER) else None
+
     def order(self, inverse):
-        """mask-sorted processing order of the (inverse) table, built once per rulebook"""
+        """processing order of the (inverse) table - rows that share their empty offsets side by side, densest first - built once per rulebook"""
         if getattr(self, "_orders", None) is None:
             self._orders = {}
         if inverse not in self._orders:
-            self._orders[inverse] = ops.rulebook_order(self.tbl_inv if inverse else self.tbl,
-                                                       self.in_indices if inverse else self.out_indices, n_dev=self.rows_dev(inverse))
+            o = None
+            if self.parity_geom(inverse) is not None:
+                o = ops.rulebook_parity_orders([self.in_indices[:self.tbl_inv.shape[0]]], [self.conv_geom], [self.rows_dev(True)])[0]
+            if o is None:
+                o = ops.rulebook_order(self.tbl_inv if inverse else self.tbl, self.in_indices if inverse else self.out_indices,
+                                       n_dev=self.rows_dev(inverse))
+            self._orders[inverse] = o
         return self._orders[inverse]
+
+    def order_for(self, inverse, cin_cout):
+        """the order a layer of cin x cout channels processes the (inverse) table in: one that exists already (prebuild_orders, an earlier
+        layer), the cheap coordinate-class order of a transposed strided table, or - where the matrix work repays four sort passes - the mask order"""
+        o = (getattr(self, "_orders", None) or {}).get(inverse)
+        if o is not None:
+            return o
+        return self.order(inverse) if (cin_cout >= ORDER_MIN_CC or self.parity_geom(inverse) is not None) else None
 
     def pairs(self, inverse, ordered):
         """compacted pair lists of the (inverse) table for the weight gradients (ops.spconv_pairs), built once per rulebook: every
@@ -117,7 +136,7 @@ class _SparseConvFn(torch.autograd.Function):
         cin, cout = weight.shape[-2], weight.shape[-1]
         W = pack_spconv(weight)[0]
         tbl = rb.tbl_inv if inverse else rb.tbl
-        order = rb.order(inverse) if cin * cout >= ORDER_MIN_CC else None
+        order = rb.order_for(inverse, cin * cout)
         x = feats.detach().contiguous()
         if x.shape[1] != W.shape[1]:
             x = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1]))
@@ -145,10 +164,10 @@ class _SparseConvFn(torch.autograd.Function):
                 wd = wd.flip(0)  # input i sees output o through the mirrored offset
             Wd = PackedWeight(wd.contiguous(), kvol, cout, _pad16(cout), cin)
             if subm:
-                tbl_t, order_t = rb.tbl, (rb.order(False) if cin * cout >= ORDER_MIN_CC else None)
+                tbl_t, order_t = rb.tbl, rb.order_for(False, cin * cout)
             else:
                 tbl_t = rb.tbl if inverse else rb.tbl_inv
-                order_t = rb.order(not inverse) if cin * cout >= ORDER_MIN_CC else None
+                order_t = rb.order_for(not inverse, cin * cout)
             g = gout
             if g.shape[1] != Wd.shape[1]:
                 g = torch.nn.functional.pad(g, (0, Wd.shape[1] - g.shape[1]))
@@ -158,7 +177,7 @@ class _SparseConvFn(torch.autograd.Function):
                 gin = ops.gather_gemm(g, Wd, tbl=tbl_t, order=order_t, cout=cin)
         if ctx.needs_input_grad[1]:
             tbl = rb.tbl_inv if inverse else rb.tbl
-            order = rb.order(inverse) if cin * cout >= ORDER_MIN_CC else None
+            order = rb.order_for(inverse, cin * cout)
             pairs = rb.pairs(inverse, order is not None) if CACHE_PAIRS else None
             gw = ops.spconv_wgrad(feats.detach().contiguous(), gout, tbl, order, cin, cout, pairs=pairs).reshape(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -232,6 +251,7 @@ class SparseConvolution(PackedModule, SparseModule):
             assert not overflow
             rb.out_indices, rb.out_shape = oc[:n_out], oshape
             rb.tbl, rb.tbl_inv = nbr_out[:n_out], nbr_inv
+            rb.conv_geom = (_triple(self.kernel_size), _triple(self.stride), _triple(self.padding))
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = rb
         return rb
@@ -253,8 +273,8 @@ class SparseConvolution(PackedModule, SparseModule):
         if ops.use_tile("inverse" if self.inverse else rb.kind, k, W.shape[1], cout) and tbl.shape[0] > 0:
             return ops.tile_conv(feats.contiguous(), W, rb.tile_plan(bool(self.inverse)), cout=cout, scale=scale, shift=shift, relu=relu,
                                  res_pre=res_pre, pair=pair, out=out, out_ld=out_ld)
-        # mask-sorted processing order only for the layers whose matrix work can repay the sort (>= 64x64 channels)
-        order = rb.order(self.inverse) if self.in_channels * self.out_channels >= ORDER_MIN_CC else None
+        # mask-sorted processing order only for the layers whose matrix work can repay the sort (>= 64x64 channels) - or whose order exists / is cheap
+        order = rb.order_for(bool(self.inverse), self.in_channels * self.out_channels)
         return ops.gather_gemm(feats.contiguous(), W, tbl=tbl, order=order, cout=cout, scale=scale, shift=shift, relu=relu,
                                res_pre=res_pre, pair=pair, out=out, out_ld=out_ld, n_dev=rb.rows_dev(bool(self.inverse)))
 
@@ -287,7 +307,7 @@ def prebuild_orders(x, layers):
     """mask-sorted processing orders of every rulebook table the given layers will ask for (same criterion as
     SparseConvolution.conv), from ONE batched sort instead of one sort per table; tile-halo plans for the layers that
     take that path"""
-    want = []
+    want, want_parity = [], []
     for m in layers:
         if not isinstance(m, SparseConvolution):
             continue
@@ -298,14 +318,23 @@ def prebuild_orders(x, layers):
                         m.out_channels):
             rb.tile_plan(bool(m.inverse))
             continue
-        if m.in_channels * m.out_channels < ORDER_MIN_CC:
+        inv = bool(m.inverse)
+        cheap = rb.parity_geom(inv) is not None
+        if m.in_channels * m.out_channels < ORDER_MIN_CC and not cheap:
             continue
         if rb._orders is None:
             rb._orders = {}
-        inv = bool(m.inverse)
-        if inv in rb._orders or any(r is rb and i == inv for r, i in want):
+        if inv in rb._orders or any(r is rb and i == inv for r, i in want + want_parity):
             continue
-        want.append((rb, inv))
+        (want_parity if cheap else want).append((rb, inv))
+    if want_parity:  # transposed strided tables: ordered by the residue class of their input coordinates, one radix pass for all of them
+        got = ops.rulebook_parity_orders([rb.in_indices[:rb.tbl_inv.shape[0]] for rb, _ in want_parity], [rb.conv_geom for rb, _ in want_parity],
+                                         [rb.rows_dev(True) for rb, _ in want_parity])
+        for (rb, inv), o in zip(want_parity, got):
+            if o is None:
+                want.append((rb, inv))
+            else:
+                rb._orders[inv] = o
     if want:
         for (rb, inv), o in zip(want, ops.rulebook_orders([rb.tbl_inv if inv else rb.tbl for rb, inv in want], [rb.rows_dev(inv) for rb, inv in want])):
             rb._orders[inv] = o
@@ -340,6 +369,7 @@ def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, cap
             rb.out_indices, rb.out_shape = oc, oshape
             rb.tbl, rb.tbl_inv = nbr_out, nbr_inv
             rb.n_in_dev, rb.n_out_dev, rb.overflow_dev = n_in_dev, cnt[0:1], cnt[1:2]
+            rb.conv_geom = (_triple(c.kernel_size), _triple(c.stride), _triple(c.padding))
             x.indice_dict[c.indice_key] = rb
         return
     pend = [p[:8] for p in pend]
@@ -354,6 +384,7 @@ def prebuild_conv_rulebooks(x, convs, coords=None, shape=None, nosync=False, cap
         rb.kind, rb.in_indices, rb.in_shape = "conv", (icoords if n_in == icoords.shape[0] else icoords[:n_in]), list(ishape)
         rb.out_indices, rb.out_shape = oc[:n_out], oshape
         rb.tbl, rb.tbl_inv = nbr_out[:n_out], nbr_inv[:n_in]
+        rb.conv_geom = (_triple(c.kernel_size), _triple(c.stride), _triple(c.padding))
         x.indice_dict[c.indice_key] = rb
         n_in = n_out
 

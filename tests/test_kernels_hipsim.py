@@ -337,6 +337,58 @@ def test_rulebook_orders_batched_sort():
         assert np.array_equal(m[single], m[o])
 
 
+def test_transposed_strided_tables_are_ordered_by_coordinate_class():
+    """ops.rulebook_parity_orders (ls3d_rulebook_parity_keys): the rows of a strided convolution's transposed table are grouped by the residue
+    class of their input coordinate, densest class first, without reading the table - a row's offsets are the class's (a subset at the border of
+    the output grid), so the grouping is as tight as the 27-bit mask order's; rows beyond the device count sort last; unsupported strides fall
+    back; an inverse layer run in that order returns the same rows bit for bit"""
+    rng = np.random.default_rng(17)
+    shape = [9, 24, 20]
+    for ksize, stride, pad in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0)), ((2, 2, 2), (2, 2, 2), (0, 0, 0)), ((3, 3, 3), (1, 2, 3), (1, 1, 1))):
+        lin = rng.choice(2 * shape[0] * shape[1] * shape[2], size=900, replace=False)
+        b, r = np.divmod(lin, shape[0] * shape[1] * shape[2])
+        z, r2 = np.divmod(r, shape[1] * shape[2])
+        y, x_ = np.divmod(r2, shape[2])
+        coords = np.stack([b, z, y, x_], 1).astype(np.int32)
+        coords = coords[np.lexsort((coords[:, 3], coords[:, 2], coords[:, 1], coords[:, 0]))]
+        T = torch.from_numpy
+        oc, cnt, nbr_out, nbr_inv, oshape = ops.rulebook_conv(T(coords), 2, shape, ksize, stride, pad)
+        n_out = int(cnt[0])
+        inv = nbr_inv.numpy()
+        kvol = inv.shape[1]
+        mask = ((inv >= 0) * (1 << np.arange(kvol))).sum(1)
+        order = ops.rulebook_parity_orders([T(coords)], [(ksize, stride, pad)])[0].numpy()
+        assert sorted(order.tolist()) == list(range(len(coords)))
+        cls = tuple(((coords[:, 1 + d] + pad[d]) % stride[d]) for d in range(3))
+        code = (cls[0] * stride[1] + cls[1]) * stride[2] + cls[2]
+        full = {}
+        for c in np.unique(code):
+            full[c] = np.bitwise_or.reduce(mask[code == c])
+            assert np.all((mask[code == c] | full[c]) == full[c])
+            # interior rows carry the whole class mask: the class is the mask, up to the border
+            assert (mask[code == c] == full[c]).mean() > 0.5
+        seq = code[order]
+        change = np.nonzero(np.diff(seq))[0]
+        assert len(change) == len(np.unique(code)) - 1, "each class is one contiguous run"
+        pops = [bin(int(full[c])).count("1") for c in seq[np.concatenate([[0], change + 1])]]
+        assert pops == sorted(pops, reverse=True), "densest class first"
+        # device count: rows beyond it are not part of the order's head
+        nd = torch.tensor([600], dtype=torch.int32)
+        part = ops.rulebook_parity_orders([T(coords)], [(ksize, stride, pad)], [nd])[0].numpy()
+        assert sorted(part[:600].tolist()) == list(range(600))
+        # an inverse layer in that order: the same output rows, bit for bit
+        cin, cout = 16, 32
+        w = (rng.normal(size=(kvol, cin, cout)) * 0.2).astype(np.float32)
+        xin = rng.normal(size=(n_out, cin)).astype(np.float32)
+        pw = PackedWeight(T(w), kvol, cin, cin, cout)
+        a = ops.gather_gemm(T(xin), pw, tbl=nbr_inv, order=None, cout=cout)
+        b_ = ops.gather_gemm(T(xin), pw, tbl=nbr_inv, order=T(order.astype(np.int32)), cout=cout)
+        assert torch.equal(a, b_)
+    # two tables in one batched sort, one of them with a stride the key does not cover
+    got = ops.rulebook_parity_orders([T(coords), T(coords)], [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (9, 1, 1), (1, 1, 1))])
+    assert got[1] is None and sorted(got[0].numpy().tolist()) == list(range(len(coords)))
+
+
 def test_gather_gemm_sparse_with_order_and_fused_epilogue(monkeypatch):
     rng = np.random.default_rng(3)
     vin, vout, kvol, cin, cout = 300, 170, 27, 32, 64
