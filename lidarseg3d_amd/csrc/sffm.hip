@@ -513,10 +513,13 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
 // A workgroup's 128 points belong to ONE frame (tiles are cut per frame from pt_off), so K / V are staged once for all four waves and no wave
 // straddles a frame.
 constexpr int RT_LMAX = 64;
+#ifndef RT_KSTAGE
+#define RT_KSTAGE 24  // channels of K a thread has in flight at the top of a layer (24 = all)
+#endif
 #ifndef RT_WGS_PER_CU
 #define RT_WGS_PER_CU 1
 #endif
-constexpr int RT_KV = 2 * SF_E * RT_LMAX;   // floats: [k | v][head][token][24]
+constexpr int RT_KV = 2 * SF_E * RT_LMAX;   // floats: K [head][token][24] | V [channel][token]
 constexpr int RT_VEC = 10 * SF_E;           // floats per layer: bq bo b1[192] b2 n2g n2b n3g n3b (+ 96 spare)
 constexpr int RT_LDS_BYTES = 2 * SF_PCHUNK * 16 + RT_KV * 4 + 2 * RT_VEC * 4 + 3 * SF_E * 4;
 
@@ -611,13 +614,13 @@ __device__ __forceinline__ void rt_layernorm(sf_f32x16 (&x)[3], const float *g, 
 }
 
 // attention of the wave's 32 points over the frame's L <= 64 class embeddings, one head: q = t's registers of groups 3 h .. 3 h + 2 (overwritten
-// by the head's output).  kvs: [k | v][head][token][24] f32 in LDS.  Exact f32 products (v_mfma_f32_32x32x2_f32), f32 softmax.
+// by the head's output).  kvs in LDS: K as [head][token][24] (a token's 4 consecutive channels are one ds_read_b128), V as [channel][token] (the layout of `kv`).  Exact f32 products (v_mfma_f32_32x32x2_f32), f32 softmax.
 template <int H>
 __device__ __forceinline__ void rt_attention_head(sf_f32x16 (&t)[3], const float *kvs, int L) {
   const int lane = threadIdx.x & 63, col = lane & 31, kk = lane >> 5;
   const float scale = 1.0f / sqrtf((float)SF_HD);
   const bool two = L > 32;
-  const float *Kh = kvs + H * L * SF_HD, *Vh = kvs + SF_E * L + H * L * SF_HD;
+  const float *Kh = kvs + H * L * SF_HD, *Vh = kvs + SF_E * L + H * SF_HD * L;  // K: [head][token][24]; V: [channel][token] (the layout of `kv`)
   const int tok0 = col < L ? col : 0, tok1 = (32 + col) < L ? 32 + col : 0;  // this lane's key rows of the two A operands (rows >= L are masked below)
   sf_f32x16 s0, s1;
 #pragma unroll
@@ -663,15 +666,19 @@ __device__ __forceinline__ void rt_attention_head(sf_f32x16 (&t)[3], const float
 #pragma unroll
   for (int s2 = 0; s2 < 16; ++s2) {
     const int token = (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
-    const float va = token < L ? Vh[token * SF_HD + dv] : 0.0f;
+    const float va = token < L ? Vh[dv * L + token] : 0.0f;
     oc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s0[s2], oc, 0, 0, 0);
   }
   if (two) {
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
-      const int token = 32 + (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
-      const float va = token < L ? Vh[token * SF_HD + dv] : 0.0f;
-      oc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s1[s2], oc, 0, 0, 0);
+      // a step multiplies tokens 32 + (s2 & 3) + 8 (s2 >> 2) and that + 4: steps whose tokens are all >= L add zeros (L = 34: 14 of the 16) -
+      // wave-uniform, so the skip is a scalar branch
+      if (32 + (s2 & 3) + 8 * (s2 >> 2) < L) {
+        const int token = 32 + (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
+        const float va = token < L ? Vh[dv * L + token] : 0.0f;
+        oc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s1[s2], oc, 0, 0, 0);
+      }
     }
   }
   const float inv = 1.0f / den;
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(256, RT_WGS_PER_CU) void k_sffm_decoder_rt(const fl
                                                             float *__restrict__ out, int out_ld) {
   HIP_DYNAMIC_SHARED(float, smem)
   uint4 *Bq = (uint4 *)smem;                                   // [2][SF_PCHUNK] weight chunks
-  float *KVs = smem + 2 * SF_PCHUNK * 4;                       // [k | v][head][token][24]
+  float *KVs = smem + 2 * SF_PCHUNK * 4;                       // K [head][token][24] | V [channel][token]
   float *VEC = KVs + RT_KV;                                    // [2][RT_VEC] the layer's per-channel vectors (double buffered over the layers)
   float *GV = VEC + 2 * RT_VEC;                                // bin | ng | nb
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -737,20 +744,55 @@ __global__ __launch_bounds__(256, RT_WGS_PER_CU) void k_sffm_decoder_rt(const fl
   for (int l = 0; l < prm.num_layers; ++l) {
     const SfLayer &Ly = prm.layer[l];
     float *V = VEC + (l & 1) * RT_VEC;
-    // ---- what the four waves share in this layer: the per-channel vectors and K / V of the frame, transposed: source [h][d][l] -> LDS
-    //      [h][l][d].  No barrier of its own: every wave is past the previous layer's attention and LayerNorms of layer l - 2 (the GEMMs in
+    // ---- what the four waves share in this layer: the per-channel vectors and K / V of the frame (as they lie in `kv`: [channel][token]).
+    //      No barrier of its own: every wave is past the previous layer's attention and LayerNorms of layer l - 2 (the GEMMs in
     //      between synchronise the workgroup), and the q-projection's first barrier orders these writes against their readers.
     for (int i = tid; i < SF_E; i += 256) {
       V[i] = Ly.bq[i]; V[SF_E + i] = Ly.bo[i]; V[2 * SF_E + i] = Ly.b1[i]; V[3 * SF_E + i] = Ly.b1[SF_E + i]; V[4 * SF_E + i] = Ly.b2[i];
       V[5 * SF_E + i] = Ly.n2g[i]; V[6 * SF_E + i] = Ly.n2b[i]; V[7 * SF_E + i] = Ly.n3g[i]; V[8 * SF_E + i] = Ly.n3b[i];
     }
     {
+      // K: [channel][token] -> [head][token][24], one token per lane and 24 channels per thread: 24 loads in flight, no division by L.
+      // V: a straight copy in 16-byte units (96 L floats, 96 * 4 bytes a multiple of 16).  Each matrix's loads are issued before its first LDS
+      // write: two memory latencies per layer.  (The loop this replaces transposed both with two runtime divisions and a dependent
+      // load -> ds_write per element, 25 trips: a latency per trip.)
       const float *kg = kv + (size_t)l * kv_layer + (size_t)f * SF_E * L, *vg = kg + (size_t)batch * SF_E * L;
-      for (int i = tid; i < SF_E * L; i += 256) {
-        const int ll = i % L, hd = i / L, h = hd / SF_HD, d = hd - h * SF_HD;
-        const int o = (h * L + ll) * SF_HD + d;
-        KVs[o] = kg[i];
-        KVs[SF_E * L + o] = vg[i];
+      {
+        int tok = tid & 63, c0 = tid >> 6;
+#ifndef HIPSIM
+        asm volatile("" : "+v"(tok), "+v"(c0));  // not loop-invariant for the compiler: 48 hoisted addresses would live (and spill) across the whole layer
+#endif
+        const int tk = tok < L ? tok : 0;
+#pragma unroll
+        for (int jb = 0; jb < 24; jb += RT_KSTAGE) {
+          float q[RT_KSTAGE];
+#pragma unroll
+          for (int j = 0; j < RT_KSTAGE; ++j) q[j] = kg[(c0 + 4 * (jb + j)) * L + tk];
+          if (tok < L) {
+#pragma unroll
+            for (int j = 0; j < RT_KSTAGE; ++j) {
+              const int c = c0 + 4 * (jb + j), h = c / SF_HD, d = c - h * SF_HD;
+              KVs[(h * L + tok) * SF_HD + d] = q[j];
+            }
+          }
+          LS3D_SCHED_FENCE();  // keeps the next batch's loads behind this batch's stores (all 24 in flight at once spill)
+        }
+      }
+      {
+        const int units = (SF_E / 4) * L;  // <= 1536
+        const float4 *src = (const float4 *)vg;
+        float4 *dst = (float4 *)(KVs + SF_E * L);
+        float4 q[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int i = tid + 256 * j;
+          q[j] = src[i < units ? i : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int i = tid + 256 * j;
+          if (i < units) dst[i] = q[j];
+        }
       }
     }
     // ---- q projection -> t
@@ -816,7 +858,7 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
   const bool planes = m->gemm_products == 6;
   if (m->gemm_products != 0 && !planes) return LS3D_ERR_ARG;
   prm.pwin = (const uint4 *)m->w_in_planes;
-  if (planes && (!m->w_in_planes || !m->pt_off || (m->d_in % 32))) return LS3D_ERR_ARG;
+  if (planes && (!m->w_in_planes || !m->pt_off || (m->d_in % 32) || ((uintptr_t)kv & 15))) return LS3D_ERR_ARG;
   if (planes && (m->attention != 0 || L > RT_LMAX)) return LS3D_ERR_UNSUPPORTED;  // the reduced-precision attentions live in the LDS-tile kernel
   for (int l = 0; l < m->num_layers; ++l) {
     const ls3d_sffm_layer_t &s = m->layers[l];

@@ -1424,6 +1424,30 @@ def test_radix_sort_is_a_stable_argsort(n, bits):
     assert np.array_equal(perm, np.argsort(keys, kind="stable"))
 
 
+@pytest.mark.parametrize("cls", [8, 23, 32])
+def test_sffm_decoder_register_resident_form_other_token_counts(cls):
+    """k_sffm_decoder_rt with L = 2 cls = 16 (one key block), 46 (Waymo: a partial second block - the P V steps beyond L are skipped) and 64
+    (both blocks full) class embeddings, two ragged frames, against the layer-by-layer composition"""
+    torch.manual_seed(cls)
+    m = point_heads.SemanticFeatureFusionModule(64, 48, 64, d_model=96, nhead=4, num_decoder_layers=2, dim_feedforward=192).eval()
+    n0, n1 = 150, 41
+    x = torch.randn(n0 + n1, 64)
+    e1, e2 = torch.randn(2, 48, cls, 1), torch.randn(2, 64, cls, 1)
+    bidx = torch.cat([torch.zeros(n0), torch.ones(n1)])
+    pts = torch.cat([bidx[:, None], torch.randn(n0 + n1, 3)], 1).contiguous()
+    try:
+        with torch.no_grad():
+            point_heads.set_fused_sffm(False)
+            ref = m(x, e1, e2, bidx, 2, points=pts)
+            point_heads.set_fused_sffm(True)
+            ops.set_precision("bf16x6")
+            planes = m(x, e1, e2, bidx, 2, points=pts)
+    finally:
+        point_heads.set_fused_sffm(True)
+        ops.set_precision("f32")
+    np.testing.assert_allclose(planes.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+
+
 def test_fused_sffm_decoder_equals_layer_by_layer_and_oracle():
     """ls3d_sffm_decoder (the point side of the SF-Phase decoder as one kernel) against the layer-by-layer composition of the same
     module and against the oracle's SFFM (pinned to the reference class), two ragged frames: a 128-point tile straddles the frame
