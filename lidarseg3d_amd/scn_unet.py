@@ -70,7 +70,7 @@ _N_SIDE = int(_os.environ.get("LS3D_GEOM_STREAMS", "2"))
 # depend on anything the deeper levels compute.  It runs on its own stream from the moment the encoder leaves the level, beside the
 # deeper levels - whose launches do not fill the chip (level 4 of a 120k-point frame: 215 tiles for 512 workgroup slots) and whose tails
 # leave CUs idle - and the decoder picks it up with one event.  Same kernels on the same inputs: bit-identical.  LS3D_LATERAL_STREAM=0: inline.
-_EARLY_ORDER = _os.environ.get("LS3D_EARLY_ORDER", "1") != "0"  # capacity mode: the first strided layer's row order from its own early sort
+_EARLY_ORDER = int(_os.environ.get("LS3D_EARLY_ORDER", "0"))  # capacity mode: the first strided layer's row order from its own early sort (2: on the rulebook chain's stream, 1: behind the level-1 geometry)
 _LATERAL = _os.environ.get("LS3D_LATERAL_STREAM", "1") != "0"
 _LATERAL_STREAMS = {}
 
@@ -460,8 +460,22 @@ class UNetSCN3D(nn.Module):
         #             strided rulebook that creates the level's sites; the devoxelization's neighbour search at the end.
         # The main stream picks the levels up one event at a time.
         with _GeometryStream(x.indices, ready, join=False, index=1) as gs:
-            rb_events = []
-            spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps, after_each=lambda: rb_events.append(gs.finish_event()))
+            rb_events, conv2_order = [], None
+            if _EARLY_ORDER == 2 and len(chain) > 1:
+                # The first strided layer (32 -> 64 on 142k output rows with 1.6 neighbours each) is too small for ORDER_MIN_CC, and unsorted it
+                # walks ~25 of the 27 offsets per 128-row tile (114 us; sorted: 4.6 offsets, 51 us - profiles/round4_ab_gather_knobs.txt).  In the
+                # frame's batched sort its order arrived too late (the layer is the first consumer: `value` 147 -> 142); behind the level-1
+                # geometry on stream 0 it was late as well (the reader leaves the sort's small kernels few CU slots: 147.7 -> 144).  Here it is
+                # sorted right behind its own rulebook, in front of the rest of the chain (whose levels run a millisecond later).
+                spconv.prebuild_conv_rulebooks(x, chain[:1], nosync=True, caps=caps[:1], after_each=lambda: rb_events.append(gs.finish_event()))
+                rb2 = x.find_indice_pair(chain[0].indice_key)
+                rb2.order(False)
+                gs.hand_over([rb2])
+                conv2_order = gs.finish_event()
+                spconv.prebuild_conv_rulebooks(x, chain[1:], coords=rb2.out_indices, shape=rb2.out_shape, n_dev=rb2.n_out_dev, nosync=True,
+                                               caps=caps[1:], after_each=lambda: rb_events.append(gs.finish_event()))
+            else:
+                spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps, after_each=lambda: rb_events.append(gs.finish_event()))
             cnts = torch.stack([torch.cat([x.indice_dict[c.indice_key].n_out_dev, x.indice_dict[c.indice_key].overflow_dev]) for c in chain])
             if cnts.is_cuda:
                 # one pinned buffer per model: a frame's counts are read (geometry_check) before the next frame is submitted, and a
@@ -481,12 +495,7 @@ class UNetSCN3D(nn.Module):
             spconv.prebuild_orders(x, list(self.conv_input.modules()) + list(self.conv1.modules()))
             gs.hand_over(x.indice_dict.values())
             level_ready.append(gs.finish_event())
-        conv2_order = None
-        if _EARLY_ORDER:
-            # The first strided layer (32 -> 64 on 142k output rows with 1.6 neighbours each) is too small for ORDER_MIN_CC, and unsorted it walks
-            # ~25 of the 27 offsets per 128-row tile (114 us; sorted: 4.6 offsets, 51 us - profiles/round4_ab_gather_knobs.txt).  In the frame's one
-            # batched sort its order arrived too late (the layer is the first consumer: `value` 147 -> 142); built HERE - behind the level-1
-            # geometry on its stream, from the first strided rulebook alone - it is ready ~0.3 ms before the layer runs.
+        if _EARLY_ORDER == 1:  # (A/B) the same sort behind the level-1 geometry on stream 0
             with _GeometryStream(x.indices, ready, join=False, index=0, after=rb_events[:1]) as gs:
                 rb2 = x.find_indice_pair(self.conv2[0][0].indice_key)
                 rb2.order(False)
