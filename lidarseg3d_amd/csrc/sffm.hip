@@ -47,6 +47,7 @@ struct SfParams {
   const float *win, *bin, *ng, *nb;
   float neps;
   int num_layers, d_in;
+  int ablate;  // measurement only (gemm_products bits 8..): 1 no attention, 2 no FFN, 4 no LayerNorm, 8 GEMMs without MFMAs, 16 GEMMs without weight staging
   const uint4 *pwin;
   SfLayer layer[SF_MAX_LAYERS];
 };
@@ -513,6 +514,9 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
 // A workgroup's 128 points belong to ONE frame (tiles are cut per frame from pt_off), so K / V are staged once for all four waves and no wave
 // straddles a frame.
 constexpr int RT_LMAX = 64;
+#ifndef RT_ABLATE_HOOKS
+#define RT_ABLATE_HOOKS 0  // 1: a measurement build for tools/bench_decoder.py (gemm_products bits 8.. leave parts of the kernel out)
+#endif
 #ifndef RT_KSTAGE
 #define RT_KSTAGE 24  // channels of K a thread has in flight at the top of a layer (24 = all)
 #endif
@@ -532,14 +536,18 @@ constexpr int RT_LDS_BYTES = 2 * SF_PCHUNK * 16 + RT_KV * 4 + 2 * RT_VEC * 4 + 3
 // `next` on exit.  Six plane products per f32 product, head x head alone in `out`, the five small ones in a second accumulator.
 template <int NB>
 __device__ __forceinline__ void rt_gemm(const sf_f32x16 (&in)[3], const uint4 *__restrict__ Wq, const uint4 *__restrict__ next, uint4 *Bq,
-                                        sf_f32x16 (&out)[3], bool zero, SfPre &pre) {
+                                        sf_f32x16 (&out)[3], bool zero, SfPre &pre, int ablate = 0) {
   constexpr int NKC = 2 * NB;
   const int lane = threadIdx.x & 63;
   if (!next) next = Wq;
-  __syncthreads();  // previous users of the weight buffers are done
-  sf_stash(Bq, pre);
-  SfPre p1 = sf_fetch(NKC > 1 ? Wq + SF_PSTRIDE : next);
-  __syncthreads();
+  const bool stage = !(ablate & 16), mul = !(ablate & 8);
+  SfPre p1 = pre;
+  if (stage) {
+    __syncthreads();  // previous users of the weight buffers are done
+    sf_stash(Bq, pre);
+    p1 = sf_fetch(NKC > 1 ? Wq + SF_PSTRIDE : next);
+    __syncthreads();
+  }
   sf_f32x16 acs[3];
 #pragma unroll
   for (int m = 0; m < 3; ++m)
@@ -551,8 +559,8 @@ __device__ __forceinline__ void rt_gemm(const sf_f32x16 (&in)[3], const uint4 *_
 #pragma unroll
   for (int c = 0; c < NKC; ++c) {
     SfPre p2 = p1;
-    if (c + 2 <= NKC) p2 = sf_fetch(c + 2 < NKC ? Wq + (size_t)(c + 2) * SF_PSTRIDE : next);
-    {
+    if (c + 2 <= NKC && stage) p2 = sf_fetch(c + 2 < NKC ? Wq + (size_t)(c + 2) * SF_PSTRIDE : next);
+    if (mul) {
       constexpr int dummy = 0; (void)dummy;
       const int n = c >> 1, u = c & 1;
       uint4 xh, xm, xl;
@@ -575,7 +583,7 @@ __device__ __forceinline__ void rt_gemm(const sf_f32x16 (&in)[3], const uint4 *_
         acs[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wh, Xm, acs[m], 0, 0, 0);
       }
     }
-    if (c + 1 < NKC) {
+    if (c + 1 < NKC && stage) {
       sf_stash(Bq + ((c + 1) & 1) * SF_PCHUNK, p1);
       __syncthreads();
     }
@@ -615,11 +623,23 @@ __device__ __forceinline__ void rt_layernorm(sf_f32x16 (&x)[3], const float *g, 
 
 // attention of the wave's 32 points over the frame's L <= 64 class embeddings, one head: q = t's registers of groups 3 h .. 3 h + 2 (overwritten
 // by the head's output).  kvs in LDS: K as [head][token][24] (a token's 4 consecutive channels are one ds_read_b128), V as [channel][token] (the layout of `kv`).  Exact f32 products (v_mfma_f32_32x32x2_f32), f32 softmax.
-template <int H>
+// exp of a non-positive argument for the softmax: v_exp_f32(x log2 e).  The product loses |x| 2^-24 absolutely, i.e. a probability e^x is
+// off by |x| e^x 6e-8 relative to the largest one: < 2.2e-8 everywhere (expf: 13 more instructions per value, 768 values per point).
+#ifdef HIPSIM
+#define RT_EXP(x_) expf(x_)
+#else
+#define RT_EXP(x_) __expf(x_)
+#endif
+// NS2: the number of second-block steps / registers that hold tokens below L, known at compile time (register r and P V step r of the second block
+// cover tokens 32 + (r & 3) + 8 (r >> 2) and that + 4, ascending in r) - 0: L <= 32, 2: L = 33 .. 34 (nuScenes: 2 x 17 classes), -1: decided at
+// run time with wave-uniform branches.  With it the four heads of a layer are ONE basic block, which hipcc schedules across (the next head's
+// K reads and MFMAs under this head's softmax).
+template <int H, int NS2>
 __device__ __forceinline__ void rt_attention_head(sf_f32x16 (&t)[3], const float *kvs, int L) {
   const int lane = threadIdx.x & 63, col = lane & 31, kk = lane >> 5;
   const float scale = 1.0f / sqrtf((float)SF_HD);
-  const bool two = L > 32;
+  const bool two = NS2 < 0 ? L > 32 : NS2 > 0;
+#define RT_IN2(r_) (NS2 < 0 ? (32 + ((r_) & 3) + 8 * ((r_) >> 2) < L) : ((r_) < NS2))
   const float *Kh = kvs + H * L * SF_HD, *Vh = kvs + SF_E * L + H * SF_HD * L;  // K: [head][token][24]; V: [channel][token] (the layout of `kv`)
   const int tok0 = col < L ? col : 0, tok1 = (32 + col) < L ? 32 + col : 0;  // this lane's key rows of the two A operands (rows >= L are masked below)
   sf_f32x16 s0, s1;
@@ -631,13 +651,17 @@ __device__ __forceinline__ void rt_attention_head(sf_f32x16 (&t)[3], const float
     const int G = 3 * H + g, n = G >> 2, i = G & 3;
     const float4 k0 = *(const float4 *)(Kh + tok0 * SF_HD + 8 * g + 4 * kk);
     const float kv0[4] = {k0.x, k0.y, k0.z, k0.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv0[j], t[n][4 * i + j], s0, 0, 0, 0);
-    if (two) {
+    if (two) {  // the two key blocks' products alternate: two independent accumulator chains
       const float4 k1 = *(const float4 *)(Kh + tok1 * SF_HD + 8 * g + 4 * kk);
       const float kv1[4] = {k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv1[j], t[n][4 * i + j], s1, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv0[j], t[n][4 * i + j], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv1[j], t[n][4 * i + j], s1, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kv0[j], t[n][4 * i + j], s0, 0, 0, 0);
     }
   }
   float m = -3.0e38f;
@@ -645,42 +669,53 @@ __device__ __forceinline__ void rt_attention_head(sf_f32x16 (&t)[3], const float
   for (int r = 0; r < 16; ++r) {
     const int token = (r & 3) + 8 * (r >> 2) + 4 * kk;
     s0[r] = token < L ? s0[r] * scale : -3.0e38f;
-    s1[r] = (two && token + 32 < L) ? s1[r] * scale : -3.0e38f;
-    m = fmaxf(m, fmaxf(s0[r], s1[r]));
+    m = fmaxf(m, s0[r]);
+    if (two && RT_IN2(r)) {
+      s1[r] = token + 32 < L ? s1[r] * scale : -3.0e38f;
+      m = fmaxf(m, s1[r]);
+    }
   }
   m = fmaxf(m, __shfl_xor(m, 32));
   float den = 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int token = (r & 3) + 8 * (r >> 2) + 4 * kk;
-    s0[r] = token < L ? expf(s0[r] - m) : 0.0f;
-    s1[r] = (two && token + 32 < L) ? expf(s1[r] - m) : 0.0f;
-    den += s0[r] + s1[r];
+    s0[r] = token < L ? RT_EXP(s0[r] - m) : 0.0f;
+    den += s0[r];
+    if (two && RT_IN2(r)) {  // (L = 34 evaluates 2 of the second block's 16 registers)
+      s1[r] = token + 32 < L ? RT_EXP(s1[r] - m) : 0.0f;
+      den += s1[r];
+    }
   }
   den += __shfl_xor(den, 32);
-  // O^T[d][point] = sum_token V_h[token][d] P[token][point]: A = V_h^T (row d: this lane's half of the step's two tokens), B = the probabilities
-  sf_f32x16 oc;
+  // O^T[d][point] = sum_token V_h[token][d] P[token][point]: A = V_h^T (row d: this lane's half of the step's two tokens), B = the probabilities.
+  // Two accumulator chains (steps 0 - 7 | steps 8 - 15 and the second block), added at the end.
+  sf_f32x16 oc, od;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) oc[r] = 0.0f;
+  for (int r = 0; r < 16; ++r) { oc[r] = 0.0f; od[r] = 0.0f; }
   const int dv = col < SF_HD ? col : 0;  // rows >= 24 of the output are discarded
 #pragma unroll
-  for (int s2 = 0; s2 < 16; ++s2) {
-    const int token = (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
-    const float va = token < L ? Vh[dv * L + token] : 0.0f;
+  for (int s2 = 0; s2 < 8; ++s2) {
+    const int ta = (s2 & 3) + 8 * (s2 >> 2) + 4 * kk, tb = ta + 16;
+    const float va = ta < L ? Vh[dv * L + ta] : 0.0f, vb = tb < L ? Vh[dv * L + tb] : 0.0f;
     oc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s0[s2], oc, 0, 0, 0);
+    od = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, s0[s2 + 8], od, 0, 0, 0);
   }
   if (two) {
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
-      // a step multiplies tokens 32 + (s2 & 3) + 8 (s2 >> 2) and that + 4: steps whose tokens are all >= L add zeros (L = 34: 14 of the 16) -
-      // wave-uniform, so the skip is a scalar branch
-      if (32 + (s2 & 3) + 8 * (s2 >> 2) < L) {
+      // steps whose tokens are all >= L add zeros (L = 34: 14 of the 16)
+      if (RT_IN2(s2)) {
         const int token = 32 + (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
         const float va = token < L ? Vh[dv * L + token] : 0.0f;
-        oc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s1[s2], oc, 0, 0, 0);
+        if (s2 & 1) od = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s1[s2], od, 0, 0, 0);
+        else oc = __builtin_amdgcn_mfma_f32_32x32x2f32(va, s1[s2], oc, 0, 0, 0);
       }
     }
   }
+#undef RT_IN2
+#pragma unroll
+  for (int r = 0; r < 12; ++r) oc[r] += od[r];
   const float inv = 1.0f / den;
 #pragma unroll
   for (int r = 0; r < 12; ++r) {  // output row d = (r & 3) + 8 (r >> 2) + 4 kk of the head = channel 24 h + d: group 3 h + (r >> 2), j = r & 3
@@ -690,7 +725,7 @@ __device__ __forceinline__ void rt_attention_head(sf_f32x16 (&t)[3], const float
   }
 }
 
-template <int NB>
+template <int NB, int NS2>
 __global__ __launch_bounds__(256, RT_WGS_PER_CU) void k_sffm_decoder_rt(const float *__restrict__ x, int x_ld, int n, const int32_t *__restrict__ pt_off,
                                                             const float *__restrict__ kv, int L, int batch, SfParams prm,
                                                             float *__restrict__ out, int out_ld) {
@@ -701,6 +736,7 @@ __global__ __launch_bounds__(256, RT_WGS_PER_CU) void k_sffm_decoder_rt(const fl
   float *GV = VEC + 2 * RT_VEC;                                // bin | ng | nb
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, kk = lane >> 5;
+  const int ab = RT_ABLATE_HOOKS ? prm.ablate : 0;  // 0 at compile time in the product build: the branches below disappear
   // ---- this workgroup's tile: 128 consecutive points of ONE frame
   int f = 0, tile = (int)blockIdx.x, lo = 0, hi = 0;
   for (;; ++f) {
@@ -736,7 +772,7 @@ __global__ __launch_bounds__(256, RT_WGS_PER_CU) void k_sffm_decoder_rt(const fl
       }
   }
   // ---- input projection -> xs
-  rt_gemm<NB>(xin, prm.pwin, prm.num_layers ? prm.layer[0].pwq : nullptr, Bq, xs, true, pre);
+  rt_gemm<NB>(xin, prm.pwin, prm.num_layers ? prm.layer[0].pwq : nullptr, Bq, xs, true, pre, ab);
   RT_FOR(nn, i) {
     const float4 b4 = RT_VEC4(GV, nn, i);
     xs[nn][4 * i + 0] += b4.x; xs[nn][4 * i + 1] += b4.y; xs[nn][4 * i + 2] += b4.z; xs[nn][4 * i + 3] += b4.w;
@@ -796,44 +832,48 @@ __global__ __launch_bounds__(256, RT_WGS_PER_CU) void k_sffm_decoder_rt(const fl
       }
     }
     // ---- q projection -> t
-    rt_gemm<3>(xs, Ly.pwq, Ly.pwo, Bq, t, true, pre);
+    rt_gemm<3>(xs, Ly.pwq, Ly.pwo, Bq, t, true, pre, ab);
     RT_FOR(nn, i) {
       const float4 b4 = RT_VEC4(V, nn, i);
       t[nn][4 * i + 0] += b4.x; t[nn][4 * i + 1] += b4.y; t[nn][4 * i + 2] += b4.z; t[nn][4 * i + 3] += b4.w;
     }
-    rt_attention_head<0>(t, KVs, L);
-    rt_attention_head<1>(t, KVs, L);
-    rt_attention_head<2>(t, KVs, L);
-    rt_attention_head<3>(t, KVs, L);
+    if (!(ab & 1)) {
+      rt_attention_head<0, NS2>(t, KVs, L);
+      rt_attention_head<1, NS2>(t, KVs, L);
+      rt_attention_head<2, NS2>(t, KVs, L);
+      rt_attention_head<3, NS2>(t, KVs, L);
+    }
     // ---- out projection + residual, LayerNorm (norm2)
-    rt_gemm<3>(t, Ly.pwo, Ly.pw1a, Bq, acc, true, pre);
+    rt_gemm<3>(t, Ly.pwo, Ly.pw1a, Bq, acc, true, pre, ab);
     RT_FOR(nn, i) {
       const float4 b4 = RT_VEC4(V + SF_E, nn, i);
       xs[nn][4 * i + 0] += acc[nn][4 * i + 0] + b4.x; xs[nn][4 * i + 1] += acc[nn][4 * i + 1] + b4.y;
       xs[nn][4 * i + 2] += acc[nn][4 * i + 2] + b4.z; xs[nn][4 * i + 3] += acc[nn][4 * i + 3] + b4.w;
     }
-    rt_layernorm(xs, V + 5 * SF_E, V + 6 * SF_E, Ly.n2eps, kk);
+    if (!(ab & 4)) rt_layernorm(xs, V + 5 * SF_E, V + 6 * SF_E, Ly.n2eps, kk);
+    if (!(ab & 2)) {
     // ---- FFN in two 96-wide halves of the hidden layer: t = relu(W1[half]^T x + b1[half]); acc += W2[half]^T t
-    rt_gemm<3>(xs, Ly.pw1a, Ly.pw2a, Bq, t, true, pre);
+    rt_gemm<3>(xs, Ly.pw1a, Ly.pw2a, Bq, t, true, pre, ab);
     RT_FOR(nn, i) {
       const float4 b4 = RT_VEC4(V + 2 * SF_E, nn, i);
       t[nn][4 * i + 0] = fmaxf(t[nn][4 * i + 0] + b4.x, 0.0f); t[nn][4 * i + 1] = fmaxf(t[nn][4 * i + 1] + b4.y, 0.0f);
       t[nn][4 * i + 2] = fmaxf(t[nn][4 * i + 2] + b4.z, 0.0f); t[nn][4 * i + 3] = fmaxf(t[nn][4 * i + 3] + b4.w, 0.0f);
     }
-    rt_gemm<3>(t, Ly.pw2a, Ly.pw1b, Bq, acc, true, pre);
-    rt_gemm<3>(xs, Ly.pw1b, Ly.pw2b, Bq, t, true, pre);
+    rt_gemm<3>(t, Ly.pw2a, Ly.pw1b, Bq, acc, true, pre, ab);
+    rt_gemm<3>(xs, Ly.pw1b, Ly.pw2b, Bq, t, true, pre, ab);
     RT_FOR(nn, i) {
       const float4 b4 = RT_VEC4(V + 3 * SF_E, nn, i);
       t[nn][4 * i + 0] = fmaxf(t[nn][4 * i + 0] + b4.x, 0.0f); t[nn][4 * i + 1] = fmaxf(t[nn][4 * i + 1] + b4.y, 0.0f);
       t[nn][4 * i + 2] = fmaxf(t[nn][4 * i + 2] + b4.z, 0.0f); t[nn][4 * i + 3] = fmaxf(t[nn][4 * i + 3] + b4.w, 0.0f);
     }
-    rt_gemm<3>(t, Ly.pw2b, (l + 1 < prm.num_layers ? prm.layer[l + 1].pwq : nullptr), Bq, acc, false, pre);
+    rt_gemm<3>(t, Ly.pw2b, (l + 1 < prm.num_layers ? prm.layer[l + 1].pwq : nullptr), Bq, acc, false, pre, ab);
     RT_FOR(nn, i) {
       const float4 b4 = RT_VEC4(V + 4 * SF_E, nn, i);
       xs[nn][4 * i + 0] += acc[nn][4 * i + 0] + b4.x; xs[nn][4 * i + 1] += acc[nn][4 * i + 1] + b4.y;
       xs[nn][4 * i + 2] += acc[nn][4 * i + 2] + b4.z; xs[nn][4 * i + 3] += acc[nn][4 * i + 3] + b4.w;
     }
-    rt_layernorm(xs, V + 7 * SF_E, V + 8 * SF_E, Ly.n3eps, kk);
+    }
+    if (!(ab & 4)) rt_layernorm(xs, V + 7 * SF_E, V + 8 * SF_E, Ly.n3eps, kk);
   }
   if (prm.ng) rt_layernorm(xs, GV + SF_E, GV + 2 * SF_E, prm.neps, kk);
   if (live) {
@@ -855,8 +895,9 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
   SfParams prm;
   prm.win = m->w_in; prm.bin = m->b_in; prm.ng = m->norm_gamma; prm.nb = m->norm_beta; prm.neps = m->norm_eps;
   prm.num_layers = m->num_layers; prm.d_in = m->d_in;
-  const bool planes = m->gemm_products == 6;
-  if (m->gemm_products != 0 && !planes) return LS3D_ERR_ARG;
+  const bool planes = (m->gemm_products & 255) == 6;
+  if ((m->gemm_products & 255) != 0 && !planes) return LS3D_ERR_ARG;
+  prm.ablate = m->gemm_products >> 8;
   prm.pwin = (const uint4 *)m->w_in_planes;
   if (planes && (!m->w_in_planes || !m->pt_off || (m->d_in % 32) || ((uintptr_t)kv & 15))) return LS3D_ERR_ARG;
   if (planes && (m->attention != 0 || L > RT_LMAX)) return LS3D_ERR_UNSUPPORTED;  // the reduced-precision attentions live in the LDS-tile kernel
@@ -873,9 +914,11 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_sffm_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<1>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<2>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<3>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess)
+        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<1, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<2, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<3, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_decoder_rt<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess)
       return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
@@ -885,8 +928,11 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
   if (planes) {  // the register-resident form: tiles cut per frame
     const unsigned grid = (unsigned)(((long long)n + 127) / 128 + batch);
     const int32_t *po = (const int32_t *)m->pt_off;
-#define RT_LAUNCH(NB_) hipLaunchKernelGGL((k_sffm_decoder_rt<NB_>), dim3(grid), dim3(256), RT_LDS_BYTES, stream, x, x_ld, n, po, kv, L, batch, prm, out, out_ld)
-    if (m->d_in == 32) RT_LAUNCH(1); else if (m->d_in == 64) RT_LAUNCH(2); else RT_LAUNCH(3);
+#define RT_LAUNCH(NB_, NS2_) hipLaunchKernelGGL((k_sffm_decoder_rt<NB_, NS2_>), dim3(grid), dim3(256), RT_LDS_BYTES, stream, x, x_ld, n, po, kv, L, batch, prm, out, out_ld)
+    // the shipped heads (d_in = 64) with up to 32 or with 33 - 34 class embeddings (nuScenes: 2 x 17) have the attention's token bounds compiled in
+    if (m->d_in == 64 && L <= 32) RT_LAUNCH(2, 0);
+    else if (m->d_in == 64 && L <= 34) RT_LAUNCH(2, 2);
+    else if (m->d_in == 32) RT_LAUNCH(1, -1); else if (m->d_in == 64) RT_LAUNCH(2, -1); else RT_LAUNCH(3, -1);
 #undef RT_LAUNCH
   } else {
     hipLaunchKernelGGL(k_sffm_decoder, dim3((unsigned)blocks), dim3(256), lds, stream, x, x_ld, n, points, pt_stride, kv, L, batch, prm, out, out_ld, att);

@@ -1112,6 +1112,7 @@ class SffmModel(object):
 
 
 _SFFM_ATTENTION = 0
+_SFFM_ABLATE = 0  # measurement only (tools/bench_decoder.py): parts of k_sffm_decoder_rt left out, see SfParams::ablate
 _SFFM_PLANES = _os.environ.get("LS3D_SFFM_PLANES", "1") != "0"  # A/B: the decoder's GEMMs on the 3-plane bf16 split in the 3-plane precisions
 
 
@@ -1130,7 +1131,7 @@ def sffm_decoder(x, points, kv, L, batch, model, pt_off=None):
     out = torch.empty((n, model.c.d_model), dtype=torch.float32, device=x.device)
     model.c.attention = _SFFM_ATTENTION
     planes = _PRECISION in (BF16X6, BF16X8, BF16) and _SFFM_PLANES and _SFFM_ATTENTION == 0 and L <= 64
-    model.c.gemm_products = 6 if planes else 0
+    model.c.gemm_products = (6 | (_SFFM_ABLATE << 8)) if planes else 0
     if planes:
         if pt_off is None:
             pt_off = frame_offsets(points if points.dim() == 2 else points.unsqueeze(1).contiguous(), batch)
