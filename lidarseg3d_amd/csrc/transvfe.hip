@@ -70,12 +70,15 @@ __device__ __forceinline__ TvPre tv_fetch(const uint4 *__restrict__ chunk) {
   p.a = chunk[tid]; p.b = chunk[tid + 256]; p.c = chunk[tid + 512];
   return p;
 }
-template <int MODE, typename Epi>
-__device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, const float *__restrict__ Wp, float *Bs, Epi epi, TvPre &pre,
+// K, N are template parameters: in the plane modes the chunk loop is fully unrolled - a kernel with one wave per SIMD has nobody to hide
+// a branch behind, and every per-chunk condition (first / last chunk of a slab, anything left to fetch) splits the MFMAs, the weight
+// prefetch and the LDS stash into basic blocks that hipcc does not schedule across.
+template <int MODE, int K, int N, typename Epi>
+__device__ __forceinline__ void tv_gemm(const float *A, int lda, const float *__restrict__ Wp, float *Bs, Epi epi, TvPre &pre,
                                         const float *__restrict__ next) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int col = lane & 31, kk = lane >> 5;
-  const int nslab = N / 64, nkc = K / 32, nchunks = nslab * nkc;
+  constexpr int nslab = N / 64, nkc = K / 32, nchunks = nslab * nkc;
   if constexpr (MODE >= 6) {
     const uint4 *Wq = (const uint4 *)Wp, *Wn = next ? (const uint4 *)next : (const uint4 *)Wp;
     uint4 *Bq = (uint4 *)Bs;
@@ -85,6 +88,7 @@ __device__ __forceinline__ void tv_gemm(const float *A, int lda, int K, int N, c
     __syncthreads();
     tv_f32x16 acc0, acc1, acs0, acs1;
     int buf = 0;
+#pragma unroll
     for (int c = 0; c < nchunks; ++c) {
       const int slab = c / nkc, kc = c - slab * nkc;
       if (kc == 0) {
@@ -303,7 +307,24 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       const int row = lane & 31;
       const int g = row / R, p = row - g * R, v = TV_VOXEL(g);
       float *t = T + row * TV_TS;
-      if (lane < 32) {
+      if (lane < 32 && P == 5 && C == 5) {
+        // the shipped readers' voxel shape, compile-time: 25 loads in flight, no runtime-indexed arrays; rows of absent voxels read voxel 0 and
+        // are zeroed by the select (no branch around the loads)
+        float xv[25], desc[13];
+        vfe_descriptor_fixed<5, 5>(voxels + (size_t)(v >= 0 ? v : 0) * 25, v >= 0 ? num[v] : 1, xv, desc);
+        const bool pad = p >= kpts, live = v >= 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          float pv = xv[c];  // point p of the voxel: a select chain over the five slots (p is a lane value)
+#pragma unroll
+          for (int q = 1; q < 5; ++q) pv = p == q ? xv[q * 5 + c] : pv;
+          t[c] = (live && !pad) ? pv : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 13; ++c) t[5 + c] = live ? desc[c] : 0.0f;
+#pragma unroll
+        for (int c = 18; c < TV_KT; ++c) t[c] = 0.0f;
+      } else if (lane < 32) {
         if (v >= 0) {
           const float *vox = voxels + (size_t)v * P * C;
           float desc[LS3D_MAX_FEAT + 8];
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
     TvPre pre;  // the weight chunk in flight across the GEMMs of the tile (plane modes)
     if constexpr (MODE >= 6) pre = tv_fetch((const uint4 *)prm.we);
     // ---- embedding (+ norm1 of layer 0)
-    tv_gemm<MODE>(T, TV_TS, TV_KT, TV_E, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+    tv_gemm<MODE, TV_KT, TV_E>(T, TV_TS, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
       const float b0 = prm.be[col], b1 = prm.be[32 + col];
       TV_FOR_ACC(r, row) {
         X[row * TV_XS + col] = a0[r] + b0;
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
     for (int l = 0; l < prm.num_layers; ++l) {
       const TvLayer &L = prm.layer[l];
       // ---- QKV -> T[:, 0:192]
-      tv_gemm<MODE>(X, TV_XS, TV_E, 3 * TV_E, L.wqkv, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<MODE, TV_E, 3 * TV_E>(X, TV_XS, L.wqkv, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.bqkv[slab * 64 + col], b1 = L.bqkv[slab * 64 + 32 + col];
         TV_FOR_ACC(r, row) {
           T[row * TV_TS + slab * 64 + col] = a0[r] + b0;
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       }
       TV_WAVE_SYNC();
       // ---- out-proj + residual (from the normed X) -> X, then norm2
-      tv_gemm<MODE>(T, TV_TS, TV_E, TV_E, L.wo, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<MODE, TV_E, TV_E>(T, TV_TS, L.wo, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.bo[col], b1 = L.bo[32 + col];
         TV_FOR_ACC(r, row) {
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       tv_layernorm(X, L.n2g, L.n2b, L.n2eps);
       TV_WAVE_SYNC();
       // ---- FF1 + ReLU -> T[:, 0:128]
-      tv_gemm<MODE>(X, TV_XS, TV_E, TV_FF, L.w1, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<MODE, TV_E, TV_FF>(X, TV_XS, L.w1, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.b1[slab * 64 + col], b1 = L.b1[slab * 64 + 32 + col];
         TV_FOR_ACC(r, row) {
           T[row * TV_TS + slab * 64 + col] = fmaxf(a0[r] + b0, 0.0f);
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       }, pre, L.w2);
       TV_WAVE_SYNC();
       // ---- FF2 + residual -> X, then norm1 of the next layer
-      tv_gemm<MODE>(T, TV_TS, TV_FF, TV_E, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
+      tv_gemm<MODE, TV_FF, TV_E>(T, TV_TS, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
         const float b0 = L.b2[col], b1 = L.b2[32 + col];
         TV_FOR_ACC(r, row) {
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
