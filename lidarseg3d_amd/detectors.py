@@ -50,7 +50,8 @@ def _voxel_inputs(example, voxel_cfg, capacity=False):
         if capacity:
             # capacity mode: all min(N, cap) rows stay, the count stays on the device (batches of more points than one frame's voxel cap paid
             # one host read of the frame offsets above - before anything of the frame was submitted)
-            example["num_voxels"] = ops.frame_offsets(c, batch_size, n_dev=nv).diff()
+            # per-frame voxel counts (predict() takes its batch size from their number): one frame's is the device count itself
+            example["num_voxels"] = nv.reshape(1) if batch_size == 1 else ops.frame_offsets(c, batch_size, n_dev=nv).diff()
             return v, c, n, batch_size, np.asarray(grid), nv
         V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it
         v, c, n = v[:V], c[:V], n[:V]
@@ -119,6 +120,14 @@ def _capacity_forward(model, example, features):
     return model.point_head.predict(example=example, test_cfg=model.test_cfg)
 
 
+def _points_bxyz(points, training):
+    """the (batch, x, y, z) columns of the sweep for the point head (seg_net.py:60: example["points"][:, 0:4]).  Every kernel behind it takes a row
+    stride, so at inference a contiguous [N, 4 + k] sweep is handed on as it is: no copy kernel between the voxelization and the reader"""
+    if not training and not torch.is_grad_enabled() and points.dim() == 2 and points.shape[1] >= 4 and points.is_contiguous():
+        return points
+    return points[:, 0:4].contiguous()
+
+
 def _coords_ready(coords):
     """event on the current stream marking "voxel coordinates are final": the backbone builds its rulebooks on a side stream
     from this point on, concurrently with the reader (extra batch_dict key, not in the reference)"""
@@ -141,7 +150,7 @@ class SegNet(SingleStageDetector):
     def forward_features(self, example, capacity=False):
         voxels, coords, num, batch_size, shape, n_dev = _voxel_inputs(example, self.voxel_generator, capacity)
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
-                    points=example["points"][:, 0:4].contiguous())
+                    points=_points_bxyz(example["points"], self.training))
         data["voxel_coords_ready"] = _coords_ready(coords)
         if n_dev is not None:
             data["num_active_voxels_dev"] = n_dev
@@ -184,7 +193,7 @@ class SegMSeg3DNet(SingleStageDetector):
     def _capacity_features(self, example):
         voxels, coords, num, batch_size, shape, n_dev = _voxel_inputs(example, self.voxel_generator, True)
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
-                    points=example["points"][:, 0:4].contiguous())
+                    points=_points_bxyz(example["points"], self.training))
         data["voxel_coords_ready"] = _coords_ready(coords)
         if n_dev is None:
             raise ops.CapacityModeUnsupported("frame-by-frame voxelization")
@@ -235,7 +244,7 @@ class SegMSeg3DNet(SingleStageDetector):
         else:
             image_features, cam_emb, camera_loss = example["image_features"], example["camera_semantic_embeddings"], None
         data = dict(features=voxels, num_voxels=num, voxel_coords=coords, batch_size=batch_size, input_shape=shape,
-                    points=example["points"][:, 0:4].contiguous())
+                    points=_points_bxyz(example["points"], self.training))
         data["voxel_coords_ready"] = _coords_ready(coords)
         cam = getattr(self.point_head, "camera_branch", None)
         if cam is not None and not return_loss and not self.training:
