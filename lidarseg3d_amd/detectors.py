@@ -51,7 +51,7 @@ def _voxel_inputs(example, voxel_cfg, capacity=False):
             # capacity mode: all min(N, cap) rows stay, the count stays on the device (batches of more points than one frame's voxel cap paid
             # one host read of the frame offsets above - before anything of the frame was submitted)
             # per-frame voxel counts (predict() takes its batch size from their number): one frame's is the device count itself
-            example["num_voxels"] = nv.reshape(1) if batch_size == 1 else ops.frame_offsets(c, batch_size, n_dev=nv).diff()
+            example["num_voxels"] = nv.reshape(1) if (batch_size == 1 and _LEAN_START) else ops.frame_offsets(c, batch_size, n_dev=nv).diff()
             return v, c, n, batch_size, np.asarray(grid), nv
         V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it
         v, c, n = v[:V], c[:V], n[:V]
@@ -120,10 +120,13 @@ def _capacity_forward(model, example, features):
     return model.point_head.predict(example=example, test_cfg=model.test_cfg)
 
 
+_LEAN_START = _os.environ.get("LS3D_LEAN_START", "1") != "0"  # A/B: without the three small launches between the voxelization and the reader
+
+
 def _points_bxyz(points, training):
     """the (batch, x, y, z) columns of the sweep for the point head (seg_net.py:60: example["points"][:, 0:4]).  Every kernel behind it takes a row
     stride, so at inference a contiguous [N, 4 + k] sweep is handed on as it is: no copy kernel between the voxelization and the reader"""
-    if not training and not torch.is_grad_enabled() and points.dim() == 2 and points.shape[1] >= 4 and points.is_contiguous():
+    if _LEAN_START and not training and not torch.is_grad_enabled() and points.dim() == 2 and points.shape[1] >= 4 and points.is_contiguous():
         return points
     return points[:, 0:4].contiguous()
 

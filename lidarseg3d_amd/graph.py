@@ -72,8 +72,20 @@ class FrameGraph(object):
         return all(k in example and torch.is_tensor(example[k]) and tuple(example[k].shape) == s and example[k].dtype == d
                    for k, (s, d) in self.shapes.items()) and int(example.get("batch_size", 1)) == self.batch_size
 
+    _shared_replay_stream = {}  # device -> handle of the stream the graphs captured WITHOUT `stream=` are replayed on
+
     def launch(self, example):
         """copy the inputs and replay on the CURRENT stream, without waiting (the example must match the captured shapes); finish() next"""
+        cur = torch.cuda.current_stream()
+        if self.stream is None:
+            # graphs captured on torch's shared capture stream have the SAME arrival counters of the tile kernel's channel split baked in
+            # (ops keys them by the capture stream): replayed side by side on two streams they would race on the counters' parity
+            seen = FrameGraph._shared_replay_stream.setdefault(cur.device, cur.cuda_stream)
+            if seen != cur.cuda_stream:
+                raise RuntimeError("FrameGraphs captured without stream= share the tile kernel's arrival counters and must be replayed on ONE "
+                                   "stream; capture each frame slot with its own stream= to run them side by side")
+        elif cur.cuda_stream != self.stream.cuda_stream:
+            raise RuntimeError("a FrameGraph captured with stream= is replayed on that stream (its arrival counters belong to it)")
         for k in self.shapes:
             self.static[k].copy_(example[k], non_blocking=True)
         self.graph.replay()

@@ -466,6 +466,10 @@ def test_frame_graph_equals_eager_forward_120k(kind):
         assert fg2.recaptures == 1 and torch.equal(ret[0]["pred_point_sem_labels"], want[1][1])
         ret = fg2(ex0)
         assert fg2.recaptures == 1 and torch.equal(ret[0]["pred_point_sem_labels"], want[0][1]) and torch.equal(fg2.logits, want[0][0])
+        # graphs captured without stream= share the tile kernel's arrival counters: replaying one beside the other on a second stream is refused
+        with torch.cuda.stream(torch.cuda.Stream()):
+            with pytest.raises(RuntimeError, match="ONE stream"):
+                fg.launch(ex0)
     finally:
         ops.set_precision("f32")
 
