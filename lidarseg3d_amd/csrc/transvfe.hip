@@ -257,6 +257,81 @@ __device__ __forceinline__ void tv_layernorm(float *X, const float *g, const flo
   }
 }
 
+// self-attention of the tokens of a voxel (<= 32 rows): one lane per (voxel g, head h, query t); q | k | v at columns 0 | E | 2 E of T, the output
+// replaces q.  RC = rows per voxel at compile time (0: run time, RR): the scores are computed once and kept, the loops are straight code.
+template <int RC>
+__device__ __forceinline__ void tv_attention(float *T, int G, int kpts, float wpad, int lane, int RR = RC) {
+  constexpr int RM = RC > 0 ? RC : 32;
+  const int R = RC > 0 ? RC : RR;
+  const float scale = 1.0f / sqrtf((float)TV_HD);
+  const int items = G * TV_H * R;
+  for (int ps = 0; ps * 64 < items; ++ps) {
+    const int it = lane + 64 * ps;
+    const bool on = it < items;
+    const int g = on ? it / (TV_H * R) : 0, rem = on ? it - g * TV_H * R : 0;
+    const int h = rem / R, t = rem - h * R;
+    float *qp = T + (g * R + t) * TV_TS + h * TV_HD;
+    float q[TV_HD], o[TV_HD];
+#pragma unroll
+    for (int d = 0; d < TV_HD; ++d) { q[d] = qp[d] * scale; o[d] = 0.0f; }
+    if constexpr (RC > 0) {
+      float sc[RM];
+      float m = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < RM; ++j) {
+        const float *kp = T + (g * R + j) * TV_TS + TV_E + h * TV_HD;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
+        sc[j] = s;
+        m = fmaxf(m, s);
+      }
+      float den = 0.0f;
+#pragma unroll
+      for (int j = 0; j < RM; ++j) {
+        const float *vp = T + (g * R + j) * TV_TS + 2 * TV_E + h * TV_HD;
+        float pr = expf(sc[j] - m);
+        if (j >= kpts) pr *= wpad;  // the padding row stands for P - kpts identical keys
+        den += pr;
+#pragma unroll
+        for (int d = 0; d < TV_HD; ++d) o[d] = fmaf(pr, vp[d], o[d]);
+      }
+      const float inv = 1.0f / den;
+      if (on) {
+#pragma unroll
+        for (int d = 0; d < TV_HD; ++d) qp[d] = o[d] * inv;
+      }
+    } else {
+      float m = -3.0e38f;
+      for (int j = 0; j < R; ++j) {
+        const float *kp = T + (g * R + j) * TV_TS + TV_E + h * TV_HD;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
+        m = fmaxf(m, s);
+      }
+      float den = 0.0f;
+      for (int j = 0; j < R; ++j) {
+        const float *kp = T + (g * R + j) * TV_TS + TV_E + h * TV_HD;
+        const float *vp = kp + TV_E;
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
+        float pr = expf(s - m);
+        if (j >= kpts) pr *= wpad;  // the padding row stands for P - kpts identical keys
+        den += pr;
+#pragma unroll
+        for (int d = 0; d < TV_HD; ++d) o[d] = fmaf(pr, vp[d], o[d]);
+      }
+      const float inv = 1.0f / den;
+      if (on) {
+#pragma unroll
+        for (int d = 0; d < TV_HD; ++d) qp[d] = o[d] * inv;
+      }
+    }
+  }
+}
+
 // Token deduplication (cls != NULL).  The reference runs the transformer over all P point slots of a voxel, zero padding included
 // and unmasked (voxel_encoder.py:154-161), so the padding slots of a voxel are IDENTICAL tokens (zero point + the voxel's descriptor)
 // and stay identical through every layer (the layers are permutation-equivariant).  A voxel with k < P points therefore has k + 1
@@ -363,46 +438,15 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
         }
       }, pre, L.wo);
       TV_WAVE_SYNC();
-      // ---- attention inside each voxel: one lane per (voxel g, head h, query token t); output over the query's slice
-      {
-        const float scale = 1.0f / sqrtf((float)TV_HD);
-        const int items = G * TV_H * R;
-        for (int ps = 0; ps * 64 < items; ++ps) {
-          const int it = lane + 64 * ps;
-          const bool on = it < items;
-          const int g = on ? it / (TV_H * R) : 0, rem = on ? it - g * TV_H * R : 0;
-          const int h = rem / R, t = rem - h * R;
-          float *qp = T + (g * R + t) * TV_TS + h * TV_HD;
-          float q[TV_HD], o[TV_HD];
-#pragma unroll
-          for (int d = 0; d < TV_HD; ++d) { q[d] = qp[d] * scale; o[d] = 0.0f; }
-          float m = -3.0e38f;
-          for (int j = 0; j < R; ++j) {
-            const float *kp = T + (g * R + j) * TV_TS + TV_E + h * TV_HD;
-            float s = 0.0f;
-#pragma unroll
-            for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
-            m = fmaxf(m, s);
-          }
-          float den = 0.0f;
-          for (int j = 0; j < R; ++j) {
-            const float *kp = T + (g * R + j) * TV_TS + TV_E + h * TV_HD;
-            const float *vp = kp + TV_E;
-            float s = 0.0f;
-#pragma unroll
-            for (int d = 0; d < TV_HD; ++d) s = fmaf(q[d], kp[d], s);
-            float pr = expf(s - m);
-            if (j >= kpts) pr *= wpad;  // the padding row stands for P - kpts identical keys
-            den += pr;
-#pragma unroll
-            for (int d = 0; d < TV_HD; ++d) o[d] = fmaf(pr, vp[d], o[d]);
-          }
-          const float inv = 1.0f / den;
-          if (on) {
-#pragma unroll
-            for (int d = 0; d < TV_HD; ++d) qp[d] = o[d] * inv;
-          }
-        }
+      // ---- attention inside each voxel: one lane per (voxel g, head h, query token t); output over the query's slice.  The rows per voxel R
+      //      (1 .. P, wave-uniform) select a compile-time instance: scores once, all key / value reads of a query issued together
+      switch (R) {
+        case 1: tv_attention<1>(T, G, kpts, wpad, lane); break;
+        case 2: tv_attention<2>(T, G, kpts, wpad, lane); break;
+        case 3: tv_attention<3>(T, G, kpts, wpad, lane); break;
+        case 4: tv_attention<4>(T, G, kpts, wpad, lane); break;
+        case 5: tv_attention<5>(T, G, kpts, wpad, lane); break;
+        default: tv_attention<0>(T, G, kpts, wpad, lane, R); break;
       }
       TV_WAVE_SYNC();
       // ---- out-proj + residual (from the normed X) -> X, then norm2
