@@ -218,6 +218,15 @@ def parity_vs_cpu(gpu_logits, cpu_logits, num_class=17):
                 within_1e3_at_scale_10=bool(10.0 * float(d.max()) / scale <= 1e-3))
 
 
+def cpu_quota():
+    """CPUs this process may use at once: the cgroup v2 quota (cpu.max = "<quota> <period>"), else None"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -238,7 +247,10 @@ def cpu_baseline(n_points, seed, gpu_logits=None):
         frame, scaled linearly; if that does not finish in 60 s, a quarter of the threads (the sweep is recorded);
       * `single_thread`: 1 thread, median of 5 warmed runs of a 1/8-size frame, scaled likewise."""
     cores = os.cpu_count() or 1
-    threads = min(cores, 32)
+    quota = cpu_quota()
+    # the thread count of `value`: where the restatement's torch-CPU index_add_ / mm stop scaling (32), and never more than the container's
+    # CPU quota (a 256-thread host behind a 16-CPU cgroup quota runs 256 OpenMP threads 20x slower than 16)
+    threads = max(1, min(cores, 32, int(quota + 0.999) if quota else cores))
     dump = None
     if gpu_logits is not None and gpu_logits.shape[0] == n_points:
         import tempfile
@@ -248,8 +260,8 @@ def cpu_baseline(n_points, seed, gpu_logits=None):
         ts = _cpu_run(n_points, seed, threads, 5, 400, dump)
         out = dict(value=1.0 / med(ts), unit="frames/s", cores=threads, kind="port", cpu_model=cpu_model(), host_threads=cores,
                    sample="median of 5 warmed runs of 1 frame of %d points (%s s), full SDSeg3D forward incl. CPU voxelization, %d of %d host "
-                          "threads; oracle/ref.py (torch-CPU gather-mm-scatter spconv restatement, OpenMP C exact 3-NN)"
-                          % (n_points, "/".join("%.1f" % t for t in ts), threads, cores))
+                          "threads%s; oracle/ref.py (torch-CPU gather-mm-scatter spconv restatement, OpenMP C exact 3-NN)"
+                          % (n_points, "/".join("%.1f" % t for t in ts), threads, cores, (" (cgroup quota: %.0f CPUs)" % quota) if quota else ""))
     except Exception as e:  # never let the baseline take the bench down
         return dict(value=None, unit="frames/s", cores=threads, kind="port", cpu_model=cpu_model(), sample="failed: %r" % (e,))
     if dump is not None:
@@ -262,9 +274,9 @@ def cpu_baseline(n_points, seed, gpu_logits=None):
                 os.remove(dump)
     try:
         out["usable_threads"] = len(os.sched_getaffinity(0))
-        out["cgroup_cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
     except (OSError, AttributeError):
         pass
+    out["cpu_quota"] = quota  # CPUs' worth of time the container gets (None: no cgroup quota)
 
     def small_leg(thr, div, timeout_s, passive):
         small = max(n_points // div, 1000)

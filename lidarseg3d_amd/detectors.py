@@ -41,7 +41,7 @@ def _voxel_inputs(example, voxel_cfg, capacity=False):
     mp = voxel_cfg.get("max_points_in_voxel", 5)
     _, grid = ops.make_grid(voxel_cfg["voxel_size"], voxel_cfg["range"])
     off = None
-    if points.shape[0] > int(mv) and batch_size > 1:
+    if points.shape[0] > int(mv) and batch_size > 1 and not capacity:
         off = ops.frame_offsets(points, batch_size).tolist()  # one host sync: can any single frame reach the per-frame cap?
     if off is None or max(b - a for a, b in zip(off[:-1], off[1:])) <= int(mv):
         # no frame can reach the dataloader's per-frame cap (a frame has at most as many voxels as points): one batched launch
@@ -52,6 +52,11 @@ def _voxel_inputs(example, voxel_cfg, capacity=False):
             # one host read of the frame offsets above - before anything of the frame was submitted)
             # per-frame voxel counts (predict() takes its batch size from their number): one frame's is the device count itself
             example["num_voxels"] = nv.reshape(1) if (batch_size == 1 and _LEAN_START) else ops.frame_offsets(c, batch_size, n_dev=nv).diff()
+            if points.shape[0] > int(mv) and batch_size > 1:
+                # the batch has more points than ONE frame's voxel cap: whether a single frame exceeds it is decided on the device (no host read, so
+                # the batch can be captured: graph.FrameGraph) - the flag joins the rulebooks' overflow flags, and a frame that trips it is run
+                # again on host-side counts, which caps each frame as the reference's dataloader does
+                example["_voxel_overflow_dev"] = (example["num_voxels"] > int(mv)).any().to(torch.int32).reshape(1)
             return v, c, n, batch_size, np.asarray(grid), nv
         V = int(nv.item())  # one host sync per batch: downstream tensor shapes depend on it
         v, c, n = v[:V], c[:V], n[:V]
@@ -157,6 +162,7 @@ class SegNet(SingleStageDetector):
         data["voxel_coords_ready"] = _coords_ready(coords)
         if n_dev is not None:
             data["num_active_voxels_dev"] = n_dev
+            data["voxel_overflow_dev"] = example.pop("_voxel_overflow_dev", None)
             data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"], n_dev=n_dev)
         else:
             data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"])
@@ -204,6 +210,7 @@ class SegMSeg3DNet(SingleStageDetector):
         if cam is not None:  # depends on the frame's inputs only: beside the reader and the backbone
             data["camera_branch"] = cam(example["image_features"], example["points_cuv"], data["points"])
         data["num_active_voxels_dev"] = n_dev
+        data["voxel_overflow_dev"] = example.pop("_voxel_overflow_dev", None)
         data["voxel_features"] = self.reader(data["features"], data["num_voxels"], data["voxel_coords"], n_dev=n_dev)
         data = self.backbone(data)
         data.update(points_cuv=example["points_cuv"], image_features=example["image_features"],

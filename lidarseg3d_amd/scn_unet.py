@@ -477,6 +477,9 @@ class UNetSCN3D(nn.Module):
             else:
                 spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps, after_each=lambda: rb_events.append(gs.finish_event()))
             cnts = torch.stack([torch.cat([x.indice_dict[c.indice_key].n_out_dev, x.indice_dict[c.indice_key].overflow_dev]) for c in chain])
+            vflag = batch_dict.get("voxel_overflow_dev")
+            if vflag is not None:  # a frame of the batch exceeded the voxelizer's per-frame cap (detectors._voxel_inputs): reported as an overflow
+                cnts[0, 1:2] += vflag.to(cnts.dtype)
             if cnts.is_cuda:
                 # one pinned buffer per model: a frame's counts are read (geometry_check) before the next frame is submitted, and a
                 # captured frame (graph.FrameGraph) needs the same host address on every replay

@@ -1415,6 +1415,46 @@ def test_capacity_mode_equals_host_count_mode_bit_for_bit(kind, precs, monkeypat
             ops.set_tile(True, min_cc=512)
 
 
+def test_capacity_mode_batch_beyond_one_frames_voxel_cap(monkeypatch):
+    """a batch with more points than ONE frame's voxel cap (max_voxel_num): capacity mode does not read the frame sizes on the host any more - the
+    per-frame cap is checked on the device and reported with the rulebooks' overflow flags.  No frame over the cap: the capacity frame stands
+    (one pass, no host read); a frame over it: the frame is run again on host-side counts, which caps EACH frame as the reference's dataloader
+    does - identical to the host-count mode either way"""
+    import lidarseg3d_amd as L
+    from lidarseg3d_amd import detectors, models_cfg
+    cfg = synth.NUSC
+    frames = [synth.lidar_frame(110, seed=41, **cfg), synth.lidar_frame(60, seed=42, **cfg)]
+    pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)]))
+    for cap, reruns in ((120, 0), (70, 1)):  # 170 points in the batch; frame 0 has ~100 voxels
+        mcfg = models_cfg.sdseg3d()
+        mcfg["backbone"]["model_cfg"] = dict(SCALING_RATIO=1)
+        mcfg["point_head"]["model_cfg"]["CONV_IN_DIM"] = 16
+        mcfg["voxel_generator"]["max_voxel_num"] = cap
+        model = L.build_detector(mcfg, train_cfg=None, test_cfg={}).eval()
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, 7).items()})
+        bb = model.backbone
+        orig_caps = bb._capacities
+        monkeypatch.setattr(bb, "_capacities", lambda n, b, sh: [min(w, 6 * n) for w in orig_caps(n, b, sh)])
+        seen, reads = [], []
+        orig_fc = bb._forward_capacity
+        monkeypatch.setattr(bb, "_forward_capacity", lambda *a, **k: (seen.append(1), orig_fc(*a, **k))[1])
+        orig_vi = detectors._voxel_inputs
+        monkeypatch.setattr(detectors, "_voxel_inputs", lambda e, c, capacity=False: (reads.append(capacity), orig_vi(e, c, capacity))[1])
+
+        def run(capacity):
+            monkeypatch.setattr(detectors, "CAPACITY_MODE", capacity)
+            with torch.no_grad():
+                ret = model(dict(points=pts, batch_size=2), return_loss=False)
+            return model.point_head.forward_ret_dict["out_logits"].clone(), [r["pred_point_sem_labels"].clone() for r in ret]
+        want, wl = run(False)
+        del seen[:], reads[:]
+        got, gl = run(True)
+        assert torch.equal(got, want) and all(torch.equal(a, b) for a, b in zip(gl, wl))
+        assert len(seen) == 1 and reads == [True] + [False] * reruns, (cap, reads)
+        monkeypatch.undo()
+
+
 @pytest.mark.parametrize("n,bits", [(1, 8), (255, 8), (2049, 13), (5000, 20), (4097, 31)])
 def test_radix_sort_is_a_stable_argsort(n, bits):
     rng = np.random.default_rng(n)
