@@ -14,6 +14,8 @@ python tools/timeline.py $(find /tmp/tl_g -name bench_kernel_trace.csv | head -1
 python tools/timeline.py $(find /tmp/tl_e -name bench_kernel_trace.csv | head -1) > $P3/round${ROUND}_timeline_eager_final.txt 2>&1
 timeout 900 python bench.py --steps 20 --warmup 5 > $P3/round${ROUND}_bench.json 2> $P3/bench.err; echo "bench rc=$?" >> $P3/summary.txt
 timeout 400 python bench.py --model mseg3d --no-cpu-baseline --no-extra-modes --steps 20 --warmup 5 > $P3/round${ROUND}_bench_mseg3d.json 2>> $P3/bench.err
+timeout 200 python tools/bench_decoder.py --out $P3/round${ROUND}_decoder.json > $P3/round${ROUND}_decoder.txt 2>&1
+timeout 200 python tools/probe_stack_brackets.py > $P3/round${ROUND}_stack_brackets.txt 2>&1
 if [ "${TRAIN:-1}" = "1" ]; then
 for P in bf16x6 f32; do
   timeout 400 python tools/bench_train_step.py --model mseg3d --geometry waymo --points 180000 --frames 2 --steps 5 --warmup 2 --precision $P > $P3/round${ROUND}_train_step_mseg3d_waymo_2frames_$P.json 2>> $P3/train.err
