@@ -168,7 +168,12 @@ class PointSegBatchlossHead(PackedModule):
         pk = self.packed()
         batch_size = batch_dict["batch_size"]
         feat = batch_dict["conv_point_features"]
-        self.forward_ret_dict["conv_logits"] = _run_mlp(feat, pk["conv_cls"])
+        # the voxel-level logits feed get_loss only (point_seg_batchloss_head.py:77-121); nothing reads them at inference, so - like the mimic branch
+        # of the MSeg3D head - they are not evaluated there (two launches on 65k voxels; set_eval_aux(True) / LS3D_EVAL_AUX_LOGITS=1 restores them)
+        if _EVAL_AUX_LOGITS:
+            self.forward_ret_dict["conv_logits"] = _run_mlp(feat, pk["conv_cls"])
+        else:
+            self.forward_ret_dict.pop("conv_logits", None)
         points = batch_dict["points"].contiguous()
         centers = batch_dict["conv_point_coords"]
         pf, _ = _devoxelize(batch_dict, points, centers, feat, batch_size)
@@ -247,6 +252,14 @@ import os as _os
 _HEAD_STREAMS = {}
 _HEAD_OVERLAP = _os.environ.get("LS3D_HEAD_OVERLAP", "1") != "0"  # MSeg3D head: camera branch / class-embedding side on their own streams
 _EVAL_MIMIC = _os.environ.get("LS3D_EVAL_MIMIC", "0") != "0"
+_EVAL_AUX_LOGITS = _os.environ.get("LS3D_EVAL_AUX_LOGITS", "0") != "0"  # PointSegBatchlossHead: voxel-level logits at inference (loss-only outputs)
+
+
+def set_eval_aux(on):
+    """evaluate the loss-only outputs of the point heads at inference as the reference does (tests that compare them with the golden vectors)"""
+    global _EVAL_AUX_LOGITS
+    _EVAL_AUX_LOGITS = bool(on)
+
 _FUSED_SFFM = _os.environ.get("LS3D_FUSED_SFFM", "1") != "0"
 # the class-embedding side of all decoder layers in one launch (ls3d_sffm_memory) instead of ~40 small ones: 0.21 ms instead of 0.37 ms per frame
 # on the device since round 4 (round 3's first version was slower than the launches: 0.66 ms); LS3D_FUSED_SFFM_MEMORY=0: layer by layer

@@ -218,8 +218,12 @@ def test_batchloss_head_vs_golden():
                                                               OUT_CLS_FC=[64, 64], IGNORED_LABEL=0))
     head.load_state_dict(seeded_sd("point_head.PointSegBatchlossHead", g["seed"]), strict=True)
     head.to(DEV).eval()
-    bd = head(dict(batch_size=1, conv_point_features=cu(g["conv_point_features"]), conv_point_coords=cu(g["conv_point_coords"]),
-                   points=cu(g["points"][:, :4].copy())), return_loss=False)
+    point_heads.set_eval_aux(True)  # the voxel-level logits are loss-only outputs: not evaluated at inference by default
+    try:
+        bd = head(dict(batch_size=1, conv_point_features=cu(g["conv_point_features"]), conv_point_coords=cu(g["conv_point_coords"]),
+                       points=cu(g["points"][:, :4].copy())), return_loss=False)
+    finally:
+        point_heads.set_eval_aux(False)
     scale = np.abs(g["out_logits"]).max()
     np.testing.assert_allclose(bd["out_logits"].cpu().numpy(), g["out_logits"], rtol=0, atol=1e-3 + 2e-5 * scale)
     np.testing.assert_allclose(head.forward_ret_dict["conv_logits"].cpu().numpy(), g["conv_logits"], rtol=0,
