@@ -72,6 +72,27 @@ _N_SIDE = int(_os.environ.get("LS3D_GEOM_STREAMS", "2"))
 # leave CUs idle - and the decoder picks it up with one event.  Same kernels on the same inputs: bit-identical.  LS3D_LATERAL_STREAM=0: inline.
 _EARLY_ORDER = int(_os.environ.get("LS3D_EARLY_ORDER", "0"))  # capacity mode: the first strided layer's row order from its own early sort (2: on the rulebook chain's stream, 1: behind the level-1 geometry)
 _LATERAL = _os.environ.get("LS3D_LATERAL_STREAM", "1") != "0"
+# capacity mode: `encoded_spconv_tensor` (scn_unet.py:218-222: conv_out of the deepest level) feeds no segmentation head - the key holds a proxy that
+# runs the convolution (and builds its rulebook) when something reads it, instead of one more rulebook, mask sort and launch beside every frame
+_LAZY_ENCODED = _os.environ.get("LS3D_LAZY_ENCODED", "1") != "0"
+
+
+class _LazyEncoded(object):
+    """stands in for the SparseConvTensor under batch_dict["encoded_spconv_tensor"]: computed on first attribute access (before the next frame
+    overwrites its inputs when the frame is a graph replay)"""
+
+    def __init__(self, fn):
+        self.__dict__["_fn"], self.__dict__["_value"] = fn, None
+
+    def materialize(self):
+        if self.__dict__["_value"] is None:
+            with torch.no_grad():
+                self.__dict__["_value"] = self.__dict__["_fn"]()
+            self.__dict__["_fn"] = None
+        return self.__dict__["_value"]
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
 _LATERAL_STREAMS = {}
 
 
@@ -392,7 +413,8 @@ class UNetSCN3D(nn.Module):
     _caps = None  # {strided layer key: [capacity of its output sites, largest count seen]} - adapted from the frames seen so far
 
     def _strided_chain(self):
-        return [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if self.conv_out is not None else [])
+        """the strided convolutions whose rulebooks a capacity-mode frame builds up front (conv_out's only when its output is computed eagerly)"""
+        return [self.conv2[0][0], self.conv3[0][0], self.conv4[0][0]] + ([self.conv_out[0]] if (self.conv_out is not None and not _LAZY_ENCODED) else [])
 
     def _capacities(self, n_in_cap, batch_size, shape):
         """output capacities of the encoder's strided convolutions for an input capacity of n_in_cap rows.  Worst case (every input
@@ -539,7 +561,11 @@ class UNetSCN3D(nn.Module):
                 lats[1 - lvl] = self._lateral_launch(x_enc, self.conv_up_t2 if lvl == 0 else self.conv_up_t3, cats[1 - lvl])
         x_conv4 = x_enc
         self._wait(x, counts_copied)  # joins stream 1 (matters for a captured frame: no unjoined work at the end of the capture)
-        conv_out_done = self._conv_out(batch_dict, x_conv4)
+        if _LAZY_ENCODED and self.conv_out is not None:
+            batch_dict["encoded_spconv_tensor"], batch_dict["encoded_spconv_tensor_stride"] = _LazyEncoded(lambda t=x_conv4: self.conv_out(t)), 8
+            conv_out_done = None
+        else:
+            conv_out_done = self._conv_out(batch_dict, x_conv4)
         x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4, next_cat=cats[0])
         x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1], lateral=lats[0])
         x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2], lateral=lats[1])

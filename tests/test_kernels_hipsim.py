@@ -1415,6 +1415,36 @@ def test_capacity_mode_equals_host_count_mode_bit_for_bit(kind, precs, monkeypat
             ops.set_tile(True, min_cc=512)
 
 
+def test_capacity_mode_encoded_tensor_is_computed_on_demand(monkeypatch):
+    """capacity mode leaves batch_dict["encoded_spconv_tensor"] (conv_out of the deepest level: no segmentation head reads it) as a proxy that runs
+    the convolution - and builds its rulebook - on first access: same sites and features as the eager conv_out of the same frame, and a frame that
+    never reads it builds three strided rulebooks instead of four"""
+    import lidarseg3d_amd as L
+    from lidarseg3d_amd import models_cfg, scn_unet
+    cfg = synth.NUSC
+    mcfg = models_cfg.sdseg3d()
+    mcfg["backbone"]["model_cfg"] = dict(SCALING_RATIO=1)
+    mcfg["point_head"]["model_cfg"]["CONV_IN_DIM"] = 16
+    model = L.build_detector(mcfg, train_cfg=None, test_cfg={}).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, 7).items()})
+    f = synth.lidar_frame(120, seed=41, **cfg)
+    pts = torch.from_numpy(np.concatenate([np.zeros((f.shape[0], 1), np.float32), f], 1))
+    bb = model.backbone
+    orig_caps = bb._capacities
+    monkeypatch.setattr(bb, "_capacities", lambda n, b, sh: [min(w, 6 * n) for w in orig_caps(n, b, sh)])
+    got = {}
+    for lazy in (True, False):
+        monkeypatch.setattr(scn_unet, "_LAZY_ENCODED", lazy)
+        with torch.no_grad():
+            data = model.forward_features(dict(points=pts, batch_size=1), capacity=True)
+        enc = data["encoded_spconv_tensor"]
+        assert isinstance(enc, scn_unet._LazyEncoded) == lazy and len(bb._strided_chain()) == (3 if lazy else 4)
+        n = int(enc.n_dev) if enc.n_dev is not None else enc.features.shape[0]
+        got[lazy] = (enc.indices[:n].clone(), enc.features[:n].clone())
+    assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1]) and got[True][0].shape[0] > 0
+
+
 def test_capacity_mode_batch_beyond_one_frames_voxel_cap(monkeypatch):
     """a batch with more points than ONE frame's voxel cap (max_voxel_num): capacity mode does not read the frame sizes on the host any more - the
     per-frame cap is checked on the device and reported with the rulebooks' overflow flags.  No frame over the cap: the capacity frame stands
