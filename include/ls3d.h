@@ -461,6 +461,20 @@ int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const
 int ls3d_interpolate_rows(const float *feat, int feat_ld, int c, const int32_t *idx, const float *weight, const float *points,
                           int pt_stride, const int32_t *vx_off, int n_points, float *out, int out_ld, ls3d_stream_t stream);
 
+/* The per-point tail of PointSegBatchlossHead at inference (det3d/models/point_heads/point_seg_batchloss_head.py:141-168) in ONE launch:
+ *   x[p] = sum_j weight[p][j] * feat[vx_off[frame(p)] + idx[p][j]]   (the arithmetic of ls3d_interpolate_rows; idx == NULL: x[p] = feat[p])
+ *   for every layer: x = [relu](x W * scale + shift)                  (Linear + BatchNorm(eval) + ReLU folded; scale / shift may be NULL)
+ *   out[p, 0:cout_last] = x;  labels[p] = argmax over the classes with torch.argmax's tie rule (labels may be NULL).
+ * W: plain [cin][cout] f32 row-major on the device.  c_in and the hidden widths are 32 or 64, the last layer's cout <= 64, <= 6 layers;
+ * anything else: LS3D_ERR_UNSUPPORTED (compose it from ls3d_interpolate_rows + ls3d_gather_gemm).  Exact f32 products (f32 MFMA). */
+typedef struct {
+  const float *w, *scale, *shift;
+  int32_t cin, cout, relu;
+} ls3d_point_mlp_layer_t;
+int ls3d_point_mlp(const float *feat, int feat_ld, int c_in, const int32_t *idx, const float *weight, const float *points, int pt_stride,
+                   const int32_t *vx_off, int n, int num_layers, const ls3d_point_mlp_layer_t *layers_host, float *out, int out_ld,
+                   int64_t *labels, ls3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LiDAR-camera fusion (MSeg3D point head)
  * ---------------------------------------------------------------------------------------------- */

@@ -996,6 +996,38 @@ def devoxelize_grid(points, pt_off, coords, centers, vx_off, batch, voxel_size, 
     return (out, idx) if return_idx else out
 
 
+class PointMlp(object):
+    """plain layers of a per-point Linear (+ BatchNorm(eval) + ReLU) chain for ls3d_point_mlp: [(W [cin, cout] f32, scale | None, shift | None, relu)]"""
+
+    def __init__(self, layers):
+        from ._lib import PointMlpLayer
+        self.keep = [(w.contiguous(), None if sc is None else sc.contiguous(), None if sh is None else sh.contiguous(), bool(r)) for w, sc, sh, r in layers]
+        self.c = (PointMlpLayer * len(self.keep))()
+        for i, (w, sc, sh, r) in enumerate(self.keep):
+            self.c[i] = PointMlpLayer(w.data_ptr(), 0 if sc is None else sc.data_ptr(), 0 if sh is None else sh.data_ptr(), int(w.shape[0]), int(w.shape[1]),
+                                      1 if r else 0)
+        self.c_in, self.c_out = int(self.keep[0][0].shape[0]), int(self.keep[-1][0].shape[1])
+
+    def supported(self):
+        widths = [w.shape[1] for w, _, _, _ in self.keep]
+        return (self.c_in in (32, 64) and len(self.keep) <= 6 and all(c in (32, 64) for c in widths[:-1]) and widths[-1] <= 64
+                and sum(w.shape[0] * 72 + 128 for w, _, _, _ in self.keep) * 4 <= 80 * 1024)
+
+
+_POINT_MLP = _os.environ.get("LS3D_POINT_MLP", "1") != "0"  # A/B: the per-point tail of PointSegBatchlossHead in one launch
+
+
+def point_mlp(feat, model, idx=None, weight=None, points=None, vx_off=None, n=None, want_labels=True):
+    """include/ls3d.h: ls3d_point_mlp.  idx / weight / points / vx_off: the 3-NN interpolation of `feat` in front of the chain (None: the chain runs on
+    the rows of feat).  -> (out [n, c_out] f32, labels [n] int64 | None)"""
+    n = (idx.shape[0] if idx is not None else feat.shape[0]) if n is None else n
+    out = torch.empty((n, model.c_out), dtype=torch.float32, device=feat.device)
+    labels = torch.empty((n,), dtype=torch.int64, device=feat.device) if want_labels else None
+    check(_L().ls3d_point_mlp(_ptr(feat), feat.shape[1], model.c_in, _ptr(idx), _ptr(weight), _ptr(points), points.shape[1] if points is not None else 1,
+                              _ptr(vx_off), n, len(model.keep), model.c, _ptr(out), model.c_out, _ptr(labels), _stream(feat)), "ls3d_point_mlp")
+    return out, labels
+
+
 def interpolate_rows(feat, idx, weight, points, vx_off, c=None):
     """second half of a split devoxelize_grid: out[p] = sum_j weight[p,j] * feat[vx_off[frame(p)] + idx[p,j]]"""
     n = points.shape[0]

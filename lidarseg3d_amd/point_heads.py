@@ -37,6 +37,26 @@ def _pack_mlp(seq):
     return out
 
 
+def _plain_mlp(mods):
+    """(Linear, BN?, ReLU?)* as ops.PointMlp (plain [cin, cout] weights, BatchNorm(eval) / bias folded to scale / shift), None when the chain
+    does not fit ls3d_point_mlp"""
+    from .packing import fold_bn
+    mods = [m for m in mods if not isinstance(m, nn.Dropout)]
+    layers, i = [], 0
+    while i < len(mods):
+        lin = mods[i]
+        if not isinstance(lin, nn.Linear):
+            return None
+        bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+        j = i + (2 if bn is not None else 1)
+        relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+        scale, shift = fold_bn(lin.bias, bn, lin.out_features, lin.weight.device)
+        layers.append((lin.weight.detach().float().t().contiguous(), scale, shift, relu))
+        i = j + (1 if relu else 0)
+    m = ops.PointMlp(layers)
+    return m if m.supported() else None
+
+
 def _run_mlp(x, packed):
     for pk, relu in packed:
         x = _lin(x, pk, relu=relu)
@@ -111,7 +131,9 @@ def _predict(head, example, test_cfg):
                 left += n
             ret_list.append(ret)
         return ret_list
-    labels = torch.argmax(logits, dim=1)
+    labels = head.forward_ret_dict.get("out_labels")  # the fused tail's argmax (ls3d_point_mlp), else torch's
+    if labels is None or labels.shape[0] != logits.shape[0]:
+        labels = torch.argmax(logits, dim=1)
     if example.get("_unsplit_predict"):  # graph.FrameGraph with several frames: the split by frame (host-synchronising masks) follows the replay
         return [dict(metadata=None, pred_point_sem_labels=labels)]
     if batch_size == 1:  # one frame: no masking (boolean-mask indexing would force a host sync)
@@ -144,12 +166,13 @@ class PointSegBatchlossHead(PackedModule):
 
     def _pack(self):
         return dict(conv_cls=_pack_mlp(self.conv_cls_layers), align=_pack_mlp(self.conv_align_layers),
-                    out_cls=_pack_mlp(self.out_cls_layers))
+                    out_cls=_pack_mlp(self.out_cls_layers), tail=_plain_mlp(list(self.conv_align_layers) + list(self.out_cls_layers)))
 
     def _forward_train(self, batch_dict, return_loss):
         """point_seg_batchloss_head.py:124-168 with autograd: the MLPs are the torch modules themselves (batch-statistics
         BatchNorm), the devoxelization = HIP neighbour search (no gradient) + a differentiable weighted gather"""
         feat = batch_dict["conv_point_features"]
+        self.forward_ret_dict.pop("out_labels", None)
         conv_logits = self.conv_cls_layers(feat)
         points = batch_dict["points"].contiguous()
         idx, w, vx_off = _devox_search(batch_dict, points, batch_dict["conv_point_coords"], batch_dict["batch_size"])
@@ -176,8 +199,18 @@ class PointSegBatchlossHead(PackedModule):
             self.forward_ret_dict.pop("conv_logits", None)
         points = batch_dict["points"].contiguous()
         centers = batch_dict["conv_point_coords"]
-        pf, _ = _devoxelize(batch_dict, points, centers, feat, batch_size)
-        out = _run_mlp(_run_mlp(pf, pk["align"]), pk["out_cls"])
+        ds = batch_dict.get("devox_search")
+        tail = pk["tail"]
+        self.forward_ret_dict.pop("out_labels", None)
+        if (ops._POINT_MLP and tail is not None and ds is not None and ds["centers"] is centers and ds["points"] is points and feat.is_contiguous()
+                and feat.shape[1] == tail.c_in):
+            # interpolation + conv_align_layers + out_cls_layers + argmax in ONE launch (include/ls3d.h: ls3d_point_mlp): layer by layer that is
+            # seven latency-bound launches with every [N, 64] intermediate through HBM
+            out, labels = ops.point_mlp(feat, tail, ds["idx"], ds["weight"], points, ds["vx_off"])
+            self.forward_ret_dict["out_labels"] = labels
+        else:
+            pf, _ = _devoxelize(batch_dict, points, centers, feat, batch_size)
+            out = _run_mlp(_run_mlp(pf, pk["align"]), pk["out_cls"])
         batch_dict["out_logits"] = out
         self.forward_ret_dict["out_logits"] = out
         return batch_dict

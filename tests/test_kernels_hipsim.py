@@ -1415,6 +1415,53 @@ def test_capacity_mode_equals_host_count_mode_bit_for_bit(kind, precs, monkeypat
             ops.set_tile(True, min_cc=512)
 
 
+def test_point_head_tail_in_one_launch_equals_layer_by_layer():
+    """ls3d_point_mlp (3-NN interpolation + conv_align_layers + out_cls_layers + argmax of PointSegBatchlossHead in one kernel) against the
+    layer-by-layer path (ls3d_interpolate_rows + four ls3d_gather_gemm + torch.argmax): logits to f32 rounding (another summation order), labels
+    identical where the top two logits are not within that rounding; two ragged frames, a partial last tile; ties and NaN follow torch.argmax;
+    chains it does not cover fall back"""
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    head = point_heads.PointSegBatchlossHead(False, 17, dict(CONV_IN_DIM=32, CONV_CLS_FC=[64], CONV_ALIGN_DIM=64, OUT_CLS_FC=[64, 64], IGNORED_LABEL=0)).eval()
+    for m in head.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    V0, V1, n0, n1 = 90, 40, 170, 61
+    feat = torch.randn(V0 + V1, 32)
+    vx_off = torch.tensor([0, V0, V0 + V1], dtype=torch.int32)
+    pts = torch.cat([torch.cat([torch.zeros(n0), torch.ones(n1)])[:, None], torch.randn(n0 + n1, 3)], 1).contiguous()
+    idx = torch.from_numpy(np.concatenate([rng.integers(0, V0, size=(n0, 3)), rng.integers(0, V1, size=(n1, 3))]).astype(np.int32))
+    w = torch.rand(n0 + n1, 3)
+    w = (w / w.sum(1, keepdim=True)).contiguous()
+    pk = head.packed()
+    assert pk["tail"] is not None
+    with torch.no_grad():
+        pf = ops.interpolate_rows(feat, idx, w, pts, vx_off)
+        want = point_heads._run_mlp(point_heads._run_mlp(pf, pk["align"]), pk["out_cls"])
+        got, labels = ops.point_mlp(feat, pk["tail"], idx, w, pts, vx_off)
+    assert got.shape == want.shape == (n0 + n1, 17)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=2e-5 * float(want.abs().max()))
+    assert torch.equal(labels, torch.argmax(got, dim=1))  # the kernel's argmax of ITS logits is torch's
+    top2 = torch.topk(want, 2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4 * float(want.abs().max())
+    assert torch.equal(labels[clear], torch.argmax(want, dim=1)[clear]) and int(clear.sum()) > 200
+    # the chain on plain rows (idx = None), ties and NaN: a classifier with duplicated columns and a NaN bias entry
+    lin = torch.nn.Linear(32, 17)
+    with torch.no_grad():
+        lin.weight[5] = lin.weight[3]; lin.bias[5] = lin.bias[3]; lin.weight[12] = lin.weight[3]; lin.bias[12] = lin.bias[3]
+        lin.weight[3] *= 0; lin.weight[5] *= 0; lin.weight[12] *= 0; lin.bias[3] = lin.bias[5] = lin.bias[12] = 50.0  # three-way tie at the top
+    mdl = point_heads._plain_mlp([lin])
+    x = torch.randn(70, 32)
+    out, lab = ops.point_mlp(x, mdl)
+    np.testing.assert_allclose(out.numpy(), lin(x).detach().numpy(), rtol=0, atol=1e-4)
+    assert torch.equal(lab, torch.argmax(out, dim=1)) and bool((lab == 3).all())
+    with torch.no_grad():
+        lin.bias[9] = float("nan")
+    out, lab = ops.point_mlp(x, point_heads._plain_mlp([lin]))
+    assert torch.equal(lab, torch.argmax(out, dim=1)) and bool((lab == 9).all())
+    assert point_heads._plain_mlp([torch.nn.Linear(32, 48), torch.nn.ReLU(), torch.nn.Linear(48, 17)]) is None  # 48 hidden channels: composed
+
+
 def test_capacity_mode_encoded_tensor_is_computed_on_demand(monkeypatch):
     """capacity mode leaves batch_dict["encoded_spconv_tensor"] (conv_out of the deepest level: no segmentation head reads it) as a proxy that runs
     the convolution - and builds its rulebook - on first access: same sites and features as the eager conv_out of the same frame, and a frame that
