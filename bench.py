@@ -417,6 +417,8 @@ def stage_rooflines(model, example, kind, census, frames=5):
         tm.wrap("devox_search", ops, "devoxelize_grid")
         tm.wrap("interpolate", ops, "interpolate_rows", note("interp_c", lambda feat, *a, **kw: int(feat.shape[1])))
         tm.wrap("head_mlp", ops, "gather_gemm", lambda x, w, tbl=None, **kw: tbl is None and x.shape[0] >= N)
+        tm.wrap("head_tail", ops, "point_mlp", note("tail", lambda feat, model_, *a, **kw: (int(model_.c_in), int(model_.c_out),
+                                                                                              sum(2.0 * w.shape[0] * w.shape[1] for w, _, _, _ in model_.keep))))
         if kind == "mseg3d":
             tm.wrap("grid_gather", ops, "grid_gather", note("img_c", lambda img, *a, **kw: int(img.shape[2])))
             tm.wrap("sfam", ops, "sfam")
@@ -469,6 +471,13 @@ def stage_rooflines(model, example, kind, census, frames=5):
     hbm("devox_search", N * 16.0 + V * 16.0 + N * 24.0, "SURVEY.md 8(d) windowed search: N*12(+4 batch) + V*12(+4) read + N*(12+12) idx / weights written")
     ic = shapes.get("interp_c", 32)
     hbm("interpolate", 3.0 * N * ic * 4 + N * ic * 4.0 + N * 24.0, "3*N*C*4 gathered + N*C*4 written + N*24 idx / weights")
+    if "tail" in shapes and "head_tail" in ms and ms["head_tail"] > 0:
+        # ls3d_point_mlp: interpolation + the head's Linear chain + argmax in one launch.  HBM side: three gathered voxel rows, the logits and the
+        # label per point; matrix side: exact-f32 MFMA
+        c_in, c_out, f_pt = shapes["tail"]
+        hbm("head_tail", N * (3.0 * c_in * 4 + 24 + c_out * 4 + 8), "ls3d_point_mlp: N*(3*C_in*4 gathered + 24 idx / weights + classes*4 logits + 8 label)")
+        out["head_tail"]["f32_mfma_tflops"] = N * f_pt / (ms["head_tail"] * 1e-3) / 1e12
+        out["head_tail"]["f32_mfma_frac"] = out["head_tail"]["f32_mfma_tflops"] / F32_MFMA_PEAK_TFLOPS
     if kind == "mseg3d":
         c_img = shapes.get("img_c", 48)
         hbm("grid_gather", 0.75 * N * 4 * c_img * 4.0 + N * c_img * 4.0, "SURVEY.md 8(d): Nv*4 taps*48*4 + N*48*4 (Nv = 0.75 N valid points)")

@@ -59,10 +59,20 @@ __global__ __launch_bounds__(256, 2) void k_point_mlp(const float *__restrict__ 
   for (int l = 0; l < prm.num_layers; ++l) {
     const PmLayer &L = prm.layer[l];
     float *Ws = smem + L.w_off, *vec = smem + L.v_off;
-    const int cpad = (L.cout + 31) & ~31;
-    for (int t = tid; t < L.cin * cpad; t += 256) {
-      const int k = t / cpad, c = t - k * cpad;
-      Ws[k * PM_WS + c] = c < L.cout ? L.w[(size_t)k * L.cout + c] : 0.0f;
+    const int cpad = (L.cout + 31) & ~31, sh = cpad == 32 ? 5 : 6;  // 32 or 64 columns: no division, eight loads in flight per trip
+    const int total = L.cin * cpad;
+    for (int t0 = tid; t0 < total; t0 += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * 256, tc = t < total ? t : 0, k = tc >> sh, c = tc & (cpad - 1);
+        v[u] = L.w[(size_t)k * L.cout + (c < L.cout ? c : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * 256, k = t >> sh, c = t & (cpad - 1);
+        if (t < total) Ws[k * PM_WS + c] = c < L.cout ? v[u] : 0.0f;
+      }
     }
     for (int c = tid; c < 64; c += 256) {
       vec[c] = (c < L.cout && L.scale) ? L.scale[c] : 1.0f;
