@@ -1500,9 +1500,9 @@ def test_capacity_mode_batch_beyond_one_frames_voxel_cap(monkeypatch):
     import lidarseg3d_amd as L
     from lidarseg3d_amd import detectors, models_cfg
     cfg = synth.NUSC
-    frames = [synth.lidar_frame(110, seed=41, **cfg), synth.lidar_frame(60, seed=42, **cfg)]
+    frames = [synth.lidar_frame(64, seed=41, **cfg), synth.lidar_frame(36, seed=42, **cfg)]
     pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)]))
-    for cap, reruns in ((120, 0), (70, 1)):  # 170 points in the batch; frame 0 has ~100 voxels
+    for cap, reruns in ((70, 0), (40, 1)):  # 100 points in the batch; frame 0 has ~60 voxels
         mcfg = models_cfg.sdseg3d()
         mcfg["backbone"]["model_cfg"] = dict(SCALING_RATIO=1)
         mcfg["point_head"]["model_cfg"]["CONV_IN_DIM"] = 16
