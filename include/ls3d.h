@@ -588,8 +588,11 @@ int ls3d_points_cuv(const float *points_cp, int n, int ncam, int res_h, int res_
  *             out2[1] = mean over the classes c present of sum_j e_(j) g_j, e = |[label == c] - softmax_c| sorted descending, g = the
  *             increments of the Jaccard index (Lovasz gradient); the workspace keeps what the backward needs.
  *   backward: grad_logits[P, ld] = grad_ce * d ce / d logits + grad_lovasz * d lovasz / d logits (device scalars; NULL = 1), from the
- *             workspace the forward filled for the SAME logits / labels. */
+ *             workspace the forward filled for the SAME logits / labels.  It reads the first ls3d_seg_loss_saved_bytes() bytes only (softmax,
+ *             Lovasz gradient, counts): a caller that holds the workspace until the backward may keep that prefix and release the rest
+ *             (5 of the 7 [P, C] arrays and the sort histograms). */
 size_t ls3d_seg_loss_workspace_bytes(int n_points, int num_classes);
+size_t ls3d_seg_loss_saved_bytes(int n_points, int num_classes);
 int ls3d_seg_loss_forward(const float *logits, int ld, const int32_t *labels, int n_points, int num_classes, int ignore_index, void *workspace,
                           size_t workspace_bytes, float *out2, ls3d_stream_t stream);
 int ls3d_seg_loss_backward(const int32_t *labels, int n_points, int num_classes, int ignore_index, const void *workspace, size_t workspace_bytes,

@@ -45,7 +45,7 @@ static inline size_t ls_al(size_t v) { return (v + 255) & ~(size_t)255; }
 static inline int ls_nb1(int P) { return (P + 255) / 256; }
 static inline int ls_nb2(int P) { return (P + LS_BLK - 1) / LS_BLK; }
 
-static size_t ls_layout(void *base, int P, int C, LossWs *w) {
+static size_t ls_layout(void *base, int P, int C, LossWs *w, size_t *saved = nullptr) {
   char *b = (char *)base;
   size_t off = 0;
   const size_t pc = (size_t)P * C;
@@ -54,6 +54,8 @@ static size_t ls_layout(void *base, int P, int C, LossWs *w) {
   off += ls_al((size_t)(count) * sizeof(type));
   LS_TAKE(probs, float, pc)
   LS_TAKE(gp, float, pc)
+  LS_TAKE(meta, float, 4)
+  if (saved) *saved = off;  // what the backward reads ends here (ls3d_seg_loss_saved_bytes): the sort's arrays behind it are the forward's alone
   LS_TAKE(keys, uint32_t, pc)
   LS_TAKE(skeys, uint32_t, pc)
   LS_TAKE(perm, int32_t, pc)
@@ -64,7 +66,6 @@ static size_t ls_layout(void *base, int P, int C, LossWs *w) {
   LS_TAKE(counts, int32_t, 1 + LS_MAXC)
   LS_TAKE(bsum, int32_t, (size_t)C * ls_nb2(P))
   LS_TAKE(lpart, float, (size_t)C * ls_nb2(P))
-  LS_TAKE(meta, float, 4)
 #undef LS_TAKE
   return off;
 }
@@ -72,6 +73,13 @@ static size_t ls_layout(void *base, int P, int C, LossWs *w) {
 extern "C" size_t ls3d_seg_loss_workspace_bytes(int n_points, int num_classes) {
   if (n_points <= 0 || num_classes < 1 || num_classes > LS_MAXC) return 0;
   return ls_layout(nullptr, n_points, num_classes, nullptr);
+}
+
+extern "C" size_t ls3d_seg_loss_saved_bytes(int n_points, int num_classes) {
+  if (n_points <= 0 || num_classes < 1 || num_classes > LS_MAXC) return 0;
+  size_t saved = 0;
+  ls_layout(nullptr, n_points, num_classes, nullptr, &saved);
+  return saved;
 }
 
 __global__ __launch_bounds__(256) void k_loss_prep(const float *__restrict__ logits, int ld, const int32_t *__restrict__ labels, int P, int C, int ignore,
@@ -307,7 +315,7 @@ extern "C" int ls3d_seg_loss_backward(const int32_t *labels, int n_points, int n
   hipStream_t stream = (hipStream_t)stream_;
   if (n_points == 0 && num_classes >= 1 && num_classes <= LS_MAXC) return LS3D_OK;
   if (!labels || !workspace || !grad_logits || n_points < 0 || num_classes < 1 || num_classes > LS_MAXC || ld < num_classes) return LS3D_ERR_ARG;
-  if (workspace_bytes < ls3d_seg_loss_workspace_bytes(n_points, num_classes)) return LS3D_ERR_WORKSPACE;
+  if (workspace_bytes < ls3d_seg_loss_saved_bytes(n_points, num_classes)) return LS3D_ERR_WORKSPACE;  // the prefix the forward left for us is enough
   LossWs w;
   ls_layout(const_cast<void *>(workspace), n_points, num_classes, &w);
   hipLaunchKernelGGL(k_loss_bwd, dim3(ls_nb1(n_points)), dim3(256), 0, stream, labels, n_points, num_classes, ignore_index, w, grad_ce, grad_lovasz,

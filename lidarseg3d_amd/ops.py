@@ -1250,7 +1250,10 @@ def seg_loss_forward(logits, labels, ignore):
     out = torch.empty((2,), dtype=torch.float32, device=logits.device)
     check(_L().ls3d_seg_loss_forward(_ptr(logits), logits.shape[1], _ptr(labels), P, C, int(ignore), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(out),
                                      _stream(logits)), "ls3d_seg_loss_forward")
-    return out, ws
+    # the backward reads the head of the workspace only (softmax, Lovasz gradient, counts): keep a copy of that prefix for autograd and let the
+    # sort's five [P, C] arrays and histograms go back to the allocator now (Waymo, 2 frames: ~165 MB per prediction level, two levels per step)
+    saved = _L().ls3d_seg_loss_saved_bytes(P, C)
+    return out, (ws[:saved].clone() if 0 < saved < ws.numel() else ws)
 
 
 def seg_loss_backward(labels, shape, ignore, ws, grad_ce, grad_lv):
