@@ -698,6 +698,37 @@ def main():
         except Exception as e:  # never let the graph path take the bench down: the eager leg is the value then
             graph_leg = dict(error=repr(e))
     head = graph_leg if (graph_leg and "error" not in graph_leg) else main_leg
+
+    def reference_outputs_leg(m, ex, want_logits, steps, warmup, keys):
+        """the same frame with EVERY output of the reference's eval forward materialised (lidarseg3d_amd.set_reference_outputs(True): the
+        loss-only conv_logits / mimic features and an eager encoded_spconv_tensor) - the like-for-like figure beside `value`, whose forward
+        computes only what out_logits / the labels need (config.outputs says so)"""
+        import lidarseg3d_amd as L3
+        from lidarseg3d_amd import graph as lgraph
+        L3.set_reference_outputs(True)
+        try:
+            ops.set_precision(args.precision)
+            with torch.no_grad():
+                m(dict(ex), return_loss=False)
+            have = {k: (k in m.point_head.forward_ret_dict) for k in keys}
+            fgr = lgraph.FrameGraph(m, ex)
+            el, lat = timed_steps(lambda: fgr(ex, clone=False)[0]["pred_point_sem_labels"], steps, warmup)
+            out = dict(frames_per_s=steps / el, ms_per_step=1e3 * el / steps, latency={k: v for k, v in lat.items() if k != "local_elapsed_s"},
+                       execution="one hipGraph per frame", outputs_materialised=dict(have, encoded_spconv_tensor=True),
+                       logits_bit_identical_to_value_mode=(bool(torch.equal(fgr.logits, want_logits)) if want_logits is not None else None),
+                       note="set_reference_outputs(True): conv_logits / point_features_pcamera evaluated and encoded_spconv_tensor (conv_out + its rulebook) "
+                            "computed with every frame, as the reference's eval forward does")
+            del fgr
+            return out
+        except Exception as e:
+            return dict(error=repr(e))
+        finally:
+            L3.set_reference_outputs(False)
+
+    ref_out_leg = None
+    if graph_leg is not None and "error" not in graph_leg and single:
+        ref_out_leg = reference_outputs_leg(model, dict(points=pts, batch_size=1, **extra), ref_logits, args.steps, args.warmup,
+                                            ["conv_logits"] if args.model == "sdseg3d" else ["voxel_logits", "point_features_pcamera"])
     # what every rank measured, gathered over the process group: a record of N ranks can be checked rank by rank
     mine = dict(rank=rank, local_rank=local_rank, device=str(dev), device_name=(torch.cuda.get_device_name(dev) if not SIM else "hipsim (test hook)"),
                 frame_seeds=[100 + i for i in my_frames], frames_per_s=head["local_frames_per_s"],
@@ -848,6 +879,9 @@ def main():
                 del fgs2, exs2
             except Exception as e:
                 mseg["two_graphs_in_flight"] = dict(error=repr(e))
+        if "graph_error" not in mseg and not args.no_graph and detectors.CAPACITY_MODE:
+            mseg["reference_outputs_mode"] = reference_outputs_leg(m2, dict(points=p2, batch_size=1, **e2), None, n2, 3,
+                                                                   ["voxel_logits", "point_features_pcamera"])
         try:  # configs[2]'s own roofline objects: the fused SF-Phase decoder (MFMA-bound) first, then the other stages of the frame
             sr2 = stage_rooflines(m2, dict(points=p2, batch_size=1, **e2), "mseg3d", census2)
             if "sffm_decoder" in sr2:
@@ -906,7 +940,12 @@ def main():
             "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "nuScenes LiDAR-only SDSeg3D (TransVFE->UNetSCN3D->PointSegBatchlossHead), "
                                    "%d pts/frame, voxel [0.1,0.1,0.2], range [-51.2,-51.2,-5,51.2,51.2,3], 17 classes, "
-                                   "1 frame per GPU per step, GPU voxelization included" % args.points,
+                                   "1 frame per GPU per step, GPU voxelization included; loss-only outputs (conv_logits, mimic) not evaluated and "
+                                   "encoded_spconv_tensor computed on demand (see config.outputs / reference_outputs_mode)" % args.points,
+                       "outputs": "out_logits [N,17] + pred_point_sem_labels, the outputs the metric is defined on.  Inference does NOT evaluate the "
+                                  "loss-only outputs of the reference's forward (forward_ret_dict['conv_logits']; MSeg3D: the mimic features) and hands out "
+                                  "batch_dict['encoded_spconv_tensor'] as an on-demand proxy (no head reads it): `reference_outputs_mode` is the same frame "
+                                  "with all of them materialised (lidarseg3d_amd.set_reference_outputs(True))",
                        "precision": args.precision, "frames_per_gpu_per_step": B * S, "streams": S,
                        "host_syncs_per_frame": ("0 blocking (capacity mode: device-side row counts; one wait for the frame's rulebook counts, "
                                                 "which are ready early in the frame)" if detectors.CAPACITY_MODE else "3 (host-side row counts)"),
@@ -927,6 +966,8 @@ def main():
             out["graph_mode"] = graph_leg
             out["eager_mode"] = dict(value=main_leg["frames_per_s"], ms_per_step=main_leg["ms_per_step"], latency=main_leg["latency"],
                                      note="same launches submitted one by one from Python; carries the conv-stack HIP-event brackets of `roofline`")
+        if ref_out_leg is not None:
+            out["reference_outputs_mode"] = ref_out_leg
         if c:
             np_ = PLANE_PRODUCTS.get(args.precision)
             # the matrix-pipe view of the same stack: every f32 product of the pair model is `np_` bf16 plane products on

@@ -18,3 +18,20 @@ def register_all():
 
 
 register_all()
+
+
+def set_reference_outputs(on=True):
+    """Inference computes by default only what `out_logits` / `pred_point_sem_labels` need.  Three tensors that the reference's eval forward also
+    produces and that nothing but get_loss() or a downstream detection head reads are elided: `forward_ret_dict["conv_logits"]`
+    (point_seg_batchloss_head.py:138-141), the mimic features `point_features_pcamera` (point_seg_mseg3d_head.py:305-334) and - in capacity mode -
+    an eager `batch_dict["encoded_spconv_tensor"]` (scn_unet.py:218-222; the key holds a proxy that computes it when read).
+    set_reference_outputs(True) (or LS3D_REFERENCE_OUTPUTS=1 in the environment) makes every inference forward produce all of them, as the
+    reference does; bench.py times both modes (`reference_outputs_mode`)."""
+    from . import point_heads, scn_unet
+    point_heads.set_eval_aux(on)
+    scn_unet.set_lazy_encoded(not on)
+
+
+def reference_outputs():
+    from . import point_heads, scn_unet
+    return bool(point_heads.eval_aux() and not scn_unet._LAZY_ENCODED)

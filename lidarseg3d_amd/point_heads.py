@@ -192,8 +192,8 @@ class PointSegBatchlossHead(PackedModule):
         batch_size = batch_dict["batch_size"]
         feat = batch_dict["conv_point_features"]
         # the voxel-level logits feed get_loss only (point_seg_batchloss_head.py:77-121); nothing reads them at inference, so - like the mimic branch
-        # of the MSeg3D head - they are not evaluated there (two launches on 65k voxels; set_eval_aux(True) / LS3D_EVAL_AUX_LOGITS=1 restores them)
-        if _EVAL_AUX_LOGITS:
+        # of the MSeg3D head - they are not evaluated there (two launches on 65k voxels; lidarseg3d_amd.set_reference_outputs(True) restores them)
+        if _EVAL_AUX:
             self.forward_ret_dict["conv_logits"] = _run_mlp(feat, pk["conv_cls"])
         else:
             self.forward_ret_dict.pop("conv_logits", None)
@@ -220,7 +220,7 @@ class PointSegBatchlossHead(PackedModule):
         from .losses import seg_loss
         d = {} if point_loss_dict is None else point_loss_dict
         r = self.forward_ret_dict
-        conv_ce, conv_lv = seg_loss(r["conv_logits"], r["voxel_sem_labels"], self.ignored_label)
+        conv_ce, conv_lv = seg_loss(_need(r, "conv_logits"), r["voxel_sem_labels"], self.ignored_label)
         out_ce, out_lv = seg_loss(r["out_logits"], r["point_sem_labels"], self.ignored_label)
         d.update(conv_ce_loss=conv_ce.detach(), conv_lovasz_loss=conv_lv.detach(), out_ce_loss=out_ce.detach(),
                  out_lovasz_loss=out_lv.detach())
@@ -284,14 +284,33 @@ class TransformerDecoder(nn.Module):
 import os as _os
 _HEAD_STREAMS = {}
 _HEAD_OVERLAP = _os.environ.get("LS3D_HEAD_OVERLAP", "1") != "0"  # MSeg3D head: camera branch / class-embedding side on their own streams
-_EVAL_MIMIC = _os.environ.get("LS3D_EVAL_MIMIC", "0") != "0"
-_EVAL_AUX_LOGITS = _os.environ.get("LS3D_EVAL_AUX_LOGITS", "0") != "0"  # PointSegBatchlossHead: voxel-level logits at inference (loss-only outputs)
+# Loss-only outputs at inference.  The reference's eval forward also computes tensors that nothing but get_loss() reads: the voxel-level
+# `conv_logits` of PointSegBatchlossHead (point_seg_batchloss_head.py:138-141) and the mimic branch `point_features_pcamera` of
+# PointSegMSeg3DHead (point_seg_mseg3d_head.py:305-334).  They do not feed `out_logits`; by default they are NOT evaluated at inference
+# (bench.py states it in `config.workload` and times the reference-outputs mode beside `value`).  lidarseg3d_amd.set_reference_outputs(True)
+# / LS3D_REFERENCE_OUTPUTS=1 restore all of them (and the eager `encoded_spconv_tensor` of the backbone, scn_unet.set_lazy_encoded).
+_EVAL_AUX = _os.environ.get("LS3D_REFERENCE_OUTPUTS", "0") != "0"
 
 
 def set_eval_aux(on):
-    """evaluate the loss-only outputs of the point heads at inference as the reference does (tests that compare them with the golden vectors)"""
-    global _EVAL_AUX_LOGITS
-    _EVAL_AUX_LOGITS = bool(on)
+    """evaluate the loss-only outputs of the point heads (conv_logits, point_features_pcamera) at inference as the reference does"""
+    global _EVAL_AUX
+    _EVAL_AUX = bool(on)
+
+
+def eval_aux():
+    return _EVAL_AUX
+
+
+class LossOnlyOutputSkipped(KeyError):
+    """get_loss() after an inference forward that did not evaluate the loss-only outputs"""
+
+
+def _need(r, key):
+    if key not in r:
+        raise LossOnlyOutputSkipped("forward_ret_dict[%r] is a loss-only output that the inference forward does not evaluate by default: call "
+                                    "lidarseg3d_amd.set_reference_outputs(True) (or run the forward with return_loss=True) before get_loss()" % key)
+    return r[key]
 
 _FUSED_SFFM = _os.environ.get("LS3D_FUSED_SFFM", "1") != "0"
 # the class-embedding side of all decoder layers in one launch (ls3d_sffm_memory) instead of ~40 small ones: 0.21 ms instead of 0.37 ms per frame
@@ -677,9 +696,13 @@ class PointSegMSeg3DHead(PackedModule):
             pc = _run_mlp(ops.grid_gather(batch_dict["image_features"].contiguous(), cuv, points), pk["camera"])
         # The mimic (pseudo-camera) branch only feeds the training loss: the reference evaluates it on the valid points and zero-pads the
         # others (:305,:320-334), so points without a camera hit get ZERO camera features at inference.  Its three layers are not evaluated
-        # at inference (nothing reads forward_ret_dict["point_features_pcamera"] outside get_loss; LS3D_EVAL_MIMIC=1 restores them).
-        if _EVAL_MIMIC:
+        # at inference (nothing reads forward_ret_dict["point_features_pcamera"] outside get_loss; lidarseg3d_amd.set_reference_outputs(True)
+        # restores them).  A tensor left under the key by an earlier training forward is dropped: never stale data.
+        if _EVAL_AUX:
             self.forward_ret_dict["point_features_pcamera"] = _run_mlp(pl, pk["mimic"])
+        else:
+            self.forward_ret_dict.pop("point_features_pcamera", None)
+            self.forward_ret_dict.pop("point_features_camera", None)
         fused = _run_mlp(ops.complete_concat(pl, pc, None, cuv), pk["lc"])
         if not early:
             lemb = ops.sfam(vf, voxel_logits, vx_off, B, vf.shape[0]).permute(0, 2, 1).contiguous().unsqueeze(3)
@@ -699,8 +722,8 @@ class PointSegMSeg3DHead(PackedModule):
         r = self.forward_ret_dict
         v_ce, v_lv = seg_loss(r["voxel_logits"], r["voxel_sem_labels"], self.ignored_label)
         o_ce, o_lv = seg_loss(r["out_logits"], r["point_sem_labels"], self.ignored_label)
-        assert not r["point_features_camera"].requires_grad
-        mimic = torch.nn.functional.mse_loss(r["point_features_pcamera"], r["point_features_camera"])
+        assert not _need(r, "point_features_camera").requires_grad
+        mimic = torch.nn.functional.mse_loss(_need(r, "point_features_pcamera"), r["point_features_camera"])
         d.update(voxel_ce_loss=v_ce.detach(), voxel_lovasz_loss=v_lv.detach(), out_ce_loss=o_ce.detach(),
                  out_lovasz_loss=o_lv.detach(), out_mimic_loss=mimic.detach())
         return (v_ce + v_lv) + (o_ce + o_lv) + mimic, d

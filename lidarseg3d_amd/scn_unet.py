@@ -74,25 +74,50 @@ _EARLY_ORDER = int(_os.environ.get("LS3D_EARLY_ORDER", "0"))  # capacity mode: t
 _LATERAL = _os.environ.get("LS3D_LATERAL_STREAM", "1") != "0"
 # capacity mode: `encoded_spconv_tensor` (scn_unet.py:218-222: conv_out of the deepest level) feeds no segmentation head - the key holds a proxy that
 # runs the convolution (and builds its rulebook) when something reads it, instead of one more rulebook, mask sort and launch beside every frame
-_LAZY_ENCODED = _os.environ.get("LS3D_LAZY_ENCODED", "1") != "0"
+# (lidarseg3d_amd.set_reference_outputs(True) / LS3D_REFERENCE_OUTPUTS=1: computed eagerly, as the reference does)
+_LAZY_ENCODED = _os.environ.get("LS3D_REFERENCE_OUTPUTS", "0") == "0"
 
 
-class _LazyEncoded(object):
-    """stands in for the SparseConvTensor under batch_dict["encoded_spconv_tensor"]: computed on first attribute access (before the next frame
-    overwrites its inputs when the frame is a graph replay)"""
+def set_lazy_encoded(on):
+    """capacity mode: batch_dict["encoded_spconv_tensor"] as an on-demand proxy (default) or computed with every frame (the reference's forward)"""
+    global _LAZY_ENCODED
+    _LAZY_ENCODED = bool(on)
 
-    def __init__(self, fn):
-        self.__dict__["_fn"], self.__dict__["_value"] = fn, None
+
+class _LazyEncoded(spconv.SparseConvTensor):
+    """batch_dict["encoded_spconv_tensor"] in capacity mode: a SparseConvTensor (isinstance holds) whose convolution - conv_out on the
+    deepest level and its rulebook - runs when the first of its attributes is read, on the stream that is current then.  It reads the
+    frame's level-4 tensor, so it has to be read (or materialize()d) before the next frame overwrites that tensor: after a graph replay
+    (graph.FrameGraph) the proxy of the capture is invalidated and computes the replayed frame's value on the next read."""
+
+    def __init__(self, fn):  # no SparseConvTensor.__init__: the attributes do not exist until they are asked for
+        self.__dict__["_fn"] = fn
 
     def materialize(self):
-        if self.__dict__["_value"] is None:
+        if "features" not in self.__dict__:
             with torch.no_grad():
-                self.__dict__["_value"] = self.__dict__["_fn"]()
-            self.__dict__["_fn"] = None
-        return self.__dict__["_value"]
+                value = self.__dict__["_fn"]()
+            self.__dict__.update(value.__dict__)
+        return self
 
-    def __getattr__(self, name):
-        return getattr(self.materialize(), name)
+    def invalidate(self):
+        """drop the computed value (the inputs have been overwritten by a new frame): the next read computes it again"""
+        fn = self.__dict__["_fn"]
+        self.__dict__.clear()
+        self.__dict__["_fn"] = fn
+
+    def __getattr__(self, name):  # only called for attributes that are not there yet
+        if name.startswith("__"):
+            raise AttributeError(name)
+        self.materialize()
+        try:
+            return self.__dict__[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self.materialize()
+        self.__dict__[name] = value
 _LATERAL_STREAMS = {}
 
 
@@ -527,8 +552,8 @@ class UNetSCN3D(nn.Module):
                 gs.hand_over([rb2])
                 conv2_order = gs.finish_event()
         for lvl, (key, src, stage) in enumerate((("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4))):
-            # the last level's block also builds what is left - the decoder's row orders (the inverse tables of EVERY strided rulebook,
-            # conv_out's included) - so it waits for the whole chain
+            # the last level's block also builds what is left - the decoder's row orders (the inverse tables of EVERY strided rulebook of the
+            # chain; conv_out's only when it is computed eagerly, set_lazy_encoded(False)) - so it waits for the whole chain
             deps = rb_events[lvl:lvl + 1] + (rb_events[-1:] if lvl == 2 else [])
             with _GeometryStream(x.indices, ready, join=False, index=(2 if lvl % 2 == 0 else 0), after=deps) as gs:
                 rb = x.find_indice_pair(src)

@@ -230,6 +230,87 @@ def test_batchloss_head_vs_golden():
                                atol=1e-3 + 2e-5 * np.abs(g["conv_logits"]).max())
 
 
+def test_point_mlp_fed_the_backbones_search_vs_golden():
+    """the SHIPPED inference path of PointSegBatchlossHead - the backbone's early neighbour search (batch_dict["devox_search"]) feeding
+    ls3d_point_mlp (interpolation + conv_align_layers + out_cls_layers + argmax in one launch) - against the fixture generated by running the
+    reference head (point_seg_batchloss_head.py:122-168): logits and argmax.  test_batchloss_head_vs_golden above takes the layer-by-layer branch."""
+    g = golden("head_batchloss_nusc.npz")
+    cfg = synth.NUSC
+    head = point_heads.PointSegBatchlossHead(False, 17, dict(CONV_IN_DIM=32, CONV_CLS_FC=[64], CONV_ALIGN_DIM=64,
+                                                              OUT_CLS_FC=[64, 64], IGNORED_LABEL=0))
+    head.load_state_dict(seeded_sd("point_head.PointSegBatchlossHead", g["seed"]), strict=True)
+    head.to(DEV).eval()
+    pts, ctr, feat = cu(g["points"][:, :4].copy()), cu(g["conv_point_coords"]), cu(g["conv_point_features"])
+    lo, vs = np.asarray(cfg["pc_range"][:3], np.float64), np.asarray(cfg["voxel_size"], np.float64)
+    zyx = np.rint((g["conv_point_coords"][:, 1:4].astype(np.float64) - lo) / vs - 0.5).astype(np.int32)[:, ::-1]
+    ind = cu(np.ascontiguousarray(np.concatenate([g["conv_point_coords"][:, :1].astype(np.int32), zyx], 1)))
+    np.testing.assert_array_equal(ops.voxel_centers(ind, cfg["voxel_size"], cfg["pc_range"]).cpu().numpy(), g["conv_point_coords"])
+    pt_off, vx_off = ops.frame_offsets(pts, 1), ops.frame_offsets(ctr, 1)
+    idx, w = ops.devoxelize_grid(pts, pt_off, ind, ctr, vx_off, 1, list(cfg["voxel_size"]), list(cfg["pc_range"]), None)
+    calls = []
+    orig = ops.point_mlp
+    ops.point_mlp = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
+    try:
+        bd = head(dict(batch_size=1, conv_point_features=feat, conv_point_coords=ctr, points=pts,
+                       devox_search=dict(points=pts, indices=ind, centers=ctr, pt_off=pt_off, vx_off=vx_off, idx=idx, weight=w, event=None)),
+                  return_loss=False)
+    finally:
+        ops.point_mlp = orig
+    assert calls == [1], "the fused tail did not run"
+    got = bd["out_logits"].cpu().numpy()
+    scale = np.abs(g["out_logits"]).max()
+    np.testing.assert_allclose(got, g["out_logits"], rtol=0, atol=1e-3 + 2e-5 * scale)
+    labels = head.forward_ret_dict["out_labels"].cpu().numpy()
+    np.testing.assert_array_equal(labels, got.argmax(1))
+    top2 = np.sort(g["out_logits"], 1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * scale
+    np.testing.assert_array_equal(labels[clear], g["out_logits"].argmax(1)[clear])
+    assert clear.sum() > 0.99 * clear.size
+    assert "conv_logits" not in head.forward_ret_dict  # a loss-only output: elided by default, and said so
+    with pytest.raises(point_heads.LossOnlyOutputSkipped):
+        head.forward_ret_dict.update(voxel_sem_labels=None, point_sem_labels=None)
+        head.get_loss()
+
+
+def test_lazy_encoded_tensor_in_capacity_mode_vs_golden():
+    """capacity mode hands out batch_dict["encoded_spconv_tensor"] (scn_unet.py:218-222) as a proxy that runs conv_out - and builds its strided
+    rulebook - when it is read: sites bit-exact and features within tolerance of the fixture generated by running the reference's scn_unet.py,
+    identical to the eager tensor of lidarseg3d_amd.set_reference_outputs(True), on tensors with spare rows behind the device count"""
+    from lidarseg3d_amd import spconv
+    cfg = synth.NUSC
+    g = golden("unet_nusc_c13.npz")
+    net = scn_unet.UNetSCN3D(num_input_features=13, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
+                             model_cfg=dict(SCALING_RATIO=2), ds_factor=8, us_factor=8)
+    net.load_state_dict(seeded_sd("backbone.UNetSCN3D.c13", g["seed"]), strict=True)
+    net.to(DEV).eval()
+    n, spare = g["coords"].shape[0], 333
+    vf = torch.zeros((n + spare, 13), dtype=torch.float32, device=DEV)
+    vf[:n] = cu(g["voxel_features"])
+    vc = torch.zeros((n + spare, 4), dtype=torch.int32, device=DEV)
+    vc[:n] = cu(g["coords"])
+    got = {}
+    try:
+        for ref_outputs in (False, True):
+            L.set_reference_outputs(ref_outputs)
+            with torch.no_grad():
+                bd = net(dict(voxel_features=vf, voxel_coords=vc, batch_size=1, num_active_voxels_dev=cu(np.array([n], np.int32)),
+                              input_shape=np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))))
+            enc = bd["encoded_spconv_tensor"]
+            assert isinstance(enc, spconv.SparseConvTensor) and isinstance(enc, scn_unet._LazyEncoded) == (not ref_outputs)
+            assert ("features" in enc.__dict__) == ref_outputs  # the proxy has computed nothing yet
+            k = int(enc.n_dev.item())
+            got[ref_outputs] = (enc.indices[:k].clone(), enc.features[:k].clone())
+            assert bd["encoded_spconv_tensor_stride"] == 8
+            np.testing.assert_allclose(bd["conv_point_features"][:n].cpu().numpy(), g["conv_point_features"], rtol=0,
+                                       atol=1e-3 + 2e-5 * np.abs(g["conv_point_features"]).max())
+    finally:
+        L.set_reference_outputs(False)
+    ind, feat = got[False]
+    np.testing.assert_array_equal(ind.cpu().numpy(), g["enc_indices"])
+    np.testing.assert_allclose(feat.cpu().numpy(), g["enc_features"], rtol=0, atol=1e-3 + 2e-5 * np.abs(g["enc_features"]).max())
+    assert torch.equal(ind, got[True][0]) and torch.equal(feat, got[True][1])
+
+
 def test_mseg3d_head_vs_golden():
     g = golden("head_mseg3d_nusc.npz")
     mcfg = models_cfg.mseg3d()["point_head"]["model_cfg"]
