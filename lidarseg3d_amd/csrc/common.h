@@ -13,6 +13,14 @@
     if (hipGetLastError() != hipSuccess) return LS3D_ERR_LAUNCH; \
   } while (0)
 
+// hipFuncSetAttribute (the opt-in to > 64 KB of dynamic LDS) is a per-DEVICE property of a kernel: call sites remember it per device
+constexpr int LS3D_MAX_DEVICES = 64;
+static inline int ls3d_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d % LS3D_MAX_DEVICES;
+}
+
 // 1-D launch geometry for grid-stride kernels: enough blocks to cover `work` items, capped so that a
 // launch never exceeds ~8 blocks per CU (256 CUs); the kernels loop over the remainder.
 static inline dim3 ls3d_grid(long long work, int block = 256, int max_blocks = 2048) {

@@ -194,7 +194,8 @@ extern "C" int ls3d_point_mlp(const float *feat, int feat_ld, int c_in, const in
   const size_t lds = pm_layout(prm);
   if (lds > 80 * 1024) return LS3D_ERR_UNSUPPORTED;
   if (n == 0) return LS3D_OK;
-  static bool attr_set = false;
+  static bool attr_set_on[LS3D_MAX_DEVICES] = {};  // the attribute is per device (multi-GPU servers, multi-device tests)
+  bool &attr_set = attr_set_on[ls3d_device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_point_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;

@@ -911,7 +911,8 @@ extern "C" int ls3d_sffm_decoder(const float *x, int x_ld, int n, const float *p
                            (const uint4 *)s.w2a_planes, (const uint4 *)s.w2b_planes};
   }
   const int lds = (4 * SF_WAVE_FLOATS + 2 * SF_BCHUNK + SF_KV) * (int)sizeof(float) + (128 + 8) * (int)sizeof(int);
-  static bool attr_set = false;
+  static bool attr_set_on[LS3D_MAX_DEVICES] = {};  // the attribute is per device (multi-GPU servers, multi-device tests)
+  bool &attr_set = attr_set_on[ls3d_device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_sffm_decoder, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_sffm_decoder_rt<1, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES) != hipSuccess ||

@@ -197,7 +197,8 @@ extern "C" int ls3d_sffm_memory(const float *mem, int batch, int L, int embed, i
     prm.layer[l] = SmLayer{s.wqkv_t, s.bqkv, s.wo_t, s.bo, s.n1_gamma, s.n1_beta, s.wk_t, s.bk, s.wv_t, s.bv, s.n1_eps};
   }
   const int lds = (2 * SM_LMAX * SM_MS + SM_LMAX * SM_QS) * (int)sizeof(float);
-  static bool attr_set = false;
+  static bool attr_set_on[LS3D_MAX_DEVICES] = {};  // the attribute is per device (multi-GPU servers, multi-device tests)
+  bool &attr_set = attr_set_on[ls3d_device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_sffm_memory, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;

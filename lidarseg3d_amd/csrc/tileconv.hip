@@ -933,7 +933,8 @@ template <int NT, int NP, bool TR = false, int LP = 0>
 static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TilePlan &p, const uint4 *wpk, int cin, int cout, const EpiDev &e, float *out,
                      int out_ld, int ablate, int swz, int max_units, int split_small, int split_tail, int split_forced, float *partial, int *counters,
                      unsigned *trace) {
-  static bool attr_set = false;
+  static bool attr_set_on[LS3D_MAX_DEVICES] = {};  // the attribute is per device (multi-GPU servers, multi-device tests)
+  bool &attr_set = attr_set_on[ls3d_device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP, TR, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;

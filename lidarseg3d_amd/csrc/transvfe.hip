@@ -585,7 +585,8 @@ extern "C" size_t ls3d_transvfe_workspace_bytes(int n, int P) {
 template <int MODE>
 static int tv_launch(hipStream_t stream, long long blocks, int lds, const float *voxels, const int32_t *num_points, int n, const int32_t *n_dev, int P, int C,
                      const TvParams &prm, float *out, int out_ld, const int32_t *cls) {
-  static bool attr_set = false;
+  static bool attr_set_on[LS3D_MAX_DEVICES] = {};  // the attribute is per device (multi-GPU servers, multi-device tests)
+  bool &attr_set = attr_set_on[ls3d_device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute((const void *)k_transvfe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;
     attr_set = true;

@@ -98,7 +98,7 @@ def _with_training_kernels(model, example, return_loss):
     decoder MLPs: 10^5..10^6 rows reduced into <= 256 x 256 matrices - go to ls3d_spconv_wgrad instead of hipBLASLt's 32 x 32 macro
     tiles (ops.fast_linear_backward patches torch.nn.functional.linear for the duration of the forward)"""
     if (return_loss or model.training) and torch.is_grad_enabled():
-        with ops.fast_linear_backward():
+        with ops.fast_linear_backward(model):
             return model._forward(example, return_loss)
     return model._forward(example, return_loss)
 

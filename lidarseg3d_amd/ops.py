@@ -832,9 +832,20 @@ class fast_linear_backward(object):
     detectors runs under it (the backward then runs the recorded functions wherever it is called); LS3D_FAST_LINEAR=0 switches the whole
     context off, LS3D_FAST_LAYERNORM=0 the LayerNorm part."""
 
+    def __init__(self, model=None):
+        """model: only the BatchNorm1d modules of THIS model take the HIP kernels while the context is active (they are marked once); without a
+        model every training-mode BatchNorm1d over >= 4096 rows in the process does (tools, tests)"""
+        self.model = model
+        if model is not None and not model.__dict__.get("_ls3d_bn_marked"):
+            for m in model.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.__dict__["_ls3d_bn_kernels"] = True
+            model.__dict__["_ls3d_bn_marked"] = True
+
     def __enter__(self):
         global _ORIG_LINEAR
         self.on = _os.environ.get("LS3D_FAST_LINEAR", "1") != "0" and _ORIG_LINEAR is None
+        scoped = self.model is not None
         if self.on:
             _ORIG_LINEAR = torch.nn.functional.linear
             orig = _ORIG_LINEAR
@@ -860,7 +871,8 @@ class fast_linear_backward(object):
             def bn_forward(mod, input):
                 # BatchNorm1d over [rows, c] in training mode: statistics, normalisation and their backward on csrc/norm.hip (the sites with a
                 # ReLU / residual behind the BatchNorm call ops.batch_norm_train themselves: spconv.SparseSequential, scn_unet.SparseBasicBlock)
-                if mod.training and input.dim() == 2 and input.is_cuda and input.shape[0] >= 4096 and torch.is_grad_enabled():
+                if (mod.training and input.dim() == 2 and input.is_cuda and input.shape[0] >= 4096 and torch.is_grad_enabled()
+                        and (not scoped or mod.__dict__.get("_ls3d_bn_kernels"))):
                     y = batch_norm_train(mod, input)
                     if y is not None:
                         return y
@@ -1387,6 +1399,8 @@ def batch_norm_train(bn, x, res=None, relu=False):
     add and the ReLU that follow it; updates the running statistics as nn.BatchNorm1d does.  -> y, or None when the shape / module is not covered
     (the caller composes it from the torch modules)"""
     if not (_BN_KERNELS and bn.training and bn.affine and batch_norm_supported(x) and (res is None or batch_norm_supported(res)) and x.shape[0] > 1):
+        return None
+    if bn.weight.data_ptr() % 16 or bn.bias.data_ptr() % 16:  # the kernels read gamma / beta as float4 (flattened-parameter views may not be aligned)
         return None
     merge = reduce = None
     state = {"count": float(x.shape[0])}
