@@ -97,15 +97,25 @@ class ConvCensus:
             return g(x, w, tbl=tbl, **kw)
 
         def wt(x, w, plan, **kw):
-            self.meta.append((plan.tbl, w.shape[1], kw.get("cout") or w.cout, "tile", plan.n_dev))
+            self.meta.append((plan.tbl, w.shape[1], kw.get("cout") or w.cout, "tile1", plan.n_dev))
             return t(x, w, plan, **kw)
-        ops.gather_gemm, ops.tile_conv = wg, wt
+        tc = ops.tile_conv_chain
+
+        def wc(layers, plan):  # a chained launch = its layers' launches for the pair model (one kernel launch on the device)
+            ok = tc(layers, plan)
+            if ok:
+                self.chained_launches += 1
+                for l in layers:
+                    self.meta.append((plan.tbl, l.w.shape[1], l.cout, "tile", plan.n_dev))
+            return ok
+        self.chained_launches = 0
+        ops.gather_gemm, ops.tile_conv, ops.tile_conv_chain = wg, wt, wc
         try:
             with torch.no_grad():
                 step()
             torch.cuda.synchronize()
         finally:
-            ops.gather_gemm, ops.tile_conv = g, t
+            ops.gather_gemm, ops.tile_conv, ops.tile_conv_chain = g, t, tc
         pairs, uniq, rows, kv, algo, flops, bmin = {}, {}, {}, {}, 0.0, 0.0, 0.0
         for tbl, cin, cout, _, n_dev in self.meta:
             key = (tbl.data_ptr(), tbl.shape[0])
@@ -122,7 +132,12 @@ class ConvCensus:
             bmin += (uniq[key] * cin + rows[key] * cout + tbl.shape[1] * cin * cout) * 4.0
         first = self.meta[0] if self.meta else None
         n_in = (int(first[4].item()) if first[4] is not None else first[0].shape[0]) if first else 0
-        return dict(launches=len(self.meta), tile_launches=sum(1 for m in self.meta if m[3] == "tile"), algo_bytes=algo, flops=flops, b_min_bytes=bmin,
+        chained_layers = sum(1 for m in self.meta if m[3] == "tile") - sum(1 for m in self.meta if m[3] == "tile1")
+        for i, m in enumerate(self.meta):
+            if m[3] == "tile1":
+                self.meta[i] = m[:3] + ("tile",) + m[4:]
+        return dict(launches=len(self.meta), tile_launches=sum(1 for m in self.meta if m[3] == "tile"), chained_layers=chained_layers,
+                    kernel_launches=len(self.meta) - chained_layers + self.chained_launches, algo_bytes=algo, flops=flops, b_min_bytes=bmin,
                     input_voxels=n_in, tables=sorted(set((rows[k], kv[k]) for k in rows), reverse=True))
 
 
@@ -983,11 +998,16 @@ def main():
                 # ~0.2x of the pair model.  achieved / peak / frac stay SURVEY.md 8(d)'s pair-model figure (algorithmic gather bytes over
                 # the measured duration against the HBM peak), the headline the scope table defines; `mfma` and `hbm_physical_GBps` are the
                 # physical utilisations of the two units.
-                "bound": "mfma", "kernel": "sparse-conv stack: %d launches/frame (%d k_tile_conv + %d k_gather_gemm), two HIP-event brackets per frame"
-                                           % (c["launches"], c["tile_launches"], c["launches"] - c["tile_launches"]),
+                "bound": "mfma", "kernel": "sparse-conv stack: %d layers/frame (%d on k_tile_conv - %d of them inside chained persistent launches, "
+                                           "ls3d_tile_conv_chain - + %d on k_gather_gemm) = %d kernel launches, two HIP-event brackets per frame"
+                                           % (c["launches"], c["tile_launches"], c.get("chained_layers", 0), c["launches"] - c["tile_launches"],
+                                              c.get("kernel_launches", c["launches"])),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "model": "pair model, SURVEY.md 8(d): sum over the layers of P_l * (Cin + Cout) * 4 bytes",
-                "avg_launch_us": 1e3 * mean_ms / max(c["launches"], 1), "algo_bytes_per_frame": c["algo_bytes"],
+                # per LAYER (37 per frame; the unit of the pair model) and per kernel launch (a chained launch runs several layers)
+                "avg_launch_us": 1e3 * mean_ms / max(c["launches"], 1), "avg_kernel_launch_us": 1e3 * mean_ms / max(c.get("kernel_launches", c["launches"]), 1),
+                "layers_per_frame": c["launches"], "kernel_launches_per_frame": c.get("kernel_launches", c["launches"]),
+                "algo_bytes_per_frame": c["algo_bytes"],
                 "algo_bytes_per_launch": c["algo_bytes"] / max(c["launches"], 1), "tflops_useful": main_leg.get("tflops"),
                 "sparse_conv_ms_per_frame": stack, "mfma": mfma, "hbm_physical_GBps": None,
                 # the traffic no kernel can avoid (each referenced input row, each output row and the weights once per launch) and the

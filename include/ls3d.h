@@ -376,6 +376,34 @@ int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int
                    int products, const ls3d_epilogue_t *epi_host, float *out, int out_ld, void *workspace, size_t workspace_bytes,
                    int32_t *counters, int flags, ls3d_stream_t stream);
 
+/* Chained launch: up to 8 consecutive SubM layers that share ONE plan (the convolutions of the SparseBasicBlocks of a UNet level,
+ * scn_unet.py:34-69, 189-249: each layer reads the previous layer's output on the same sites) in ONE persistent launch.  Work units
+ * (layer, tile) are taken from a ticket counter in layer-major order; a tile of layer l + 1 starts as soon as the tiles that own its halo
+ * rows (the plan's producer lists, built by ls3d_tile_build) have finished layer l - so the tail of a layer (677 tiles on 512 workgroup
+ * slots) is filled with the next layer's tiles instead of idle CUs.  A unit waits only for units with smaller tickets, so the launch cannot
+ * deadlock whatever the number of resident workgroups; a wait of more than ~1 s sets state[1] (int32) and goes on.
+ *   layers[l]: the operands of ls3d_tile_conv for layer l (epilogue by value).  A layer may read anything an EARLIER layer of the chain wrote
+ *              on the plan's rows (its input, res_pre, pair) and anything written before the launch.  All layers: cout in the same class
+ *              (<= 32, <= 64, <= 128), cout % 4 == 0, float4-aligned leading dimensions, no LayerNorm epilogue, products == 6,
+ *              n_rows * ld * 4 < 4 GiB - else LS3D_ERR_UNSUPPORTED (the caller launches the layers one by one).
+ *   state:     ls3d_tile_chain_state_bytes(n_rows) bytes of per-call scratch, 16-byte aligned (tickets, completion counters, the layer
+ *              table; initialised by the call).  workspace / counters / flags bits 6-7, 30: as for ls3d_tile_conv (the split over the
+ *              input channels is decided layer by layer by the same rule).
+ * Results are bit-identical to n_layers calls of ls3d_tile_conv: a unit runs the same code on the same tile in the same summation order;
+ * only the data movement between layers (coherent sc1 accesses across the XCDs' L2s) and the dispatch order of the tiles (spatial) differ. */
+typedef struct {
+  const float *in;
+  int32_t in_ld;
+  const void *w_packed;
+  int32_t cin, cout;
+  ls3d_epilogue_t epi;
+  float *out;
+  int32_t out_ld;
+} ls3d_tile_chain_layer_t;
+size_t ls3d_tile_chain_state_bytes(int n_rows);
+int ls3d_tile_conv_chain(const void *plan, int n_rows, int kvol, const ls3d_tile_chain_layer_t *layers, int n_layers, int products, void *state,
+                         size_t state_bytes, void *workspace, size_t workspace_bytes, int32_t *counters, int flags, ls3d_stream_t stream);
+
 /* Backward of the sparse convolutions (spconv v1.x indice_conv_backward).
  *   grad_in : ls3d_gather_gemm on grad_out with the TRANSPOSED table (SubM: the same table; SparseConv3d: nbr_inv;
  *             SparseInverseConv3d: nbr_out) and weights W'[k] = W[k]^T (SubM: W'[k] = W[kvol-1-k]^T) - no extra entry point;

@@ -20,7 +20,7 @@ EXPORTS = [
     "ls3d_vfe_tokens", "ls3d_transvfe", "ls3d_transvfe_workspace_bytes", "ls3d_mha_core", "ls3d_group_max", "ls3d_layernorm", "ls3d_index_build",
     "ls3d_rulebook_subm", "ls3d_rulebook_conv_workspace_bytes", "ls3d_rulebook_conv", "ls3d_rulebook_masks", "ls3d_rulebook_sort_keys", "ls3d_rulebook_parity_keys", "ls3d_point_mlp", "ls3d_segment_local_index", "ls3d_segment_local_index32", "ls3d_gather_gemm", "ls3d_gather_gemm_pack", "ls3d_gather_gemm_packed_floats", "ls3d_gather_gemm_default_nt", "ls3d_spconv_wgrad_workspace_bytes", "ls3d_spconv_wgrad", "ls3d_spconv_pairs_bytes", "ls3d_spconv_pairs", "ls3d_spconv_wgrad_on_pairs", 
     "ls3d_tile_keys", "ls3d_tile_plan_bytes", "ls3d_tile_build", "ls3d_tile_plan", "ls3d_tile_plan_workspace_bytes", "ls3d_radix_sort",
-    "ls3d_radix_sort_workspace_bytes", "ls3d_tile_conv_packed_bytes", "ls3d_tile_conv_pack", "ls3d_tile_conv_packed_bytes_bf16", "ls3d_tile_conv_pack_bf16", "ls3d_tile_conv", "ls3d_tile_conv_workspace_bytes", "ls3d_tile_conv_counter_bytes", "ls3d_tile_conv_trace_bytes", "ls3d_transvfe_planes_bytes", "ls3d_transvfe_pack_planes",
+    "ls3d_radix_sort_workspace_bytes", "ls3d_tile_conv_packed_bytes", "ls3d_tile_conv_pack", "ls3d_tile_conv_packed_bytes_bf16", "ls3d_tile_conv_pack_bf16", "ls3d_tile_conv", "ls3d_tile_conv_workspace_bytes", "ls3d_tile_conv_counter_bytes", "ls3d_tile_conv_trace_bytes", "ls3d_tile_chain_state_bytes", "ls3d_tile_conv_chain", "ls3d_transvfe_planes_bytes", "ls3d_transvfe_pack_planes",
     "ls3d_voxel_centers", "ls3d_frame_offsets", "ls3d_three_nn", "ls3d_three_interpolate", "ls3d_three_interpolate_grad",
     "ls3d_seg_loss_workspace_bytes", "ls3d_seg_loss_saved_bytes", "ls3d_seg_loss_forward", "ls3d_seg_loss_backward", "ls3d_layer_norm_workspace_bytes", "ls3d_layer_norm_forward", "ls3d_layer_norm_backward", "ls3d_batch_norm_workspace_bytes", "ls3d_batch_norm_stats", "ls3d_batch_norm_apply", "ls3d_batch_norm_backward_sums", "ls3d_batch_norm_backward_apply", "ls3d_devoxelize", "ls3d_devoxelize_grid", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_interpolate_rows", "ls3d_grid_gather", "ls3d_nchw_to_nhwc", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn", "ls3d_sffm_decoder", "ls3d_sffm_memory", "ls3d_points_cp", "ls3d_points_cuv",
 ]
@@ -39,6 +39,12 @@ class Epilogue(ctypes.Structure):
     _fields_ = [("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("res_pre", ctypes.c_void_p),
                 ("res_pre_ld", ctypes.c_int32), ("pair", ctypes.c_void_p), ("pair_ld", ctypes.c_int32),
                 ("relu", ctypes.c_int32), ("ln_gamma", ctypes.c_void_p), ("ln_beta", ctypes.c_void_p), ("ln_eps", ctypes.c_float)]
+
+
+class TileChainLayer(ctypes.Structure):
+    """ls3d_tile_chain_layer_t: one layer of ls3d_tile_conv_chain"""
+    _fields_ = [("in_", ctypes.c_void_p), ("in_ld", ctypes.c_int32), ("w_packed", ctypes.c_void_p), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32),
+                ("epi", Epilogue), ("out", ctypes.c_void_p), ("out_ld", ctypes.c_int32)]
 
 
 class TransVFELayer(ctypes.Structure):
@@ -87,7 +93,7 @@ def _configure(lib):
     for name in ("ls3d_voxelize_hard_workspace_bytes", "ls3d_dynamic_scatter_workspace_bytes", "ls3d_dynamic_scatter_backward_workspace_bytes", "ls3d_segment_reduce_workspace_bytes",
                  "ls3d_rulebook_conv_workspace_bytes", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_gather_gemm_packed_floats",
                  "ls3d_spconv_wgrad_workspace_bytes", "ls3d_spconv_pairs_bytes", "ls3d_tile_plan_bytes", "ls3d_tile_conv_packed_bytes", "ls3d_tile_conv_packed_bytes_bf16", "ls3d_tile_plan_workspace_bytes", "ls3d_radix_sort_workspace_bytes",
-                 "ls3d_tile_conv_workspace_bytes", "ls3d_tile_conv_counter_bytes", "ls3d_tile_conv_trace_bytes", "ls3d_transvfe_planes_bytes", "ls3d_transvfe_workspace_bytes",
+                 "ls3d_tile_conv_workspace_bytes", "ls3d_tile_conv_counter_bytes", "ls3d_tile_conv_trace_bytes", "ls3d_tile_chain_state_bytes", "ls3d_transvfe_planes_bytes", "ls3d_transvfe_workspace_bytes",
                  "ls3d_seg_loss_workspace_bytes", "ls3d_seg_loss_saved_bytes", "ls3d_layer_norm_workspace_bytes", "ls3d_batch_norm_workspace_bytes"):
         getattr(lib, name).restype = ctypes.c_size_t
     for name in EXPORTS:

@@ -54,6 +54,13 @@ __device__ __forceinline__ void ls3d_glds16x3(const void *gbase, unsigned voff0,
 }
 __device__ __forceinline__ float ls3d_load_agent(const float *p) { return *p; }
 __device__ __forceinline__ void ls3d_store_agent(float *p, float v) { *p = v; }
+__device__ __forceinline__ int ls3d_load_agent_i32(const int *p) { return *(const volatile int *)p; }
+__device__ __forceinline__ void ls3d_store_agent_i32(int *p, int v) { *(volatile int *)p = v; }
+struct ls3d_cohbuf { const char *base; };
+__device__ __forceinline__ ls3d_cohbuf ls3d_cohbuf_make(const void *base) { return ls3d_cohbuf{(const char *)base}; }
+__device__ __forceinline__ float4 ls3d_load4_agent(const ls3d_cohbuf &b, unsigned byte_off) { return *(const float4 *)(b.base + byte_off); }
+__device__ __forceinline__ void ls3d_store4_agent(const ls3d_cohbuf &b, unsigned byte_off, const float4 &v) { *(float4 *)(b.base + byte_off) = v; }
+__device__ __forceinline__ void ls3d_sleep() {}
 #define LS3D_WAIT_VMCNT(n) ((void)0)
 #define LS3D_WAIT_LGKMCNT0() ((void)0)
 #define LS3D_SCHED_FENCE() ((void)0)
@@ -81,6 +88,26 @@ __device__ __forceinline__ void ls3d_glds16x3(const void *gbase, unsigned voff0,
 // release / acquire fence pair would cost every other workgroup of the XCD
 __device__ __forceinline__ float ls3d_load_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ls3d_store_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ls3d_load_agent_i32(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ls3d_store_agent_i32(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte accesses with the same cache policy as those atomics (`sc1`: the access is performed where all XCDs agree, a load never returns
+// another XCD's stale line, a store is written through): raw buffer instructions over [base, base + 4 GB) with the sc1 bit in their
+// cache-policy operand - hipcc tracks them in vmcnt like any load.  Used by the chained tile convolution (tileconv.hip), whose layers
+// read each other's output rows across XCDs inside ONE launch.
+struct ls3d_cohbuf { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ ls3d_cohbuf ls3d_cohbuf_make(const void *base) {
+  return ls3d_cohbuf{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xFFFFFFFF, 0x00020000)};
+}
+typedef int ls3d_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ls3d_load4_agent(const ls3d_cohbuf &b, unsigned byte_off) {
+  const ls3d_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)byte_off, 0, 16 /* sc1 */);
+  return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ __forceinline__ void ls3d_store4_agent(const ls3d_cohbuf &b, unsigned byte_off, const float4 &v) {
+  const ls3d_i32x4 w = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(w, b.r, (int)byte_off, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ void ls3d_sleep() { __builtin_amdgcn_s_sleep(16); }
 #define LS3D_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define LS3D_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  /* every LDS read issued so far has returned */
 #define LS3D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)  /* nothing is scheduled across: e.g. keeps a batch of ds_reads together */

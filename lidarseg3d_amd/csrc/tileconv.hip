@@ -23,7 +23,9 @@
 constexpr int TC_TR = 128;     // output rows per tile (4 waves x 32)
 constexpr int TC_HCAP = 448;   // halo rows resident in LDS per pass
 constexpr int TC_KMAX = 32;    // kernel offsets per table (3x3x3 = 27)
-constexpr int TC_META = 8;     // ints per tile: halo size, tile offset mask, 4 wave offset masks, live rows, spare
+constexpr int TC_META = 8;     // ints per tile: halo size, tile offset mask, 4 wave offset masks, live rows, producer tiles (-1: more than TC_DEPCAP)
+constexpr int TC_DEPCAP = 32;  // producer tiles listed per tile (ls3d_tile_conv_chain)
+constexpr int TC_DEPHASH = 128;
 
 // ---------------------------------------------------------------------------------------------------------------
 // spatial sort keys
@@ -88,6 +90,9 @@ struct TilePlan {
   uint16_t *tloc;   // [T][kvol][128] position of tbl[row][k] in the tile's halo, 0xFFFF = no neighbour
   int32_t *torder;  // [T + 1]       dispatch order of the tiles: most expensive first (k_tile_order); torder[T] = number of LIVE tiles (tiles
                     //               with at least one row below the device row count)
+  int32_t *rowtile; // [T * 128]     tile that holds output row r (inverse of the spatial order, / 128)
+  int32_t *tdep;    // [T][TC_DEPCAP] the tiles whose OUTPUT rows the tile's halo reads (its producers in a chained launch; meaningful when
+                    //               the table's input sites are its output sites: SubM); their number in tmeta[7]
 };
 
 static inline size_t tc_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -102,14 +107,26 @@ static TilePlan tc_plan(void *buf, int n_rows, int kvol) {
   p.tmeta = (int32_t *)b; b += tc_align((size_t)p.ntiles * TC_META * 4);
   p.thalo = (int32_t *)b; b += tc_align((size_t)p.ntiles * p.hs * 4);
   p.tloc = (uint16_t *)b; b += tc_align((size_t)p.ntiles * kvol * TC_TR * 2);
-  p.torder = (int32_t *)b;
+  p.torder = (int32_t *)b; b += tc_align((size_t)(p.ntiles + 1) * 4);
+  p.rowtile = (int32_t *)b; b += tc_align((size_t)p.ntiles * TC_TR * 4);
+  p.tdep = (int32_t *)b;
   return p;
 }
 
 extern "C" size_t ls3d_tile_plan_bytes(int n_rows, int kvol) {
   if (n_rows < 0 || kvol < 1) return 0;
   const size_t t = (size_t)(n_rows + TC_TR - 1) / TC_TR;
-  return tc_align(t * TC_TR * 4) + tc_align(t * TC_META * 4) + tc_align(t * kvol * TC_TR * 4) + tc_align(t * kvol * TC_TR * 2) + tc_align((t + 1) * 4);
+  return tc_align(t * TC_TR * 4) + tc_align(t * TC_META * 4) + tc_align(t * kvol * TC_TR * 4) + tc_align(t * kvol * TC_TR * 2) + tc_align((t + 1) * 4) +
+         tc_align(t * TC_TR * 4) + tc_align(t * TC_DEPCAP * 4);
+}
+
+// rowtile[r] = tile of output row r: position of r in the spatial order / 128 (the order is a permutation of all n rows, spare rows last)
+__global__ __launch_bounds__(256) void k_tile_rowtile(const int32_t *__restrict__ sorder, int n, const int32_t *n_dev, int32_t *__restrict__ rowtile) {
+  const int N = ls3d_count(n, n_dev);  // the order beyond the device count is unspecified (ls3d_radix_sort_pairs)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    const int r = sorder[i];
+    if ((unsigned)r < (unsigned)n) rowtile[r] = i / TC_TR;
+  }
 }
 
 // one workgroup per tile.  The tile's distinct input rows: the <= kvol*128 table entries go through an LDS hash set (insertion
@@ -236,6 +253,36 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
         }
       }
     }
+    // Producer tiles (ls3d_tile_conv_chain: layer l + 1 of a chained launch starts a tile as soon as the tiles that own its halo rows have
+    // finished layer l): the distinct rowtile[] of the halo rows through a small LDS hash set (s_hash is dead since the compaction); the
+    // list's order is arbitrary, the set is not.  More than TC_DEPCAP producers: tmeta[7] = -1 ("wait for the whole layer").
+    __syncthreads();
+    if (tid < TC_DEPHASH) s_hash[tid] = -1;
+    if (tid < 2) s_scan[0][tid] = 0;
+    __syncthreads();
+    {
+      const int nrt = N;  // halo rows are valid input rows; only rows below the device count are output rows of this plan
+      for (int i = tid; i < H; i += 256) {
+        const int v = s_uniq[i];
+        if (v >= nrt) { atomicAdd(&s_scan[0][0], TC_DEPHASH); continue; }  // not an output row of this plan (a table that is not SubM)
+        const int t = p.rowtile[v];
+        unsigned h = ((unsigned)t * 2654435761u) >> 25;  // 7 bits
+        int probe = 0;
+        for (; probe < TC_DEPHASH; ++probe) {
+          const int prev = atomicCAS(&s_hash[h], -1, t);
+          if (prev == -1) { atomicAdd(&s_scan[0][0], 1); break; }
+          if (prev == t) break;
+          h = (h + 1) & (TC_DEPHASH - 1);
+        }
+        if (probe == TC_DEPHASH) atomicAdd(&s_scan[0][0], TC_DEPHASH);
+      }
+    }
+    __syncthreads();
+    const int ndep = s_scan[0][0];
+    if (tid < TC_DEPHASH && ndep <= TC_DEPCAP) {
+      const int t = s_hash[tid];
+      if (t >= 0) p.tdep[(size_t)tile * TC_DEPCAP + atomicAdd(&s_scan[0][1], 1)] = t;
+    }
     if (tid < TC_TR) p.trow[(size_t)tile * TC_TR + tid] = s_srow[tid];
     if (tid < 8) {
       int v = 0;
@@ -243,6 +290,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
       else if (tid == 1) { unsigned m = 0u; for (int s2 = 0; s2 < TC_TR; ++s2) m |= s_smask[s2]; v = (int)m; }
       else if (tid < 6) { unsigned m = 0u; for (int s2 = 0; s2 < 32; ++s2) m |= s_smask[(tid - 2) * 32 + s2]; v = (int)m; }
       else if (tid == 6) { int c2 = 0; for (int s2 = 0; s2 < TC_TR; ++s2) c2 += s_srow[s2] >= 0; v = c2; }
+      else if (tid == 7) v = ndep <= TC_DEPCAP ? ndep : -1;
       p.tmeta[(size_t)tile * TC_META + tid] = v;
     }
   }
@@ -318,6 +366,7 @@ extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_
   if (((uintptr_t)plan & 15)) return LS3D_ERR_ARG;
   if (n_rows == 0) return LS3D_OK;
   TilePlan p = tc_plan(plan, n_rows, kvol);
+  hipLaunchKernelGGL(k_tile_rowtile, ls3d_grid(n_rows), dim3(256), 0, (hipStream_t)stream, spatial_order, n_rows, n_rows_dev, p.rowtile);
   hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, (hipStream_t)stream, tbl, n_rows, n_rows_dev,
                      kvol, spatial_order, p);
   hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, (flags & 1) ? 0 : 1);
@@ -355,6 +404,7 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
   int rc = ls3d_radix_sort_pairs(keys, nullptr, n_rows, n_rows_dev, bits, nullptr, order, sort_ws, workspace_bytes - 2 * seg, stream);
   if (rc != LS3D_OK) return rc;
   TilePlan p = tc_plan(plan, n_rows, kvol);
+  hipLaunchKernelGGL(k_tile_rowtile, ls3d_grid(n_rows), dim3(256), 0, stream, (const int32_t *)order, n_rows, n_rows_dev, p.rowtile);
   hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, stream, tbl, n_rows, n_rows_dev, kvol,
                      (const int32_t *)order, p);
   hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, p, (flags & 1) ? 0 : 1);
@@ -454,7 +504,9 @@ constexpr int TC_THREADS = 256;
 // residual / pair operands are fetched in batches of branch-free loads: one memory latency per batch.  gg_epilogue (two passes of 64
 // rows, a conditional load chain per row group) took 18 of a 128 -> 128 tile's 204 us (tools/trace_tile.py).  Same arithmetic per
 // element, in the same order: results are bit-identical to gg_epilogue's.
-template <int NT>
+// CH (chained launch): the residual / pair operands may be rows another XCD wrote earlier in THIS launch and the output rows are read by
+// other XCDs later in it - coherent (sc1) 16-byte accesses instead of cached ones (common.h: ls3d_load4_agent / ls3d_store4_agent).
+template <int NT, bool CH = false>
 __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, const int *s_rows, int wave, int kk, int col, int cout, const EpiDev &e,
                                             float *__restrict__ out, int out_ld) {
   constexpr int SLAB = NT * 32, C4 = SLAB / 4, RPI = TC_THREADS / C4, ITER = TC_TR / RPI, BATCH = ITER < 8 ? ITER : 8;
@@ -480,6 +532,22 @@ __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, con
     float4 q[BATCH], p0[BATCH], p1[BATCH];
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) orow[j] = s_rows[lr0 + (b0 + j) * RPI];
+    if constexpr (CH) {
+      if (e.res_pre) {
+        const ls3d_cohbuf rb = ls3d_cohbuf_make(e.res_pre);
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) q[j] = ls3d_load4_agent(rb, ((unsigned)(orow[j] >= 0 ? orow[j] : 0) * (unsigned)e.res_pre_ld + (unsigned)occ) * 4u);
+      }
+      if (e.pair) {
+        const ls3d_cohbuf pb = ls3d_cohbuf_make(e.pair);
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const unsigned po = ((unsigned)(orow[j] >= 0 ? orow[j] : 0) * (unsigned)e.pair_ld + 2u * (unsigned)occ) * 4u;
+          p0[j] = ls3d_load4_agent(pb, po);
+          p1[j] = ls3d_load4_agent(pb, po + 16u);
+        }
+      }
+    } else {
     if (e.res_pre) {
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) q[j] = *(const float4 *)(e.res_pre + (size_t)(orow[j] >= 0 ? orow[j] : 0) * e.res_pre_ld + occ);
@@ -492,6 +560,7 @@ __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, con
         p1[j] = *(const float4 *)(pp + 4);
       }
     }
+    }
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) {
       float4 v = *(const float4 *)(stage + (lr0 + (b0 + j) * RPI) * SLAB + oc);
@@ -500,8 +569,72 @@ __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, con
       if (e.res_pre) { v.x += q[j].x; v.y += q[j].y; v.z += q[j].z; v.w += q[j].w; }
       if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if (e.pair) { v.x += p0[j].x + p0[j].y; v.y += p0[j].z + p0[j].w; v.z += p1[j].x + p1[j].y; v.w += p1[j].z + p1[j].w; }
-      if (oncol && orow[j] >= 0) *(float4 *)(out + (size_t)orow[j] * out_ld + oc) = v;
+      if constexpr (CH) {
+        if (oncol && orow[j] >= 0) ls3d_store4_agent(ls3d_cohbuf_make(out), ((unsigned)orow[j] * (unsigned)out_ld + (unsigned)oc) * 4u, v);
+      } else {
+        if (oncol && orow[j] >= 0) *(float4 *)(out + (size_t)orow[j] * out_ld + oc) = v;
+      }
     }
+  }
+}
+
+// ---- chained launch (ls3d_tile_conv_chain): up to TC_CHAIN_MAX layers on ONE plan in one persistent launch.
+// Work units (layer, tile [, half]) are handed out in layer-major order by a ticket counter; a unit of layer l > 0 first waits until the
+// tiles that own its halo rows (the plan's producer lists) have finished layer l - 1.  A unit only ever waits for units with smaller
+// tickets, every ticket is held by a running workgroup, so the smallest outstanding ticket never waits: no deadlock whatever the number
+// of resident workgroups.  What it buys: the tail of a launch - 677 tiles on 512 workgroup slots leave the second round 32 % full - is
+// filled with the next layer's tiles.
+constexpr int TC_CHAIN_MAX = 8;
+template <typename T>
+__device__ __forceinline__ T *tc_uniform(T *p) {  // a pointer every lane holds the same value of -> scalar registers
+  const unsigned long long v = (unsigned long long)(uintptr_t)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+struct TcLayer {
+  const float *in;
+  const uint4 *wpk;
+  float *out;
+  EpiDev e;
+  int in_ld, cin, cout, out_ld, n_split, pad_;
+};
+// state (ints): [0] ticket, [1] error (1: a wait ran into the watchdog), [2] total units, [3 .. 3 + TC_CHAIN_MAX] first ticket of each
+// layer (+ the total again), [16 .. 16 + TC_CHAIN_MAX) finished tiles per layer, [32 .. 32 + T) layers finished per tile;
+// the layer table follows at byte TC_CH_LAYERS_OFF(T)
+constexpr int TC_CH_USTART = 3, TC_CH_LDONE = 16, TC_CH_DONE = 32;
+constexpr int TC_CH_SPIN_MAX = 1 << 22;  // ~1 s of polling: a wait that long is a bug; the unit goes on and flags state[1]
+static inline size_t tc_chain_layers_off(int ntiles) { return tc_align((size_t)(TC_CH_DONE + ntiles) * 4); }
+struct TcChain {
+  const TcLayer *layers;
+  int *state;
+  int n_layers;
+};
+struct TcChainSetup {
+  TcLayer l[TC_CHAIN_MAX];
+};
+
+// one workgroup in front of the chained launch: zeroes the ticket / completion counters, decides every layer's split over the input
+// channels from the plan's live tile count (the rule of ls3d_tile_conv) and writes the layer table to device memory
+__global__ __launch_bounds__(256) void k_tile_chain_setup(TilePlan p, TcChainSetup su, int n_layers, int split_small, TcLayer *dst, int *state) {
+  const int tid = threadIdx.x;
+  const int tlive = p.torder[p.ntiles];
+  for (int i = tid; i < p.ntiles; i += 256) state[TC_CH_DONE + i] = 0;
+  if (tid < TC_CH_DONE) state[tid] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+#pragma unroll
+    for (int l = 0; l < TC_CHAIN_MAX; ++l) {
+      if (l < n_layers) {
+        TcLayer L = su.l[l];
+        L.n_split = (L.n_split && tlive <= split_small) ? tlive : 0;  // host: n_split = 1 when the layer may split (cin >= 64, workspace + counters given)
+        dst[l] = L;
+        state[TC_CH_USTART + l] = run;
+        run += tlive + L.n_split;
+      }
+    }
+    for (int l = n_layers; l <= TC_CHAIN_MAX; ++l) state[TC_CH_USTART + l] = run;
+    state[2] = run;
   }
 }
 
@@ -519,11 +652,16 @@ __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, con
 // LP = 1 (NT >= 2, NP == 6): the offset loop software-pipelined one offset ahead with the step barrier in the MIDDLE of an offset's
 // MFMAs (see the loop); LP = 0: fragments read at the start of the step that uses them (NT = 1, NP = 1 / 8, flags bit 0).
 constexpr int TC_TRACE_WORDS = 16;
-template <int NT, int NP, bool TR = false, int LP = 0>
-__global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in, int in_ld, TilePlan p, const uint4 *__restrict__ wpk,
-                                                             int cin, int cout, EpiDev e, float *__restrict__ out, int out_ld, int ablate, int swz,
+// CH = chained launch (ls3d_tile_conv_chain): persistent workgroups take (layer, tile [, half]) units from a ticket counter, the layer's operands
+// come from the device-side layer table, a unit of layer l > 0 waits for the producer tiles of its halo at layer l - 1, and everything that
+// one layer writes and another reads inside the launch moves with coherent (sc1) accesses.  Tiles are taken in the plan's spatial order
+// (neighbours finish close together).  The arithmetic of a unit is the same code: results are bit-identical to layer-by-layer launches.
+template <int NT, int NP, bool TR = false, int LP = 0, bool CH = false>
+__global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in_a, int in_ld_a, TilePlan p, const uint4 *__restrict__ wpk_a,
+                                                             int cin_a, int cout_a, EpiDev e_a, float *__restrict__ out_a, int out_ld_a, int ablate, int swz,
                                                              int split_small, int split_tail, int split_forced, float *partial, int *counters,
-                                                             unsigned *trace) {
+                                                             unsigned *trace, TcChain ch) {
+  static_assert(!(CH && TR), "no tracing build of the chained launch");
   constexpr int PLN = NP == 1 ? 1 : 3;     // weight planes in the packed layout (NP == 1: the head plane only, ls3d_tile_conv_pack_bf16)
   constexpr int PU = NT * 64 * PLN;        // 16-byte units of one (offset, chunk) weight piece
   constexpr int PB = NT * PLN;             // ... in 1 KB LDS-DMA blocks
@@ -540,7 +678,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                         // scalar: per-wave decisions are s_cbranch
   const int col = lane & 31, kk = lane >> 5;
-  const int kvol = p.kvol, nchunk = cin / 16;
+  const int kvol = p.kvol;
   // this wave's share of a step's weight DMA: blocks [3 wave, 3 wave + 3) of the 12; with three planes all inside one offset's piece
   // (dma_g, from block dma_j on), with one plane each block in its own (offset, block) - TC_DMA_GROUP
   const int dma_g = (3 * wave) / PB, dma_j = (3 * wave) % PB;
@@ -556,19 +694,50 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   // capacity: a plan built on spare rows (capacity mode) and the plan of the exact table run the same units on the same tiles.
   // The launch covers the worst case; workgroups beyond the units of the live tiles leave at once.
   const int tlive = p.torder[p.ntiles];
-  // split_tail < 0: the tiles beyond the last full round of TC_SPLIT_MAX workgroup slots (the tail that would run one per CU)
-  int n_split = split_forced >= 0 ? split_forced : (tlive <= split_small ? tlive : (split_tail < 0 ? tlive % 512 : split_tail));  // scalar
-  if (n_split > tlive) n_split = tlive;
-  const int nfull = tlive - n_split;
-  if ((int)blockIdx.x >= nfull + 2 * n_split) return;
-  {
-    int tile, part = 0, ksplit = 1, sidx = 0;
-    if ((int)blockIdx.x < nfull) {
-      tile = p.torder[blockIdx.x];
+  for (;;) {  // CH: one work unit per ticket until the tickets run out; otherwise one pass (the unit of this workgroup)
+    const float *__restrict__ in = in_a;
+    const uint4 *__restrict__ wpk = wpk_a;
+    float *__restrict__ out = out_a;
+    EpiDev e = e_a;
+    int in_ld = in_ld_a, cin = cin_a, cout = cout_a, out_ld = out_ld_a;
+    int n_split, blk;
+    [[maybe_unused]] int ch_layer = 0;
+    if constexpr (CH) {
+      __syncthreads();  // the previous unit of this workgroup is done with LDS
+      if (tid == 0) *(int *)s_stat = atomicAdd(ch.state, 1);
+      __syncthreads();
+      const int u = __builtin_amdgcn_readfirstlane(*(const int *)s_stat);
+      if (u >= ch.state[2]) return;
+      for (int l = 1; l < ch.n_layers; ++l)
+        if (u >= ch.state[TC_CH_USTART + l]) ch_layer = l;
+      blk = u - ch.state[TC_CH_USTART + ch_layer];
+      // the layer's operands, made wave-uniform explicitly (scalar registers: the weight DMA takes a scalar base, the coherent accesses a
+      // scalar buffer descriptor)
+      const TcLayer *L = ch.layers + ch_layer;
+      in = tc_uniform(L->in); wpk = tc_uniform(L->wpk); out = tc_uniform(L->out);
+      e.scale = tc_uniform(L->e.scale); e.shift = tc_uniform(L->e.shift); e.res_pre = tc_uniform(L->e.res_pre); e.pair = tc_uniform(L->e.pair);
+      e.ln_gamma = e.ln_beta = nullptr; e.ln_eps = 0.0f;
+      e.res_pre_ld = __builtin_amdgcn_readfirstlane(L->e.res_pre_ld); e.pair_ld = __builtin_amdgcn_readfirstlane(L->e.pair_ld);
+      e.relu = __builtin_amdgcn_readfirstlane(L->e.relu);
+      in_ld = __builtin_amdgcn_readfirstlane(L->in_ld); cin = __builtin_amdgcn_readfirstlane(L->cin);
+      cout = __builtin_amdgcn_readfirstlane(L->cout); out_ld = __builtin_amdgcn_readfirstlane(L->out_ld);
+      n_split = __builtin_amdgcn_readfirstlane(L->n_split);
     } else {
-      const int v = (int)blockIdx.x - nfull;
+      // split_tail < 0: the tiles beyond the last full round of TC_SPLIT_MAX workgroup slots (the tail that would run one per CU)
+      n_split = split_forced >= 0 ? split_forced : (tlive <= split_small ? tlive : (split_tail < 0 ? tlive % 512 : split_tail));  // scalar
+      blk = (int)blockIdx.x;
+    }
+    if (n_split > tlive) n_split = tlive;
+    const int nfull = tlive - n_split;
+    if (blk >= nfull + 2 * n_split) return;
+    const int nchunk = cin / 16;
+    int tile, part = 0, ksplit = 1, sidx = 0;
+    if (blk < nfull) {
+      tile = CH ? blk : p.torder[blk];
+    } else {
+      const int v = blk - nfull;
       sidx = v >> 1;
-      tile = p.torder[nfull + sidx];
+      tile = CH ? nfull + sidx : p.torder[nfull + sidx];
       part = v & 1;
       ksplit = 2;
     }
@@ -576,7 +745,35 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     const int H = meta[0];
     const unsigned kmask = (unsigned)meta[1];
     const unsigned wmask = (unsigned)__builtin_amdgcn_readfirstlane(meta[2 + wave]);
-    if (meta[6] == 0) return;
+    if (meta[6] == 0) {
+      if constexpr (CH) continue; else return;
+    }
+    if constexpr (CH) {
+      if (ch_layer > 0) {
+        // the tiles that own this tile's halo rows must have finished the previous layer (its output rows are this layer's halo, residual
+        // and pair operands; everything older follows by induction: a tile is its own producer).  One lane per producer polls its
+        // completion counter with coherent loads; more than TC_DEPCAP producers: wait for the whole previous layer.
+        const int nd = meta[7];
+        if (nd >= 0) {
+          if (tid < nd) {
+            const int *flag = ch.state + TC_CH_DONE + p.tdep[(size_t)tile * TC_DEPCAP + tid];
+            for (int spins = 0; ls3d_load_agent_i32(flag) < ch_layer; ++spins) {
+              ls3d_sleep();
+              if (spins > TC_CH_SPIN_MAX) { ls3d_store_agent_i32(ch.state + 1, 1); break; }
+            }
+          }
+        } else if (tid == 0) {
+          const int *flag = ch.state + TC_CH_LDONE + ch_layer - 1;
+          for (int spins = 0; ls3d_load_agent_i32(flag) < tlive; ++spins) {
+            ls3d_sleep();
+            if (spins > TC_CH_SPIN_MAX) { ls3d_store_agent_i32(ch.state + 1, 1); break; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    [[maybe_unused]] ls3d_cohbuf in_coh;
+    if constexpr (CH) in_coh = ls3d_cohbuf_make(in);
     unsigned long long tr_w0 = 0, tr_t0 = 0, tr_mark = 0;
     unsigned tr_pro = 0, tr_stage = 0, tr_bar = 0, tr_steps = 0;
     if constexpr (TR) { tr_w0 = ls3d_walltime(); tr_t0 = ls3d_cycles(); }
@@ -623,7 +820,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   _Pragma("unroll") for (int j = 0; j < HPT; ++j) {                                       \
     const int i = tid + j * TC_THREADS, hrow = i >> 2, q = i & 3;                         \
     const int hr = hrow < nh ? hrow : nh - 1;                                             \
-    hv[j] = *(const float4 *)(in + (size_t)s_hid[hr] * in_ld + (c_) * 16 + q * 4);        \
+    if constexpr (CH)                                                                     \
+      hv[j] = ls3d_load4_agent(in_coh, ((unsigned)s_hid[hr] * (unsigned)in_ld + (unsigned)((c_) * 16 + q * 4)) * 4u); \
+    else                                                                                  \
+      hv[j] = *(const float4 *)(in + (size_t)s_hid[hr] * in_ld + (c_) * 16 + q * 4);      \
   }
       const int c_lo = nchunk * part / ksplit, c_hi = nchunk * (part + 1) / ksplit;
       if (!(ablate & 16)) { TC_LOAD_HALO(c_lo) }
@@ -912,7 +1112,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
       __syncthreads();
       if (s_hid[0] == 0) {  // first of the two: the other unit finishes the tile
         TC_TRACE_WRITE(0)
-        return;
+        if constexpr (CH) continue; else return;
       }
       const float *other = partial + ((size_t)sidx * 2 + (part ^ 1)) * (NT * 16 * TC_THREADS) + tid;
 #pragma unroll
@@ -920,12 +1120,24 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] += ls3d_load_agent(other + (n * 16 + r) * TC_THREADS);  // a + b == b + a: order-independent
     }
+    if constexpr (CH) {  // (the host takes only float4-aligned layers without LayerNorm into a chain)
+      tc_epilogue<NT, true>(acc, (float *)smem, s_rows, wave, kk, col, cout, e, out, out_ld);
+      // the tile's output rows are written through; when every wave's stores have been acknowledged the tile counts as finished
+      LS3D_WAIT_VMCNT(0);
+      __syncthreads();
+      if (tid == 0) {
+        ls3d_store_agent_i32(ch.state + TC_CH_DONE + tile, ch_layer + 1);
+        atomicAdd(ch.state + TC_CH_LDONE + ch_layer, 1);
+      }
+    } else {
     if (!e.ln_gamma && !(cout & 3) && !(out_ld & 3) && !(e.res_pre && (e.res_pre_ld & 3)) && !(e.pair && (e.pair_ld & 3)) && !(ablate & 2))
       tc_epilogue<NT>(acc, (float *)smem, s_rows, wave, kk, col, cout, e, out, out_ld);
     else  // LayerNorm epilogue, unaligned leading dimensions, or flags bit 1 (A/B): the general one
       gg_epilogue<NT, 1, TC_TR, 64, TC_THREADS>(acc, (float *)smem, s_rows, s_stat, wave, 0, kk, col, 0, cout, e, out, out_ld);
+    }
     TC_TRACE_WRITE(1)
 #undef TC_TRACE_WRITE
+    if constexpr (!CH) return;
   }
 }
 
@@ -940,7 +1152,22 @@ static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TileP
     attr_set = true;
   }
   hipLaunchKernelGGL((k_tile_conv<NT, NP, TR, LP>), dim3((unsigned)max_units), dim3(TC_THREADS), TC_LDS_BYTES, stream, in, in_ld, p, wpk, cin, cout,
-                     e, out, out_ld, ablate, swz, split_small, split_tail, split_forced, partial, counters, trace);
+                     e, out, out_ld, ablate, swz, split_small, split_tail, split_forced, partial, counters, trace, TcChain{nullptr, nullptr, 0});
+  return LS3D_OK;
+}
+
+template <int NT, int NP, int LP>
+static int tc_launch_chain(hipStream_t stream, const TilePlan &p, int swz, int grid, float *partial, int *counters, const TcChain &ch) {
+  static bool attr_set_on[LS3D_MAX_DEVICES] = {};
+  bool &attr_set = attr_set_on[ls3d_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void *)k_tile_conv<NT, NP, false, LP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS_BYTES) != hipSuccess)
+      return LS3D_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const EpiDev e0 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.0f};
+  hipLaunchKernelGGL((k_tile_conv<NT, NP, false, LP, true>), dim3((unsigned)grid), dim3(TC_THREADS), TC_LDS_BYTES, stream, (const float *)nullptr, 0, p,
+                     (const uint4 *)nullptr, 16, 32, e0, (float *)nullptr, 0, 0, swz, 0, 0, -1, partial, counters, (unsigned *)nullptr, ch);
   return LS3D_OK;
 }
 
@@ -1059,6 +1286,89 @@ static int tc_conv_slab(const float *in, int in_ld, const void *plan, int n_rows
      : nt == 2 ? (products == 8 ? tc_launch<2, 8>(TC_ARGS) : products == 6 ? (pipelined ? tc_launch<2, 6, false, 1>(TC_ARGS) : tc_launch<2, 6>(TC_ARGS)) : tc_launch<2, 1>(TC_ARGS))
                : (products == 8 ? tc_launch<4, 8>(TC_ARGS) : products == 6 ? (pipelined ? tc_launch<4, 6, false, 1>(TC_ARGS) : tc_launch<4, 6>(TC_ARGS)) : tc_launch<4, 1>(TC_ARGS));
 #undef TC_ARGS
+  if (rc != LS3D_OK) return rc;
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// chained launch
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" size_t ls3d_tile_chain_state_bytes(int n_rows) {
+  if (n_rows < 0) return 0;
+  const int t = (n_rows + TC_TR - 1) / TC_TR;
+  return tc_chain_layers_off(t) + tc_align(sizeof(TcLayer) * TC_CHAIN_MAX);
+}
+
+static int tc_workgroup_slots() {  // persistent workgroups of a chained launch: two per CU (LDS 77 KB each)
+  static int slots_on[LS3D_MAX_DEVICES] = {};
+  int &slots = slots_on[ls3d_device_slot()];
+  if (slots == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slots = 2 * cus;
+  }
+  return slots;
+}
+
+extern "C" int ls3d_tile_conv_chain(const void *plan, int n_rows, int kvol, const ls3d_tile_chain_layer_t *layers, int n_layers, int products,
+                                    void *state, size_t state_bytes, void *workspace, size_t workspace_bytes, int32_t *counters, int flags,
+                                    ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!layers || n_layers < 1 || kvol < 1) return LS3D_ERR_ARG;
+  if (n_layers > TC_CHAIN_MAX || kvol > TC_KMAX || products != 6) return LS3D_ERR_UNSUPPORTED;
+  if (n_rows == 0) return LS3D_OK;
+  if (!plan || !state || n_rows < 0 || ((uintptr_t)plan & 15) || ((uintptr_t)state & 15) || ((uintptr_t)workspace & 15)) return LS3D_ERR_ARG;
+  if (state_bytes < ls3d_tile_chain_state_bytes(n_rows)) return LS3D_ERR_WORKSPACE;
+  const TilePlan p = tc_plan(const_cast<void *>(plan), n_rows, kvol);
+  TcChainSetup su;
+  int nt = 0;
+  bool any_split = false;
+  size_t need_ws = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    const ls3d_tile_chain_layer_t &a = layers[l];
+    if (!a.in || !a.w_packed || !a.out || a.cin < 16 || a.cout < 1) return LS3D_ERR_ARG;
+    if ((a.cin % 16) || (a.in_ld % 4) || a.in_ld < a.cin || a.out_ld < a.cout) return LS3D_ERR_ARG;
+    if (((uintptr_t)a.in & 15) || ((uintptr_t)a.w_packed & 15) || ((uintptr_t)a.out & 15)) return LS3D_ERR_ARG;
+    if (a.cout > 128) return LS3D_ERR_UNSUPPORTED;
+    const int nt_l = a.cout <= 32 ? 1 : a.cout <= 64 ? 2 : 4;
+    if (nt && nt_l != nt) return LS3D_ERR_UNSUPPORTED;  // one kernel variant (column blocks) per chain
+    nt = nt_l;
+    // the chain runs the single-pass float4 epilogue on coherent 16-byte accesses with 32-bit byte offsets
+    const ls3d_epilogue_t &ep = a.epi;
+    if (ep.ln_gamma || ep.ln_beta) return LS3D_ERR_UNSUPPORTED;
+    if ((a.cout & 3) || (a.out_ld & 3) || (ep.res_pre && ((ep.res_pre_ld & 3) || ((uintptr_t)ep.res_pre & 15))) ||
+        (ep.pair && ((ep.pair_ld & 3) || ((uintptr_t)ep.pair & 15))))
+      return LS3D_ERR_UNSUPPORTED;
+    const unsigned long long lim = 0xFFFFFFFFull;
+    if ((unsigned long long)n_rows * a.in_ld * 4 > lim || (unsigned long long)n_rows * a.out_ld * 4 > lim ||
+        (ep.res_pre && (unsigned long long)n_rows * ep.res_pre_ld * 4 > lim) || (ep.pair && (unsigned long long)n_rows * ep.pair_ld * 4 > lim))
+      return LS3D_ERR_UNSUPPORTED;
+    TcLayer &L = su.l[l];
+    L.in = a.in; L.wpk = (const uint4 *)a.w_packed; L.out = a.out;
+    L.e = EpiDev{ep.scale, ep.shift, ep.res_pre, ep.pair, nullptr, nullptr, ep.res_pre_ld, ep.pair_ld, ep.relu, 0.0f};
+    L.in_ld = a.in_ld; L.cin = a.cin; L.cout = a.cout; L.out_ld = a.out_ld; L.pad_ = 0;
+    // the split over the input channels, layer by layer as ls3d_tile_conv decides it (flags bits 6-7 == 1: never)
+    L.n_split = (workspace && counters && a.cin >= 64 && ((flags >> 6) & 3) != 1) ? 1 : 0;
+    if (L.n_split) {
+      any_split = true;
+      const int ns = p.ntiles < TC_SPLIT_MAX ? p.ntiles : TC_SPLIT_MAX;
+      if (tc_partial_bytes(ns, nt_l) > need_ws) need_ws = tc_partial_bytes(ns, nt_l);
+    }
+  }
+  for (int l = n_layers; l < TC_CHAIN_MAX; ++l) su.l[l] = su.l[0];
+  if (any_split && workspace_bytes < need_ws) return LS3D_ERR_WORKSPACE;
+  int *st = (int *)state;
+  TcLayer *dst = (TcLayer *)((char *)state + tc_chain_layers_off(p.ntiles));
+  hipLaunchKernelGGL(k_tile_chain_setup, dim3(1), dim3(256), 0, stream, p, su, n_layers, TC_SPLIT_MAX, dst, st);
+  const long long worst = (long long)n_layers * p.ntiles * 2;
+  const int slots = tc_workgroup_slots();
+  const int grid = (int)(worst < slots ? worst : slots);
+  const int swz = (flags >> 30) & 1 ? 0 : 1;
+  const TcChain ch = {dst, st, n_layers};
+  int rc = nt == 1 ? tc_launch_chain<1, 6, 0>(stream, p, swz, grid, (float *)workspace, (int *)counters, ch)
+         : nt == 2 ? tc_launch_chain<2, 6, 1>(stream, p, swz, grid, (float *)workspace, (int *)counters, ch)
+                   : tc_launch_chain<4, 6, 1>(stream, p, swz, grid, (float *)workspace, (int *)counters, ch);
   if (rc != LS3D_OK) return rc;
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;

@@ -565,10 +565,11 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
         out_view = out
     else:
         out_view = out
-        out_ld = out_ld or out.shape[1]
-    epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
-                   pair.shape[1] if pair is not None else 0, 1 if relu else 0, _vp(ln[0]) if ln is not None else ctypes.c_void_p(0),
-                   _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
+        out_ld = out_ld or _ld(out)
+    epi = Epilogue(_vp(scale), _vp(shift), _vp_any(res_pre) if res_pre is not None else ctypes.c_void_p(0), _ld(res_pre) if res_pre is not None else 0,
+                   _vp_any(pair) if pair is not None else ctypes.c_void_p(0), _ld(pair) if pair is not None else 0, 1 if relu else 0,
+                   _vp(ln[0]) if ln is not None else ctypes.c_void_p(0), _vp(ln[1]) if ln is not None else ctypes.c_void_p(0),
+                   float(ln[2]) if ln is not None else 0.0)
     check(_L().ls3d_gather_gemm(_ptr(x), in_ld, _ptr(tbl), _ptr(order), kvol, _ptr(wdata), nt, wc, prec, cin, cout, n_rows, _ndev(n_dev), ctypes.byref(epi),
                                 _vp_any(out_view), out_ld, _GEMM_FLAGS, _stream(x)), "ls3d_gather_gemm")
     return out
@@ -671,10 +672,12 @@ def tile_conv(x, w, plan, cout=None, products=None, scale=None, shift=None, res_
         out_ld = out_ld or cout
         out = torch.empty((plan.n_rows, out_ld), dtype=torch.float32, device=x.device)
     else:
-        out_ld = out_ld or out.shape[1]
-    epi = Epilogue(_vp(scale), _vp(shift), _vp(res_pre), res_pre.shape[1] if res_pre is not None else 0, _vp(pair),
-                   pair.shape[1] if pair is not None else 0, 1 if relu else 0, _vp(ln[0]) if ln is not None else ctypes.c_void_p(0),
-                   _vp(ln[1]) if ln is not None else ctypes.c_void_p(0), float(ln[2]) if ln is not None else 0.0)
+        out_ld = out_ld or _ld(out)
+    # residual / pair operands may be column views of a wider buffer (a level's concat buffer): their row stride is the leading dimension
+    epi = Epilogue(_vp(scale), _vp(shift), _vp_any(res_pre) if res_pre is not None else ctypes.c_void_p(0), _ld(res_pre) if res_pre is not None else 0,
+                   _vp_any(pair) if pair is not None else ctypes.c_void_p(0), _ld(pair) if pair is not None else 0, 1 if relu else 0,
+                   _vp(ln[0]) if ln is not None else ctypes.c_void_p(0), _vp(ln[1]) if ln is not None else ctypes.c_void_p(0),
+                   float(ln[2]) if ln is not None else 0.0)
     split = _TILE_KSPLIT and cin >= 64
     flags = _TILE_FLAGS
     nbytes = int(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout)) if split else 0
@@ -683,12 +686,82 @@ def tile_conv(x, w, plan, cout=None, products=None, scale=None, shift=None, res_
         off = int(_L().ls3d_tile_conv_workspace_bytes(plan.n_rows, cout))
         nbytes = off + int(_L().ls3d_tile_conv_trace_bytes(plan.n_rows))
     ws = _tile_ws(nbytes, x) if nbytes else None
-    check(_L().ls3d_tile_conv(_ptr(x), in_ld, _ptr(plan.buf), plan.n_rows, kvol, _ptr(w.for_tile(bf16=(products == 1))), cin, cout, products, ctypes.byref(epi),
+    check(_L().ls3d_tile_conv(_vp_any(x), in_ld, _ptr(plan.buf), plan.n_rows, kvol, _ptr(w.for_tile(bf16=(products == 1))), cin, cout, products, ctypes.byref(epi),
                               _vp_any(out), out_ld, _vp(ws), ctypes.c_size_t(ws.numel() if ws is not None else 0),
                               _vp(_tile_counters(x) if split else None), flags, _stream(x)), "ls3d_tile_conv")
     if flags & 32:
         _TILE_TRACE.append(dict(rows=plan.n_rows, kvol=kvol, cin=cin, cout=cout, records=ws[off:].view(torch.int32).view(-1, 4, 16).clone()))
     return out
+
+
+class ChainLayer(object):
+    """one layer of tile_conv_chain: the arguments of tile_conv (x: [rows, >= cin] features, possibly a column view of a wider buffer - its row
+    stride is taken from the tensor; out: preallocated [rows, >= cout] or a column view)"""
+    __slots__ = ("x", "w", "cout", "scale", "shift", "res_pre", "relu", "pair", "out")
+
+    def __init__(self, x, w, out, cout=None, scale=None, shift=None, res_pre=None, relu=False, pair=None):
+        self.x, self.w, self.out, self.cout, self.scale, self.shift, self.res_pre, self.relu, self.pair = x, w, out, cout or w.cout, scale, shift, res_pre, relu, pair
+
+
+_TILE_CHAIN = _os.environ.get("LS3D_TILE_CHAIN", "1") != "0"  # A/B: consecutive SubM layers of a UNet level as ONE persistent launch (ls3d_tile_conv_chain)
+TILE_CHAIN_MAX = 8
+_CHAIN_STATES = None  # tests: a list that collects the state buffers of the chained launches (state[1] != 0: a wait ran into its watchdog)
+
+
+def collect_chain_states(on=True):
+    """-> the list that receives the int32 state buffer of every chained launch from now on (None: off)"""
+    global _CHAIN_STATES
+    _CHAIN_STATES = [] if on else None
+    return _CHAIN_STATES
+
+
+def set_tile_chain(on):
+    global _TILE_CHAIN
+    _TILE_CHAIN = bool(on)
+
+
+def tile_chain_enabled():
+    return _TILE_CHAIN and tile_products() == 6
+
+
+def _ld(t):
+    return t.stride(0) if t.dim() == 2 else t.shape[-1]
+
+
+def tile_conv_chain(layers, plan):
+    """the layers (ChainLayer, <= TILE_CHAIN_MAX, each reading what earlier ones wrote on the plan's rows) in ONE persistent launch of the tile
+    kernel (include/ls3d.h: ls3d_tile_conv_chain); -> True, or False when the library declines the combination (the caller launches the
+    layers one by one: same results)"""
+    L = _L()
+    n = len(layers)
+    arr = (_lib.TileChainLayer * n)()
+    keep = []
+    split = False
+    for a, l in zip(arr, layers):
+        kvol, cin, _ = l.w.shape
+        assert kvol == plan.kvol and l.x.stride(1) == 1 and l.out.stride(1) == 1
+        a.in_, a.in_ld, a.cin, a.cout = _vp_any(l.x).value, _ld(l.x), cin, l.cout
+        wp = l.w.for_tile(bf16=False)
+        keep.append(wp)
+        a.w_packed = _ptr(wp).value
+        a.epi = Epilogue(_vp(l.scale), _vp(l.shift), _vp_any(l.res_pre) if l.res_pre is not None else ctypes.c_void_p(0),
+                         _ld(l.res_pre) if l.res_pre is not None else 0, _vp_any(l.pair) if l.pair is not None else ctypes.c_void_p(0),
+                         _ld(l.pair) if l.pair is not None else 0, 1 if l.relu else 0, ctypes.c_void_p(0), ctypes.c_void_p(0), 0.0)
+        a.out, a.out_ld = _vp_any(l.out).value, _ld(l.out)
+        split = split or (_TILE_KSPLIT and cin >= 64)
+    x0 = layers[0].x
+    state = _ws(int(L.ls3d_tile_chain_state_bytes(plan.n_rows)), x0)
+    nbytes = max(int(L.ls3d_tile_conv_workspace_bytes(plan.n_rows, l.cout)) for l in layers) if split else 0
+    ws = _tile_ws(nbytes, x0) if nbytes else None
+    rc = L.ls3d_tile_conv_chain(_ptr(plan.buf), plan.n_rows, plan.kvol, arr, n, 6, _ptr(state), ctypes.c_size_t(state.numel()), _vp(ws),
+                                ctypes.c_size_t(ws.numel() if ws is not None else 0), _vp(_tile_counters(x0) if split else None), _TILE_FLAGS & ~63,
+                                _stream(x0))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return False
+    check(rc, "ls3d_tile_conv_chain")
+    if _CHAIN_STATES is not None:
+        _CHAIN_STATES.append(state.view(torch.int32))
+    return True
 
 
 _TILE_TRACE = None

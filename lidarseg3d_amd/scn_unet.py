@@ -128,6 +128,75 @@ def _lateral_stream(dev):
     return st
 
 
+class _Chain(object):
+    """Consecutive SubM layers on ONE rulebook (the SparseBasicBlocks of a UNet level, scn_unet.py:34-69, its lateral block and conv_m,
+    :163-171) collected first and launched together: ONE persistent launch of the tile kernel (ops.tile_conv_chain, include/ls3d.h:
+    ls3d_tile_conv_chain) in which the tiles of a layer start as soon as the tiles that own their halo rows have finished the previous layer -
+    a layer's tail (677 tiles on 512 workgroup slots) is filled with the next layer's tiles.  Where the library declines (other precisions,
+    layers too narrow for the tile kernel, LS3D_TILE_CHAIN=0) the layers run one by one through SparseConvolution.conv: same arithmetic,
+    bit-identical results."""
+
+    def __init__(self, x, key):
+        self.x, self.rb, self.recs = x, x.find_indice_pair(key), []
+        assert self.rb is not None and self.rb.kind == "subm", key
+
+    def add(self, conv, bn, feats, relu=True, res_pre=None, pair=None, out=None):
+        """queue conv + BN(eval) [+ res_pre] [+ ReLU] [+ channel-pair sum of `pair`] on feats -> the output tensor (written when run() is called)"""
+        assert conv.subm and conv.indice_key is not None and self.x.find_indice_pair(conv.indice_key) is self.rb
+        if out is None:
+            out = torch.empty((self.rb.tbl.shape[0], conv.out_channels), dtype=torch.float32, device=feats.device)
+        scale, shift = spconv.cached_bn_scale_shift(conv, bn)
+        self.recs.append((conv, feats, scale, shift, relu, res_pre, pair, out))
+        return out
+
+    def block(self, blk, feats, out=None):
+        """SparseBasicBlock (scn_unet.py:51-69): relu(bn2(conv2(relu(bn1(conv1(x))))) + x)"""
+        mid = self.add(blk.conv1, blk.bn1, feats)
+        return self.add(blk.conv2, blk.bn2, mid, res_pre=feats, out=out)
+
+    def _chain_layers(self):
+        """ops.ChainLayer per queued layer, or None when one of them does not take the tile kernel in its chained form"""
+        if not ops.tile_chain_enabled() or len(self.recs) < 2 or self.rb.tbl.shape[0] == 0:
+            return None
+        layers, k = [], self.rb.tbl.shape[1]
+        for conv, feats, scale, shift, relu, res_pre, pair, out in self.recs:
+            pk = conv.packed()
+            if k not in pk:
+                with torch.no_grad():
+                    pk[k] = spconv.pack_spconv(conv._weight_for(self.rb))
+            W, _, _, cout = pk[k]
+            if conv.bias is not None or not ops.use_tile("subm", k, W.shape[1], cout) or cout > 128 or cout % 4:
+                return None
+            if feats.shape[1] != W.shape[1]:  # e.g. 13 input channels feeding a 16-wide K chunk (a layer fed from outside the chain)
+                feats = torch.nn.functional.pad(feats, (0, W.shape[1] - feats.shape[1]))
+            if feats.stride(1) != 1 or feats.stride(0) % 4 or out.stride(1) != 1 or out.stride(0) % 4:
+                return None
+            layers.append(ops.ChainLayer(feats, W, out, cout=cout, scale=scale, shift=shift, res_pre=res_pre, relu=relu, pair=pair))
+        nt = set(1 if l.cout <= 32 else 2 if l.cout <= 64 else 4 for l in layers)
+        return layers if len(nt) == 1 else None
+
+    def run(self):
+        layers = self._chain_layers()
+        recs, self.recs = self.recs, []
+        if layers is not None:
+            plan = self.rb.tile_plan(False)
+            done = 0
+            while done < len(layers):
+                part = layers[done:done + ops.TILE_CHAIN_MAX]
+                if len(part) == 1:  # a single layer left over: the plain launch (most-expensive-first dispatch)
+                    l = part[0]
+                    ops.tile_conv(l.x, l.w, plan, cout=l.cout, scale=l.scale, shift=l.shift, res_pre=l.res_pre, relu=l.relu, pair=l.pair, out=l.out,
+                                  in_ld=l.x.stride(0))
+                elif not ops.tile_conv_chain(part, plan):
+                    break
+                done += len(part)
+            if done == len(layers):
+                return
+            recs = recs[done:]
+        for conv, feats, scale, shift, relu, res_pre, pair, out in recs:
+            conv.conv(feats, self.rb, scale=scale, shift=shift, relu=relu, res_pre=res_pre, pair=pair, out=out, out_ld=out.stride(0))
+
+
 class _GeometryStream(object):
     """`with _GeometryStream(t):` runs the body on a per-device side stream that starts after the current stream's work so far;
     on exit the current stream waits for it.  hand_over() tells the caching allocator that tensors created inside are used
@@ -279,6 +348,58 @@ class UNetSCN3D(nn.Module):
         cat.record_stream(lat)
         return done
 
+    @staticmethod
+    def _chained(features):
+        """the chained form of the inference forward (one persistent tile-kernel launch per level segment) applies: device tensors (or the
+        host emulation of the tests), 6-product arithmetic, not switched off"""
+        return ops.tile_chain_enabled() and (features.is_cuda or ops.sim_mode())
+
+    def _level_chain(self, x_s, key, blocks, lateral, first=None, conv_m=None):
+        """One UNet level's SubM layers on the level's rulebook `key` as ONE chained launch (_Chain): [first = (conv, bn) in front of the blocks:
+        conv_input] + the encoder's SparseBasicBlocks + the decoder's lateral block conv_up_t of the same level (it reads the encoder output
+        only, scn_unet.py:163-165) [+ conv_m where the level is the deepest: its concat buffer is complete then].  The last encoder layer
+        writes the LEFT half of the level's concat buffer when conv_m follows, the lateral block's second layer always the RIGHT half.
+        -> (encoder output tensor, concat buffer, conv_m's output tensor or None)"""
+        ch = _Chain(x_s, key)
+        f = x_s.features
+        if first is not None:
+            f = ch.add(first[0], first[1], f)
+        c = blocks[-1].conv2.out_channels
+        cat = torch.empty((f.shape[0], 2 * c), dtype=torch.float32, device=f.device)
+        for i, blk in enumerate(blocks):
+            f = ch.block(blk, f, out=cat[:, :c] if (conv_m is not None and i == len(blocks) - 1) else None)
+        x_enc = x_s._like(f)
+        mid = ch.add(lateral.conv1, lateral.bn1, f)
+        ch.add(lateral.conv2, lateral.bn2, mid, res_pre=f, out=cat[:, c:])
+        x_m = None
+        if conv_m is not None:
+            x_m = x_s._like(ch.add(conv_m[0], conv_m[1], cat, pair=cat))
+        ch.run()
+        return x_enc, cat, x_m
+
+    def _decoder_chained(self, x_conv1, x_conv2, x_conv3, x_m4, cats):
+        """the decoder behind the chained encoder levels: conv_m4 ran with level 4's chain (x_m4), the lateral blocks with their levels' chains
+        (the right halves of cats = [level 3, level 2, level 1] are written); what is left per level is the inverse convolution into the next
+        level's left half, conv_m of that level, and at the top conv_m1 + conv5 as one more chain"""
+        x_up4 = self._inverse_into(x_m4, self.inv_conv4, cats[0])
+        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1], lateral=True)
+        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2], lateral=True)
+        ch = _Chain(x_conv1, "subm1")
+        fm = ch.add(self.conv_up_m1[0], self.conv_up_m1[1], cats[2], pair=cats[2])
+        f5 = ch.add(self.conv5[0][0], self.conv5[0][1], fm)
+        ch.run()
+        return x_conv1._like(f5), x_up2, x_up3, x_up4
+
+    @staticmethod
+    def _inverse_into(x, conv_inv, next_cat):
+        """the inverse convolution of a decoder level, written straight into the left half of the next level's concat buffer"""
+        inv, bn = conv_inv[0], conv_inv[1]
+        rbi = inv.rulebook(x)
+        s, t = spconv.cached_bn_scale_shift(inv, bn)
+        cout = inv.out_channels
+        inv.conv(x, rbi, scale=s, shift=t, relu=True, out=next_cat[:, :cout], out_ld=next_cat.shape[1])
+        return x._like(next_cat[:, :cout], rbi.in_indices, rbi.in_shape, n_dev=rbi.rows_dev(True))
+
     def UR_block_forward(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv, cat=None, next_cat=None, lateral=None):
         """scn_unet.py:163-171 with the data movement fused away:
           * `cat` [V, 2C] is the concat buffer; its left half already holds x_bottom when the previous UR block's
@@ -299,12 +420,7 @@ class UNetSCN3D(nn.Module):
         x = conv_bn_act(conv_m[0], conv_m[1], x, relu=True, pair=cat)
         if next_cat is None:
             return conv_inv(x)
-        inv, bn = conv_inv[0], conv_inv[1]
-        rbi = inv.rulebook(x)
-        s, t = spconv.cached_bn_scale_shift(inv, bn)
-        cout = inv.out_channels
-        inv.conv(x, rbi, scale=s, shift=t, relu=True, out=next_cat[:, :cout], out_ld=next_cat.shape[1])
-        return x._like(next_cat[:, :cout], rbi.in_indices, rbi.in_shape, n_dev=rbi.rows_dev(True))
+        return self._inverse_into(x, conv_inv, next_cat)
 
     def UR_block_forward_train(self, x_lateral, x_bottom, conv_t, conv_m, conv_inv):
         """scn_unet.py:163-171 as written (training: every step is a differentiable op)"""
@@ -344,9 +460,14 @@ class UNetSCN3D(nn.Module):
             spconv.prebuild_orders(x, self.modules())
             gs.hand_over(x.indice_dict.values())
             gs.release()
+        infer = not (self.training or (torch.is_grad_enabled() and voxel_features.requires_grad))
+        chained = infer and self._chained(voxel_features)
         ev0 = self._stack_event()
-        x = self.conv_input(x)  # ... the five level-1 launches are queued behind it ...
-        x_conv1 = self.conv1(x)
+        if chained:  # conv_input + conv1's blocks + the level's lateral block: one launch
+            x_conv1, cat1, _ = self._level_chain(x, "subm1", [self.conv1[0], self.conv1[1]], self.conv_up_t1, first=(self.conv_input[0], self.conv_input[1]))
+        else:
+            x = self.conv_input(x)  # ... the five level-1 launches are queued behind it ...
+            x_conv1 = self.conv1(x)
         ev1 = self._stack_event(ev0)
         # ... stage 2 = the strided rulebooks of the encoder (the first one now, the other three chained on device counts behind the
         # level-2 convolutions: two host syncs for their sizes, both while the main stream is busy) ...
@@ -360,9 +481,9 @@ class UNetSCN3D(nn.Module):
         # gets level k's convolutions (a millisecond of GPU work) before the host turns to level k+1's geometry (round-2 trace with
         # all geometry submitted first: 0.6 ms of idle main stream per frame, all of it host submission time).
         ev0, x_enc = None, x_conv1
-        infer = not (self.training or (torch.is_grad_enabled() and voxel_features.requires_grad))
-        cats, lats = [None, None, self._new_cat(x_conv1) if infer else None], [None, None, None]  # levels 3, 2, 1 (the order the decoder takes them)
-        if infer:
+        cats, lats = [None, None, (cat1 if chained else self._new_cat(x_conv1)) if infer else None], [None, None, None]  # levels 3, 2, 1 (the order the decoder takes them)
+        x_m4 = None
+        if infer and not chained:
             lats[2] = self._lateral_launch(x_conv1, self.conv_up_t1, cats[2])
         for lvl, (key, src, stage) in enumerate((("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4))):
             with _GeometryStream(x.indices, ready, join=False) as gs:
@@ -374,7 +495,13 @@ class UNetSCN3D(nn.Module):
             self._wait(x, level_ready)
             if lvl == 0:
                 ev0 = self._stack_event() if ev1 is not None else None
-            x_enc = stage(x_enc)
+            if chained:  # the strided convolution, then the level's blocks + lateral block (+ conv_m on the deepest level) as one launch
+                x_enc, cat_l, x_m4 = self._level_chain(stage[0](x_enc), key, [stage[1], stage[2]], (self.conv_up_t2, self.conv_up_t3, self.conv_up_t4)[lvl],
+                                                       conv_m=self.conv_up_m4 if lvl == 2 else None)
+                if lvl < 2:
+                    cats[1 - lvl] = cat_l
+            else:
+                x_enc = stage(x_enc)
             if lvl == 0:
                 x_conv2 = x_enc
                 with _GeometryStream(x.indices, ready, join=False) as gs:
@@ -383,7 +510,7 @@ class UNetSCN3D(nn.Module):
                     spconv.prebuild_conv_rulebooks(x, rest, coords=rb2.out_indices, shape=rb2.out_shape)
             elif lvl == 1:
                 x_conv3 = x_enc
-            if infer and lvl < 2:  # the level's lateral block starts beside the deeper levels
+            if infer and not chained and lvl < 2:  # the level's lateral block starts beside the deeper levels
                 cats[1 - lvl] = self._new_cat(x_enc)
                 lats[1 - lvl] = self._lateral_launch(x_enc, self.conv_up_t2 if lvl == 0 else self.conv_up_t3, cats[1 - lvl])
         x_conv4 = x_enc
@@ -398,6 +525,11 @@ class UNetSCN3D(nn.Module):
             x_up2 = self.UR_block_forward_train(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2)
             x_up1 = self.UR_block_forward_train(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5)
             self._stack_event(ev0)
+            return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
+        if chained:
+            x_up1, x_up2, x_up3, x_up4 = self._decoder_chained(x_conv1, x_conv2, x_conv3, x_m4, cats)
+            self._stack_event(ev0)
+            self._wait(x, conv_out_done)
             return self._outputs(batch_dict, x_up1, x_up2, x_up3, x_up4, x_conv4)
         x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4, next_cat=cats[0])
         x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1], lateral=lats[0])
@@ -563,25 +695,37 @@ class UNetSCN3D(nn.Module):
                 level_ready.append(gs.finish_event())
         with _GeometryStream(x.indices, ready, join=False, index=0) as gs2:
             self._start_devox_search(batch_dict, x, gs2)
+        chained = self._chained(voxel_features)
         ev0 = self._stack_event()
         self._wait(x, level_ready[0])
-        x = self.conv_input(x)
-        x_conv1 = self.conv1(x)
+        cats, lats, x_m4 = [None, None, None], [None, None, None], None  # levels 3, 2, 1 (the order the decoder takes them)
+        if chained:  # conv_input + conv1's blocks + the level's lateral block: one launch
+            x_conv1, cats[2], _ = self._level_chain(x, "subm1", [self.conv1[0], self.conv1[1]], self.conv_up_t1, first=(self.conv_input[0], self.conv_input[1]))
+        else:
+            x = self.conv_input(x)
+            x_conv1 = self.conv1(x)
         ev1 = self._stack_event(ev0)
         ev0, x_enc = None, x_conv1
-        cats, lats = [None, None, self._new_cat(x_conv1)], [None, None, None]  # levels 3, 2, 1 (the order the decoder takes them)
-        lats[2] = self._lateral_launch(x_conv1, self.conv_up_t1, cats[2])
-        for lvl, stage in enumerate((self.conv2, self.conv3, self.conv4)):
+        if not chained:
+            cats[2] = self._new_cat(x_conv1)
+            lats[2] = self._lateral_launch(x_conv1, self.conv_up_t1, cats[2])
+        for lvl, (key, stage) in enumerate((("subm2", self.conv2), ("subm3", self.conv3), ("subm4", self.conv4))):
             self._wait(x, level_ready[lvl + 1])
             if lvl == 0:
                 self._wait(x, conv2_order)
                 ev0 = self._stack_event() if ev1 is not None else None
-            x_enc = stage(x_enc)
+            if chained:  # the strided convolution, then the level's blocks + lateral block (+ conv_m on the deepest level) as one launch
+                x_enc, cat_l, x_m4 = self._level_chain(stage[0](x_enc), key, [stage[1], stage[2]], (self.conv_up_t2, self.conv_up_t3, self.conv_up_t4)[lvl],
+                                                       conv_m=self.conv_up_m4 if lvl == 2 else None)
+                if lvl < 2:
+                    cats[1 - lvl] = cat_l
+            else:
+                x_enc = stage(x_enc)
             if lvl == 0:
                 x_conv2 = x_enc
             elif lvl == 1:
                 x_conv3 = x_enc
-            if lvl < 2:  # the level's lateral block starts beside the deeper levels
+            if not chained and lvl < 2:  # the level's lateral block starts beside the deeper levels
                 cats[1 - lvl] = self._new_cat(x_enc)
                 lats[1 - lvl] = self._lateral_launch(x_enc, self.conv_up_t2 if lvl == 0 else self.conv_up_t3, cats[1 - lvl])
         x_conv4 = x_enc
@@ -591,10 +735,13 @@ class UNetSCN3D(nn.Module):
             conv_out_done = None
         else:
             conv_out_done = self._conv_out(batch_dict, x_conv4)
-        x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4, next_cat=cats[0])
-        x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1], lateral=lats[0])
-        x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2], lateral=lats[1])
-        x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2], lateral=lats[2])
+        if chained:
+            x_up1, x_up2, x_up3, x_up4 = self._decoder_chained(x_conv1, x_conv2, x_conv3, x_m4, cats)
+        else:
+            x_up4 = self.UR_block_forward(x_conv4, x_conv4, self.conv_up_t4, self.conv_up_m4, self.inv_conv4, next_cat=cats[0])
+            x_up3 = self.UR_block_forward(x_conv3, x_up4, self.conv_up_t3, self.conv_up_m3, self.inv_conv3, cat=cats[0], next_cat=cats[1], lateral=lats[0])
+            x_up2 = self.UR_block_forward(x_conv2, x_up3, self.conv_up_t2, self.conv_up_m2, self.inv_conv2, cat=cats[1], next_cat=cats[2], lateral=lats[1])
+            x_up1 = self.UR_block_forward(x_conv1, x_up2, self.conv_up_t1, self.conv_up_m1, self.conv5, cat=cats[2], lateral=lats[2])
         self._stack_event(ev0)
         self._wait(x, conv_out_done)
         batch_dict["num_active_voxels_dev"] = x_up1.n_dev

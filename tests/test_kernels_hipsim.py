@@ -1043,6 +1043,107 @@ def test_tile_plan_structure_on_a_subm_rulebook():
     assert meta[:, 0].mean() < 3.0 * 128
 
 
+def _plan_deps(plan):
+    """(rowtile [T * 128], tdep [T, 32]) of an ops.TilePlan buffer (csrc/tileconv.hip:tc_plan)"""
+    al = lambda v: (v + 255) // 256 * 256
+    t, kvol = (plan.n_rows + 127) // 128, plan.kvol
+    o = al(t * 128 * 4) + al(t * 8 * 4) + al(t * kvol * 128 * 4) + al(t * kvol * 128 * 2) + al((t + 1) * 4)
+    raw = plan.buf.numpy()
+    rowtile = raw[o:o + t * 128 * 4].view(np.int32).copy(); o += al(t * 128 * 4)
+    return rowtile, raw[o:o + t * 32 * 4].view(np.int32).reshape(t, 32).copy()
+
+
+def _subm_frame(n_points, seed, spare=0):
+    cfg = synth.NUSC
+    pts = synth.lidar_frame(n_points, seed=seed, **cfg)
+    v, c, n, nv = ops.voxelize_hard(torch.from_numpy(pts), cfg["voxel_size"], cfg["pc_range"], 5, 20000)
+    V = int(nv)
+    coords = torch.zeros((V + spare, 4), dtype=torch.int32)
+    coords[:V, 1:] = c[:V]
+    shape = orc.spatial_shape(cfg["voxel_size"], cfg["pc_range"])
+    n_dev = torch.tensor([V], dtype=torch.int32) if spare else None
+    tbl = ops.rulebook_subm(coords, shape, (3, 3, 3), n_dev=n_dev)
+    return V, coords, shape, tbl, n_dev
+
+
+def test_tile_plan_producer_lists_on_a_subm_rulebook():
+    """the producer list of a tile (ls3d_tile_conv_chain waits on it) = the set of tiles that own its halo rows, itself included; rowtile is the
+    inverse of the tiles' row lists; with spare rows behind a device count the lists of the live tiles are the same"""
+    for spare in (0, 200):
+        V, coords, shape, tbl, n_dev = _subm_frame(4000, 11, spare)
+        plan = ops.tile_plan(tbl, coords, shape, 1, n_dev=n_dev)
+        trow, meta, halo, loc = _plan_views(plan)
+        rowtile, tdep = _plan_deps(plan)
+        live_tiles = (V + 127) // 128
+        for t in range(live_tiles):
+            rows = trow[t][trow[t] >= 0]
+            assert (rowtile[rows] == t).all()
+            want = set(rowtile[halo[t, :meta[t, 0]]].tolist())
+            assert t in want and 0 <= meta[t, 7] == len(want) <= 32
+            assert set(tdep[t, :meta[t, 7]].tolist()) == want
+        assert meta[:live_tiles, 7].mean() < 12  # spatial tiles: a handful of neighbours
+        if spare == 0:
+            ref = [set(tdep[t, :meta[t, 7]].tolist()) for t in range(live_tiles)]
+        else:
+            assert ref == [set(tdep[t, :meta[t, 7]].tolist()) for t in range(live_tiles)]
+
+
+@pytest.mark.parametrize("c,spare", [(32, 0), (64, 0), (128, 0), (64, 300)])
+def test_tile_conv_chain_equals_layer_by_layer_launches(c, spare):
+    """ls3d_tile_conv_chain - the layers of a UNet level in ONE persistent launch, tiles of layer l + 1 waiting on the producer tiles of their
+    halo at layer l - is bit-identical to launching the layers one by one: a first layer of another input width, two SparseBasicBlocks
+    (residual from two layers back, read coherently), a lateral block whose second convolution writes the right half of a concat buffer, and
+    the 2C -> C layer with the channel-pair sum of that buffer (scn_unet.py:34-69,163-171); with the split over the input channels where
+    ls3d_tile_conv takes it (c >= 64, fewer tiles than workgroup slots); on tensors with spare rows behind a device count."""
+    rng = np.random.default_rng(c + spare)
+    V, coords, shape, tbl, n_dev = _subm_frame(2500 if c < 128 else 700, 5, spare)
+    rows = V + spare
+    plan = ops.tile_plan(tbl, coords, shape, 1, n_dev=n_dev)
+    T = torch.from_numpy
+    c0 = 16 if c == 32 else c
+
+    def weight(cin, cout):
+        return PackedWeight(T((rng.normal(size=(27, cin, cout)) * (0.3 / np.sqrt(cin))).astype(np.float32)), 27, cin, cin, cout)
+
+    def ss(cout):
+        return T(rng.uniform(0.5, 1.5, cout).astype(np.float32)), T((rng.normal(size=cout) * 0.1).astype(np.float32))
+    ws = [weight(c0, c)] + [weight(c, c) for _ in range(6)] + [weight(2 * c, c)]
+    sc = [ss(c) for _ in range(8)]
+    x0 = T(rng.normal(size=(rows, c0)).astype(np.float32))
+
+    def run(chained):
+        bufs = [torch.full((rows, c), float("nan")) for _ in range(5)]
+        cat = torch.full((rows, 2 * c), float("nan"))
+        outm = torch.full((rows, c), float("nan"))
+        # conv_input | block 1 | block 2 (its output = the left half of the level's concat buffer) | lateral block -> right half | conv_m (pair)
+        spec = [(x0, 0, bufs[0], None, None), (bufs[0], 1, bufs[1], None, None), (bufs[1], 2, bufs[2], bufs[0], None),
+                (bufs[2], 3, bufs[3], None, None), (bufs[3], 4, cat[:, :c], bufs[2], None),
+                (cat[:, :c], 5, bufs[4], None, None), (bufs[4], 6, cat[:, c:], cat[:, :c], None), (cat, 7, outm, None, cat)]
+        layers = [ops.ChainLayer(x, ws[i], out, cout=c, scale=sc[i][0], shift=sc[i][1], res_pre=res, relu=True, pair=pair) for x, i, out, res, pair in spec]
+        if chained:
+            states = ops.collect_chain_states(True)
+            try:
+                assert ops.tile_conv_chain(layers, plan)
+            finally:
+                ops.collect_chain_states(False)
+            assert len(states) == 1 and int(states[0][1]) == 0  # no wait ran into the watchdog
+            total = int(states[0][2])
+            assert int(states[0][0]) >= total and total >= 8 * ((V + 127) // 128)  # every ticket was taken
+        else:
+            for l in layers:
+                ops.tile_conv(l.x, l.w, plan, cout=c, products=6, scale=l.scale, shift=l.shift, res_pre=l.res_pre, relu=True, pair=l.pair, out=l.out,
+                              in_ld=l.x.stride(0))
+        return bufs, cat, outm
+    ops.set_precision("bf16x6")
+    try:
+        want, got = run(False), run(True)
+    finally:
+        ops.set_precision("f32")
+    for a, b in zip(want[0] + [want[1], want[2]], got[0] + [got[1], got[2]]):
+        assert torch.equal(a[:V], b[:V]) and bool(torch.isfinite(a[:V]).all())
+    assert float(want[2][:V].abs().max()) > 0
+
+
 @pytest.mark.parametrize("cin,cout,products", [(32, 64, 8), (64, 128, 8), (16, 32, 6), (48, 96, 8)])
 def test_tile_conv_matches_float64_and_gather_gemm(cin, cout, products):
     """random table (halos far beyond the LDS window: several passes per tile), fused epilogue, output into a column slice"""
@@ -1302,6 +1403,64 @@ def test_unet_bf16x8_tile_path_vs_f32(monkeypatch):
         ops.set_tile(True, min_cc=512)
     assert len(calls) >= 25
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("min_cc,cin,capacity", [(256, 13, True), (512, 16, False)])
+def test_unet_chained_levels_equal_layer_by_layer_launches(min_cc, cin, capacity, monkeypatch):
+    """UNetSCN3D's inference forward with every level's SubM layers as one chained launch (scn_unet._Chain -> ls3d_tile_conv_chain) is
+    bit-identical to the layer-by-layer launches (LS3D_TILE_CHAIN=0: the round-4 schedule with the lateral blocks on their own stream), with
+    host-side counts (one case) and in capacity mode (the other); the shipped structure (7 + 6 + 6 + 7 + 2 chained layers; the narrow net of the emulation with the
+    tile kernel's width limit lowered to its 16 channels) and the same net whose 16-channel level falls back to the gather-GEMM inside the
+    same code path; every output of the backbone is compared.  (The 128-channel variant of the kernel: test_tile_conv_chain_equals_...)"""
+    ratio = 1
+    cfg = synth.NUSC
+    pts = synth.lidar_frame(150, seed=31, **cfg)
+    v, c, n, nv = ops.voxelize_hard(torch.from_numpy(pts), cfg["voxel_size"], cfg["pc_range"], 5, 20000)
+    V = int(nv)
+    coords = torch.cat([torch.zeros((V, 1), dtype=torch.int32), c[:V]], 1).contiguous()
+    net = scn_unet.UNetSCN3D(num_input_features=cin, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
+                             model_cfg=dict(SCALING_RATIO=ratio), ds_factor=8, us_factor=8).eval()
+    shapes = {k: tuple(t.shape) for k, t in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(a) for k, a in synth.random_state_dict(shapes, 3).items()})
+    feats = torch.from_numpy(np.random.default_rng(2).normal(size=(V, cin)).astype(np.float32))
+    shape = np.asarray(orc.grid_size(cfg["voxel_size"], cfg["pc_range"]))
+    orig_caps = net._capacities
+    monkeypatch.setattr(net, "_capacities", lambda n_, b, sh: [min(w, 6 * n_) for w in orig_caps(n_, b, sh)])
+    chains = []
+    orig = ops.tile_conv_chain
+    monkeypatch.setattr(ops, "tile_conv_chain", lambda layers, plan: (chains.append(len(layers)), orig(layers, plan))[1])
+
+    def run(chain, capacity):
+        ops.set_tile_chain(chain)
+        bd = dict(voxel_features=feats, voxel_coords=coords, batch_size=1, input_shape=shape)
+        if capacity:
+            bd["num_active_voxels_dev"] = torch.tensor([V], dtype=torch.int32)
+        with torch.no_grad():
+            bd = net(bd)
+        ms = bd["multi_scale_3d_features"]
+        outs = [bd["conv_point_features"][:V]]
+        for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+            t = ms[k]
+            m = int(t.n_dev) if t.n_dev is not None else t.features.shape[0]
+            outs += [t.features[:m].contiguous(), t.indices[:m]]
+        return outs
+    ops.set_precision("bf16x6")
+    ops.set_tile(True, min_cc=min_cc)
+    states = ops.collect_chain_states(True)
+    try:
+        want = run(False, capacity)
+        assert chains == []
+        got = run(True, capacity)
+        assert chains == ([7, 6, 6, 7, 2] if min_cc == 256 else [6, 6, 7])  # 16 x 16 channels: below the tile kernel's default width limit
+        for a, b in zip(want, got):
+            assert a.shape == b.shape and torch.equal(a, b)
+        assert bool(torch.isfinite(got[0]).all()) and float(got[0].abs().max()) > 0
+        assert all(int(st[1]) == 0 for st in states)
+    finally:
+        ops.collect_chain_states(False)
+        ops.set_tile_chain(True)
+        ops.set_tile(True, min_cc=512)
+        ops.set_precision("f32")
 
 
 def test_frozen_batchnorm_and_eval_mode_input_gradients_keep_the_graph():
