@@ -1762,6 +1762,67 @@ def test_unet_tile_path_equals_gather_path_120k():
     assert float((outs[True].argmax(1) == outs[False].argmax(1)).float().mean()) >= 0.9999
 
 
+@pytest.mark.parametrize("kind", ["sdseg3d", "mseg3d"])
+def test_chained_tile_launches_equal_layer_by_layer_launches_120k(kind):
+    """the shipped inference schedule - every UNet level's SubM layers as ONE persistent launch (ls3d_tile_conv_chain: ticket queue, tiles of
+    layer l + 1 waiting on their producer tiles of layer l, coherent sc1 accesses across the XCDs' L2s inside the launch) - against the
+    layer-by-layer launches of round 4 (LS3D_TILE_CHAIN=0) on a 120 000-point frame and on a two-frame batch: logits BIT-IDENTICAL, in eager
+    capacity mode, with host-side counts and as a hipGraph replayed several times; no wait ran into its watchdog; the chained path really runs
+    (5 chained launches per frame: 7 + 6 + 6 + 7 + 2 layers)."""
+    from lidarseg3d_amd import detectors, graph as lgraph
+    cfg = synth.NUSC
+    model, _ = _model(getattr(models_cfg, kind)())
+    frames = [synth.lidar_frame(120000, seed=100, **cfg), synth.lidar_frame(34000, seed=3, **cfg)]
+
+    def example(fs):
+        pts = cu(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(fs)]))
+        ex = dict(points=pts, batch_size=len(fs))
+        if kind == "mseg3d":
+            img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=9, ncam=6, c_img=48, h=40, w=60, batch=len(fs))
+            ex.update(points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
+        return ex
+    chains = []
+    orig = ops.tile_conv_chain
+    ops.tile_conv_chain = lambda layers, plan: (chains.append(len(layers)), orig(layers, plan))[1]
+    states = ops.collect_chain_states(True)
+    try:
+        ops.set_precision("bf16x6")
+        for fs in (frames[:1], frames):
+            ex = example(fs)
+            outs = {}
+            for chain in (False, True):
+                ops.set_tile_chain(chain)
+                for cap in (True, False):
+                    detectors.CAPACITY_MODE = cap
+                    del chains[:]
+                    with torch.no_grad():
+                        for _ in range(2):  # the second capacity frame runs on adapted capacities
+                            model(dict(ex), return_loss=False)
+                    assert chains[-5:] == ([7, 6, 6, 7, 2] if chain else []), chains
+                    outs[(chain, cap)] = model.point_head.forward_ret_dict["out_logits"].clone()
+            ref = outs[(False, True)]
+            assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 0
+            for key, got in outs.items():
+                assert torch.equal(got, ref), key
+            if len(fs) == 1:  # the frame as one hipGraph: 5 replays, each bit-identical to the eager forward
+                detectors.CAPACITY_MODE = True
+                ops.set_tile_chain(True)
+                fg = lgraph.FrameGraph(model, ex)
+                for _ in range(5):
+                    fg(ex, clone=False)
+                    assert torch.equal(fg.logits, ref)
+                assert fg.fallbacks == 0
+                del fg
+        torch.cuda.synchronize()
+        assert len(states) > 0 and all(int(st[1]) == 0 for st in states if st.device.type == "cuda")
+    finally:
+        ops.tile_conv_chain = orig
+        ops.collect_chain_states(False)
+        ops.set_tile_chain(True)
+        detectors.CAPACITY_MODE = True
+        ops.set_precision("f32")
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16x8"])
 def test_spconv_modules_equal_dense_convolution_on_device(prec):
     """lidarseg3d_amd.spconv on the MI355X against dense convolutions of the densified grids (tests/dense_cases.py): SubM, strided
