@@ -423,6 +423,10 @@ int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int gra
  * ls3d_spconv_pairs into its own workspace followed by ls3d_spconv_wgrad_on_pairs: the two give bit-identical gradients.
  * workspace of ls3d_spconv_wgrad_on_pairs: ls3d_spconv_wgrad_workspace_bytes (only its partial-sum part is used). */
 size_t ls3d_spconv_pairs_bytes(int kvol, int n_rows);
+/* identity lists (kvol = 1: the tall-skinny weight gradient of a Linear layer) for a row capacity: build != 0 writes the lists of n_rows_cap
+ * rows, every call sets the number of valid rows to n_rows <= n_rows_cap; pass n_rows_cap as n_rows of ls3d_spconv_wgrad_on_pairs / its
+ * workspace query.  pairs: ls3d_spconv_pairs_bytes(1, n_rows_cap) bytes. */
+int ls3d_spconv_identity_pairs(int n_rows_cap, int n_rows, int build, void *pairs, size_t pairs_bytes, ls3d_stream_t stream);
 int ls3d_spconv_pairs(const int32_t *tbl, const int32_t *row_order, int n_rows, const int32_t *n_rows_dev, int kvol, void *pairs,
                       size_t pairs_bytes, ls3d_stream_t stream);
 int ls3d_spconv_wgrad_on_pairs(const float *in, int in_ld, const float *grad_out, int grad_out_ld, const void *pairs, int kvol, int cin,

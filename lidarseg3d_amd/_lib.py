@@ -18,7 +18,7 @@ EXPORTS = [
     "ls3d_dynamic_scatter_workspace_bytes", "ls3d_dynamic_scatter", "ls3d_dynamic_scatter_backward_workspace_bytes",
     "ls3d_dynamic_scatter_backward", "ls3d_segment_reduce_workspace_bytes", "ls3d_segment_reduce", "ls3d_vfe_mean", "ls3d_vfe_improved_mean",
     "ls3d_vfe_tokens", "ls3d_transvfe", "ls3d_transvfe_workspace_bytes", "ls3d_mha_core", "ls3d_group_max", "ls3d_layernorm", "ls3d_index_build",
-    "ls3d_rulebook_subm", "ls3d_rulebook_conv_workspace_bytes", "ls3d_rulebook_conv", "ls3d_rulebook_masks", "ls3d_rulebook_sort_keys", "ls3d_rulebook_parity_keys", "ls3d_point_mlp", "ls3d_segment_local_index", "ls3d_segment_local_index32", "ls3d_gather_gemm", "ls3d_gather_gemm_pack", "ls3d_gather_gemm_packed_floats", "ls3d_gather_gemm_default_nt", "ls3d_spconv_wgrad_workspace_bytes", "ls3d_spconv_wgrad", "ls3d_spconv_pairs_bytes", "ls3d_spconv_pairs", "ls3d_spconv_wgrad_on_pairs", 
+    "ls3d_rulebook_subm", "ls3d_rulebook_conv_workspace_bytes", "ls3d_rulebook_conv", "ls3d_rulebook_masks", "ls3d_rulebook_sort_keys", "ls3d_rulebook_parity_keys", "ls3d_point_mlp", "ls3d_segment_local_index", "ls3d_segment_local_index32", "ls3d_gather_gemm", "ls3d_gather_gemm_pack", "ls3d_gather_gemm_packed_floats", "ls3d_gather_gemm_default_nt", "ls3d_spconv_wgrad_workspace_bytes", "ls3d_spconv_wgrad", "ls3d_spconv_pairs_bytes", "ls3d_spconv_pairs", "ls3d_spconv_identity_pairs", "ls3d_spconv_wgrad_on_pairs", 
     "ls3d_tile_keys", "ls3d_tile_plan_bytes", "ls3d_tile_build", "ls3d_tile_plan", "ls3d_tile_plan_workspace_bytes", "ls3d_radix_sort",
     "ls3d_radix_sort_workspace_bytes", "ls3d_tile_conv_packed_bytes", "ls3d_tile_conv_pack", "ls3d_tile_conv_packed_bytes_bf16", "ls3d_tile_conv_pack_bf16", "ls3d_tile_conv", "ls3d_tile_conv_workspace_bytes", "ls3d_tile_conv_counter_bytes", "ls3d_tile_conv_trace_bytes", "ls3d_tile_chain_state_bytes", "ls3d_tile_conv_chain", "ls3d_transvfe_planes_bytes", "ls3d_transvfe_pack_planes",
     "ls3d_voxel_centers", "ls3d_frame_offsets", "ls3d_three_nn", "ls3d_three_interpolate", "ls3d_three_interpolate_grad",

@@ -60,6 +60,7 @@ struct ls3d_cohbuf { const char *base; };
 __device__ __forceinline__ ls3d_cohbuf ls3d_cohbuf_make(const void *base) { return ls3d_cohbuf{(const char *)base}; }
 __device__ __forceinline__ float4 ls3d_load4_agent(const ls3d_cohbuf &b, unsigned byte_off) { return *(const float4 *)(b.base + byte_off); }
 __device__ __forceinline__ void ls3d_store4_agent(const ls3d_cohbuf &b, unsigned byte_off, const float4 &v) { *(float4 *)(b.base + byte_off) = v; }
+__device__ __forceinline__ float4 ls3d_load4_buf(const ls3d_cohbuf &b, unsigned byte_off) { return *(const float4 *)(b.base + byte_off); }
 __device__ __forceinline__ void ls3d_sleep() {}
 #define LS3D_WAIT_VMCNT(n) ((void)0)
 #define LS3D_WAIT_LGKMCNT0() ((void)0)
@@ -106,6 +107,11 @@ __device__ __forceinline__ float4 ls3d_load4_agent(const ls3d_cohbuf &b, unsigne
 __device__ __forceinline__ void ls3d_store4_agent(const ls3d_cohbuf &b, unsigned byte_off, const float4 &v) {
   const ls3d_i32x4 w = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(w, b.r, (int)byte_off, 0, 16 /* sc1 */);
+}
+// the same addressing (scalar base + 32-bit lane offset: half the address registers of a 64-bit global load) with the ordinary cache policy
+__device__ __forceinline__ float4 ls3d_load4_buf(const ls3d_cohbuf &b, unsigned byte_off) {
+  const ls3d_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)byte_off, 0, 0);
+  return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
 }
 __device__ __forceinline__ void ls3d_sleep() { __builtin_amdgcn_s_sleep(16); }
 #define LS3D_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")

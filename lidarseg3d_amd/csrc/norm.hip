@@ -275,21 +275,41 @@ __global__ __launch_bounds__(256) void k_bn_stats_part(const float *__restrict__
   }
 }
 
-// (mean_b, M2_b, n_b) of the row blocks -> mean[c], M2[c] of all n rows: Chan's pairwise update, blocks in order, one thread per column
-__global__ __launch_bounds__(256) void k_bn_stats_merge(const float *__restrict__ part, int nblocks, int n, int c, float *__restrict__ out) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= c) return;
-  double mean = 0.0, m2 = 0.0, cnt = 0.0;  // (c threads x nblocks steps: double costs nothing here and keeps the merge out of the error budget)
-  for (int b = 0; b < nblocks; ++b) {
-    const double nb = (double)min(BN_ROWS, n - b * BN_ROWS);
-    const double mb = part[((size_t)b * 2 + 0) * c + col], qb = part[((size_t)b * 2 + 1) * c + col];
-    const double tot = cnt + nb, d = mb - mean;
+// (mean_b, M2_b, n_b) of the row blocks -> mean[c], M2[c] of all n rows: Chan's pairwise update in a FIXED-SHAPE tree - 32 chains per column
+// (chain l merges blocks l, l + 32, ... in order), then five pairwise levels through LDS.  Deterministic (the shape depends on nblocks only),
+// merged in double.  Round 4's version walked all row blocks of a column with ONE thread: up to 703 dependent double divisions = 120 us per
+// call, 5x its own k_bn_stats_part, 5 ms of a Waymo training step.  8 columns per workgroup.
+__device__ __forceinline__ void bn_chan_merge(double &mean, double &m2, double &cnt, double mb, double qb, double nb) {
+  const double tot = cnt + nb;
+  if (tot > 0.0) {
+    const double d = mb - mean;
     mean += d * (nb / tot);
     m2 += qb + d * d * (cnt * nb / tot);
     cnt = tot;
   }
-  out[col] = (float)mean;
-  out[c + col] = (float)m2;
+}
+
+__global__ __launch_bounds__(256) void k_bn_stats_merge(const float *__restrict__ part, int nblocks, int n, int c, float *__restrict__ out) {
+  __shared__ double s_mean[256], s_m2[256], s_cnt[256];
+  const int tid = threadIdx.x, lane = tid & 31, col = blockIdx.x * 8 + (tid >> 5);
+  double mean = 0.0, m2 = 0.0, cnt = 0.0;
+  if (col < c)
+    for (int b = lane; b < nblocks; b += 32)
+      bn_chan_merge(mean, m2, cnt, (double)part[((size_t)b * 2 + 0) * c + col], (double)part[((size_t)b * 2 + 1) * c + col],
+                    (double)min(BN_ROWS, n - b * BN_ROWS));
+  s_mean[tid] = mean; s_m2[tid] = m2; s_cnt[tid] = cnt;
+  __syncthreads();
+  for (int d = 16; d >= 1; d >>= 1) {
+    if (lane < d) {
+      bn_chan_merge(mean, m2, cnt, s_mean[tid + d], s_m2[tid + d], s_cnt[tid + d]);
+      s_mean[tid] = mean; s_m2[tid] = m2; s_cnt[tid] = cnt;
+    }
+    __syncthreads();
+  }
+  if (lane == 0 && col < c) {
+    out[col] = (float)mean;
+    out[c + col] = (float)m2;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int ld, int n, int c, const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -393,7 +413,7 @@ extern "C" int ls3d_batch_norm_stats(const float *x, int ld, int n, int c, void 
   if (workspace_bytes < ls3d_batch_norm_workspace_bytes(n, c)) return LS3D_ERR_WORKSPACE;
   const int nb = bn_blocks(n);
   hipLaunchKernelGGL(k_bn_stats_part, dim3(nb), dim3(256), 0, stream, x, ld, n, c, (float *)workspace);
-  hipLaunchKernelGGL(k_bn_stats_merge, dim3((c + 255) / 256), dim3(256), 0, stream, (const float *)workspace, nb, n, c, mean_m2);
+  hipLaunchKernelGGL(k_bn_stats_merge, dim3((c + 7) / 8), dim3(256), 0, stream, (const float *)workspace, nb, n, c, mean_m2);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

@@ -501,6 +501,30 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
 }
 
 // the same on pair lists built once (ls3d_spconv_pairs) for every layer that shares the table: the SubM layers of a UNet level
+// Identity pair lists (a Linear layer's weight gradient = one kernel offset, row i of x paired with row i of grad_out) for a row CAPACITY:
+// built once per capacity, the number of valid rows set per use - the lists of every row count up to the capacity are prefixes of it.
+__global__ __launch_bounds__(256) void k_pairs_identity(int n, int32_t *pin, int32_t *pout) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) pin[i] = pout[i] = i;
+}
+__global__ void k_pairs_set_count(int32_t *pair_cnt, int kvol, int count) {
+  if ((int)threadIdx.x < kvol) pair_cnt[threadIdx.x] = count;
+}
+extern "C" int ls3d_spconv_identity_pairs(int n_rows_cap, int n_rows, int build, void *pairs, size_t pairs_bytes, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!pairs || n_rows_cap < 1 || n_rows < 0 || n_rows > n_rows_cap || ((uintptr_t)pairs & 15)) return LS3D_ERR_ARG;
+  if (pairs_bytes < ls3d_spconv_pairs_bytes(1, n_rows_cap)) return LS3D_ERR_WORKSPACE;
+  const int nb = (n_rows_cap + PL_BLK - 1) / PL_BLK;
+  char *wsp = (char *)pairs;
+  int32_t *pin = (int32_t *)wsp; wsp += wg_align((size_t)n_rows_cap * 4);
+  int32_t *pout = (int32_t *)wsp; wsp += wg_align((size_t)n_rows_cap * 4);
+  wsp += wg_align((size_t)nb * 4);
+  int32_t *pair_cnt = (int32_t *)wsp;
+  if (build) hipLaunchKernelGGL(k_pairs_identity, ls3d_grid(n_rows_cap), dim3(256), 0, stream, n_rows_cap, pin, pout);
+  hipLaunchKernelGGL(k_pairs_set_count, dim3(1), dim3(64), 0, stream, pair_cnt, 1, n_rows);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
 extern "C" int ls3d_spconv_wgrad_on_pairs(const float *in, int in_ld, const float *grad_out, int go_ld, const void *pairs, int kvol, int cin, int cout,
                                           int n_rows, int products, void *workspace, size_t workspace_bytes, float *grad_w, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -504,8 +504,9 @@ constexpr int TC_THREADS = 256;
 // residual / pair operands are fetched in batches of branch-free loads: one memory latency per batch.  gg_epilogue (two passes of 64
 // rows, a conditional load chain per row group) took 18 of a 128 -> 128 tile's 204 us (tools/trace_tile.py).  Same arithmetic per
 // element, in the same order: results are bit-identical to gg_epilogue's.
-// CH (chained launch): the residual / pair operands may be rows another XCD wrote earlier in THIS launch and the output rows are read by
-// other XCDs later in it - coherent (sc1) 16-byte accesses instead of cached ones (common.h: ls3d_load4_agent / ls3d_store4_agent).
+// CH (chained launch): the output rows are read by other XCDs later in the SAME launch - they are written through to memory with coherent
+// (sc1) 16-byte stores (common.h: ls3d_store4_agent).  The residual / pair operands - rows another XCD wrote earlier in this launch - are
+// read with ordinary cached loads: see the note on coherence at k_tile_conv.
 template <int NT, bool CH = false>
 __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, const int *s_rows, int wave, int kk, int col, int cout, const EpiDev &e,
                                             float *__restrict__ out, int out_ld) {
@@ -532,22 +533,7 @@ __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, con
     float4 q[BATCH], p0[BATCH], p1[BATCH];
 #pragma unroll
     for (int j = 0; j < BATCH; ++j) orow[j] = s_rows[lr0 + (b0 + j) * RPI];
-    if constexpr (CH) {
-      if (e.res_pre) {
-        const ls3d_cohbuf rb = ls3d_cohbuf_make(e.res_pre);
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) q[j] = ls3d_load4_agent(rb, ((unsigned)(orow[j] >= 0 ? orow[j] : 0) * (unsigned)e.res_pre_ld + (unsigned)occ) * 4u);
-      }
-      if (e.pair) {
-        const ls3d_cohbuf pb = ls3d_cohbuf_make(e.pair);
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-          const unsigned po = ((unsigned)(orow[j] >= 0 ? orow[j] : 0) * (unsigned)e.pair_ld + 2u * (unsigned)occ) * 4u;
-          p0[j] = ls3d_load4_agent(pb, po);
-          p1[j] = ls3d_load4_agent(pb, po + 16u);
-        }
-      }
-    } else {
+    {
     if (e.res_pre) {
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) q[j] = *(const float4 *)(e.res_pre + (size_t)(orow[j] >= 0 ? orow[j] : 0) * e.res_pre_ld + occ);
@@ -653,9 +639,17 @@ __global__ __launch_bounds__(256) void k_tile_chain_setup(TilePlan p, TcChainSet
 // MFMAs (see the loop); LP = 0: fragments read at the start of the step that uses them (NT = 1, NP = 1 / 8, flags bit 0).
 constexpr int TC_TRACE_WORDS = 16;
 // CH = chained launch (ls3d_tile_conv_chain): persistent workgroups take (layer, tile [, half]) units from a ticket counter, the layer's operands
-// come from the device-side layer table, a unit of layer l > 0 waits for the producer tiles of its halo at layer l - 1, and everything that
-// one layer writes and another reads inside the launch moves with coherent (sc1) accesses.  Tiles are taken in the plan's spatial order
-// (neighbours finish close together).  The arithmetic of a unit is the same code: results are bit-identical to layer-by-layer launches.
+// come from the device-side layer table, a unit of layer l > 0 waits for the producer tiles of its halo at layer l - 1.  Tiles are taken in the
+// plan's spatial order (neighbours finish close together).  The arithmetic of a unit is the same code: results are bit-identical to
+// layer-by-layer launches.
+// Coherence inside the launch (the eight XCDs' L2s do not snoop each other): a tile's output rows are WRITTEN THROUGH (sc1 stores), every
+// wave waits for its stores' acknowledgements, then the tile's completion counter is set with an sc1 store; a consumer polls that counter
+// with sc1 loads and then reads the rows with ORDINARY loads.  That is safe because no L2 can hold a stale copy of such a line: nobody reads
+// an output row of the launch before its producer has finished it (the wait above), a 128-byte line belongs to ONE row (the host takes only
+// layers of >= 32 output channels with 128-byte-aligned rows into a chain), hence to one writer, and lines cached before the launch were
+// dropped at its start like at any kernel boundary.  The first reader on an XCD misses and fetches the written-through data; later readers on
+// that XCD hit.  (First build of the round: sc1 LOADS for the halo - 10 % slower than layer-by-layer launches: the halo loads of the next chunk
+// are issued one step ahead of a `s_waitcnt vmcnt(0)`, which an L2 hit meets and a trip to memory does not.)
 template <int NT, int NP, bool TR = false, int LP = 0, bool CH = false>
 __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__restrict__ in_a, int in_ld_a, TilePlan p, const uint4 *__restrict__ wpk_a,
                                                              int cin_a, int cout_a, EpiDev e_a, float *__restrict__ out_a, int out_ld_a, int ablate, int swz,
@@ -694,6 +688,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   // capacity: a plan built on spare rows (capacity mode) and the plan of the exact table run the same units on the same tiles.
   // The launch covers the worst case; workgroups beyond the units of the live tiles leave at once.
   const int tlive = p.torder[p.ntiles];
+  [[maybe_unused]] int ch_next = -1;  // thread 0: the next ticket, drawn early
   for (;;) {  // CH: one work unit per ticket until the tickets run out; otherwise one pass (the unit of this workgroup)
     const float *__restrict__ in = in_a;
     const uint4 *__restrict__ wpk = wpk_a;
@@ -704,7 +699,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     [[maybe_unused]] int ch_layer = 0;
     if constexpr (CH) {
       __syncthreads();  // the previous unit of this workgroup is done with LDS
-      if (tid == 0) *(int *)s_stat = atomicAdd(ch.state, 1);
+      // (the ticket of this unit was drawn while the previous unit ran its epilogue - thread 0 holds it: the atomic's round trip to memory is
+      // hidden; a unit still only waits for smaller tickets, and the holder of a drawn-but-not-started ticket runs a smaller one)
+      if (tid == 0) *(int *)s_stat = ch_next >= 0 ? ch_next : atomicAdd(ch.state, 1);
+      ch_next = -1;
       __syncthreads();
       const int u = __builtin_amdgcn_readfirstlane(*(const int *)s_stat);
       if (u >= ch.state[2]) return;
@@ -713,14 +711,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
       blk = u - ch.state[TC_CH_USTART + ch_layer];
       // the layer's operands, made wave-uniform explicitly (scalar registers: the weight DMA takes a scalar base, the coherent accesses a
       // scalar buffer descriptor)
+      // (what the MFMA loop needs now; the epilogue's operands are read from the table when the epilogue starts - fewer live registers)
       const TcLayer *L = ch.layers + ch_layer;
-      in = tc_uniform(L->in); wpk = tc_uniform(L->wpk); out = tc_uniform(L->out);
-      e.scale = tc_uniform(L->e.scale); e.shift = tc_uniform(L->e.shift); e.res_pre = tc_uniform(L->e.res_pre); e.pair = tc_uniform(L->e.pair);
-      e.ln_gamma = e.ln_beta = nullptr; e.ln_eps = 0.0f;
-      e.res_pre_ld = __builtin_amdgcn_readfirstlane(L->e.res_pre_ld); e.pair_ld = __builtin_amdgcn_readfirstlane(L->e.pair_ld);
-      e.relu = __builtin_amdgcn_readfirstlane(L->e.relu);
+      in = tc_uniform(L->in); wpk = tc_uniform(L->wpk);
       in_ld = __builtin_amdgcn_readfirstlane(L->in_ld); cin = __builtin_amdgcn_readfirstlane(L->cin);
-      cout = __builtin_amdgcn_readfirstlane(L->cout); out_ld = __builtin_amdgcn_readfirstlane(L->out_ld);
       n_split = __builtin_amdgcn_readfirstlane(L->n_split);
     } else {
       // split_tail < 0: the tiles beyond the last full round of TC_SPLIT_MAX workgroup slots (the tail that would run one per CU)
@@ -748,6 +742,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     if (meta[6] == 0) {
       if constexpr (CH) continue; else return;
     }
+    [[maybe_unused]] ls3d_cohbuf in_buf;
+    if constexpr (CH) in_buf = ls3d_cohbuf_make(in);
     if constexpr (CH) {
       if (ch_layer > 0) {
         // the tiles that own this tile's halo rows must have finished the previous layer (its output rows are this layer's halo, residual
@@ -772,8 +768,6 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         __syncthreads();
       }
     }
-    [[maybe_unused]] ls3d_cohbuf in_coh;
-    if constexpr (CH) in_coh = ls3d_cohbuf_make(in);
     unsigned long long tr_w0 = 0, tr_t0 = 0, tr_mark = 0;
     unsigned tr_pro = 0, tr_stage = 0, tr_bar = 0, tr_steps = 0;
     if constexpr (TR) { tr_w0 = ls3d_walltime(); tr_t0 = ls3d_cycles(); }
@@ -820,8 +814,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   _Pragma("unroll") for (int j = 0; j < HPT; ++j) {                                       \
     const int i = tid + j * TC_THREADS, hrow = i >> 2, q = i & 3;                         \
     const int hr = hrow < nh ? hrow : nh - 1;                                             \
-    if constexpr (CH)                                                                     \
-      hv[j] = ls3d_load4_agent(in_coh, ((unsigned)s_hid[hr] * (unsigned)in_ld + (unsigned)((c_) * 16 + q * 4)) * 4u); \
+    if constexpr (CH)  /* scalar base + 32-bit offsets: fewer address registers (the chained build is at the register limit) */ \
+      hv[j] = ls3d_load4_buf(in_buf, ((unsigned)s_hid[hr] * (unsigned)in_ld + (unsigned)((c_) * 16 + q * 4)) * 4u); \
     else                                                                                  \
       hv[j] = *(const float4 *)(in + (size_t)s_hid[hr] * in_ld + (c_) * 16 + q * 4);      \
   }
@@ -1121,6 +1115,16 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         for (int r = 0; r < 16; ++r) acc[n][r] += ls3d_load_agent(other + (n * 16 + r) * TC_THREADS);  // a + b == b + a: order-independent
     }
     if constexpr (CH) {  // (the host takes only float4-aligned layers without LayerNorm into a chain)
+      if (tid == 0) ch_next = atomicAdd(ch.state, 1);
+      {
+        const TcLayer *L = ch.layers + ch_layer;
+        out = tc_uniform(L->out);
+        e.scale = tc_uniform(L->e.scale); e.shift = tc_uniform(L->e.shift); e.res_pre = tc_uniform(L->e.res_pre); e.pair = tc_uniform(L->e.pair);
+        e.ln_gamma = e.ln_beta = nullptr; e.ln_eps = 0.0f;
+        e.res_pre_ld = __builtin_amdgcn_readfirstlane(L->e.res_pre_ld); e.pair_ld = __builtin_amdgcn_readfirstlane(L->e.pair_ld);
+        e.relu = __builtin_amdgcn_readfirstlane(L->e.relu);
+        cout = __builtin_amdgcn_readfirstlane(L->cout); out_ld = __builtin_amdgcn_readfirstlane(L->out_ld);
+      }
       tc_epilogue<NT, true>(acc, (float *)smem, s_rows, wave, kk, col, cout, e, out, out_ld);
       // the tile's output rows are written through; when every wave's stores have been acknowledged the tile counts as finished
       LS3D_WAIT_VMCNT(0);
@@ -1331,6 +1335,8 @@ extern "C" int ls3d_tile_conv_chain(const void *plan, int n_rows, int kvol, cons
     if ((a.cin % 16) || (a.in_ld % 4) || a.in_ld < a.cin || a.out_ld < a.cout) return LS3D_ERR_ARG;
     if (((uintptr_t)a.in & 15) || ((uintptr_t)a.w_packed & 15) || ((uintptr_t)a.out & 15)) return LS3D_ERR_ARG;
     if (a.cout > 128) return LS3D_ERR_UNSUPPORTED;
+    // one 128-byte line = one row = one writer (the coherence argument at k_tile_conv): rows of at least 32 floats, 128-byte aligned
+    if (a.cout < 32 || (a.out_ld % 32) || ((uintptr_t)a.out & 127)) return LS3D_ERR_UNSUPPORTED;
     const int nt_l = a.cout <= 32 ? 1 : a.cout <= 64 ? 2 : 4;
     if (nt && nt_l != nt) return LS3D_ERR_UNSUPPORTED;  // one kernel variant (column blocks) per chain
     nt = nt_l;

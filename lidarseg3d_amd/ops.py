@@ -715,9 +715,36 @@ def collect_chain_states(on=True):
     return _CHAIN_STATES
 
 
-def set_tile_chain(on):
-    global _TILE_CHAIN
+# Where chaining pays (measured on the 120k-point frame, profiles/round5_experiments.md): a level whose tiles exceed the chip's 512 workgroup
+# slots (the tail of every launch is what the chain fills: levels 2 and 3; on level 4 - 216 tiles - the layers of a chain run as a wavefront
+# of dependent tiles, no faster than launches) and units long enough to carry a ticket, a poll of the producers' counters and a written-through
+# epilogue (64+ output channels; the 32-channel units of level 1 last 10 - 17 us).
+_CHAIN_MIN_TILES = int(_os.environ.get("LS3D_CHAIN_MIN_TILES", "600"))
+_CHAIN_MIN_COUT = int(_os.environ.get("LS3D_CHAIN_MIN_COUT", "64"))
+
+
+def set_tile_chain(on, min_tiles=None, min_cout=None):
+    """A/B switch of the chained launches (tests lower the two thresholds to chain small frames / narrow layers)"""
+    global _TILE_CHAIN, _CHAIN_MIN_TILES, _CHAIN_MIN_COUT
     _TILE_CHAIN = bool(on)
+    if min_tiles is not None:
+        _CHAIN_MIN_TILES = int(min_tiles)
+    if min_cout is not None:
+        _CHAIN_MIN_COUT = int(min_cout)
+
+
+def empty_rows(rows, cols, device):
+    """[rows, cols] f32 whose rows are whole 128-byte lines when cols % 32 == 0 (what a chained layer's output needs): the device allocator's
+    blocks are 512-byte aligned; the CPU allocator of the host emulation (tests) gives 64 bytes, so there the view starts at an aligned offset"""
+    if device.type == "cuda" or rows * cols == 0:
+        return torch.empty((rows, cols), dtype=torch.float32, device=device)
+    flat = torch.empty((rows * cols + 32,), dtype=torch.float32, device=device)
+    off = (-flat.data_ptr() // 4) % 32
+    return flat[off:off + rows * cols].view(rows, cols)
+
+
+def tile_chain_pays(n_rows, cout):
+    return (n_rows + 127) // 128 >= _CHAIN_MIN_TILES and cout >= _CHAIN_MIN_COUT
 
 
 def tile_chain_enabled():
@@ -833,19 +860,29 @@ def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None, pairs=None):
     return gw
 
 
-_ARANGE = {}
+_IDENTITY_PAIRS = {}
+_IDENTITY_STEP = 1 << 16
 
 
 def _identity(device, n):
-    """(identity table [n, 1], its pair lists), built once per row count"""
-    key = (device, n)
-    ident = _ARANGE.get(key)
-    if ident is None:
-        if len(_ARANGE) > 8:
-            _ARANGE.clear()
-        tbl = torch.arange(n, dtype=_i32, device=device).unsqueeze(1).contiguous()
-        ident = _ARANGE[key] = (tbl, spconv_pairs(tbl))
-    return ident
+    """(row capacity, pair lists) of the identity table for n rows: ONE buffer per capacity (n rounded up to 65 536 rows), built once - a new row
+    count only sets the number of valid rows (one tiny launch, and only when it differs from the last one used: every training step has its own
+    point / voxel counts, every Linear layer of a step the same ones).  Round 4 rebuilt an arange + three pair kernels per new row count."""
+    cap = max(_IDENTITY_STEP, -(-n // _IDENTITY_STEP) * _IDENTITY_STEP)
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (device, cap, stream)  # per stream: the valid-row count is set in stream order
+    ent = _IDENTITY_PAIRS.get(key)
+    L = _L()
+    if ent is None:
+        if len(_IDENTITY_PAIRS) > 16:
+            _IDENTITY_PAIRS.clear()
+        buf = torch.empty((int(L.ls3d_spconv_pairs_bytes(1, cap)),), dtype=torch.uint8, device=device)
+        ent = _IDENTITY_PAIRS[key] = [buf, -1]
+    if ent[1] != n:
+        check(L.ls3d_spconv_identity_pairs(cap, n, 1 if ent[1] < 0 else 0, _ptr(ent[0]), ctypes.c_size_t(ent[0].numel()), ctypes.c_void_p(stream)),
+              "ls3d_spconv_identity_pairs")
+        ent[1] = n
+    return cap, ent[0]
 
 
 def linear_wgrad(x, gy, products=None):
@@ -859,14 +896,14 @@ def linear_wgrad(x, gy, products=None):
     cout = gy.shape[1]
     if products is None:
         products = 6 if cin >= 128 else 0
-    pairs = _identity(x.device, n)[1]
+    cap, pairs = _identity(x.device, n)
     L = _L()
     gw = torch.empty((cout, cin), dtype=torch.float32, device=x.device)
     for c0 in range(0, cout, 128):
         c1 = min(c0 + 128, cout)
         part = torch.empty((1, cin, c1 - c0), dtype=torch.float32, device=x.device)
-        ws = _ws(L.ls3d_spconv_wgrad_workspace_bytes(1, cin, c1 - c0, n), x)
-        check(L.ls3d_spconv_wgrad_on_pairs(_ptr(x), x.shape[1], ctypes.c_void_p(gy.data_ptr() + 4 * c0), gy.shape[1], _ptr(pairs), 1, cin, c1 - c0, n,
+        ws = _ws(L.ls3d_spconv_wgrad_workspace_bytes(1, cin, c1 - c0, cap), x)
+        check(L.ls3d_spconv_wgrad_on_pairs(_ptr(x), x.shape[1], ctypes.c_void_p(gy.data_ptr() + 4 * c0), gy.shape[1], _ptr(pairs), 1, cin, c1 - c0, cap,
                                            int(products), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(part), _stream(x)),
               "ls3d_spconv_wgrad_on_pairs")
         gw[c0:c1] = part[0].t()

@@ -144,7 +144,7 @@ class _Chain(object):
         """queue conv + BN(eval) [+ res_pre] [+ ReLU] [+ channel-pair sum of `pair`] on feats -> the output tensor (written when run() is called)"""
         assert conv.subm and conv.indice_key is not None and self.x.find_indice_pair(conv.indice_key) is self.rb
         if out is None:
-            out = torch.empty((self.rb.tbl.shape[0], conv.out_channels), dtype=torch.float32, device=feats.device)
+            out = ops.empty_rows(self.rb.tbl.shape[0], conv.out_channels, feats.device)
         scale, shift = spconv.cached_bn_scale_shift(conv, bn)
         self.recs.append((conv, feats, scale, shift, relu, res_pre, pair, out))
         return out
@@ -165,11 +165,13 @@ class _Chain(object):
                 with torch.no_grad():
                     pk[k] = spconv.pack_spconv(conv._weight_for(self.rb))
             W, _, _, cout = pk[k]
-            if conv.bias is not None or not ops.use_tile("subm", k, W.shape[1], cout) or cout > 128 or cout % 4:
+            if conv.bias is not None or not ops.use_tile("subm", k, W.shape[1], cout) or cout > 128 or cout % 32:
+                return None
+            if not ops.tile_chain_pays(self.rb.tbl.shape[0], cout):
                 return None
             if feats.shape[1] != W.shape[1]:  # e.g. 13 input channels feeding a 16-wide K chunk (a layer fed from outside the chain)
                 feats = torch.nn.functional.pad(feats, (0, W.shape[1] - feats.shape[1]))
-            if feats.stride(1) != 1 or feats.stride(0) % 4 or out.stride(1) != 1 or out.stride(0) % 4:
+            if feats.stride(1) != 1 or feats.stride(0) % 4 or out.stride(1) != 1 or out.stride(0) % 32 or out.data_ptr() % 128:
                 return None
             layers.append(ops.ChainLayer(feats, W, out, cout=cout, scale=scale, shift=shift, res_pre=res_pre, relu=relu, pair=pair))
         nt = set(1 if l.cout <= 32 else 2 if l.cout <= 64 else 4 for l in layers)
@@ -365,7 +367,7 @@ class UNetSCN3D(nn.Module):
         if first is not None:
             f = ch.add(first[0], first[1], f)
         c = blocks[-1].conv2.out_channels
-        cat = torch.empty((f.shape[0], 2 * c), dtype=torch.float32, device=f.device)
+        cat = ops.empty_rows(f.shape[0], 2 * c, f.device)
         for i, blk in enumerate(blocks):
             f = ch.block(blk, f, out=cat[:, :c] if (conv_m is not None and i == len(blocks) - 1) else None)
         x_enc = x_s._like(f)

@@ -1111,10 +1111,15 @@ def test_tile_conv_chain_equals_layer_by_layer_launches(c, spare):
     sc = [ss(c) for _ in range(8)]
     x0 = T(rng.normal(size=(rows, c0)).astype(np.float32))
 
+    def nans(r, w):  # 128-byte aligned like the device allocator's blocks (a chained layer's output rows are whole 128-byte lines)
+        flat = torch.full((r * w + 32,), float("nan"))
+        off = (-flat.data_ptr() // 4) % 32
+        return flat[off:off + r * w].view(r, w)
+
     def run(chained):
-        bufs = [torch.full((rows, c), float("nan")) for _ in range(5)]
-        cat = torch.full((rows, 2 * c), float("nan"))
-        outm = torch.full((rows, c), float("nan"))
+        bufs = [nans(rows, c) for _ in range(5)]
+        cat = nans(rows, 2 * c)
+        outm = nans(rows, c)
         # conv_input | block 1 | block 2 (its output = the left half of the level's concat buffer) | lateral block -> right half | conv_m (pair)
         spec = [(x0, 0, bufs[0], None, None), (bufs[0], 1, bufs[1], None, None), (bufs[1], 2, bufs[2], bufs[0], None),
                 (bufs[2], 3, bufs[3], None, None), (bufs[3], 4, cat[:, :c], bufs[2], None),
@@ -1405,14 +1410,15 @@ def test_unet_bf16x8_tile_path_vs_f32(monkeypatch):
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("min_cc,cin,capacity", [(256, 13, True), (512, 16, False)])
-def test_unet_chained_levels_equal_layer_by_layer_launches(min_cc, cin, capacity, monkeypatch):
+@pytest.mark.parametrize("cin,capacity", [(13, True), (16, False)])
+def test_unet_chained_levels_equal_layer_by_layer_launches(cin, capacity, monkeypatch):
     """UNetSCN3D's inference forward with every level's SubM layers as one chained launch (scn_unet._Chain -> ls3d_tile_conv_chain) is
     bit-identical to the layer-by-layer launches (LS3D_TILE_CHAIN=0: the round-4 schedule with the lateral blocks on their own stream), with
-    host-side counts (one case) and in capacity mode (the other); the shipped structure (7 + 6 + 6 + 7 + 2 chained layers; the narrow net of the emulation with the
-    tile kernel's width limit lowered to its 16 channels) and the same net whose 16-channel level falls back to the gather-GEMM inside the
-    same code path; every output of the backbone is compared.  (The 128-channel variant of the kernel: test_tile_conv_chain_equals_...)"""
-    ratio = 1
+    host-side counts (one case) and in capacity mode (the other): the narrow net of the emulation (16 / 32 / 64 / 64 channels) with the chain's
+    thresholds lowered - levels 2 - 4 chained (6 + 6 + 7 layers, the last with conv_m4 reading the concat buffer the chain itself fills), the
+    16-channel level 1 (rows narrower than a 128-byte line: not chainable) through the same code path layer by layer; every output of the
+    backbone is compared.  (First layers of another width, the 2-layer chain, 128 channels: test_tile_conv_chain_equals_...)"""
+    ratio, min_cc = 1, 512
     cfg = synth.NUSC
     pts = synth.lidar_frame(150, seed=31, **cfg)
     v, c, n, nv = ops.voxelize_hard(torch.from_numpy(pts), cfg["voxel_size"], cfg["pc_range"], 5, 20000)
@@ -1431,7 +1437,7 @@ def test_unet_chained_levels_equal_layer_by_layer_launches(min_cc, cin, capacity
     monkeypatch.setattr(ops, "tile_conv_chain", lambda layers, plan: (chains.append(len(layers)), orig(layers, plan))[1])
 
     def run(chain, capacity):
-        ops.set_tile_chain(chain)
+        ops.set_tile_chain(chain, min_tiles=1, min_cout=16)  # (by default only levels of > 600 tiles and >= 64 channels are chained)
         bd = dict(voxel_features=feats, voxel_coords=coords, batch_size=1, input_shape=shape)
         if capacity:
             bd["num_active_voxels_dev"] = torch.tensor([V], dtype=torch.int32)
@@ -1451,14 +1457,14 @@ def test_unet_chained_levels_equal_layer_by_layer_launches(min_cc, cin, capacity
         want = run(False, capacity)
         assert chains == []
         got = run(True, capacity)
-        assert chains == ([7, 6, 6, 7, 2] if min_cc == 256 else [6, 6, 7])  # 16 x 16 channels: below the tile kernel's default width limit
+        assert chains == [6, 6, 7]
         for a, b in zip(want, got):
             assert a.shape == b.shape and torch.equal(a, b)
         assert bool(torch.isfinite(got[0]).all()) and float(got[0].abs().max()) > 0
         assert all(int(st[1]) == 0 for st in states)
     finally:
         ops.collect_chain_states(False)
-        ops.set_tile_chain(True)
+        ops.set_tile_chain(True, min_tiles=600, min_cout=64)
         ops.set_tile(True, min_cc=512)
         ops.set_precision("f32")
 
