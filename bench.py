@@ -518,6 +518,137 @@ def stage_rooflines(model, example, kind, census, frames=5):
     return out
 
 
+def train_leg(args, dist, dev, rank, world, steps, warmup):
+    """BASELINE configs[3] as a bench leg: ONE data-parallel training step of MSeg3D on Waymo geometry (23 classes, 5 cameras, 180k points per
+    frame, 2 frames per GPU = semwaymo_..._e12.py:231) - forward + (CE + Lovasz + mimic) loss + backward + SGD update, every _BatchNorm converted
+    to its count-weighted synchronised form (train.py:313-321) and the model wrapped in DistributedDataParallel over RCCL (train.py:345-352):
+    one flat gradient bucket, conv_out (no gradient on the segmentation path) excluded from the reducer instead of find_unused_parameters.
+    Timed like the inference legs (barrier + synchronise around K steps, MAX over ranks).  Beside the step time the record carries what the
+    exchange costs: gradient bytes per step, the number of SyncBN collectives per step (counted by wrapping torch.distributed for one step),
+    and the EXPOSED all-reduce time = step time - step time with the gradient all-reduce skipped (DDP.no_sync)."""
+    import lidarseg3d_amd as L
+    from lidarseg3d_amd import models_cfg, ops, sharding, synth, syncbn
+    cfg = synth.WAYMO
+    ncls, ncam, B = 23, 5, (1 if SIM else 2)
+    points = args.train_points or (400 if SIM else 180000)
+    kw = dict(num_class=ncls, pc_range=cfg["pc_range"], voxel_size=cfg["voxel_size"])
+    if SIM:  # test hook: a small grid and narrow levels keep the host emulation in seconds
+        kw.update(pc_range=(-6.4, -6.4, -2.0, 6.4, 6.4, 4.0))
+    mcfg = models_cfg.mseg3d(**kw)
+    if SIM:
+        mcfg["backbone"]["model_cfg"] = dict(mcfg["backbone"].get("model_cfg", {}), SCALING_RATIO=1)
+        mcfg["point_head"]["model_cfg"] = dict(mcfg["point_head"]["model_cfg"], VOXEL_IN_DIM=16)
+    torch.manual_seed(0)
+    ops.set_precision(args.precision if args.precision in ("f32", "bf16x6", "bf16x8") else "bf16x6")
+    model = L.build_detector(mcfg, train_cfg=None, test_cfg={})
+    model = syncbn.convert_sync_batchnorm(model).to(dev).train()
+    grad_params = [(k, p) for k, p in model.named_parameters() if p.requires_grad and not k.startswith("backbone.conv_out")]
+    grad_bytes = sum(p.numel() for _, p in grad_params) * 4
+    net = model
+    own_group = False
+    if dist is None and not SIM and world == 1:
+        # N = 1 without a launcher: a process group of one rank, so that the step runs the same DDP reducer and SyncBN modules as N > 1 and the
+        # driver's N = 1 / 2 / 4 / 8 figures are like for like
+        import socket
+        import torch.distributed as dist
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+        own_group = True
+    if dist is not None:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        # conv_out feeds nothing the segmentation loss sees (scn_unet.py:218-222): excluded from the reducer, so that DDP need not walk the
+        # autograd graph for unused parameters every step (the reference passes find_unused_parameters=True, train.py:351)
+        DDP._set_params_and_buffers_to_ignore_for_model(model, [k for k, _ in model.named_parameters() if k.startswith("backbone.conv_out")] +
+                                                        [k for k, _ in model.named_buffers() if k.startswith("backbone.conv_out")])
+        net = DDP(model, device_ids=None if SIM else [dev.index], bucket_cap_mb=128, gradient_as_bucket_view=True)
+    pc = cfg["pc_range"] if not SIM else kw["pc_range"]
+    fcfg = dict(cfg, pc_range=pc)
+    frames = [synth.lidar_frame(points, seed=500 + rank * B + b, **fcfg) for b in range(B)]
+    pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])).to(dev)
+    v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], pc, 5, 300000 * B, batched=True)
+    V = int(nv)
+    gen = torch.Generator().manual_seed(7 + rank)
+    ex = dict(points=pts, voxels=v[:V], coordinates=c[:V], num_points=n[:V], num_voxels=[0] * B, shape=[np.asarray(ops.make_grid(cfg["voxel_size"], pc)[1])],
+              voxel_sem_labels=torch.randint(0, ncls, (V,), generator=gen).to(dev), point_sem_labels=torch.randint(0, ncls, (pts.shape[0],), generator=gen).to(dev))
+    h, w = (8, 12) if SIM else (160, 240)
+    img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=rank, ncam=ncam, c_img=48, h=h, w=w, num_class=ncls, batch=B)
+    ex.update(image_features=torch.from_numpy(img).to(dev), camera_semantic_embeddings=torch.from_numpy(emb).to(dev), points_cuv=torch.from_numpy(cuv).to(dev))
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    losses = []
+
+    def step(sync=True):
+        opt.zero_grad(set_to_none=True)
+        if dist is not None and not sync:
+            with net.no_sync():
+                loss = net(dict(ex), return_loss=True)["loss"][0]
+                loss.backward()
+        else:
+            loss = net(dict(ex), return_loss=True)["loss"][0]
+            loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+
+    def timed(k, sync=True):
+        _sync()
+        if dist is not None:
+            dist.barrier()
+        _sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(sync)
+        _sync()
+        el = time.perf_counter() - t0
+        local = el
+        if dist is not None:
+            dist.barrier()
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, local
+    for _ in range(warmup):
+        step()
+    # collectives of ONE step, by kind (the SyncBN layers' all_gather / all_reduce pairs + DDP's bucket reduction, which does not go through
+    # the python API and is counted from the reducer's bucket list)
+    calls = {}
+    if dist is not None:
+        orig = {k: getattr(dist, k) for k in ("all_gather", "all_reduce")}
+
+        def counted(name):
+            def f(*a, **kw):
+                calls[name] = calls.get(name, 0) + 1
+                return orig[name](*a, **kw)
+            return f
+        for k in orig:
+            setattr(dist, k, counted(k))
+        try:
+            step()
+        finally:
+            for k, f in orig.items():
+                setattr(dist, k, f)
+    el, local = timed(steps)
+    rec = dict(metric="frames/sec, MSeg3D TRAINING step (forward + loss + backward + SGD), Waymo geometry, %d pts/frame, %d frames per GPU (BASELINE configs[3])"
+                      % (points, B), precision=ops.get_precision(), frames_per_gpu=B, points_per_frame=points, active_voxels_rank0=V, steps=steps, warmup=warmup,
+               step_ms=1e3 * el / steps, value=world * B * steps / el, unit="frames/s", n_gpus=world,
+               parallelism=("DistributedDataParallel (one flat %d MB bucket) + count-weighted SyncBN over %s, %d ranks" % (128, "gloo" if SIM else "RCCL", world))
+               if dist is not None else "single process (host emulation test hook): plain model, local BatchNorm statistics",
+               gradient_allreduce_bytes_per_step=grad_bytes if dist is not None else 0, parameters_reduced=len(grad_params),
+               syncbn_layers=sum(1 for m in model.modules() if isinstance(m, (syncbn.CountSyncBatchNorm1d, syncbn.CountSyncBatchNorm2d, syncbn.CountSyncBatchNorm3d))),
+               collectives_per_step=dict(calls, ddp_buckets=1) if dist is not None else {}, loss_first=float(losses[0]), loss_last=float(losses[-1]))
+    if dist is not None:
+        el0, _ = timed(max(2, steps // 2), sync=False)
+        k0 = max(2, steps // 2)
+        rec["step_ms_without_gradient_allreduce"] = 1e3 * el0 / k0
+        rec["exposed_gradient_allreduce_ms"] = max(0.0, rec["step_ms"] - rec["step_ms_without_gradient_allreduce"])
+        mine = dict(rank=rank, device=str(dev), step_ms=1e3 * local / steps, active_voxels=V)
+        rec["ranks"] = sharding.gather_frame_results(mine)
+    del net, model, opt, ex
+    if own_group:
+        dist.destroy_process_group()
+    return rec
+
+
 def relaunch_under_launcher(args, argv):
     """`python bench.py --gpus N` (N > 1) outside a torch.distributed.run environment: fail loudly when the box does not have N GPUs, else
     re-execute this command as one rank per GPU (tools/dist_test.py:99-104 of the reference runs under torch.distributed.launch the same way)"""
@@ -557,6 +688,8 @@ def main():
                     help="time the eager path (Python submits every launch) instead of one hipGraph per frame (lidarseg3d_amd.graph.FrameGraph)")
     ap.add_argument("--model", choices=["sdseg3d", "mseg3d"], default="sdseg3d",
                     help="sdseg3d = BASELINE configs[1] (the metric's config); mseg3d = configs[2] (LiDAR + 6-camera features)")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the data-parallel training step (BASELINE configs[3]) that follows the inference legs")
+    ap.add_argument("--train-points", type=int, default=None, help="points per frame of the training leg (default 180000: Waymo)")
     ap.add_argument("--cpu-baseline-worker", nargs="+", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -942,6 +1075,20 @@ def main():
     else:
         cfg4 = None
     ops.set_precision(args.precision)
+    # BASELINE configs[3] in the same run, for every N: the data-parallel training step under DDP + SyncBN (a process group of one rank when
+    # N = 1 and the bench was started by a launcher; a plain model otherwise)
+    train = None
+    if not args.no_train_leg and args.model == "sdseg3d" and S == 1 and B == 1 and (extra_modes or world > 1 or SIM):
+        try:
+            model = None
+            if not SIM:
+                torch.cuda.empty_cache()
+            train = train_leg(args, dist, dev, rank, world, steps=(1 if SIM else max(3, args.steps // 4)), warmup=(0 if SIM else 2))
+        except Exception as e:
+            train = dict(error=repr(e))
+        if not SIM:
+            torch.cuda.empty_cache()
+    ops.set_precision(args.precision)
 
     if rank == 0:
         c = main_leg.get("census") or {}
@@ -1044,6 +1191,8 @@ def main():
             out["batched"] = batched
         if throughput is not None:
             out["throughput_mode"] = throughput
+        if train is not None:
+            out["train_step"] = train
         if mseg is not None:
             out["mseg3d"] = mseg
         if cfg4 is not None:

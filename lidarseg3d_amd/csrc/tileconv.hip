@@ -727,7 +727,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     const int nchunk = cin / 16;
     int tile, part = 0, ksplit = 1, sidx = 0;
     if (blk < nfull) {
-      tile = CH ? blk : p.torder[blk];
+      tile = (CH && !(ablate & 1024)) ? blk : p.torder[blk];
     } else {
       const int v = blk - nfull;
       sidx = v >> 1;
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     [[maybe_unused]] ls3d_cohbuf in_buf;
     if constexpr (CH) in_buf = ls3d_cohbuf_make(in);
     if constexpr (CH) {
-      if (ch_layer > 0) {
+      if (ch_layer > 0 && !(ablate & 256)) {
         // the tiles that own this tile's halo rows must have finished the previous layer (its output rows are this layer's halo, residual
         // and pair operands; everything older follows by induction: a tile is its own producer).  One lane per producer polls its
         // completion counter with coherent loads; more than TC_DEPCAP producers: wait for the whole previous layer.
@@ -1125,9 +1125,10 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
         e.relu = __builtin_amdgcn_readfirstlane(L->e.relu);
         cout = __builtin_amdgcn_readfirstlane(L->cout); out_ld = __builtin_amdgcn_readfirstlane(L->out_ld);
       }
-      tc_epilogue<NT, true>(acc, (float *)smem, s_rows, wave, kk, col, cout, e, out, out_ld);
+      if (ablate & 512) tc_epilogue<NT, false>(acc, (float *)smem, s_rows, wave, kk, col, cout, e, out, out_ld);
+      else tc_epilogue<NT, true>(acc, (float *)smem, s_rows, wave, kk, col, cout, e, out, out_ld);
       // the tile's output rows are written through; when every wave's stores have been acknowledged the tile counts as finished
-      LS3D_WAIT_VMCNT(0);
+      if (!(ablate & 512)) LS3D_WAIT_VMCNT(0);
       __syncthreads();
       if (tid == 0) {
         ls3d_store_agent_i32(ch.state + TC_CH_DONE + tile, ch_layer + 1);
@@ -1161,7 +1162,7 @@ static int tc_launch(hipStream_t stream, const float *in, int in_ld, const TileP
 }
 
 template <int NT, int NP, int LP>
-static int tc_launch_chain(hipStream_t stream, const TilePlan &p, int swz, int grid, float *partial, int *counters, const TcChain &ch) {
+static int tc_launch_chain(hipStream_t stream, const TilePlan &p, int swz, int ablate, int grid, float *partial, int *counters, const TcChain &ch) {
   static bool attr_set_on[LS3D_MAX_DEVICES] = {};
   bool &attr_set = attr_set_on[ls3d_device_slot()];
   if (!attr_set) {
@@ -1171,7 +1172,7 @@ static int tc_launch_chain(hipStream_t stream, const TilePlan &p, int swz, int g
   }
   const EpiDev e0 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.0f};
   hipLaunchKernelGGL((k_tile_conv<NT, NP, false, LP, true>), dim3((unsigned)grid), dim3(TC_THREADS), TC_LDS_BYTES, stream, (const float *)nullptr, 0, p,
-                     (const uint4 *)nullptr, 16, 32, e0, (float *)nullptr, 0, 0, swz, 0, 0, -1, partial, counters, (unsigned *)nullptr, ch);
+                     (const uint4 *)nullptr, 16, 32, e0, (float *)nullptr, 0, ablate, swz, 0, 0, -1, partial, counters, (unsigned *)nullptr, ch);
   return LS3D_OK;
 }
 
@@ -1372,9 +1373,12 @@ extern "C" int ls3d_tile_conv_chain(const void *plan, int n_rows, int kvol, cons
   const int grid = (int)(worst < slots ? worst : slots);
   const int swz = (flags >> 30) & 1 ? 0 : 1;
   const TcChain ch = {dst, st, n_layers};
-  int rc = nt == 1 ? tc_launch_chain<1, 6, 0>(stream, p, swz, grid, (float *)workspace, (int *)counters, ch)
-         : nt == 2 ? tc_launch_chain<2, 6, 1>(stream, p, swz, grid, (float *)workspace, (int *)counters, ch)
-                   : tc_launch_chain<4, 6, 1>(stream, p, swz, grid, (float *)workspace, (int *)counters, ch);
+  // timing experiments, flags bits 1-3 (results are WRONG with bits 1 / 2): bit 1 no producer waits, bit 2 cached stores, bit 3 cost order;
+  // bit 4 (16): no halo loads, bits 8 in ablate: no weight DMA (the kernel's own ablation bits)
+  const int ablate = ((flags & 14) << 7) | (flags & 16) | ((flags & 32) ? 8 : 0);
+  int rc = nt == 1 ? tc_launch_chain<1, 6, 0>(stream, p, swz, ablate, grid, (float *)workspace, (int *)counters, ch)
+         : nt == 2 ? tc_launch_chain<2, 6, 1>(stream, p, swz, ablate, grid, (float *)workspace, (int *)counters, ch)
+                   : tc_launch_chain<4, 6, 1>(stream, p, swz, ablate, grid, (float *)workspace, (int *)counters, ch);
   if (rc != LS3D_OK) return rc;
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;

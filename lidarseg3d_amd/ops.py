@@ -715,10 +715,13 @@ def collect_chain_states(on=True):
     return _CHAIN_STATES
 
 
-# Where chaining pays (measured on the 120k-point frame, profiles/round5_experiments.md): a level whose tiles exceed the chip's 512 workgroup
-# slots (the tail of every launch is what the chain fills: levels 2 and 3; on level 4 - 216 tiles - the layers of a chain run as a wavefront
-# of dependent tiles, no faster than launches) and units long enough to carry a ticket, a poll of the producers' counters and a written-through
-# epilogue (64+ output channels; the 32-channel units of level 1 last 10 - 17 us).
+# Where chaining is used (measured on the 120k-point frame, profiles/round5_experiments.md): a level whose tiles exceed the chip's 512 workgroup
+# slots (levels 2 and 3; on level 4 - 216 tiles - the layers of a chain run as a wavefront of dependent tiles: 1.11 ms against 0.92 ms of
+# launches) and units long enough to carry a ticket, a poll of the producers' counters and a written-through epilogue (64+ output channels; the
+# 32-channel units of level 1 last 10 - 17 us: 0.32 ms chained against 0.15 ms).  What it buys there is small (+0.5 - 1 % frames/s: fewer
+# launches; the conv stack itself does not get shorter): the tails the chain fills were not idle POWER - the chip is power-limited in these
+# layers, a workgroup alone on its CU runs 122 us per tile against 213 us for two sharing one, and filling the tails trades clock for occupancy.
+_CHAIN_ABLATE = int(_os.environ.get("LS3D_CHAIN_ABLATE", "0")) & 62  # timing experiments of the chained kernel (ls3d_tile_conv_chain flags bits 1-3)
 _CHAIN_MIN_TILES = int(_os.environ.get("LS3D_CHAIN_MIN_TILES", "600"))
 _CHAIN_MIN_COUT = int(_os.environ.get("LS3D_CHAIN_MIN_COUT", "64"))
 
@@ -781,7 +784,7 @@ def tile_conv_chain(layers, plan):
     nbytes = max(int(L.ls3d_tile_conv_workspace_bytes(plan.n_rows, l.cout)) for l in layers) if split else 0
     ws = _tile_ws(nbytes, x0) if nbytes else None
     rc = L.ls3d_tile_conv_chain(_ptr(plan.buf), plan.n_rows, plan.kvol, arr, n, 6, _ptr(state), ctypes.c_size_t(state.numel()), _vp(ws),
-                                ctypes.c_size_t(ws.numel() if ws is not None else 0), _vp(_tile_counters(x0) if split else None), _TILE_FLAGS & ~63,
+                                ctypes.c_size_t(ws.numel() if ws is not None else 0), _vp(_tile_counters(x0) if split else None), (_TILE_FLAGS & ~63) | _CHAIN_ABLATE,
                                 _stream(x0))
     if rc == _lib.ERR_UNSUPPORTED:
         return False
@@ -1496,7 +1499,10 @@ class _BatchNormTrainFn(torch.autograd.Function):
         gb, gw = sums[:c].clone(), sums[c:].clone()  # local sums: the parameter gradients (DDP averages them over the ranks)
         if ctx.reduce is not None:
             sums = ctx.reduce(sums)
-        dx, dres = batch_norm_backward_apply(x, gy, y, mean, rstd, weight.detach().contiguous(), sums, ctx.count, ctx.has_res)
+        count = ctx.count
+        if torch.is_tensor(count):  # SyncBN: the total row count of all ranks stays on the device (no host synchronisation per layer) - the sums are scaled here
+            sums, count = sums / count.clamp_min(1.0), 1.0
+        dx, dres = batch_norm_backward_apply(x, gy, y, mean, rstd, weight.detach().contiguous(), sums, count, ctx.has_res)
         return dx, gw, gb, dres, None, None, None, None
 
 
@@ -1527,5 +1533,6 @@ def batch_norm_train(bn, x, res=None, relu=False):
             m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             n = state["count"]
             bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1.0, 1.0)), alpha=m)  # unbiased, as nn.BatchNorm does
+            unbias = (n / (n - 1.0).clamp_min(1.0)) if torch.is_tensor(n) else (n / max(n - 1.0, 1.0))
+            bn.running_var.mul_(1 - m).add_(var * unbias, alpha=m)  # unbiased, as nn.BatchNorm does
     return y

@@ -77,8 +77,8 @@ class CountSyncBatchNorm1d(nn.BatchNorm1d):
             tot = cnt.sum().clamp_min(1.0)
             mean = (allp[:, :c] * cnt).sum(0) / tot
             var = (allp[:, c:2 * c] + cnt * (allp[:, :c] - mean) ** 2).sum(0) / tot
-            state["count"] = float(tot)
-            return mean, var, float(tot)
+            state["count"] = tot  # a device scalar: no host synchronisation per layer (ops._BatchNormTrainFn scales the backward's sums with it)
+            return mean, var, tot
 
         def reduce(sums):
             sums = sums.clone()

@@ -196,10 +196,21 @@ def test_bench_gpus_2_is_two_ranks_on_gloo_with_the_kernels_on_hipsim():
     """`python bench.py --gpus 2` - the REAL bench.py, not a stand-in: it re-executes itself under torch.distributed.run, the two ranks
     take their shares of the frames (sharding.shard_frames), barrier, time, MAX-reduce and gather; the record says what the process
     group saw.  The LS3D_BENCH_HIPSIM hook puts the kernels on tests/hipsim and the group on gloo (there is no GPU here)."""
-    out = _run_bench(["--gpus", "2", "--points", "300", "--steps", "1", "--warmup", "0", "--precision", "f32", "--no-extra-modes", "--no-cpu-baseline"],
-                     env=dict(LS3D_BENCH_HIPSIM="1"))
+    out = _run_bench(["--gpus", "2", "--points", "300", "--steps", "1", "--warmup", "0", "--precision", "f32", "--no-extra-modes", "--no-cpu-baseline",
+                      "--train-points", "250"], env=dict(LS3D_BENCH_HIPSIM="1"), timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
+    # the training leg (BASELINE configs[3]) of the same run: DDP over the two ranks, count-weighted SyncBN, per-rank entries, the exchange it costs
+    tr = rec["train_step"]
+    assert "error" not in tr, tr
+    assert tr["n_gpus"] == 2 and "DistributedDataParallel" in tr["parallelism"] and [r["rank"] for r in tr["ranks"]] == [0, 1]
+    assert tr["gradient_allreduce_bytes_per_step"] > 1e5 and tr["syncbn_layers"] > 40
+    # every SyncBN layer that ran: one all_gather forward, one all_reduce backward; conv_out's BatchNorm never runs in the segmentation step
+    # (a layer whose input needs no gradient and that feeds the loss through a detached tensor has no backward collective)
+    cps = tr["collectives_per_step"]
+    assert tr["syncbn_layers"] - 2 <= cps["all_gather"] <= tr["syncbn_layers"] and cps["all_gather"] - 2 <= cps["all_reduce"] <= cps["all_gather"]
+    assert np.isfinite(tr["loss_first"]) and tr["step_ms"] > 0 and tr["value"] == pytest.approx(2 * 1 * 1e3 / tr["step_ms"], rel=1e-6)
+    assert tr["ranks"][0]["active_voxels"] != tr["ranks"][1]["active_voxels"]  # different frames per rank: the statistics ARE count-weighted
     assert rec["n_gpus"] == 2 and rec["rccl_world_size"] == 2 and rec["collective_backend"] == "gloo" and rec["scaling"] == "weak"
     assert [r["rank"] for r in rec["ranks"]] == [0, 1] and [r["frame_seeds"] for r in rec["ranks"]] == [[100], [101]]
     # whole-job value = frames of all ranks over the slowest rank's time: never above the sum of the per-rank rates

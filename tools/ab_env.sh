@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; OUT="$R/gpurun_out/ab"; mkdir -p $OUT
 while [ $# -ge 2 ]; do
   name=$1; envs=$2; shift 2
-  env $envs timeout 200 python bench.py --steps 30 --warmup 5 --no-extra-modes --no-cpu-baseline $EXTRA > $OUT/$name.json 2> $OUT/$name.err
+  env $envs timeout 200 python bench.py --steps 30 --warmup 5 --no-extra-modes --no-cpu-baseline --no-train-leg $EXTRA > $OUT/$name.json 2> $OUT/$name.err
   python - "$OUT/$name.json" "$name" <<'PY'
 import json,sys
 try:
