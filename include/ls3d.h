@@ -492,6 +492,14 @@ int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_points, const
  * out[p] = sum_j weight[p][j] * feat[vx_off[frame(p)] + idx[p][j]] (same arithmetic as the fused call). */
 int ls3d_interpolate_rows(const float *feat, int feat_ld, int c, const int32_t *idx, const float *weight, const float *points,
                           int pt_stride, const int32_t *vx_off, int n_points, float *out, int out_ld, ls3d_stream_t stream);
+/* Backward of ls3d_interpolate_rows with respect to the voxel features: grad_feat[v] = sum over the (point, neighbour) entries that refer to row v
+ * of weight * grad_out[point] (three_interpolate_grad, interpolate_gpu.cu:127-149, which scatters with atomicAdd: run-to-run different sums).
+ * Here the entries are sorted by voxel row (stable radix sort) and summed in entry order: bit-reproducible.  Every row of grad_feat[n_voxels,
+ * c] is written.  workspace: ls3d_interpolate_rows_backward_workspace_bytes(n_points, n_voxels) bytes, 16-byte aligned. */
+size_t ls3d_interpolate_rows_backward_workspace_bytes(int n_points, int n_voxels);
+int ls3d_interpolate_rows_backward(const float *grad_out, int go_ld, int c, const int32_t *idx, const float *weight, const float *points,
+                                   int pt_stride, const int32_t *vx_off, int n_points, int n_voxels, void *workspace, size_t workspace_bytes,
+                                   float *grad_feat, int gf_ld, ls3d_stream_t stream);
 
 /* The per-point tail of PointSegBatchlossHead at inference (det3d/models/point_heads/point_seg_batchloss_head.py:141-168) in ONE launch:
  *   x[p] = sum_j weight[p][j] * feat[vx_off[frame(p)] + idx[p][j]]   (the arithmetic of ls3d_interpolate_rows; idx == NULL: x[p] = feat[p])

@@ -678,6 +678,82 @@ __global__ __launch_bounds__(256) void k_interp_rows(const float *feat, int feat
   }
 }
 
+// Backward of ls3d_interpolate_rows with respect to the voxel features (interpolate_gpu.cu:127-149 scatters with atomicAdd: the order of the
+// float additions, and with it the last bits of the gradient, changes from run to run).  Here: the 3 n (point, neighbour) entries are sorted
+// by their voxel row (stable radix sort: entries of a voxel stay in entry order), and every (voxel, 4-channel group) sums its entries in that
+// order: bit-reproducible.  grad_feat[v] = sum over entries e = (p, j) with vx_off[frame(p)] + idx[p][j] == v of weight[p][j] * grad_out[p].
+__global__ __launch_bounds__(256) void k_interp_bwd_keys(const int32_t *idx, const float *points, int pt_stride, const int32_t *vx_off, int n, int V,
+                                                         uint32_t *keys) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 3 * n; e += gridDim.x * blockDim.x) {
+    const int p = e / 3;
+    const int f = (int)points[(size_t)p * pt_stride];
+    const int v0 = vx_off[f], m = vx_off[f + 1] - v0;
+    const int i = idx[e];
+    keys[e] = (m > 0 && i >= 0 && i < m) ? (uint32_t)(v0 + i) : (uint32_t)V;  // frames without voxels: the entry sorts behind every row
+  }
+}
+__global__ __launch_bounds__(256) void k_interp_bwd_starts(const uint32_t *skeys, int n3, int V, int32_t *start) {
+  // start[v] = first sorted position with key >= v (v = 0 .. V): every thread looks at one boundary of the sorted key list
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n3; i += gridDim.x * blockDim.x) {
+    const int lo = i == 0 ? -1 : (int)min(skeys[i - 1], (uint32_t)V), hi = i == n3 ? V : (int)min(skeys[i], (uint32_t)V);
+    for (int v = lo + 1; v <= hi; ++v) start[v] = i;
+  }
+}
+__global__ __launch_bounds__(256) void k_interp_bwd_sum(const float *gout, int go_ld, int C, const float *w, const int32_t *order, const int32_t *start,
+                                                        int V, float *gfeat, int gf_ld) {
+  const int c4n = C >> 2;
+  const long long work = (long long)V * c4n;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(t / c4n), c4 = (int)(t % c4n);
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = start[v]; i < start[v + 1]; ++i) {
+      const int e = order[i];
+      const float we = w[e];
+      const float4 g = *(const float4 *)(gout + (size_t)(e / 3) * go_ld + c4 * 4);
+      o.x = fmaf(we, g.x, o.x); o.y = fmaf(we, g.y, o.y); o.z = fmaf(we, g.z, o.z); o.w = fmaf(we, g.w, o.w);
+    }
+    *(float4 *)(gfeat + (size_t)v * gf_ld + c4 * 4) = o;
+  }
+}
+int ls3d_radix_sort_pairs(const uint32_t *keys_in, const int32_t *vals_in, int n, const int32_t *n_dev, int bits, uint32_t *keys_out, int32_t *vals_out,
+                          void *workspace, size_t workspace_bytes, hipStream_t stream);
+extern "C" size_t ls3d_radix_sort_workspace_bytes(int n);
+static inline size_t ib_align(size_t v) { return (v + 255) & ~(size_t)255; }
+extern "C" size_t ls3d_interpolate_rows_backward_workspace_bytes(int n_points, int n_voxels) {
+  if (n_points < 0 || n_voxels < 0) return 0;
+  const size_t n3 = (size_t)3 * n_points;
+  return 3 * ib_align(n3 * 4) + ib_align(((size_t)n_voxels + 2) * 4) + ls3d_radix_sort_workspace_bytes((int)n3) + 256;
+}
+extern "C" int ls3d_interpolate_rows_backward(const float *grad_out, int go_ld, int c, const int32_t *idx, const float *weight, const float *points,
+                                              int pt_stride, const int32_t *vx_off, int n_points, int n_voxels, void *workspace,
+                                              size_t workspace_bytes, float *grad_feat, int gf_ld, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!grad_feat || n_points < 0 || n_voxels < 0 || (c % 4) || (go_ld % 4) || (gf_ld % 4) || go_ld < c || gf_ld < c) return LS3D_ERR_ARG;
+  if (n_voxels == 0) return LS3D_OK;
+  if (!workspace || ((uintptr_t)workspace & 15)) return LS3D_ERR_ARG;
+  if (n_points > 0 && (!grad_out || !idx || !weight || !points || !vx_off || pt_stride < 1)) return LS3D_ERR_ARG;
+  if ((long long)3 * n_points > 0x7FFFFFFFll) return LS3D_ERR_UNSUPPORTED;
+  if (workspace_bytes < ls3d_interpolate_rows_backward_workspace_bytes(n_points, n_voxels)) return LS3D_ERR_WORKSPACE;
+  const int n3 = 3 * n_points;
+  char *wsp = (char *)workspace;
+  uint32_t *keys = (uint32_t *)wsp; wsp += ib_align((size_t)n3 * 4);
+  uint32_t *skeys = (uint32_t *)wsp; wsp += ib_align((size_t)n3 * 4);
+  int32_t *order = (int32_t *)wsp; wsp += ib_align((size_t)n3 * 4);
+  int32_t *start = (int32_t *)wsp; wsp += ib_align(((size_t)n_voxels + 2) * 4);
+  int bits = 1;
+  while ((1ll << bits) <= (long long)n_voxels) ++bits;  // keys 0 .. V
+  if (n3 > 0) {  // (no points: every segment is empty, the gradient is zero)
+    hipLaunchKernelGGL(k_interp_bwd_keys, ls3d_grid(n3), dim3(256), 0, stream, idx, points, pt_stride, vx_off, n_points, n_voxels, keys);
+    const int rc = ls3d_radix_sort_pairs(keys, nullptr, n3, nullptr, bits, skeys, order, wsp, workspace_bytes - (size_t)(wsp - (char *)workspace), stream);
+    if (rc != LS3D_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_interp_bwd_starts, ls3d_grid((long long)n3 + 1), dim3(256), 0, stream, (const uint32_t *)skeys, n3, n_voxels, start);
+  hipLaunchKernelGGL(k_interp_bwd_sum, ls3d_grid((long long)n_voxels * (c / 4)), dim3(256), 0, stream, grad_out, go_ld, c, weight, (const int32_t *)order,
+                     (const int32_t *)start, n_voxels, grad_feat, gf_ld);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
 extern "C" int ls3d_interpolate_rows(const float *feat, int feat_ld, int c, const int32_t *idx, const float *weight, const float *points,
                                      int pt_stride, const int32_t *vx_off, int n_points, float *out, int out_ld, ls3d_stream_t stream) {
   if (!feat || !idx || !weight || !points || !vx_off || !out || n_points < 0 || pt_stride < 1) return LS3D_ERR_ARG;

@@ -24,11 +24,6 @@ def _L():
     return _lib.load()
 
 
-def _os_environ_get(k, d):
-    import os
-    return os.environ.get(k, d)
-
-
 class CapacityModeUnsupported(RuntimeError):
     """raised by a stage that cannot run on device-side row counts; the detector then runs the frame with host-side counts"""
 
@@ -438,7 +433,7 @@ def rulebook_orders(tbls, n_devs=None):
     """rulebook_order for several tables at once: one batched sort (keys carry the table number in their top bits) instead
     of one sort per table - the sorts are launch-bound (~10 small kernels each).  -> list of int32 orders (None where a
     table has no rows / too many offsets / row order is disabled)."""
-    descending = _os_environ_get("LS3D_ORDER_ASC", "0") != "1"
+    descending = True
     out = [None] * len(tbls)
     sel = [i for i, t in enumerate(tbls) if t.shape[0] > 0 and t.shape[1] <= 27 and _ROW_ORDER != "none"]
     for lo in range(0, len(sel), 16):
@@ -499,9 +494,9 @@ def rulebook_parity_orders(coords, geoms, n_devs=None):
 
 
 _TRANSVFE_DIRECT = _os.environ.get("LS3D_TRANSVFE_DIRECT", "0") != "0"
-_TRANSVFE_DEDUP = _os.environ.get("LS3D_TRANSVFE_DEDUP", "1") != "0"  # identical padding tokens of a voxel computed once (ls3d_transvfe)
+_TRANSVFE_DEDUP = True  # (set_transvfe_dedup: A/B in the tests) identical padding tokens of a voxel computed once (ls3d_transvfe)
 # per-call flags of ls3d_gather_gemm (include/ls3d.h): bits 0-1 workgroup -> tile mapping, bit 2 the one-stage pipeline of the sparse 6-product kernel (A/B)
-_GEMM_FLAGS = (int(_os.environ.get("LS3D_XCD_MAP", "0")) & 3) | (int(_os.environ.get("LS3D_GEMM_FLAGS", "0"), 0) & 4)
+_GEMM_FLAGS = 0  # set_gemm_flags: the `flags` of ls3d_gather_gemm (workgroup -> tile mapping, one-stage pipeline) for A/B runs
 
 
 def set_transvfe_direct(on):
@@ -578,7 +573,7 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
 # ---------------------------------------------------------------------------------------------- tile-halo convolution
 _TILE = _os.environ.get("LS3D_TILE", "1") != "0"          # 3-plane modes: SubM layers on ls3d_tile_conv
 _TILE_KINDS = _os.environ.get("LS3D_TILE_KINDS", "subm")  # which rulebook kinds take the tile path: subm[,conv][,inverse]
-_TILE_MIN_CC = int(_os.environ.get("LS3D_TILE_MIN_CC", "512"))  # cin*cout below which the gather-GEMM stays
+_TILE_MIN_CC = 512  # cin*cout below which the gather-GEMM stays
 
 
 def set_tile(on, kinds=None, min_cc=None):
@@ -591,7 +586,7 @@ def set_tile(on, kinds=None, min_cc=None):
 
 
 _TILE_FLAGS = int(_os.environ.get("LS3D_TILE_FLAGS", "0"))       # per-call flags of ls3d_tile_conv (include/ls3d.h), for A/B runs of unmodified scripts
-_TILE_PLAN_FLAGS = int(_os.environ.get("LS3D_TILE_PLAN_FLAGS", "0"))  # ... of ls3d_tile_plan / ls3d_tile_build
+_TILE_PLAN_FLAGS = 0  # ... of ls3d_tile_plan / ls3d_tile_build
 
 
 def set_tile_flags(conv=None, plan=None):
@@ -805,7 +800,7 @@ def trace_tile_convs(on=True):
     return _TILE_TRACE
 
 
-_TILE_KSPLIT = _os.environ.get("LS3D_TILE_KSPLIT", "1") != "0"  # hand ls3d_tile_conv the workspace for its split over the input channels
+_TILE_KSPLIT = True  # hand ls3d_tile_conv the workspace for its split over the input channels
 _TILE_COUNTERS = {}
 
 
@@ -826,7 +821,7 @@ def _tile_ws(nbytes, like):
     return _ws(nbytes, like)
 
 
-_WGRAD_PLANES = _os.environ.get("LS3D_WGRAD_PLANES", "1") != "0"
+_WGRAD_PLANES = True
 
 
 def spconv_pairs(tbl, order=None):
@@ -844,7 +839,7 @@ def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None, pairs=None):
     """grad_w[kvol, cin, cout] of a sparse convolution: x = the forward input features (rows indexed by tbl), grad_out on the
     forward output rows, tbl/order = the table and row order of the forward launch.  products: 0 = exact-f32 MFMA kernel, 6 / 8 = the exact
     3-plane bf16 split (f32-grade; the library uses it for layers with >= 8 output blocks of 32 x 32 and the exact-f32 kernel below that);
-    None = ops.set_precision's product count (0 in "f32" / "bf16x3"; LS3D_WGRAD_PLANES=0 forces 0).  pairs = spconv_pairs(tbl, order)
+    None = ops.set_precision's product count (0 in "f32" / "bf16x3").  pairs = spconv_pairs(tbl, order)
     when several layers share the table (same result, the lists are not rebuilt)."""
     n, kvol = tbl.shape
     gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
@@ -926,24 +921,34 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            cout, cin = weight.shape
+            if _LINEAR_DGRAD and cout % 16 == 0 and cin % 4 == 0 and cin <= 256 and (gy.is_cuda or _SIM):
+                # grad_x = grad_y W on the dense exact-f32 gather-GEMM (W [out, in] IS the [K][N] operand): hipBLASLt serves these
+                # [10^5..10^6 rows] x [<= 256 x 256] products with 32 x 32 macro tiles (~10 ms of a Waymo step, profiles/round4_train_step_*)
+                from .packing import PackedWeight
+                gx = gather_gemm(gy, PackedWeight(weight.detach().reshape(1, cout, cin), 1, cout, cout, cin), cout=cin)
+            else:
+                gx = gy @ weight
         gw = linear_wgrad(x.detach().contiguous(), gy) if ctx.needs_input_grad[1] else None
         gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb
 
 
 _ORIG_LINEAR = None
-_FAST_LINEAR_DEBUG = _os.environ.get("LS3D_FAST_LINEAR_DEBUG", "0") != "0"
+_LINEAR_DGRAD = True  # A/B: the input gradient of the tall-skinny Linear layers on ls3d_gather_gemm instead of hipBLASLt
+_FAST_LINEAR_DEBUG = False  # print the Linear shapes the context does not take (once each)
 _FAST_LINEAR_SEEN = set()
-_FAST_LINEAR_MIN_ROWS = int(_os.environ.get("LS3D_FAST_LINEAR_MIN_ROWS", "32768"))
+_FAST_LINEAR_MIN_ROWS = 32768
 
 
 class fast_linear_backward(object):
     """`with ops.fast_linear_backward():` - inside, torch.nn.functional.linear (hence nn.Linear, nn.MultiheadAttention's projections)
     records _LinearFn for the tall-skinny case (>= 32768 rows on the device, both dimensions <= 256, a gradient wanted) and
     torch.nn.functional.layer_norm records _LayerNormFn (csrc/norm.hip) for [>= 32768, c <= 256] f32 rows.  The training forward of the
-    detectors runs under it (the backward then runs the recorded functions wherever it is called); LS3D_FAST_LINEAR=0 switches the whole
-    context off, LS3D_FAST_LAYERNORM=0 the LayerNorm part."""
+    detectors runs under it (the backward then runs the recorded functions wherever it is called); LS3D_FAST_LAYERNORM=0 switches the
+    LayerNorm part off."""
 
     def __init__(self, model=None):
         """model: only the BatchNorm1d modules of THIS model take the HIP kernels while the context is active (they are marked once); without a
@@ -957,7 +962,7 @@ class fast_linear_backward(object):
 
     def __enter__(self):
         global _ORIG_LINEAR
-        self.on = _os.environ.get("LS3D_FAST_LINEAR", "1") != "0" and _ORIG_LINEAR is None
+        self.on = _ORIG_LINEAR is None
         scoped = self.model is not None
         if self.on:
             _ORIG_LINEAR = torch.nn.functional.linear
@@ -1139,7 +1144,7 @@ class PointMlp(object):
                 and sum(w.shape[0] * 72 + 128 for w, _, _, _ in self.keep) * 4 <= 80 * 1024)
 
 
-_POINT_MLP = _os.environ.get("LS3D_POINT_MLP", "1") != "0"  # A/B: the per-point tail of PointSegBatchlossHead in one launch
+_POINT_MLP = True  # A/B: the per-point tail of PointSegBatchlossHead in one launch
 
 
 def point_mlp(feat, model, idx=None, weight=None, points=None, vx_off=None, n=None, want_labels=True):
@@ -1161,6 +1166,37 @@ def interpolate_rows(feat, idx, weight, points, vx_off, c=None):
     check(_L().ls3d_interpolate_rows(_ptr(feat), feat.shape[1], c, _ptr(idx), _ptr(weight), _ptr(points), points.shape[1], _ptr(vx_off), n,
                                      _ptr(out), c, _stream(feat)), "ls3d_interpolate_rows")
     return out
+
+
+def interpolate_rows_backward(grad_out, idx, weight, points, vx_off, n_voxels):
+    """d interpolate_rows / d feat: deterministic (entries sorted by voxel row, summed in entry order; include/ls3d.h)"""
+    n, c = grad_out.shape
+    gf = torch.empty((n_voxels, c), dtype=torch.float32, device=grad_out.device)
+    L = _L()
+    ws = _ws(L.ls3d_interpolate_rows_backward_workspace_bytes(n, n_voxels), grad_out)
+    check(L.ls3d_interpolate_rows_backward(_ptr(grad_out), c, c, _ptr(idx), _ptr(weight), _ptr(points), points.shape[1], _ptr(vx_off), n, n_voxels,
+                                           _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(gf), c, _stream(grad_out)), "ls3d_interpolate_rows_backward")
+    return gf
+
+
+class _InterpolateRowsFn(torch.autograd.Function):
+    """the devoxelization of the training forward (point_utils.py:8-52 with the neighbour search done): forward ls3d_interpolate_rows, backward
+    ls3d_interpolate_rows_backward - instead of a torch gather whose backward scatters with atomics (run-to-run different gradients)"""
+
+    @staticmethod
+    def forward(ctx, feat, idx, weight, points, vx_off):
+        ctx.save_for_backward(idx, weight, points, vx_off)
+        ctx.nv = feat.shape[0]
+        return interpolate_rows(feat.contiguous(), idx, weight, points, vx_off)
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx, weight, points, vx_off = ctx.saved_tensors
+        return interpolate_rows_backward(gout.contiguous(), idx, weight, points, vx_off, ctx.nv), None, None, None, None
+
+
+def interpolate_rows_autograd(feat, idx, weight, points, vx_off):
+    return _InterpolateRowsFn.apply(feat, idx.contiguous(), weight.contiguous(), points, vx_off)
 
 
 # ---------------------------------------------------------------------------------------------- fusion
@@ -1270,7 +1306,7 @@ class SffmModel(object):
 
 _SFFM_ATTENTION = 0
 _SFFM_ABLATE = 0  # measurement only (tools/bench_decoder.py): parts of k_sffm_decoder_rt left out, see SfParams::ablate
-_SFFM_PLANES = _os.environ.get("LS3D_SFFM_PLANES", "1") != "0"  # A/B: the decoder's GEMMs on the 3-plane bf16 split in the 3-plane precisions
+_SFFM_PLANES = True  # A/B: the decoder's GEMMs on the 3-plane bf16 split in the 3-plane precisions
 
 
 def set_sffm_attention(mode):
@@ -1506,7 +1542,7 @@ class _BatchNormTrainFn(torch.autograd.Function):
         return dx, gw, gb, dres, None, None, None, None
 
 
-_BN_KERNELS = _os.environ.get("LS3D_BN_KERNELS", "1") != "0"
+_BN_KERNELS = True
 _TORCH_RELU = torch.relu
 
 

@@ -106,6 +106,15 @@ def _devox_search(batch_dict, points, centers, batch_size):
     return idx, w, vx_off
 
 
+def _interpolate_train(feat, idx, w, points, vx_off):
+    """the weighted 3-NN gather of the training forward with a gradient for feat: the HIP pair ls3d_interpolate_rows / _backward (deterministic)
+    where the shapes allow, else the torch composition (whose backward scatters with atomics)"""
+    if feat.shape[1] % 4 == 0 and (feat.is_cuda or ops.sim_mode()) and points.is_contiguous():
+        return ops.interpolate_rows_autograd(feat, idx, w, points, vx_off)
+    v0 = vx_off[points[:, 0].long()].unsqueeze(1)
+    return (feat[(idx + v0).long()] * w.unsqueeze(-1)).sum(1)
+
+
 def _predict(head, example, test_cfg):
     """point_seg_batchloss_head.py:171-271 / point_seg_mseg3d_head.py:379-479: per-frame argmax, or the mean of
     the softmax over TTA variants.  Pure bookkeeping on top of out_logits."""
@@ -176,8 +185,7 @@ class PointSegBatchlossHead(PackedModule):
         conv_logits = self.conv_cls_layers(feat)
         points = batch_dict["points"].contiguous()
         idx, w, vx_off = _devox_search(batch_dict, points, batch_dict["conv_point_coords"], batch_dict["batch_size"])
-        v0 = vx_off[points[:, 0].long()].unsqueeze(1)
-        pf = (feat[(idx + v0).long()] * w.unsqueeze(-1)).sum(1)
+        pf = _interpolate_train(feat, idx, w, points, vx_off)
         out = self.out_cls_layers(self.conv_align_layers(pf))
         batch_dict["out_logits"] = out
         self.forward_ret_dict.update(conv_logits=conv_logits, out_logits=out)
@@ -283,7 +291,7 @@ class TransformerDecoder(nn.Module):
 
 import os as _os
 _HEAD_STREAMS = {}
-_HEAD_OVERLAP = _os.environ.get("LS3D_HEAD_OVERLAP", "1") != "0"  # MSeg3D head: camera branch / class-embedding side on their own streams
+_HEAD_OVERLAP = True  # MSeg3D head: camera branch / class-embedding side on their own streams
 # Loss-only outputs at inference.  The reference's eval forward also computes tensors that nothing but get_loss() reads: the voxel-level
 # `conv_logits` of PointSegBatchlossHead (point_seg_batchloss_head.py:138-141) and the mimic branch `point_features_pcamera` of
 # PointSegMSeg3DHead (point_seg_mseg3d_head.py:305-334).  They do not feed `out_logits`; by default they are NOT evaluated at inference
@@ -636,8 +644,7 @@ class PointSegMSeg3DHead(PackedModule):
         points = batch_dict["points"].contiguous()
         centers = batch_dict["conv_point_coords"]
         idx, w, vx_off = _devox_search(batch_dict, points, centers, B)
-        v0 = vx_off[points[:, 0].long()].unsqueeze(1)
-        pl = self.gffm_lidar((vf[(idx + v0).long()] * w.unsqueeze(-1)).sum(1))
+        pl = self.gffm_lidar(_interpolate_train(vf, idx, w, points, vx_off))
         cuv = batch_dict["points_cuv"]
         valid = cuv[:, 0] == 1
         pc = self.gffm_camera(_sample_image_rows(batch_dict["image_features"], cuv[valid], points[:, 0][valid]))

@@ -11,7 +11,7 @@ from .packing import PackedModule, pack_linear
 from .registry import READERS
 
 import os as _os
-_FUSED = _os.environ.get("LS3D_TRANSVFE_FUSED", "1") != "0"  # 0: compose the TransVFE from the individual ops (A/B, tests)
+_FUSED = True  # False: compose the TransVFE from the individual ops (A/B, tests)
 
 
 @READERS.register_module

@@ -63,14 +63,13 @@ _SIDE_STREAMS = {}
 import os as _os
 # side streams of the capacity-mode geometry: 2 = {strided-rulebook chain | per-level rulebooks, plans, orders, devoxelization search}
 # (measured on MI355X, one hipGraph per frame: 7.40 ms; 3 streams 7.63 ms; everything on one chain 7.84 ms)
-_N_SIDE = int(_os.environ.get("LS3D_GEOM_STREAMS", "2"))
+_N_SIDE = 2
 
 
 # The lateral SparseBasicBlock of a decoder level (conv_up_t<l>, scn_unet.py:163-165) reads the ENCODER output of its level only: it does not
 # depend on anything the deeper levels compute.  It runs on its own stream from the moment the encoder leaves the level, beside the
 # deeper levels - whose launches do not fill the chip (level 4 of a 120k-point frame: 215 tiles for 512 workgroup slots) and whose tails
 # leave CUs idle - and the decoder picks it up with one event.  Same kernels on the same inputs: bit-identical.  LS3D_LATERAL_STREAM=0: inline.
-_EARLY_ORDER = int(_os.environ.get("LS3D_EARLY_ORDER", "0"))  # capacity mode: the first strided layer's row order from its own early sort (2: on the rulebook chain's stream, 1: behind the level-1 geometry)
 _LATERAL = _os.environ.get("LS3D_LATERAL_STREAM", "1") != "0"
 # capacity mode: `encoded_spconv_tensor` (scn_unet.py:218-222: conv_out of the deepest level) feeds no segmentation head - the key holds a proxy that
 # runs the convolution (and builds its rulebook) when something reads it, instead of one more rulebook, mask sort and launch beside every frame
@@ -641,22 +640,10 @@ class UNetSCN3D(nn.Module):
         #             strided rulebook that creates the level's sites; the devoxelization's neighbour search at the end.
         # The main stream picks the levels up one event at a time.
         with _GeometryStream(x.indices, ready, join=False, index=1) as gs:
-            rb_events, conv2_order = [], None
-            if _EARLY_ORDER == 2 and len(chain) > 1:
-                # The first strided layer (32 -> 64 on 142k output rows with 1.6 neighbours each) is too small for ORDER_MIN_CC, and unsorted it
-                # walks ~25 of the 27 offsets per 128-row tile (114 us; sorted: 4.6 offsets, 51 us - profiles/round4_ab_gather_knobs.txt).  In the
-                # frame's batched sort its order arrived too late (the layer is the first consumer: `value` 147 -> 142); behind the level-1
-                # geometry on stream 0 it was late as well (the reader leaves the sort's small kernels few CU slots: 147.7 -> 144).  Here it is
-                # sorted right behind its own rulebook, in front of the rest of the chain (whose levels run a millisecond later).
-                spconv.prebuild_conv_rulebooks(x, chain[:1], nosync=True, caps=caps[:1], after_each=lambda: rb_events.append(gs.finish_event()))
-                rb2 = x.find_indice_pair(chain[0].indice_key)
-                rb2.order(False)
-                gs.hand_over([rb2])
-                conv2_order = gs.finish_event()
-                spconv.prebuild_conv_rulebooks(x, chain[1:], coords=rb2.out_indices, shape=rb2.out_shape, n_dev=rb2.n_out_dev, nosync=True,
-                                               caps=caps[1:], after_each=lambda: rb_events.append(gs.finish_event()))
-            else:
-                spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps, after_each=lambda: rb_events.append(gs.finish_event()))
+            # (an early mask sort of the first strided layer's table - the layer 114 -> 51 us alone - was measured in round 4: its sort kernels
+            # slow the reader beside them and the frame gains nothing; profiles/round4_ab_gather_knobs.txt.  Removed in round 5.)
+            rb_events = []
+            spconv.prebuild_conv_rulebooks(x, chain, nosync=True, caps=caps, after_each=lambda: rb_events.append(gs.finish_event()))
             cnts = torch.stack([torch.cat([x.indice_dict[c.indice_key].n_out_dev, x.indice_dict[c.indice_key].overflow_dev]) for c in chain])
             vflag = batch_dict.get("voxel_overflow_dev")
             if vflag is not None:  # a frame of the batch exceeded the voxelizer's per-frame cap (detectors._voxel_inputs): reported as an overflow
@@ -679,12 +666,6 @@ class UNetSCN3D(nn.Module):
             spconv.prebuild_orders(x, list(self.conv_input.modules()) + list(self.conv1.modules()))
             gs.hand_over(x.indice_dict.values())
             level_ready.append(gs.finish_event())
-        if _EARLY_ORDER == 1:  # (A/B) the same sort behind the level-1 geometry on stream 0
-            with _GeometryStream(x.indices, ready, join=False, index=0, after=rb_events[:1]) as gs:
-                rb2 = x.find_indice_pair(self.conv2[0][0].indice_key)
-                rb2.order(False)
-                gs.hand_over([rb2])
-                conv2_order = gs.finish_event()
         for lvl, (key, src, stage) in enumerate((("subm2", "spconv2", self.conv2), ("subm3", "spconv3", self.conv3), ("subm4", "spconv4", self.conv4))):
             # the last level's block also builds what is left - the decoder's row orders (the inverse tables of EVERY strided rulebook of the
             # chain; conv_out's only when it is computed eagerly, set_lazy_encoded(False)) - so it waits for the whole chain
@@ -714,7 +695,6 @@ class UNetSCN3D(nn.Module):
         for lvl, (key, stage) in enumerate((("subm2", self.conv2), ("subm3", self.conv3), ("subm4", self.conv4))):
             self._wait(x, level_ready[lvl + 1])
             if lvl == 0:
-                self._wait(x, conv2_order)
                 ev0 = self._stack_event() if ev1 is not None else None
             if chained:  # the strided convolution, then the level's blocks + lateral block (+ conv_m on the deepest level) as one launch
                 x_enc, cat_l, x_m4 = self._level_chain(stage[0](x_enc), key, [stage[1], stage[2]], (self.conv_up_t2, self.conv_up_t3, self.conv_up_t4)[lvl],

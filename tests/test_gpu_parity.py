@@ -9,6 +9,7 @@ import torch
 
 import lidarseg3d_amd as L
 from lidarseg3d_amd import models_cfg, ops, point_heads, readers, scn_unet, synth
+from lidarseg3d_amd import scn_unet as sn
 from oracle import ref as orc
 from tests.util import golden, seeded_sd
 
@@ -976,6 +977,48 @@ def test_linear_weight_gradient_gpu(cin, cout):
     assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,other_n", [(96, 96, 241737), (192, 96, 100000), (64, 192, 70001)])
+def test_linear_layer_backward_on_the_hip_kernels_gpu(cin, cout, other_n):
+    """nn.Linear under ops.fast_linear_backward (the training forward of the detectors): output, input gradient (ls3d_gather_gemm on the [out, in]
+    weight: round 5) and weight / bias gradients (ls3d_spconv_wgrad on the identity pair lists of a row CAPACITY: a second row count reuses the
+    lists of the first) against float64; the row counts of a Waymo step"""
+    torch.manual_seed(cin * cout)
+    lin = torch.nn.Linear(cin, cout).to(DEV)
+    for n in (360000, other_n):
+        x = torch.randn(n, cin, device=DEV).relu_().requires_grad_(True)
+        gy = torch.randn(n, cout, device=DEV) * 0.1
+        lin.zero_grad()
+        with ops.fast_linear_backward():
+            y = lin(x)
+        y.backward(gy)
+        xd, wd, bd, gd = x.detach().double(), lin.weight.detach().double(), lin.bias.detach().double(), gy.double()
+        assert float((y.detach().double() - (xd @ wd.t() + bd)).abs().max()) <= 3e-6 * float(y.abs().max())
+        gx, gw, gb = gd @ wd, gd.t() @ xd, gd.sum(0)
+        assert float((x.grad.double() - gx).abs().max()) <= 3e-6 * float(gx.abs().max())
+        assert float((lin.weight.grad.double() - gw).abs().max()) <= 3e-6 * float(gw.abs().max())
+        assert float((lin.bias.grad.double() - gb).abs().max()) <= 3e-5 * float(gb.abs().max())
+
+
+def test_interpolate_rows_backward_full_size_gpu():
+    """the devoxelization's feature gradient at the size of a Waymo step (360k points, 241k voxels, 32 channels): against float64, and
+    bit-reproducible where torch's index_put backward (atomics) is not"""
+    torch.manual_seed(1)
+    n, V, C = 360000, 241737, 32
+    vx_off = cu(np.array([0, 120000, V], np.int32))
+    pts = torch.cat([(torch.arange(n, device=DEV) >= 180000).float()[:, None], torch.randn(n, 3, device=DEV)], 1).contiguous()
+    m = torch.where(pts[:, 0] == 0, 120000, V - 120000)
+    idx = (torch.rand(n, 3, device=DEV) * m[:, None]).int().clamp_(min=0)
+    idx = torch.minimum(idx, (m - 1).int()[:, None]).contiguous()
+    w = torch.rand(n, 3, device=DEV)
+    g = torch.randn(n, C, device=DEV)
+    got = ops.interpolate_rows_backward(g, idx, w, pts, vx_off, V)
+    assert torch.equal(got, ops.interpolate_rows_backward(g, idx, w, pts, vx_off, V))
+    want = torch.zeros((V, C), dtype=torch.float64, device=DEV)
+    rows = (idx.long() + vx_off[pts[:, 0].long()].long()[:, None]).reshape(-1)
+    want.index_add_(0, rows, (g.double()[:, None, :] * w.double()[:, :, None]).reshape(-1, C))
+    assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (128, 128), (96, 32)])
 def test_sparse_conv_backward_gpu(cin, cout):
     """dgrad (gather-GEMM on the transposed tables) and wgrad (ls3d_spconv_wgrad) of SubM / strided / inverse convolutions on
@@ -1821,6 +1864,57 @@ def test_chained_tile_launches_equal_layer_by_layer_launches_120k(kind):
         ops.collect_chain_states(False)
         ops.set_tile_chain(True, min_tiles=600, min_cout=64)
         detectors.CAPACITY_MODE = True
+        ops.set_precision("f32")
+
+
+def test_every_schedule_switch_of_the_host_layer_keeps_the_logits(monkeypatch):
+    """the A/B switches the host layer still reads from the environment (DESIGN.md 4.7 lists them) change WHEN and WHERE kernels run, or which of
+    two equivalent kernels runs - never the result beyond the stated tolerance: each one toggled against the default on a 60k-point frame in the
+    bf16x6 arithmetic, SDSeg3D and MSeg3D.  Bit-identical: stream overlap off, lateral stream off, lean start off, coordinate-class row orders
+    off, mask orders for every strided table, another workgroup geometry target, the tile kernel's dispatch / swizzle / split flags, the chained
+    launches everywhere.  Within tolerance (another summation order or arithmetic): the 6-product gather-GEMM off (exact f32 for the strided
+    layers), the reader's plane GEMMs off, the fused SF-Phase decoder / memory side off."""
+    from lidarseg3d_amd import detectors, spconv as sp
+    cfg = synth.NUSC
+    frame = synth.lidar_frame(60000, seed=21, **cfg)
+    pts = cu(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1))
+    img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=9, ncam=6, c_img=48, h=40, w=60, batch=1)
+    cam = dict(points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
+    # (owner, attribute, value, relative tolerance: 0 = bit-identical)
+    switches = [(sn, "_LATERAL", False, 0), (detectors, "_LEAN_START", False, 0), (ops, "_PARITY_ORDER", False, 0), (sp, "ORDER_MIN_CC", 0, 0),
+                (ops, "_TARGET_BLOCKS", 256, 0), (ops, "_TILE_FLAGS", (1 << 30) | (1 << 6), 0), (ops, "_TILE_FLAGS", 2 << 6, 2e-6),
+                (ops, "_CHAIN_MIN_TILES", 1, 0), (ops, "_GATHER_X6", False, 2e-5), (ops, "_TRANSVFE_PLANES", False, 2e-5),
+                (point_heads, "_FUSED_SFFM", False, 2e-5), (point_heads, "_FUSED_SFFM_MEMORY", False, 2e-5), (point_heads, "_HEAD_OVERLAP", False, 0)]
+    try:
+        ops.set_precision("bf16x6")
+        for kind in ("sdseg3d", "mseg3d"):
+            model, _ = _model(getattr(models_cfg, kind)())
+            ex = dict(points=pts, batch_size=1, **(cam if kind == "mseg3d" else {}))
+
+            def run():
+                with torch.no_grad():
+                    model(dict(ex), return_loss=False)
+                return model.point_head.forward_ret_dict["out_logits"].clone()
+            run()
+            ref = run()
+            scale = float(ref.abs().max())
+            assert torch.equal(run(), ref)
+            monkeypatch.setenv("LS3D_OVERLAP", "0")
+            assert torch.equal(run(), ref), "LS3D_OVERLAP=0"
+            monkeypatch.delenv("LS3D_OVERLAP")
+            for owner, name, value, tol in switches:
+                if kind == "sdseg3d" and owner is point_heads:
+                    continue
+                old = getattr(owner, name)
+                setattr(owner, name, value)
+                try:
+                    got = run()
+                finally:
+                    setattr(owner, name, old)
+                err = float((got - ref).abs().max()) / scale
+                assert err <= tol, (kind, owner.__name__, name, value, err)
+                assert float((got.argmax(1) == ref.argmax(1)).float().mean()) >= 0.9995
+    finally:
         ops.set_precision("f32")
 
 

@@ -1469,6 +1469,52 @@ def test_unet_chained_levels_equal_layer_by_layer_launches(cin, capacity, monkey
         ops.set_precision("f32")
 
 
+def test_interpolate_rows_backward_is_the_transpose_and_deterministic():
+    """ls3d_interpolate_rows_backward (the devoxelization's gradient for the voxel features in the training forward): equals torch's backward of
+    the gather composition, every voxel row written (also rows no point refers to), two ragged frames, bit-reproducible"""
+    rng = np.random.default_rng(0)
+    V0, V1, n0, n1, C = 90, 40, 170, 61, 8
+    feat = torch.randn(V0 + V1, C, requires_grad=True)
+    vx_off = torch.tensor([0, V0, V0 + V1], dtype=torch.int32)
+    pts = torch.cat([torch.cat([torch.zeros(n0), torch.ones(n1)])[:, None], torch.randn(n0 + n1, 3)], 1).contiguous()
+    idx = torch.from_numpy(np.concatenate([rng.integers(0, V0 - 10, size=(n0, 3)), rng.integers(0, V1, size=(n1, 3))]).astype(np.int32))
+    w = torch.rand(n0 + n1, 3)
+    out = ops.interpolate_rows_autograd(feat, idx, w, pts, vx_off)
+    g = torch.randn_like(out)
+    out.backward(g)
+    f2 = feat.detach().clone().requires_grad_(True)
+    v0 = vx_off[pts[:, 0].long()].unsqueeze(1)
+    ref = (f2[(idx + v0).long()] * w.unsqueeze(-1)).sum(1)
+    ref.backward(g)
+    assert float((out - ref).abs().max()) <= 1e-6 and float((feat.grad - f2.grad).abs().max()) <= 2e-6 * float(f2.grad.abs().max())
+    assert float(feat.grad[V0 - 10:V0].abs().max()) == 0.0  # rows nobody interpolates from: zero, not garbage
+    again = ops.interpolate_rows_backward(g, idx, w, pts, vx_off, V0 + V1)
+    assert torch.equal(again, feat.grad)
+    assert float(ops.interpolate_rows_backward(torch.empty((0, C)), torch.empty((0, 3), dtype=torch.int32), torch.empty((0, 3)), torch.empty((0, 4)),
+                                               vx_off, V0 + V1).abs().max()) == 0.0
+
+
+def test_linear_function_gradients_on_the_kernels():
+    """ops._LinearFn (what nn.Linear records under ops.fast_linear_backward on the device): grad_x on ls3d_gather_gemm with the [out, in] weight as
+    the [K][N] operand, grad_W on ls3d_spconv_wgrad over the identity pair lists of a row capacity (two row counts share one list), grad_b"""
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(48, 32)
+    for n in (700, 333):
+        x = torch.randn(n, 48).relu_().requires_grad_(True)
+        gy = torch.randn(n, 32) * 0.1
+        lin.zero_grad()
+        y = ops._LinearFn.apply(x, lin.weight, lin.bias)
+        y.backward(gy)
+        xr = x.detach().clone().requires_grad_(True)
+        lr = torch.nn.Linear(48, 32)
+        lr.load_state_dict(lin.state_dict())
+        lr(xr).backward(gy)
+        assert float((x.grad - xr.grad).abs().max()) <= 2e-6 * float(xr.grad.abs().max())
+        assert float((lin.weight.grad - lr.weight.grad).abs().max()) <= 2e-6 * float(lr.weight.grad.abs().max())
+        assert float((lin.bias.grad - lr.bias.grad).abs().max()) <= 2e-6 * float(lr.bias.grad.abs().max())
+    assert len(ops._IDENTITY_PAIRS) == 1  # one identity list for both row counts
+
+
 def test_frozen_batchnorm_and_eval_mode_input_gradients_keep_the_graph():
     """with BatchNorm frozen (bn.eval() inside a model in train mode) the epilogue-fused launches must not cut the
     graph: every convolution on the path still gets its weight gradient; in eval mode an input that requires grad gets one, and
