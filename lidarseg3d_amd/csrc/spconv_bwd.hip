@@ -490,7 +490,7 @@ extern "C" int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_o
   }
   if (!in || !grad_out || !tbl || !grad_w || !workspace || kvol < 1 || cin < 1 || cout < 1 || n_rows < 0) return LS3D_ERR_ARG;
   if (in_ld < cin || go_ld < cout) return LS3D_ERR_ARG;
-  if (products != 0 && products != 6 && products != 8) return LS3D_ERR_ARG;
+  if ((products & 63) != 0 && (products & 63) != 6 && (products & 63) != 8) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_spconv_wgrad_workspace_bytes(kvol, cin, cout, n_rows)) return LS3D_ERR_WORKSPACE;
   // the pair lists go behind the partial sums of the same workspace
   const int cw_max = cout < 128 ? cout : 128;
@@ -534,14 +534,17 @@ extern "C" int ls3d_spconv_wgrad_on_pairs(const float *in, int in_ld, const floa
   }
   if (!in || !grad_out || !pairs || !grad_w || !workspace || kvol < 1 || cin < 1 || cout < 1 || n_rows < 0) return LS3D_ERR_ARG;
   if (in_ld < cin || go_ld < cout) return LS3D_ERR_ARG;
-  if (products != 0 && products != 6 && products != 8) return LS3D_ERR_ARG;
+  if ((products & 63) != 0 && (products & 63) != 6 && (products & 63) != 8) return LS3D_ERR_ARG;
   const int cw_max = cout < 128 ? cout : 128;
   if (workspace_bytes < wg_align((size_t)wg_chunks(n_rows, kvol, cin) * kvol * cin * cw_max * sizeof(float))) return LS3D_ERR_WORKSPACE;
   return wg_on_pairs(in, in_ld, grad_out, go_ld, pairs, kvol, cin, cout, n_rows, products, workspace, grad_w, stream);
 }
 
+constexpr int wg_plane_min_blocks = 8;  // 32 x 32 output blocks per staged row group from which the plane kernel wins (products bit 6 forces it: A/B)
 static int wg_on_pairs(const float *in, int in_ld, const float *grad_out, int go_ld, const void *pairs, int kvol, int cin, int cout, int n_rows,
                        int products, void *workspace, float *grad_w, hipStream_t stream) {
+  const bool force_planes = (products & 64) != 0;
+  products &= 63;
   const int nchunks = wg_chunks(n_rows, kvol, cin);
   float *partial = (float *)workspace;
   const int cout_all = cout;
@@ -569,7 +572,7 @@ static int wg_on_pairs(const float *in, int in_ld, const float *grad_out, int go
   // against 1.84 ms; 32 -> 32 1.75 ms against 0.20 ms: one block leaves three waves idle behind the same staging cost) - narrower
   // layers keep the exact-f32 kernel, which is f32-grade by construction
   const int nblk = ((cin < 128 ? cin : 128) + 31) / 32 * cob;
-  if (products != 0 && nblk < 8) products = 0;
+  if (products != 0 && nblk < wg_plane_min_blocks && !force_planes) products = 0;
   if (products == 0) {
     if (cob == 1) LS3D_WG(1);
     else if (cob == 2) LS3D_WG(2);

@@ -915,6 +915,12 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        cout, cin = weight.shape
+        if _LINEAR_DGRAD and cin % 16 == 0 and cout % 4 == 0 and cout <= 256 and (x.is_cuda or _SIM) and x.is_contiguous():
+            # y = x W^T + b on the dense exact-f32 gather-GEMM as well (hipBLASLt: ~6 ms of a Waymo step in 32-row macro tiles for these shapes)
+            from .packing import PackedWeight
+            wt = weight.detach().t().contiguous().reshape(1, cin, cout)
+            return gather_gemm(x.detach(), PackedWeight(wt, 1, cin, cin, cout), cout=cout, shift=bias.detach().contiguous() if bias is not None else None)
         return torch.nn.functional.linear(x, weight, bias) if _ORIG_LINEAR is None else _ORIG_LINEAR(x, weight, bias)
 
     @staticmethod

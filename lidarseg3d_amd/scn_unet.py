@@ -589,7 +589,7 @@ class UNetSCN3D(nn.Module):
             sh = osh
         if self._caps is None:
             self._caps = {}
-        seen = self._caps.get((n_in_cap, batch_size))
+        seen = self._caps.get((n_in_cap, batch_size, len(worst)))  # (the chain has one more rulebook when conv_out is computed eagerly)
         if seen is None:
             return worst
         return [min(w, max(4096, -(-int(1.3 * m) // 4096) * 4096)) for w, m in zip(worst, seen)]
@@ -655,10 +655,10 @@ class UNetSCN3D(nn.Module):
                 if host is None or host.shape != cnts.shape:
                     host = self.__dict__["_pinned_counts"] = torch.empty(cnts.shape, dtype=cnts.dtype, pin_memory=True)
                 host.copy_(cnts, non_blocking=True)
-                batch_dict["geometry_record"] = (host, gs.finish_event(), (vc.shape[0], batch_size))
+                batch_dict["geometry_record"] = (host, gs.finish_event(), (vc.shape[0], batch_size, len(chain)))
                 gs.keep(cnts)
             else:
-                batch_dict["geometry_record"] = (cnts, None, (vc.shape[0], batch_size))
+                batch_dict["geometry_record"] = (cnts, None, (vc.shape[0], batch_size, len(chain)))
             counts_copied = gs.finish_event()
         level_ready = []
         with _GeometryStream(x.indices, ready, join=False, index=0) as gs:

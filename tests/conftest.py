@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on a GPU box)")
+    config.addinivalue_line("markers", "gpu_slow: the largest variants of a gpu test (A/B-only parametrisations, second full-size oracle forwards): "
+                                       "skipped unless LS3D_GPU_SLOW=1, so that `pytest -m gpu` stays well inside the driver's time limit")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("LS3D_GPU_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="gpu_slow variant: LS3D_GPU_SLOW=1 python -m pytest tests -m gpu runs it")
+    for item in items:
+        if "gpu_slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

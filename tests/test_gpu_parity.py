@@ -421,16 +421,11 @@ def test_sdseg3d_120k_frame_logits_and_miou_vs_oracle():
     cfg = synth.NUSC
     model, sd = _model(models_cfg.sdseg3d())
     frame = synth.lidar_frame(120000, seed=100, **cfg)  # the frame bench.py times on rank 0
-    want = orc.sdseg3d_forward(sd, [frame], cfg["voxel_size"], cfg["pc_range"])
-    last_w = max(k for k in sd if k.startswith("point_head.out_cls_layers.") and k.endswith(".weight") and sd[k].dim() == 2)
-    factor = 10.0 / float(want["out_logits"].abs().max())
-    sd10 = _scale_logits(sd, last_w, last_w[:-6] + "bias", factor)
-    model.load_state_dict(sd10)
-    # the last layer is linear: rescaling it rescales the oracle's logits exactly up to one f32 rounding; evaluate it again anyway
+    pts = cu(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1))
+    sd10 = _at_logit_scale_10(model, sd, dict(points=pts, batch_size=1))  # the logit range from one GPU forward: ONE 120k oracle forward (~40 s)
     want = orc.sdseg3d_forward(sd10, [frame], cfg["voxel_size"], cfg["pc_range"])
     ref = want["out_logits"]
     assert ref.shape == (120000, 17) and 9.0 <= float(ref.abs().max()) <= 11.0
-    pts = cu(np.concatenate([np.zeros((frame.shape[0], 1), np.float32), frame], 1))
     v, c, n, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 5, 300000, batched=True)
     V = int(nv)
     assert V == want["coordinates"].shape[0]
@@ -599,7 +594,7 @@ def test_frame_graph_of_a_batch_of_frames_equals_eager_forward(kind):
         ops.set_precision("f32")
 
 
-@pytest.mark.parametrize("n", [30000, 120000])
+@pytest.mark.parametrize("n", [30000, pytest.param(120000, marks=pytest.mark.gpu_slow)])
 def test_bf16_mode_tolerance_vs_oracle(n):
     """BASELINE configs[4]'s arithmetic (at 30k points and at the 120k points the configuration names): ops.set_precision("bf16") - SubM layers with plain bf16 operands (one MFMA per product, f32
     accumulation), strided / inverse layers on the bf16x3 gather-GEMM - and, for MSeg3D, fp8 (e4m3) operands in the SF-Phase
@@ -623,11 +618,11 @@ def test_bf16_mode_tolerance_vs_oracle(n):
         else:
             fwd = lambda s_: orc.sdseg3d_forward(s_, [frame], cfg["voxel_size"], cfg["pc_range"])["out_logits"]
             last_w = max(k for k in sd if k.startswith("point_head.out_cls_layers.") and k.endswith(".weight") and sd[k].dim() == 2)
-        want = fwd(sd)
-        sd10 = _scale_logits(sd, last_w, last_w[:-6] + "bias", 10.0 / float(want.abs().max()))
-        model.load_state_dict(sd10)
-        want = fwd(sd10)
         pts = cu(np.concatenate([np.zeros((n, 1), np.float32), frame], 1))
+        ops.set_precision("bf16x6")
+        sd10 = _at_logit_scale_10(model, sd, dict(points=pts, batch_size=1, **extra))  # the logit range from one GPU forward: ONE oracle forward
+        want = fwd(sd10)
+        assert 9.0 <= float(want.abs().max()) <= 11.0
         try:
             for prec, att in (("bf16x6", "f32"), ("bf16", "fp8" if kind == "mseg3d" else "f32")):
                 ops.set_precision(prec)
@@ -789,12 +784,13 @@ def test_semantickitti_config_end_to_end():
     model, sd = _model(models_cfg.sdseg3d(num_class=20, cp=4, pc_range=cfg["pc_range"], voxel_size=cfg["voxel_size"]), seed=3)
     frames = [synth.lidar_frame(30000, seed=31, **cfg)]
     pts = np.concatenate([np.zeros((30000, 1), np.float32), frames[0]], 1)
-    model(dict(points=cu(pts), batch_size=1), return_loss=False)
+    ex = dict(points=cu(pts), batch_size=1)
+    sd = _at_logit_scale_10(model, sd, ex)
+    model(dict(ex), return_loss=False)
     got = model.point_head.forward_ret_dict["out_logits"].cpu()
     want = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])
-    assert got.shape == (30000, 20)
-    scale = float(want["out_logits"].abs().max())
-    assert float((got - want["out_logits"]).abs().max()) <= 1e-3 + 2e-5 * scale
+    assert got.shape == (30000, 20) and 9.0 <= float(want["out_logits"].abs().max()) <= 11.0
+    assert float((got - want["out_logits"]).abs().max()) <= 1e-3  # absolute, at |logit|max 10
     assert float((got.argmax(1) == want["out_logits"].argmax(1)).float().mean()) >= 0.999
 
 
@@ -807,15 +803,16 @@ def test_semantickitti_config_at_5cm_voxels_end_to_end():
     model, sd = _model(models_cfg.sdseg3d(num_class=20, cp=4, pc_range=cfg["pc_range"], voxel_size=cfg["voxel_size"]), seed=3)
     frames = [synth.lidar_frame(5000, seed=33, **cfg), synth.lidar_frame(2500, seed=34, **cfg)]
     pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    sd = _at_logit_scale_10(model, sd, dict(points=cu(pts), batch_size=2))
     want = orc.sdseg3d_forward(sd, frames, cfg["voxel_size"], cfg["pc_range"])
-    scale = float(want["out_logits"].abs().max())
+    assert 9.0 <= float(want["out_logits"].abs().max()) <= 11.0
     try:
         for prec in ("f32", "bf16x6"):
             ops.set_precision(prec)
             model(dict(points=cu(pts), batch_size=2), return_loss=False)
             got = model.point_head.forward_ret_dict["out_logits"].cpu()
             assert got.shape == (7500, 20)
-            assert float((got - want["out_logits"]).abs().max()) <= 1e-3 + 2e-5 * scale, prec
+            assert float((got - want["out_logits"]).abs().max()) <= 1e-3, prec  # absolute, at |logit|max 10
             assert float((got.argmax(1) == want["out_logits"].argmax(1)).float().mean()) >= 0.999
     finally:
         ops.set_precision("f32")
@@ -853,14 +850,14 @@ def test_waymo_config_mseg3d_end_to_end():
     frames = [synth.lidar_frame(18000, seed=41, **cfg), synth.lidar_frame(9000, seed=42, **cfg)]
     pts = np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
     img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=6, ncam=5, c_img=48, h=40, w=60, num_class=23, batch=2)
-    model(dict(points=cu(pts), batch_size=2, points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb)),
-          return_loss=False)
+    ex = dict(points=cu(pts), batch_size=2, points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
+    sd = _at_logit_scale_10(model, sd, ex)
+    model(dict(ex), return_loss=False)
     got = model.point_head.forward_ret_dict["out_logits"].cpu()
     want = orc.mseg3d_forward(sd, frames, torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), cfg["voxel_size"],
                               cfg["pc_range"])
-    assert got.shape == (27000, 23)
-    scale = float(want["out_logits"].abs().max())
-    assert float((got - want["out_logits"]).abs().max()) <= 1e-3 + 2e-5 * scale
+    assert got.shape == (27000, 23) and 9.0 <= float(want["out_logits"].abs().max()) <= 11.0
+    assert float((got - want["out_logits"]).abs().max()) <= 1e-3  # absolute, at |logit|max 10
     assert float((got.argmax(1) == want["out_logits"].argmax(1)).float().mean()) >= 0.999
 
 
@@ -995,7 +992,7 @@ def test_linear_layer_backward_on_the_hip_kernels_gpu(cin, cout, other_n):
         assert float((y.detach().double() - (xd @ wd.t() + bd)).abs().max()) <= 3e-6 * float(y.abs().max())
         gx, gw, gb = gd @ wd, gd.t() @ xd, gd.sum(0)
         assert float((x.grad.double() - gx).abs().max()) <= 3e-6 * float(gx.abs().max())
-        assert float((lin.weight.grad.double() - gw).abs().max()) <= 3e-6 * float(gw.abs().max())
+        assert float((lin.weight.grad.double() - gw).abs().max()) <= 1e-5 * float(gw.abs().max())  # f32 sums over 7e4 .. 3.6e5 rows
         assert float((lin.bias.grad.double() - gb).abs().max()) <= 3e-5 * float(gb.abs().max())
 
 
@@ -1640,6 +1637,19 @@ def _f64_sdseg3d(sd, frame, cfg):
     return orc._mlp_cls(sd64, p + "out_cls_layers.", pf), feat
 
 
+def _at_logit_scale_10(model, sd, ex):
+    """rescales the last classifier layer of `model` (and of the returned state_dict, for the oracle) so that |logit|max ~ 10 on this input - the
+    scale at which the north_star's "within 1e-3" is an ABSOLUTE statement (random-init logits reach several thousand); the range is taken from
+    one GPU forward, so the oracle runs once"""
+    with torch.no_grad():
+        model(dict(ex), return_loss=False)
+    m = float(model.point_head.forward_ret_dict["out_logits"].abs().max())
+    last_w = max(k for k in sd if k.startswith("point_head.out_cls_layers") and k.endswith("weight") and sd[k].dim() == 2)
+    sd10 = _scale_logits(sd, last_w, last_w[:-6] + "bias", 10.0 / m)
+    model.load_state_dict(sd10)
+    return sd10
+
+
 def _scale_logits(sd, key_w, key_b, factor):
     sd = dict(sd)
     sd[key_w] = sd[key_w] * factor
@@ -1696,7 +1706,7 @@ def test_sdseg3d_every_arithmetic_vs_float64_and_absolute_tolerance():
         assert rec[prec]["max_abs_vs_f64"] <= 1.1 * rec["f32"]["max_abs_vs_f64"], rec
 
 
-@pytest.mark.parametrize("seed,n", [(5, 30000), (7, 60000), (21, 45000)])
+@pytest.mark.parametrize("seed,n", [(5, 30000), pytest.param(7, 60000, marks=pytest.mark.gpu_slow), (21, 45000)])
 def test_three_plane_modes_are_f32_grade_on_other_frames(seed, n):
     """the f32-grade claim of bench.py's `value` arithmetic on more frames (unscaled random-init logits, errors relative to |logit|max):
     rms error against the float64 evaluation <= the exact-f32 MFMA path's, max error <= 1.1x"""
@@ -1725,19 +1735,19 @@ def test_three_plane_modes_are_f32_grade_on_other_frames(seed, n):
 
 
 def test_mseg3d_absolute_tolerance_at_logit_scale_10():
-    """MSeg3D (GF-/SF-Phase head) end to end, |logit|max ~ 10: max-abs <= 1e-3 against the CPU oracle in every f32-grade mode"""
+    """BASELINE configs[2] at the size it names - MSeg3D (GF-/SF-Phase head) end to end on 60 000 points with the camera feature maps
+    [1, 6, 48, 160, 240] (k_nchw_to_nhwc / k_grid_gather at the shipped size), |logit|max ~ 10: max-abs <= 1e-3 ABSOLUTE against the CPU oracle
+    in every f32-grade mode, argmax agreement >= 99.9 %"""
     cfg = synth.NUSC
     model, sd = _model(models_cfg.mseg3d())
-    n = 19000
+    n = 60000
     frame = synth.lidar_frame(n, seed=14, **cfg)
-    img, emb, cuv = synth.camera_inputs(n, seed=5, ncam=6, c_img=48, h=40, w=60)
-    ref = orc.mseg3d_forward(sd, [frame], torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), cfg["voxel_size"], cfg["pc_range"])
-    last_w = max(k for k in sd if k.startswith("point_head.out_cls_layers.") and k.endswith(".weight") and sd[k].dim() == 2)
-    sd10 = _scale_logits(sd, last_w, last_w[:-6] + "bias", 10.0 / float(ref["out_logits"].abs().max()))
-    model.load_state_dict(sd10)
+    img, emb, cuv = synth.camera_inputs(n, seed=5, ncam=6, c_img=48, h=160, w=240)
+    assert img.shape == (1, 6, 48, 160, 240)
+    pts = cu(np.concatenate([np.zeros((n, 1), np.float32), frame], 1))
+    sd10 = _at_logit_scale_10(model, sd, dict(points=pts, batch_size=1, points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb)))
     ref = orc.mseg3d_forward(sd10, [frame], torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), cfg["voxel_size"], cfg["pc_range"])
     assert 9.0 <= float(ref["out_logits"].abs().max()) <= 11.0
-    pts = cu(np.concatenate([np.zeros((n, 1), np.float32), frame], 1))
     try:
         for prec in ("f32", "bf16x8", "bf16x6"):
             ops.set_precision(prec)
@@ -1746,6 +1756,7 @@ def test_mseg3d_absolute_tolerance_at_logit_scale_10():
             got = model.point_head.forward_ret_dict["out_logits"].cpu()
             err = float((got - ref["out_logits"]).abs().max())
             assert err <= 1e-3, (prec, err)
+            assert float((got.argmax(1) == ref["out_logits"].argmax(1)).float().mean()) >= 0.999, prec
     finally:
         ops.set_precision("f32")
 
@@ -1871,9 +1882,9 @@ def test_every_schedule_switch_of_the_host_layer_keeps_the_logits(monkeypatch):
     """the A/B switches the host layer still reads from the environment (DESIGN.md 4.7 lists them) change WHEN and WHERE kernels run, or which of
     two equivalent kernels runs - never the result beyond the stated tolerance: each one toggled against the default on a 60k-point frame in the
     bf16x6 arithmetic, SDSeg3D and MSeg3D.  Bit-identical: stream overlap off, lateral stream off, lean start off, coordinate-class row orders
-    off, mask orders for every strided table, another workgroup geometry target, the tile kernel's dispatch / swizzle / split flags, the chained
-    launches everywhere.  Within tolerance (another summation order or arithmetic): the 6-product gather-GEMM off (exact f32 for the strided
-    layers), the reader's plane GEMMs off, the fused SF-Phase decoder / memory side off."""
+    off, mask orders for every strided table, another workgroup geometry target, the tile kernel's LDS swizzle off, the chained launches
+    everywhere.  Within tolerance (another summation order or arithmetic): the tile kernel's split over the input channels off / forced (two
+    partial sums added at the end), the 6-product gather-GEMM off (exact f32 for the strided layers), the reader's plane GEMMs off, the fused SF-Phase decoder / memory side off."""
     from lidarseg3d_amd import detectors, spconv as sp
     cfg = synth.NUSC
     frame = synth.lidar_frame(60000, seed=21, **cfg)
@@ -1882,7 +1893,7 @@ def test_every_schedule_switch_of_the_host_layer_keeps_the_logits(monkeypatch):
     cam = dict(points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
     # (owner, attribute, value, relative tolerance: 0 = bit-identical)
     switches = [(sn, "_LATERAL", False, 0), (detectors, "_LEAN_START", False, 0), (ops, "_PARITY_ORDER", False, 0), (sp, "ORDER_MIN_CC", 0, 0),
-                (ops, "_TARGET_BLOCKS", 256, 0), (ops, "_TILE_FLAGS", (1 << 30) | (1 << 6), 0), (ops, "_TILE_FLAGS", 2 << 6, 2e-6),
+                (ops, "_TARGET_BLOCKS", 512, 0), (ops, "_TILE_FLAGS", 1 << 30, 0), (ops, "_TILE_FLAGS", 1 << 6, 2e-6), (ops, "_TILE_FLAGS", 2 << 6, 2e-6),
                 (ops, "_CHAIN_MIN_TILES", 1, 0), (ops, "_GATHER_X6", False, 2e-5), (ops, "_TRANSVFE_PLANES", False, 2e-5),
                 (point_heads, "_FUSED_SFFM", False, 2e-5), (point_heads, "_FUSED_SFFM_MEMORY", False, 2e-5), (point_heads, "_HEAD_OVERLAP", False, 0)]
     try:
