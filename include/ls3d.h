@@ -412,7 +412,7 @@ int ls3d_tile_conv_chain(const void *plan, int n_rows, int kvol, const ls3d_tile
  *             columns of grad_out over one transposed table).
  * Deterministic (fixed summation order).  products: 0 = exact f32 MFMA (two rows per v_mfma_f32_32x32x2_f32); 6 | 8 = the exact 3-plane
  * bf16 split of both operands (16 rows per v_mfma_f32_32x32x16_bf16, operands transposed through LDS, head x head in its own accumulator):
- * f32-grade like ls3d_tile_conv; used for layers with >= 8 output blocks of 32 x 32, narrower ones run the exact-f32 kernel either way. */
+ * f32-grade like ls3d_tile_conv; used for layers with >= 4 output blocks of 32 x 32 (64 -> 64 and wider), narrower ones run the exact-f32 kernel either way. */
 size_t ls3d_spconv_wgrad_workspace_bytes(int kvol, int cin, int cout, int n_rows);
 int ls3d_spconv_wgrad(const float *in, int in_ld, const float *grad_out, int grad_out_ld, const int32_t *tbl, const int32_t *row_order,
                       int kvol, int cin, int cout, int n_rows, const int32_t *n_rows_dev, int products, void *workspace,

@@ -540,7 +540,10 @@ extern "C" int ls3d_spconv_wgrad_on_pairs(const float *in, int in_ld, const floa
   return wg_on_pairs(in, in_ld, grad_out, go_ld, pairs, kvol, cin, cout, n_rows, products, workspace, grad_w, stream);
 }
 
-constexpr int wg_plane_min_blocks = 8;  // 32 x 32 output blocks per staged row group from which the plane kernel wins (products bit 6 forces it: A/B)
+// 32 x 32 output blocks per staged row group from which the plane kernel wins (products bit 6 forces it: A/B).  tools/probe_wgrad_sparse.py on
+// the tables of a 2 x 180k Waymo batch: 64 -> 64 (4 blocks, 5.8 M pairs) exact f32 1.04 ms, planes 0.90 ms; 32 -> 32 (1 block) 0.10 vs 0.22 ms;
+// 128 -> 128 (16 blocks) 1.88 vs 0.96 ms.  (Round 3 set the limit to 8 from the two outer points.)
+constexpr int wg_plane_min_blocks = 4;
 static int wg_on_pairs(const float *in, int in_ld, const float *grad_out, int go_ld, const void *pairs, int kvol, int cin, int cout, int n_rows,
                        int products, void *workspace, float *grad_w, hipStream_t stream) {
   const bool force_planes = (products & 64) != 0;

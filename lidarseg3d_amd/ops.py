@@ -838,7 +838,7 @@ def spconv_pairs(tbl, order=None):
 def spconv_wgrad(x, grad_out, tbl, order, cin, cout, products=None, pairs=None):
     """grad_w[kvol, cin, cout] of a sparse convolution: x = the forward input features (rows indexed by tbl), grad_out on the
     forward output rows, tbl/order = the table and row order of the forward launch.  products: 0 = exact-f32 MFMA kernel, 6 / 8 = the exact
-    3-plane bf16 split (f32-grade; the library uses it for layers with >= 8 output blocks of 32 x 32 and the exact-f32 kernel below that);
+    3-plane bf16 split (f32-grade; the library uses it for layers with >= 4 output blocks of 32 x 32 and the exact-f32 kernel below that);
     None = ops.set_precision's product count (0 in "f32" / "bf16x3").  pairs = spconv_pairs(tbl, order)
     when several layers share the table (same result, the lists are not rebuilt)."""
     n, kvol = tbl.shape

@@ -470,7 +470,7 @@ def test_tile_kernel_offset_loop_waits_for_nothing_but_its_weight_dma():
                               stderr=subprocess.DEVNULL)
         asm = open(out).read()
     for nt, per_offset in ((4, 24), (2, 12)):
-        name = "_Z11k_tile_convILi%dELi6ELb0ELi1E" % nt
+        name = "_Z11k_tile_convILi%dELi6ELb0ELi1ELb0EE" % nt
         start = asm.index("\n" + name)
         body = asm[start:asm.index("s_endpgm", start)]
         parts = re.split(r"^(\.LBB\d+_\d+):.*$", body, flags=re.M)
@@ -492,6 +492,61 @@ def test_tile_kernel_offset_loop_waits_for_nothing_but_its_weight_dma():
             assert len(dma) == 3 and min(dma) > bars[0], (name, label, dma)  # three 1 KB blocks per wave and step, into the buffer just released
             assert not any(o.startswith(("global_load_dword", "buffer_load", "flat_load")) for o in ops), (name, label)
         assert with_barrier >= 1 and mfmas % per_offset == 0, (name, with_barrier, mfmas)
+
+
+def test_gather_x6_memory_side_and_point_tail_kernels_keep_their_loops_clean():
+    """the disassembly checks covered the tile, weight-gradient and single-wave kernels only.  What hipcc emits for gfx950 for the rest
+    of the inference hot path: k_gather_gemm_x6<1 | 2 | 4> (the strided / inverse layers: gathered rows two stages ahead) - the basic blocks that
+    issue MFMAs touch no scratch and never drain the memory pipeline (`s_waitcnt vmcnt(0)`), what spills there is (<= 64 bytes per lane in the
+    narrow variants, whose launch bounds ask for 3 - 4 workgroups per CU) sits in the per-tile prologue / epilogue; k_sffm_memory and
+    k_point_mlp use no scratch at all; the chained build of the tile kernel keeps the offset loop of the plain one (no scratch, no global loads
+    between two step barriers)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    from lidarseg3d_amd import build as B
+    usage, asm = {}, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for src in ("spconv.hip", "sffm_memory.hip", "pointmlp.hip", "tileconv.hip"):
+            out = os.path.join(tmp, src + ".s")
+            r = subprocess.run([hipcc] + B.CFLAGS + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", os.path.join(B.CSRC, src), "-o", out],
+                               cwd=tmp, stderr=subprocess.PIPE, text=True, check=True)
+            name = None
+            for ln in r.stderr.splitlines():
+                m = re.search(r"Function Name: (\S+)", ln)
+                if m:
+                    name = m.group(1)
+                m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", ln)
+                if m and name:
+                    usage[name] = int(m.group(1))
+            asm[src] = open(out).read()
+    assert usage["_Z13k_sffm_memoryPKfii8SmParamsPfS2_"] == 0
+    assert [v for k, v in usage.items() if k.startswith("_Z11k_point_mlp")] == [0]
+    x6 = {k: v for k, v in usage.items() if k.startswith("_Z16k_gather_gemm_x6")}
+    assert len(x6) == 3 and x6[[k for k in x6 if "ILi4EE" in k][0]] == 0 and max(x6.values()) <= 64, x6
+
+    def mfma_blocks(text, name):
+        start = text.index("\n" + name)
+        body = text[start:text.index("s_endpgm", start)]
+        parts = re.split(r"^(\.LBB\d+_\d+):.*$", body, flags=re.M)
+        for label, blk in zip(parts[1::2], parts[2::2]):
+            ops = [ln.strip() for ln in blk.splitlines() if ln.strip() and not ln.strip().startswith((";", "."))]
+            if any("v_mfma" in o for o in ops):
+                yield label, ops
+    for nt in (1, 2, 4):
+        blocks = list(mfma_blocks(asm["spconv.hip"], "_Z16k_gather_gemm_x6ILi%dEE" % nt))
+        assert blocks
+        for label, ops in blocks:
+            assert not any("scratch_" in o for o in ops), (nt, label)
+            assert not any(o.startswith("s_waitcnt") and "vmcnt(0)" in o for o in ops), (nt, label)
+    for nt in (2, 4):  # the chained build (CH = true) of the pipelined tile kernel
+        blocks = list(mfma_blocks(asm["tileconv.hip"], "_Z11k_tile_convILi%dELi6ELb0ELi1ELb1EE" % nt))
+        assert blocks
+        for label, ops in blocks:
+            assert not any("scratch_" in o for o in ops), (nt, label)
+            if not any(o.startswith("s_barrier") for o in ops):
+                assert not any(o.startswith("s_waitcnt") and "vmcnt" in o for o in ops), (nt, label)
+            assert not any(o.startswith(("global_load_dword", "buffer_load", "flat_load")) for o in ops), (nt, label)
 
 
 def test_single_wave_kernels_keep_their_registers_and_their_blocks():
