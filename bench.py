@@ -1169,9 +1169,13 @@ def main():
                 j = json.load(open(PMC_RECORD))
                 r = j.get(args.precision)
                 if r:
-                    out["roofline"]["traffic"] = r["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = os.path.relpath(PMC_RECORD, ROOT) + ": (2*FETCH_SIZE+WRITE_SIZE)*1024 per sparse-conv launch, corrected per MI355X_MICROARCH.md; kernels " + ", ".join(r.get("kernels", []))
-                    out["roofline"]["hbm_physical_GBps"] = r["traffic_bytes_per_launch"] * c["launches"] / (mean_ms * 1e-3) / 1e9 if mean_ms else None
+                    # the counters are per KERNEL launch (a chained launch runs several layers); per frame = x kernel launches, and per LAYER
+                    # (the unit of `achieved`'s algorithmic bytes) = the frame's bytes / layers
+                    frame_bytes = r["traffic_bytes_per_launch"] * c.get("kernel_launches", c["launches"])
+                    out["roofline"]["traffic"] = frame_bytes / max(c["launches"], 1)
+                    out["roofline"]["traffic_per_kernel_launch"] = r["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = os.path.relpath(PMC_RECORD, ROOT) + ": (2*FETCH_SIZE+WRITE_SIZE)*1024 per sparse-conv kernel launch, corrected per MI355X_MICROARCH.md, x kernel launches per frame / layers per frame; kernels " + ", ".join(r.get("kernels", []))
+                    out["roofline"]["hbm_physical_GBps"] = frame_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms else None
                     if r.get("mfma_busy") is not None:
                         out["roofline"]["mfma"]["mfma_busy"] = r["mfma_busy"]
                         out["roofline"]["mfma"]["mfma_busy_source"] = os.path.relpath(PMC_RECORD, ROOT).replace(".json", "_sq.md") + ": SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles, time-weighted over the stack's kernels"

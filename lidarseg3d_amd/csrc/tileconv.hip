@@ -966,7 +966,6 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
     if constexpr (TR) ++tr_steps;                                                                                    \
     if (BAR_) {                                                                                                      \
       if constexpr (TR) tr_mark = ls3d_cycles();                                                                     \
-      if constexpr (CH) { if (!(ablate & 2048)) LS3D_WAIT_VMCNT(0); } else /* (timing experiment: no wait) */        \
       LS3D_WAIT_VMCNT(0);                                                                                            \
       __syncthreads(); /* every wave: done reading this step's weights, its share of the next step's has landed */   \
       if constexpr (TR) tr_bar += (unsigned)(ls3d_cycles() - tr_mark);                                               \
@@ -1376,7 +1375,7 @@ extern "C" int ls3d_tile_conv_chain(const void *plan, int n_rows, int kvol, cons
   const TcChain ch = {dst, st, n_layers};
   // timing experiments, flags bits 1-3 (results are WRONG with bits 1 / 2): bit 1 no producer waits, bit 2 cached stores, bit 3 cost order;
   // bit 4 (16): no halo loads, bits 8 in ablate: no weight DMA (the kernel's own ablation bits)
-  const int ablate = ((flags & 14) << 7) | (flags & 16) | ((flags & 32) ? 8 : 0) | ((flags & 1) ? 2048 : 0);  // bit 0: no DMA wait at the step barriers
+  const int ablate = ((flags & 14) << 7) | (flags & 16) | ((flags & 32) ? 8 : 0);  // (round 5 also timed the loop without its DMA wait - bit 0, a branch inside the step: removed after the experiment)
   int rc = nt == 1 ? tc_launch_chain<1, 6, 0>(stream, p, swz, ablate, grid, (float *)workspace, (int *)counters, ch)
          : nt == 2 ? tc_launch_chain<2, 6, 1>(stream, p, swz, ablate, grid, (float *)workspace, (int *)counters, ch)
                    : tc_launch_chain<4, 6, 1>(stream, p, swz, ablate, grid, (float *)workspace, (int *)counters, ch);

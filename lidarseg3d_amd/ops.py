@@ -716,7 +716,7 @@ def collect_chain_states(on=True):
 # 32-channel units of level 1 last 10 - 17 us: 0.32 ms chained against 0.15 ms).  What it buys there is small (+0.5 - 1 % frames/s: fewer
 # launches; the conv stack itself does not get shorter): the tails the chain fills were not idle POWER - the chip is power-limited in these
 # layers, a workgroup alone on its CU runs 122 us per tile against 213 us for two sharing one, and filling the tails trades clock for occupancy.
-_CHAIN_ABLATE = int(_os.environ.get("LS3D_CHAIN_ABLATE", "0")) & 63  # timing experiments of the chained kernel (ls3d_tile_conv_chain flags bits 1-3)
+_CHAIN_ABLATE = int(_os.environ.get("LS3D_CHAIN_ABLATE", "0")) & 62  # timing experiments of the chained kernel (ls3d_tile_conv_chain flags bits 1-3)
 _CHAIN_MIN_TILES = int(_os.environ.get("LS3D_CHAIN_MIN_TILES", "600"))
 _CHAIN_MIN_COUT = int(_os.environ.get("LS3D_CHAIN_MIN_COUT", "64"))
 

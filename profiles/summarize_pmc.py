@@ -28,7 +28,7 @@ def main(d, rnd="4", commit=""):
     os.makedirs(here, exist_ok=True)
     out, lines = {}, ["# HBM-side traffic of the sparse-conv launches (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes)", "",
                       "`python bench.py --precision P --steps 3 --warmup 2 --no-cpu-baseline --no-extra-modes` (120k-pt SDSeg3D frame).  bytes = (2 x FETCH_SIZE +",
-                      "WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section).  Algorithmic pair-model bytes: 24.4 GB/frame = 659 MB/launch.", ""]
+                      "WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section).  Algorithmic pair-model bytes: 24.4 GB/frame = 659 MB per layer (37 layers; since round 5 the 12 SubM layers of levels 2 and 3 run inside two chained kernel launches: 27 kernel launches per frame).", ""]
     for prec in ("bf16x6", "bf16x8", "f32"):
         try:
             f, w = load(d, "pmc_FETCH_SIZE_" + prec, "FETCH_SIZE"), load(d, "pmc_WRITE_SIZE_" + prec, "WRITE_SIZE")

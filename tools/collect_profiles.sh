@@ -4,12 +4,12 @@
 # ON the box by profiles/summarize_pmc.py into gpurun_out/profiles_r$ROUND/ (the raw counter CSVs exceed gpurun's pull limit).  Copy that
 # directory's files into profiles/ afterwards.   usage: COMMIT=<sha> bash tools/collect_profiles.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-4}
+ROUND=${ROUND:-5}
 cd "$R"; mkdir -p gpurun_out/profiles_r$ROUND; OUT="$R/gpurun_out"; P3="$OUT/profiles_r$ROUND"
 export TMPDIR=/tmp
 RAW=/tmp/ls3d_prof; rm -rf $RAW; mkdir -p $RAW
 cd /tmp
-BENCH="python $R/bench.py --no-cpu-baseline --no-extra-modes"
+BENCH="python $R/bench.py --no-cpu-baseline --no-extra-modes --no-train-leg"
 for P in bf16x6 f32; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/prof_$P -o bench -- $BENCH --precision $P --steps 10 --warmup 3 > $P3/prof_$P.log 2>&1
   echo "rocprof stats $P rc=$?" >> $P3/summary.txt

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round-end record on the MI355X box (one gpurun call): profiles of HEAD (tools/collect_profiles.sh), kernel timeline of one frame, the
 # full bench line (reads the fresh PMC record), training-step timings, then the whole -m gpu suite with durations.
-ROUND=${ROUND:-4}; R=${GRAFT_REPO_ROOT:-/root/repo}
+ROUND=${ROUND:-5}; R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R"; OUT="$R/gpurun_out"; P3="$OUT/profiles_r$ROUND"; mkdir -p $P3
 export TMPDIR=/tmp
 COMMIT=${COMMIT:-unknown} bash tools/collect_profiles.sh > $P3/collect.log 2>&1
 cp $P3/round${ROUND}_pmc.json $P3/round${ROUND}_pmc.md $P3/round${ROUND}_pmc_sq.md profiles/ 2>/dev/null   # bench.py reads profiles/round${ROUND}_pmc.json
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_g -o bench -- python $R/bench.py --steps 5 --warmup 3 --no-extra-modes --no-cpu-baseline > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_e -o bench -- python $R/bench.py --steps 5 --warmup 3 --no-extra-modes --no-cpu-baseline --no-graph > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_g -o bench -- python $R/bench.py --steps 5 --warmup 3 --no-extra-modes --no-cpu-baseline --no-train-leg > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_e -o bench -- python $R/bench.py --steps 5 --warmup 3 --no-extra-modes --no-cpu-baseline --no-train-leg --no-graph > /dev/null 2>&1
 cd "$R"
 python tools/timeline.py $(find /tmp/tl_g -name bench_kernel_trace.csv | head -1) > $P3/round${ROUND}_timeline_graph.txt 2>&1
 python tools/timeline.py $(find /tmp/tl_e -name bench_kernel_trace.csv | head -1) > $P3/round${ROUND}_timeline_eager_final.txt 2>&1

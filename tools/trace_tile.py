@@ -80,6 +80,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0"); torch.cuda.set_device(0)
     ops.set_precision("bf16x6")
+    ops.set_tile_chain(False)  # every layer as its own launch (the chained launches of levels 2 / 3 would hide six layers in one call)
     model, _ = bench.build_model(dev)
     f = synth.lidar_frame(a.points, seed=100, **synth.NUSC)
     pts = torch.from_numpy(np.concatenate([np.zeros((f.shape[0], 1), np.float32), f], 1)).to(dev)
