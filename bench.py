@@ -132,7 +132,7 @@ class ConvCensus:
             bmin += (uniq[key] * cin + rows[key] * cout + tbl.shape[1] * cin * cout) * 4.0
         first = self.meta[0] if self.meta else None
         n_in = (int(first[4].item()) if first[4] is not None else first[0].shape[0]) if first else 0
-        chained_layers = sum(1 for m in self.meta if m[3] == "tile") - sum(1 for m in self.meta if m[3] == "tile1")
+        chained_layers = sum(1 for m in self.meta if m[3] == "tile")  # ("tile1": a layer launched on its own)
         for i, m in enumerate(self.meta):
             if m[3] == "tile1":
                 self.meta[i] = m[:3] + ("tile",) + m[4:]
@@ -785,6 +785,10 @@ def main():
         """one leg: W untimed + K timed steps; with one stream also the conv-stack event brackets of the timed steps"""
         ops.set_precision(prec)
         st = make_step(model, pts, extra, n_streams)
+        if n_streams == 1 and not SIM:
+            with torch.no_grad():  # two frames first: the census then sees the launches of the steady state (capacities learned, the chain policy of the
+                for _ in range(2):  # timed frames), not a first frame on worst-case capacities
+                    make_step(model, pts, extra, 1)()
         census = ConvCensus(ops).run(make_step(model, pts, extra, 1)) if (n_streams == 1 and not SIM) else None
         events = []
         scn_unet.UNetSCN3D.conv_stack_events = events if (n_streams == 1 and not SIM) else None

@@ -710,7 +710,8 @@ def test_linear_weight_gradient_on_the_wgrad_kernel(n, cin, cout):
     for t in (x, w, b):
         t.grad = None
     y = ops._LinearFn.apply(x, w, b)
-    assert torch.equal(y, torch.nn.functional.linear(x, w, b))
+    ref = torch.nn.functional.linear(x, w, b)  # (round 5: eligible shapes run the forward on the dense gather-GEMM too - another summation order)
+    assert float((y - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     (y * r).sum().backward()
     for g, t in zip(want, (x, w, b)):
         assert float((t.grad - g).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-6
