@@ -640,20 +640,28 @@ int ls3d_seg_loss_backward(const int32_t *labels, int n_points, int num_classes,
 
 /* BatchNorm1d over [n, c] rows in training mode (batch statistics) with the ReLU / residual add that follow it in the UNet fused in
  * (det3d/models/backbones/scn_unet.py:11-69; nn.BatchNorm1d semantics: biased variance for the normalisation), c % 4 == 0, c <= 256, 256 % (c / 4) == 0:
- *   ls3d_batch_norm_stats         : mean_m2[2 c] = per-column mean and sum of squared deviations of the n rows (one pass over x, per-block partials
- *                                   merged with Chan's update in block order: deterministic, no cancellation); workspace = ls3d_batch_norm_workspace_bytes;
+ *   ls3d_batch_norm_stats         : mean_m2[2 c + 1] = per-column mean and sum of squared deviations of the n rows, then n itself as a float (one pass
+ *                                   over x, per-block partials merged with Chan's update in a fixed-shape tree: deterministic, no cancellation);
+ *                                   workspace = ls3d_batch_norm_workspace_bytes;
+ *   ls3d_batch_norm_finalize      : parts[world][2 c + 1] (the triples of `world` ranks; world == 1 and local_n >= 0: parts[0 .. 2 c) with n = local_n)
+ *                                   -> mean[c], var[c] (biased), rstd[c] = 1 / sqrt(var + eps), count_out[1] = total rows, and - running_mean /
+ *                                   running_var != NULL - nn.BatchNorm's running update (momentum, unbiased variance; num_batches_tracked += 1 when given);
  *   ls3d_batch_norm_apply         : y = [relu]((x - mean) * rstd * gamma + beta [+ res]);
  *   ls3d_batch_norm_backward_sums : sums[2 c] = column sums of g and of g * xhat, g = dy * [y > 0] (y_or_null = NULL: g = dy) - exposed so that a
  *                                   data-parallel step can all-reduce them (lidarseg3d_amd/syncbn.py);
- *   ls3d_batch_norm_backward_apply: dx = gamma rstd (g - sums[0..c) * inv_count - xhat * sums[c..2c) * inv_count), dres = g (dres may be NULL). */
+ *   ls3d_batch_norm_backward_apply: dx = gamma rstd (g - sums[0..c) * inv_count - xhat * sums[c..2c) * inv_count), dres = g (dres may be NULL);
+ *                                   count_dev != NULL: inv_count = 1 / max(count_dev[0], 1) read on the device (ls3d_batch_norm_finalize's count_out). */
 size_t ls3d_batch_norm_workspace_bytes(int n, int c);
 int ls3d_batch_norm_stats(const float *x, int ld, int n, int c, void *workspace, size_t workspace_bytes, float *mean_m2, ls3d_stream_t stream);
+int ls3d_batch_norm_finalize(const float *parts, int world, int c, int local_n, float eps, float momentum, float *running_mean, float *running_var,
+                             int64_t *num_batches_tracked, float *mean, float *var, float *rstd, float *count_out, ls3d_stream_t stream);
 int ls3d_batch_norm_apply(const float *x, int ld, int n, int c, const float *mean, const float *rstd, const float *gamma, const float *beta,
                           const float *res, int res_ld, int relu, float *y, int y_ld, ls3d_stream_t stream);
 int ls3d_batch_norm_backward_sums(const float *x, int ld, const float *dy, const float *y_or_null, int n, int c, const float *mean, const float *rstd,
                                   void *workspace, size_t workspace_bytes, float *sums, ls3d_stream_t stream);
 int ls3d_batch_norm_backward_apply(const float *x, int ld, const float *dy, const float *y_or_null, int n, int c, const float *mean, const float *rstd,
-                                   const float *gamma, const float *sums, float inv_count, float *dx, float *dres, ls3d_stream_t stream);
+                                   const float *gamma, const float *sums, float inv_count, const float *count_dev, float *dx, float *dres,
+                                   ls3d_stream_t stream);
 
 /* Row LayerNorm over [n, c] (rows contiguous, c % 4 == 0, c <= 256), forward and backward, for the training step: the LayerNorms of the
  * reader (voxel_encoder.py:149-163) and of the SF-Phase decoder (context_module.py:319-376) over 10^5 - 10^6 token rows.

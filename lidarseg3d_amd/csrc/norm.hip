@@ -310,6 +310,37 @@ __global__ __launch_bounds__(256) void k_bn_stats_merge(const float *__restrict_
     out[col] = (float)mean;
     out[c + col] = (float)m2;
   }
+  if (blockIdx.x == 0 && tid == 0) out[2 * c] = (float)n;  // the (mean, M2, n) triple a data-parallel step gathers over the ranks
+}
+
+// The ranks' (mean, M2, n) triples -> the batch statistics of all rows, rstd, the total row count and nn.BatchNorm's running statistics, in
+// ONE launch (round 4 composed this from ~14 small torch kernels per layer - and two more for rstd, six for the running statistics: ~700 of
+// the ~1480 elementwise launches of a Waymo training step).  Chan's update over the ranks in rank order, in double: the same on every rank.
+__global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ parts, int world, int c, int local_n, float eps, float momentum,
+                                                     float *__restrict__ running_mean, float *__restrict__ running_var, long long *num_batches,
+                                                     float *__restrict__ mean_out, float *__restrict__ var_out, float *__restrict__ rstd_out, float *count_out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  const int stride = 2 * c + 1;
+  double mean = 0.0, m2 = 0.0, cnt = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const float *p = parts + (size_t)r * stride;
+    const double nb = (world == 1 && local_n >= 0) ? (double)local_n : (double)p[2 * c];
+    bn_chan_merge(mean, m2, cnt, (double)p[col], (double)p[c + col], nb);
+  }
+  const double tot = cnt > 1.0 ? cnt : 1.0;  // every rank empty: statistics 0 / eps, no NaN
+  const double var = m2 / tot;
+  mean_out[col] = (float)mean;
+  var_out[col] = (float)var;
+  rstd_out[col] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    running_mean[col] = (float)((1.0 - (double)momentum) * (double)running_mean[col] + (double)momentum * mean);
+    running_var[col] = (float)((1.0 - (double)momentum) * (double)running_var[col] + (double)momentum * var * (tot / (tot - 1.0 > 1.0 ? tot - 1.0 : 1.0)));
+  }
+  if (col == 0) {
+    count_out[0] = (float)tot;
+    if (num_batches) num_batches[0] += 1;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ x, int ld, int n, int c, const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -377,8 +408,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_part(const float *__restrict__ x
 // sums[2 c] = (sum g, sum g xhat) over all rows, ALREADY divided by nothing: dx = gamma rstd (g - sums[0] / N - xhat sums[1] / N); dres = g
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ x, int ld, const float *__restrict__ dy, const float *__restrict__ y, int n, int c,
                                                       const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
-                                                      const float *__restrict__ sums, float inv_count, float *__restrict__ dx, float *__restrict__ dres) {
+                                                      const float *__restrict__ sums, float inv_count_host, const float *count_dev, float *__restrict__ dx,
+                                                      float *__restrict__ dres) {
   const int c4 = c >> 2;
+  const float inv_count = count_dev ? 1.0f / fmaxf(count_dev[0], 1.0f) : inv_count_host;  // the total row count of all ranks stays on the device
   const long long work = (long long)n * c4;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
     const int r = (int)(t / c4), cg = (int)(t % c4);
@@ -408,12 +441,23 @@ extern "C" int ls3d_batch_norm_stats(const float *x, int ld, int n, int c, void 
   hipStream_t stream = (hipStream_t)stream_;
   if (!mean_m2 || n < 0 || c < 4 || (c & 3)) return LS3D_ERR_ARG;
   if (!bn_shape_ok(c)) return LS3D_ERR_UNSUPPORTED;
-  if (n == 0) return hipMemsetAsync(mean_m2, 0, 2 * c * sizeof(float), stream) == hipSuccess ? LS3D_OK : LS3D_ERR_LAUNCH;
+  if (n == 0) return hipMemsetAsync(mean_m2, 0, (2 * c + 1) * sizeof(float), stream) == hipSuccess ? LS3D_OK : LS3D_ERR_LAUNCH;
   if (!x || !workspace || ld < c || (ld & 3) || ((uintptr_t)x & 15) || ((uintptr_t)workspace & 15)) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_batch_norm_workspace_bytes(n, c)) return LS3D_ERR_WORKSPACE;
   const int nb = bn_blocks(n);
   hipLaunchKernelGGL(k_bn_stats_part, dim3(nb), dim3(256), 0, stream, x, ld, n, c, (float *)workspace);
   hipLaunchKernelGGL(k_bn_stats_merge, dim3((c + 7) / 8), dim3(256), 0, stream, (const float *)workspace, nb, n, c, mean_m2);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_batch_norm_finalize(const float *parts, int world, int c, int local_n, float eps, float momentum, float *running_mean,
+                                        float *running_var, int64_t *num_batches_tracked, float *mean, float *var, float *rstd, float *count_out,
+                                        ls3d_stream_t stream_) {
+  if (!parts || !mean || !var || !rstd || !count_out || world < 1 || c < 1) return LS3D_ERR_ARG;
+  if ((running_mean != nullptr) != (running_var != nullptr)) return LS3D_ERR_ARG;
+  hipLaunchKernelGGL(k_bn_finalize, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream_, parts, world, c, local_n, eps, momentum, running_mean, running_var,
+                     (long long *)num_batches_tracked, mean, var, rstd, count_out);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }
@@ -443,11 +487,12 @@ extern "C" int ls3d_batch_norm_backward_sums(const float *x, int ld, const float
 }
 
 extern "C" int ls3d_batch_norm_backward_apply(const float *x, int ld, const float *dy, const float *y_or_null, int n, int c, const float *mean, const float *rstd,
-                                              const float *gamma, const float *sums, float inv_count, float *dx, float *dres, ls3d_stream_t stream_) {
+                                              const float *gamma, const float *sums, float inv_count, const float *count_dev, float *dx, float *dres,
+                                              ls3d_stream_t stream_) {
   if (n == 0 && bn_shape_ok(c)) return LS3D_OK;
   if (!x || !dy || !mean || !rstd || !gamma || !sums || !dx || n < 0 || !bn_shape_ok(c) || ld < c || (ld & 3)) return LS3D_ERR_ARG;
   hipLaunchKernelGGL(k_bn_bwd_apply, ls3d_grid((long long)n * (c >> 2)), dim3(256), 0, (hipStream_t)stream_, x, ld, dy, y_or_null, n, c, mean, rstd, gamma, sums,
-                     inv_count, dx, dres);
+                     inv_count, count_dev, dx, dres);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

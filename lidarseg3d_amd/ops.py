@@ -1477,18 +1477,35 @@ def batch_norm_supported(x):
 
 
 def batch_norm_stats(x):
-    """-> [2 c]: per-column mean and sum of squared deviations over the rows of x (ls3d_batch_norm_stats)"""
+    """-> [2 c + 1]: per-column mean and sum of squared deviations over the rows of x, then the row count as a float (ls3d_batch_norm_stats): the
+    triple a data-parallel step gathers over its ranks"""
     n, c = x.shape
-    out = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+    out = torch.empty((2 * c + 1,), dtype=torch.float32, device=x.device)
     ws = _ws(_L().ls3d_batch_norm_workspace_bytes(n, c), x)
     check(_L().ls3d_batch_norm_stats(_vp_any(x), x.stride(0), n, c, _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(out), _stream(x)), "ls3d_batch_norm_stats")
     return out
 
 
+def batch_norm_finalize(parts, c, eps, bn=None):
+    """the ranks' triples parts [world, 2 c + 1] (or one [2 c + 1]) -> (mean [c], var [c] biased, rstd [c], count [1] on the device) in ONE launch, and
+    - bn given (an nn.BatchNorm1d with running statistics and a momentum) - its running_mean / running_var / num_batches_tracked update"""
+    world = parts.shape[0] if parts.dim() == 2 else 1
+    dev = parts.device
+    out = torch.empty((3 * c + 1,), dtype=torch.float32, device=dev)
+    mean, var, rstd, count = out[:c], out[c:2 * c], out[2 * c:3 * c], out[3 * c:]
+    rm = rv = nbt = None
+    mom = 0.0
+    if bn is not None:
+        rm, rv, nbt, mom = bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum)
+    check(_L().ls3d_batch_norm_finalize(_ptr(parts), world, c, -1, ctypes.c_float(eps), ctypes.c_float(mom), _ptr(rm), _ptr(rv), _ptr(nbt), _vp_any(mean), _vp_any(var),
+                                        _vp_any(rstd), _vp_any(count), _stream(parts)), "ls3d_batch_norm_finalize")
+    return mean, var, rstd, count
+
+
 def batch_norm_apply(x, mean, rstd, gamma, beta, res=None, relu=False):
     n, c = x.shape
     y = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    check(_L().ls3d_batch_norm_apply(_vp_any(x), x.stride(0), n, c, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _vp_any(res) if res is not None else None,
+    check(_L().ls3d_batch_norm_apply(_vp_any(x), x.stride(0), n, c, _vp_any(mean), _vp_any(rstd), _ptr(gamma), _ptr(beta), _vp_any(res) if res is not None else None,
                                      res.stride(0) if res is not None else 0, 1 if relu else 0, _ptr(y), c, _stream(x)), "ls3d_batch_norm_apply")
     return y
 
@@ -1497,55 +1514,52 @@ def batch_norm_backward_sums(x, dy, y, mean, rstd):
     n, c = x.shape
     sums = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
     ws = _ws(_L().ls3d_batch_norm_workspace_bytes(n, c), x)
-    check(_L().ls3d_batch_norm_backward_sums(_vp_any(x), x.stride(0), _ptr(dy), _vp(y), n, c, _ptr(mean), _ptr(rstd), _ptr(ws), ctypes.c_size_t(ws.numel()),
+    check(_L().ls3d_batch_norm_backward_sums(_vp_any(x), x.stride(0), _ptr(dy), _vp(y), n, c, _vp_any(mean), _vp_any(rstd), _ptr(ws), ctypes.c_size_t(ws.numel()),
                                              _ptr(sums), _stream(x)), "ls3d_batch_norm_backward_sums")
     return sums
 
 
 def batch_norm_backward_apply(x, dy, y, mean, rstd, gamma, sums, count, want_dres):
+    """count: a host number, or the device scalar of batch_norm_finalize (no host synchronisation)"""
     n, c = x.shape
     dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
     dres = torch.empty((n, c), dtype=torch.float32, device=x.device) if want_dres else None
-    check(_L().ls3d_batch_norm_backward_apply(_vp_any(x), x.stride(0), _ptr(dy), _vp(y), n, c, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(sums),
-                                              ctypes.c_float(1.0 / max(float(count), 1.0)), _ptr(dx), _vp(dres), _stream(x)), "ls3d_batch_norm_backward_apply")
+    on_dev = torch.is_tensor(count)
+    check(_L().ls3d_batch_norm_backward_apply(_vp_any(x), x.stride(0), _ptr(dy), _vp(y), n, c, _vp_any(mean), _vp_any(rstd), _ptr(gamma), _ptr(sums),
+                                              ctypes.c_float(0.0 if on_dev else 1.0 / max(float(count), 1.0)), _vp_any(count) if on_dev else None,
+                                              _ptr(dx), _vp(dres), _stream(x)), "ls3d_batch_norm_backward_apply")
     return dx, dres
 
 
 class _BatchNormTrainFn(torch.autograd.Function):
-    """[relu](BatchNorm1d(x) [+ res]) with batch statistics on ls3d_batch_norm_* (csrc/norm.hip).  `merge`: None, or a callable
-    (mean_m2 [2 c], n) -> (mean [c], var [c], count) that combines the ranks' statistics (syncbn.py) - its partner `reduce` all-reduces the
-    backward's two column sums.  Returns y and the statistics the module's running averages are updated with."""
+    """[relu](BatchNorm1d(x) [+ res]) with batch statistics on ls3d_batch_norm_* (csrc/norm.hip): statistics (2 launches), the merge of the ranks'
+    triples + rstd + running statistics (ONE launch, ls3d_batch_norm_finalize), apply.  `gather`: None, or a callable [2 c + 1] -> [world, 2 c + 1]
+    that all-gathers the ranks' (mean, M2, n) triples (syncbn.py) - its partner `reduce` all-reduces the backward's two column sums.  `bn`: the
+    module whose running statistics are updated in the same launch (None: no update).  Returns y and the batch statistics."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, eps, relu, merge, reduce):
+    def forward(ctx, x, weight, bias, res, eps, relu, gather, reduce, bn):
         n, c = x.shape
         st = batch_norm_stats(x)
-        if merge is None:
-            mean, var, count = st[:c], st[c:] / max(n, 1), float(n)
-        else:
-            mean, var, count = merge(st, n)
-        mean, var = mean.contiguous(), var.contiguous()
-        rstd = (1.0 / torch.sqrt(var.double() + eps)).float()
+        parts = st if gather is None else gather(st)
+        mean, var, rstd, count = batch_norm_finalize(parts, c, eps, bn)
         y = batch_norm_apply(x, mean, rstd, weight.detach().contiguous(), bias.detach().contiguous(), res, relu)
-        ctx.save_for_backward(x, y if relu else None, mean, rstd, weight)
-        ctx.count, ctx.reduce, ctx.has_res = count, reduce, res is not None and res.requires_grad
-        ctx.mark_non_differentiable(mean, var)
-        return y, mean, var
+        ctx.save_for_backward(x, y if relu else None, mean, rstd, weight, count)
+        ctx.reduce, ctx.has_res = reduce, res is not None and res.requires_grad
+        ctx.mark_non_differentiable(mean, var, count)
+        return y, mean, var, count
 
     @staticmethod
-    def backward(ctx, gy, _gm, _gv):
-        x, y, mean, rstd, weight = ctx.saved_tensors
+    def backward(ctx, gy, _gm, _gv, _gc):
+        x, y, mean, rstd, weight, count = ctx.saved_tensors
         c = x.shape[1]
         gy = gy.contiguous()
         sums = batch_norm_backward_sums(x, gy, y, mean, rstd)
-        gb, gw = sums[:c].clone(), sums[c:].clone()  # local sums: the parameter gradients (DDP averages them over the ranks)
+        gb, gw = sums[:c], sums[c:]  # local sums: the parameter gradients (DDP averages them over the ranks)
         if ctx.reduce is not None:
-            sums = ctx.reduce(sums)
-        count = ctx.count
-        if torch.is_tensor(count):  # SyncBN: the total row count of all ranks stays on the device (no host synchronisation per layer) - the sums are scaled here
-            sums, count = sums / count.clamp_min(1.0), 1.0
+            sums = ctx.reduce(sums)  # (a copy: gb / gw keep the local sums)
         dx, dres = batch_norm_backward_apply(x, gy, y, mean, rstd, weight.detach().contiguous(), sums, count, ctx.has_res)
-        return dx, gw, gb, dres, None, None, None, None
+        return dx, gw, gb, dres, None, None, None, None, None
 
 
 _BN_KERNELS = True
@@ -1560,21 +1574,19 @@ def batch_norm_train(bn, x, res=None, relu=False):
         return None
     if bn.weight.data_ptr() % 16 or bn.bias.data_ptr() % 16:  # the kernels read gamma / beta as float4 (flattened-parameter views may not be aligned)
         return None
-    merge = reduce = None
-    state = {"count": float(x.shape[0])}
+    gather = reduce = None
     sync = getattr(bn, "_ls3d_sync", None)
     if sync is not None:
-        merge, reduce = sync(state)  # (None, None) without an active process group
+        gather, reduce = sync()  # (None, None) without an active process group
     fuse_relu = relu and torch.relu is _TORCH_RELU  # an instrumented torch.relu (tests pin / count ReLU gates by patching it) still sees the ReLU
-    y, mean, var = _BatchNormTrainFn.apply(x, bn.weight, bn.bias, res, bn.eps, fuse_relu, merge, reduce)
+    in_kernel = bn.track_running_stats and bn.momentum is not None  # the running statistics in ls3d_batch_norm_finalize's launch
+    y, mean, var, count = _BatchNormTrainFn.apply(x, bn.weight, bn.bias, res, bn.eps, fuse_relu, gather, reduce, bn if in_kernel else None)
     if relu and not fuse_relu:
         y = torch.relu(y)
-    if bn.track_running_stats:
+    if bn.track_running_stats and not in_kernel:  # momentum None: the cumulative average needs the batch counter on the host
         with torch.no_grad():
             bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            n = state["count"]
+            m = 1.0 / float(bn.num_batches_tracked)
             bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            unbias = (n / (n - 1.0).clamp_min(1.0)) if torch.is_tensor(n) else (n / max(n - 1.0, 1.0))
-            bn.running_var.mul_(1 - m).add_(var * unbias, alpha=m)  # unbiased, as nn.BatchNorm does
+            bn.running_var.mul_(1 - m).add_(var * (count / (count - 1.0).clamp_min(1.0)), alpha=m)  # unbiased, as nn.BatchNorm does
     return y

@@ -60,31 +60,24 @@ class CountSyncBatchNorm1d(nn.BatchNorm1d):
         super().__init__(*a, **k)
         self.process_group = process_group
 
-    def _ls3d_sync(self, state):
-        """protocol of ops.batch_norm_train (the HIP BatchNorm kernels): -> (merge, reduce) closures that combine the ranks' statistics / the
-        backward's column sums, (None, None) without an active group.  merge stores the total row count in state["count"]."""
+    def _ls3d_sync(self):
+        """protocol of ops.batch_norm_train (the HIP BatchNorm kernels): -> (gather, reduce) closures - gather all-gathers the ranks' (mean, M2, n)
+        triples [2 c + 1] into [world, 2 c + 1] (merged, with rstd and the running statistics, by ONE ls3d_batch_norm_finalize launch), reduce
+        all-reduces a copy of the backward's column sums - or (None, None) without an active group"""
         group = self.process_group
         if not _active(group):
             return None, None
 
-        def merge(mean_m2, n):
-            c = mean_m2.numel() // 2
-            local = torch.cat([mean_m2, mean_m2.new_tensor([float(n)])])
+        def gather(local):
             parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
             dist.all_gather(parts, local, group=group)
-            allp = torch.stack(parts)
-            cnt = allp[:, -1:]
-            tot = cnt.sum().clamp_min(1.0)
-            mean = (allp[:, :c] * cnt).sum(0) / tot
-            var = (allp[:, c:2 * c] + cnt * (allp[:, :c] - mean) ** 2).sum(0) / tot
-            state["count"] = tot  # a device scalar: no host synchronisation per layer (ops._BatchNormTrainFn scales the backward's sums with it)
-            return mean, var, tot
+            return torch.stack(parts)
 
         def reduce(sums):
             sums = sums.clone()
             dist.all_reduce(sums, group=group)
             return sums
-        return merge, reduce
+        return gather, reduce
 
     def forward(self, x):
         if self.training and x.dim() == 2 and torch.is_grad_enabled():
