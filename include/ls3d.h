@@ -345,7 +345,12 @@ int ls3d_gather_gemm(const float *in, int in_ld, const int32_t *tbl, const int32
  *                    the step barriers / epilogue, steps) into the workspace behind the partial sums, at byte offset
  *                    ls3d_tile_conv_workspace_bytes(n_rows, cout): the workspace must then hold that many bytes +
  *                    ls3d_tile_conv_trace_bytes(n_rows) (records [unit][wave][16] uint32, unit = blockIdx; tools/trace_tile.py).
- *   ls3d_tile_build / ls3d_tile_plan flags: bit 0 = dispatch the tiles in plan (spatial) order instead of most expensive first. */
+ *   ls3d_tile_build / ls3d_tile_plan flags: bit 0 = dispatch the tiles in plan (spatial) order instead of most expensive first;
+ *                    bit 1 (ls3d_tile_plan on a 3x3x3 table whose input sites are its output sites - SubM; ignored otherwise): the
+ *                    COLOURED halo layout - a tile's rows are dealt by a linear colour of their coordinates (mod 16) to the lane groups
+ *                    of the kernel's LDS reads and its halo rows get LDS slots = colour (mod 16), so that the 16 rows a group gathers
+ *                    at any offset sit in different bank columns (csrc/tileconv.hip: tc_color) instead of the neighbour-mask order.
+ *                    Placement only: ls3d_tile_conv results are bit-identical with either layout. */
 int ls3d_tile_keys(const int32_t *coords /*[n,4] b,z,y,x*/, int n, const int32_t *n_dev, const int32_t shape_zyx_host[3], int batch,
                    uint32_t *keys, ls3d_stream_t stream);
 size_t ls3d_tile_plan_bytes(int n_rows, int kvol);

@@ -23,7 +23,7 @@
 constexpr int TC_TR = 128;     // output rows per tile (4 waves x 32)
 constexpr int TC_HCAP = 448;   // halo rows resident in LDS per pass
 constexpr int TC_KMAX = 32;    // kernel offsets per table (3x3x3 = 27)
-constexpr int TC_META = 8;     // ints per tile: halo size, tile offset mask, 4 wave offset masks, live rows, producer tiles (-1: more than TC_DEPCAP)
+constexpr int TC_META = 8;     // ints per tile: halo slots, tile offset mask, 4 wave offset masks, live rows, producer tiles (-1: more than TC_DEPCAP)
 constexpr int TC_DEPCAP = 32;  // producer tiles listed per tile (ls3d_tile_conv_chain)
 constexpr int TC_DEPHASH = 128;
 
@@ -82,12 +82,28 @@ extern "C" int ls3d_tile_keys(const int32_t *coords, int n, const int32_t *n_dev
 // ---------------------------------------------------------------------------------------------------------------
 // tile plan
 // ---------------------------------------------------------------------------------------------------------------
+// Coloured halo layout (ls3d_tile_plan flag bit 1, 3x3x3 SubM tables).  The convolution's A fragments are gathered from the LDS halo with
+// ds_read_b128: four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} of each half-wave), one LDS cycle per group when the 16 halo
+// rows sit in 16 different 16-byte columns of the 256-byte bank row, i.e. (with the kernel's half swizzle) when their LDS slots differ mod 16.
+// Neighbours of spatially ordered rows are NOT consecutive halo rows (9.1 cycles per read measured instead of 4).  With a LINEAR colour
+// f(z, y, x) = (a z + b y + c x) mod 16 the neighbour at offset d of a row of colour q has colour q + f(d): if the 16 rows of a lane group
+// have 16 different colours, so have their neighbours at every offset.  So: a halo row of colour q gets a slot = q (mod 16), the tile's 128 rows
+// are sorted by colour and dealt round-robin to the 8 lane groups (a colour with <= 8 rows never meets itself), an ABSENT neighbour reads the
+// zero row of the colour it would have had (16 zero rows), and (a, b, c) is the best of 16 candidates per tile (fewest rows beyond 8 per
+// colour; the candidates: greedy choice over the tiles of synthetic nuScenes / Waymo frames, levels 2 - 4).  Slots are holes where a colour
+// has fewer rows than the fullest one; a hole stages a duplicate of the tile's first halo row.  Placement only: any assignment is correct.
+constexpr unsigned long long TC_COL_Z = 0x2124281128828188ull, TC_COL_Y = 0x4C834294712C1741ull, TC_COL_X = 0x3B187349CE51AC1Cull;  // 16 x 4 bits each
+__device__ __forceinline__ int tc_color(int cand, int z, int y, int x) {
+  const int a = (int)((TC_COL_Z >> (4 * cand)) & 15ull), b = (int)((TC_COL_Y >> (4 * cand)) & 15ull), c = (int)((TC_COL_X >> (4 * cand)) & 15ull);
+  return (a * z + b * y + c * x) & 15;
+}
+
 struct TilePlan {
   int ntiles, kvol, hs;
-  int32_t *trow;    // [T][128]      output row of each tile slot (-1 = none), slots sorted by neighbour mask (densest first)
+  int32_t *trow;    // [T][128]      output row of each tile slot (-1 = none), slots sorted by neighbour mask (densest first) or dealt by colour
   int32_t *tmeta;   // [T][TC_META]
-  int32_t *thalo;   // [T][hs]       unique input rows of the tile, ascending
-  uint16_t *tloc;   // [T][kvol][128] position of tbl[row][k] in the tile's halo, 0xFFFF = no neighbour
+  int32_t *thalo;   // [T][hs]       input rows of the tile's halo slots: the unique rows ascending, or (coloured) by colour with duplicates in the holes
+  uint16_t *tloc;   // [T][kvol][128] position of tbl[row][k] in the tile's halo; >= 0xFFF0 = no neighbour (low 4 bits: the zero row to read)
   int32_t *torder;  // [T + 1]       dispatch order of the tiles: most expensive first (k_tile_order); torder[T] = number of LIVE tiles (tiles
                     //               with at least one row below the device row count)
   int32_t *rowtile; // [T * 128]     tile that holds output row r (inverse of the spatial order, / 128)
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(256) void k_tile_rowtile(const int32_t *__restrict_
 // order is arbitrary, the SET is not), the occupied slots are compacted and only that list (a few hundred rows) is sorted
 // (bitonic), so the halo list, and with it every local index, is the same on every run.
 __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ tbl, int n, const int32_t *n_dev, int kvol,
-                                                    const int32_t *__restrict__ sorder, TilePlan p) {
+                                                    const int32_t *__restrict__ sorder, const int32_t *__restrict__ coords, TilePlan p) {
   constexpr int NC = TC_KMAX * TC_TR;  // 4096 candidate slots
   constexpr int HS = 2 * NC;           // hash slots
   __shared__ int s_row[TC_TR], s_srow[TC_TR], s_rank[TC_TR];
@@ -141,8 +157,10 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
   __shared__ int s_hash[HS];
   __shared__ int s_uniq[NC];
   __shared__ int s_scan[2][256];
+  __shared__ int s_ch[16 * 16], s_exc[16], s_col[TC_TR], s_cw[4 * 16], s_run[16], s_cnt2[2];
   const int tid = threadIdx.x;
   const int N = ls3d_count(n, n_dev);
+  const bool colored = coords != nullptr && kvol == 27;  // the coloured layout (see tc_color)
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     __syncthreads();
     if (tid < TC_TR) {
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
       s_mask[tid] = 0u;
     }
     for (int i = tid; i < HS; i += 256) s_hash[i] = -1;
+    s_ch[tid] = 0;
     __syncthreads();
     // neighbour masks + hash-set insertion of every neighbour: two threads per slot.  The thread's <= 16 table entries are fetched with
     // unconditional loads first (clamped addresses, masked afterwards: one memory latency instead of one per entry - under a condition
@@ -184,15 +203,44 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
       }
       if (m) atomicOr(&s_mask[slot], m);
     }
+    int best = 0;  // the tile's colour candidate
+    if (colored) {  // colour histograms of the tile's rows under the 16 candidates (two threads per row, 8 candidates each)
+      const int row = s_row[slot];
+      int z = 0, y = 0, x = 0;
+      if (row >= 0) {
+        z = coords[4 * (size_t)row + 1]; y = coords[4 * (size_t)row + 2]; x = coords[4 * (size_t)row + 3];
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) atomicAdd(&s_ch[(part * 8 + c8) * 16 + tc_color(part * 8 + c8, z, y, x)], 1);
+      }
+      __syncthreads();
+      if (tid < 16) {
+        int e = 0;
+        for (int q = 0; q < 16; ++q) e += s_ch[tid * 16 + q] > 8 ? s_ch[tid * 16 + q] - 8 : 0;  // rows that must share a lane group with their colour
+        s_exc[tid] = e;
+      }
+      __syncthreads();
+      int be = s_exc[0];
+      for (int q = 1; q < 16; ++q)
+        if (s_exc[q] < be) { be = s_exc[q]; best = q; }
+      if (part == 0) s_col[slot] = row >= 0 ? tc_color(best, z, y, x) : 16;
+    }
     __syncthreads();
-    if (tid < TC_TR) {  // slots sorted by mask, densest first (ties keep the spatial order); empty slots go last
+    if (tid < TC_TR) {
       const unsigned mine = s_mask[tid];
       const bool live = s_row[tid] >= 0;
       int rank = 0;
-      for (int j = 0; j < TC_TR; ++j) {
-        const unsigned mj = s_mask[j];
-        const bool lj = s_row[j] >= 0;
-        rank += (lj && !live) || (lj == live && (mj > mine || (mj == mine && j < tid)));
+      if (!colored) {  // slots sorted by mask, densest first (ties keep the spatial order); empty slots go last
+        for (int j = 0; j < TC_TR; ++j) {
+          const unsigned mj = s_mask[j];
+          const bool lj = s_row[j] >= 0;
+          rank += (lj && !live) || (lj == live && (mj > mine || (mj == mine && j < tid)));
+        }
+      } else {  // sorted by colour (ties: spatial order; empty slots last), then dealt round-robin to the 8 ds_read_b128 lane groups
+        const int key = s_col[tid] * TC_TR + tid;
+        int r = 0;
+        for (int j = 0; j < TC_TR; ++j) r += (s_col[j] * TC_TR + j) < key;
+        const int g = r & 7, j = r >> 3;
+        rank = (g >> 1) * 32 + ((g & 1) ? (j < 8 ? j + 4 : j < 12 ? j + 8 : j + 16) : (j < 4 ? j : j < 8 ? j + 8 : j + 12));
       }
       s_srow[rank] = s_row[tid];
       s_smask[rank] = mine;
@@ -232,22 +280,81 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
         }
         __syncthreads();
       }
-    for (int i = tid; i < H; i += 256) p.thalo[(size_t)tile * p.hs + i] = s_uniq[i];
-    {  // local indices of the thread's own table entries (still in registers), written at the slot's position in the mask order
+    // Coloured tiles (one LDS pass): the halo entry of colour q that is the r-th of its colour (in ascending row order: ranks from wave
+    // ballots, no atomics on the placement) gets slot q + 16 r; entries beyond the window (a colour with more than TC_HCAP / 16 rows) take
+    // the free slots in order.  s_hash is dead since the compaction: s_slot = slot of entry i, s_inv = entry at slot s (-1: a hole).
+    const bool tcol = colored && H <= TC_HCAP;
+    int *const s_slot = s_hash, *const s_inv = s_hash + TC_HCAP;
+    int nslot = H;
+    if (tcol) {
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int i = tid; i < TC_HCAP; i += 256) s_inv[i] = -1;
+      if (tid < 16) s_run[tid] = 0;
+      if (tid < 2) s_cnt2[tid] = 0;
+      __syncthreads();
+      for (int base = 0; base < H; base += 256) {
+        const int i = base + tid;
+        int c = 16;
+        if (i < H) {
+          const int v = s_uniq[i];
+          c = v < n ? tc_color(best, coords[4 * (size_t)v + 1], coords[4 * (size_t)v + 2], coords[4 * (size_t)v + 3]) : 0;
+        }
+        int myrank = 0;
+        for (int q = 0; q < 16; ++q) {
+          const unsigned long long m = __ballot(c == q);
+          if (c == q) myrank = __popcll(m & ((1ull << lane) - 1ull));
+          if (lane == 0) s_cw[wave * 16 + q] = __popcll(m);
+        }
+        __syncthreads();
+        if (i < H) {
+          int r = s_run[c] + myrank;
+          for (int w = 0; w < wave; ++w) r += s_cw[w * 16 + c];
+          const int sl = c + 16 * r;
+          if (sl < TC_HCAP) {
+            s_slot[i] = sl;
+            s_inv[sl] = i;
+            atomicMax(&s_cnt2[0], sl + 1);
+          } else {
+            s_slot[i] = -1;
+            atomicAdd(&s_cnt2[1], 1);
+          }
+        }
+        __syncthreads();
+        if (tid < 16) s_run[tid] += s_cw[tid] + s_cw[16 + tid] + s_cw[32 + tid] + s_cw[48 + tid];
+        __syncthreads();
+      }
+      if (tid == 0 && s_cnt2[1] > 0) {
+        int sl = 0;
+        for (int i = 0; i < H; ++i)
+          if (s_slot[i] < 0) {
+            while (s_inv[sl] >= 0) ++sl;
+            s_slot[i] = sl;
+            s_inv[sl] = i;
+            if (sl + 1 > s_cnt2[0]) s_cnt2[0] = sl + 1;
+          }
+      }
+      __syncthreads();
+      nslot = s_cnt2[0];
+      for (int i = tid; i < nslot; i += 256) p.thalo[(size_t)tile * p.hs + i] = s_uniq[s_inv[i] >= 0 ? s_inv[i] : 0];
+    } else {
+      for (int i = tid; i < H; i += 256) p.thalo[(size_t)tile * p.hs + i] = s_uniq[i];
+    }
+    {  // local indices of the thread's own table entries (still in registers), written at the slot's position in the mask / colour order
       const int s2 = s_rank[slot];
 #pragma unroll
       for (int i = 0; i < KPT; ++i) {
         const int k = part + 2 * i;
         if (k < kvol) {
           const int v = vals[i];
-          unsigned li = 0xFFFFu;
+          // no neighbour: 0xFFF0 | the colour it would have had (the kernel reads the zero row of that colour; 0xFFFF where there are no colours)
+          unsigned li = tcol ? (0xFFF0u | (unsigned)((s_col[slot] + tc_color(best, k / 9 - 1, (k / 3) % 3 - 1, k % 3 - 1)) & 15)) : 0xFFFFu;
           if (v >= 0) {
             int lo = 0, hi = H;  // lower bound of v in s_uniq (it is present)
             while (lo < hi) {
               const int mid = (lo + hi) >> 1;
               if (s_uniq[mid] < v) lo = mid + 1; else hi = mid;
             }
-            li = (unsigned)lo;
+            li = (unsigned)(tcol ? s_slot[lo] : lo);
           }
           p.tloc[((size_t)tile * kvol + k) * TC_TR + s2] = (uint16_t)li;
         }
@@ -286,7 +393,7 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
     if (tid < TC_TR) p.trow[(size_t)tile * TC_TR + tid] = s_srow[tid];
     if (tid < 8) {
       int v = 0;
-      if (tid == 0) v = H;
+      if (tid == 0) v = nslot;
       else if (tid == 1) { unsigned m = 0u; for (int s2 = 0; s2 < TC_TR; ++s2) m |= s_smask[s2]; v = (int)m; }
       else if (tid < 6) { unsigned m = 0u; for (int s2 = 0; s2 < 32; ++s2) m |= s_smask[(tid - 2) * 32 + s2]; v = (int)m; }
       else if (tid == 6) { int c2 = 0; for (int s2 = 0; s2 < TC_TR; ++s2) c2 += s_srow[s2] >= 0; v = c2; }
@@ -368,7 +475,7 @@ extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_
   TilePlan p = tc_plan(plan, n_rows, kvol);
   hipLaunchKernelGGL(k_tile_rowtile, ls3d_grid(n_rows), dim3(256), 0, (hipStream_t)stream, spatial_order, n_rows, n_rows_dev, p.rowtile);
   hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, (hipStream_t)stream, tbl, n_rows, n_rows_dev,
-                     kvol, spatial_order, p);
+                     kvol, spatial_order, (const int32_t *)nullptr, p);
   hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, (flags & 1) ? 0 : 1);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
@@ -406,7 +513,7 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
   TilePlan p = tc_plan(plan, n_rows, kvol);
   hipLaunchKernelGGL(k_tile_rowtile, ls3d_grid(n_rows), dim3(256), 0, stream, (const int32_t *)order, n_rows, n_rows_dev, p.rowtile);
   hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, stream, tbl, n_rows, n_rows_dev, kvol,
-                     (const int32_t *)order, p);
+                     (const int32_t *)order, (flags & 2) ? coords : (const int32_t *)nullptr, p);
   hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, p, (flags & 1) ? 0 : 1);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
@@ -490,7 +597,7 @@ extern "C" int ls3d_tile_conv_pack_bf16(const float *w_plain, int kvol, int cin_
 // ---------------------------------------------------------------------------------------------------------------
 // the convolution
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int TC_PLANE_BYTES = (TC_HCAP + 1) * 32;             // one bf16 plane of the halo chunk: [row][16 channels], + the zero row
+constexpr int TC_PLANE_BYTES = (TC_HCAP + 16) * 32;            // one bf16 plane of the halo chunk: [row][16 channels], + 16 zero rows (one per colour)
 constexpr int TC_HALO_BYTES = ((3 * TC_PLANE_BYTES + 255) / 256) * 256;
 constexpr int TC_WBUF_UNITS = 768;                             // 16-byte units of one step's weight pieces (12 KB)
 constexpr int TC_LOC_BYTES = TC_KMAX * TC_TR * 2;
@@ -790,7 +897,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
       const uint4 *src = (const uint4 *)(p.tloc + (size_t)tile * kvol * TC_TR);
       for (int i = tid; i < kvol * (TC_TR / 8); i += TC_THREADS) ((uint4 *)s_loc)[i] = src[i];
     }
-    if (tid < 24) ((unsigned *)(smem + (tid >> 3) * TC_PLANE_BYTES + TC_HCAP * 32))[tid & 7] = 0u;  // the zero row of each plane
+    for (int i = tid; i < 3 * 128; i += TC_THREADS) ((unsigned *)(smem + (i >> 7) * TC_PLANE_BYTES + TC_HCAP * 32))[i & 127] = 0u;  // the 16 zero rows of each plane
     f32x16 acc[NT], acs[NT];  // head x head products / everything else (see the MFMA block)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -917,8 +1024,8 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
   }
 #define TC_HALO_PTR(raw_, dst_)                                                                        \
   {                                                                                                    \
-    const int li_ = (raw_) - seg_lo;                                                                   \
-    const int lz_ = ((unsigned)li_ < (unsigned)TC_HCAP) ? li_ : TC_HCAP; /* absent / other pass -> the zero row */ \
+    const int rw_ = (raw_), li_ = rw_ - seg_lo;                                                        \
+    const int lz_ = ((unsigned)li_ < (unsigned)TC_HCAP) ? li_ : TC_HCAP + (rw_ & 15); /* absent / other pass -> a zero row (its colour: tc_color) */ \
     dst_ = (const uint4 *)smem + lz_ * 2 + (kk ^ ((lz_ >> 3) & swz));                                  \
   }
 #define TC_MFMA(dst_, a_, b_)                                                                         \
@@ -1031,7 +1138,7 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
             const int k = ks[g];
             if (k >= 0 && ((wmask >> k) & 1u) && !(ablate & 4)) {
               const int li = lc[g] - seg_lo;
-              const int lz = ((unsigned)li < (unsigned)TC_HCAP) ? li : TC_HCAP;  // absent / other pass -> the zero row
+              const int lz = ((unsigned)li < (unsigned)TC_HCAP) ? li : TC_HCAP + (lc[g] & 15);  // absent / other pass -> a zero row
               const uint4 *hp = (const uint4 *)smem + lz * 2 + (kk ^ ((lz >> 3) & swz));
               const uint4 *bs = Bs + buf * TC_WBUF_UNITS + g * PU + lane;
               // weight fragments plane by plane (the MFMAs are grouped by the weight plane they need): plane 2 is read after plane

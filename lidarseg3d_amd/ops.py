@@ -626,9 +626,16 @@ def tile_keys(coords, shape_zyx, batch, n_dev=None):
     return keys
 
 
-def tile_plan(tbl, coords, shape_zyx, batch, order=None, n_dev=None):
+# 0: neighbour-mask slot order everywhere (default: the coloured layout removes 70 % of the tile kernel's LDS bank conflicts and changes neither its
+# cycles nor its time - profiles/round5_experiments.md 1b - while its plan costs 18 us more per level); 1: coloured halo layout where the caller
+# asks for it (the >= 64-channel levels); 2: on every 3x3x3 SubM table
+_TILE_COLOR = int(_os.environ.get("LS3D_TILE_COLOR", "0"))
+
+
+def tile_plan(tbl, coords, shape_zyx, batch, order=None, n_dev=None, color=False):
     """plan for table tbl[n, kvol] whose output sites are coords[n, 4] (b, z, y, x).  `order`: a precomputed spatial row
-    order (int32 permutation); default = stable sort of ls3d_tile_keys (torch.sort: plumbing)."""
+    order (int32 permutation); default = stable sort of ls3d_tile_keys (torch.sort: plumbing).  color: the coloured halo layout
+    (include/ls3d.h: ls3d_tile_plan flag bit 1; SubM 3x3x3 tables), honoured when _TILE_COLOR >= 1."""
     n, kvol = tbl.shape
     L = _L()
     p = TilePlan()
@@ -637,7 +644,8 @@ def tile_plan(tbl, coords, shape_zyx, batch, order=None, n_dev=None):
     if order is None:  # keys -> in-library radix sort -> plan: one C call (ls3d_tile_plan)
         ws = _ws(L.ls3d_tile_plan_workspace_bytes(n), tbl)
         check(L.ls3d_tile_plan(_ptr(tbl), _ptr(coords), n, _ndev(n_dev), kvol, _i3(shape_zyx), int(batch), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(p.buf),
-                               ctypes.c_size_t(p.buf.numel()), _TILE_PLAN_FLAGS, _stream(tbl)), "ls3d_tile_plan")
+                               ctypes.c_size_t(p.buf.numel()), _TILE_PLAN_FLAGS | (2 if (_TILE_COLOR == 2 or (color and _TILE_COLOR == 1)) else 0), _stream(tbl)),
+              "ls3d_tile_plan")
         p.order = None  # the spatial order lives in the call's workspace and is not needed once the plan is built
         return p
     p.order = order

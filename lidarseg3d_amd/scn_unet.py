@@ -180,7 +180,7 @@ class _Chain(object):
         layers = self._chain_layers()
         recs, self.recs = self.recs, []
         if layers is not None:
-            plan = self.rb.tile_plan(False)
+            plan = self.rb.tile_plan(False, layers[0].cout)
             done = 0
             while done < len(layers):
                 part = layers[done:done + ops.TILE_CHAIN_MAX]

@@ -76,15 +76,17 @@ class _Rulebook(object):
         """device count of the rows of the (inverse) table = the output rows of a launch on it (None: the table has no spare rows)"""
         return getattr(self, "n_in_dev", None) if inverse else getattr(self, "n_out_dev", None)
 
-    def tile_plan(self, inverse):
-        """tile-halo plan (ops.tile_plan) of the (inverse) table, built once per rulebook"""
+    def tile_plan(self, inverse, width=0):
+        """tile-halo plan (ops.tile_plan) of the (inverse) table, built once per rulebook.  width: output channels of the layer that asks first -
+        with ops._TILE_COLOR = 1 the SubM tables of the >= 64-channel levels get the coloured halo layout (ops.tile_plan; the 16 / 32-channel
+        level keeps the neighbour-mask order, whose per-wave offset skipping is worth more there)"""
         if getattr(self, "_plans", None) is None:
             self._plans = {}
         if inverse not in self._plans:
             tbl = self.tbl_inv if inverse else self.tbl
             sites, shape = (self.in_indices, self.in_shape) if inverse else (self.out_indices, self.out_shape)
             self._plans[inverse] = ops.tile_plan(tbl, sites[:tbl.shape[0]], shape, getattr(self, "batch_size", None) or 256,
-                                                 n_dev=self.rows_dev(inverse))
+                                                 n_dev=self.rows_dev(inverse), color=(self.kind == "subm" and not inverse and width >= 64))
         return self._plans[inverse]
 
     def parity_geom(self, inverse):
@@ -142,7 +144,7 @@ class _SparseConvFn(torch.autograd.Function):
             x = torch.nn.functional.pad(x, (0, W.shape[1] - x.shape[1]))
         shift = None if bias is None else bias.detach()
         if subm and ops.use_tile("subm", tbl.shape[1], W.shape[1], cout):  # the f32-grade 3-plane modes: SubM layers on the tile-halo kernel
-            out = ops.tile_conv(x, W, rb.tile_plan(False), cout=cout, shift=shift)
+            out = ops.tile_conv(x, W, rb.tile_plan(False, cout), cout=cout, shift=shift)
         else:
             out = ops.gather_gemm(x, W, tbl=tbl, order=order, cout=cout, shift=shift)
         ctx.save_for_backward(feats, weight)
@@ -172,7 +174,7 @@ class _SparseConvFn(torch.autograd.Function):
             if g.shape[1] != Wd.shape[1]:
                 g = torch.nn.functional.pad(g, (0, Wd.shape[1] - g.shape[1]))
             if subm and ops.use_tile("subm", kvol, Wd.shape[1], cin):  # same table, same plan as the forward
-                gin = ops.tile_conv(g, Wd, rb.tile_plan(False), cout=cin)
+                gin = ops.tile_conv(g, Wd, rb.tile_plan(False, cin), cout=cin)
             else:
                 gin = ops.gather_gemm(g, Wd, tbl=tbl_t, order=order_t, cout=cin)
         if ctx.needs_input_grad[1]:
@@ -271,7 +273,7 @@ class SparseConvolution(PackedModule, SparseModule):
         if feats.shape[1] != W.shape[1]:  # e.g. 13 input channels feeding a 16-wide K chunk
             feats = torch.nn.functional.pad(feats, (0, W.shape[1] - feats.shape[1]))
         if ops.use_tile("inverse" if self.inverse else rb.kind, k, W.shape[1], cout) and tbl.shape[0] > 0:
-            return ops.tile_conv(feats.contiguous(), W, rb.tile_plan(bool(self.inverse)), cout=cout, scale=scale, shift=shift, relu=relu,
+            return ops.tile_conv(feats.contiguous(), W, rb.tile_plan(bool(self.inverse), cout), cout=cout, scale=scale, shift=shift, relu=relu,
                                  res_pre=res_pre, pair=pair, out=out, out_ld=out_ld)
         # mask-sorted processing order only for the layers whose matrix work can repay the sort (>= 64x64 channels) - or whose order exists / is cheap
         order = rb.order_for(bool(self.inverse), self.in_channels * self.out_channels)
@@ -316,7 +318,7 @@ def prebuild_orders(x, layers):
             continue
         if ops.use_tile("inverse" if m.inverse else rb.kind, (rb.tbl_inv if m.inverse else rb.tbl).shape[1], (m.in_channels + 15) // 16 * 16,
                         m.out_channels):
-            rb.tile_plan(bool(m.inverse))
+            rb.tile_plan(bool(m.inverse), m.out_channels)
             continue
         inv = bool(m.inverse)
         cheap = rb.parity_geom(inv) is not None

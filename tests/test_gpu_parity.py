@@ -1883,7 +1883,7 @@ def test_every_schedule_switch_of_the_host_layer_keeps_the_logits(monkeypatch):
     two equivalent kernels runs - never the result beyond the stated tolerance: each one toggled against the default on a 60k-point frame in the
     bf16x6 arithmetic, SDSeg3D and MSeg3D.  Bit-identical: stream overlap off, lateral stream off, lean start off, coordinate-class row orders
     off, mask orders for every strided table, another workgroup geometry target, the tile kernel's LDS swizzle off, the chained launches
-    everywhere.  Within tolerance (another summation order or arithmetic): the tile kernel's split over the input channels off / forced (two
+    everywhere, the coloured halo layout of the tile plans.  Within tolerance (another summation order or arithmetic): the tile kernel's split over the input channels off / forced (two
     partial sums added at the end), the 6-product gather-GEMM off (exact f32 for the strided layers), the reader's plane GEMMs off, the fused SF-Phase decoder / memory side off."""
     from lidarseg3d_amd import detectors, spconv as sp
     cfg = synth.NUSC
@@ -1894,7 +1894,7 @@ def test_every_schedule_switch_of_the_host_layer_keeps_the_logits(monkeypatch):
     # (owner, attribute, value, relative tolerance: 0 = bit-identical)
     switches = [(sn, "_LATERAL", False, 0), (detectors, "_LEAN_START", False, 0), (ops, "_PARITY_ORDER", False, 0), (sp, "ORDER_MIN_CC", 0, 0),
                 (ops, "_TARGET_BLOCKS", 512, 0), (ops, "_TILE_FLAGS", 1 << 30, 0), (ops, "_TILE_FLAGS", 1 << 6, 2e-6), (ops, "_TILE_FLAGS", 2 << 6, 2e-6),
-                (ops, "_CHAIN_MIN_TILES", 1, 0), (ops, "_GATHER_X6", False, 2e-5), (ops, "_TRANSVFE_PLANES", False, 2e-5),
+                (ops, "_CHAIN_MIN_TILES", 1, 0), (ops, "_TILE_COLOR", 2, 0), (ops, "_GATHER_X6", False, 2e-5), (ops, "_TRANSVFE_PLANES", False, 2e-5),
                 (point_heads, "_FUSED_SFFM", False, 2e-5), (point_heads, "_FUSED_SFFM_MEMORY", False, 2e-5), (point_heads, "_HEAD_OVERLAP", False, 0)]
     try:
         ops.set_precision("bf16x6")

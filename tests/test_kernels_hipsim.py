@@ -1044,6 +1044,81 @@ def test_tile_plan_structure_on_a_subm_rulebook():
     assert meta[:, 0].mean() < 3.0 * 128
 
 
+_B128_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+
+
+def _a_read_cycles(trow, meta, loc):
+    """mean LDS cycles of one gathered A-fragment ds_read_b128 of k_tile_conv on a plan (MI355X_MICROARCH.md, LDS: four groups of 16 lanes, one
+    cycle per group + one per extra distinct address on a busy 16-byte bank column; same address = broadcast).  Halo row l of the kernel's
+    [row][32 B] planes with swapped halves on odd (l >> 3): a lane group (one k half) reads column (2 l + half) mod 16; absent -> zero row 448 + (loc & 15)"""
+    tot = cnt = 0
+    for t in range(trow.shape[0]):
+        for w in range(4):
+            if not meta[t, 2 + w]:
+                continue
+            for k in range(loc.shape[1]):
+                if not (int(meta[t, 2 + w]) >> k) & 1:
+                    continue
+                raw = loc[t, k, 32 * w:32 * w + 32].astype(np.int64)
+                l = np.where(raw < 448, raw, 448 + (raw & 15))
+                for g in _B128_GROUPS:
+                    col = {}
+                    for lane in g:
+                        col.setdefault((2 * int(l[lane]) + ((int(l[lane]) >> 3) & 1)) % 16, set()).add(int(l[lane]))
+                    tot += 2 * max(len(v) for v in col.values())  # both k halves: the same rows, the other half-columns
+                cnt += 1
+    return tot / max(cnt, 1)
+
+
+def test_coloured_tile_plan_places_a_lane_groups_neighbours_in_different_bank_columns(monkeypatch):
+    """ls3d_tile_plan flag bit 1 on a level-3-like SubM table: the same tiles / halo sets / neighbour references as the mask-ordered plan, absent
+    neighbours marked >= 0xFFF0, bit-identical convolutions (both kernel loops), and the point of it: the gathered A reads of the kernel cost far
+    fewer LDS cycles (model of the ds_read_b128 groups)"""
+    monkeypatch.setattr(ops, "_TILE_COLOR", 1)
+    cfg = synth.NUSC
+    pts = synth.lidar_frame(30000, seed=5, **cfg)
+    v, c, n, nv = ops.voxelize_hard(torch.from_numpy(pts), cfg["voxel_size"], cfg["pc_range"], 5, 60000)
+    c = np.unique(c[:int(nv)].numpy() // np.array([4, 4, 4]), axis=0).astype(np.int32)
+    V = c.shape[0]
+    coords = torch.from_numpy(np.concatenate([np.zeros((V, 1), np.int32), c], 1)).contiguous()
+    shape = tuple(int(s) // 4 + 1 for s in orc.spatial_shape(cfg["voxel_size"], cfg["pc_range"]))
+    tbl = ops.rulebook_subm(coords, shape, (3, 3, 3))
+    tb = tbl.numpy()
+    plain = _plan_views(ops.tile_plan(tbl, coords, shape, 1))
+    plan = ops.tile_plan(tbl, coords, shape, 1, color=True)
+    trow, meta, halo, loc = _plan_views(plan)
+    assert trow.shape[0] >= 8
+    for t in range(trow.shape[0]):
+        rows = trow[t]
+        live = rows >= 0
+        assert sorted(rows[live].tolist()) == sorted(plain[0][t][plain[0][t] >= 0].tolist()) and meta[t, 6] == live.sum()
+        want_halo = np.unique(tb[rows[live]][tb[rows[live]] >= 0])
+        H = meta[t, 0]
+        assert want_halo.size <= H <= 448 and set(halo[t, :H].tolist()) == set(want_halo.tolist())  # holes repeat a halo row
+        masks = np.array([sum(1 << k for k in range(27) if tb[r, k] >= 0) if r >= 0 else 0 for r in rows])
+        assert meta[t, 1] == np.bitwise_or.reduce(masks) and meta[t, 1] == plain[1][t, 1]
+        for w in range(4):
+            assert meta[t, 2 + w] == np.bitwise_or.reduce(masks[32 * w:32 * w + 32])
+        used = {}
+        for s in np.nonzero(live)[0]:
+            for k in range(27):
+                nb = tb[rows[s], k]
+                if nb < 0:
+                    assert loc[t, k, s] >= 0xFFF0
+                else:
+                    assert loc[t, k, s] < H and halo[t, loc[t, k, s]] == nb
+                    assert used.setdefault(int(nb), int(loc[t, k, s])) == int(loc[t, k, s])  # one slot per halo row
+    assert np.array_equal(_plan_deps(plan)[0], _plan_deps(ops.tile_plan(tbl, coords, shape, 1))[0])
+    cyc_plain, cyc_col = _a_read_cycles(*plain[:2], plain[3]), _a_read_cycles(trow, meta, loc)
+    assert cyc_plain > 6.5 and cyc_col < 0.85 * cyc_plain and cyc_col < 6.0, (cyc_plain, cyc_col)
+    rng = np.random.default_rng(3)
+    for cin, cout in ((16, 32), (32, 64)):  # the plain offset loop (one column block) and the pipelined one
+        x = torch.from_numpy(rng.normal(size=(V, cin)).astype(np.float32))
+        pw = PackedWeight(torch.from_numpy(rng.normal(size=(27, cin, cout)).astype(np.float32) * 0.1), 27, cin, cin, cout)
+        a = ops.tile_conv(x, pw, ops.tile_plan(tbl, coords, shape, 1), cout=cout, products=6)
+        assert torch.equal(ops.tile_conv(x, pw, plan, cout=cout, products=6), a)
+
+
 def _plan_deps(plan):
     """(rowtile [T * 128], tdep [T, 32]) of an ops.TilePlan buffer (csrc/tileconv.hip:tc_plan)"""
     al = lambda v: (v + 255) // 256 * 256

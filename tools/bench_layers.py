@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--precision", default="bf16x6")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "layers.json"))
+    ap.add_argument("--zero-input", action="store_true", help="time every launch on an all-zero input matrix as well (same instructions, less switching: the power side of the clock)")
     a = ap.parse_args()
     dev = torch.device("cuda:0"); torch.cuda.set_device(0)
     ops.set_precision(a.precision)
@@ -64,12 +65,27 @@ def main():
             e1.record(); torch.cuda.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / a.reps
             total += us
+            us_zero = None
+            if a.zero_input:
+                keep = args[0].clone()
+                args[0].zero_()
+                for _ in range(2):
+                    fn(*args, **kw)
+                e0.record()
+                for _ in range(a.reps):
+                    fn(*args, **kw)
+                e1.record(); torch.cuda.synchronize()
+                us_zero = 1e3 * e0.elapsed_time(e1) / a.reps
+                args[0].copy_(keep)
             r = dict(launch=i, path=kind, rows=n, kvol=int(tbl.shape[1]), cin=cin, cout=cout, pairs=pairs, pairs_per_row=pairs / max(n, 1), us=us,
                      pair_model_GBps=pairs * (cin + cout) * 4.0 / us / 1e3, useful_TFLOPs=2.0 * pairs * cin * cout / us / 1e6,
                      fused=[k for k in ("scale", "res_pre", "pair", "relu") if kw.get(k) is not None and kw.get(k) is not False])
+            if us_zero is not None:
+                r["us_zero_input"] = us_zero
             rows_out.append(r)
             print("#%02d %-6s rows %6d kvol %2d %3d->%3d pairs/row %5.2f  %7.1f us  %6.0f GB/s (pair model)  %5.1f TF useful  %s"
-                  % (i, kind, n, r["kvol"], cin, cout, r["pairs_per_row"], us, r["pair_model_GBps"], r["useful_TFLOPs"], ",".join(r["fused"])), flush=True)
+                  % (i, kind, n, r["kvol"], cin, cout, r["pairs_per_row"], us, r["pair_model_GBps"], r["useful_TFLOPs"], ",".join(r["fused"]))
+                  + ("  zero input %7.1f us" % us_zero if us_zero is not None else ""), flush=True)
         print("sum of the %d launches, each alone on the GPU: %.1f us" % (len(rows_out), total))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(dict(precision=a.precision, points=a.points, reps=a.reps, total_us=total, launches=rows_out), open(a.out, "w"), indent=1)
