@@ -946,7 +946,7 @@ class _LinearFn(torch.autograd.Function):
             else:
                 gx = gy @ weight
         gw = linear_wgrad(x.detach().contiguous(), gy) if ctx.needs_input_grad[1] else None
-        gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gb = column_sums(gy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb
 
 
@@ -1491,6 +1491,45 @@ def batch_norm_stats(x):
     out = torch.empty((2 * c + 1,), dtype=torch.float32, device=x.device)
     ws = _ws(_L().ls3d_batch_norm_workspace_bytes(n, c), x)
     check(_L().ls3d_batch_norm_stats(_vp_any(x), x.stride(0), n, c, _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(out), _stream(x)), "ls3d_batch_norm_stats")
+    return out
+
+
+def token_attention_supported(q, k):
+    """shapes ls3d_token_attention_* take: q [n, H, 24] f32 rows on the device, k [H, 24, L] with L in {34, 38, 40, 46}"""
+    return ((q.is_cuda or _SIM) and q.dtype == torch.float32 and q.dim() == 3 and q.shape[2] == 24 and k.dim() == 3 and k.shape[2] in (34, 38, 40, 46)
+            and q.is_contiguous() and q.data_ptr() % 16 == 0)
+
+
+def token_attention_forward(q, k, v, scale):
+    """softmax(scale q_h K_h) V_h per point and head: q [n, H, hd], k / v [H, hd, L] -> [n, H, hd] (ls3d_token_attention_forward)"""
+    n, H, hd = q.shape
+    out = torch.empty_like(q)
+    check(_L().ls3d_token_attention_forward(_ptr(q), n, H, hd, _ptr(k.contiguous()), _ptr(v.contiguous()), k.shape[2], ctypes.c_float(scale), _ptr(out),
+                                            _stream(q)), "ls3d_token_attention_forward")
+    return out
+
+
+def token_attention_backward(q, dout, k, v, scale):
+    """-> (dq [n, H, hd], ds [n, H * L], att [n, H * L]) of token_attention_forward, the probabilities recomputed from q"""
+    n, H, hd = q.shape
+    L = k.shape[2]
+    dq = torch.empty_like(q)
+    ds = torch.empty((n, H * L), dtype=torch.float32, device=q.device)
+    att = torch.empty((n, H * L), dtype=torch.float32, device=q.device)
+    check(_L().ls3d_token_attention_backward(_ptr(q), _ptr(dout), n, H, hd, _ptr(k.contiguous()), _ptr(v.contiguous()), L, ctypes.c_float(scale), _ptr(dq),
+                                             _ptr(ds), _ptr(att), _stream(q)), "ls3d_token_attention_backward")
+    return dq, ds, att
+
+
+def column_sums(x):
+    """x[n, c].sum(0) on ls3d_column_sums (deterministic row blocks + fixed tree), or torch's reduction where the shape is not covered"""
+    n, c = x.shape
+    if not ((x.is_cuda or _SIM) and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and c % 4 == 0 and 4 <= c <= 256
+            and x.data_ptr() % 16 == 0 and n >= 4096):
+        return x.sum(0)
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _ws(_L().ls3d_column_sums_workspace_bytes(n, c), x)
+    check(_L().ls3d_column_sums(_vp_any(x), x.stride(0), n, c, _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(out), _stream(x)), "ls3d_column_sums")
     return out
 
 

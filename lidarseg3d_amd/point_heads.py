@@ -477,32 +477,44 @@ class SemanticFeatureFusionModule(PackedModule):
 
 
 class _TokenAttention(torch.autograd.Function):
-    """softmax(q k / sqrt(hd)) v of n points against L class tokens per head (context_module.py:222-257) with the token-side gradients on
-    ls3d_spconv_wgrad: d k and d v reduce 10^5 points into hd x L matrices per head - torch hands that to hipBLASLt as [H, hd, n] x [H, n, L]
-    batched GEMMs with 32 x 32 macro tiles (0.58 + 0.40 ms per frame and layer, 11.7 ms of a Waymo step); here one tall-skinny reduction over
-    all heads' columns at once (ops.linear_wgrad), from which the H diagonal blocks are taken"""
+    """softmax(q k / sqrt(hd)) v of n points against L class tokens per head (context_module.py:222-257) on csrc/tokenattn.hip: one thread per
+    (point, head) with its scores in registers, nothing kept from the forward (the backward recomputes the probabilities from q); the token-side
+    gradients d k and d v reduce 10^5 points into hd x L matrices per head - one tall-skinny reduction over all heads' columns at once
+    (ops.linear_wgrad, from which the H diagonal blocks are taken).  torch ran this as batched GEMMs with 32 x 32 macro tiles plus six passes over
+    [n, H, L] tensors: 1.2 ms per frame and layer, 14 ms of a Waymo step.  Shapes the kernels do not take (ops.token_attention_supported) run
+    the same algebra on torch."""
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
+        q = q.contiguous()
+        ctx.fused = ops.token_attention_supported(q, k)
+        ctx.scale = scale
+        if ctx.fused:
+            ctx.save_for_backward(q, k, v)
+            return ops.token_attention_forward(q, k, v, scale)
         att = torch.softmax(torch.einsum("nhd,hdl->nhl", q, k) * scale, dim=-1)
         ctx.save_for_backward(q, k, v, att)
-        ctx.scale = scale
         return torch.einsum("nhl,hdl->nhd", att, v)
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, att = ctx.saved_tensors
+        q, k, v = ctx.saved_tensors[:3]
         n, H, hd = q.shape
         L = k.shape[2]
         dout = dout.contiguous()
-        datt = torch.einsum("nhd,hdl->nhl", dout, v)
-        ds = att * (datt - (datt * att).sum(-1, keepdim=True)) * ctx.scale
-        dq = torch.einsum("nhl,hdl->nhd", ds, k)
+        if ctx.fused:
+            dq, ds, att = ops.token_attention_backward(q, dout, k, v, ctx.scale)
+        else:
+            att = ctx.saved_tensors[3]
+            datt = torch.einsum("nhd,hdl->nhl", dout, v)
+            ds = att * (datt - (datt * att).sum(-1, keepdim=True)) * ctx.scale
+            dq = torch.einsum("nhl,hdl->nhd", ds, k)
+            ds, att = ds.reshape(n, H * L).contiguous(), att.reshape(n, H * L).contiguous()
 
         def blocks(x, gy):  # [H, hd, L]: block h of gy^T x over all heads' columns
-            full = ops.linear_wgrad(x.reshape(n, H * L), gy.reshape(n, H * hd))  # [H * hd, H * L]
+            full = ops.linear_wgrad(x, gy.reshape(n, H * hd))  # [H * hd, H * L]
             return torch.stack([full[h * hd:(h + 1) * hd, h * L:(h + 1) * L] for h in range(H)], 0)
-        return dq, blocks(ds.contiguous(), q.contiguous()), blocks(att.contiguous(), dout), None
+        return dq, blocks(ds, q), blocks(att, dout), None
 
 
 def _sffm_forward_train(self, x, emb1, emb2, batch_idx, batch_size, return_context=False):

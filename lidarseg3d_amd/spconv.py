@@ -183,7 +183,7 @@ class _SparseConvFn(torch.autograd.Function):
             pairs = rb.pairs(inverse, order is not None) if CACHE_PAIRS else None
             gw = ops.spconv_wgrad(feats.detach().contiguous(), gout, tbl, order, cin, cout, pairs=pairs).reshape(weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gout.sum(0)
+            gb = ops.column_sums(gout)
         return gin, gw, gb, None, None, None
 
 

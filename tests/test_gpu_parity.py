@@ -996,6 +996,58 @@ def test_linear_layer_backward_on_the_hip_kernels_gpu(cin, cout, other_n):
         assert float((lin.bias.grad.double() - gb).abs().max()) <= 3e-5 * float(gb.abs().max())
 
 
+@pytest.mark.parametrize("L", [46, 34])
+def test_token_attention_full_size_gpu(L):
+    """the SF-Phase decoder's point -> class-token attention in training (csrc/tokenattn.hip through point_heads._TokenAttention) at the size of a
+    Waymo frame - 180 000 points, 4 heads of 24 channels, 2 x 23 (2 x 17) tokens: output and the three gradients against float64 autograd of the
+    einsum / softmax algebra; the time of forward + backward beside the torch composition it replaces (printed)"""
+    from lidarseg3d_amd.point_heads import _TokenAttention
+    torch.manual_seed(L)
+    n, H, hd = 180000, 4, 24
+    q = torch.randn(n, H, hd, device=DEV).requires_grad_()
+    k = torch.randn(H, hd, L, device=DEV).requires_grad_()
+    v = torch.randn(H, hd, L, device=DEV).requires_grad_()
+    g = torch.randn(n, H, hd, device=DEV)
+    assert ops.token_attention_supported(q, k)
+    out = _TokenAttention.apply(q, k, v, hd ** -0.5)
+    out.backward(g)
+    qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
+    ref = torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", qd, kd) * hd ** -0.5, dim=-1), vd)
+    ref.backward(g.double())
+    for name, got, want, tol in (("out", out, ref, 2e-6), ("dq", q.grad, qd.grad, 2e-6), ("dk", k.grad, kd.grad, 1e-5), ("dv", v.grad, vd.grad, 1e-5)):
+        err = float((got.detach().double() - want.detach()).abs().max()) / float(want.detach().abs().max())
+        assert err <= tol, (name, err)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 5
+
+    def fused():
+        _TokenAttention.apply(q, k, v, hd ** -0.5).backward(g)
+
+    def composed():
+        torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", q, k) * hd ** -0.5, dim=-1), v).backward(g)
+    print("token attention fwd + bwd, L = %d: kernels %.3f ms, torch composition %.3f ms" % (L, timed(fused), timed(composed)))
+
+
+def test_column_sums_full_size_gpu():
+    """ls3d_column_sums (bias gradients of the Linear layers) on the point rows of a Waymo step against float64; bit-reproducible"""
+    torch.manual_seed(2)
+    for n, c in ((360000, 64), (360000, 96 + 32), (241737, 32), (360000, 96), (360000, 192)):
+        wide = torch.randn(n, c + 32, device=DEV)
+        x = wide[:, 32:] if c % 32 == 0 else wide[:, :c]
+        got = ops.column_sums(x)
+        assert torch.equal(got, ops.column_sums(x))
+        want = x.double().sum(0)
+        assert float((got.double() - want).abs().max()) <= 1e-6 * float(x.double().abs().sum(0).max())
+
+
 def test_interpolate_rows_backward_full_size_gpu():
     """the devoxelization's feature gradient at the size of a Waymo step (360k points, 241k voxels, 32 channels): against float64, and
     bit-reproducible where torch's index_put backward (atomics) is not"""

@@ -81,6 +81,50 @@ def test_voxel_ops_modules_vs_reference_cpp():
     voxel_cases.run("cpu")
 
 
+@pytest.mark.parametrize("L,n", [(34, 300), (46, 257), (40, 70), (38, 64)])
+def test_token_attention_kernels_vs_torch_autograd(L, n):
+    """ls3d_token_attention_forward / _backward (the SF-Phase decoder's point -> class-token attention in training, csrc/tokenattn.hip) through
+    point_heads._TokenAttention against torch autograd of the same einsum / softmax algebra in float64: output, d q, d k, d v; ragged last block;
+    an unsupported token count takes the torch branch of the same Function"""
+    from lidarseg3d_amd.point_heads import _TokenAttention
+    rng = np.random.default_rng(L + n)
+    H, hd = 4, 24
+    q = torch.from_numpy(rng.normal(size=(n, H, hd)).astype(np.float32)).requires_grad_()
+    k = torch.from_numpy(rng.normal(size=(H, hd, L)).astype(np.float32)).requires_grad_()
+    v = torch.from_numpy(rng.normal(size=(H, hd, L)).astype(np.float32)).requires_grad_()
+    g = torch.from_numpy(rng.normal(size=(n, H, hd)).astype(np.float32))
+    assert ops.token_attention_supported(q, k)
+    out = _TokenAttention.apply(q, k, v, hd ** -0.5)
+    out.backward(g)
+    qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
+    ref = torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", qd, kd) * hd ** -0.5, dim=-1), vd)
+    ref.backward(g.double())
+    for name, got, want in (("out", out, ref), ("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
+        err = float((got.detach().double() - want.detach()).abs().max()) / float(want.detach().abs().max())
+        assert err <= 2e-6, (name, err)
+    # 50 tokens: not a compiled token count -> the torch branch
+    k2 = torch.from_numpy(rng.normal(size=(H, hd, 50)).astype(np.float32))
+    assert not ops.token_attention_supported(q, k2)
+    o2 = _TokenAttention.apply(q.detach(), k2, k2, hd ** -0.5)
+    r2 = torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", q.detach(), k2) * hd ** -0.5, dim=-1), k2)
+    assert float((o2 - r2).abs().max()) <= 1e-5
+
+
+def test_column_sums_kernel_is_the_float64_sum_and_deterministic():
+    """ls3d_column_sums (a Linear layer's bias gradient): column slices with a row stride, ragged row counts around the 512-row blocks, against
+    float64; the same bits on every call; shapes it does not take fall back to torch"""
+    rng = np.random.default_rng(0)
+    for n, c, ld in ((4096, 64, 64), (5000, 32, 96), (9217, 128, 128), (4097, 4, 8), (4500, 96, 96), (4100, 192, 256), (4096, 20, 24)):
+        wide = torch.from_numpy((rng.normal(size=(n, ld)) * np.exp(rng.normal(size=(n, ld)))).astype(np.float32))
+        x = wide[:, ld - c:]
+        got = ops.column_sums(x)
+        want = x.double().sum(0)
+        assert float((got.double() - want).abs().max()) <= 1e-6 * float(x.double().abs().sum(0).max())
+        assert torch.equal(ops.column_sums(x), got)
+    small = torch.from_numpy(rng.normal(size=(100, 23)).astype(np.float32))
+    assert torch.equal(ops.column_sums(small), small.sum(0))
+
+
 @pytest.mark.parametrize("n,c,relu,res", [(1500, 64, True, True), (777, 16, True, False), (2100, 128, False, False), (5, 32, True, True), (1030, 32, False, True)])
 def test_batch_norm_train_kernels_vs_torch(n, c, relu, res):
     """ls3d_batch_norm_* (training-mode BatchNorm1d with the ReLU / residual add fused in, csrc/norm.hip) against nn.BatchNorm1d + add + relu under
