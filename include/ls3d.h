@@ -671,17 +671,18 @@ int ls3d_batch_norm_backward_apply(const float *x, int ld, const float *dy, cons
 /* Point -> class-token attention of the SF-Phase decoder under autograd (context_module.py:222-257): n point queries q[n, heads * hd] against the
  * frame's L tokens, k / v [heads, hd, L] (the [E, L] layout of the reference's k_proj / v_proj outputs), per point and head
  *   forward : out = softmax(scale q_h K_h) V_h                                                        -> out[n, heads * hd]
- *   backward: dq[n, heads * hd]; ds[n, heads * L] = scale att (d att - <d att, att>) and att[n, heads * L] (recomputed from q: the forward keeps
- *             nothing) - the token-side gradients are d K_h = q_h^T ds_h, d V_h = dout_h^T att_h, tall-skinny reductions the caller runs on
- *             ls3d_spconv_wgrad (identity pairs).
+ *   backward: dq[n, heads * hd], dk / dv [heads, hd, L] (the sums over the points: row blocks on the matrix pipe, two points per
+ *             v_mfma_f32_32x32x2_f32 step, then the blocks' partials in order - deterministic, no atomics); the probabilities are recomputed from q,
+ *             the forward keeps nothing.  workspace: ls3d_token_attention_workspace_bytes(n, heads, L) bytes, 16-byte aligned.
  * Exact f32; one thread per (point, head), K / V through the scalar cache.  hd == 24, L in {34, 38, 40, 46} (2 x 17 / 19 / 20 / 23 classes):
- * LS3D_ERR_UNSUPPORTED otherwise (the caller composes it from GEMMs).  q / dout / out / dq 16-byte aligned, ds / att 8-byte aligned. */
+ * LS3D_ERR_UNSUPPORTED otherwise (the caller composes it from GEMMs).  q / dout / out / dq 16-byte aligned. */
 int ls3d_token_attention_forward(const float *q, int n, int heads, int hd, const float *k, const float *v, int L, float scale, float *out,
                                  ls3d_stream_t stream);
+size_t ls3d_token_attention_workspace_bytes(int n, int heads, int L);
 int ls3d_token_attention_backward(const float *q, const float *dout, int n, int heads, int hd, const float *k, const float *v, int L, float scale,
-                                  float *dq, float *ds, float *att, ls3d_stream_t stream);
+                                  float *dq, float *dk, float *dv, void *workspace, size_t workspace_bytes, ls3d_stream_t stream);
 
-/* out[c] = column sums of x[n, c] (row stride ld floats; c % 4 == 0, c <= 256, x 16-byte aligned): the bias gradient of a
+/* out[c] = column sums of x[n, c] (row stride ld floats; c <= 256; float4 loads when c, ld are multiples of 4 and x is 16-byte aligned): the bias gradient of a
  * Linear layer over 10^5 - 10^6 point rows (torch.nn.functional.linear's backward, sum of grad_out over the rows).  Row blocks + a fixed tree:
  * deterministic.  workspace: ls3d_column_sums_workspace_bytes(n, c). */
 size_t ls3d_column_sums_workspace_bytes(int n, int c);

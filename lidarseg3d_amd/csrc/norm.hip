@@ -433,29 +433,68 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
 }
 
 // per row block: column sums of x -> part[block][c] (a Linear layer's bias gradient: the sum of grad_out over 10^5 - 10^6 point rows, which
-// torch's reduce serves at 117 us per call on [360 000, 64]; same blocks, same fixed tree as the BatchNorm sums: deterministic)
+// torch's reduce serves at 117 us per call on [360 000, 64] and 0.9 ms on [360 000, 23]; same blocks, same fixed tree as the BatchNorm sums:
+// deterministic).  VEC = 4: float4 loads (c % 4 == 0, aligned rows); VEC = 1: any c <= 256 (the class logits' 17 / 20 / 23 columns).
+template <int VEC>
 __global__ __launch_bounds__(256) void k_colsum_part(const float *__restrict__ x, int ld, int n, int c, float *__restrict__ part) {
-  __shared__ float4 s_red[256];
-  const int c4 = c >> 2, RP = 256 / c4, tid = threadIdx.x;
-  const int cg = tid % c4, rg = tid / c4;
+  __shared__ float s_red[256][VEC];
+  const int cv = c / VEC, RP = 256 / cv, tid = threadIdx.x;
+  const int cg = tid % cv, rg = tid / cv;
   const int r0 = blockIdx.x * BN_ROWS, r1 = min(n, r0 + BN_ROWS);
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
   if (rg < RP) {
     for (int r = r0 + rg; r < r1; r += 4 * RP) {
-      float4 v[4];
+      float v[4][VEC];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(x + (size_t)min(r + u * RP, r1 - 1) * ld + cg * 4);
+      for (int u = 0; u < 4; ++u) {
+        const float *src = x + (size_t)min(r + u * RP, r1 - 1) * ld + cg * VEC;
+        if constexpr (VEC == 4) {
+          const float4 t = *(const float4 *)src;
+          v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+        } else {
+          v[u][0] = *src;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (r + u * RP < r1) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        if (r + u * RP < r1) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) s[e] += v[u][e];
+        }
     }
   }
-  s_red[tid] = s;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s_red[tid][e] = s[e];
   __syncthreads();
-  if (tid < c4) {
-    float4 t = s_red[tid];
-    for (int g = 1; g < RP; ++g) { const float4 u = s_red[g * c4 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-    *(float4 *)(part + (size_t)blockIdx.x * c + tid * 4) = t;
+  if (tid < cv) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float t = s_red[tid][e];
+      for (int g = 1; g < RP; ++g) t += s_red[g * cv + tid][e];
+      part[(size_t)blockIdx.x * c + tid * VEC + e] = t;
+    }
+  }
+}
+
+// out[c] = the row blocks' partials [block][c] added: a workgroup owns 32 columns, its 8 groups each add every 8th block in order, then the 8 sums in order
+__global__ __launch_bounds__(256) void k_colsum_reduce(const float *__restrict__ partial, int nblocks, int c, float *__restrict__ out) {
+  __shared__ float red[8][32];
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + lane;
+  float s = 0.0f;
+  if (i < c) {
+#pragma unroll 8
+    for (int b = grp; b < nblocks; b += 8) s += partial[(size_t)b * c + i];
+  }
+  red[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && i < c) {
+    float t = red[0][lane];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += red[g][lane];
+    out[i] = t;
   }
 }
 
@@ -491,16 +530,19 @@ extern "C" int ls3d_batch_norm_finalize(const float *parts, int world, int c, in
 
 extern "C" size_t ls3d_column_sums_workspace_bytes(int n, int c) { return (size_t)bn_blocks(n) * (c > 0 ? c : 1) * sizeof(float) + 256; }
 
-// out[c] = sum over the n rows of x[n, c] (row stride ld): row blocks, then the fixed tree of k_ln_bwd_reduce (its [2][c / 2] view of a partial row)
+// out[c] = sum over the n rows of x[n, c] (row stride ld): row blocks, then a fixed tree over the blocks' partials
 extern "C" int ls3d_column_sums(const float *x, int ld, int n, int c, void *workspace, size_t workspace_bytes, float *out, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!out || n < 0 || c < 4 || (c & 3) || c > 256) return LS3D_ERR_ARG;  // (any c / 4 <= 64: the threads beyond 256 / (c / 4) row groups idle)
+  if (!out || n < 0 || c < 1 || c > 256) return LS3D_ERR_ARG;
   if (n == 0) return hipMemsetAsync(out, 0, c * sizeof(float), stream) == hipSuccess ? LS3D_OK : LS3D_ERR_LAUNCH;
-  if (!x || !workspace || ld < c || (ld & 3) || ((uintptr_t)x & 15)) return LS3D_ERR_ARG;
+  if (!x || !workspace || ld < c) return LS3D_ERR_ARG;
   if (workspace_bytes < ls3d_column_sums_workspace_bytes(n, c)) return LS3D_ERR_WORKSPACE;
   const int nb = bn_blocks(n);
-  hipLaunchKernelGGL(k_colsum_part, dim3(nb), dim3(256), 0, stream, x, ld, n, c, (float *)workspace);
-  hipLaunchKernelGGL(k_ln_bwd_reduce, dim3((c + 31) / 32), dim3(256), 0, stream, (const float *)workspace, nb, c / 2, out, out + c / 2);
+  if (!(c & 3) && !(ld & 3) && !((uintptr_t)x & 15))
+    hipLaunchKernelGGL((k_colsum_part<4>), dim3(nb), dim3(256), 0, stream, x, ld, n, c, (float *)workspace);
+  else
+    hipLaunchKernelGGL((k_colsum_part<1>), dim3(nb), dim3(256), 0, stream, x, ld, n, c, (float *)workspace);
+  hipLaunchKernelGGL(k_colsum_reduce, dim3((c + 31) / 32), dim3(256), 0, stream, (const float *)workspace, nb, c, out);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

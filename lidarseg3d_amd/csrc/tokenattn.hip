@@ -4,8 +4,8 @@
 //
 //   forward   att = softmax(scale q_h K_h), out_h = att V_h                      per point and head
 //   backward  d att = d out_h V_h^T, d s = scale att (d att - <d att, att>), d q_h = d s K_h^T      per point and head;
-//             d K_h = q_h^T d s and d V_h = d out_h^T att reduce over the points: the kernel writes d s and att as [n, H L] rows and
-//             the caller takes them with the tall-skinny weight-gradient kernel it already has (ls3d_spconv_wgrad on identity pairs).
+//             d K_h = q_h^T d s and d V_h = d out_h^T att reduce over the points: on the matrix pipe inside the same kernel (below).
+
 //
 // torch runs this as batched GEMMs of [n, 24] x [24, L] per head plus six elementwise / reduction passes over [n, H, L] tensors that it
 // also keeps from the forward (132 MB per frame and layer on a Waymo frame): 1.2 ms per frame and layer, 14 ms of a training step.  Here
@@ -15,6 +15,18 @@
 #include "common.h"
 
 constexpr int TA_HD = 24;  // channels per head (d_model 96 / 4 heads)
+
+// K_h / V_h are the same in every trip of a kernel's point loop, and hipcc hoists all 2 x 24 x L scalar loads out of it - 2208 SGPR values that it then
+// parks in VGPR lanes and scratch and fetches back with one v_readlane per FMA.  Offsetting the base pointers by a zero that comes out of an empty asm statement per trip
+// (an opaque zero added to them) keeps the loads where they are used: s_load_dwordx16 from the scalar cache straight into the FMAs' SGPR operands.
+#ifdef HIPSIM
+#define TA_OPAQUE_KV(K0_, V0_) const float *__restrict__ K = K0_, *__restrict__ V = V0_;
+#else
+#define TA_OPAQUE_KV(K0_, V0_)                \
+  int zero_ = 0;                              \
+  asm volatile("" : "+s"(zero_));             \
+  const float *__restrict__ K = (K0_) + zero_, *__restrict__ V = (V0_) + zero_;
+#endif
 
 template <int L>
 __device__ __forceinline__ void ta_probabilities(const float (&q)[TA_HD], const float *__restrict__ K, float scale, float (&p)[L]) {
@@ -53,9 +65,10 @@ template <int L>
 __global__ __launch_bounds__(256) void k_token_attn_fwd(const float *__restrict__ q, int n, int heads, const float *__restrict__ k, const float *__restrict__ v,
                                                         float scale, float *__restrict__ out) {
   const int h = blockIdx.y;
-  const float *__restrict__ K = k + (size_t)h * TA_HD * L, *__restrict__ V = v + (size_t)h * TA_HD * L;
+  const float *__restrict__ K0 = k + (size_t)h * TA_HD * L, *__restrict__ V0 = v + (size_t)h * TA_HD * L;
   const int ld = heads * TA_HD;
   for (int p0 = blockIdx.x * 256; p0 < n; p0 += gridDim.x * 256) {
+    TA_OPAQUE_KV(K0, V0)
     const int pt = p0 + threadIdx.x;
     if (pt >= n) continue;
     float qr[TA_HD], pr[L], o[TA_HD];
@@ -72,36 +85,97 @@ __global__ __launch_bounds__(256) void k_token_attn_fwd(const float *__restrict_
   }
 }
 
-// dq: [n, H * 24]; ds, att: [n, H * L] (row p, columns h L .. h L + L of the thread's head).  The L values of a thread go through a
-// per-wave LDS tile so that the stores run along the rows (a thread writing its own 4 L bytes would touch 64 lines per store instruction).
+// Backward.  dq per (point, head) as above; the token-side gradients d K_h[d][l] = sum_p q[p][d] ds[p][l] and d V_h[d][l] = sum_p dout[p][d] att[p][l]
+// reduce over the points: the wave's 64 points' rows go through LDS (they are held point-per-lane, the MFMA wants them point-per-k-step) and
+// every PAIR of points is one v_mfma_f32_32x32x2_f32 step per 32 tokens: A[d][kk] = q[p_kk][d] (rows >= 24 zero), B[kk][l] = ds[p_kk][l]
+// (tokens >= L zero) - 2 x 2 accumulator blocks of 32 x 32 per wave that live across the workgroup's whole share of the points.  At the end
+// the four waves' blocks are added in wave order and written as partial[block][head][2][24][L]; k_token_attn_reduce adds the blocks in order:
+// deterministic, no atomics, and neither ds nor att ever reaches memory (2 x 132 MB per frame and layer on a Waymo frame).
+typedef float ta_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TA_QLD = TA_HD + 1;  // LDS row stride of the staged q / dout rows
+
 template <int L>
-__global__ __launch_bounds__(256) void k_token_attn_bwd(const float *__restrict__ q, const float *__restrict__ dout, int n, int heads,
+struct TaSmem {
+  float tile[4][64 + 1][L + 1];  // a wave's probabilities / d s rows (+ a spare row: lanes of masked columns read past the last one)
+  float rows[4][64 + 2][TA_QLD]; // a wave's q / dout rows
+};
+
+template <int L>
+constexpr int ta_lds_bytes() { return (int)(sizeof(TaSmem<L>) > 4 * 2 * 32 * 64 * sizeof(float) ? sizeof(TaSmem<L>) : 4 * 2 * 32 * 64 * sizeof(float)); }
+
+template <int L>
+__device__ __forceinline__ void ta_accumulate(const float (*tile)[L + 1], const float (*rows)[TA_QLD], int lane, ta_f32x16 (&acc)[2]) {
+  const int i = lane & 31, kk = lane >> 5;
+#pragma unroll 4
+  for (int j = 0; j < 32; ++j) {
+    const int p = 2 * j + kk;
+    const float a = i < TA_HD ? rows[p][i] : 0.0f;
+    const float b0 = tile[p][i], b1 = (32 + i) < L ? tile[p][32 + i] : 0.0f;
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+  }
+}
+
+template <int L>
+__global__ __launch_bounds__(256, 2) void k_token_attn_bwd(const float *__restrict__ q, const float *__restrict__ dout, int n, int heads,
                                                         const float *__restrict__ k, const float *__restrict__ v, float scale, float *__restrict__ dq,
-                                                        float *__restrict__ ds_out, float *__restrict__ att_out) {
-  static_assert(L % 2 == 0, "rows of L floats are stored as float2");
-  __shared__ float s_tile[4][64][L + 1];
+                                                        float *__restrict__ partial) {
+  static_assert(L > 32 && L <= 64, "two 32-token blocks");
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  TaSmem<L> &sm = *(TaSmem<L> *)smem_raw;
   const int h = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *__restrict__ K = k + (size_t)h * TA_HD * L, *__restrict__ V = v + (size_t)h * TA_HD * L;
-  const int ld = heads * TA_HD, ldl = heads * L;
+  const float *__restrict__ K0 = k + (size_t)h * TA_HD * L, *__restrict__ V0 = v + (size_t)h * TA_HD * L;
+  const int ld = heads * TA_HD;
+  ta_f32x16 aK[2], aV[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aK[b][r] = 0.0f; aV[b][r] = 0.0f; }
   for (int p0 = blockIdx.x * 256; p0 < n; p0 += gridDim.x * 256) {
+    TA_OPAQUE_KV(K0, V0)
     const int w0 = p0 + wave * 64, pt = w0 + lane;
     const bool live = pt < n;
     const size_t row = (size_t)(live ? pt : n - 1);
-    float qr[TA_HD], g[TA_HD], pr[L], da[L];
+    // (register budget: two waves per SIMD beside the 64 accumulator registers - dout and the probabilities are re-read from the thread's own
+    // row of the LDS tiles once they are staged, so at most q and one L-vector are live at a time)
+    float qr[TA_HD], da[L];
     ta_load_row(q + row * ld + h * TA_HD, qr);
-    ta_load_row(dout + row * ld + h * TA_HD, g);
-    ta_probabilities<L>(qr, K, scale, pr);
+    {
+      float g[TA_HD], pr[L];
+      ta_load_row(dout + row * ld + h * TA_HD, g);
+      ta_probabilities<L>(qr, K, scale, pr);
+      // d V += dout^T att: the wave's rows through its LDS tiles (points past the end contribute zero rows).  Every thread of the workgroup runs
+      // the same trips, so the block barriers are uniform.
+#pragma unroll
+      for (int l = 0; l < L; ++l) sm.tile[wave][lane][l] = live ? pr[l] : 0.0f;
+#pragma unroll
+      for (int d = 0; d < TA_HD; ++d) sm.rows[wave][lane][d] = g[d];
+    }
+    __syncthreads();
+    ta_accumulate<L>(sm.tile[wave], sm.rows[wave], lane, aV);
 #pragma unroll
     for (int l = 0; l < L; ++l) da[l] = 0.0f;
 #pragma unroll
-    for (int d = 0; d < TA_HD; ++d)
+    for (int d = 0; d < TA_HD; ++d) {
+      const float gd = sm.rows[wave][lane][d];
 #pragma unroll
-      for (int l = 0; l < L; ++l) da[l] = fmaf(g[d], V[d * L + l], da[l]);
-    float dot = 0.0f;
+      for (int l = 0; l < L; ++l) da[l] = fmaf(gd, V[d * L + l], da[l]);
+    }
+    {
+      float dot = 0.0f;
 #pragma unroll
-    for (int l = 0; l < L; ++l) dot = fmaf(da[l], pr[l], dot);
+      for (int l = 0; l < L; ++l) dot = fmaf(da[l], sm.tile[wave][lane][l], dot);
 #pragma unroll
-    for (int l = 0; l < L; ++l) da[l] = pr[l] * (da[l] - dot) * scale;  // d s
+      for (int l = 0; l < L; ++l) da[l] = sm.tile[wave][lane][l] * (da[l] - dot) * scale;  // d s (a dead point's probabilities are staged as zeros: d s = 0)
+    }
+    __syncthreads();  // every wave is done with the tiles of d V
+    // d K += q^T d s
+#pragma unroll
+    for (int l = 0; l < L; ++l) sm.tile[wave][lane][l] = live ? da[l] : 0.0f;
+#pragma unroll
+    for (int d = 0; d < TA_HD; ++d) sm.rows[wave][lane][d] = qr[d];
+    __syncthreads();
+    ta_accumulate<L>(sm.tile[wave], sm.rows[wave], lane, aK);
     {
       float o[TA_HD];
 #pragma unroll
@@ -113,20 +187,42 @@ __global__ __launch_bounds__(256) void k_token_attn_bwd(const float *__restrict_
       }
       if (live) ta_store_row(dq + (size_t)pt * ld + h * TA_HD, o);
     }
-    // the wave's 64 x L tiles of att, then d s: through LDS, stored as float2 along the rows (every thread of the workgroup runs the same trips)
-    const int nrows = min(64, n - w0);
+    __syncthreads();
+  }
+  // the four waves' accumulator blocks, added in wave order: dump [wave][matrix][d 32][l 64] over the tiles (dead by now; ta_lds_bytes covers it)
+  float *dump = (float *)smem_raw;
+  {
+    const int i = lane & 31, half = lane >> 5;
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int l = 0; l < L; ++l) s_tile[wave][lane][l] = which ? da[l] : pr[l];
-      __syncthreads();
-      float *__restrict__ dst = which ? ds_out : att_out;
-      for (int i = lane; i < nrows * (L / 2); i += 64) {
-        const int r = i / (L / 2), c2 = i % (L / 2);
-        *(float2 *)(dst + (size_t)(w0 + r) * ldl + h * L + 2 * c2) = make_float2(s_tile[wave][r][2 * c2], s_tile[wave][r][2 * c2 + 1]);
-      }
-      __syncthreads();
-    }
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = (r & 3) + 8 * (r >> 2) + 4 * half;  // fragment layout of the 32 x 32 MFMA: row d, column i of block b
+          dump[((wave * 2 + m) * 32 + d) * 64 + b * 32 + i] = m ? aV[b][r] : aK[b][r];
+        }
+  }
+  __syncthreads();
+  float *__restrict__ dst = partial + ((size_t)blockIdx.x * heads + h) * 2 * TA_HD * L;  // [dK | dV][24][L]
+  for (int e = threadIdx.x; e < 2 * TA_HD * L; e += 256) {
+    const int m = e / (TA_HD * L), d = (e / L) % TA_HD, l = e % L;
+    float s = dump[((0 * 2 + m) * 32 + d) * 64 + l];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) s += dump[((w * 2 + m) * 32 + d) * 64 + l];
+    dst[e] = s;
+  }
+}
+
+// dk, dv [heads][24][L] = sum over the row blocks' partials [block][head][2][24][L], in block order
+__global__ __launch_bounds__(256) void k_token_attn_reduce(const float *__restrict__ partial, int nblocks, int heads, int L, float *__restrict__ dk,
+                                                           float *__restrict__ dv) {
+  const int per = TA_HD * L, total = heads * 2 * per;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    float s = 0.0f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * total + e];
+    const int h = e / (2 * per), m = (e / per) & 1, r = e % per;
+    (m ? dv : dk)[(size_t)h * per + r] = s;
   }
 }
 
@@ -152,16 +248,41 @@ extern "C" int ls3d_token_attention_forward(const float *q, int n, int heads, in
   return LS3D_OK;
 }
 
+static inline int ta_bwd_blocks(int n) { const int b = (n + 255) / 256; return b < 1 ? 1 : (b < 256 ? b : 256); }
+
+extern "C" size_t ls3d_token_attention_workspace_bytes(int n, int heads, int L) {
+  if (n < 0 || heads < 1 || L < 1) return 0;
+  return (size_t)ta_bwd_blocks(n) * heads * 2 * TA_HD * L * sizeof(float) + 256;
+}
+
 extern "C" int ls3d_token_attention_backward(const float *q, const float *dout, int n, int heads, int hd, const float *k, const float *v, int L, float scale,
-                                             float *dq, float *ds, float *att, ls3d_stream_t stream_) {
+                                             float *dq, float *dk, float *dv, void *workspace, size_t workspace_bytes, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || heads < 1 || hd < 1 || L < 1) return LS3D_ERR_ARG;
   if (!ta_shape_ok(heads, hd, L)) return LS3D_ERR_UNSUPPORTED;
-  if (n == 0) return LS3D_OK;
-  if (!q || !dout || !k || !v || !dq || !ds || !att || ((uintptr_t)q & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 15) || ((uintptr_t)ds & 7) ||
-      ((uintptr_t)att & 7))
+  if (!dk || !dv) return LS3D_ERR_ARG;
+  if (n == 0) {
+    const size_t bytes = (size_t)heads * TA_HD * L * sizeof(float);
+    return hipMemsetAsync(dk, 0, bytes, stream) == hipSuccess && hipMemsetAsync(dv, 0, bytes, stream) == hipSuccess ? LS3D_OK : LS3D_ERR_LAUNCH;
+  }
+  if (!q || !dout || !k || !v || !dq || !workspace || ((uintptr_t)q & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 15) || ((uintptr_t)workspace & 15))
     return LS3D_ERR_ARG;
-  const dim3 grid((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), (unsigned)heads);
-  TA_DISPATCH(L, hipLaunchKernelGGL((k_token_attn_bwd<LL>), grid, dim3(256), 0, (hipStream_t)stream_, q, dout, n, heads, k, v, scale, dq, ds, att))
+  if (workspace_bytes < ls3d_token_attention_workspace_bytes(n, heads, L)) return LS3D_ERR_WORKSPACE;
+  const int nb = ta_bwd_blocks(n);
+  static bool attr_set[LS3D_MAX_DEVICES] = {};
+  const int slot = ls3d_device_slot();
+  if (!attr_set[slot]) {  // the opt-in to > 64 KB of dynamic LDS is per device
+    bool ok = true;
+    TA_DISPATCH(46, ok = ok && hipFuncSetAttribute((const void *)k_token_attn_bwd<LL>, hipFuncAttributeMaxDynamicSharedMemorySize, ta_lds_bytes<LL>()) == hipSuccess)
+    TA_DISPATCH(40, ok = ok && hipFuncSetAttribute((const void *)k_token_attn_bwd<LL>, hipFuncAttributeMaxDynamicSharedMemorySize, ta_lds_bytes<LL>()) == hipSuccess)
+    TA_DISPATCH(38, ok = ok && hipFuncSetAttribute((const void *)k_token_attn_bwd<LL>, hipFuncAttributeMaxDynamicSharedMemorySize, ta_lds_bytes<LL>()) == hipSuccess)
+    TA_DISPATCH(34, ok = ok && hipFuncSetAttribute((const void *)k_token_attn_bwd<LL>, hipFuncAttributeMaxDynamicSharedMemorySize, ta_lds_bytes<LL>()) == hipSuccess)
+    if (!ok) return LS3D_ERR_LAUNCH;
+    attr_set[slot] = true;
+  }
+  TA_DISPATCH(L, hipLaunchKernelGGL((k_token_attn_bwd<LL>), dim3((unsigned)nb, (unsigned)heads), dim3(256), ta_lds_bytes<LL>(), stream, q, dout, n, heads, k, v,
+                                    scale, dq, (float *)workspace))
+  hipLaunchKernelGGL(k_token_attn_reduce, dim3((unsigned)((heads * 2 * TA_HD * L + 255) / 256)), dim3(256), 0, stream, (const float *)workspace, nb, heads, L, dk, dv);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
 }

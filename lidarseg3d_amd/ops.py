@@ -1510,22 +1510,22 @@ def token_attention_forward(q, k, v, scale):
 
 
 def token_attention_backward(q, dout, k, v, scale):
-    """-> (dq [n, H, hd], ds [n, H * L], att [n, H * L]) of token_attention_forward, the probabilities recomputed from q"""
+    """-> (dq [n, H, hd], dk [H, hd, L], dv [H, hd, L]) of token_attention_forward, the probabilities recomputed from q (ls3d_token_attention_backward)"""
     n, H, hd = q.shape
     L = k.shape[2]
     dq = torch.empty_like(q)
-    ds = torch.empty((n, H * L), dtype=torch.float32, device=q.device)
-    att = torch.empty((n, H * L), dtype=torch.float32, device=q.device)
+    dk = torch.empty((H, hd, L), dtype=torch.float32, device=q.device)
+    dv = torch.empty((H, hd, L), dtype=torch.float32, device=q.device)
+    ws = _ws(_L().ls3d_token_attention_workspace_bytes(n, H, L), q)
     check(_L().ls3d_token_attention_backward(_ptr(q), _ptr(dout), n, H, hd, _ptr(k.contiguous()), _ptr(v.contiguous()), L, ctypes.c_float(scale), _ptr(dq),
-                                             _ptr(ds), _ptr(att), _stream(q)), "ls3d_token_attention_backward")
-    return dq, ds, att
+                                             _ptr(dk), _ptr(dv), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(q)), "ls3d_token_attention_backward")
+    return dq, dk, dv
 
 
 def column_sums(x):
     """x[n, c].sum(0) on ls3d_column_sums (deterministic row blocks + fixed tree), or torch's reduction where the shape is not covered"""
     n, c = x.shape
-    if not ((x.is_cuda or _SIM) and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and c % 4 == 0 and 4 <= c <= 256
-            and x.data_ptr() % 16 == 0 and n >= 4096):
+    if not ((x.is_cuda or _SIM) and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and 1 <= c <= 256 and n >= 4096):
         return x.sum(0)
     out = torch.empty((c,), dtype=torch.float32, device=x.device)
     ws = _ws(_L().ls3d_column_sums_workspace_bytes(n, c), x)

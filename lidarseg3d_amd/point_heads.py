@@ -479,10 +479,9 @@ class SemanticFeatureFusionModule(PackedModule):
 class _TokenAttention(torch.autograd.Function):
     """softmax(q k / sqrt(hd)) v of n points against L class tokens per head (context_module.py:222-257) on csrc/tokenattn.hip: one thread per
     (point, head) with its scores in registers, nothing kept from the forward (the backward recomputes the probabilities from q); the token-side
-    gradients d k and d v reduce 10^5 points into hd x L matrices per head - one tall-skinny reduction over all heads' columns at once
-    (ops.linear_wgrad, from which the H diagonal blocks are taken).  torch ran this as batched GEMMs with 32 x 32 macro tiles plus six passes over
-    [n, H, L] tensors: 1.2 ms per frame and layer, 14 ms of a Waymo step.  Shapes the kernels do not take (ops.token_attention_supported) run
-    the same algebra on torch."""
+    gradients d k and d v - 10^5 points reduced into hd x L matrices per head - inside the same kernel on the matrix pipe.  torch ran this as
+    batched GEMMs with 32 x 32 macro tiles plus six passes over [n, H, L] tensors: 1.8 ms per frame and layer, 14 ms of a Waymo step.  Shapes the
+    kernels do not take (ops.token_attention_supported) run the same algebra on torch, the token-side reductions on ops.linear_wgrad."""
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
@@ -503,16 +502,15 @@ class _TokenAttention(torch.autograd.Function):
         L = k.shape[2]
         dout = dout.contiguous()
         if ctx.fused:
-            dq, ds, att = ops.token_attention_backward(q, dout, k, v, ctx.scale)
-        else:
-            att = ctx.saved_tensors[3]
-            datt = torch.einsum("nhd,hdl->nhl", dout, v)
-            ds = att * (datt - (datt * att).sum(-1, keepdim=True)) * ctx.scale
-            dq = torch.einsum("nhl,hdl->nhd", ds, k)
-            ds, att = ds.reshape(n, H * L).contiguous(), att.reshape(n, H * L).contiguous()
+            dq, dk, dv = ops.token_attention_backward(q, dout, k, v, ctx.scale)
+            return dq, dk, dv, None
+        att = ctx.saved_tensors[3]
+        datt = torch.einsum("nhd,hdl->nhl", dout, v)
+        ds = att * (datt - (datt * att).sum(-1, keepdim=True)) * ctx.scale
+        dq = torch.einsum("nhl,hdl->nhd", ds, k)
 
-        def blocks(x, gy):  # [H, hd, L]: block h of gy^T x over all heads' columns
-            full = ops.linear_wgrad(x, gy.reshape(n, H * hd))  # [H * hd, H * L]
+        def blocks(x, gy):  # [H, hd, L]: block h of gy^T x over all heads' columns (one tall-skinny reduction, the H diagonal blocks taken)
+            full = ops.linear_wgrad(x.reshape(n, H * L).contiguous(), gy.reshape(n, H * hd))  # [H * hd, H * L]
             return torch.stack([full[h * hd:(h + 1) * hd, h * L:(h + 1) * L] for h in range(H)], 0)
         return dq, blocks(ds, q), blocks(att, dout), None
 

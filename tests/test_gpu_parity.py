@@ -1039,9 +1039,9 @@ def test_token_attention_full_size_gpu(L):
 def test_column_sums_full_size_gpu():
     """ls3d_column_sums (bias gradients of the Linear layers) on the point rows of a Waymo step against float64; bit-reproducible"""
     torch.manual_seed(2)
-    for n, c in ((360000, 64), (360000, 96 + 32), (241737, 32), (360000, 96), (360000, 192)):
+    for n, c in ((360000, 64), (360000, 96 + 32), (241737, 32), (360000, 96), (360000, 192), (360000, 23), (241233, 17)):
         wide = torch.randn(n, c + 32, device=DEV)
-        x = wide[:, 32:] if c % 32 == 0 else wide[:, :c]
+        x = wide[:, 32:] if c % 32 == 0 else (wide[:, :c] if c % 4 == 0 else wide[:, :c].contiguous())
         got = ops.column_sums(x)
         assert torch.equal(got, ops.column_sums(x))
         want = x.double().sum(0)

@@ -114,14 +114,14 @@ def test_column_sums_kernel_is_the_float64_sum_and_deterministic():
     """ls3d_column_sums (a Linear layer's bias gradient): column slices with a row stride, ragged row counts around the 512-row blocks, against
     float64; the same bits on every call; shapes it does not take fall back to torch"""
     rng = np.random.default_rng(0)
-    for n, c, ld in ((4096, 64, 64), (5000, 32, 96), (9217, 128, 128), (4097, 4, 8), (4500, 96, 96), (4100, 192, 256), (4096, 20, 24)):
+    for n, c, ld in ((4096, 64, 64), (5000, 32, 96), (9217, 128, 128), (4097, 4, 8), (4500, 96, 96), (4100, 192, 256), (4096, 20, 24), (4300, 23, 23), (4200, 17, 40), (4096, 1, 3)):
         wide = torch.from_numpy((rng.normal(size=(n, ld)) * np.exp(rng.normal(size=(n, ld)))).astype(np.float32))
         x = wide[:, ld - c:]
         got = ops.column_sums(x)
         want = x.double().sum(0)
         assert float((got.double() - want).abs().max()) <= 1e-6 * float(x.double().abs().sum(0).max())
         assert torch.equal(ops.column_sums(x), got)
-    small = torch.from_numpy(rng.normal(size=(100, 23)).astype(np.float32))
+    small = torch.from_numpy(rng.normal(size=(100, 23)).astype(np.float32))  # few rows: torch
     assert torch.equal(ops.column_sums(small), small.sum(0))
 
 
@@ -1152,7 +1152,7 @@ def test_coloured_tile_plan_places_a_lane_groups_neighbours_in_different_bank_co
                 else:
                     assert loc[t, k, s] < H and halo[t, loc[t, k, s]] == nb
                     assert used.setdefault(int(nb), int(loc[t, k, s])) == int(loc[t, k, s])  # one slot per halo row
-    assert np.array_equal(_plan_deps(plan)[0], _plan_deps(ops.tile_plan(tbl, coords, shape, 1))[0])
+    assert np.array_equal(_plan_deps(plan)[0][:V], _plan_deps(ops.tile_plan(tbl, coords, shape, 1))[0][:V])  # (entries beyond the rows are not written)
     cyc_plain, cyc_col = _a_read_cycles(*plain[:2], plain[3]), _a_read_cycles(trow, meta, loc)
     assert cyc_plain > 6.5 and cyc_col < 0.85 * cyc_plain and cyc_col < 6.0, (cyc_plain, cyc_col)
     rng = np.random.default_rng(3)
