@@ -38,6 +38,8 @@ def main():
              ("  no LayerNorm", "bf16x6", 4), ("  GEMMs without MFMAs", "bf16x6", 8), ("  GEMMs without weight staging", "bf16x6", 16),
              ("  no attention, no FFN", "bf16x6", 3), ("  GEMMs: neither", "bf16x6", 24), ("  only GEMM staging + barriers", "bf16x6", 1 | 4 | 8),
              ("  only GEMM MFMAs", "bf16x6", 1 | 4 | 16)]
+    print("(the indented rows leave parts of the kernel out and need a library built with -DRT_ABLATE_HOOKS=1 (csrc/sffm.hip); in the product build the\n"
+          " hooks are compiled out and they time the full kernel)")
     for name, prec, ab in cases:
         ops.set_precision(prec)
         ops._SFFM_ABLATE = ab
