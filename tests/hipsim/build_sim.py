@@ -11,6 +11,16 @@ LIB = os.path.join(HERE, "libls3d_sim.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
+def _host_has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read().replace("\n", " ")
+    except OSError:
+        return False
+
+
+_FMA = ["-mfma"] if _host_has_fma() else []
+
+
 def build(force=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "*.cpp")) + \
@@ -20,7 +30,9 @@ def build(force=False):
     objs = []
     for s in srcs + [os.path.join(HERE, "hipsim.cpp")]:
         o = os.path.join(HERE, os.path.basename(s) + ".o")
-        subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-Wno-psabi",
+        # -mfma: fmaf() (the emulated MFMAs' 16 K multiply-adds per instruction, the kernels' explicit fmaf) inlines to vfmadd instead of a libm
+        # call - the same correctly rounded result, ~3x faster suite; -ffp-contract=off still keeps a * b + c two roundings
+        subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2"] + _FMA + ["-fPIC", "-ffp-contract=off", "-Wno-psabi",
                                "-Wno-unused-value", "-I", HERE, "-c", s, "-o", o])
         objs.append(o)
     subprocess.check_call([CLANG, "-shared", "-o", LIB] + objs)

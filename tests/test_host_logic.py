@@ -300,7 +300,7 @@ def frame(seed, n):  # voxel coordinates + 16 input features of one frame
     g = torch.Generator().manual_seed(seed)
     return c[:V], torch.randn(V, 16, generator=g)
 
-frames = [frame(11, 150), frame(12, 90)]  # DIFFERENT voxel counts: the statistics must be weighted by row count
+frames = [frame(11, 110), frame(12, 60)]  # DIFFERENT voxel counts: the statistics must be weighted by row count
 torch.manual_seed(0)
 net = scn_unet.UNetSCN3D(num_input_features=16, voxel_size=cfg["voxel_size"], point_cloud_range=cfg["pc_range"],
                          model_cfg=dict(SCALING_RATIO=1, RETURN_ENCODED_TENSOR=False), ds_factor=8, us_factor=8)
