@@ -192,30 +192,40 @@ int __all(int p) {
   return ok;
 }
 
+// The emulated MFMAs exchange their operands through per-wave staging arrays with ONE wave barrier per instruction: the arrays are double
+// buffered by a per-wave generation count (the first lane released from the barrier advances it), so a lane that runs ahead into the next MFMA
+// writes the other buffer while slower lanes still read this one, and nobody can reach the MFMA after that - which reuses this buffer - before
+// every lane has passed the next barrier, i.e. has finished reading.  (A second barrier per instruction was 40 % of the suite's fiber switches.)
+static unsigned mfma_gen[16];
+
 hipsim_f32x16 hipsim_mfma_32x32x2f32(float a, float b, hipsim_f32x16 c, int, int, int) {
-  static float A[16][32][2], B[16][2][32];
+  static float A[2][16][32][2], B[2][16][2][32];
   int w = hipsim::wave(), l = hipsim::lane();
-  A[w][l & 31][l >> 5] = a;
-  B[w][l >> 5][l & 31] = b;
+  const unsigned gen = mfma_gen[w];
+  const int p = gen & 1;
+  A[p][w][l & 31][l >> 5] = a;
+  B[p][w][l >> 5][l & 31] = b;
   hipsim::wave_barrier();
+  if (mfma_gen[w] == gen) mfma_gen[w] = gen + 1;
   hipsim_f32x16 d = c;
   int col = l & 31;
   for (int r = 0; r < 16; ++r) {
     int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
     float acc = c[r];
-    acc = fmaf(A[w][row][0], B[w][0][col], acc);
-    acc = fmaf(A[w][row][1], B[w][1][col], acc);
+    acc = fmaf(A[p][w][row][0], B[p][w][0][col], acc);
+    acc = fmaf(A[p][w][row][1], B[p][w][1][col], acc);
     d[r] = acc;
   }
-  hipsim::wave_barrier();
   return d;
 }
 
 // 32x32x16 bf16: lane l holds A[i=l&31][k=8*(l>>5)+j] and B[k=8*(l>>5)+j][col=l&31], j = 0..7; C/D as the f32 form.
 // (Any consistent k assignment gives the same product; kernels must not depend on it beyond A/B pairing.)
 hipsim_f32x16 hipsim_mfma_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim_f32x16 c, int, int, int) {
-  static float A[16][32][16], B[16][16][32];
+  static float A[2][16][32][16], B[2][16][16][32];
   int w = hipsim::wave(), l = hipsim::lane();
+  const unsigned gen = mfma_gen[w];
+  const int p = gen & 1;
   uint16_t ra[8], rb[8];
   memcpy(ra, &a, 16);
   memcpy(rb, &b, 16);
@@ -224,19 +234,23 @@ hipsim_f32x16 hipsim_mfma_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim
     float fa, fb;
     memcpy(&fa, &ua, 4);
     memcpy(&fb, &ub, 4);
-    A[w][l & 31][8 * (l >> 5) + j] = fa;
-    B[w][8 * (l >> 5) + j][l & 31] = fb;
+    A[p][w][l & 31][8 * (l >> 5) + j] = fa;
+    B[p][w][8 * (l >> 5) + j][l & 31] = fb;
   }
   hipsim::wave_barrier();
-  hipsim_f32x16 d = c;
-  int col = l & 31;
-  for (int r = 0; r < 16; ++r) {
-    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    float acc = c[r];
-    for (int k = 0; k < 16; ++k) acc = fmaf(A[w][row][k], B[w][k][col], acc);
-    d[r] = acc;
+  if (mfma_gen[w] == gen) mfma_gen[w] = gen + 1;
+  // k outermost: the 16 outputs of a lane are 16 independent chains in flight (r outermost made one dependent chain of 16 multiply-adds per
+  // output: latency-bound, 4x slower); per output the products are still added in ascending k
+  float acc[16];
+  const float *bcol = &B[p][w][0][l & 31];
+  const int half4 = 4 * (l >> 5);
+  for (int r = 0; r < 16; ++r) acc[r] = c[r];
+  for (int k = 0; k < 16; ++k) {
+    const float bk = bcol[k * 32];
+    for (int r = 0; r < 16; ++r) acc[r] = fmaf(A[p][w][(r & 3) + 8 * (r >> 2) + half4][k], bk, acc[r]);
   }
-  hipsim::wave_barrier();
+  hipsim_f32x16 d;
+  for (int r = 0; r < 16; ++r) d[r] = acc[r];
   return d;
 }
 
@@ -274,24 +288,30 @@ int hipsim_cvt_pk_fp8_f32(float a, float b, int old, bool word_sel) {
   return (int)(word_sel ? ((o & 0x0000FFFFu) | (pk << 16)) : ((o & 0xFFFF0000u) | pk));
 }
 hipsim_f32x16 hipsim_mfma_32x32x16_fp8(long a, long b, hipsim_f32x16 c, int, int, int) {
-  static float A[16][32][16], B[16][16][32];
+  static float A[2][16][32][16], B[2][16][16][32];
   int w = hipsim::wave(), l = hipsim::lane();
+  const unsigned gen = mfma_gen[w];
+  const int p = gen & 1;
   uint8_t ra[8], rb[8];
   memcpy(ra, &a, 8);
   memcpy(rb, &b, 8);
   for (int j = 0; j < 8; ++j) {
-    A[w][l & 31][8 * (l >> 5) + j] = hipsim_e4m3_to_f32(ra[j]);
-    B[w][8 * (l >> 5) + j][l & 31] = hipsim_e4m3_to_f32(rb[j]);
+    A[p][w][l & 31][8 * (l >> 5) + j] = hipsim_e4m3_to_f32(ra[j]);
+    B[p][w][8 * (l >> 5) + j][l & 31] = hipsim_e4m3_to_f32(rb[j]);
   }
   hipsim::wave_barrier();
-  hipsim_f32x16 d = c;
-  int col = l & 31;
-  for (int r = 0; r < 16; ++r) {
-    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    float acc = c[r];
-    for (int k = 0; k < 16; ++k) acc = fmaf(A[w][row][k], B[w][k][col], acc);
-    d[r] = acc;
+  if (mfma_gen[w] == gen) mfma_gen[w] = gen + 1;
+  // k outermost: the 16 outputs of a lane are 16 independent chains in flight (r outermost made one dependent chain of 16 multiply-adds per
+  // output: latency-bound, 4x slower); per output the products are still added in ascending k
+  float acc[16];
+  const float *bcol = &B[p][w][0][l & 31];
+  const int half4 = 4 * (l >> 5);
+  for (int r = 0; r < 16; ++r) acc[r] = c[r];
+  for (int k = 0; k < 16; ++k) {
+    const float bk = bcol[k * 32];
+    for (int r = 0; r < 16; ++r) acc[r] = fmaf(A[p][w][(r & 3) + 8 * (r >> 2) + half4][k], bk, acc[r]);
   }
-  hipsim::wave_barrier();
+  hipsim_f32x16 d;
+  for (int r = 0; r < 16; ++r) d[r] = acc[r];
   return d;
 }
