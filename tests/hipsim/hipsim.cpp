@@ -192,37 +192,48 @@ int __all(int p) {
   return ok;
 }
 
-// The emulated MFMAs exchange their operands through per-wave staging arrays with ONE wave barrier per instruction: the arrays are double
-// buffered by a per-wave generation count (the first lane released from the barrier advances it), so a lane that runs ahead into the next MFMA
-// writes the other buffer while slower lanes still read this one, and nobody can reach the MFMA after that - which reuses this buffer - before
-// every lane has passed the next barrier, i.e. has finished reading.  (A second barrier per instruction was 40 % of the suite's fiber switches.)
+// The emulated MFMAs: every lane stages its operand fragments and its 16 accumulator values in per-wave arrays, ONE wave barrier, then the FIRST
+// lane released from it computes the whole 32 x 32 x K product (rows x K x columns with the columns innermost: the compiler vectorises them;
+// per output the products are added in ascending k, one fmaf each, as before) and the others read their 16 results.  The arrays are double
+// buffered by a per-wave generation count, advanced by that first lane: a lane that runs ahead into the next MFMA writes the other buffer
+// while slower lanes still read this one, and nobody reaches the MFMA after that - which reuses this buffer - before every lane has passed the
+// next barrier, i.e. has read its results.  (Per-lane products and a second barrier per instruction were ~2/3 of the CPU suite's time.)
 static unsigned mfma_gen[16];
+static float mfma_A[2][16][32][16], mfma_B[2][16][16][32], mfma_D[2][16][32][32];
+
+template <int K>
+static inline hipsim_f32x16 mfma_finish(int p, int w, int l, unsigned gen, const hipsim_f32x16 &c) {
+  const int col = l & 31, half4 = 4 * (l >> 5);
+  for (int r = 0; r < 16; ++r) mfma_D[p][w][(r & 3) + 8 * (r >> 2) + half4][col] = c[r];
+  hipsim::wave_barrier();
+  if (mfma_gen[w] == gen) {  // the first lane out of the barrier: the whole product
+    for (int i = 0; i < 32; ++i) {
+      float *__restrict__ drow = mfma_D[p][w][i];
+      for (int k = 0; k < K; ++k) {
+        const float a = mfma_A[p][w][i][k];
+        const float *__restrict__ brow = mfma_B[p][w][k];
+        for (int j = 0; j < 32; ++j) drow[j] = fmaf(a, brow[j], drow[j]);
+      }
+    }
+    mfma_gen[w] = gen + 1;
+  }
+  hipsim_f32x16 d;
+  for (int r = 0; r < 16; ++r) d[r] = mfma_D[p][w][(r & 3) + 8 * (r >> 2) + half4][col];
+  return d;
+}
 
 hipsim_f32x16 hipsim_mfma_32x32x2f32(float a, float b, hipsim_f32x16 c, int, int, int) {
-  static float A[2][16][32][2], B[2][16][2][32];
   int w = hipsim::wave(), l = hipsim::lane();
   const unsigned gen = mfma_gen[w];
   const int p = gen & 1;
-  A[p][w][l & 31][l >> 5] = a;
-  B[p][w][l >> 5][l & 31] = b;
-  hipsim::wave_barrier();
-  if (mfma_gen[w] == gen) mfma_gen[w] = gen + 1;
-  hipsim_f32x16 d = c;
-  int col = l & 31;
-  for (int r = 0; r < 16; ++r) {
-    int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    float acc = c[r];
-    acc = fmaf(A[p][w][row][0], B[p][w][0][col], acc);
-    acc = fmaf(A[p][w][row][1], B[p][w][1][col], acc);
-    d[r] = acc;
-  }
-  return d;
+  mfma_A[p][w][l & 31][l >> 5] = a;
+  mfma_B[p][w][l >> 5][l & 31] = b;
+  return mfma_finish<2>(p, w, l, gen, c);
 }
 
 // 32x32x16 bf16: lane l holds A[i=l&31][k=8*(l>>5)+j] and B[k=8*(l>>5)+j][col=l&31], j = 0..7; C/D as the f32 form.
 // (Any consistent k assignment gives the same product; kernels must not depend on it beyond A/B pairing.)
 hipsim_f32x16 hipsim_mfma_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim_f32x16 c, int, int, int) {
-  static float A[2][16][32][16], B[2][16][16][32];
   int w = hipsim::wave(), l = hipsim::lane();
   const unsigned gen = mfma_gen[w];
   const int p = gen & 1;
@@ -234,24 +245,10 @@ hipsim_f32x16 hipsim_mfma_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim
     float fa, fb;
     memcpy(&fa, &ua, 4);
     memcpy(&fb, &ub, 4);
-    A[p][w][l & 31][8 * (l >> 5) + j] = fa;
-    B[p][w][8 * (l >> 5) + j][l & 31] = fb;
+    mfma_A[p][w][l & 31][8 * (l >> 5) + j] = fa;
+    mfma_B[p][w][8 * (l >> 5) + j][l & 31] = fb;
   }
-  hipsim::wave_barrier();
-  if (mfma_gen[w] == gen) mfma_gen[w] = gen + 1;
-  // k outermost: the 16 outputs of a lane are 16 independent chains in flight (r outermost made one dependent chain of 16 multiply-adds per
-  // output: latency-bound, 4x slower); per output the products are still added in ascending k
-  float acc[16];
-  const float *bcol = &B[p][w][0][l & 31];
-  const int half4 = 4 * (l >> 5);
-  for (int r = 0; r < 16; ++r) acc[r] = c[r];
-  for (int k = 0; k < 16; ++k) {
-    const float bk = bcol[k * 32];
-    for (int r = 0; r < 16; ++r) acc[r] = fmaf(A[p][w][(r & 3) + 8 * (r >> 2) + half4][k], bk, acc[r]);
-  }
-  hipsim_f32x16 d;
-  for (int r = 0; r < 16; ++r) d[r] = acc[r];
-  return d;
+  return mfma_finish<16>(p, w, l, gen, c);
 }
 
 // ---- fp8 e4m3fn (OCP): 1 sign, 4 exponent (bias 7), 3 mantissa bits; max 448, no inf, 0x7F / 0xFF = NaN; round to nearest even,
@@ -288,7 +285,6 @@ int hipsim_cvt_pk_fp8_f32(float a, float b, int old, bool word_sel) {
   return (int)(word_sel ? ((o & 0x0000FFFFu) | (pk << 16)) : ((o & 0xFFFF0000u) | pk));
 }
 hipsim_f32x16 hipsim_mfma_32x32x16_fp8(long a, long b, hipsim_f32x16 c, int, int, int) {
-  static float A[2][16][32][16], B[2][16][16][32];
   int w = hipsim::wave(), l = hipsim::lane();
   const unsigned gen = mfma_gen[w];
   const int p = gen & 1;
@@ -296,22 +292,8 @@ hipsim_f32x16 hipsim_mfma_32x32x16_fp8(long a, long b, hipsim_f32x16 c, int, int
   memcpy(ra, &a, 8);
   memcpy(rb, &b, 8);
   for (int j = 0; j < 8; ++j) {
-    A[p][w][l & 31][8 * (l >> 5) + j] = hipsim_e4m3_to_f32(ra[j]);
-    B[p][w][8 * (l >> 5) + j][l & 31] = hipsim_e4m3_to_f32(rb[j]);
+    mfma_A[p][w][l & 31][8 * (l >> 5) + j] = hipsim_e4m3_to_f32(ra[j]);
+    mfma_B[p][w][8 * (l >> 5) + j][l & 31] = hipsim_e4m3_to_f32(rb[j]);
   }
-  hipsim::wave_barrier();
-  if (mfma_gen[w] == gen) mfma_gen[w] = gen + 1;
-  // k outermost: the 16 outputs of a lane are 16 independent chains in flight (r outermost made one dependent chain of 16 multiply-adds per
-  // output: latency-bound, 4x slower); per output the products are still added in ascending k
-  float acc[16];
-  const float *bcol = &B[p][w][0][l & 31];
-  const int half4 = 4 * (l >> 5);
-  for (int r = 0; r < 16; ++r) acc[r] = c[r];
-  for (int k = 0; k < 16; ++k) {
-    const float bk = bcol[k * 32];
-    for (int r = 0; r < 16; ++r) acc[r] = fmaf(A[p][w][(r & 3) + 8 * (r >> 2) + half4][k], bk, acc[r]);
-  }
-  hipsim_f32x16 d;
-  for (int r = 0; r < 16; ++r) d[r] = acc[r];
-  return d;
+  return mfma_finish<16>(p, w, l, gen, c);
 }
