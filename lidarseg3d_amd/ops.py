@@ -1500,24 +1500,28 @@ def token_attention_supported(q, k):
             and q.is_contiguous() and q.data_ptr() % 16 == 0)
 
 
-def token_attention_forward(q, k, v, scale):
-    """softmax(scale q_h K_h) V_h per point and head: q [n, H, hd], k / v [H, hd, L] -> [n, H, hd] (ls3d_token_attention_forward)"""
+def token_attention_forward(q, k, v, scale, out=None):
+    """softmax(scale q_h K_h) V_h per point and head: q [n, H, hd], k / v [H, hd, L] -> [n, H, hd] (ls3d_token_attention_forward); out: a row slice
+    of a caller's buffer (the frames of a batch write one output)"""
     n, H, hd = q.shape
-    out = torch.empty_like(q)
-    check(_L().ls3d_token_attention_forward(_ptr(q), n, H, hd, _ptr(k.contiguous()), _ptr(v.contiguous()), k.shape[2], ctypes.c_float(scale), _ptr(out),
+    if out is None:
+        out = torch.empty_like(q)
+    check(_L().ls3d_token_attention_forward(_vp_any(q), n, H, hd, _ptr(k.contiguous()), _ptr(v.contiguous()), k.shape[2], ctypes.c_float(scale), _vp_any(out),
                                             _stream(q)), "ls3d_token_attention_forward")
     return out
 
 
-def token_attention_backward(q, dout, k, v, scale):
-    """-> (dq [n, H, hd], dk [H, hd, L], dv [H, hd, L]) of token_attention_forward, the probabilities recomputed from q (ls3d_token_attention_backward)"""
+def token_attention_backward(q, dout, k, v, scale, dq=None):
+    """-> (dq [n, H, hd], dk [H, hd, L], dv [H, hd, L]) of token_attention_forward, the probabilities recomputed from q (ls3d_token_attention_backward);
+    q / dout / dq may be row slices of the batch's buffers"""
     n, H, hd = q.shape
     L = k.shape[2]
-    dq = torch.empty_like(q)
+    if dq is None:
+        dq = torch.empty_like(q)
     dk = torch.empty((H, hd, L), dtype=torch.float32, device=q.device)
     dv = torch.empty((H, hd, L), dtype=torch.float32, device=q.device)
     ws = _ws(_L().ls3d_token_attention_workspace_bytes(n, H, L), q)
-    check(_L().ls3d_token_attention_backward(_ptr(q), _ptr(dout), n, H, hd, _ptr(k.contiguous()), _ptr(v.contiguous()), L, ctypes.c_float(scale), _ptr(dq),
+    check(_L().ls3d_token_attention_backward(_vp_any(q), _vp_any(dout), n, H, hd, _ptr(k.contiguous()), _ptr(v.contiguous()), L, ctypes.c_float(scale), _vp_any(dq),
                                              _ptr(dk), _ptr(dv), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(q)), "ls3d_token_attention_backward")
     return dq, dk, dv
 

@@ -477,42 +477,55 @@ class SemanticFeatureFusionModule(PackedModule):
 
 
 class _TokenAttention(torch.autograd.Function):
-    """softmax(q k / sqrt(hd)) v of n points against L class tokens per head (context_module.py:222-257) on csrc/tokenattn.hip: one thread per
-    (point, head) with its scores in registers, nothing kept from the forward (the backward recomputes the probabilities from q); the token-side
-    gradients d k and d v - 10^5 points reduced into hd x L matrices per head - inside the same kernel on the matrix pipe.  torch ran this as
-    batched GEMMs with 32 x 32 macro tiles plus six passes over [n, H, L] tensors: 1.8 ms per frame and layer, 14 ms of a Waymo step.  Shapes the
-    kernels do not take (ops.token_attention_supported) run the same algebra on torch, the token-side reductions on ops.linear_wgrad."""
+    """softmax(q k / sqrt(hd)) v of the points of a BATCH against each frame's L class tokens per head (context_module.py:222-257) on
+    csrc/tokenattn.hip: q [n, H, hd] frame-sorted rows, k / v [B, H, hd, L], off = the frames' row offsets (host list).  One thread per (point,
+    head) with its scores in registers, nothing kept from the forward (the backward recomputes the probabilities from q); the token-side gradients
+    d k and d v - 10^5 points reduced into hd x L matrices per head - inside the same kernel on the matrix pipe.  The frames write ONE output / ONE
+    d q (row slices handed to the kernels: no cat, no slice copies).  torch ran this as batched GEMMs with 32 x 32 macro tiles plus six passes over
+    [n, H, L] tensors: 1.8 ms per frame and layer, 14 ms of a Waymo step.  Shapes the kernels do not take (ops.token_attention_supported) run the
+    same algebra on torch, the token-side reductions on ops.linear_wgrad."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
+    def forward(ctx, q, k, v, scale, off):
         q = q.contiguous()
-        ctx.fused = ops.token_attention_supported(q, k)
-        ctx.scale = scale
+        ctx.fused = ops.token_attention_supported(q, k[0])
+        ctx.scale, ctx.off = scale, off
         if ctx.fused:
             ctx.save_for_backward(q, k, v)
-            return ops.token_attention_forward(q, k, v, scale)
-        att = torch.softmax(torch.einsum("nhd,hdl->nhl", q, k) * scale, dim=-1)
-        ctx.save_for_backward(q, k, v, att)
-        return torch.einsum("nhl,hdl->nhd", att, v)
+            out = torch.empty_like(q)
+            for b in range(k.shape[0]):
+                if off[b + 1] > off[b]:
+                    ops.token_attention_forward(q[off[b]:off[b + 1]], k[b], v[b], scale, out=out[off[b]:off[b + 1]])
+            return out
+        att = [torch.softmax(torch.einsum("nhd,hdl->nhl", q[off[b]:off[b + 1]], k[b]) * scale, dim=-1) for b in range(k.shape[0])]
+        ctx.save_for_backward(q, k, v, *att)
+        return torch.cat([torch.einsum("nhl,hdl->nhd", a, v[b]) for b, a in enumerate(att)], 0)
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v = ctx.saved_tensors[:3]
-        n, H, hd = q.shape
-        L = k.shape[2]
+        off, B = ctx.off, k.shape[0]
+        H, hd, L = q.shape[1], q.shape[2], k.shape[3]
         dout = dout.contiguous()
-        if ctx.fused:
-            dq, dk, dv = ops.token_attention_backward(q, dout, k, v, ctx.scale)
-            return dq, dk, dv, None
-        att = ctx.saved_tensors[3]
-        datt = torch.einsum("nhd,hdl->nhl", dout, v)
-        ds = att * (datt - (datt * att).sum(-1, keepdim=True)) * ctx.scale
-        dq = torch.einsum("nhl,hdl->nhd", ds, k)
+        dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        for b in range(B):
+            sl = slice(off[b], off[b + 1])
+            n = off[b + 1] - off[b]
+            if n == 0:
+                continue
+            if ctx.fused:
+                _, dk[b], dv[b] = ops.token_attention_backward(q[sl], dout[sl], k[b], v[b], ctx.scale, dq=dq[sl])
+                continue
+            att = ctx.saved_tensors[3 + b]
+            datt = torch.einsum("nhd,hdl->nhl", dout[sl], v[b])
+            ds = att * (datt - (datt * att).sum(-1, keepdim=True)) * ctx.scale
+            dq[sl] = torch.einsum("nhl,hdl->nhd", ds, k[b])
 
-        def blocks(x, gy):  # [H, hd, L]: block h of gy^T x over all heads' columns (one tall-skinny reduction, the H diagonal blocks taken)
-            full = ops.linear_wgrad(x.reshape(n, H * L).contiguous(), gy.reshape(n, H * hd))  # [H * hd, H * L]
-            return torch.stack([full[h * hd:(h + 1) * hd, h * L:(h + 1) * L] for h in range(H)], 0)
-        return dq, blocks(ds, q), blocks(att, dout), None
+            def blocks(x, gy):  # [H, hd, L]: block h of gy^T x over all heads' columns (one tall-skinny reduction, the H diagonal blocks taken)
+                full = ops.linear_wgrad(x.reshape(n, H * L).contiguous(), gy.reshape(n, H * hd).contiguous())  # [H * hd, H * L]
+                return torch.stack([full[h * hd:(h + 1) * hd, h * L:(h + 1) * L] for h in range(H)], 0)
+            dk[b], dv[b] = blocks(ds, q[sl]), blocks(att, dout[sl])
+        return dq, dk, dv, None, None
 
 
 def _sffm_forward_train(self, x, emb1, emb2, batch_idx, batch_size, return_context=False):
@@ -532,15 +545,15 @@ def _sffm_forward_train(self, x, emb1, emb2, batch_idx, batch_size, return_conte
         q = ca.q_proj(tgt).view(-1, H, hd)
         kv_in = mem.permute(1, 2, 0)  # [B, E, L]; the [B,E,L] result is then VIEWED as [B,H,hd,L] like the reference
         k, v = ca.k_proj(kv_in).reshape(B, H, hd, L), ca.v_proj(kv_in).reshape(B, H, hd, L)
-        rows = []
-        for b in range(B):
-            qb = q[off[b]:off[b + 1]]
-            if qb.is_cuda and qb.shape[0] >= 32768 and torch.is_grad_enabled():
-                rows.append(_TokenAttention.apply(qb, k[b], v[b], hd ** -0.5))
-                continue
-            att = torch.softmax(torch.einsum("nhd,hdl->nhl", qb, k[b]) * hd ** -0.5, dim=-1)
-            rows.append(torch.einsum("nhl,hdl->nhd", att, v[b]))
-        tgt = l.norm2(tgt + drop(ca.out_proj(torch.cat(rows, 0).reshape(-1, H * hd))))
+        if q.is_cuda and q.shape[0] >= 32768 * B and torch.is_grad_enabled():
+            att_out = _TokenAttention.apply(q, k, v, hd ** -0.5, off)  # every frame of the batch: one output, one d q
+        else:
+            rows = []
+            for b in range(B):
+                att = torch.softmax(torch.einsum("nhd,hdl->nhl", q[off[b]:off[b + 1]], k[b]) * hd ** -0.5, dim=-1)
+                rows.append(torch.einsum("nhl,hdl->nhd", att, v[b]))
+            att_out = torch.cat(rows, 0)
+        tgt = l.norm2(tgt + drop(ca.out_proj(att_out.reshape(-1, H * hd))))
         tgt = l.norm3(tgt + drop(l.linear2(drop(F.relu(l.linear1(tgt))))))
     tgt = self.decoder.norm_tgt(tgt)
     return (tgt, mem) if return_context else tgt

@@ -1009,7 +1009,7 @@ def test_token_attention_full_size_gpu(L):
     v = torch.randn(H, hd, L, device=DEV).requires_grad_()
     g = torch.randn(n, H, hd, device=DEV)
     assert ops.token_attention_supported(q, k)
-    out = _TokenAttention.apply(q, k, v, hd ** -0.5)
+    out = _TokenAttention.apply(q, k[None], v[None], hd ** -0.5, [0, n])
     out.backward(g)
     qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
     ref = torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", qd, kd) * hd ** -0.5, dim=-1), vd)
@@ -1029,7 +1029,7 @@ def test_token_attention_full_size_gpu(L):
         return e0.elapsed_time(e1) / 5
 
     def fused():
-        _TokenAttention.apply(q, k, v, hd ** -0.5).backward(g)
+        _TokenAttention.apply(q, k[None], v[None], hd ** -0.5, [0, n]).backward(g)
 
     def composed():
         torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", q, k) * hd ** -0.5, dim=-1), v).backward(g)

@@ -94,7 +94,7 @@ def test_token_attention_kernels_vs_torch_autograd(L, n):
     v = torch.from_numpy(rng.normal(size=(H, hd, L)).astype(np.float32)).requires_grad_()
     g = torch.from_numpy(rng.normal(size=(n, H, hd)).astype(np.float32))
     assert ops.token_attention_supported(q, k)
-    out = _TokenAttention.apply(q, k, v, hd ** -0.5)
+    out = _TokenAttention.apply(q, k[None], v[None], hd ** -0.5, [0, n])
     out.backward(g)
     qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
     ref = torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", qd, kd) * hd ** -0.5, dim=-1), vd)
@@ -102,10 +102,24 @@ def test_token_attention_kernels_vs_torch_autograd(L, n):
     for name, got, want in (("out", out, ref), ("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
         err = float((got.detach().double() - want.detach()).abs().max()) / float(want.detach().abs().max())
         assert err <= 2e-6, (name, err)
+    # a batch of two frames (ragged, each with its own tokens): one output / one d q, the frames' slices handed to the kernels
+    off = [0, n // 3, n]
+    kb = torch.from_numpy(rng.normal(size=(2, H, hd, L)).astype(np.float32)).requires_grad_()
+    vb = torch.from_numpy(rng.normal(size=(2, H, hd, L)).astype(np.float32)).requires_grad_()
+    q2 = q.detach().clone().requires_grad_()
+    ob = _TokenAttention.apply(q2, kb, vb, hd ** -0.5, off)
+    ob.backward(g)
+    qd, kd, vd = (t.detach().double().requires_grad_() for t in (q2, kb, vb))
+    refb = torch.cat([torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", qd[off[b]:off[b + 1]], kd[b]) * hd ** -0.5, dim=-1), vd[b])
+                      for b in range(2)], 0)
+    refb.backward(g.double())
+    for name, got, want in (("out", ob, refb), ("dq", q2.grad, qd.grad), ("dk", kb.grad, kd.grad), ("dv", vb.grad, vd.grad)):
+        err = float((got.detach().double() - want.detach()).abs().max()) / float(want.detach().abs().max())
+        assert err <= 2e-6, ("batch", name, err)
     # 50 tokens: not a compiled token count -> the torch branch
     k2 = torch.from_numpy(rng.normal(size=(H, hd, 50)).astype(np.float32))
     assert not ops.token_attention_supported(q, k2)
-    o2 = _TokenAttention.apply(q.detach(), k2, k2, hd ** -0.5)
+    o2 = _TokenAttention.apply(q.detach(), k2[None], k2[None], hd ** -0.5, [0, n])
     r2 = torch.einsum("nhl,hdl->nhd", torch.softmax(torch.einsum("nhd,hdl->nhl", q.detach(), k2) * hd ** -0.5, dim=-1), k2)
     assert float((o2 - r2).abs().max()) <= 1e-5
 
