@@ -148,6 +148,9 @@ __global__ __launch_bounds__(256) void k_tile_rowtile(const int32_t *__restrict_
 // one workgroup per tile.  The tile's distinct input rows: the <= kvol*128 table entries go through an LDS hash set (insertion
 // order is arbitrary, the SET is not), the occupied slots are compacted and only that list (a few hundred rows) is sorted
 // (bitonic), so the halo list, and with it every local index, is the same on every run.
+// COLOR: the build with the coloured layout compiled in (it needs 250 registers: two workgroups per CU instead of three - 88 instead of 70 us per
+// call - so the plain build stays a kernel of its own)
+template <bool COLOR>
 __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ tbl, int n, const int32_t *n_dev, int kvol,
                                                     const int32_t *__restrict__ sorder, const int32_t *__restrict__ coords, TilePlan p) {
   constexpr int NC = TC_KMAX * TC_TR;  // 4096 candidate slots
@@ -157,10 +160,12 @@ __global__ __launch_bounds__(256) void k_tile_build(const int32_t *__restrict__ 
   __shared__ int s_hash[HS];
   __shared__ int s_uniq[NC];
   __shared__ int s_scan[2][256];
-  __shared__ int s_ch[16 * 16], s_exc[16], s_col[TC_TR], s_cw[4 * 16], s_run[16], s_cnt2[2];
+  __shared__ int s_col[TC_TR];
+  // the coloured layout's scratch lives in arrays that are dead while it is needed (no more than the one array the plain build can afford beside its three workgroups per CU): the candidates' colour histograms in s_uniq (empty until the compaction), the rest in the second scan row
+  int *const s_ch = s_uniq, *const s_exc = &s_scan[1][0], *const s_cw = &s_scan[1][32], *const s_run = &s_scan[1][96], *const s_cnt2 = &s_scan[1][112];
   const int tid = threadIdx.x;
   const int N = ls3d_count(n, n_dev);
-  const bool colored = coords != nullptr && kvol == 27;  // the coloured layout (see tc_color)
+  const bool colored = COLOR && coords != nullptr && kvol == 27;  // the coloured layout (see tc_color)
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     __syncthreads();
     if (tid < TC_TR) {
@@ -474,7 +479,7 @@ extern "C" int ls3d_tile_build(const int32_t *tbl, int n_rows, const int32_t *n_
   if (n_rows == 0) return LS3D_OK;
   TilePlan p = tc_plan(plan, n_rows, kvol);
   hipLaunchKernelGGL(k_tile_rowtile, ls3d_grid(n_rows), dim3(256), 0, (hipStream_t)stream, spatial_order, n_rows, n_rows_dev, p.rowtile);
-  hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, (hipStream_t)stream, tbl, n_rows, n_rows_dev,
+  hipLaunchKernelGGL(k_tile_build<false>, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, (hipStream_t)stream, tbl, n_rows, n_rows_dev,
                      kvol, spatial_order, (const int32_t *)nullptr, p);
   hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, (flags & 1) ? 0 : 1);
   LS3D_RETURN_IF_LAUNCH_FAILED();
@@ -512,8 +517,12 @@ extern "C" int ls3d_tile_plan(const int32_t *tbl, const int32_t *coords, int n_r
   if (rc != LS3D_OK) return rc;
   TilePlan p = tc_plan(plan, n_rows, kvol);
   hipLaunchKernelGGL(k_tile_rowtile, ls3d_grid(n_rows), dim3(256), 0, stream, (const int32_t *)order, n_rows, n_rows_dev, p.rowtile);
-  hipLaunchKernelGGL(k_tile_build, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, stream, tbl, n_rows, n_rows_dev, kvol,
-                     (const int32_t *)order, (flags & 2) ? coords : (const int32_t *)nullptr, p);
+  if ((flags & 2) && kvol == 27)
+    hipLaunchKernelGGL(k_tile_build<true>, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, stream, tbl, n_rows, n_rows_dev, kvol,
+                       (const int32_t *)order, coords, p);
+  else
+    hipLaunchKernelGGL(k_tile_build<false>, dim3((unsigned)(p.ntiles < 8192 ? p.ntiles : 8192)), dim3(256), 0, stream, tbl, n_rows, n_rows_dev, kvol,
+                       (const int32_t *)order, (const int32_t *)nullptr, p);
   hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, p, (flags & 1) ? 0 : 1);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
