@@ -113,6 +113,26 @@ int ls3d_dynamic_scatter_backward(const float *grad_voxels, const int32_t *point
                                   const float *feats_in, const float *feats_out, void *workspace, size_t workspace_bytes,
                                   float *grad_points, ls3d_stream_t stream);
 
+/* voxel_layer.dynamic_point_to_voxel_forward / _backward with the reference's own argument shapes (det3d/ops/voxel/src/voxelization.h:63-111,
+ * bound at voxelization.cpp:6-11; CUDA: scatter_points_cuda.cu:142-282), for a maintainer who replaces `voxel_layer` function by function
+ * (the module path above - ls3d_dynamic_scatter - never materialises the padded tensor):
+ *   _index   : voxel_mapping[n, ndim] (ndim 3 = (z,y,x) or 4 = (batch,z,y,x); rows with a negative coordinate are outside) ->
+ *              point_to_voxelidx[n] (slot of the point inside its voxel, point order; -1 outside), coor_to_voxelidx[n] (voxel of the point,
+ *              first-appearance order; -1 outside), num_points_per_voxel[n] (first voxel_num entries), voxel_coors[n, ndim],
+ *              counts_dev[2] = (voxel_num, max_points = the fullest voxel's count).  The reference copies the same two counts to the host
+ *              between its kernels (scatter_points_cuda.cu:218-221) to size `voxels`; here the caller does, then calls
+ *   _forward : voxels[voxel_num, max_points, n_feat] = zero padded scatter of points[n, n_feat] (scatter_point_to_voxel_kernel, :20-48);
+ *   _backward: grad_input_points[i] = grad_output_voxels[coor_to_voxelidx[i], point_to_voxelidx[i]] for the points inside, other rows
+ *              untouched (map_voxel_to_point_kernel, :50-69; the caller passes zeros, scatter_points.py:57-63). */
+size_t ls3d_dynamic_point_to_voxel_workspace_bytes(int n);
+int ls3d_dynamic_point_to_voxel_index(const int32_t *voxel_mapping, int n, int ndim, const int32_t shape_zyx_host[3], void *workspace,
+                                      size_t workspace_bytes, int32_t *point_to_voxelidx, int32_t *coor_to_voxelidx,
+                                      int32_t *num_points_per_voxel, int32_t *voxel_coors, int32_t *counts_dev, ls3d_stream_t stream);
+int ls3d_dynamic_point_to_voxel_forward(const float *points, int n, int n_feat, const int32_t *point_to_voxelidx, const int32_t *coor_to_voxelidx,
+                                        int voxel_num, int max_points, float *voxels, ls3d_stream_t stream);
+int ls3d_dynamic_point_to_voxel_backward(float *grad_input_points, const float *grad_output_voxels, const int32_t *point_to_voxelidx,
+                                         const int32_t *coor_to_voxelidx, int n, int n_feat, int max_points, ls3d_stream_t stream);
+
 size_t ls3d_segment_reduce_workspace_bytes(int n, int n_seg);
 
 /* Segment mean / max over dim 0: out[n_seg,n_feat] from src[n,n_feat] and one int64 segment id per row (mode 0 = mean,
@@ -122,6 +142,57 @@ size_t ls3d_segment_reduce_workspace_bytes(int n, int n_seg);
  * dependency absent from the reference tree).  Ids outside [0, n_seg) are skipped. */
 int ls3d_segment_reduce(const float *src, const int64_t *index, int n, int n_feat, int n_seg, int mode, void *workspace,
                         size_t workspace_bytes, float *out, int64_t *arg_out, ls3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The dynamic (point-wise) readers and the Cylinder3D blocks: SURVEY.md 8f rank 4
+ * ---------------------------------------------------------------------------------------------- */
+
+/* cart2cylind + voxelize of PolarNetDynamicVoxelFeatureExtractor / Cylinder3DDynamicVoxelFeatureExtractor
+ * (det3d/models/readers/voxel_encoder.py:11-18,333-360,563-590): points[n, stride] = (batch, x, y, z, features...);
+ *   cyl5[n, 5]   = (rho = sqrt(x*x + y*y), phi = atan2(y, x), z, x, y) - the five columns the readers centre on their voxel mean;
+ *   vcoors[n, 4] = (batch, cell columns) int64, cell_j = clamp(int(floor((cyl_j - lo_j) / vs_j)), 0, grid_j - 1) (f32 subtraction and
+ *                  division; the reference clamps BEFORE its range test, so every point is inside), columns (c0, c1, c2) or - reverse != 0,
+ *                  Cylinder3D - (c2, c1, c0);
+ *   keys[n]      = the row linearised in that column order (collapse_last != 0, PolarNet: last column = grid[2] / 2 for every point),
+ *                  so that sorting the keys is torch.unique(dim=0)'s lexicographic row order.  LS3D_ERR_UNSUPPORTED when
+ *                  batch * grid cells >= 2^32.
+ * phi is atan2 evaluated in double and rounded once; torch's f32 atan2 may differ from it by an ulp, which moves a point that sits within
+ * ~1e-5 of a cell boundary into the neighbouring cell (the reference's CPU and CUDA builds differ from each other in the same way). */
+int ls3d_cyl_voxelize(const float *points, int n, int stride, const ls3d_grid_t *grid_host, int reverse, int collapse_last, int batch, float *cyl5,
+                      int64_t *vcoors, uint32_t *keys, ls3d_stream_t stream);
+
+/* torch.unique(rows, return_inverse=True, return_counts=True, dim=0) (voxel_encoder.py:441,670) from the SORTED keys of ls3d_cyl_voxelize
+ * (ls3d_radix_sort: keys_sorted, perm = source positions): inverse[n] (int64, indexed by the unsorted position), unique_rows[n, 4]
+ * (int64, the key decoded with dims_host = the sizes of its last three columns), counts[n] (int64), *n_unique_dev; the first
+ * *n_unique_dev rows of unique_rows / counts are valid.  workspace: ls3d_unique_sorted_workspace_bytes(n). */
+size_t ls3d_unique_sorted_workspace_bytes(int n);
+int ls3d_unique_sorted(const uint32_t *keys_sorted, const int32_t *perm, int n, const int32_t dims_host[3], void *workspace, size_t workspace_bytes,
+                       int64_t *inverse, int64_t *unique_rows, int64_t *counts, int32_t *n_unique_dev, ls3d_stream_t stream);
+
+/* prepare_input_feature (voxel_encoder.py:362-386,592-616) for every point, then x * scale + shift (PPmodel's leading BatchNorm1d in
+ * eval mode; NULL = none): out[n, out_ld] = [cyl5 (5), points[:, 4:] (stride - 4), cyl5 - mean5[inverse] (5), cyl - voxel centre (3)],
+ * zero padded to out_ld >= stride + 9 columns; mean5[V, 5] = ls3d_segment_reduce(cyl5, inverse, mean); the voxel centre is
+ * common_utils.get_voxel_centers on the three stored cell columns of vcoors, whatever their order (core/utils/common_utils.py:74-90). */
+int ls3d_dyn_point_features(const float *points, int n, int stride, const float *cyl5, const int64_t *vcoors, const int64_t *inverse,
+                            const float *mean5, const ls3d_grid_t *grid_host, const float *scale, const float *shift, float *out, int out_ld,
+                            ls3d_stream_t stream);
+
+/* Test-time-augmentation merge of PointSegBatchlossHead.predict / PointSegMSeg3DHead.predict (det3d/models/point_heads/
+ * point_seg_batchloss_head.py:190-245, point_seg_mseg3d_head.py:398-453, merge_type "ArithmeticMean"): the k augmented variants of one sample
+ * are k frames of n points each inside the collated batch, variant t starting at row variant_first_row_host[t] of logits[*, ld];
+ * probs_out[n, num_class] (may be NULL) = mean over t of softmax(logits[first_t + p]), labels_out[n] (int64) = its argmax (first index on
+ * ties).  One pass, no boolean masks, no [k, n, C] intermediate.  k <= 16; num_class <= 64 (LS3D_ERR_UNSUPPORTED beyond). */
+int ls3d_tta_merge(const float *logits, int ld, int num_class, int n, const int32_t *variant_first_row_host, int k, float *probs_out,
+                   int64_t *labels_out, ls3d_stream_t stream);
+
+/* y[r, c] = post(pre(x[r, c]) * scale[c] + shift[c]) [+ add[r, c]] [* mul[r, c]] over n rows (n_dev: device count, optional) of c columns:
+ * the tails of the Cylinder3D blocks - convolution, LeakyReLU, BatchNorm1d in THAT order, the residual sums, ReconBlock's sigmoid gates
+ * times its input (det3d/models/backbones/scn_unet_cylinder3d.py:52-252, cylinder3d_backbone.py:50-252) - which the BN -> ReLU epilogue
+ * of the gather-GEMM does not cover.  pre_act / post_act: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 sigmoid; scale / shift / add / mul
+ * may be NULL; y may alias x.  float4 accesses when c and every row stride are multiples of 4 and the pointers 16-byte aligned. */
+int ls3d_act_affine(const float *x, int x_ld, int n, const int32_t *n_dev, int c, int pre_act, int post_act, float slope, const float *scale,
+                    const float *shift, const float *add, int add_ld, const float *mul, int mul_ld, float *y, int y_ld, ls3d_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Voxel feature extractors (readers)

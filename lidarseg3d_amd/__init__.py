@@ -14,7 +14,7 @@ from .registry import (BACKBONES, DETECTORS, POINT_HEADS, READERS, Registry, bui
 
 def register_all():
     """import the modules that register the hot-path components (needs torch; loads libls3d lazily on first op)"""
-    from . import detectors, img_heads, point_heads, readers, scn_unet  # noqa: F401
+    from . import detectors, img_heads, point_heads, readers, scn_unet, sparse_backbones  # noqa: F401
 
 
 register_all()

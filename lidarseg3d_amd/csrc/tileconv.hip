@@ -643,6 +643,11 @@ __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, con
   if (e.scale) sc = *(const float4 *)(e.scale + occ);
   if (e.shift) sh = *(const float4 *)(e.shift + occ);
   __syncthreads();
+  // rows of a partial tile that do not exist (s_rows < 0) still issue the branch-free operand loads.  In a chained launch they must read a
+  // row THIS tile's own dependencies cover - its first slot, live in every live tile (k_tile_build puts the empty slots last) - not row 0
+  // of the buffer: that row belongs to some other tile, which may still be writing it, and an ordinary cached load would leave a stale
+  // line of it in this XCD's L2 for a later halo / pair load of the same launch to hit.
+  const int dead_row = CH ? s_rows[0] : 0;
 #pragma unroll
   for (int b0 = 0; b0 < ITER; b0 += BATCH) {
     int orow[BATCH];
@@ -652,12 +657,12 @@ __device__ __forceinline__ void tc_epilogue(f32x16 (&acc)[NT], float *stage, con
     {
     if (e.res_pre) {
 #pragma unroll
-      for (int j = 0; j < BATCH; ++j) q[j] = *(const float4 *)(e.res_pre + (size_t)(orow[j] >= 0 ? orow[j] : 0) * e.res_pre_ld + occ);
+      for (int j = 0; j < BATCH; ++j) q[j] = *(const float4 *)(e.res_pre + (size_t)(orow[j] >= 0 ? orow[j] : dead_row) * e.res_pre_ld + occ);
     }
     if (e.pair) {
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
-        const float *pp = e.pair + (size_t)(orow[j] >= 0 ? orow[j] : 0) * e.pair_ld + 2 * occ;
+        const float *pp = e.pair + (size_t)(orow[j] >= 0 ? orow[j] : dead_row) * e.pair_ld + 2 * occ;
         p0[j] = *(const float4 *)pp;
         p1[j] = *(const float4 *)(pp + 4);
       }

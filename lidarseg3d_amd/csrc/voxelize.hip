@@ -568,6 +568,120 @@ extern "C" int ls3d_dynamic_scatter_backward(const float *grad_voxels, const int
   return LS3D_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ dynamic_point_to_voxel_{forward,backward}
+// The two remaining functions of the reference's `voxel_layer` module with their own argument shapes (det3d/ops/voxel/src/voxelization.h:63-111,
+// bound at voxelization.cpp:6-11; CUDA: scatter_points_cuda.cu:142-282): the padded voxels[V, M, C] tensor, point_to_voxelidx (a point's slot
+// inside its voxel), coor_to_voxelidx (its voxel).  The reference sizes voxels from two device counts it copies to the host between its
+// kernels (scatter_points_cuda.cu:218-221); a C ABI that never allocates splits at exactly that point: ls3d_dynamic_point_to_voxel_index
+// leaves (voxel_num, max_points) on the device, the caller reads them, allocates and calls ls3d_dynamic_point_to_voxel_forward.
+// Voxel ids are first-appearance order, slots the point order inside a voxel (what the O(N^2) search + the <<<1,1>>> kernel of the
+// reference compute, scatter_points_cuda.cu:72-138); M = the fullest voxel's count as the CPU twin computes it (scatter_points_cpu.cpp:28-31;
+// the CUDA kernel leaves M = 0 when no voxel holds two points, :131 - a zero-width tensor - not reproduced).
+__global__ __launch_bounds__(256) void k_p2v_keys(int n, const int32_t *slot_of_pt, const int32_t *slot_vid, int32_t *coor_to_voxelidx, uint32_t *keys) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int s = slot_of_pt[i];
+    const int v = s >= 0 ? slot_vid[s] : -1;
+    coor_to_voxelidx[i] = v;
+    keys[i] = v >= 0 ? (uint32_t)v : 0x7FFFFFFFu;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_p2v_slots(int n, const uint32_t *skeys, const int32_t *perm, const int32_t *start, const int32_t *end,
+                                                  int32_t *point_to_voxelidx, int32_t *num_points_per_voxel, int32_t *counts) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const uint32_t v = skeys[p];
+    if (v >= (uint32_t)n) continue;  // points outside the grid keep slot -1
+    const int a = start[v];
+    point_to_voxelidx[perm[p]] = p - a;  // the stable sort keeps a voxel's points in point order
+    if (p == a) {
+      num_points_per_voxel[v] = end[v] - a;
+      atomicMax(&counts[1], end[v] - a);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_p2v_scatter(const float *points, int n, int C, const int32_t *p2v, const int32_t *c2v, int M, float *voxels) {
+  const long long work = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / C), k = (int)(t % C);
+    const int num = p2v[i], v = c2v[i];
+    if (num > -1 && v > -1 && num < M) voxels[((size_t)v * M + num) * C + k] = points[t];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_p2v_gather(float *grad_points, int n, int C, const float *grad_voxels, const int32_t *p2v, const int32_t *c2v, int M) {
+  const long long work = (long long)n * C;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < work; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / C), k = (int)(t % C);
+    const int num = p2v[i];
+    if (num > -1 && num < M) grad_points[t] = grad_voxels[((size_t)c2v[i] * M + num) * C + k];  // map_voxel_to_point_kernel: other rows untouched
+  }
+}
+
+extern "C" size_t ls3d_dynamic_point_to_voxel_workspace_bytes(int n) { return ds_ws_layout(nullptr, n > 0 ? n : 1).bytes; }
+
+extern "C" int ls3d_dynamic_point_to_voxel_index(const int32_t *voxel_mapping, int n, int ndim, const int32_t shape_zyx[3], void *workspace,
+                                                 size_t workspace_bytes, int32_t *point_to_voxelidx, int32_t *coor_to_voxelidx,
+                                                 int32_t *num_points_per_voxel, int32_t *voxel_coors, int32_t *counts_dev, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!counts_dev || !shape_zyx || n < 0 || (ndim != 3 && ndim != 4)) return LS3D_ERR_ARG;
+  hipMemsetAsync(counts_dev, 0, 8, stream);
+  if (n == 0) return LS3D_OK;
+  if (!voxel_mapping || !workspace || !point_to_voxelidx || !coor_to_voxelidx || !num_points_per_voxel || !voxel_coors) return LS3D_ERR_ARG;
+  DsWs w = ds_ws_layout((char *)workspace, n);
+  if (workspace_bytes < w.bytes) return LS3D_ERR_WORKSPACE;
+  hipMemsetAsync(w.keys, 0xFF, (size_t)w.cap * 8, stream);
+  hipMemsetAsync(w.first_pt, 0x7F, (size_t)w.cap * 4, stream);
+  hipMemsetAsync(w.slot_vid, 0xFF, (size_t)w.cap * 4, stream);
+  hipMemsetAsync(point_to_voxelidx, 0xFF, (size_t)n * 4, stream);
+  hipMemsetAsync(num_points_per_voxel, 0, (size_t)n * 4, stream);
+  const dim3 gp = ls3d_grid(n), blk(256);
+  hipLaunchKernelGGL(k_ds_insert, gp, blk, 0, stream, voxel_mapping, n, ndim, shape_zyx[0], shape_zyx[1], shape_zyx[2], w.keys, w.cap - 1, w.first_pt,
+                     w.slot_of_pt);
+  hipLaunchKernelGGL(k_vox_flag, gp, blk, 0, stream, n, (const int32_t *)w.slot_of_pt, (const int32_t *)w.first_pt, w.flag);
+  int rc = ls3d_exclusive_scan_i32(w.flag, w.vid, n, w.scan_tmp, w.total, stream);
+  if (rc != LS3D_OK) return rc;
+  hipLaunchKernelGGL(k_ds_assign, gp, blk, 0, stream, n, (const int32_t *)w.flag, (const int32_t *)w.vid, (const int32_t *)w.slot_of_pt, voxel_mapping, ndim,
+                     w.slot_vid, voxel_coors, (const int32_t *)w.total, counts_dev);
+  hipLaunchKernelGGL(k_p2v_keys, gp, blk, 0, stream, n, (const int32_t *)w.slot_of_pt, (const int32_t *)w.slot_vid, coor_to_voxelidx, w.seg.keys);
+  int bits = 1;
+  while ((1u << bits) <= (unsigned)n && bits < 31) ++bits;
+  rc = ls3d_radix_sort_pairs(w.seg.keys, nullptr, n, nullptr, bits, w.seg.skeys, w.seg.perm, w.seg.sort_ws, w.seg.sort_bytes, stream);
+  if (rc != LS3D_OK) return rc;
+  hipMemsetAsync(w.seg.start, 0, (size_t)(n + 1) * 4, stream);
+  hipMemsetAsync(w.seg.end, 0, (size_t)(n + 1) * 4, stream);
+  hipLaunchKernelGGL(k_seg_bounds, gp, blk, 0, stream, (const uint32_t *)w.seg.skeys, n, n, w.seg.start, w.seg.end);
+  hipLaunchKernelGGL(k_p2v_slots, gp, blk, 0, stream, n, (const uint32_t *)w.seg.skeys, (const int32_t *)w.seg.perm, (const int32_t *)w.seg.start,
+                     (const int32_t *)w.seg.end, point_to_voxelidx, num_points_per_voxel, counts_dev);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_dynamic_point_to_voxel_forward(const float *points, int n, int n_feat, const int32_t *point_to_voxelidx, const int32_t *coor_to_voxelidx,
+                                                   int voxel_num, int max_points, float *voxels, ls3d_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || n_feat < 1 || voxel_num < 0 || max_points < 0) return LS3D_ERR_ARG;
+  const size_t cells = (size_t)voxel_num * max_points * n_feat;
+  if (cells == 0 || n == 0) return LS3D_OK;
+  if (!points || !point_to_voxelidx || !coor_to_voxelidx || !voxels) return LS3D_ERR_ARG;
+  hipMemsetAsync(voxels, 0, cells * 4, stream);
+  hipLaunchKernelGGL(k_p2v_scatter, ls3d_grid((long long)n * n_feat), dim3(256), 0, stream, points, n, n_feat, point_to_voxelidx, coor_to_voxelidx, max_points,
+                     voxels);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
+extern "C" int ls3d_dynamic_point_to_voxel_backward(float *grad_input_points, const float *grad_output_voxels, const int32_t *point_to_voxelidx,
+                                                    const int32_t *coor_to_voxelidx, int n, int n_feat, int max_points, ls3d_stream_t stream_) {
+  if (n < 0 || n_feat < 1 || max_points < 0) return LS3D_ERR_ARG;
+  if (n == 0 || max_points == 0) return LS3D_OK;
+  if (!grad_input_points || !grad_output_voxels || !point_to_voxelidx || !coor_to_voxelidx) return LS3D_ERR_ARG;
+  hipLaunchKernelGGL(k_p2v_gather, ls3d_grid((long long)n * n_feat), dim3(256), 0, (hipStream_t)stream_, grad_input_points, n, n_feat, grad_output_voxels,
+                     point_to_voxelidx, coor_to_voxelidx, max_points);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ segment reductions
 // What the dynamic readers (det3d/models/readers/voxel_encoder.py:366-372,451-456,594-600,682-686) ask of torch_scatter
 // (third-party, absent from the reference tree: scatter_mean / scatter_max over dim 0 with an int64 segment id per row, e.g.

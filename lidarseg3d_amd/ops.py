@@ -137,6 +137,120 @@ def dynamic_scatter_backward(grad_voxels, p2v, feats_in, feats_out, mode="mean")
     return gp
 
 
+def dynamic_point_to_voxel_index(voxel_mapping, shape_zyx):
+    """voxel_mapping [n, 3 or 4] int32 -> point_to_voxelidx [n], coor_to_voxelidx [n], num_points_per_voxel [n], voxel_coors [n, cols],
+    counts [2] = (voxel_num, max_points) on the device (include/ls3d.h: ls3d_dynamic_point_to_voxel_index)"""
+    n, cols = voxel_mapping.shape
+    dev = voxel_mapping.device
+    p2v, c2v, num = (torch.empty((max(n, 1),), dtype=_i32, device=dev) for _ in range(3))
+    vc = torch.empty((max(n, 1), cols), dtype=_i32, device=dev)
+    counts = torch.zeros((2,), dtype=_i32, device=dev)
+    L = _L()
+    ws = _ws(L.ls3d_dynamic_point_to_voxel_workspace_bytes(n), voxel_mapping)
+    check(L.ls3d_dynamic_point_to_voxel_index(_ptr(voxel_mapping), n, cols, _i3(shape_zyx), _ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(p2v), _ptr(c2v),
+                                              _ptr(num), _ptr(vc), _ptr(counts), _stream(voxel_mapping)), "ls3d_dynamic_point_to_voxel_index")
+    return p2v[:n], c2v[:n], num, vc, counts
+
+
+def dynamic_point_to_voxel_forward(points, p2v, c2v, voxel_num, max_points):
+    """-> voxels [voxel_num, max_points, C], zero padded (ls3d_dynamic_point_to_voxel_forward)"""
+    n, c = points.shape
+    voxels = torch.empty((int(voxel_num), int(max_points), c), dtype=torch.float32, device=points.device)
+    check(_L().ls3d_dynamic_point_to_voxel_forward(_ptr(points), n, c, _ptr(p2v), _ptr(c2v), int(voxel_num), int(max_points), _ptr(voxels), _stream(points)),
+          "ls3d_dynamic_point_to_voxel_forward")
+    return voxels
+
+
+def dynamic_point_to_voxel_backward(grad_points, grad_voxels, p2v, c2v):
+    """in place: grad_points[i] = grad_voxels[c2v[i], p2v[i]] for the points inside a voxel (ls3d_dynamic_point_to_voxel_backward)"""
+    n, c = grad_points.shape
+    check(_L().ls3d_dynamic_point_to_voxel_backward(_ptr(grad_points), _ptr(grad_voxels), _ptr(p2v), _ptr(c2v), n, c, int(grad_voxels.shape[1]),
+                                                   _stream(grad_points)), "ls3d_dynamic_point_to_voxel_backward")
+    return grad_points
+
+
+# ---------------------------------------------------------------------------------------------- dynamic readers, Cylinder3D tails (csrc/dynreader.hip)
+_ACT = {None: 0, "none": 0, "relu": 1, "leaky": 2, "sigmoid": 3}
+
+
+def act_affine(x, pre=None, post=None, slope=0.01, scale=None, shift=None, add=None, mul=None, out=None, n_dev=None):
+    """out = post(pre(x) * scale + shift) [+ add] [* mul] row-wise (ls3d_act_affine); x / add / mul / out may be column views of wider buffers"""
+    n, c = x.shape
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    for t in (x, add, mul, out):
+        assert t is None or (t.stride(1) == 1 and t.shape == (n, c))
+    check(_L().ls3d_act_affine(_vp_any(x), _ld(x), n, _ndev(n_dev), c, _ACT[pre], _ACT[post], ctypes.c_float(slope), _vp(scale), _vp(shift),
+                               _vp_any(add) if add is not None else None, _ld(add) if add is not None else 0,
+                               _vp_any(mul) if mul is not None else None, _ld(mul) if mul is not None else 0, _vp_any(out), _ld(out), _stream(x)),
+          "ls3d_act_affine")
+    return out
+
+
+def tta_merge(logits, first_rows, n, want_probs=False):
+    """mean over the variants (frames of n rows starting at first_rows[t]) of softmax(logits), argmax -> labels [n] int64 (, probs [n, C])  (ls3d_tta_merge)"""
+    c = logits.shape[1]
+    labels = torch.empty((n,), dtype=torch.int64, device=logits.device)
+    probs = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_probs else None
+    rows = (ctypes.c_int32 * len(first_rows))(*[int(v) for v in first_rows])
+    check(_L().ls3d_tta_merge(_vp_any(logits), _ld(logits), c, int(n), rows, len(first_rows), _vp(probs), _ptr(labels), _stream(logits)), "ls3d_tta_merge")
+    return (labels, probs) if want_probs else labels
+
+
+def cyl_grid(grid_size, pc_range):
+    """the readers' own cell size (range / grid in double, used as f32: voxel_encoder.py:319-323,549-553) as an ls3d_grid_t"""
+    vs = [(float(pc_range[3 + i]) - float(pc_range[i])) / float(grid_size[i]) for i in range(3)]
+    return Grid(_f3(vs), _f3(pc_range[:3]), _i3(grid_size)), vs
+
+
+def cyl_voxelize(points, grid_size, pc_range, reverse, collapse_last, batch_size):
+    """points [n, 1 + 3 + f] (batch, x, y, z, ...) -> cyl5 [n, 5] f32, vcoors [n, 4] int64, keys [n] (ls3d_cyl_voxelize)"""
+    n = points.shape[0]
+    dev = points.device
+    grid, _ = cyl_grid(grid_size, pc_range)
+    cyl5 = torch.empty((n, 5), dtype=torch.float32, device=dev)
+    vcoors = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    keys = torch.empty((n,), dtype=_i32, device=dev)
+    check(_L().ls3d_cyl_voxelize(_ptr(points), n, points.shape[1], ctypes.byref(grid), 1 if reverse else 0, 1 if collapse_last else 0, int(batch_size),
+                                 _ptr(cyl5), _ptr(vcoors), _ptr(keys), _stream(points)), "ls3d_cyl_voxelize")
+    return cyl5, vcoors, keys
+
+
+def unique_rows(keys, dims, batch_size):
+    """torch.unique(rows, return_inverse=True, return_counts=True, dim=0) of the rows the uint32 keys linearise (dims = sizes of the last three
+    columns): in-library radix sort + ls3d_unique_sorted -> unique [V, 4] int64 (sorted), inverse [n] int64, counts [V] int64.  One host
+    synchronisation: V sizes the result (torch.unique has the same one)."""
+    n = keys.shape[0]
+    dev = keys.device
+    L = _L()
+    bits = max(1, int(int(batch_size) * int(dims[0]) * int(dims[1]) * int(dims[2]) - 1).bit_length())
+    skeys = torch.empty((n,), dtype=_i32, device=dev)
+    perm = torch.empty((n,), dtype=_i32, device=dev)
+    ws = _ws(L.ls3d_radix_sort_workspace_bytes(n), keys)
+    check(L.ls3d_radix_sort(_ptr(keys), None, n, None, min(32, bits), _ptr(skeys), _ptr(perm), _ptr(ws), ctypes.c_size_t(ws.numel()), _stream(keys)),
+          "ls3d_radix_sort")
+    inverse = torch.empty((n,), dtype=torch.int64, device=dev)
+    rows = torch.empty((max(n, 1), 4), dtype=torch.int64, device=dev)
+    counts = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    nu = torch.zeros((1,), dtype=_i32, device=dev)
+    ws2 = _ws(L.ls3d_unique_sorted_workspace_bytes(n), keys)
+    check(L.ls3d_unique_sorted(_ptr(skeys), _ptr(perm), n, _i3(dims), _ptr(ws2), ctypes.c_size_t(ws2.numel()), _ptr(inverse), _ptr(rows), _ptr(counts),
+                               _ptr(nu), _stream(keys)), "ls3d_unique_sorted")
+    v = int(nu.item())
+    return rows[:v], inverse, counts[:v]
+
+
+def dyn_point_features(points, cyl5, vcoors, inverse, mean5, grid_size, pc_range, scale=None, shift=None, ld=None):
+    """[n, ld] input rows of the dynamic readers' point MLP (ls3d_dyn_point_features), ld >= C + 9 columns, zero padded"""
+    n, stride = points.shape
+    ld = ld or (stride + 9 + 15) // 16 * 16
+    grid, _ = cyl_grid(grid_size, pc_range)
+    out = torch.empty((n, ld), dtype=torch.float32, device=points.device)
+    check(_L().ls3d_dyn_point_features(_ptr(points), n, stride, _ptr(cyl5), _ptr(vcoors), _ptr(inverse), _ptr(mean5), ctypes.byref(grid), _vp(scale),
+                                       _vp(shift), _ptr(out), ld, _stream(points)), "ls3d_dyn_point_features")
+    return out
+
+
 def segment_reduce(src, index, n_seg, mode="mean", want_arg=False):
     """src [n,C] f32, index [n] int64 -> out [n_seg,C] (+ arg [n_seg,C] int64 for mode "max")  (ls3d_segment_reduce)"""
     n, c = src.shape

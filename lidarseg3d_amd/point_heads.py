@@ -128,14 +128,16 @@ def _predict(head, example, test_cfg):
         k = test_cfg.get("num_tta_tranforms", 4)
         if test_cfg.get("merge_type", "ArithmeticMean") != "ArithmeticMean":
             raise NotImplementedError
-        probs = torch.softmax(logits, dim=-1)
-        masks = [pts[:, 0] == i for i in range(batch_size)]
+        # the collated batch is frame-sorted: variant t of sample j is the row range [off[j k + t], off[j k + t + 1]); one read of the frame
+        # offsets replaces the reference's per-frame boolean masks, the merge itself is one launch per sample (ls3d_tta_merge)
+        off = ops.frame_offsets(pts.contiguous(), batch_size).tolist()
         left = 0
-        for j, i in enumerate(range(0, batch_size, k)):
-            merged = torch.stack([probs[masks[t]] for t in range(i, i + k)], 0).mean(0)
-            ret = dict(metadata=meta[i], pred_point_sem_labels=torch.argmax(merged, dim=1))
+        for i in range(0, batch_size - batch_size % k, k):
+            n = off[i + 1] - off[i]
+            if any(off[t + 1] - off[t] != n for t in range(i, i + k)):
+                raise ValueError("test-time augmentation: the %d variants of sample %d differ in their point counts" % (k, i // k))
+            ret = dict(metadata=meta[i], pred_point_sem_labels=ops.tta_merge(logits, off[i:i + k], n))
             if "point_sem_labels" in example:
-                n = int(masks[i].sum())
                 ret["point_sem_labels"] = example["point_sem_labels"][left:left + n]
                 left += n
             ret_list.append(ret)

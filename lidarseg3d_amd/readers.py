@@ -173,3 +173,128 @@ class TransformerVoxelFeatureExtractor(PackedModule):
         if self.compress_layer is not None:
             x = self._lin(x, pk["compress"], relu=True)
         return x
+
+
+# ---------------------------------------------------------------------------------------------------------------- dynamic (point-wise) readers
+class _CylindricalDynamicReader(PackedModule):
+    """What PolarNetDynamicVoxelFeatureExtractor and Cylinder3DDynamicVoxelFeatureExtractor share (voxel_encoder.py:275-497,503-720):
+    points -> (rho, phi, z) -> cells of a cylindrical grid (clamped, so every point is kept) -> torch.unique of the cell rows ->
+    per point [cyl, x, y, extras, offsets from the voxel mean and the cell centre] -> BatchNorm + 3 x (Linear, BN, ReLU) + Linear ->
+    scatter mean / max per voxel -> optional compression.  On the device: ls3d_cyl_voxelize, the in-library radix sort +
+    ls3d_unique_sorted, ls3d_segment_reduce, ls3d_dyn_point_features and the MFMA gather-GEMM for every Linear (csrc/dynreader.hip,
+    voxelize.hip, spconv.hip); the leading BatchNorm is folded into the feature kernel, the others into the GEMM epilogues."""
+    _reverse = False   # cell columns stored (c2, c1, c0): the (z, y, x) order spconv wants
+    _collapse = False  # group whole (rho, phi) columns (PolarNet's bird's-eye-view pillars)
+
+    def __init__(self, grid_size, point_cloud_range, average_points, num_input_features, num_output_features, fea_compre=None, voxel_label_enc=None,
+                 **kwargs):
+        super().__init__()
+        fea_dim = num_input_features + 2 + 8
+        self.PPmodel = nn.Sequential(nn.BatchNorm1d(fea_dim),
+                                     nn.Linear(fea_dim, 64), nn.BatchNorm1d(64), nn.ReLU(inplace=True),
+                                     nn.Linear(64, 128), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                     nn.Linear(128, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True),
+                                     nn.Linear(256, num_output_features))
+        self.pool_dim = num_output_features
+        self.fea_compre = fea_compre
+        if fea_compre is not None:
+            self.fea_compression = nn.Sequential(nn.Linear(self.pool_dim, fea_compre), nn.ReLU())
+            self.pt_fea_dim = fea_compre
+        else:
+            self.pt_fea_dim = self.pool_dim
+        self.grid_size, self.point_cloud_range, self.average_points = grid_size, point_cloud_range, average_points
+        self.voxel_size = [(point_cloud_range[3 + i] - point_cloud_range[i]) / grid_size[i] for i in range(3)]
+        self.voxel_label_enc = voxel_label_enc
+        self._fea_dim = fea_dim
+
+    def _pack(self):
+        from .packing import fold_bn
+        pp = self.PPmodel
+        s0, t0 = fold_bn(None, pp[0], self._fea_dim, pp[0].weight.device)
+        p = dict(in_scale=s0, in_shift=t0, mlp=[pack_linear(pp[1].weight, pp[1].bias, pp[2]), pack_linear(pp[4].weight, pp[4].bias, pp[5]),
+                                                 pack_linear(pp[7].weight, pp[7].bias, pp[8]), pack_linear(pp[10].weight, pp[10].bias)])
+        if self.fea_compre is not None:
+            p["compress"] = pack_linear(self.fea_compression[0].weight, self.fea_compression[0].bias)
+        return p
+
+    def voxelize_labels(self, point_labels, point_vcoors):
+        """majority label per voxel (voxel_encoder.py:388-406,618-636), in torch.unique's voxel order; ties go to the smallest label"""
+        from . import scatter
+        lbxyz = torch.cat([point_labels.reshape(-1, 1).to(point_vcoors.dtype), point_vcoors], dim=-1)
+        unq, count = torch.unique(lbxyz, return_counts=True, dim=0)
+        inv = torch.unique(unq[:, 1:], return_inverse=True, dim=0)[1]
+        if self.voxel_label_enc != "major":
+            raise AssertionError("voxel_label_enc %r" % (self.voxel_label_enc,))
+        return unq[:, 0][scatter.scatter_max(count, inv)[1]]
+
+    def _point_rows(self, points, batch_size):
+        g = [int(v) for v in self.grid_size]
+        cyl5, vcoors, keys = ops.cyl_voxelize(points, g, self.point_cloud_range, self._reverse, self._collapse, batch_size)
+        rows, inverse, counts = ops.unique_rows(keys, g[::-1] if self._reverse else g, batch_size)
+        mean5 = ops.segment_reduce(cyl5, inverse, rows.shape[0], "mean")
+        return cyl5, vcoors, rows, inverse, counts, mean5
+
+    def _voxel_features(self, points, batch_size):
+        """-> voxel features [V, C], unique cell rows [V, 4], per-point rows [n, 4], inverse [n], counts [V]"""
+        cyl5, vcoors, rows, inverse, counts, mean5 = self._point_rows(points, batch_size)
+        g = [int(v) for v in self.grid_size]
+        if self.training:
+            feats = ops.dyn_point_features(points, cyl5, vcoors, inverse, mean5, g, self.point_cloud_range)[:, :self._fea_dim]
+            x = self.PPmodel(feats)
+            idx = inverse[:, None].expand(-1, x.shape[1])
+            pooled = torch.zeros((rows.shape[0], x.shape[1]), dtype=x.dtype, device=x.device).scatter_reduce(
+                0, idx, x, "mean" if self.average_points else "amax", include_self=False)
+            if self.fea_compre:
+                pooled = self.fea_compression(pooled)
+            return pooled, rows, vcoors, inverse, counts
+        pk = self.packed()
+        ld = pk["mlp"][0][0].shape[1]
+        x = ops.dyn_point_features(points, cyl5, vcoors, inverse, mean5, g, self.point_cloud_range, pk["in_scale"], pk["in_shift"], ld)
+        for i, (W, scale, shift, cout) in enumerate(pk["mlp"]):
+            x = ops.gather_gemm(x, W, cout=cout, scale=scale, shift=shift, relu=i < 3)
+        pooled = ops.segment_reduce(x, inverse, rows.shape[0], "mean" if self.average_points else "max")
+        if self.fea_compre:
+            W, scale, shift, cout = pk["compress"]
+            pooled = ops.gather_gemm(pooled, W, cout=cout, scale=scale, shift=shift, relu=True)
+        return pooled, rows, vcoors, inverse, counts
+
+    def _labels(self, batch_dict, vcoors):
+        labels = batch_dict.get("point_sem_labels")
+        if self.voxel_label_enc is not None and labels is not None:
+            batch_dict["voxel_sem_labels"] = self.voxelize_labels(labels, vcoors)
+
+
+@READERS.register_module
+class PolarNetDynamicVoxelFeatureExtractor(_CylindricalDynamicReader):
+    """voxel_encoder.py:275-497: pillars of a polar bird's-eye-view grid -> dense [B, C, grid0, grid1] map for PolarNet's 2-D UNet"""
+    _collapse = True
+
+    def forward(self, batch_dict):
+        points, batch_size = batch_dict["points"].float().contiguous(), batch_dict["batch_size"]
+        feats, rows, vcoors, inverse, counts = self._voxel_features(points, batch_size)
+        g = [int(v) for v in self.grid_size]
+        bev = torch.zeros((batch_size, g[0], g[1], feats.shape[-1]), dtype=feats.dtype, device=feats.device)
+        bev[rows[:, 0], rows[:, 1], rows[:, 2], :] = feats
+        batch_dict["voxel_features"] = bev.permute(0, 3, 1, 2)
+        batch_dict["point_vcoors"] = vcoors
+        batch_dict["input_shape"] = self.grid_size
+        batch_dict["num_points_in_voxel"] = counts
+        self._labels(batch_dict, vcoors)
+        return batch_dict
+
+
+@READERS.register_module
+class Cylinder3DDynamicVoxelFeatureExtractor(_CylindricalDynamicReader):
+    """voxel_encoder.py:503-720: sparse voxels of the cylindrical grid, rows (batch, z, y, x) in torch.unique's sorted order"""
+    _reverse = True
+
+    def forward(self, batch_dict):
+        points, batch_size = batch_dict["points"].float().contiguous(), batch_dict["batch_size"]
+        feats, rows, vcoors, inverse, counts = self._voxel_features(points, batch_size)
+        batch_dict["voxel_features"] = feats
+        batch_dict["point_vcoors"] = vcoors[:, [0, 3, 2, 1]]  # (b, vz, vy, vx) -> (b, vx, vy, vz) for the dense-to-sparse mapping of the head
+        batch_dict["input_shape"] = self.grid_size
+        batch_dict["voxel_coords"] = rows
+        batch_dict["num_points_in_voxel"] = counts
+        self._labels(batch_dict, vcoors)
+        return batch_dict

@@ -29,16 +29,17 @@ def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stri
 
 
 class SparseBasicBlock(spconv.SparseModule):
-    """scn_unet.py:34-69: relu(bn2(conv2(relu(bn1(conv1(x))))) + x), two kernel launches."""
+    """scn_unet.py:34-69: relu(bn2(conv2(relu(bn1(conv1(x))))) + x), two kernel launches.  bias=True: the biased variant of
+    det3d/models/backbones/scn.py:37-80 (SpMiddleResNetFHD; the bias folds into the epilogue's shift)."""
     expansion = 1
 
-    def __init__(self, inplanes, planes, stride=1, downsample=None, indice_key=None, norm_fn=None):
+    def __init__(self, inplanes, planes, stride=1, downsample=None, indice_key=None, norm_fn=None, bias=False):
         super().__init__()
-        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False,
+        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=bias,
                                        indice_key=indice_key)
         self.bn1 = norm_fn(planes)
         self.relu = nn.ReLU()
-        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False,
+        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=1, padding=1, bias=bias,
                                        indice_key=indice_key)
         self.bn2 = norm_fn(planes)
         self.downsample = downsample

@@ -2093,6 +2093,20 @@ def test_other_backbones_conv_calls_on_device(prec):
     assert torch.equal(d[i[:, 0], :, i[:, 1], i[:, 2], i[:, 3]], x.features) and float(d.abs().sum()) == float(x.features.abs().sum())
 
 
+@pytest.mark.parametrize("case", ["spmiddleresnetfhd", "unetcylinder3d", "cylinder3d_v2p", "cylinder3d_asymm", "reader_cylinder3d", "reader_polarnet", "tta_merge",
+                                  "dynamic_point_to_voxel"])
+def test_other_backbones_and_dynamic_readers_as_registered_modules_gpu(case):
+    """SURVEY 8f rank 4 as components on the MI355X (tests/f4_module_cases.py): each of SpMiddleResNetFHD, UNetCylinder3D,
+    Cylinder3D_Asymm_3d_spconv, Cylinder3D_Asymm_3d_spconv_v2p, Cylinder3DDynamicVoxelFeatureExtractor, PolarNetDynamicVoxelFeatureExtractor is
+    built by build_from_cfg, loads the seeded reference-layout state_dict strict=True and reproduces the output the reference's own file gave for
+    the same input (sites / cell rows / counts / majority labels bit-exact, features within 1e-3 of the output scale); predict() with test-time
+    augmentation against the reference head's labels; ls3d_dynamic_point_to_voxel_index / _forward / _backward against the reference's C++"""
+    from tests import f4_module_cases
+    getattr(f4_module_cases, case)(DEV)
+    if f4_module_cases.MEASURED:
+        print("f4 modules[%s]: %s" % (case, {k: "%.2g" % v for k, v in f4_module_cases.MEASURED.items()}))
+
+
 # ------------------------------------------------------------------------------------------------ fused segmentation loss, round 3
 @pytest.mark.parametrize("P,C", [(700, 17), (360000, 23), (120000, 17)])
 def test_fused_seg_loss_gpu(P, C):

@@ -73,6 +73,30 @@ def test_state_dict_layout_equals_reference(cfg, parts):
     assert sd == want
 
 
+_CYL = dict(grid=[480, 360, 32], rng=[0.0, -np.pi, -5.0, 51.2, np.pi, 3.0])
+
+
+@pytest.mark.parametrize("registry,cfg,key", [
+    ("BACKBONES", dict(type="SpMiddleResNetFHD", num_input_features=16, ds_factor=8), "backbone.SpMiddleResNetFHD"),
+    ("BACKBONES", dict(type="UNetCylinder3D", num_input_features=16, voxel_size=[0.1, 0.1, 0.2], point_cloud_range=_CYL["rng"], model_cfg=dict(init_size=8)),
+     "backbone.UNetCylinder3D"),
+    ("BACKBONES", dict(type="Cylinder3D_Asymm_3d_spconv", output_shape=[16, 48, 41], num_input_features=16, nclasses=7, init_size=8),
+     "backbone.Cylinder3D_Asymm_3d_spconv"),
+    ("BACKBONES", dict(type="Cylinder3D_Asymm_3d_spconv_v2p", num_input_features=16, grid_size=_CYL["grid"], point_cloud_range=_CYL["rng"],
+                       model_cfg=dict(init_size=8)), "backbone.Cylinder3D_Asymm_3d_spconv_v2p"),
+    ("READERS", dict(type="Cylinder3DDynamicVoxelFeatureExtractor", grid_size=_CYL["grid"], point_cloud_range=_CYL["rng"], average_points=False,
+                     num_input_features=5, num_output_features=64, fea_compre=16, voxel_label_enc="major"), "reader.Cylinder3DDynamicVoxelFeatureExtractor"),
+    ("READERS", dict(type="PolarNetDynamicVoxelFeatureExtractor", grid_size=[120, 90, 8], point_cloud_range=_CYL["rng"], average_points=True,
+                     num_input_features=5, num_output_features=64, fea_compre=16, voxel_label_enc="major"), "reader.PolarNetDynamicVoxelFeatureExtractor"),
+])
+def test_other_backbones_and_dynamic_readers_are_registered_with_the_reference_layout(registry, cfg, key):
+    """the reference's other sparse backbones and its two dynamic readers build from the reference's cfg dicts through the
+    registry, with the reference modules' state_dict keys and shapes (manifests captured by tests/golden/make_golden_f4.py --modules)"""
+    m = L.build_from_cfg(cfg, getattr(L.registry, registry))
+    assert type(m).__name__ == cfg["type"]
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest(key)
+
+
 def test_build_detector_injects_cfgs_and_checkpoint_roundtrip(tmp_path):
     model = L.build_detector(models_cfg.sdseg3d(), train_cfg=dict(a=1), test_cfg=dict(b=2))
     assert model.train_cfg == dict(a=1) and model.test_cfg == dict(b=2)

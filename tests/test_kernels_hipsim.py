@@ -2018,6 +2018,16 @@ def test_other_backbones_conv_calls_replayed_on_our_spconv():
     assert (1, (3, 1, 1), (2, 1, 1)) in seen
 
 
+@pytest.mark.parametrize("case", ["spmiddleresnetfhd", "unetcylinder3d", "cylinder3d_v2p", "cylinder3d_asymm", "reader_cylinder3d", "reader_polarnet", "tta_merge",
+                                  "dynamic_point_to_voxel"])
+def test_other_backbones_and_dynamic_readers_as_registered_modules(case):
+    """SURVEY 8f rank 4 as components: SpMiddleResNetFHD, UNetCylinder3D, Cylinder3D_Asymm_3d_spconv(_v2p), the PolarNet / Cylinder3D dynamic
+    readers built through the registry with the reference's state_dict (strict) against module-level fixtures of the reference's own files;
+    the TTA merge of predict() against the reference head's; ls3d_dynamic_point_to_voxel_* against the reference's C++ (tests/f4_module_cases.py)"""
+    from tests import f4_module_cases
+    getattr(f4_module_cases, case)(torch.device("cpu"))
+
+
 # ------------------------------------------------------------------------------------------------ fused segmentation loss, round 3
 @pytest.mark.parametrize("P,C,ignore,case", [(3000, 17, 0, "mixed"), (5000, 23, 0, "absent_classes"), (700, 5, 255, "no_ignored"), (1500, 17, 0, "one_valid"),
                                               (1025, 32, 0, "mixed")])
