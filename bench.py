@@ -877,10 +877,68 @@ def main():
         finally:
             L3.set_reference_outputs(False)
 
+    def frame_stream_leg(m, kind, passes=3):
+        """SURVEY.md 8(d) / tools/dist_test.py:189-230: a STREAM of different sweeps, not replays of one frame: seeds 0..7 with 120k +- 10 % points
+        each (a sweep's point count changes from frame to frame) and the 34 720-point size of a real nuScenes key frame, every frame through
+        graph.BucketedFrameGraph (one hipGraph per 16384-point bucket, the frame padded inside the graph's input buffers with rows that belong to
+        no frame).  Timed frame by frame (host copy-in of device-resident points, replay, wait, overflow check) after one pass that captures
+        the buckets; labels of the first frame are checked against the eager forward of the unpadded frame."""
+        from lidarseg3d_amd import graph as lgraph
+        ops.set_precision(args.precision)
+        sizes = [int(round(args.points * (0.9 + 0.2 * float(np.random.Generator(np.random.PCG64(1000 + sd)).uniform())))) for sd in range(8)]
+        exs = []
+        for sd, npts in enumerate(sizes):
+            pts_ = frames_to_points([synth.lidar_frame(npts, seed=sd, **synth.NUSC)])
+            ex_ = dict(points=pts_, batch_size=1)
+            if kind == "mseg3d":
+                img, emb, cuv = synth.camera_inputs(npts, seed=sd, ncam=6, c_img=48, h=160, w=240, batch=1)
+                ex_.update(points_cuv=torch.from_numpy(cuv).to(dev), image_features=torch.from_numpy(img).to(dev),
+                           camera_semantic_embeddings=torch.from_numpy(emb).to(dev))
+            exs.append(ex_)
+        bfg = lgraph.BucketedFrameGraph(m, bucket_points=16384)
+        with torch.no_grad():
+            want = m(dict(exs[0]), return_loss=False)[0]["pred_point_sem_labels"].clone()
+        same = bool(torch.equal(bfg(exs[0])[0]["pred_point_sem_labels"], want))
+        for ex_ in exs[1:]:
+            bfg(ex_, clone=False)
+        _sync()
+        ms = []
+        t_all = time.perf_counter()
+        for _ in range(passes):
+            for ex_ in exs:
+                t0 = time.perf_counter()
+                bfg(ex_, clone=False)   # returns after the frame: finish() waits for its stream
+                ms.append(1e3 * (time.perf_counter() - t0))
+        _sync()
+        total = time.perf_counter() - t_all
+        ms_sorted = sorted(ms)
+        out = dict(frames=len(ms), points_per_frame=sizes, buckets=sorted({bfg.bucket(n) for n in sizes}), graphs_captured=bfg.captures,
+                   fallbacks_to_eager=bfg.fallbacks, recaptures=bfg.recaptures, labels_bit_identical_to_eager_unpadded_frame=same,
+                   frames_per_s=len(ms) / total, median_frames_per_s=1e3 / statistics.median(ms), min_frames_per_s=1e3 / ms_sorted[-1],
+                   max_frames_per_s=1e3 / ms_sorted[0], ms_per_frame=dict(median=statistics.median(ms), p95=ms_sorted[min(len(ms) - 1, int(round(0.95 * (len(ms) - 1))))],
+                                                                          max=ms_sorted[-1]),
+                   note="8 different synthetic sweeps (seeds 0..7) of 120k +- 10 % points, %d passes, one hipGraph per 16384-point bucket" % passes)
+        if kind == "sdseg3d":  # the size of a real nuScenes key frame (SURVEY.md 8d): its own bucket
+            pk = frames_to_points([synth.lidar_frame(34720, seed=0, **synth.NUSC)])
+            exk = dict(points=pk, batch_size=1)
+            for _ in range(3):
+                bfg(exk, clone=False)
+            elk, _ = timed_steps(lambda: bfg(exk, clone=False)[0]["pred_point_sem_labels"], 20, 2)
+            out["keyframe_34720_points"] = dict(frames_per_s=20 / elk, ms_per_frame=1e3 * elk / 20, bucket=bfg.bucket(34720))
+        del bfg
+        return out
+
     ref_out_leg = None
     if graph_leg is not None and "error" not in graph_leg and single:
         ref_out_leg = reference_outputs_leg(model, dict(points=pts, batch_size=1, **extra), ref_logits, args.steps, args.warmup,
                                             ["conv_logits"] if args.model == "sdseg3d" else ["voxel_logits", "point_features_pcamera"])
+    stream_leg = None
+    if graph_leg is not None and "error" not in graph_leg and single and extra_modes and B == 1 and S == 1:
+        try:
+            stream_leg = frame_stream_leg(model, args.model)
+        except Exception as e:
+            stream_leg = dict(error=repr(e))
+        torch.cuda.empty_cache()
     # what every rank measured, gathered over the process group: a record of N ranks can be checked rank by rank
     mine = dict(rank=rank, local_rank=local_rank, device=str(dev), device_name=(torch.cuda.get_device_name(dev) if not SIM else "hipsim (test hook)"),
                 frame_seeds=[100 + i for i in my_frames], frames_per_s=head["local_frames_per_s"],
@@ -1034,6 +1092,12 @@ def main():
         if "graph_error" not in mseg and not args.no_graph and detectors.CAPACITY_MODE:
             mseg["reference_outputs_mode"] = reference_outputs_leg(m2, dict(points=p2, batch_size=1, **e2), None, n2, 3,
                                                                    ["voxel_logits", "point_features_pcamera"])
+        if "graph_error" not in mseg and not args.no_graph and detectors.CAPACITY_MODE:
+            try:
+                mseg["frame_stream"] = frame_stream_leg(m2, "mseg3d", passes=2)
+            except Exception as e:
+                mseg["frame_stream"] = dict(error=repr(e))
+            torch.cuda.empty_cache()
         try:  # configs[2]'s own roofline objects: the fused SF-Phase decoder (MFMA-bound) first, then the other stages of the frame
             sr2 = stage_rooflines(m2, dict(points=p2, batch_size=1, **e2), "mseg3d", census2)
             if "sffm_decoder" in sr2:
@@ -1134,6 +1198,12 @@ def main():
                                      note="same launches submitted one by one from Python; carries the conv-stack HIP-event brackets of `roofline`")
         if ref_out_leg is not None:
             out["reference_outputs_mode"] = ref_out_leg
+            # the like-for-like figure as a first-class key: the same frame with EVERY tensor the reference's eval forward produces materialised
+            out["reference_outputs_value"] = ref_out_leg.get("frames_per_s")
+        if stream_leg is not None:
+            out["frame_stream"] = stream_leg
+            out["frame_stream_median_value"] = stream_leg.get("median_frames_per_s")
+            out["frame_stream_min_value"] = stream_leg.get("min_frames_per_s")
         if c:
             np_ = PLANE_PRODUCTS.get(args.precision)
             # the matrix-pipe view of the same stack: every f32 product of the pair model is `np_` bf16 plane products on

@@ -229,13 +229,17 @@ __device__ __forceinline__ void cg_point_cell(const CGeom &g, const float *pu, i
 // The query points are processed in coarse-cell order (counting sort -> `perm`): the lanes of a wave then walk
 // the same cells, so the search neither diverges nor scatters its candidate reads, whatever order the LiDAR
 // points arrive in.
-__global__ __launch_bounds__(256) void k_pt_count(const float *points, int pt_stride, int n, CGeom g, int32_t *cell_of, int32_t *cnt) {
+// Rows whose batch index lies outside [0, batch) belong to no frame (the padding rows of a point-count bucket, graph.BucketedFrameGraph):
+// they are not counted, get no slot in `perm` and - pt_off being the offsets of the frames 0 .. batch - 1 - are never searched.
+__global__ __launch_bounds__(256) void k_pt_count(const float *points, int pt_stride, int n, int batch, CGeom g, int32_t *cell_of, int32_t *cnt) {
   const int ncf = g.dim[0] * g.dim[1] * g.dim[2];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float *u = points + (size_t)i * pt_stride;
+    const int f = (int)u[0];
+    if (f < 0 || f >= batch) { cell_of[i] = -1; continue; }
     int cc[3];
     cg_point_cell(g, u + 1, cc);
-    const int cell = (int)u[0] * ncf + (cc[2] * g.dim[1] + cc[1]) * g.dim[0] + cc[0];
+    const int cell = f * ncf + (cc[2] * g.dim[1] + cc[1]) * g.dim[0] + cc[0];
     cell_of[i] = cell;
     atomicAdd(&cnt[cell], 1);
   }
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256) void k_pt_count(const float *points, int pt_st
 __global__ __launch_bounds__(256) void k_pt_fill(int n, const int32_t *cell_of, const int32_t *start, int32_t *cursor, int32_t *perm) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int cell = cell_of[i];
+    if (cell < 0) continue;
     perm[start[cell] + atomicAdd(&cursor[cell], 1)] = i;
   }
 }
@@ -634,7 +639,7 @@ extern "C" int ls3d_devoxelize_grid(const float *points, int pt_stride, int n_po
   int32_t *pstart = (int32_t *)base; base += dv_align((size_t)(ncell + 1) * 4);
   int32_t *hard_list = (int32_t *)base;
   hipMemsetAsync(zero_begin, 0, (size_t)(zero_end - zero_begin), stream);
-  hipLaunchKernelGGL(k_pt_count, ls3d_grid(n_points), dim3(256), 0, stream, points, pt_stride, n_points, g, pcell, pcnt);
+  hipLaunchKernelGGL(k_pt_count, ls3d_grid(n_points), dim3(256), 0, stream, points, pt_stride, n_points, batch, g, pcell, pcnt);
   int rcp = ls3d_exclusive_scan_i32(pcnt, pstart, (int)(ncell + 1), scan_tmp, nullptr, stream);
   if (rcp != LS3D_OK) return rcp;
   hipLaunchKernelGGL(k_pt_fill, ls3d_grid(n_points), dim3(256), 0, stream, n_points, (const int32_t *)pcell, (const int32_t *)pstart, pcursor, perm);

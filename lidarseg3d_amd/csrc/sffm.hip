@@ -399,7 +399,10 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
   const size_t kv_layer = (size_t)2 * batch * SF_E * L;  // floats per layer: k[batch][E][L] then v[batch][E][L]
   for (int p0 = blockIdx.x * 128; p0 < n; p0 += gridDim.x * 128) {
     __syncthreads();
-    if (tid < 128) s_frame[tid] = (p0 + tid < n) ? (int)points[(size_t)(p0 + tid) * pt_stride] : -1;
+    if (tid < 128) {  // rows of no frame - beyond n, or padding rows of a point-count bucket (batch index >= batch, graph.FrameGraph) - count as the wave's frame
+      const int fr = (p0 + tid < n) ? (int)points[(size_t)(p0 + tid) * pt_stride] : -1;
+      s_frame[tid] = (fr >= 0 && fr < batch) ? fr : -1;
+    }
     // ---- the wave's 32 input rows -> T[:, 0:d_in]
     for (int i = lane; i < 32 * (prm.d_in / 4); i += 64) {
       const int row = i / (prm.d_in / 4), c4 = i - row * (prm.d_in / 4);
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void k_sffm_decoder(const float *__restrict
       *(float4 *)(T + row * SF_XS + c4 * 4) = v;
     }
     __syncthreads();
-    const int fs = s_frame[0];  // the frame whose K / V are staged (the tile's first point)
+    const int fs = s_frame[0] >= 0 ? s_frame[0] : 0;  // the frame whose K / V are staged (the tile's first point; a tile of padding rows only: any frame)
     sf_f32x16 acc[3];
 #define SF_GEMM(A_, K_, Wf_, Wp_, Wnext_, acc_, zero_) sf_gemm(A_, SF_XS, K_, Wf_, Bs, acc_, zero_)
     // ---- input projection -> X

@@ -15,7 +15,12 @@ Correctness contract: a replay runs exactly the launches of the eager capacity-m
 strided rulebooks are the ones learned from the warm-up frames (1.3x the largest count seen); every replay copies the frame's counts and
 overflow flags to pinned host memory, and __call__ checks them after the frame: an overflowing frame is computed again by the eager
 path (host-side counts, always correct) and the graph is captured again with the new capacities.  Inputs of another shape than the
-captured one go to the eager path as well (a graph is a fixed-shape object: one FrameGraph per point-count bucket).  A batch of several
+captured one go to the eager path as well (a graph is a fixed-shape object) - unless the graph was captured with `point_keys`: then a
+frame of FEWER points than the captured capacity is padded inside the graph's input buffers with rows that belong to no frame (batch
+index = batch_size, coordinates far outside every range: the voxelizer rejects them, the devoxelization and the decoder never visit them,
+the per-point tail gives them zero features) and the outputs are cut back to the frame's rows - bit-identical labels for the real points.
+BucketedFrameGraph keeps one such graph per point-count bucket, so a sweep stream whose point count changes from frame to frame
+(tools/dist_test.py:189-230 times exactly that) stays on the graph path.  A batch of several
 frames (round 4) is captured up to the labels of all points; the split into per-frame results - boolean masks, i.e. host synchronisations - runs
 after the replay.
 
@@ -27,8 +32,21 @@ import torch
 from . import detectors
 
 
+PAD_COORD = 1.0e6  # metres: outside any point-cloud range, finite in f32 arithmetic
+
+
+def pad_rows(key, like, rows, batch_size):
+    """`rows` padding rows for the per-point input `key`: points = (batch_size, far away, zero features); any other per-point table = zeros
+    (points_cuv: valid flag 0 - no camera sees the point)"""
+    pad = torch.zeros((rows,) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+    if key == "points" and rows:
+        pad[:, 0] = float(batch_size)
+        pad[:, 1:4] = PAD_COORD
+    return pad
+
+
 class FrameGraph(object):
-    def __init__(self, model, example, warmup=3, stream=None):
+    def __init__(self, model, example, warmup=3, stream=None, point_keys=None):
         if model.training:
             raise ValueError("FrameGraph is an inference path: model.eval() first")
         if (getattr(model, "test_cfg", None) or {}).get("tta_flag", False) and int(example.get("batch_size", 1)) != 1:
@@ -43,7 +61,11 @@ class FrameGraph(object):
             # of all points, _after_replay() splits them by the batch column of the replayed example
             self.static["_unsplit_predict"] = True
         self.shapes = {k: (tuple(v.shape), v.dtype) for k, v in example.items() if torch.is_tensor(v)}
+        # per-point inputs (dim 0 = the sweep's points): a frame may bring FEWER rows than captured, the rest is padding (module docstring)
+        self.point_keys = tuple(k for k in (point_keys or ()) if k in self.shapes)
+        self.capacity = self.shapes[self.point_keys[0]][0][0] if self.point_keys else None
         self.graph, self.ret, self.record, self.recaptures, self.fallbacks = None, None, None, 0, 0
+        self._rows = self.capacity
         self._capture()
 
     def _capture(self):
@@ -69,8 +91,19 @@ class FrameGraph(object):
         self.logits = model.point_head.forward_ret_dict.get("out_logits")
 
     def matches(self, example):
-        return all(k in example and torch.is_tensor(example[k]) and tuple(example[k].shape) == s and example[k].dtype == d
-                   for k, (s, d) in self.shapes.items()) and int(example.get("batch_size", 1)) == self.batch_size
+        if int(example.get("batch_size", 1)) != self.batch_size:
+            return False
+        n = example[self.point_keys[0]].shape[0] if (self.point_keys and self.point_keys[0] in example) else None
+        for k, (s, d) in self.shapes.items():
+            v = example.get(k)
+            if not torch.is_tensor(v) or v.dtype != d:
+                return False
+            if k in self.point_keys:
+                if tuple(v.shape[1:]) != s[1:] or v.shape[0] != n or n > s[0]:
+                    return False
+            elif tuple(v.shape) != s:
+                return False
+        return True
 
     _shared_replay_stream = {}  # device -> handle of the stream the graphs captured WITHOUT `stream=` are replayed on
 
@@ -86,10 +119,21 @@ class FrameGraph(object):
                                    "stream; capture each frame slot with its own stream= to run them side by side")
         elif cur.cuda_stream != self.stream.cuda_stream:
             raise RuntimeError("a FrameGraph captured with stream= is replayed on that stream (its arrival counters belong to it)")
+        self._rows = example[self.point_keys[0]].shape[0] if self.point_keys else None
         for k in self.shapes:
-            self.static[k].copy_(example[k], non_blocking=True)
+            if k in self.point_keys and self._rows < self.capacity:
+                self.static[k][:self._rows].copy_(example[k], non_blocking=True)
+                self.static[k][self._rows:] = self._pad(k)[:self.capacity - self._rows]
+            else:
+                self.static[k].copy_(example[k], non_blocking=True)
         self.graph.replay()
         self._launched_on = torch.cuda.current_stream()
+
+    def _pad(self, key):
+        cache = self.__dict__.setdefault("_pad_cache", {})
+        if key not in cache:
+            cache[key] = pad_rows(key, self.static[key], self.capacity, self.batch_size)
+        return cache[key]
 
     def finish(self, example, clone=True):
         """wait for the frame launch() started, check its rulebook counts (overflow -> eager rerun + recapture) -> the frame's outputs"""
@@ -124,14 +168,21 @@ class FrameGraph(object):
         if self.batch_size > 1:
             return self._split_frames(example)
         meta = example.get("metadata") or [None] * len(self.ret)
-        out = self.ret if not clone else [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in r.items()} for r in self.ret]
+        n = self._rows if (self.point_keys and self._rows is not None and self._rows < self.capacity) else None
+
+        def cut(v):  # per-point outputs of a padded frame: the frame's own rows
+            if n is not None and torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == self.capacity:
+                v = v[:n]
+            return v.clone() if (clone and torch.is_tensor(v)) else v
+        out = self.ret if (not clone and n is None) else [{k: cut(v) for k, v in r.items()} for r in self.ret]
         for i, r in enumerate(out):
             r["metadata"] = meta[i] if i < len(meta) else None
         return out
 
     def _split_frames(self, example):
         """the list predict() returns for a batch (point_seg_batchloss_head.py:255-270): labels of frame i = the rows with batch index i"""
-        labels, b = self.ret[0]["pred_point_sem_labels"], example["points"][:, 0]
+        b = example["points"][:, 0]
+        labels = self.ret[0]["pred_point_sem_labels"][:b.shape[0]]  # a padded batch: the padding rows sit behind the last frame
         meta = example.get("metadata") or [None] * self.batch_size
         out = []
         for i in range(self.batch_size):
@@ -141,3 +192,50 @@ class FrameGraph(object):
                 r["point_sem_labels"] = example["point_sem_labels"][m]
             out.append(r)
         return out
+
+
+class BucketedFrameGraph(object):
+    """One FrameGraph per point-count bucket: a frame of n points runs on the graph captured for ceil(n / bucket_points) * bucket_points rows,
+    padded inside the graph's input buffers (FrameGraph, `point_keys`).  Padding costs the per-point tail only (the voxelizer rejects the rows,
+    the neighbour search and the decoder never visit them), so coarse buckets are cheap: 16384 points = 14 % of a 120k sweep at most ~0.1 ms.
+    A bucket is captured the first time a frame falls into it (from that frame, padded); `max_graphs` bounds the private memory pools kept
+    (least recently used bucket dropped).  Same results as the eager forward for every real point (tests: bit-identical labels)."""
+
+    def __init__(self, model, bucket_points=16384, point_keys=("points", "points_cuv"), warmup=3, max_graphs=8):
+        self.model, self.bucket_points, self.point_keys, self.warmup, self.max_graphs = model, int(bucket_points), tuple(point_keys), warmup, int(max_graphs)
+        self.graphs, self.captures = {}, 0
+
+    def bucket(self, n):
+        return max(1, -(-int(n) // self.bucket_points)) * self.bucket_points
+
+    def _key(self, example):
+        n = example["points"].shape[0]
+        other = tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(example.items()) if torch.is_tensor(v) and k not in self.point_keys)
+        return (self.bucket(n), int(example.get("batch_size", 1)), other)
+
+    def graph_for(self, example):
+        key = self._key(example)
+        fg = self.graphs.pop(key, None)
+        if fg is None:
+            cap, bs = key[0], key[1]
+            padded = dict(example)
+            for k in self.point_keys:
+                if k in example:
+                    padded[k] = torch.cat([example[k], pad_rows(k, example[k], cap - example[k].shape[0], bs)])
+            if len(self.graphs) >= self.max_graphs:
+                self.graphs.pop(next(iter(self.graphs)))
+            fg = FrameGraph(self.model, padded, warmup=self.warmup, point_keys=[k for k in self.point_keys if k in example])
+            self.captures += 1
+        self.graphs[key] = fg  # most recently used last
+        return fg
+
+    def __call__(self, example, clone=True):
+        return self.graph_for(example)(example, clone=clone)
+
+    @property
+    def fallbacks(self):
+        return sum(g.fallbacks for g in self.graphs.values())
+
+    @property
+    def recaptures(self):
+        return sum(g.recaptures for g in self.graphs.values())

@@ -1209,10 +1209,13 @@ def frame_offsets(table, batch_size, col=0, n_dev=None):
     is_float = 1 if table.dtype == torch.float32 else 0
     if not is_float and table.dtype != _i32:
         table = table.to(_i32)
-    off = torch.empty((batch_size + 1,), dtype=_i32, device=table.device)
-    check(_L().ls3d_frame_offsets(_ptr(table), is_float, table.shape[1], col, table.shape[0], _ndev(n_dev), batch_size, _ptr(off), _stream(table)),
+    # one entry more than the caller sees: off[B + 1] = the end of the rows with batch index B, an EMPTY extra frame when the table is a voxel
+    # table (no voxel carries index B) - so that a kernel that looks up the frame of a PADDING point (batch index B, graph.BucketedFrameGraph)
+    # finds a frame of zero voxels instead of reading past the array
+    off = torch.empty((batch_size + 2,), dtype=_i32, device=table.device)
+    check(_L().ls3d_frame_offsets(_ptr(table), is_float, table.shape[1], col, table.shape[0], _ndev(n_dev), batch_size + 1, _ptr(off), _stream(table)),
           "ls3d_frame_offsets")
-    return off
+    return off[:batch_size + 1]
 
 
 def devoxelize(points, pt_off, centers, vx_off, batch, max_frame_points, feat, c=None, return_idx=False):

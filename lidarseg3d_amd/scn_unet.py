@@ -87,8 +87,10 @@ def set_lazy_encoded(on):
 class _LazyEncoded(spconv.SparseConvTensor):
     """batch_dict["encoded_spconv_tensor"] in capacity mode: a SparseConvTensor (isinstance holds) whose convolution - conv_out on the
     deepest level and its rulebook - runs when the first of its attributes is read, on the stream that is current then.  It reads the
-    frame's level-4 tensor, so it has to be read (or materialize()d) before the next frame overwrites that tensor: after a graph replay
-    (graph.FrameGraph) the proxy of the capture is invalidated and computes the replayed frame's value on the next read."""
+    frame's level-4 tensor, so it has to be read (or materialize()d) before the next frame overwrites that tensor.  Nothing refreshes a
+    proxy that was already read: graph.FrameGraph replays never see the batch_dict (the captured forward hands out predict()'s list only),
+    so under a FrameGraph the tensor is available through set_reference_outputs(True) - computed inside every replay - and not through
+    this proxy; invalidate() is for callers that keep a batch_dict across frames themselves."""
 
     def __init__(self, fn):  # no SparseConvTensor.__init__: the attributes do not exist until they are asked for
         self.__dict__["_fn"] = fn

@@ -2107,6 +2107,41 @@ def test_other_backbones_and_dynamic_readers_as_registered_modules_gpu(case):
         print("f4 modules[%s]: %s" % (case, {k: "%.2g" % v for k, v in f4_module_cases.MEASURED.items()}))
 
 
+@pytest.mark.parametrize("kind", ["sdseg3d", "mseg3d"])
+def test_bucketed_frame_graph_keeps_a_varying_sweep_stream_on_the_graph_path(kind):
+    """graph.BucketedFrameGraph over a stream of 8 different sweeps whose point count changes from frame to frame (60k +- 10 %; tools/dist_test.py:189-230
+    times such a stream): every frame is replayed from the hipGraph of its 16384-point bucket, padded inside the graph's inputs with rows that
+    belong to no frame - labels bit-identical to the eager forward of the unpadded frame, zero fallbacks to the eager path, at most one
+    capture per bucket"""
+    from lidarseg3d_amd import graph
+    model, _ = _model(models_cfg.sdseg3d() if kind == "sdseg3d" else models_cfg.mseg3d())
+    sizes = [int(round(60000 * (0.9 + 0.2 * float(np.random.Generator(np.random.PCG64(1000 + sd)).uniform())))) for sd in range(8)]
+    exs = []
+    for sd, n in enumerate(sizes):
+        f = synth.lidar_frame(n, seed=sd, **synth.NUSC)
+        ex = dict(points=cu(np.concatenate([np.zeros((n, 1), np.float32), f], 1)), batch_size=1, metadata=[dict(token="s%d" % sd)])
+        if kind == "mseg3d":
+            img, emb, cuv = synth.camera_inputs(n, seed=sd, ncam=6, c_img=48, h=40, w=60, batch=1)
+            ex.update(points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
+        exs.append(ex)
+    try:
+        ops.set_precision("bf16x6")
+        want = []
+        with torch.no_grad():
+            for ex in exs:
+                want.append(model(dict(ex), return_loss=False)[0]["pred_point_sem_labels"].clone())
+        bfg = graph.BucketedFrameGraph(model, bucket_points=16384)
+        for _ in range(2):
+            for ex, w in zip(exs, want):
+                out = bfg(ex)
+                assert out[0]["metadata"] == ex["metadata"][0]
+                assert out[0]["pred_point_sem_labels"].shape == w.shape and torch.equal(out[0]["pred_point_sem_labels"], w)
+        assert bfg.fallbacks == 0, "a frame left the graph path"
+        assert bfg.captures == len({bfg.bucket(n) for n in sizes}) and bfg.captures >= 2
+    finally:
+        ops.set_precision("f32")
+
+
 # ------------------------------------------------------------------------------------------------ fused segmentation loss, round 3
 @pytest.mark.parametrize("P,C", [(700, 17), (360000, 23), (120000, 17)])
 def test_fused_seg_loss_gpu(P, C):

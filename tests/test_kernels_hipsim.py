@@ -2248,3 +2248,39 @@ def test_deferred_points_on_a_grid_whose_rows_are_not_whole_bitmap_words():
     assert torch.equal(ia, ib) and torch.equal(a, b)
     want, widx = orc.three_interpolate_wrap(pts, ctr, feat, 2, return_idx=True)
     assert np.array_equal(ia.numpy(), np.concatenate(widx))
+
+
+@pytest.mark.parametrize("kind", ["sdseg3d", "mseg3d"])
+def test_padding_rows_of_a_point_bucket_belong_to_no_frame(kind):
+    """graph.FrameGraph(point_keys=...) / BucketedFrameGraph pad a frame up to its bucket with rows of batch index = batch_size far outside the
+    range (graph.pad_rows).  The forward of the padded batch must give the real points bit-identical logits and labels, the voxelizer must
+    reject the padding, the neighbour search must never visit it (ls3d_devoxelize_grid skips rows outside [0, batch)) and the per-point
+    tail must find an empty frame for it (ops.frame_offsets' hidden entry): eager capacity-mode forward on the host emulation, 2 frames"""
+    from lidarseg3d_amd import graph, models_cfg
+    import lidarseg3d_amd as L
+    cfg = models_cfg.sdseg3d() if kind == "sdseg3d" else models_cfg.mseg3d()
+    model = L.build_detector(cfg, train_cfg=None, test_cfg={}).eval()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.random_state_dict(shapes, 5).items()})
+    frames = [synth.lidar_frame(160, seed=1, **synth.NUSC), synth.lidar_frame(130, seed=2, **synth.NUSC)]  # the last tile of frame 1 holds 2 points
+    pts = torch.from_numpy(np.concatenate([np.concatenate([np.full((f.shape[0], 1), b, np.float32), f], 1) for b, f in enumerate(frames)]))
+    ex = dict(points=pts, batch_size=2)
+    if kind == "mseg3d":
+        img, emb, cuv = synth.camera_inputs(pts.shape[0], seed=3, ncam=2, c_img=48, h=8, w=12, batch=2)
+        ex.update(points_cuv=torch.from_numpy(cuv), image_features=torch.from_numpy(img), camera_semantic_embeddings=torch.from_numpy(emb))
+    with torch.no_grad():
+        want = model(dict(ex), return_loss=False)
+    want_logits = model.point_head.forward_ret_dict["out_logits"].clone()
+    padded = dict(ex)
+    for k in ("points", "points_cuv"):
+        if k in ex:
+            padded[k] = torch.cat([ex[k], graph.pad_rows(k, ex[k], 37, 2)])
+    assert float(padded["points"][-1, 0]) == 2.0 and float(padded["points"][-1, 1]) == graph.PAD_COORD
+    with torch.no_grad():
+        got = model(dict(padded), return_loss=False)
+    logits = model.point_head.forward_ret_dict["out_logits"]
+    assert logits.shape[0] == padded["points"].shape[0]
+    assert torch.equal(logits[:pts.shape[0]], want_logits)
+    assert len(got) == len(want) == 2
+    for a, b in zip(got, want):
+        assert torch.equal(a["pred_point_sem_labels"], b["pred_point_sem_labels"])
