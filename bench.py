@@ -917,7 +917,7 @@ def main():
                    frames_per_s=len(ms) / total, median_frames_per_s=1e3 / statistics.median(ms), min_frames_per_s=1e3 / ms_sorted[-1],
                    max_frames_per_s=1e3 / ms_sorted[0], ms_per_frame=dict(median=statistics.median(ms), p95=ms_sorted[min(len(ms) - 1, int(round(0.95 * (len(ms) - 1))))],
                                                                           max=ms_sorted[-1]),
-                   note="8 different synthetic sweeps (seeds 0..7) of 120k +- 10 % points, %d passes, one hipGraph per 16384-point bucket" % passes)
+                   note="8 different synthetic sweeps (seeds 0..7) of 120k +- 10 %% points, %d passes, one hipGraph per 16384-point bucket" % passes)
         if kind == "sdseg3d":  # the size of a real nuScenes key frame: its own bucket
             pk = frames_to_points([synth.lidar_frame(34720, seed=0, **synth.NUSC)])
             exk = dict(points=pk, batch_size=1)
