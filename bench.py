@@ -141,6 +141,56 @@ class ConvCensus:
                     input_voxels=n_in, tables=sorted(set((rows[k], kv[k]) for k in rows), reverse=True))
 
 
+class TrainCensus:
+    """one untimed TRAINING step with the sparse-convolution entry points wrapped: forward and input-gradient launches (ops.gather_gemm with a table /
+    ops.tile_conv: the dgrad is the same operator on the transposed table) and weight-gradient launches (ops.spconv_wgrad), each between two HIP events
+    -> pair-model bytes / flops of the step (SURVEY.md 8(d)'s formulas once per direction: P (Cin + Cout) 4 bytes, 2 P Cin Cout flops) and the time
+    the device spent in them"""
+
+    def __init__(self, ops):
+        self.ops, self.calls = ops, []
+
+    def run(self, step):
+        ops = self.ops
+        g, t, wgr = ops.gather_gemm, ops.tile_conv, ops.spconv_wgrad
+
+        def bracket(kind, tbl, cin, cout, fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = fn()
+            b.record()
+            self.calls.append((kind, tbl, int(cin), int(cout), a, b))
+            return r
+
+        def wg(x, w, tbl=None, **kw):
+            if tbl is None:
+                return g(x, w, tbl=tbl, **kw)
+            return bracket("conv", tbl, w.shape[1], kw.get("cout") or w.cout, lambda: g(x, w, tbl=tbl, **kw))
+
+        def wt(x, w, plan, **kw):
+            return bracket("conv", plan.tbl, w.shape[1], kw.get("cout") or w.cout, lambda: t(x, w, plan, **kw))
+
+        def ww(x, grad_out, tbl, order, cin, cout, **kw):
+            return bracket("wgrad", tbl, cin, cout, lambda: wgr(x, grad_out, tbl, order, cin, cout, **kw))
+        ops.gather_gemm, ops.tile_conv, ops.spconv_wgrad = wg, wt, ww
+        try:
+            step()
+            torch.cuda.synchronize()
+        finally:
+            ops.gather_gemm, ops.tile_conv, ops.spconv_wgrad = g, t, wgr
+        pairs, out = {}, {"conv": [0, 0.0, 0.0, 0.0], "wgrad": [0, 0.0, 0.0, 0.0]}  # launches, bytes, flops, ms
+        for kind, tbl, cin, cout, a, b in self.calls:
+            key = (tbl.data_ptr(), tbl.shape[0], tbl.shape[1])
+            if key not in pairs:
+                pairs[key] = int((tbl >= 0).sum().item())
+            o = out[kind]
+            o[0] += 1
+            o[1] += pairs[key] * (cin + cout) * 4.0
+            o[2] += 2.0 * pairs[key] * cin * cout
+            o[3] += a.elapsed_time(b)
+        return out
+
+
 SIM = os.environ.get("LS3D_BENCH_HIPSIM") == "1"  # test hook, see the module docstring
 
 
@@ -636,6 +686,47 @@ def train_leg(args, dist, dev, rank, world, steps, warmup):
                gradient_allreduce_bytes_per_step=grad_bytes if dist is not None else 0, parameters_reduced=len(grad_params),
                syncbn_layers=sum(1 for m in model.modules() if isinstance(m, (syncbn.CountSyncBatchNorm1d, syncbn.CountSyncBatchNorm2d, syncbn.CountSyncBatchNorm3d))),
                collectives_per_step=dict(calls, ddp_buckets=1) if dist is not None else {}, loss_first=float(losses[0]), loss_last=float(losses[-1]))
+    if not SIM:
+        # the step's roofline object: the sparse convolutions of forward, input-gradient and weight-gradient pass in the pair
+        # model, over the device time between their HIP events in one instrumented step; and where the step's wall time goes (forward incl.
+        # loss / backward incl. the gradient all-reduce / optimiser), each bracketed by events on the current stream
+        try:
+            cz = TrainCensus(ops).run(step)
+            conv_b, conv_f, conv_ms = cz["conv"][1] + cz["wgrad"][1], cz["conv"][2] + cz["wgrad"][2], cz["conv"][3] + cz["wgrad"][3]
+            np_ = PLANE_PRODUCTS.get(ops.get_precision())
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            opt.zero_grad(set_to_none=True)
+            _sync()
+            ev[0].record()
+            loss = net(dict(ex), return_loss=True)["loss"][0]
+            ev[1].record()
+            loss.backward()
+            ev[2].record()
+            opt.step()
+            ev[3].record()
+            _sync()
+            rec["stage_ms"] = dict(forward_and_loss=ev[0].elapsed_time(ev[1]), backward_and_gradient_allreduce=ev[1].elapsed_time(ev[2]),
+                                   optimizer=ev[2].elapsed_time(ev[3]),
+                                   note="one step bracketed by HIP events on the compute stream (the host runs ahead of the device: stage boundaries are the device's)")
+            rec["roofline"] = {
+                "bound": "mfma", "kernel": "sparse convolutions of the step: %d forward + input-gradient launches (ls3d_gather_gemm / ls3d_tile_conv) and %d "
+                                           "weight-gradient launches (ls3d_spconv_wgrad)" % (cz["conv"][0], cz["wgrad"][0]),
+                "achieved": conv_b / (conv_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": conv_b / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": None, "model": "pair model, SURVEY.md 8(d), once per direction: forward, dgrad (the same operator on the transposed table) and wgrad "
+                                          "each move P (Cin + Cout) 4 bytes and do 2 P Cin Cout flops per layer",
+                "algo_bytes_per_step": conv_b, "algo_flops_per_step": conv_f, "sparse_conv_ms_per_step": conv_ms,
+                "share_of_step": conv_ms / rec["step_ms"], "tflops_useful": conv_f / (conv_ms * 1e-3) / 1e12,
+                "forward_and_dgrad": dict(launches=cz["conv"][0], algo_bytes=cz["conv"][1], flops=cz["conv"][2], ms=cz["conv"][3],
+                                          frac=cz["conv"][1] / (cz["conv"][3] * 1e-3) / 1e9 / HBM_PEAK_GBS if cz["conv"][3] else None),
+                "wgrad": dict(launches=cz["wgrad"][0], algo_bytes=cz["wgrad"][1], flops=cz["wgrad"][2], ms=cz["wgrad"][3],
+                              frac=cz["wgrad"][1] / (cz["wgrad"][3] * 1e-3) / 1e9 / HBM_PEAK_GBS if cz["wgrad"][3] else None),
+                "mfma": (dict(unit="TFLOP/s", dtype="bf16", plane_products_per_f32_product=np_, achieved=np_ * conv_f / (conv_ms * 1e-3) / 1e12,
+                              peak=BF16_MFMA_PEAK_TFLOPS, frac=np_ * conv_f / (conv_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS) if np_ else
+                         dict(unit="TFLOP/s", dtype="f32", achieved=conv_f / (conv_ms * 1e-3) / 1e12, peak=F32_MFMA_PEAK_TFLOPS,
+                              frac=conv_f / (conv_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS)),
+                "note": "device time between the HIP events around each launch of one instrumented step (launches of a stream do not overlap)"}
+        except Exception as e:
+            rec["roofline"] = dict(error=repr(e))
     if dist is not None:
         el0, _ = timed(max(2, steps // 2), sync=False)
         k0 = max(2, steps // 2)

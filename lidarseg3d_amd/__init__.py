@@ -19,6 +19,9 @@ def register_all():
 
 register_all()
 
+from . import experiments as _experiments  # noqa: E402
+_experiments.apply()  # LS3D_EXPERIMENT: the measurement tools' A/B hook (no-op when unset)
+
 
 def set_reference_outputs(on=True):
     """Inference computes by default only what `out_logits` / `pred_point_sem_labels` need.  Three tensors that the reference's eval forward also

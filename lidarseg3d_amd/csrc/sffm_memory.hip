@@ -6,7 +6,8 @@
 // nuScenes) and never sees the points, so ls3d_sffm_decoder takes the k / v of every layer as an input.  Layer by layer that side is
 // five launches per layer on a 34-row matrix (qkv projection, attention core, out-projection + residual + LayerNorm, k, v) plus the copies
 // that put k / v into [layer][B][E][L] - ~40 launches of 7 - 30 us each, serial, in front of the decoder (0.35 ms of the 9 ms MSeg3D frame).
-// Here: one workgroup of 16 waves per frame keeps the tokens in LDS through all layers and writes k / v in the decoder's layout.  Round 3's first
+// Here: one workgroup of 16 waves per frame keeps the tokens in LDS through all layers and writes k / v in the decoder's layout (round 6: four
+// phases per layer instead of five, and no second MFMA row block for a 2-token tail: 0.21 -> see profiles/round6_experiments.md).  Round 3's first
 // version (256 threads, a thread per output column walking 96 dependent weight loads per 8 rows) was latency-bound: 0.66 ms against 0.37 ms for
 // the ~40 launches.  Now every contraction is a [64 x 96] x [96 x N] product on v_mfma_f32_32x32x2_f32 (exact f32): a wave owns 32 x 32 output
 // tiles, loads the 48 B-operand values of a tile (two weight rows x 32 columns per step: 2 x 128 contiguous bytes) up front - 48 independent
@@ -29,25 +30,56 @@ struct SmParams {
   SmLayer layer[SM_MAX_LAYERS];
 };
 
-// C tile (rb, cb) = A[rb * 32 .. + 32][0 .. 96) (LDS, row stride lda) x W[0 .. 96)[32 columns], W(e, c) = wtile(cb)[e * ldw + c].  Tile
-// t = rb + nrb * cb goes to wave t % 16.  `epi(rb, cb, acc)` gets the tile in the MFMA's C layout: acc[r] = C[(r & 3) + 8 (r >> 2) + 4 (lane >> 5)][lane & 31].
-template <typename WTile, typename Epi>
-__device__ __forceinline__ void sm_gemm(const float *A, int lda, int nrb, int ncb, WTile wtile, int ldw, Epi epi) {
+// One GEMM phase over the token tile A (LDS, row stride lda, K = 96): `ntile` column blocks of 32 outputs, tile t = W_t[0 .. 96)[32 columns] with
+// W_t(e, c) = wtile(t)[e * ldw(t) + c]; put(t, row, col, value) receives every output of the rows < L.
+//   * rows 0 .. 31 (and 32 .. 63 when the tail is long) on v_mfma_f32_32x32x2_f32, one 32 x 32 tile per wave: the 48 B-operand values of a tile (two
+//     weight rows x 32 columns per step) are loaded up front - 48 independent loads in flight - the A operand comes from LDS;
+//   * a SHORT tail (L - 32 <= SM_TAIL rows: nuScenes' 34 = 2 x 17 tokens leave 2) on the vector ALU, one output per thread: a second row
+//     block would cost a full MFMA tile for 2 live rows and a second round of the 16 waves (18 tiles instead of 9 for the q | k | v projection).
+constexpr int SM_TAIL = 8, SM_TB = 24;
+template <typename WTile, typename Ldw, typename Put>
+__device__ __forceinline__ void sm_phase(const float *A, int lda, int L, int ntile, WTile wtile, Ldw ldw, Put put) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = lane & 31, kk = lane >> 5;
-  for (int t = wave; t < nrb * ncb; t += SM_WAVES) {
-    const int rb = t % nrb, cb = t / nrb;
-    const float *w = wtile(cb) + (size_t)kk * ldw + col;
+  int col = lane & 31, kk = lane >> 5;
+#ifndef HIPSIM
+  asm volatile("" : "+v"(col), "+v"(kk));  // per-call values for the compiler: hoisted out of the layer loop, the 16 row predicates and LDS addresses of
+#endif                                       // every phase would live (and spill) across the whole kernel
+  const bool short_tail = L > 32 && L - 32 <= SM_TAIL;
+  const int nrb = (L > 32 && !short_tail) ? 2 : 1;
+  for (int t = wave; t < nrb * ntile; t += SM_WAVES) {
+    const int rb = t % nrb, cb = t / nrb, ld = ldw(cb);
+    const float *w = wtile(cb) + (size_t)kk * ld + col;
     float bv[SM_E / 2];
 #pragma unroll
-    for (int s2 = 0; s2 < SM_E / 2; ++s2) bv[s2] = w[(size_t)(2 * s2) * ldw];  // all 48 loads of the tile in flight at once
+    for (int s2 = 0; s2 < SM_E / 2; ++s2) bv[s2] = w[(size_t)(2 * s2) * ld];
     const float *a = A + (rb * 32 + col) * lda + kk;
     sm_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
     for (int s2 = 0; s2 < SM_E / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s2], bv[s2], acc, 0, 0, 0);
-    epi(rb, cb, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // the MFMA's C layout: acc[r] = C[(r & 3) + 8 (r >> 2) + 4 (lane >> 5)][lane & 31]
+      const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (row < L) put(cb, row, col, acc[r]);
+    }
+  }
+  if (short_tail) {
+    const int per_row = ntile * 32, work = (L - 32) * per_row;
+    for (int o = threadIdx.x; o < work; o += SM_THREADS) {
+      const int row = 32 + o / per_row, cc = o % per_row, cb = cc >> 5, c = cc & 31, ld = ldw(cb);
+      const float *w = wtile(cb) + c, *a = A + row * lda;
+      float acc = 0.0f;
+#pragma unroll
+      for (int h = 0; h < SM_E / SM_TB; ++h) {  // batches of SM_TB loads in flight (the 16-wave workgroup leaves 128 registers per lane: 96 at once spill)
+        float wv[SM_TB];
+#pragma unroll
+        for (int e = 0; e < SM_TB; ++e) wv[e] = w[(size_t)(h * SM_TB + e) * ld];  // consecutive threads read consecutive columns: coalesced
+#pragma unroll
+        for (int e = 0; e < SM_TB; ++e) acc = fmaf(a[h * SM_TB + e], wv[e], acc);
+      }
+      put(cb, row, c, acc);
+    }
   }
 }
 
@@ -57,24 +89,36 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
   float *M = smem;                       // [SM_LMAX][SM_MS] tokens (rows >= L stay zero)
   float *Q = M + SM_LMAX * SM_MS;        // [SM_LMAX][SM_QS] q | k | v of the self-attention
   float *A = Q + SM_LMAX * SM_QS;        // [SM_LMAX][SM_MS] attention output
-  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
-  const int col = lane & 31, kk = lane >> 5;
-  const int nrb = L > 32 ? 2 : 1;        // 32-row blocks that hold tokens
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int NL = prm.num_layers;
   for (int i = tid; i < SM_LMAX * SM_MS; i += SM_THREADS) {
     const int r = i / SM_MS, c = i - r * SM_MS;
     M[i] = (r < L && c < SM_E) ? mem[((size_t)b * L + r) * SM_E + c] : 0.0f;
     A[i] = 0.0f;
   }
   __syncthreads();
-  for (int l = 0; l < prm.num_layers; ++l) {
+  // Everything that reads the tokens as they stand between two layers in ONE phase: the cross attention's k / v projections of layer l - 1
+  // (6 column blocks -> kv[2 (l - 1) + {0, 1}][b][c][token], the decoder's layout) and the q | k | v projection of layer l's self-attention (9
+  // column blocks -> Q): 15 tiles for the 16 waves, one round, one barrier - they were two phases (and, with 34 tokens, 18 + 12 tiles).
+  auto token_phase = [&](int l) {
+    const int nq = l < NL ? 9 : 0, nk = l >= 1 ? 6 : 0;
+    const SmLayer &Pq = prm.layer[l < NL ? l : 0], &Pk = prm.layer[l >= 1 ? l - 1 : 0];
+    sm_phase(M, SM_MS, L, nq + nk,
+             [&](int t) { return t < nq ? Pq.wqkv_t + t * 32 : ((t - nq) < 3 ? Pk.wk_t : Pk.wv_t) + ((t - nq) % 3) * 32; },
+             [&](int t) { return t < nq ? 3 * SM_E : SM_E; },
+             [&](int t, int row, int col, float v) {
+               if (t < nq) {
+                 const int c = t * 32 + col;
+                 Q[row * SM_QS + c] = v + Pq.bqkv[c];
+               } else {
+                 const int which = (t - nq) / 3, c = ((t - nq) % 3) * 32 + col;
+                 kv[(((size_t)(2 * (l - 1) + which) * batch + b) * SM_E + c) * L + row] = v + (which ? Pk.bv : Pk.bk)[c];
+               }
+             });
+  };
+  token_phase(0);
+  for (int l = 0; l < NL; ++l) {
     const SmLayer &P = prm.layer[l];
-    // ---- q | k | v of the self-attention: 288 columns = 9 column blocks (rows >= L hold the bias: never read)
-    sm_gemm(M, SM_MS, nrb, 9, [&](int cb) { return P.wqkv_t + cb * 32; }, 3 * SM_E, [&](int rb, int cb, const sm_f32x16 &acc) {
-      const int c = cb * 32 + col;
-      const float bc = P.bqkv[c];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Q[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * SM_QS + c] = acc[r] + bc;
-    });
     __syncthreads();
     // ---- softmax(q k^T / sqrt(hd)) v: 16 threads per token = 4 heads x 4 key groups (keys j = g, g + 4, ...); the groups' maxima, sums and
     //      outputs are merged over the 4 adjacent lanes by shuffles
@@ -128,15 +172,10 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
       }
     }
     __syncthreads();
-    // ---- out-projection + residual, in place: element (row, column) of M is read and written by one lane only
-    sm_gemm(A, SM_MS, nrb, 3, [&](int cb) { return P.wo_t + cb * 32; }, SM_E, [&](int rb, int cb, const sm_f32x16 &acc) {
-      const int c = cb * 32 + col;
-      const float bc = P.bo[c];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (row < L) M[row * SM_MS + c] += acc[r] + bc;
-      }
+    // ---- out-projection + residual, in place: element (row, column) of M is read and written by one thread only
+    sm_phase(A, SM_MS, L, 3, [&](int t) { return P.wo_t + t * 32; }, [&](int) { return SM_E; }, [&](int t, int row, int col, float v) {
+      const int c = t * 32 + col;
+      M[row * SM_MS + c] += v + P.bo[c];
     });
     __syncthreads();
     // ---- norm1: four lanes per token, two-pass statistics
@@ -164,18 +203,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
       }
     }
     __syncthreads();
-    // ---- k_proj / v_proj of the cross attention -> kv[2 l + {0, 1}][b][c][token]: column blocks 0 - 2 = k, 3 - 5 = v
-    sm_gemm(M, SM_MS, nrb, 6, [&](int cb) { return (cb < 3 ? P.wk_t : P.wv_t) + (cb % 3) * 32; }, SM_E, [&](int rb, int cb, const sm_f32x16 &acc) {
-      const int which = cb / 3, c = (cb % 3) * 32 + col;
-      const float bc = (which ? P.bv : P.bk)[c];
-      float *dst = kv + (((size_t)(2 * l + which) * batch + b) * SM_E + c) * L;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (row < L) dst[row] = acc[r] + bc;
-      }
-    });
-    // (the next layer's first phase only reads M and writes Q; its barrier orders it against this one's reads)
+    token_phase(l + 1);  // k / v of this layer for the decoder + q | k | v of the next layer's self-attention
   }
   if (mem_out) {
     __syncthreads();

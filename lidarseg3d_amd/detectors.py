@@ -125,7 +125,7 @@ def _capacity_forward(model, example, features):
     return model.point_head.predict(example=example, test_cfg=model.test_cfg)
 
 
-_LEAN_START = _os.environ.get("LS3D_LEAN_START", "1") != "0"  # A/B: without the three small launches between the voxelization and the reader
+_LEAN_START = True  # A/B (module constant; experiments.py): without the three small launches between the voxelization and the reader
 
 
 def _points_bxyz(points, training):

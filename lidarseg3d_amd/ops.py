@@ -338,8 +338,9 @@ class TransVFEModel(object):
         return v
 
 
-_TRANSVFE_PLANES = _os.environ.get("LS3D_TRANSVFE_PLANES", "1") != "0"
-_GATHER_X6 = _os.environ.get("LS3D_GATHER_X6", "1") != "0"  # bf16x6: strided / inverse layers on the 6-product gather-GEMM (split accumulators); 0: exact f32
+_TRANSVFE_PLANES = True
+_FAST_LAYERNORM = True  # training: nn.LayerNorm over >= 4096 rows on ls3d_layer_norm_* (fast_linear_backward)
+_GATHER_X6 = True  # bf16x6: strided / inverse layers on the 6-product gather-GEMM (split accumulators); False: exact f32
 
 
 def transvfe(voxels, num_points, model, n_dev=None):
@@ -498,7 +499,7 @@ def gather_gemm_pack(w_plain, kvol, cin, cin_pad, cout, nt=0, precision=F32):
     return out
 
 
-_TARGET_BLOCKS = int(_os.environ.get("LS3D_TARGET_BLOCKS", "0"))
+_TARGET_BLOCKS = 0
 
 
 def choose_geometry(cout, n_rows, target_blocks=None):
@@ -571,7 +572,7 @@ def rulebook_orders(tbls, n_devs=None):
     return out
 
 
-_PARITY_ORDER = _os.environ.get("LS3D_PARITY_ORDER", "1") != "0"  # A/B: transposed strided tables ordered by coordinate residue class (one radix pass)
+_PARITY_ORDER = True  # A/B: transposed strided tables ordered by coordinate residue class (one radix pass)
 
 
 def rulebook_parity_orders(coords, geoms, n_devs=None):
@@ -607,7 +608,7 @@ def rulebook_parity_orders(coords, geoms, n_devs=None):
     return out
 
 
-_TRANSVFE_DIRECT = _os.environ.get("LS3D_TRANSVFE_DIRECT", "0") != "0"
+_TRANSVFE_DIRECT = False
 _TRANSVFE_DEDUP = True  # (set_transvfe_dedup: A/B in the tests) identical padding tokens of a voxel computed once (ls3d_transvfe)
 # per-call flags of ls3d_gather_gemm (include/ls3d.h): bits 0-1 workgroup -> tile mapping, bit 2 the one-stage pipeline of the sparse 6-product kernel (A/B)
 _GEMM_FLAGS = 0  # set_gemm_flags: the `flags` of ls3d_gather_gemm (workgroup -> tile mapping, one-stage pipeline) for A/B runs
@@ -685,8 +686,8 @@ def gather_gemm(x, w, tbl=None, order=None, n_rows=None, cout=None, scale=None, 
 
 
 # ---------------------------------------------------------------------------------------------- tile-halo convolution
-_TILE = _os.environ.get("LS3D_TILE", "1") != "0"          # 3-plane modes: SubM layers on ls3d_tile_conv
-_TILE_KINDS = _os.environ.get("LS3D_TILE_KINDS", "subm")  # which rulebook kinds take the tile path: subm[,conv][,inverse]
+_TILE = True          # 3-plane modes: SubM layers on ls3d_tile_conv
+_TILE_KINDS = "subm"  # which rulebook kinds take the tile path: subm[,conv][,inverse]
 _TILE_MIN_CC = 512  # cin*cout below which the gather-GEMM stays
 
 
@@ -699,7 +700,7 @@ def set_tile(on, kinds=None, min_cc=None):
         _TILE_MIN_CC = int(min_cc)
 
 
-_TILE_FLAGS = int(_os.environ.get("LS3D_TILE_FLAGS", "0"))       # per-call flags of ls3d_tile_conv (include/ls3d.h), for A/B runs of unmodified scripts
+_TILE_FLAGS = 0       # per-call flags of ls3d_tile_conv (include/ls3d.h); A/B runs set it through experiments.py
 _TILE_PLAN_FLAGS = 0  # ... of ls3d_tile_plan / ls3d_tile_build
 
 
@@ -743,7 +744,7 @@ def tile_keys(coords, shape_zyx, batch, n_dev=None):
 # 0: neighbour-mask slot order everywhere (default: the coloured layout removes 70 % of the tile kernel's LDS bank conflicts and changes neither its
 # cycles nor its time - profiles/round5_experiments.md 1b - while its plan costs 18 us more per level); 1: coloured halo layout where the caller
 # asks for it (the >= 64-channel levels); 2: on every 3x3x3 SubM table
-_TILE_COLOR = int(_os.environ.get("LS3D_TILE_COLOR", "0"))
+_TILE_COLOR = 0
 
 
 def tile_plan(tbl, coords, shape_zyx, batch, order=None, n_dev=None, color=False):
@@ -820,7 +821,7 @@ class ChainLayer(object):
         self.x, self.w, self.out, self.cout, self.scale, self.shift, self.res_pre, self.relu, self.pair = x, w, out, cout or w.cout, scale, shift, res_pre, relu, pair
 
 
-_TILE_CHAIN = _os.environ.get("LS3D_TILE_CHAIN", "1") != "0"  # A/B: consecutive SubM layers of a UNet level as ONE persistent launch (ls3d_tile_conv_chain)
+_TILE_CHAIN = True  # A/B: consecutive SubM layers of a UNet level as ONE persistent launch (ls3d_tile_conv_chain)
 TILE_CHAIN_MAX = 8
 _CHAIN_STATES = None  # tests: a list that collects the state buffers of the chained launches (state[1] != 0: a wait ran into its watchdog)
 
@@ -838,9 +839,9 @@ def collect_chain_states(on=True):
 # 32-channel units of level 1 last 10 - 17 us: 0.32 ms chained against 0.15 ms).  What it buys there is small (+0.5 - 1 % frames/s: fewer
 # launches; the conv stack itself does not get shorter): the tails the chain fills were not idle POWER - the chip is power-limited in these
 # layers, a workgroup alone on its CU runs 122 us per tile against 213 us for two sharing one, and filling the tails trades clock for occupancy.
-_CHAIN_ABLATE = int(_os.environ.get("LS3D_CHAIN_ABLATE", "0")) & 62  # timing experiments of the chained kernel (ls3d_tile_conv_chain flags bits 1-3)
-_CHAIN_MIN_TILES = int(_os.environ.get("LS3D_CHAIN_MIN_TILES", "600"))
-_CHAIN_MIN_COUT = int(_os.environ.get("LS3D_CHAIN_MIN_COUT", "64"))
+_CHAIN_ABLATE = 0  # (& 62) timing experiments of the chained kernel (ls3d_tile_conv_chain flags bits 1-3)
+_CHAIN_MIN_TILES = 600
+_CHAIN_MIN_COUT = 64
 
 
 def set_tile_chain(on, min_tiles=None, min_cout=None):
@@ -1133,7 +1134,7 @@ class fast_linear_backward(object):
                 rows = input.numel() // max(c, 1)
                 if (input.is_cuda and input.is_contiguous() and input.dtype == torch.float32 and len(normalized_shape) == 1 and normalized_shape[0] == c
                         and weight is not None and bias is not None and c % 4 == 0 and 4 <= c <= 256 and rows >= _FAST_LINEAR_MIN_ROWS
-                        and torch.is_grad_enabled() and _os.environ.get("LS3D_FAST_LAYERNORM", "1") != "0"):
+                        and torch.is_grad_enabled() and _FAST_LAYERNORM):
                     return _LayerNormFn.apply(input.reshape(rows, c), weight, bias, float(eps)).reshape(input.shape)
                 return orig_ln(input, normalized_shape, weight, bias, eps)
             torch.nn.functional.layer_norm = layer_norm

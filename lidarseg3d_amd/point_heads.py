@@ -322,10 +322,10 @@ def _need(r, key):
                                     "lidarseg3d_amd.set_reference_outputs(True) (or run the forward with return_loss=True) before get_loss()" % key)
     return r[key]
 
-_FUSED_SFFM = _os.environ.get("LS3D_FUSED_SFFM", "1") != "0"
+_FUSED_SFFM = True
 # the class-embedding side of all decoder layers in one launch (ls3d_sffm_memory) instead of ~40 small ones: 0.21 ms instead of 0.37 ms per frame
 # on the device since round 4 (round 3's first version was slower than the launches: 0.66 ms); LS3D_FUSED_SFFM_MEMORY=0: layer by layer
-_FUSED_SFFM_MEMORY = _os.environ.get("LS3D_FUSED_SFFM_MEMORY", "1") != "0"
+_FUSED_SFFM_MEMORY = True
 
 
 def set_fused_sffm(on):

@@ -71,7 +71,7 @@ _N_SIDE = 2
 # depend on anything the deeper levels compute.  It runs on its own stream from the moment the encoder leaves the level, beside the
 # deeper levels - whose launches do not fill the chip (level 4 of a 120k-point frame: 215 tiles for 512 workgroup slots) and whose tails
 # leave CUs idle - and the decoder picks it up with one event.  Same kernels on the same inputs: bit-identical.  LS3D_LATERAL_STREAM=0: inline.
-_LATERAL = _os.environ.get("LS3D_LATERAL_STREAM", "1") != "0"
+_LATERAL = True
 # capacity mode: `encoded_spconv_tensor` (scn_unet.py:218-222: conv_out of the deepest level) feeds no segmentation head - the key holds a proxy that
 # runs the convolution (and builds its rulebook) when something reads it, instead of one more rulebook, mask sort and launch beside every frame
 # (lidarseg3d_amd.set_reference_outputs(True) / LS3D_REFERENCE_OUTPUTS=1: computed eagerly, as the reference does)

@@ -25,7 +25,7 @@ def _triple(v):
 # sort (>= 64 x 64 channels).  tools/bench_layers.py: sorted, the 32 -> 64 / 64 -> 32 strided layers of the 120k frame take 61 / 44 us
 # instead of 124 / 87 (~4 offsets per tile instead of ~27), but their two extra 4-pass sorts sit on the geometry stream in front of
 # the level-2 plan and the frame does not get shorter (LS3D_ORDER_MIN_CC=0: 6.08 vs 6.08 ms of convolutions) - left off.
-ORDER_MIN_CC = int(os.environ.get("LS3D_ORDER_MIN_CC", "4096"))
+ORDER_MIN_CC = 4096
 # weight gradients of the layers that share a table run on one set of pair lists (False: each layer builds its own)
 CACHE_PAIRS = True
 

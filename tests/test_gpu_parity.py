@@ -1872,7 +1872,7 @@ def test_unet_tile_path_equals_gather_path_120k():
 def test_chained_tile_launches_equal_layer_by_layer_launches_120k(kind):
     """the shipped inference schedule - every UNet level's SubM layers as ONE persistent launch (ls3d_tile_conv_chain: ticket queue, tiles of
     layer l + 1 waiting on their producer tiles of layer l, coherent sc1 accesses across the XCDs' L2s inside the launch) - against the
-    layer-by-layer launches of round 4 (LS3D_TILE_CHAIN=0) on a 120 000-point frame and on a two-frame batch: logits BIT-IDENTICAL, in eager
+    layer-by-layer launches of round 4 (ops.set_tile_chain(False)) on a 120 000-point frame and on a two-frame batch: logits BIT-IDENTICAL, in eager
     capacity mode, with host-side counts and as a hipGraph replayed several times; no wait ran into its watchdog; the chained path really runs
     (where it pays by default: levels 2 and 3, 6 layers each; with the thresholds lowered every level: 7 + 6 + 6 + 7 + 2 layers)."""
     from lidarseg3d_amd import detectors, graph as lgraph

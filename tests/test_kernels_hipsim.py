@@ -1547,7 +1547,7 @@ def test_unet_bf16x8_tile_path_vs_f32(monkeypatch):
 @pytest.mark.parametrize("cin,capacity", [(13, True), (16, False)])
 def test_unet_chained_levels_equal_layer_by_layer_launches(cin, capacity, monkeypatch):
     """UNetSCN3D's inference forward with every level's SubM layers as one chained launch (scn_unet._Chain -> ls3d_tile_conv_chain) is
-    bit-identical to the layer-by-layer launches (LS3D_TILE_CHAIN=0: the round-4 schedule with the lateral blocks on their own stream), with
+    bit-identical to the layer-by-layer launches (ops.set_tile_chain(False): the round-4 schedule with the lateral blocks on their own stream), with
     host-side counts (one case) and in capacity mode (the other): the narrow net of the emulation (16 / 32 / 64 / 64 channels) with the chain's
     thresholds lowered - levels 2 - 4 chained (6 + 6 + 7 layers, the last with conv_m4 reading the concat buffer the chain itself fills), the
     16-channel level 1 (rows narrower than a 128-byte line: not chainable) through the same code path layer by layer; every output of the

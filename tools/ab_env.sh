@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of environment knobs on the inference bench: one short bench run per setting, one line per run.
+# A/B of module constants on the inference bench (LS3D_EXPERIMENT="ops._TILE_CHAIN=0,..." - lidarseg3d_amd/experiments.py - or the four user switches): one short bench run per setting, one line per run.
 #   bash tools/ab_env.sh name1 "ENV1=a ENV2=b" name2 "ENV3=c" ...      (EXTRA="--model mseg3d" for other bench arguments)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; OUT="$R/gpurun_out/ab"; mkdir -p $OUT
 while [ $# -ge 2 ]; do

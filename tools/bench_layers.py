@@ -5,7 +5,7 @@ One eager frame runs with ops.tile_conv / ops.gather_gemm wrapped: every launch 
 back to back between two events (same inputs, same output buffer).  Per launch: kernel path, rows, channels, kernel offsets, active
 pairs, microseconds, pair-model GB/s (pairs x (cin + cout) x 4 bytes) and useful TFLOP/s.
 
-usage: bench_layers.py [--model sdseg3d|mseg3d] [--reps 20] [--out gpurun_out/layers.json]; environment knobs (LS3D_TILE_FLAGS, ...) apply
+usage: bench_layers.py [--model sdseg3d|mseg3d] [--reps 20] [--out gpurun_out/layers.json]; LS3D_EXPERIMENT="ops._TILE_FLAGS=1,..." (lidarseg3d_amd/experiments.py) applies
 """
 import os, sys, json, argparse
 import numpy as np, torch

@@ -20,7 +20,7 @@ if [ "${TRAIN:-1}" = "1" ]; then
 for P in bf16x6 f32; do
   timeout 400 python tools/bench_train_step.py --model mseg3d --geometry waymo --points 180000 --frames 2 --steps 5 --warmup 2 --precision $P > $P3/round${ROUND}_train_step_mseg3d_waymo_2frames_$P.json 2>> $P3/train.err
 done
-LS3D_FUSED_LOSS=0 LS3D_FAST_LAYERNORM=0 timeout 400 python tools/bench_train_step.py --model mseg3d --geometry waymo --points 180000 --frames 2 --steps 5 --warmup 2 --precision bf16x6 > $P3/round${ROUND}_train_step_mseg3d_waymo_2frames_bf16x6_torch_loss_and_layernorm.json 2>> $P3/train.err
+LS3D_EXPERIMENT="losses.FUSED=0,ops._FAST_LAYERNORM=0" timeout 400 python tools/bench_train_step.py --model mseg3d --geometry waymo --points 180000 --frames 2 --steps 5 --warmup 2 --precision bf16x6 > $P3/round${ROUND}_train_step_mseg3d_waymo_2frames_bf16x6_torch_loss_and_layernorm.json 2>> $P3/train.err
 (cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ptr -o tr -- python $R/tools/bench_train_step.py --model mseg3d --geometry waymo --points 180000 --frames 2 --steps 5 --warmup 2 --precision bf16x6 > /dev/null 2>&1; cp $(find /tmp/ptr -name tr_kernel_stats.csv | head -1) $P3/round${ROUND}_train_step_mseg3d_waymo_kernel_stats.csv)
 timeout 300 python tools/bench_train_step.py --steps 5 --warmup 2 --precision bf16x6 > $P3/round${ROUND}_train_step_sdseg3d_nusc_bf16x6.json 2>> $P3/train.err
 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 tools/bench_train_step.py --model mseg3d --geometry waymo --points 180000 --frames 2 --steps 5 --warmup 2 --precision bf16x6 --ddp --syncbn 2>> $P3/train.err | grep "^{" | tail -1 > $P3/round${ROUND}_train_step_mseg3d_waymo_2frames_ddp_syncbn_bf16x6.json
