@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void k_token_attn_bwd(const float *__restri
 #pragma unroll
       for (int l = 0; l < L; ++l) sm.tile[wave][lane][l] = live ? pr[l] : 0.0f;
 #pragma unroll
-      for (int d = 0; d < TA_HD; ++d) sm.rows[wave][lane][d] = g[d];
+      for (int d = 0; d < TA_HD; ++d) sm.rows[wave][lane][d] = live ? g[d] : 0.0f;  // a dead lane re-read row n - 1: 0 x Inf / NaN of that row must not reach d V
     }
     __syncthreads();
     ta_accumulate<L>(sm.tile[wave], sm.rows[wave], lane, aV);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void k_token_attn_bwd(const float *__restri
 #pragma unroll
     for (int l = 0; l < L; ++l) sm.tile[wave][lane][l] = live ? da[l] : 0.0f;
 #pragma unroll
-    for (int d = 0; d < TA_HD; ++d) sm.rows[wave][lane][d] = qr[d];
+    for (int d = 0; d < TA_HD; ++d) sm.rows[wave][lane][d] = live ? qr[d] : 0.0f;
     __syncthreads();
     ta_accumulate<L>(sm.tile[wave], sm.rows[wave], lane, aK);
     {

@@ -1043,7 +1043,10 @@ class _LinearFn(torch.autograd.Function):
             # y = x W^T + b on the dense exact-f32 gather-GEMM as well (hipBLASLt: ~6 ms of a Waymo step in 32-row macro tiles for these shapes)
             from .packing import PackedWeight
             wt = weight.detach().t().contiguous().reshape(1, cin, cout)
-            return gather_gemm(x.detach(), PackedWeight(wt, 1, cin, cin, cout), cout=cout, shift=bias.detach().contiguous() if bias is not None else None)
+            shift = bias.detach().contiguous() if bias is not None else None
+            if shift is not None and shift.data_ptr() % 16:  # a view into a flattened parameter buffer: the epilogue reads scale / shift with float4 loads
+                shift = shift.clone()
+            return gather_gemm(x.detach(), PackedWeight(wt, 1, cin, cin, cout), cout=cout, shift=shift)
         return torch.nn.functional.linear(x, weight, bias) if _ORIG_LINEAR is None else _ORIG_LINEAR(x, weight, bias)
 
     @staticmethod
