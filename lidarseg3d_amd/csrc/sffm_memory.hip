@@ -17,7 +17,8 @@
 
 constexpr int SM_E = 96, SM_H = 4, SM_HD = 24, SM_LMAX = 64, SM_MAX_LAYERS = 8;
 constexpr int SM_MS = SM_E + 1;       // row stride of the token tiles (floats)
-constexpr int SM_QS = 3 * SM_E + 1;   // row stride of the q | k | v tile
+constexpr int SM_QS = SM_E + 1;       // row stride of the q tile of the self-attention
+constexpr int SM_KS = 2 * SM_E + 4;   // row stride of its k | v tile: a multiple of 4 floats, so that a head's 24 values are six 16-byte reads
 constexpr int SM_THREADS = 1024, SM_WAVES = SM_THREADS / 64;
 typedef float sm_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -87,8 +88,10 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
                                                            float *__restrict__ mem_out) {
   HIP_DYNAMIC_SHARED(float, smem)
   float *M = smem;                       // [SM_LMAX][SM_MS] tokens (rows >= L stay zero)
-  float *Q = M + SM_LMAX * SM_MS;        // [SM_LMAX][SM_QS] q | k | v of the self-attention
+  float *Q = M + SM_LMAX * SM_MS;        // [SM_LMAX][SM_QS] q of the self-attention
   float *A = Q + SM_LMAX * SM_QS;        // [SM_LMAX][SM_MS] attention output
+  float *KV = A + SM_LMAX * SM_MS;       // [SM_LMAX][SM_KS] k | v of the self-attention (16-byte aligned rows: the attention reads them with ds_read_b128 -
+                                         // a key's 24 values per head were 24 ds_read_b32 on the odd-stride q | k | v tile, 432 LDS instructions per thread and layer)
   const int tid = threadIdx.x, b = blockIdx.x;
   const int NL = prm.num_layers;
   for (int i = tid; i < SM_LMAX * SM_MS; i += SM_THREADS) {
@@ -109,7 +112,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
              [&](int t, int row, int col, float v) {
                if (t < nq) {
                  const int c = t * 32 + col;
-                 Q[row * SM_QS + c] = v + Pq.bqkv[c];
+                 const float y = v + Pq.bqkv[c];
+                 if (c < SM_E) Q[row * SM_QS + c] = y;
+                 else KV[row * SM_KS + c - SM_E] = y;
                } else {
                  const int which = (t - nq) / 3, c = ((t - nq) % 3) * 32 + col;
                  kv[(((size_t)(2 * (l - 1) + which) * batch + b) * SM_E + c) * L + row] = v + (which ? Pk.bv : Pk.bk)[c];
@@ -136,10 +141,13 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
         const int j = g + 4 * u;
         float s2 = -3.0e38f;
         if (j < L) {
-          const float *kp = Q + j * SM_QS + SM_E + h * SM_HD;
+          const float4 *kp = (const float4 *)(KV + j * SM_KS + h * SM_HD);
           s2 = 0.0f;
 #pragma unroll
-          for (int d = 0; d < SM_HD; ++d) s2 = fmaf(q[d], kp[d], s2);
+          for (int d4 = 0; d4 < SM_HD / 4; ++d4) {
+            const float4 kq = kp[d4];
+            s2 = fmaf(q[4 * d4], kq.x, s2); s2 = fmaf(q[4 * d4 + 1], kq.y, s2); s2 = fmaf(q[4 * d4 + 2], kq.z, s2); s2 = fmaf(q[4 * d4 + 3], kq.w, s2);
+          }
         }
         sc[u] = s2;
         m = fmaxf(m, s2);
@@ -151,11 +159,15 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
       for (int u = 0; u < SM_LMAX / 4; ++u) {
         const int j = g + 4 * u;
         if (j < L) {
-          const float *vp = Q + j * SM_QS + 2 * SM_E + h * SM_HD;
+          const float4 *vp = (const float4 *)(KV + j * SM_KS + SM_E + h * SM_HD);
           const float p = expf(sc[u] - m);
           den += p;
 #pragma unroll
-          for (int d = 0; d < SM_HD; ++d) o[d] = fmaf(p, vp[d], o[d]);
+          for (int d4 = 0; d4 < SM_HD / 4; ++d4) {
+            const float4 vq = vp[d4];
+            o[4 * d4] = fmaf(p, vq.x, o[4 * d4]); o[4 * d4 + 1] = fmaf(p, vq.y, o[4 * d4 + 1]);
+            o[4 * d4 + 2] = fmaf(p, vq.z, o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(p, vq.w, o[4 * d4 + 3]);
+          }
         }
       }
       den += __shfl_xor(den, 1);
@@ -224,7 +236,7 @@ extern "C" int ls3d_sffm_memory(const float *mem, int batch, int L, int embed, i
     if (!s.wqkv_t || !s.bqkv || !s.wo_t || !s.bo || !s.n1_gamma || !s.n1_beta || !s.wk_t || !s.bk || !s.wv_t || !s.bv) return LS3D_ERR_ARG;
     prm.layer[l] = SmLayer{s.wqkv_t, s.bqkv, s.wo_t, s.bo, s.n1_gamma, s.n1_beta, s.wk_t, s.bk, s.wv_t, s.bv, s.n1_eps};
   }
-  const int lds = (2 * SM_LMAX * SM_MS + SM_LMAX * SM_QS) * (int)sizeof(float);
+  const int lds = SM_LMAX * (2 * SM_MS + SM_QS + SM_KS) * (int)sizeof(float);
   static bool attr_set_on[LS3D_MAX_DEVICES] = {};  // the attribute is per device (multi-GPU servers, multi-device tests)
   bool &attr_set = attr_set_on[ls3d_device_slot()];
   if (!attr_set) {
