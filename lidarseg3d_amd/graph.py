@@ -29,10 +29,23 @@ kernel's channel split are per stream, the pinned count buffer is per capture), 
 and later `fg.finish(ex)` - the replays of different slots overlap on the GPU (bench.py's `throughput_mode.graph_*`)."""
 import torch
 
-from . import detectors
+from . import detectors, ops
 
 
 PAD_COORD = 1.0e6  # metres: outside any point-cloud range, finite in f32 arithmetic
+
+# Captured graphs are RETIRED, never destroyed.  A frame's graph forks into side streams (geometry, lateral blocks, head), so its hipGraphExec runs on
+# several internal streams of the HIP runtime; on ROCm 7.0 destroying a hipGraphExec while another one exists leaves the runtime with dangling
+# stream pointers, and the replay of a graph captured LATER segfaults in hip::Graph::UpdateStreams (hipGraphLaunch) - reproduced in seconds by
+# tools/scratch/stress_bucket.py (two bucket graphs of one model captured, replayed, dropped; the next model's first replay crashes), gone when the
+# torch.cuda.CUDAGraph objects stay referenced, whatever else is freed.  The price is the retired graph's private memory pool (1 - 3 GB for a 120k-point
+# frame) until the process ends; graphs retire only on an overflow recapture, an LRU eviction of BucketedFrameGraph or when their FrameGraph is dropped.
+_RETIRED = []
+
+
+def retired_graphs():
+    """number of captured graphs that were dropped by their owners and are kept alive (see _RETIRED)"""
+    return len(_RETIRED)
 
 
 def pad_rows(key, like, rows, batch_size):
@@ -46,14 +59,14 @@ def pad_rows(key, like, rows, batch_size):
 
 
 class FrameGraph(object):
-    def __init__(self, model, example, warmup=3, stream=None, point_keys=None):
+    def __init__(self, model, example, warmup=3, stream=None, point_keys=None, pool=None):
         if model.training:
             raise ValueError("FrameGraph is an inference path: model.eval() first")
         if (getattr(model, "test_cfg", None) or {}).get("tta_flag", False) and int(example.get("batch_size", 1)) != 1:
             raise ValueError("FrameGraph does not capture test-time-augmentation batches (their merge is per group of frames)")
         if not detectors.CAPACITY_MODE:
             raise ValueError("FrameGraph needs capacity mode (LS3D_CAPACITY_MODE=0 is set)")
-        self.model, self.warmup, self.stream = model, int(warmup), stream
+        self.model, self.warmup, self.stream, self.pool = model, int(warmup), stream, pool
         self.batch_size = int(example.get("batch_size", 1))
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example.items()}
         if self.batch_size > 1:
@@ -80,15 +93,23 @@ class FrameGraph(object):
         bb.__dict__.pop("_captured_record", None)
         old = bb.__dict__.get("_pinned_counts")
         if old is not None:  # this graph's own pinned count buffer (allocated outside the capture): graphs of other frame slots keep theirs
-            bb.__dict__["_pinned_counts"] = torch.empty(old.shape, dtype=old.dtype, pin_memory=True)
+            bb.__dict__["_pinned_counts"] = ops.registered_host(old.shape, old.dtype)
+        if self.graph is not None:
+            _RETIRED.append(self.graph)  # the graph this capture replaces (overflow -> recapture)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), (torch.cuda.graph(g) if self.stream is None else torch.cuda.graph(g, stream=self.stream)):
+        kw = dict(pool=self.pool) if self.pool is not None else {}
+        with torch.no_grad(), (torch.cuda.graph(g, **kw) if self.stream is None else torch.cuda.graph(g, stream=self.stream, **kw)):
             ret = model(dict(self.static), return_loss=False)
         rec = bb.__dict__.pop("_captured_record", None)
         if rec is None:
             raise RuntimeError("the captured forward did not take the capacity path (see detectors._capacity_ok)")
         self.graph, self.ret, self.record = g, ret, rec
         self.logits = model.point_head.forward_ret_dict.get("out_logits")
+
+    def __del__(self):
+        g = self.__dict__.get("graph")
+        if g is not None:
+            _RETIRED.append(g)
 
     def matches(self, example):
         if int(example.get("batch_size", 1)) != self.batch_size:
@@ -198,12 +219,15 @@ class BucketedFrameGraph(object):
     """One FrameGraph per point-count bucket: a frame of n points runs on the graph captured for ceil(n / bucket_points) * bucket_points rows,
     padded inside the graph's input buffers (FrameGraph, `point_keys`).  Padding costs the per-point tail only (the voxelizer rejects the rows,
     the neighbour search and the decoder never visit them), so coarse buckets are cheap: 16384 points = 14 % of a 120k sweep at most ~0.1 ms.
-    A bucket is captured the first time a frame falls into it (from that frame, padded); `max_graphs` bounds the private memory pools kept
-    (least recently used bucket dropped).  Same results as the eager forward for every real point (tests: bit-identical labels)."""
+    A bucket is captured the first time a frame falls into it (from that frame, padded); the buckets share one private memory pool; beyond
+    `max_graphs` the least recently used bucket is dropped (its graph is retired, see _RETIRED).  Same results as the eager forward for every real point (tests: bit-identical labels)."""
 
-    def __init__(self, model, bucket_points=16384, point_keys=("points", "points_cuv"), warmup=3, max_graphs=8):
+    def __init__(self, model, bucket_points=16384, point_keys=("points", "points_cuv"), warmup=3, max_graphs=8, share_pool=True):
         self.model, self.bucket_points, self.point_keys, self.warmup, self.max_graphs = model, int(bucket_points), tuple(point_keys), warmup, int(max_graphs)
         self.graphs, self.captures = {}, 0
+        # one private memory pool for all buckets: they are never replayed side by side, so a bucket's intermediates may live where another bucket's
+        # were (its OUTPUTS stay allocated while its FrameGraph lives; like every clone=False result they are valid until the next call)
+        self.pool = torch.cuda.graph_pool_handle() if (share_pool and torch.cuda.is_available()) else None
 
     def bucket(self, n):
         return max(1, -(-int(n) // self.bucket_points)) * self.bucket_points
@@ -224,7 +248,7 @@ class BucketedFrameGraph(object):
                     padded[k] = torch.cat([example[k], pad_rows(k, example[k], cap - example[k].shape[0], bs)])
             if len(self.graphs) >= self.max_graphs:
                 self.graphs.pop(next(iter(self.graphs)))
-            fg = FrameGraph(self.model, padded, warmup=self.warmup, point_keys=[k for k in self.point_keys if k in example])
+            fg = FrameGraph(self.model, padded, warmup=self.warmup, point_keys=[k for k in self.point_keys if k in example], pool=self.pool)
             self.captures += 1
         self.graphs[key] = fg  # most recently used last
         return fg

@@ -70,6 +70,26 @@ def make_grid(voxel_size, pc_range):
     return Grid(_f3(vs), _f3(r[:3]), _i3(g)), [int(x) for x in g]
 
 
+def registered_host(shape, dtype):
+    """page-locked host tensor that PyTorch's caching host allocator does not own: plain host memory registered with hipHostRegister, unregistered when
+    the tensor dies.  For the count buffers a CAPTURED frame copies into (scn_unet.UNetSCN3D, graph.FrameGraph): a non_blocking copy into a
+    torch.empty(pin_memory=True) tensor makes the caching host allocator record one of its pooled events on the stream - inside a capture that becomes
+    an event-record node of the hipGraph, the pooled event outlives the graph, and once two graphs that coexisted have been destroyed the
+    replay of a later graph that got the same pooled event segfaults inside hipGraphLaunch (tools/scratch/stress_bucket.py reproduces it in seconds on
+    ROCm 7.0; keeping the destroyed graphs alive avoids it).  Registered memory is pinned for the copy engine and invisible to that allocator."""
+    import weakref
+    t = torch.empty(shape, dtype=dtype)
+    if not torch.cuda.is_available():
+        return t
+    rt = torch.cuda.cudart()
+    nbytes = max(t.numel() * t.element_size(), 1)
+    err = rt.cudaHostRegister(t.data_ptr(), nbytes, 0)
+    if int(err) != 0:
+        raise RuntimeError("hipHostRegister failed: %r" % (err,))
+    weakref.finalize(t.untyped_storage(), rt.cudaHostUnregister, t.data_ptr())
+    return t
+
+
 def _ws(nbytes, like):
     return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=like.device)
 

@@ -656,7 +656,7 @@ class UNetSCN3D(nn.Module):
                 # captured frame (graph.FrameGraph) needs the same host address on every replay
                 host = self.__dict__.get("_pinned_counts")
                 if host is None or host.shape != cnts.shape:
-                    host = self.__dict__["_pinned_counts"] = torch.empty(cnts.shape, dtype=cnts.dtype, pin_memory=True)
+                    host = self.__dict__["_pinned_counts"] = ops.registered_host(cnts.shape, cnts.dtype)
                 host.copy_(cnts, non_blocking=True)
                 batch_dict["geometry_record"] = (host, gs.finish_event(), (vc.shape[0], batch_size, len(chain)))
                 gs.keep(cnts)
