@@ -4,7 +4,7 @@
 # ON the box by profiles/summarize_pmc.py into gpurun_out/profiles_r$ROUND/ (the raw counter CSVs exceed gpurun's pull limit).  Copy that
 # directory's files into profiles/ afterwards.   usage: COMMIT=<sha> bash tools/collect_profiles.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-5}
+ROUND=${ROUND:-6}
 cd "$R"; mkdir -p gpurun_out/profiles_r$ROUND; OUT="$R/gpurun_out"; P3="$OUT/profiles_r$ROUND"
 export TMPDIR=/tmp
 RAW=/tmp/ls3d_prof; rm -rf $RAW; mkdir -p $RAW
