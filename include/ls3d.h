@@ -669,6 +669,10 @@ typedef struct {
 } ls3d_sffm_memory_layer_t;
 int ls3d_sffm_memory(const float *mem, int batch, int L, int embed, int heads, int num_layers, const ls3d_sffm_memory_layer_t *layers_host,
                      float *kv, float *mem_out, ls3d_stream_t stream);
+/* diagnostics (tools/trace_memory.py): the same launch in a tracing build - trace[2 + 4 num_layers] shader-clock values of frame 0's first thread at the
+ * phase boundaries (tokens staged; per layer: q | k | v projections, self-attention, out-projection, norm1; the last k / v projections) */
+int ls3d_sffm_memory_trace(const float *mem, int batch, int L, int embed, int heads, int num_layers, const ls3d_sffm_memory_layer_t *layers,
+                           float *kv, unsigned long long *trace, ls3d_stream_t stream);
 
 /* SparsePointCorssAttention core (context_module.py:339-372): q[n,embed] (already projected), per-frame
  * k,v[batch, heads, embed/heads, L] (Conv1d outputs reshaped as the reference does), softmax(q.k*scale) v

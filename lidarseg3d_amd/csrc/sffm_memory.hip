@@ -84,8 +84,16 @@ __device__ __forceinline__ void sm_phase(const float *A, int lda, int L, int nti
   }
 }
 
+// TR: tracing build (ls3d_sffm_memory_trace): thread 0 of frame 0 records the shader clock at every phase boundary
+template <bool TR>
 __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restrict__ mem, int batch, int L, SmParams prm, float *__restrict__ kv,
-                                                           float *__restrict__ mem_out) {
+                                                           float *__restrict__ mem_out, unsigned long long *__restrict__ trace) {
+  [[maybe_unused]] int tr_n = 0;
+#define SM_MARK()                                                                   \
+  if constexpr (TR) {                                                               \
+    if (threadIdx.x == 0 && blockIdx.x == 0) trace[tr_n] = ls3d_cycles();           \
+    ++tr_n;                                                                         \
+  }
   HIP_DYNAMIC_SHARED(float, smem)
   float *M = smem;                       // [SM_LMAX][SM_MS] tokens (rows >= L stay zero)
   float *Q = M + SM_LMAX * SM_MS;        // [SM_LMAX][SM_QS] q of the self-attention
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
     A[i] = 0.0f;
   }
   __syncthreads();
+  SM_MARK()  // 0: tokens staged
   // Everything that reads the tokens as they stand between two layers in ONE phase: the cross attention's k / v projections of layer l - 1
   // (6 column blocks -> kv[2 (l - 1) + {0, 1}][b][c][token], the decoder's layout) and the q | k | v projection of layer l's self-attention (9
   // column blocks -> Q): 15 tiles for the 16 waves, one round, one barrier - they were two phases (and, with 34 tokens, 18 + 12 tiles).
@@ -125,6 +134,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
   for (int l = 0; l < NL; ++l) {
     const SmLayer &P = prm.layer[l];
     __syncthreads();
+    SM_MARK()  // 1 + 4 l: q | k | v (+ the previous layer's k / v projections) done
     // ---- softmax(q k^T / sqrt(hd)) v: 16 threads per token = 4 heads x 4 key groups (keys j = g, g + 4, ...); the groups' maxima, sums and
     //      outputs are merged over the 4 adjacent lanes by shuffles
     {
@@ -184,12 +194,14 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
       }
     }
     __syncthreads();
+    SM_MARK()  // 2 + 4 l: self-attention done
     // ---- out-projection + residual, in place: element (row, column) of M is read and written by one thread only
     sm_phase(A, SM_MS, L, 3, [&](int t) { return P.wo_t + t * 32; }, [&](int) { return SM_E; }, [&](int t, int row, int col, float v) {
       const int c = t * 32 + col;
       M[row * SM_MS + c] += v + P.bo[c];
     });
     __syncthreads();
+    SM_MARK()  // 3 + 4 l: out-projection done
     // ---- norm1: four lanes per token, two-pass statistics
     if (tid < 4 * SM_LMAX) {
       const int r = tid >> 2, part = tid & 3;
@@ -215,16 +227,20 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
       }
     }
     __syncthreads();
+    SM_MARK()  // 4 + 4 l: norm1 done
     token_phase(l + 1);  // k / v of this layer for the decoder + q | k | v of the next layer's self-attention
   }
+  __syncthreads();
+  SM_MARK()  // 1 + 4 NL: the last k / v projections done
+#undef SM_MARK
   if (mem_out) {
     __syncthreads();
     for (int i = tid; i < L * SM_E; i += SM_THREADS) mem_out[(size_t)b * L * SM_E + i] = M[(i / SM_E) * SM_MS + i % SM_E];
   }
 }
 
-extern "C" int ls3d_sffm_memory(const float *mem, int batch, int L, int embed, int heads, int num_layers, const ls3d_sffm_memory_layer_t *layers,
-                                float *kv, float *mem_out, ls3d_stream_t stream_) {
+static int sm_launch(const float *mem, int batch, int L, int embed, int heads, int num_layers, const ls3d_sffm_memory_layer_t *layers,
+                     float *kv, float *mem_out, unsigned long long *trace, ls3d_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!mem || !kv || batch < 0 || L < 1 || num_layers < 0 || (num_layers > 0 && !layers)) return LS3D_ERR_ARG;
   if (embed != SM_E || heads != SM_H || L > SM_LMAX || num_layers > SM_MAX_LAYERS) return LS3D_ERR_UNSUPPORTED;  // the caller composes it layer by layer
@@ -240,10 +256,24 @@ extern "C" int ls3d_sffm_memory(const float *mem, int batch, int L, int embed, i
   static bool attr_set_on[LS3D_MAX_DEVICES] = {};  // the attribute is per device (multi-GPU servers, multi-device tests)
   bool &attr_set = attr_set_on[ls3d_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void *)k_sffm_memory, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return LS3D_ERR_LAUNCH;
+    if (hipFuncSetAttribute((const void *)k_sffm_memory<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_sffm_memory<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return LS3D_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_sffm_memory, dim3((unsigned)batch), dim3(SM_THREADS), lds, stream, mem, batch, L, prm, kv, mem_out);
+  if (trace) hipLaunchKernelGGL(k_sffm_memory<true>, dim3((unsigned)batch), dim3(SM_THREADS), lds, stream, mem, batch, L, prm, kv, mem_out, trace);
+  else hipLaunchKernelGGL(k_sffm_memory<false>, dim3((unsigned)batch), dim3(SM_THREADS), lds, stream, mem, batch, L, prm, kv, mem_out, trace);
   LS3D_RETURN_IF_LAUNCH_FAILED();
   return LS3D_OK;
+}
+
+extern "C" int ls3d_sffm_memory(const float *mem, int batch, int L, int embed, int heads, int num_layers, const ls3d_sffm_memory_layer_t *layers,
+                                float *kv, float *mem_out, ls3d_stream_t stream) {
+  return sm_launch(mem, batch, L, embed, heads, num_layers, layers, kv, mem_out, nullptr, stream);
+}
+
+extern "C" int ls3d_sffm_memory_trace(const float *mem, int batch, int L, int embed, int heads, int num_layers, const ls3d_sffm_memory_layer_t *layers,
+                                      float *kv, unsigned long long *trace, ls3d_stream_t stream) {
+  if (!trace) return LS3D_ERR_ARG;
+  return sm_launch(mem, batch, L, embed, heads, num_layers, layers, kv, nullptr, trace, stream);
 }

@@ -1813,6 +1813,42 @@ def test_mseg3d_absolute_tolerance_at_logit_scale_10():
         ops.set_precision("f32")
 
 
+def test_mseg3d_120k_frame_logits_and_miou_vs_oracle():
+    """BASELINE configs[2] at its FULL size (MSeg3D at 120k had properties only): ONE 120 000-point frame - the frame bench.py's `mseg3d` leg
+    times - with the six camera feature maps [1, 6, 48, 160, 240], GPU logits in the bf16x6 arithmetic of the bench and in exact f32 against the CPU
+    oracle's at |logit|max = 10: max-abs <= 1e-3 absolute, argmax agreement >= 99.9 %, mIoU(GPU labels, oracle labels) >= 0.999.  One oracle forward."""
+    import json
+    import os
+    cfg = synth.NUSC
+    model, sd = _model(models_cfg.mseg3d())
+    n = 120000
+    frame = synth.lidar_frame(n, seed=100, **cfg)
+    img, emb, cuv = synth.camera_inputs(n, seed=100, ncam=6, c_img=48, h=160, w=240)
+    pts = cu(np.concatenate([np.zeros((n, 1), np.float32), frame], 1))
+    ex = dict(points=pts, batch_size=1, points_cuv=cu(cuv), image_features=cu(img), camera_semantic_embeddings=cu(emb))
+    sd10 = _at_logit_scale_10(model, sd, ex)
+    ref = orc.mseg3d_forward(sd10, [frame], torch.from_numpy(cuv), torch.from_numpy(img), torch.from_numpy(emb), cfg["voxel_size"], cfg["pc_range"])["out_logits"]
+    assert ref.shape == (n, 17) and 9.0 <= float(ref.abs().max()) <= 11.0
+    rec = {}
+    try:
+        for prec in ("bf16x6", "f32"):
+            ops.set_precision(prec)
+            with torch.no_grad():
+                ret = model(dict(ex), return_loss=False)
+            got = model.point_head.forward_ret_dict["out_logits"].cpu()
+            pred = ret[0]["pred_point_sem_labels"].cpu()
+            rec[prec] = dict(max_abs=float((got - ref).abs().max()), rms=float((got - ref).pow(2).mean().sqrt()),
+                             argmax=float((pred == ref.argmax(1)).float().mean()), miou=float(orc.miou(pred.numpy(), ref.argmax(1).numpy(), 17)))
+    finally:
+        ops.set_precision("f32")
+    print(json.dumps(rec))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rec, open("gpurun_out/parity_mseg3d_120k.json", "w"), indent=1)
+    for prec, r in rec.items():
+        assert r["max_abs"] <= 1e-3, (prec, r)
+        assert r["argmax"] >= 0.999 and r["miou"] >= 0.999, (prec, r)
+
+
 def test_sffm_decoder_three_plane_gemms_are_f32_grade():
     """ls3d_sffm_decoder with gemm_products = 6 (the decoder's 37 GEMMs per tile on the exact 3-plane bf16 split, what MSeg3D runs in the
     bf16x6 / bf16x8 precisions) against a float64 evaluation of the reference's SFFM (oracle restatement of context_module.py:89-376 on
