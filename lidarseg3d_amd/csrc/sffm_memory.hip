@@ -137,7 +137,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
     SM_MARK()  // 1 + 4 l: q | k | v (+ the previous layer's k / v projections) done
     // ---- softmax(q k^T / sqrt(hd)) v: 16 threads per token = 4 heads x 4 key groups (keys j = g, g + 4, ...); the groups' maxima, sums and
     //      outputs are merged over the 4 adjacent lanes by shuffles
-    {
+    if ((tid >> 6) * 4 < L) {  // a wave holds 4 tokens: the waves beyond the last token (7 of 16 at 34 tokens) skip the phase
       const int r = tid >> 4, h = (tid >> 2) & 3, g = tid & 3;
       const bool on = r < L;
       const float scale = 1.0f / sqrtf((float)SM_HD);
