@@ -32,14 +32,17 @@ struct SmParams {
 };
 
 // One GEMM phase over the token tile A (LDS, row stride lda, K = 96): `ntile` column blocks of 32 outputs, tile t = W_t[0 .. 96)[32 columns] with
-// W_t(e, c) = wtile(t)[e * ldw(t) + c]; put(t, row, col, value) receives every output of the rows < L.
-//   * rows 0 .. 31 (and 32 .. 63 when the tail is long) on v_mfma_f32_32x32x2_f32, one 32 x 32 tile per wave: the 48 B-operand values of a tile (two
-//     weight rows x 32 columns per step) are loaded up front - 48 independent loads in flight - the A operand comes from LDS;
-//   * a SHORT tail (L - 32 <= SM_TAIL rows: nuScenes' 34 = 2 x 17 tokens leave 2) on the vector ALU, one output per thread: a second row
-//     block would cost a full MFMA tile for 2 live rows and a second round of the 16 waves (18 tiles instead of 9 for the q | k | v projection).
-constexpr int SM_TAIL = 8, SM_TB = 24;
-template <typename WTile, typename Ldw, typename Put>
-__device__ __forceinline__ void sm_phase(const float *A, int lda, int L, int ntile, WTile wtile, Ldw ldw, Put put) {
+// W_t(e, c) = wtile(t)[e * ldw(t) + c]; put(t, row, col, value + bias(t, col)) receives every output of the rows < L.
+//   * rows 0 .. 31 (and 32 .. 63 when the tail is long) on v_mfma_f32_32x32x2_f32, one 32 x 32 tile per wave.  ALL 48 B-operand values of a tile (two
+//     weight rows x 32 columns per step) and the tile's bias are loaded before the first MFMA - a scheduling fence keeps hipcc from interleaving them
+//     with the MFMAs, which it does with 5 - 9 loads in flight (round 6 trace, tools/trace_memory.py: a 15-tile phase took 44 k cycles, 48 dependent
+//     MFMAs are 3 k) - the A operand comes from LDS;
+//   * a SHORT tail (L - 32 <= SM_TAIL rows: nuScenes' 34 = 2 x 17 tokens leave 2) from the SAME registers: lane (col, kk) holds W[2 s + kk][col] for
+//     s = 0 .. 47, i.e. the even (kk = 0) or odd (kk = 1) half of its column's weights, so a tail row's output is two 48-term dot products and one
+//     cross-half shuffle - no second MFMA row block (a full tile and a second round of the 16 waves for 2 live rows), no further loads.
+constexpr int SM_TAIL = 8;
+template <typename WTile, typename Ldw, typename Bias, typename Put>
+__device__ __forceinline__ void sm_phase(const float *A, int lda, int L, int ntile, WTile wtile, Ldw ldw, Bias bias, Put put) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int col = lane & 31, kk = lane >> 5;
 #ifndef HIPSIM
@@ -53,6 +56,8 @@ __device__ __forceinline__ void sm_phase(const float *A, int lda, int L, int nti
     float bv[SM_E / 2];
 #pragma unroll
     for (int s2 = 0; s2 < SM_E / 2; ++s2) bv[s2] = w[(size_t)(2 * s2) * ld];
+    const float bc = bias(cb, col);
+    LS3D_SCHED_FENCE();
     const float *a = A + (rb * 32 + col) * lda + kk;
     sm_f32x16 acc;
 #pragma unroll
@@ -62,24 +67,17 @@ __device__ __forceinline__ void sm_phase(const float *A, int lda, int L, int nti
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // the MFMA's C layout: acc[r] = C[(r & 3) + 8 (r >> 2) + 4 (lane >> 5)][lane & 31]
       const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-      if (row < L) put(cb, row, col, acc[r]);
+      if (row < L) put(cb, row, col, acc[r] + bc);
     }
-  }
-  if (short_tail) {
-    const int per_row = ntile * 32, work = (L - 32) * per_row;
-    for (int o = threadIdx.x; o < work; o += SM_THREADS) {
-      const int row = 32 + o / per_row, cc = o % per_row, cb = cc >> 5, c = cc & 31, ld = ldw(cb);
-      const float *w = wtile(cb) + c, *a = A + row * lda;
-      float acc = 0.0f;
+    if (short_tail) {
+      for (int row = 32; row < L; ++row) {
+        const float *ar = A + row * lda + kk;
+        float part = 0.0f;
 #pragma unroll
-      for (int h = 0; h < SM_E / SM_TB; ++h) {  // batches of SM_TB loads in flight (the 16-wave workgroup leaves 128 registers per lane: 96 at once spill)
-        float wv[SM_TB];
-#pragma unroll
-        for (int e = 0; e < SM_TB; ++e) wv[e] = w[(size_t)(h * SM_TB + e) * ld];  // consecutive threads read consecutive columns: coalesced
-#pragma unroll
-        for (int e = 0; e < SM_TB; ++e) acc = fmaf(a[h * SM_TB + e], wv[e], acc);
+        for (int s2 = 0; s2 < SM_E / 2; ++s2) part = fmaf(ar[2 * s2], bv[s2], part);
+        part += __shfl_xor(part, 32);
+        if (kk == ((row - 32) & 1)) put(cb, row, col, part + bc);  // the two halves hold the same sum: they take the rows alternately
       }
-      put(cb, row, c, acc);
     }
   }
 }
@@ -118,15 +116,15 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
     sm_phase(M, SM_MS, L, nq + nk,
              [&](int t) { return t < nq ? Pq.wqkv_t + t * 32 : ((t - nq) < 3 ? Pk.wk_t : Pk.wv_t) + ((t - nq) % 3) * 32; },
              [&](int t) { return t < nq ? 3 * SM_E : SM_E; },
-             [&](int t, int row, int col, float v) {
+             [&](int t, int col) { return t < nq ? Pq.bqkv[t * 32 + col] : ((t - nq) < 3 ? Pk.bk : Pk.bv)[((t - nq) % 3) * 32 + col]; },
+             [&](int t, int row, int col, float y) {
                if (t < nq) {
                  const int c = t * 32 + col;
-                 const float y = v + Pq.bqkv[c];
                  if (c < SM_E) Q[row * SM_QS + c] = y;
                  else KV[row * SM_KS + c - SM_E] = y;
                } else {
                  const int which = (t - nq) / 3, c = ((t - nq) % 3) * 32 + col;
-                 kv[(((size_t)(2 * (l - 1) + which) * batch + b) * SM_E + c) * L + row] = v + (which ? Pk.bv : Pk.bk)[c];
+                 kv[(((size_t)(2 * (l - 1) + which) * batch + b) * SM_E + c) * L + row] = y;
                }
              });
   };
@@ -196,10 +194,8 @@ __global__ __launch_bounds__(SM_THREADS) void k_sffm_memory(const float *__restr
     __syncthreads();
     SM_MARK()  // 2 + 4 l: self-attention done
     // ---- out-projection + residual, in place: element (row, column) of M is read and written by one thread only
-    sm_phase(A, SM_MS, L, 3, [&](int t) { return P.wo_t + t * 32; }, [&](int) { return SM_E; }, [&](int t, int row, int col, float v) {
-      const int c = t * 32 + col;
-      M[row * SM_MS + c] += v + P.bo[c];
-    });
+    sm_phase(A, SM_MS, L, 3, [&](int t) { return P.wo_t + t * 32; }, [&](int) { return SM_E; }, [&](int t, int col) { return P.bo[t * 32 + col]; },
+             [&](int t, int row, int col, float y) { M[row * SM_MS + t * 32 + col] += y; });
     __syncthreads();
     SM_MARK()  // 3 + 4 l: out-projection done
     // ---- norm1: four lanes per token, two-pass statistics
