@@ -73,12 +73,18 @@ __device__ __forceinline__ TvPre tv_fetch(const uint4 *__restrict__ chunk) {
 // K, N are template parameters: in the plane modes the chunk loop is fully unrolled - a kernel with one wave per SIMD has nobody to hide
 // a branch behind, and every per-chunk condition (first / last chunk of a slab, anything left to fetch) splits the MFMAs, the weight
 // prefetch and the LDS stash into basic blocks that hipcc does not schedule across.
+// bias: the GEMM's per-column bias [N]; a lane's two values per 64-column slab are loaded HERE, in front of the chunk loop, and handed to the epilogue:
+// loaded inside the epilogue (round 5) they were two global loads per slab with ~250 cycles of cover - 22 exposed L2 round trips per tile in a kernel
+// that runs one wave per SIMD (round 6, `tools/asm_waits.py`-style reading of the disassembly: `G2 v62 s_waitcnt vmcnt(0)` behind every slab's last MFMA).
 template <int MODE, int K, int N, typename Epi>
-__device__ __forceinline__ void tv_gemm(const float *A, int lda, const float *__restrict__ Wp, float *Bs, Epi epi, TvPre &pre,
+__device__ __forceinline__ void tv_gemm(const float *A, int lda, const float *__restrict__ Wp, float *Bs, const float *__restrict__ bias, Epi epi, TvPre &pre,
                                         const float *__restrict__ next) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int col = lane & 31, kk = lane >> 5;
   constexpr int nslab = N / 64, nkc = K / 32, nchunks = nslab * nkc;
+  float bz0[nslab], bz1[nslab];
+#pragma unroll
+  for (int sb = 0; sb < nslab; ++sb) { bz0[sb] = bias[sb * 64 + col]; bz1[sb] = bias[sb * 64 + 32 + col]; }
   if constexpr (MODE >= 6) {
     const uint4 *Wq = (const uint4 *)Wp, *Wn = next ? (const uint4 *)next : (const uint4 *)Wp;
     uint4 *Bq = (uint4 *)Bs;
@@ -136,7 +142,7 @@ __device__ __forceinline__ void tv_gemm(const float *A, int lda, const float *__
         tv_f32x16 o0, o1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] = acc0[r] + acs0[r]; o1[r] = acc1[r] + acs1[r]; }
-        epi(slab, o0, o1);
+        epi(slab, o0, o1, bz0[slab], bz1[slab]);
       }
       if (c + 1 < nchunks) {
         uint4 *dst = Bq + (buf ^ 1) * TV_PCHUNK;
@@ -173,7 +179,7 @@ __device__ __forceinline__ void tv_gemm(const float *A, int lda, const float *__
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[u].x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[u].y, acc1, 0, 0, 0);
       }
-      if (kc == nkc - 1) epi(slab, acc0, acc1);
+      if (kc == nkc - 1) epi(slab, acc0, acc1, bz0[slab], bz1[slab]);
       if (c + 1 < nchunks) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) bc[u] = bn[u];
@@ -215,7 +221,7 @@ __device__ __forceinline__ void tv_gemm(const float *A, int lda, const float *__
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b.y, acc1, 0, 0, 0);
       }
     }
-    if (kc == nkc - 1) epi(slab, acc0, acc1);
+    if (kc == nkc - 1) epi(slab, acc0, acc1, bz0[slab], bz1[slab]);
     if (c + 1 < nchunks) {
       float4 *dst = (float4 *)(Bs + (buf ^ 1) * TV_BCHUNK);
       dst[tid] = r0; dst[tid + 256] = r1;
@@ -229,7 +235,19 @@ __device__ __forceinline__ void tv_gemm(const float *A, int lda, const float *__
 #define TV_FOR_ACC(r, row) _Pragma("unroll") for (int r = 0, row = 4 * kk; r < 16; ++r, row = (r & 3) + 8 * (r >> 2) + 4 * kk)
 
 // in-place LayerNorm of the 32 x 64 tile X (two lanes per row)
-__device__ __forceinline__ void tv_layernorm(float *X, const float *g, const float *b, float eps) {
+// a LayerNorm's scale / shift for this lane's half row (32 channels): fetched BEFORE the GEMM whose output it normalises and held in registers across it -
+// fetched inside tv_layernorm the 16 loads had ~130 VALU instructions of cover for an L2 round trip (seven LayerNorms per tile, one wave per SIMD)
+struct TvLn { float4 g[8], b[8]; };
+__device__ __forceinline__ TvLn tv_ln_fetch(const float *__restrict__ g, const float *__restrict__ b) {
+  const int half = (threadIdx.x & 63) >> 5;
+  const float4 *gp = (const float4 *)(g + half * 32), *bp = (const float4 *)(b + half * 32);
+  TvLn w;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { w.g[q] = gp[q]; w.b[q] = bp[q]; }
+  return w;
+}
+
+__device__ __forceinline__ void tv_layernorm(float *X, const TvLn &w, float eps) {
   const int lane = threadIdx.x & 63, row = lane & 31, half = lane >> 5;
   float4 *p = (float4 *)(X + row * TV_XS + half * 32);
   float4 v[8];
@@ -246,10 +264,9 @@ __device__ __forceinline__ void tv_layernorm(float *X, const float *g, const flo
   }
   q2 += __shfl_xor(q2, 32);
   const float rstd = 1.0f / sqrtf(q2 / (float)TV_E + eps);
-  const float4 *gp = (const float4 *)(g + half * 32), *bp = (const float4 *)(b + half * 32);
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const float4 gg = gp[q], bb = bp[q];
+    const float4 gg = w.g[q], bb = w.b[q];
     float4 o;
     o.x = v[q].x * rstd * gg.x + bb.x; o.y = v[q].y * rstd * gg.y + bb.y;
     o.z = v[q].z * rstd * gg.z + bb.z; o.w = v[q].w * rstd * gg.w + bb.w;
@@ -416,22 +433,22 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
     TV_WAVE_SYNC();
     TvPre pre;  // the weight chunk in flight across the GEMMs of the tile (plane modes)
     if constexpr (MODE >= 6) pre = tv_fetch((const uint4 *)prm.we);
+    TvLn ln;    // scale / shift of the LayerNorm behind the next GEMM
+    if (prm.num_layers > 0) ln = tv_ln_fetch(prm.layer[0].n1g, prm.layer[0].n1b);
     // ---- embedding (+ norm1 of layer 0)
-    tv_gemm<MODE, TV_KT, TV_E>(T, TV_TS, prm.we, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
-      const float b0 = prm.be[col], b1 = prm.be[32 + col];
+    tv_gemm<MODE, TV_KT, TV_E>(T, TV_TS, prm.we, Bs, prm.be, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1, float b0, float b1) {
       TV_FOR_ACC(r, row) {
         X[row * TV_XS + col] = a0[r] + b0;
         X[row * TV_XS + 32 + col] = a1[r] + b1;
       }
     }, pre, (prm.num_layers > 0 ? prm.layer[0].wqkv : nullptr));
     TV_WAVE_SYNC();
-    if (prm.num_layers > 0) tv_layernorm(X, prm.layer[0].n1g, prm.layer[0].n1b, prm.layer[0].n1eps);
+    if (prm.num_layers > 0) tv_layernorm(X, ln, prm.layer[0].n1eps);
     TV_WAVE_SYNC();
     for (int l = 0; l < prm.num_layers; ++l) {
       const TvLayer &L = prm.layer[l];
       // ---- QKV -> T[:, 0:192]
-      tv_gemm<MODE, TV_E, 3 * TV_E>(X, TV_XS, L.wqkv, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
-        const float b0 = L.bqkv[slab * 64 + col], b1 = L.bqkv[slab * 64 + 32 + col];
+      tv_gemm<MODE, TV_E, 3 * TV_E>(X, TV_XS, L.wqkv, Bs, L.bqkv, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1, float b0, float b1) {
         TV_FOR_ACC(r, row) {
           T[row * TV_TS + slab * 64 + col] = a0[r] + b0;
           T[row * TV_TS + slab * 64 + 32 + col] = a1[r] + b1;
@@ -450,19 +467,18 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       }
       TV_WAVE_SYNC();
       // ---- out-proj + residual (from the normed X) -> X, then norm2
-      tv_gemm<MODE, TV_E, TV_E>(T, TV_TS, L.wo, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
-        const float b0 = L.bo[col], b1 = L.bo[32 + col];
+      ln = tv_ln_fetch(L.n2g, L.n2b);
+      tv_gemm<MODE, TV_E, TV_E>(T, TV_TS, L.wo, Bs, L.bo, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1, float b0, float b1) {
         TV_FOR_ACC(r, row) {
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
           X[row * TV_XS + 32 + col] = a1[r] + b1 + X[row * TV_XS + 32 + col];
         }
       }, pre, L.w1);
       TV_WAVE_SYNC();
-      tv_layernorm(X, L.n2g, L.n2b, L.n2eps);
+      tv_layernorm(X, ln, L.n2eps);
       TV_WAVE_SYNC();
       // ---- FF1 + ReLU -> T[:, 0:128]
-      tv_gemm<MODE, TV_E, TV_FF>(X, TV_XS, L.w1, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
-        const float b0 = L.b1[slab * 64 + col], b1 = L.b1[slab * 64 + 32 + col];
+      tv_gemm<MODE, TV_E, TV_FF>(X, TV_XS, L.w1, Bs, L.b1, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1, float b0, float b1) {
         TV_FOR_ACC(r, row) {
           T[row * TV_TS + slab * 64 + col] = fmaxf(a0[r] + b0, 0.0f);
           T[row * TV_TS + slab * 64 + 32 + col] = fmaxf(a1[r] + b1, 0.0f);
@@ -470,8 +486,8 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       }, pre, L.w2);
       TV_WAVE_SYNC();
       // ---- FF2 + residual -> X, then norm1 of the next layer
-      tv_gemm<MODE, TV_FF, TV_E>(T, TV_TS, L.w2, Bs, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1) {
-        const float b0 = L.b2[col], b1 = L.b2[32 + col];
+      if (l + 1 < prm.num_layers) ln = tv_ln_fetch(prm.layer[l + 1].n1g, prm.layer[l + 1].n1b);
+      tv_gemm<MODE, TV_FF, TV_E>(T, TV_TS, L.w2, Bs, L.b2, [&](int slab, const tv_f32x16 &a0, const tv_f32x16 &a1, float b0, float b1) {
         TV_FOR_ACC(r, row) {
           X[row * TV_XS + col] = a0[r] + b0 + X[row * TV_XS + col];
           X[row * TV_XS + 32 + col] = a1[r] + b1 + X[row * TV_XS + 32 + col];
@@ -479,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void k_transvfe(const float *__restrict__ v
       }, pre, (l + 1 < prm.num_layers ? prm.layer[l + 1].wqkv : nullptr));
       TV_WAVE_SYNC();
       if (l + 1 < prm.num_layers) {
-        tv_layernorm(X, prm.layer[l + 1].n1g, prm.layer[l + 1].n1b, prm.layer[l + 1].n1eps);
+        tv_layernorm(X, ln, prm.layer[l + 1].n1eps);
         TV_WAVE_SYNC();
       }
     }

@@ -70,23 +70,68 @@ def make_grid(voxel_size, pc_range):
     return Grid(_f3(vs), _f3(r[:3]), _i3(g)), [int(x) for x in g]
 
 
+_REGISTERED_HOST = "hip"   # measurement hook (LS3D_EXPERIMENT): "heap" = hipHostRegister on the tensor's own malloc'ed bytes (round 6's first form: a long-lived
+#                            userptr mapping of a heap page, profiles/round6_experiments.md 5), "" = the caching host allocator's pinned memory
+_HOST_SLABS = []           # [tensor over a whole hipHostMalloc'ed slab, bytes handed out]; kept until the process ends
+_HOST_SLAB_BYTES = 1 << 16
+_HIPRT = None
+
+
+def _hip_runtime():
+    """the HIP runtime this process already runs on (the one libtorch_hip.so brought in), for the two calls torch does not expose"""
+    global _HIPRT
+    if _HIPRT is None:
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64.so" in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            raise RuntimeError("the HIP runtime is not loaded in this process")
+        _HIPRT = ctypes.CDLL(path)
+        _HIPRT.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        _HIPRT.hipHostMalloc.restype = ctypes.c_int
+    return _HIPRT
+
+
 def registered_host(shape, dtype):
-    """page-locked host tensor that PyTorch's caching host allocator does not own: plain host memory registered with hipHostRegister, unregistered when
-    the tensor dies.  For the count buffers a CAPTURED frame copies into (scn_unet.UNetSCN3D, graph.FrameGraph): a non_blocking copy into a
-    torch.empty(pin_memory=True) tensor makes the caching host allocator record one of its pooled events on the stream - inside a capture that becomes
-    an event-record node of the hipGraph, the pooled event outlives the graph, and once two graphs that coexisted have been destroyed the
-    replay of a later graph that got the same pooled event segfaults inside hipGraphLaunch (tools/scratch/stress_bucket.py reproduces it in seconds on
-    ROCm 7.0; keeping the destroyed graphs alive avoids it).  Registered memory is pinned for the copy engine and invisible to that allocator."""
-    import weakref
-    t = torch.empty(shape, dtype=dtype)
+    """page-locked host tensor that PyTorch's caching host allocator does not own: a 256-byte slice of a slab from hipHostMalloc that lives until the
+    process ends (a count buffer is a few dozen bytes).  For the count buffers a CAPTURED frame copies into (scn_unet.UNetSCN3D, graph.FrameGraph):
+    a non_blocking copy into a torch.empty(pin_memory=True) tensor makes the caching host allocator record one of its pooled events on the stream -
+    inside a capture that becomes an event-record node of the hipGraph whose event outlives the graph.  Driver-allocated host memory is mapped for
+    the copy engine once and for good: no user-pointer mapping the kernel would have to revalidate whenever it touches the page (what registering a
+    malloc'ed tensor with hipHostRegister created; with it the -m gpu suite died of a GPU memory fault inside one of torch's pageable H2D copies
+    in 3 of 16 runs, never before or after: profiles/round6_experiments.md 5)."""
     if not torch.cuda.is_available():
+        return torch.empty(shape, dtype=dtype)
+    if not _REGISTERED_HOST:
+        return torch.empty(shape, dtype=dtype, pin_memory=True)
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
+        n *= int(d)
+    nbytes = max(n * torch.empty((), dtype=dtype).element_size(), 1)
+    if _REGISTERED_HOST == "heap":
+        import weakref
+        rt = torch.cuda.cudart()
+        t = torch.empty(shape, dtype=dtype)
+        err = rt.cudaHostRegister(t.data_ptr(), nbytes, 0)
+        if int(err) != 0:
+            raise RuntimeError("hipHostRegister failed: %r" % (err,))
+        weakref.finalize(t.untyped_storage(), rt.cudaHostUnregister, t.data_ptr())
         return t
-    rt = torch.cuda.cudart()
-    nbytes = max(t.numel() * t.element_size(), 1)
-    err = rt.cudaHostRegister(t.data_ptr(), nbytes, 0)
-    if int(err) != 0:
-        raise RuntimeError("hipHostRegister failed: %r" % (err,))
-    weakref.finalize(t.untyped_storage(), rt.cudaHostUnregister, t.data_ptr())
+    need = (nbytes + 255) & ~255
+    if not _HOST_SLABS or _HOST_SLABS[-1][1] + need > _HOST_SLABS[-1][0].numel():
+        torch.cuda.current_device()   # the runtime is initialised and this thread has its device
+        size = max(_HOST_SLAB_BYTES, (need + 4095) & ~4095)
+        ptr = ctypes.c_void_p()
+        check(_hip_runtime().hipHostMalloc(ctypes.byref(ptr), size, 0), "hipHostMalloc")
+        whole = torch.frombuffer((ctypes.c_uint8 * size).from_address(ptr.value), dtype=torch.uint8)
+        whole.zero_()
+        _HOST_SLABS.append([whole, 0])
+    slab = _HOST_SLABS[-1]
+    t = slab[0][slab[1]:slab[1] + nbytes].view(dtype).view(shape)
+    slab[1] += need
     return t
 
 
