@@ -457,7 +457,7 @@ int ls3d_tile_conv(const float *in, int in_ld, const void *plan, int n_rows, int
  * (layer, tile) are taken from a ticket counter in layer-major order; a tile of layer l + 1 starts as soon as the tiles that own its halo
  * rows (the plan's producer lists, built by ls3d_tile_build) have finished layer l - so the tail of a layer (677 tiles on 512 workgroup
  * slots) is filled with the next layer's tiles instead of idle CUs.  A unit waits only for units with smaller tickets, so the launch cannot
- * deadlock whatever the number of resident workgroups; a wait of more than ~1 s sets state[1] (int32) and goes on.
+ * deadlock whatever the number of resident workgroups; a wait of more than ~1 s sets state[1] (int32) and traps (the process aborts: no rows computed from a missing halo are published).
  *   layers[l]: the operands of ls3d_tile_conv for layer l (epilogue by value).  A layer may read anything an EARLIER layer of the chain wrote
  *              on the plan's rows (its input, res_pre, pair) and anything written before the launch.  All layers: cout in the same class
  *              (<= 32, <= 64, <= 128), cout % 4 == 0, float4-aligned leading dimensions, no LayerNorm epilogue, products == 6,
@@ -673,6 +673,10 @@ int ls3d_sffm_memory(const float *mem, int batch, int L, int embed, int heads, i
  * phase boundaries (tokens staged; per layer: q | k | v projections, self-attention, out-projection, norm1; the last k / v projections) */
 int ls3d_sffm_memory_trace(const float *mem, int batch, int L, int embed, int heads, int num_layers, const ls3d_sffm_memory_layer_t *layers,
                            float *kv, unsigned long long *trace, ls3d_stream_t stream);
+
+/* diagnostics (tools/probe_graph_timeline.py): *dst = the GPU's 100 MHz wall clock when `stream` reaches this launch (a one-lane kernel: inside a captured
+ * frame it is a graph node, so a replay can be timed stream by stream) */
+int ls3d_stamp(unsigned long long *dst, ls3d_stream_t stream);
 
 /* SparsePointCorssAttention core (context_module.py:339-372): q[n,embed] (already projected), per-frame
  * k,v[batch, heads, embed/heads, L] (Conv1d outputs reshaped as the reference does), softmax(q.k*scale) v

@@ -22,7 +22,7 @@ EXPORTS = [
     "ls3d_tile_keys", "ls3d_tile_plan_bytes", "ls3d_tile_build", "ls3d_tile_plan", "ls3d_tile_plan_workspace_bytes", "ls3d_radix_sort",
     "ls3d_radix_sort_workspace_bytes", "ls3d_tile_conv_packed_bytes", "ls3d_tile_conv_pack", "ls3d_tile_conv_packed_bytes_bf16", "ls3d_tile_conv_pack_bf16", "ls3d_tile_conv", "ls3d_tile_conv_workspace_bytes", "ls3d_tile_conv_counter_bytes", "ls3d_tile_conv_trace_bytes", "ls3d_tile_chain_state_bytes", "ls3d_tile_conv_chain", "ls3d_transvfe_planes_bytes", "ls3d_transvfe_pack_planes",
     "ls3d_voxel_centers", "ls3d_frame_offsets", "ls3d_three_nn", "ls3d_three_interpolate", "ls3d_three_interpolate_grad",
-    "ls3d_seg_loss_workspace_bytes", "ls3d_seg_loss_saved_bytes", "ls3d_seg_loss_forward", "ls3d_seg_loss_backward", "ls3d_layer_norm_workspace_bytes", "ls3d_layer_norm_forward", "ls3d_layer_norm_backward", "ls3d_batch_norm_workspace_bytes", "ls3d_batch_norm_stats", "ls3d_batch_norm_finalize", "ls3d_batch_norm_apply", "ls3d_batch_norm_backward_sums", "ls3d_batch_norm_backward_apply", "ls3d_column_sums_workspace_bytes", "ls3d_column_sums", "ls3d_token_attention_forward", "ls3d_token_attention_workspace_bytes", "ls3d_token_attention_backward", "ls3d_devoxelize", "ls3d_devoxelize_grid", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_interpolate_rows", "ls3d_interpolate_rows_backward", "ls3d_interpolate_rows_backward_workspace_bytes", "ls3d_grid_gather", "ls3d_nchw_to_nhwc", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn", "ls3d_sffm_decoder", "ls3d_sffm_memory", "ls3d_sffm_memory_trace", "ls3d_points_cp", "ls3d_points_cuv",
+    "ls3d_seg_loss_workspace_bytes", "ls3d_seg_loss_saved_bytes", "ls3d_seg_loss_forward", "ls3d_seg_loss_backward", "ls3d_layer_norm_workspace_bytes", "ls3d_layer_norm_forward", "ls3d_layer_norm_backward", "ls3d_batch_norm_workspace_bytes", "ls3d_batch_norm_stats", "ls3d_batch_norm_finalize", "ls3d_batch_norm_apply", "ls3d_batch_norm_backward_sums", "ls3d_batch_norm_backward_apply", "ls3d_column_sums_workspace_bytes", "ls3d_column_sums", "ls3d_token_attention_forward", "ls3d_token_attention_workspace_bytes", "ls3d_token_attention_backward", "ls3d_devoxelize", "ls3d_devoxelize_grid", "ls3d_devoxelize_grid_workspace_bytes", "ls3d_interpolate_rows", "ls3d_interpolate_rows_backward", "ls3d_interpolate_rows_backward_workspace_bytes", "ls3d_grid_gather", "ls3d_nchw_to_nhwc", "ls3d_complete_concat", "ls3d_sfam", "ls3d_cross_attn", "ls3d_sffm_decoder", "ls3d_sffm_memory", "ls3d_sffm_memory_trace", "ls3d_stamp", "ls3d_points_cp", "ls3d_points_cuv",
     "ls3d_dynamic_point_to_voxel_workspace_bytes", "ls3d_dynamic_point_to_voxel_index", "ls3d_dynamic_point_to_voxel_forward", "ls3d_dynamic_point_to_voxel_backward",
     "ls3d_cyl_voxelize", "ls3d_unique_sorted_workspace_bytes", "ls3d_unique_sorted", "ls3d_dyn_point_features", "ls3d_act_affine", "ls3d_tta_merge",
 ]

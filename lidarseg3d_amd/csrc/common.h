@@ -66,7 +66,11 @@ __device__ __forceinline__ void ls3d_sleep() {}
 #define LS3D_WAIT_LGKMCNT0() ((void)0)
 #define LS3D_SCHED_FENCE() ((void)0)
 #define LS3D_RAW_BARRIER() __syncthreads()
+#define LS3D_TRAP() abort()
 #else
+// the wave enters the trap handler: the queue reports an exception and the process aborts.  (As inline assembly, not __builtin_trap(): a noreturn call
+// changes the control flow graph of the kernel around it.)
+#define LS3D_TRAP() asm volatile("s_trap 2" ::: "memory")
 __device__ __forceinline__ void ls3d_glds16(const void *gsrc, void *lds_wave_base) {
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);

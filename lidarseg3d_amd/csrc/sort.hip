@@ -175,3 +175,13 @@ extern "C" int ls3d_radix_sort(const uint32_t *keys, const int32_t *vals, int n,
                                void *workspace, size_t workspace_bytes, ls3d_stream_t stream) {
   return ls3d_radix_sort_pairs(keys, vals, n, n_dev, bits, keys_out, vals_out, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+// diagnostics (tools/probe_graph_timeline.py): one lane writes the 100 MHz wall clock when the stream reaches this point - a node of a captured frame
+// like any other kernel, so the replay of a hipGraph can be timed stream by stream (rocprofv3 serialises the kernels of the side streams)
+__global__ void k_stamp(unsigned long long *dst) { *dst = ls3d_walltime(); }
+extern "C" int ls3d_stamp(unsigned long long *dst, ls3d_stream_t stream) {
+  if (!dst) return LS3D_ERR_ARG;
+  hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, dst);
+  LS3D_RETURN_IF_LAUNCH_FAILED();
+  return LS3D_OK;
+}

@@ -709,7 +709,9 @@ struct TcLayer {
 // layer (+ the total again), [16 .. 16 + TC_CHAIN_MAX) finished tiles per layer, [32 .. 32 + T) layers finished per tile;
 // the layer table follows at byte TC_CH_LAYERS_OFF(T)
 constexpr int TC_CH_USTART = 3, TC_CH_LDONE = 16, TC_CH_DONE = 32;
-constexpr int TC_CH_SPIN_MAX = 1 << 22;  // ~1 s of polling: a wait that long is a bug; the unit goes on and flags state[1]
+constexpr int TC_CH_SPIN_MAX = 1 << 22;  // ~1 s of polling: a wait that long is a bug (producers take their tickets before their consumers and never
+//                                         wait for later tickets) - the unit flags state[1] and TRAPS: the process dies loudly instead of publishing rows
+//                                         computed from a halo that was not there yet
 static inline size_t tc_chain_layers_off(int ntiles) { return tc_align((size_t)(TC_CH_DONE + ntiles) * 4); }
 struct TcChain {
   const TcLayer *layers;
@@ -876,14 +878,14 @@ __global__ __launch_bounds__(TC_THREADS, 2) void k_tile_conv(const float *__rest
             const int *flag = ch.state + TC_CH_DONE + p.tdep[(size_t)tile * TC_DEPCAP + tid];
             for (int spins = 0; ls3d_load_agent_i32(flag) < ch_layer; ++spins) {
               ls3d_sleep();
-              if (spins > TC_CH_SPIN_MAX) { ls3d_store_agent_i32(ch.state + 1, 1); break; }
+              if (spins > TC_CH_SPIN_MAX) { ls3d_store_agent_i32(ch.state + 1, 1); LS3D_TRAP(); break; }
             }
           }
         } else if (tid == 0) {
           const int *flag = ch.state + TC_CH_LDONE + ch_layer - 1;
           for (int spins = 0; ls3d_load_agent_i32(flag) < tlive; ++spins) {
             ls3d_sleep();
-            if (spins > TC_CH_SPIN_MAX) { ls3d_store_agent_i32(ch.state + 1, 1); break; }
+            if (spins > TC_CH_SPIN_MAX) { ls3d_store_agent_i32(ch.state + 1, 1); LS3D_TRAP(); break; }
           }
         }
         __syncthreads();

@@ -135,6 +135,11 @@ def registered_host(shape, dtype):
     return t
 
 
+def stamp(buf, i):
+    """diagnostics: buf[i] (uint64 viewed as int64, on the GPU) = the 100 MHz wall clock when the current stream gets here (ls3d_stamp)"""
+    check(_L().ls3d_stamp(ctypes.c_void_p(buf.data_ptr() + 8 * int(i)), _stream(buf)), "ls3d_stamp")
+
+
 def _ws(nbytes, like):
     return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=like.device)
 

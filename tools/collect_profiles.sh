@@ -36,4 +36,7 @@ echo "summarize rc=$?" >> $P3/summary.txt
 timeout 300 python tools/trace_tile.py --flags 0 --out $P3/round${ROUND}_trace_tile_pipelined > $P3/round${ROUND}_trace_tile_pipelined.txt 2>&1
 rm -f $P3/round${ROUND}_trace_tile_pipelined_flags0.npz
 timeout 300 python tools/bench_layers.py --out $P3/round${ROUND}_layers.json > $P3/round${ROUND}_layers.txt 2>&1
+# when every ops call of a captured frame starts and ends during a replay, stream by stream (ls3d_stamp nodes; rocprofv3 serialises the side streams)
+timeout 300 python tools/probe_graph_timeline.py --min-us 6 > $P3/round${ROUND}_graph_timeline.txt 2>&1
+timeout 300 python tools/probe_graph_timeline.py --model mseg3d --min-us 6 > $P3/round${ROUND}_graph_timeline_mseg3d.txt 2>&1
 cat $P3/summary.txt; tail -30 $P3/summarize.log
