@@ -503,6 +503,29 @@ def test_capacity_mode_equals_host_count_mode_full_size(kind, monkeypatch):
         ops.set_precision("f32")
 
 
+def test_count_buffers_are_driver_allocated_host_memory_and_stamps_tick():
+    """ops.registered_host: the per-model count buffers a captured frame copies into are 256-byte slices of hipHostMalloc slabs - page-locked
+    for the copy engine (a non_blocking copy into them is asynchronous and arrives), disjoint, not owned by torch's caching host allocator,
+    and NOT a hipHostRegister'ed range of the malloc heap (profiles/round6_experiments.md 5b).  ls3d_stamp: the wall clock a stream writes
+    when it gets there - monotonic along a stream, 100 MHz"""
+    a, b = ops.registered_host((3, 2), torch.int32), ops.registered_host((5,), torch.int64)
+    assert a.is_pinned() and b.is_pinned() and a.shape == (3, 2) and b.dtype == torch.int64
+    assert a.data_ptr() % 256 == 0 and b.data_ptr() % 256 == 0 and abs(a.data_ptr() - b.data_ptr()) >= 256
+    src = torch.arange(6, dtype=torch.int32, device="cuda").view(3, 2) + 7
+    a.copy_(src, non_blocking=True)
+    b.copy_(torch.arange(5, device="cuda") * 3, non_blocking=True)
+    torch.cuda.synchronize()
+    assert a.tolist() == [[7, 8], [9, 10], [11, 12]] and b.tolist() == [0, 3, 6, 9, 12]
+    big = torch.randn(3 << 20)  # a pageable copy above the runtime's pin-on-the-fly threshold right beside it: still fine
+    assert torch.equal(big.cuda().cpu(), big)
+    buf = torch.zeros(4, dtype=torch.int64, device="cuda")
+    ops.stamp(buf, 0)
+    torch.cuda._sleep(2_000_000)  # ~1 ms of spinning at ~2 GHz
+    ops.stamp(buf, 1)
+    t = buf.cpu().tolist()
+    assert t[0] > 0 and 2e4 < t[1] - t[0] < 2e6, t  # 0.2 ms .. 20 ms in 10-ns ticks
+
+
 @pytest.mark.parametrize("kind", ["sdseg3d", "mseg3d"])
 def test_frame_graph_equals_eager_forward_120k(kind):
     """graph.FrameGraph: one capacity-mode frame captured into a hipGraph (both streams) and replayed - bit-identical logits and labels
