@@ -2166,6 +2166,105 @@ def test_other_backbones_and_dynamic_readers_as_registered_modules_gpu(case):
         print("f4 modules[%s]: %s" % (case, {k: "%.2g" % v for k, v in f4_module_cases.MEASURED.items()}))
 
 
+def test_spmiddleresnetfhd_full_size_sites_vs_oracle_and_arithmetic_modes():
+    """SpMiddleResNetFHD (scn.py:84-176) on the voxels of a 120k-point sweep at the nuScenes grid (its fixture holds 3k voxels): the output sites of
+    conv1 .. conv4 bit-exact against the oracle's strided rulebook chain (oracle.ref.conv_rulebook: spconv's output order), the dense map's
+    non-zero columns inside those sites' columns; the f32-grade plane arithmetic against the library's exact-f32 mode (1e-4 of the output scale:
+    19 convolutions deep), deterministic (two runs bit-identical)"""
+    cfg = synth.NUSC
+    f = synth.lidar_frame(120000, seed=41, **cfg)
+    pts = cu(np.concatenate([np.zeros((f.shape[0], 1), np.float32), f], 1))
+    v, c, npv, nv = ops.voxelize_hard(pts, cfg["voxel_size"], cfg["pc_range"], 10, 120000, batched=True)
+    V = int(nv)
+    coords = c[:V].contiguous()
+    grid = [int(x) for x in ops.make_grid(cfg["voxel_size"], cfg["pc_range"])[1]]  # x, y, z
+    feats = torch.randn((V, 16), generator=torch.Generator().manual_seed(2)).to(DEV)
+    net = L.build_from_cfg(dict(type="SpMiddleResNetFHD", num_input_features=16, ds_factor=8), L.BACKBONES)
+    sd = {k: torch.from_numpy(a) for k, a in synth.random_state_dict({k: tuple(t.shape) for k, t in net.state_dict().items()}, 7).items()}
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    outs = {}
+    try:
+        for prec in ("f32", "bf16x6", "bf16x6"):
+            ops.set_precision(prec)
+            with torch.no_grad():
+                ret, scales = net(feats, coords, 1, grid)
+            outs.setdefault(prec, []).append((ret.clone(), {k: (t.indices.clone(), t.features.clone(), list(t.spatial_shape)) for k, t in scales.items()}))
+    finally:
+        ops.set_precision("f32")
+    # sites: the oracle's chain
+    cc, sh = coords.cpu().numpy(), [grid[2] + 1, grid[1], grid[0]]
+    want = {"conv1": (cc, sh)}
+    for name, pad in (("conv2", 1), ("conv3", 1), ("conv4", (0, 1, 1))):
+        cc, sh, _ = orc.conv_rulebook(cc, sh, 3, 2, pad)
+        want[name] = (cc, list(sh))
+    ret32, sc32 = outs["f32"][0]
+    for name, (wc, wsh) in want.items():
+        idx, _, shp = sc32[name]
+        assert [int(a) for a in shp] == [int(a) for a in wsh] and np.array_equal(idx.cpu().numpy(), wc.astype(np.int32)), name
+    (ret_a, sc_a), (ret_b, sc_b) = outs["bf16x6"]
+    assert torch.equal(ret_a, ret_b) and all(torch.equal(sc_a[k][1], sc_b[k][1]) for k in sc_a), "two runs of the same frame differ"
+    for name in want:
+        a, b = sc_a[name][1], sc32[name][1]
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), name
+    assert float((ret_a - ret32).abs().max()) <= 1e-4 * float(ret32.abs().max()) and bool(torch.isfinite(ret32).all())
+    # the dense map is non-zero only above columns (y, x) that hold a conv4 site one strided step further down
+    c4 = want["conv4"][0]
+    cols = torch.zeros(ret32.shape[2:], dtype=torch.bool)
+    cols[torch.from_numpy(c4[:, 2]).long(), torch.from_numpy(c4[:, 3]).long()] = True
+    assert not bool((ret32[0].abs().sum(0).cpu() > 0)[~cols].any())
+
+
+@pytest.mark.parametrize("kind,avg", [("Cylinder3DDynamicVoxelFeatureExtractor", False), ("PolarNetDynamicVoxelFeatureExtractor", True)])
+def test_dynamic_cylindrical_readers_full_size_properties(kind, avg):
+    """the dynamic readers of SURVEY 8f rank 4 on a BATCH OF TWO 120k-point sweeps (the module-level fixtures hold 4k points): size-independent properties
+    of the integer side against independent implementations - the cell of every point against a float64 restatement of cart2cylind + the cell
+    formula (voxel_encoder.py:319-345; points whose float64 cell coordinate lies within 1e-4 of a cell boundary may land on either side), the unique
+    rows / inverse / counts against torch.unique(dim=0) on the CPU for the SAME cells, the majority label of every cell against a numpy bincount,
+    counts sum to N; the voxel means against an ordered float64 mean (1e-5), the features finite"""
+    n, B, grid, rng_ = 120000, 2, [480, 360, 32], [0.0, -np.pi, -4.0, 50.0, np.pi, 2.0]
+    frames = [synth.lidar_frame(n, seed=30 + b, **synth.NUSC) for b in range(B)]
+    pts = np.concatenate([np.concatenate([np.full((n, 1), b, np.float32), f], 1) for b, f in enumerate(frames)])
+    lab = np.random.Generator(np.random.PCG64(9)).integers(0, 17, size=(B * n,)).astype(np.int64)
+    rd = L.build_from_cfg(dict(type=kind, grid_size=grid, point_cloud_range=rng_, average_points=avg, num_input_features=5, num_output_features=64,
+                               fea_compre=16, voxel_label_enc="major"), L.READERS).to(DEV).eval()
+    with torch.no_grad():
+        o = rd(dict(points=cu(pts), batch_size=B, point_sem_labels=cu(lab)))
+    pv = o["point_vcoors"].cpu().numpy()
+    assert pv.shape == (B * n, 4) and np.array_equal(pv[:, 0], pts[:, 0].astype(np.int64))
+    # float64 restatement: rho, phi, z -> clamp to the range -> floor((v - lo) / cell)
+    x, y, z = (pts[:, 1 + a].astype(np.float64) for a in range(3))
+    cyl = np.stack([np.sqrt(x * x + y * y), np.arctan2(y, x), z], 1)
+    lo, hi = np.asarray(rng_[:3], np.float64), np.asarray(rng_[3:], np.float64)
+    cell = (hi - lo) / np.asarray(grid, np.float64)
+    t = (np.clip(cyl, lo, hi) - lo) / cell
+    want = np.minimum(np.floor(t), np.asarray(grid) - 1).astype(np.int64)
+    got = pv[:, 1:]
+    cols = got if np.abs(got - want).sum() <= np.abs(got[:, ::-1] - want).sum() else got[:, ::-1]  # (a reader may store the columns reversed)
+    near = (np.abs(t - np.round(t)) < 1e-4).any(1)
+    bad = (cols != want).any(1) & ~near
+    assert not bad.any(), (int(bad.sum()), cols[bad][:3], want[bad][:3])
+    assert (np.abs(cols - want).max() <= 1) and (cols != want).any(1).mean() < 1e-3
+    # unique rows of the cells the DEVICE assigned, by torch on the CPU
+    vc, cnt = (o["voxel_coords"].cpu(), o["num_points_in_voxel"].cpu()) if kind.startswith("Cyl") else (None, None)
+    pvt = torch.from_numpy(pv)
+    uniq = [torch.unique(q, return_inverse=True, return_counts=True, dim=0) for q in (pvt, pvt[:, [0, 3, 2, 1]])]  # rows as stored | (b, z, y, x)
+    if kind.startswith("Cyl"):
+        hit = [k for k, (uq, _, c2) in enumerate(uniq) if uq.shape == vc.shape and torch.equal(vc, uq) and torch.equal(cnt.long(), c2)]
+        assert hit, "voxel_coords / num_points_in_voxel are not torch.unique's rows / counts of the points' cells"
+        assert int(cnt.sum()) == B * n
+        # majority label per cell: the most frequent label, ties to the smaller one, in the unique order of the rows voxelize_labels was given
+        vl = o["voxel_sem_labels"].cpu().numpy().reshape(-1)
+        ok = False
+        for uq, inv, _ in uniq:
+            tab = np.zeros((uq.shape[0], 17), np.int64)
+            np.add.at(tab, (inv.numpy(), lab), 1)
+            ok = ok or (vl.shape[0] == uq.shape[0] and np.array_equal(vl, tab.argmax(1)))
+        assert ok, "majority labels"
+    f = o["voxel_features"]
+    assert bool(torch.isfinite(f).all()) and float(f.abs().max()) > 0
+
+
 @pytest.mark.parametrize("kind", ["sdseg3d", "mseg3d"])
 def test_bucketed_frame_graph_keeps_a_varying_sweep_stream_on_the_graph_path(kind):
     """graph.BucketedFrameGraph over a stream of 8 different sweeps whose point count changes from frame to frame (66k +- 10 %: two buckets; tools/dist_test.py:189-230
