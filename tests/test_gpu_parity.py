@@ -2166,6 +2166,45 @@ def test_other_backbones_and_dynamic_readers_as_registered_modules_gpu(case):
         print("f4 modules[%s]: %s" % (case, {k: "%.2g" % v for k, v in f4_module_cases.MEASURED.items()}))
 
 
+def test_cylinder3d_reader_into_backbone_full_size():
+    """Cylinder3DDynamicVoxelFeatureExtractor -> Cylinder3D_Asymm_3d_spconv_v2p as the reference's config chains them, on a 120k-point sweep
+    (the module fixtures: 4k points / 3k voxels): the backbone's output sites are the reader's unique rows (SubM trunk + matching down / up samplings),
+    conv_point_coords are the cells' centres mapped back to Cartesian (float64 restatement), the f32-grade plane arithmetic against the exact-f32
+    mode through reader + 37 convolutions (per row: median <= 1e-4, 99 % of the rows <= 1e-3), two runs are bit-identical"""
+    n, grid, rng_ = 120000, [480, 360, 32], [0.0, -np.pi, -4.0, 50.0, np.pi, 2.0]
+    f = synth.lidar_frame(n, seed=52, **synth.NUSC)
+    pts = cu(np.concatenate([np.zeros((n, 1), np.float32), f], 1))
+    rd = L.build_from_cfg(dict(type="Cylinder3DDynamicVoxelFeatureExtractor", grid_size=grid, point_cloud_range=rng_, average_points=False, num_input_features=5,
+                               num_output_features=64, fea_compre=16), L.READERS)
+    bb = L.build_from_cfg(dict(type="Cylinder3D_Asymm_3d_spconv_v2p", num_input_features=16, grid_size=grid, point_cloud_range=rng_, model_cfg=dict(init_size=16)),
+                          L.BACKBONES)
+    for m, seed in ((rd, 3), (bb, 4)):
+        m.load_state_dict({k: torch.from_numpy(a) for k, a in synth.random_state_dict({k: tuple(t.shape) for k, t in m.state_dict().items()}, seed).items()})
+        m.to(DEV).eval()
+    res = []
+    try:
+        for prec in ("f32", "bf16x6", "bf16x6"):
+            ops.set_precision(prec)
+            with torch.no_grad():
+                o = bb(rd(dict(points=pts, batch_size=1)))
+            res.append((o["conv_point_features"].clone(), o["conv_point_coords"].clone(), o["voxel_coords"].clone()))
+    finally:
+        ops.set_precision("f32")
+    (f32, c32, vc), (fa, ca, _), (fb, cb, _) = res
+    assert torch.equal(fa, fb) and torch.equal(ca, cb), "two runs of the same sweep differ"
+    assert f32.shape[0] == vc.shape[0] and bool(torch.isfinite(f32).all()) and float(f32.abs().max()) > 0
+    # (a random-init network of this depth with sigmoid gates and LeakyReLUs is ill-conditioned in a few rows - its output scale is 3e9, the 8-product and the
+    # 6-product arithmetic differ from each other by 4e-4 of it, both from exact f32 by 1.8e-3, tools/scratch/cyl_modes.py - so the bar is per row)
+    rel = (fa - f32).abs().max(1)[0] / f32.abs().max(1)[0].clamp_min(1e-30)
+    assert float(rel.median()) <= 1e-4 and float(rel.quantile(0.99)) <= 1e-3 and float((fa - f32).abs().max()) <= 1e-2 * float(f32.abs().max())
+    # centres: (b, rho cos phi, rho sin phi, z) of the cell centres, voxel_coords = (b, z, y = phi, x = rho)
+    v = vc.cpu().numpy().astype(np.float64)
+    cell = (np.asarray(rng_[3:]) - np.asarray(rng_[:3])) / np.asarray(grid, np.float64)
+    rho, phi, zz = ((v[:, 3 - a] + 0.5) * cell[a] + rng_[a] for a in range(3))
+    want = np.stack([v[:, 0], rho * np.cos(phi), rho * np.sin(phi), zz], 1)
+    np.testing.assert_allclose(c32.cpu().numpy(), want, rtol=0, atol=2e-5 * 50)
+
+
 def test_spmiddleresnetfhd_full_size_sites_vs_oracle_and_arithmetic_modes():
     """SpMiddleResNetFHD (scn.py:84-176) on the voxels of a 120k-point sweep at the nuScenes grid (its fixture holds 3k voxels): the output sites of
     conv1 .. conv4 bit-exact against the oracle's strided rulebook chain (oracle.ref.conv_rulebook: spconv's output order), the dense map's
