@@ -108,7 +108,7 @@ class FrameGraph(object):
 
     def __del__(self):
         g = self.__dict__.get("graph")
-        if g is not None:
+        if g is not None and _RETIRED is not None:  # (None: the interpreter is shutting down and has cleared the module's globals)
             _RETIRED.append(g)
 
     def matches(self, example):
